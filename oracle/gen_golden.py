@@ -1,0 +1,272 @@
+"""Generate tests/golden/*.npz from the REFERENCE itself (run in the build container only).
+
+* The Python reference (/root/reference) is imported with an in-memory stub of the un-installed
+  external `bitorch` package (names only; no behaviour) -- SURVEY.md section 8c.
+* The reference's binary CPU extensions are the ones compiled by oracle/Makefile into oracle/_ref/.
+
+The fixtures are DATA: seeded inputs + the reference's outputs.  No reference source is copied.
+Run:  python oracle/gen_golden.py      (needs /root/reference; never runs on the GPU box)
+"""
+import importlib.util
+import json
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+OUT = os.path.join(ROOT, "tests", "golden")
+REF = os.environ.get("BIE_REFERENCE", "/root/reference")
+
+
+def _stub_bitorch():
+    """Names the reference imports from the external `bitorch` package (not installed here)."""
+    def mod(name):
+        m = types.ModuleType(name)
+        sys.modules[name] = m
+        return m
+
+    b = mod("bitorch")
+    layers = mod("bitorch.layers")
+    ext = mod("bitorch.layers.extensions")
+    ql = mod("bitorch.layers.qlinear")
+    reg = mod("bitorch.layers.register")
+    quant = mod("bitorch.quantizations")
+    cfg = mod("bitorch.layers.config")
+    mod("bitorch.layers.qconv")
+
+    class RuntimeMode:
+        INFERENCE_AUTO = 1
+        CPU = 2
+        GPU = 4
+        DEFAULT = 8
+
+    class _Base(torch.nn.Module):
+        pass
+
+    class CustomImplementationMixin:
+        pass
+
+    class LayerRecipe:
+        pass
+
+    def deco(*a, **k):
+        def wrap(cls):
+            return cls
+        return wrap
+
+    b.RuntimeMode = RuntimeMode
+    b.layers = layers
+    layers.extensions = ext
+    ext.LayerRecipe = LayerRecipe
+    ext.CustomImplementationMixin = CustomImplementationMixin
+    layers.qlinear = ql
+    ql.QLinearBase = _Base
+    ql.QLinearImplementation = deco
+    layers.register = reg
+    reg.QLinearImplementation = deco
+    reg.QConv2dImplementation = deco
+    layers.QLinearBase = _Base
+    layers.CustomImplementationMixin = CustomImplementationMixin
+    layers.QConv2dBase = _Base
+    layers.QEmbedding = _Base
+    layers.QEmbeddingBag = _Base
+    layers.config = cfg
+    cfg.Config = object
+    b.quantizations = quant
+    quant.Sign = _Base
+    quant.SwishSign = _Base
+    quant.Quantization = _Base
+
+
+def u16(t):
+    return t.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+def tonp(t):
+    if t is None:
+        return None
+    if t.dtype in (torch.float16, torch.bfloat16):
+        return u16(t)
+    return t.detach().cpu().contiguous().numpy()
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    _stub_bitorch()
+    sys.path.insert(0, REF)
+    import warnings
+    warnings.filterwarnings("ignore")
+    from bitorch_engine.layers.qlinear.nbit import MPQWeightParameter
+    from bitorch_engine.layers.qlinear.nbit.cuda.utils import unpack_qweight, pack_fp_weight, make_group_map
+    from bitorch_engine.layers.qlinear.nbit.cuda import MPQLinearCuda, MBWQLinearCuda
+    from bitorch_engine.utils.quant_operators import gptq_style_zeros_packing
+
+    g = torch.Generator().manual_seed(1234)
+    manifest = {}
+
+    # ------------------------------------------------------------------ 1. unpack_qweight / pack_fp_weight
+    cases = []
+    for dt_name, dt in (("f16", torch.float16), ("bf16", torch.bfloat16)):
+        for w_bit in (1, 2, 4, 8):
+            for mode in ("sym_gidx", "sym_nogidx", "sym_actorder", "asym"):
+                if mode == "sym_nogidx" and w_bit != 4:
+                    continue
+                if mode == "sym_actorder" and w_bit not in (2, 4):
+                    continue
+                for (K, N, gs) in ((128, 32, 64), (64, 64, 32)):
+                    G = K // gs
+                    qweight = torch.randint(-2 ** 31, 2 ** 31 - 1, (K * w_bit // 32, N), generator=g, dtype=torch.int64).to(torch.int32)
+                    scales = (torch.rand((G, N), generator=g) * 0.01 + 0.005).to(dt)
+                    maxq = 2 ** w_bit - 1
+                    g_idx = torch.tensor([i // gs for i in range(K)], dtype=torch.int32)
+                    if mode == "sym_actorder":
+                        g_idx = g_idx[torch.randperm(K, generator=g)]
+                    p = MPQWeightParameter(qweight.clone(), requires_grad=False, w_bit=w_bit, asym=(mode == "asym"),
+                                           group_size=gs, layer_type=1)
+                    p.scales = scales
+                    p.g_idx = None if mode == "sym_nogidx" else g_idx
+                    if mode == "asym":
+                        if (N * w_bit) % 32:
+                            continue
+                        p.zeros = torch.randint(-2 ** 31, 2 ** 31 - 1, (G, N * w_bit // 32), generator=g, dtype=torch.int64).to(torch.int32)
+                    else:
+                        p.zeros = (scales.float() * torch.rand((G, N), generator=g) * maxq).to(dt)
+                    W = unpack_qweight(p)
+                    assert W.dtype == dt, (W.dtype, dt)
+                    # pack_fp_weight of a *perturbed* dense weight (exercises rounding + clamping)
+                    Wp = (W.float() + (torch.rand(W.shape, generator=g) - 0.5) * 0.004).to(dt)
+                    packed = pack_fp_weight(Wp, p)
+                    name = f"mpq_{dt_name}_w{w_bit}_{mode}_K{K}N{N}g{gs}"
+                    cases.append(name)
+                    np.savez_compressed(os.path.join(OUT, name + ".npz"), qweight=tonp(qweight), scales=tonp(scales),
+                                        zeros=tonp(p.zeros), g_idx=(np.zeros(0, np.int32) if p.g_idx is None else tonp(p.g_idx)),
+                                        W=tonp(W), Wp=tonp(Wp), packed=tonp(packed),
+                                        meta=np.array([K, N, gs, w_bit, int(mode == "asym"), int(p.g_idx is not None)], np.int64))
+    manifest["mpq_dequant_pack"] = cases
+
+    # gptq_style_zeros_packing
+    zq = torch.randint(0, 16, (4, 64), generator=g)
+    zp = gptq_style_zeros_packing(zq.clone(), 4, 64, 64)
+    np.savez_compressed(os.path.join(OUT, "gptq_zeros_packing.npz"), zq=tonp(zq), packed=tonp(zp))
+
+    # ------------------------------------------------------------------ 2. full MPQLinearCuda layers (CPU path, M > 32)
+    layer_cases = []
+    sd_tables = {}
+    for name, kw in (
+        ("gba_sym_w4_g128_dq2", dict(w_bit=4, dtype=torch.half, group_size=128, dq_group_size=32, dq_mode=2, use_gba_quant=True, asym=False)),
+        ("gba_sym_w2_g32_dq1", dict(w_bit=2, dtype=torch.half, group_size=32, dq_group_size=1, dq_mode=1, use_gba_quant=True, asym=False)),
+        ("gba_sym_w4_g128_bf16", dict(w_bit=4, dtype=torch.bfloat16, group_size=128, dq_group_size=32, dq_mode=2, use_gba_quant=True, asym=False)),
+        ("gba_asym_w4_g64", dict(w_bit=4, dtype=torch.half, group_size=64, dq_group_size=32, dq_mode=2, use_gba_quant=True, asym=True)),
+        ("gptq_w4_g64", dict(w_bit=4, dtype=torch.half, group_size=64, use_gba_quant=False, asym=True)),
+        ("gptq_w8_g128", dict(w_bit=8, dtype=torch.half, group_size=128, use_gba_quant=False, asym=True)),
+        ("gba_sym_w4_g256_nodq", dict(w_bit=4, dtype=torch.half, group_size=256, dq_group_size=32, dq_mode=2, use_gba_quant=True, asym=False)),
+    ):
+        K, N = 256, 128
+        layer = MPQLinearCuda(in_channels=K, out_channels=N, requires_grad=False, **kw)
+        sd_tables["MPQLinearCuda/" + name] = {k: [list(v.shape), str(v.dtype)] for k, v in layer.state_dict().items()}
+        sd = {}
+        for k, v in layer.state_dict().items():
+            if k == "qweight" or (k == "qzeros" and v.dtype == torch.int32):
+                nv = torch.randint(-2 ** 31, 2 ** 31 - 1, v.shape, generator=g, dtype=torch.int64).to(torch.int32)
+            elif v.dtype == torch.uint8:
+                nv = torch.randint(0, 256, v.shape, generator=g, dtype=torch.int64).to(torch.uint8)
+            elif k in ("g_idx", "wf"):
+                nv = v.clone()
+            elif k == "bias":
+                nv = torch.zeros_like(v)
+            elif "scales" in k:
+                nv = (torch.rand(v.shape, generator=g) * 0.01 + 0.002).to(v.dtype)
+            else:  # *_zeros, zeros
+                nv = (torch.rand(v.shape, generator=g) * 4).to(v.dtype)
+            sd[k] = nv
+        layer.load_state_dict(sd)
+        layer.qweight.data = sd["qweight"]
+        layer.prepare_params()
+        outs = {}
+        for M in (33, 64):
+            x = torch.randn((M, K), generator=g).to(kw["dtype"])
+            y = layer(x)
+            outs[f"x{M}"] = tonp(x)
+            outs[f"y{M}"] = tonp(y)
+        np.savez_compressed(os.path.join(OUT, f"layer_{name}.npz"),
+                            **{"sd_" + k: tonp(v) for k, v in sd.items()},
+                            prep_scales=tonp(layer.scales), prep_zeros=tonp(layer.zeros), **outs)
+        layer_cases.append(name)
+    manifest["mpq_layers"] = layer_cases
+
+    # MBWQ constructor state_dict tables + make_group_map
+    for name, kw in (
+        ("q4", dict(w_bit=4, dtype=torch.half, group_size=32, dq_group_size=1, use_gba_quant=True, asym=False, dq_mode=2, use_mbw=False)),
+        ("exl2", dict(w_bit=4, dtype=torch.half, group_size=32, dq_group_size=1, use_gba_quant=True, asym=False, dq_mode=2, use_mbw=True, groups=8, rows_packed=24)),
+    ):
+        layer = MBWQLinearCuda(in_channels=256, out_channels=128, requires_grad=False, **kw)
+        sd_tables["MBWQLinearCuda/" + name] = {k: [list(v.shape), str(v.dtype)] for k, v in layer.state_dict().items()}
+
+    spec = importlib.util.spec_from_file_location("ref_test_util", os.path.join(REF, "tests", "layers", "util.py"))
+    ref_util = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_util)
+    gm = {}
+    for cname, K, bits, prop, gsz in (
+        ("q_proj", 256, [4, 2], [0.75, 0.25], {"4": 32, "2": 32}),
+        ("k_proj", 256, [4, 2], [0.25, 0.75], {"4": 32, "2": 32}),
+        ("w3w2", 512, [3, 2], [0.5, 0.5], {"3": 32, "2": 32}),
+        ("all6", 1024, [8, 6, 5, 4, 3, 2], [0.125, 0.125, 0.125, 0.25, 0.125, 0.25], {"8": 32, "6": 32, "5": 32, "4": 32, "3": 32, "2": 32}),
+    ):
+        groups, rows = ref_util.get_packed_info(K, bits, prop, gsz)
+        qg = ref_util.get_q_groups(groups, bits, gsz, K, prop)
+        gmap = make_group_map(torch.tensor(qg, dtype=torch.short), rows)
+        gm[cname + "_meta"] = np.array([K, groups, rows], np.int64)
+        gm[cname + "_q_groups"] = np.array(qg, np.int16)
+        gm[cname + "_group_map"] = tonp(gmap)
+    np.savez_compressed(os.path.join(OUT, "exl2_group_maps.npz"), **gm)
+
+    with open(os.path.join(OUT, "state_dict_tables.json"), "w") as f:
+        json.dump(sd_tables, f, indent=1, sort_keys=True)
+
+    # ------------------------------------------------------------------ 3. binary CPU extensions (compiled reference)
+    sys.path.insert(0, os.path.join(HERE, "_ref"))
+    import binary_linear_cpp
+    import binary_conv_cpp
+    bl = {}
+    for (M, N, K) in ((1, 64, 128), (4, 96, 256), (33, 40, 64)):
+        x = torch.randn((M, K), generator=g)
+        x[0, :4] = 0.0  # sign(0) must count as +1
+        w = torch.randn((N, K), generator=g)
+        y = binary_linear_cpp.forward(x, w, M, N, K)
+        wp = binary_linear_cpp.w_pack(w, N, K)
+        y2 = binary_linear_cpp.forward(x, wp, M, N, K)
+        assert torch.equal(y, y2)
+        tag = f"M{M}N{N}K{K}"
+        bl[tag + "_x"], bl[tag + "_w"], bl[tag + "_y"], bl[tag + "_wpacked"] = tonp(x), tonp(w), tonp(y), tonp(wp)
+    np.savez_compressed(os.path.join(OUT, "binary_linear_cpp.npz"), **bl)
+
+    bc = {}
+    for (B, C, H, OC, ks, st, pad, dil) in ((2, 16, 7, 8, 3, 1, 1, 1), (1, 8, 9, 16, 3, 2, 1, 1), (2, 8, 8, 8, 1, 1, 0, 1), (1, 8, 10, 8, 3, 1, 2, 2)):
+        x = torch.randn((B, C, H, H), generator=g)
+        w = torch.randn((OC, C, ks, ks), generator=g)
+        oe = (H + 2 * pad - dil * (ks - 1) - 1) // st + 1
+        k_ = C * ks * ks
+        y = binary_conv_cpp.forward(x, w.view(OC, -1).contiguous(), OC, oe * oe, k_, ks, st, pad, dil, oe)
+        tag = f"B{B}C{C}H{H}OC{OC}k{ks}s{st}p{pad}d{dil}"
+        bc[tag + "_x"], bc[tag + "_w"], bc[tag + "_y"] = tonp(x), tonp(w), tonp(y)
+    np.savez_compressed(os.path.join(OUT, "binary_conv_cpp.npz"), **bc)
+
+    # ------------------------------------------------------------------ 4. known-answer vector held by the reference's tests
+    # tests/functions/test_quant_ops.py:110-157 : bytes [0,16,35,255] -> +-1, LSB first
+    kat_bytes = np.array([0, 16, 35, 255], np.uint8)
+    kat_expected = np.array([-1] * 8 + [-1, -1, -1, +1, -1, -1, -1, -1][::-1] + [-1, -1, +1, -1, -1, -1, +1, +1][::-1] + [1] * 8, np.float32)
+    np.savez_compressed(os.path.join(OUT, "kat_unpack_uint8.npz"), bytes=kat_bytes, expected=kat_expected)
+
+    with open(os.path.join(OUT, "MANIFEST.json"), "w") as f:
+        json.dump(manifest, f, indent=1)
+    tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
+    print("golden fixtures written to", OUT, "total bytes:", tot)
+
+
+if __name__ == "__main__":
+    main()

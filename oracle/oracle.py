@@ -1,0 +1,237 @@
+"""ctypes front-end of the CPU oracle (oracle/bie_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg.  The product package (bitorch-engine_amd/) never imports this module.
+
+All functions take / return numpy arrays.  16-bit float tensors travel as uint16 bit patterns
+(`torch_to_np` / `np_to_torch` convert to and from torch tensors).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libbie_oracle.so")
+F16, BF16, F32 = 0, 1, 2
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the C restatement (and oracle/_ref when /root/reference is present)."""
+    src = os.path.join(_HERE, "bie_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, _LIB_PATH])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _c(a, dtype=None):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a)
+    if dtype is not None and a.dtype != dtype:
+        a = a.astype(dtype)
+    return a
+
+
+def dt_code(torch_dtype) -> int:
+    import torch
+    return {torch.float16: F16, torch.bfloat16: BF16, torch.float32: F32}[torch_dtype]
+
+
+def torch_to_np(t):
+    """torch tensor -> numpy (fp16/bf16 as uint16 bit patterns)."""
+    import torch
+    if t is None:
+        return None
+    t = t.detach().cpu().contiguous()
+    if t.dtype in (torch.float16, torch.bfloat16):
+        return t.view(torch.int16).numpy().view(np.uint16)
+    return t.numpy()
+
+
+def np_to_torch(a, torch_dtype):
+    import torch
+    if torch_dtype in (torch.float16, torch.bfloat16):
+        return torch.from_numpy(a.view(np.int16).copy()).view(torch_dtype)
+    return torch.from_numpy(a.copy())
+
+
+def _out(shape, dt):
+    return np.empty(shape, dtype=np.float32 if dt == F32 else np.uint16)
+
+
+def mpq_dequant(qweight, scales, zeros, g_idx, w_bit, group_size, asym, dt):
+    qweight = _c(qweight, np.int32)
+    K = qweight.shape[0] * 32 // w_bit
+    N = qweight.shape[1]
+    scales, zeros, g_idx = _c(scales), _c(zeros), _c(g_idx, np.int32)
+    out = _out((K, N), dt)
+    lib().orc_mpq_dequant(_p(qweight), _p(scales), _p(zeros), _p(g_idx), _p(out), K, N, w_bit,
+                          group_size, int(asym), dt)
+    return out
+
+
+def mpq_pack(weight, scales, zeros, g_idx, w_bit, group_size, asym, dt):
+    weight = _c(weight)
+    K, N = weight.shape
+    scales, zeros, g_idx = _c(scales), _c(zeros), _c(g_idx, np.int32)
+    out = np.empty((K * w_bit // 32, N), dtype=np.int32)
+    lib().orc_mpq_pack(_p(weight), _p(scales), _p(zeros), _p(g_idx), _p(out), K, N, w_bit,
+                       group_size, int(asym), dt)
+    return out
+
+
+def pack_qzeros(zq, w_bit):
+    zq = _c(zq, np.int32)
+    G, N = zq.shape
+    out = np.empty((G, N * w_bit // 32), dtype=np.int32)
+    lib().orc_pack_qzeros(_p(zq), _p(out), G, N, w_bit)
+    return out
+
+
+def gemm(x, W, dt, bias=None):
+    x, W, bias = _c(x), _c(W), _c(bias)
+    M, K = x.shape
+    N = W.shape[1]
+    y = _out((M, N), dt)
+    lib().orc_gemm(_p(x), _p(W), _p(bias), _p(y), M, K, N, dt)
+    return y
+
+
+def mpq_forward(x, qweight, scales, zeros, g_idx, w_bit, group_size, asym, dt):
+    """Fused dequant+GEMM with float accumulation (the timed CPU baseline)."""
+    x, qweight = _c(x), _c(qweight, np.int32)
+    M, K = x.shape
+    N = qweight.shape[1]
+    scales, zeros, g_idx = _c(scales), _c(zeros), _c(g_idx, np.int32)
+    y = _out((M, N), dt)
+    lib().orc_mpq_forward_f32acc(_p(x), _p(qweight), _p(scales), _p(zeros), _p(g_idx), _p(y), M, K, N,
+                                 w_bit, group_size, int(asym), dt)
+    return y
+
+
+def mbwq_q4_dequant(qweight, scales, zeros, q_perm, bits, group_size):
+    qweight = _c(qweight, np.int32)
+    K = qweight.shape[0] * 32 // bits
+    N = qweight.shape[1]
+    scales, zeros = _c(scales, np.uint16), _c(zeros, np.uint16)
+    q_perm = None if q_perm is None else _c(q_perm).view(np.uint16)
+    out = np.zeros((K, N), dtype=np.uint16)
+    lib().orc_mbwq_q4_dequant(_p(qweight), _p(scales), _p(zeros), _p(q_perm), _p(out), K, N, bits, group_size)
+    return out
+
+
+def exl2_rows(q_groups, K):
+    q_groups = _c(q_groups, np.int16)
+    rows = (ctypes.c_int * 7)()
+    lib().orc_exl2_rows(_p(q_groups), q_groups.size // 2, K, rows)
+    return list(rows)
+
+
+def exl2_dequant(qweight, scales, zeros, q_perm, q_groups, K):
+    qweight = _c(qweight, np.int32)
+    N = qweight.shape[1]
+    scales, zeros = _c(scales, np.uint16), _c(zeros, np.uint16)
+    q_groups = _c(q_groups, np.int16)
+    q_perm = None if q_perm is None else _c(q_perm).view(np.uint16)
+    out = np.zeros((K, N), dtype=np.uint16)
+    lib().orc_exl2_dequant(_p(qweight), _p(scales), _p(zeros), _p(q_perm), _p(q_groups), _p(out), K, N,
+                           q_groups.size // 2, qweight.shape[0])
+    return out
+
+
+def binary_pack_rows(a):
+    a = _c(a, np.float32)
+    rows, K = a.shape
+    out = np.empty((rows, K // 8), dtype=np.uint8)
+    lib().orc_binary_pack_rows(_p(a), _p(out), ctypes.c_long(rows), ctypes.c_long(K))
+    return out
+
+
+def binary_pack_cols(w):
+    w = _c(w, np.float32)
+    N, K = w.shape
+    out = np.empty((K // 8) * N, dtype=np.uint8)
+    lib().orc_binary_pack_cols(_p(w), _p(out), ctypes.c_long(N), ctypes.c_long(K))
+    return out
+
+
+def binary_linear(x, wpacked, N):
+    x = _c(x, np.float32)
+    M, K = x.shape
+    wpacked = _c(wpacked, np.uint8)
+    y = np.empty((M, N), dtype=np.float32)
+    lib().orc_binary_linear(_p(x), _p(wpacked), _p(y), ctypes.c_long(M), ctypes.c_long(N), ctypes.c_long(K))
+    return y
+
+
+def binary_linear_rowpacked(xb, wb, K, scale=1.0):
+    xb, wb = _c(xb, np.uint8), _c(wb, np.uint8)
+    M, N = xb.shape[0], wb.shape[0]
+    y = np.empty((M, N), dtype=np.float32)
+    lib().orc_binary_linear_rowpacked(_p(xb), _p(wb), _p(y), ctypes.c_long(M), ctypes.c_long(N),
+                                      ctypes.c_long(K), ctypes.c_float(scale))
+    return y
+
+
+def binary_conv2d(x, w, stride, pad, dil):
+    x, w = _c(x, np.float32), _c(w, np.float32)
+    B, C, H, W = x.shape
+    OC, _, ksz, _ = w.shape
+    OH = (H + 2 * pad - dil * (ksz - 1) - 1) // stride + 1
+    OW = (W + 2 * pad - dil * (ksz - 1) - 1) // stride + 1
+    y = np.empty((B, OC, OH, OW), dtype=np.float32)
+    lib().orc_binary_conv2d(_p(x), _p(w), _p(y), B, C, H, W, OC, ksz, stride, pad, dil)
+    return y
+
+
+def pack_sign_u8(a):
+    a = _c(a, np.float32)
+    out = np.empty(a.size // 8, dtype=np.uint8)
+    lib().orc_pack_sign_u8(_p(a), _p(out), ctypes.c_long(out.size))
+    return out.reshape(a.shape[:-1] + (a.shape[-1] // 8,))
+
+
+def unpack_u8_scaled(packed, scale):
+    packed = _c(packed, np.uint8)
+    rows = int(np.prod(packed.shape[:-1]))
+    pd = packed.shape[-1]
+    scale = _c(np.broadcast_to(np.asarray(scale, dtype=np.float32).reshape(-1), (rows,)), np.float32)
+    out = np.empty((rows, pd * 8), dtype=np.float32)
+    lib().orc_unpack_u8_scaled(_p(packed), _p(scale), _p(out), ctypes.c_long(rows), ctypes.c_long(pd))
+    return out.reshape(packed.shape[:-1] + (pd * 8,))
+
+
+def q4_pack(a):
+    a = _c(a, np.int32)
+    out = np.empty(a.size // 2, dtype=np.int8)
+    lib().orc_q4_pack(_p(a), _p(out), ctypes.c_long(out.size))
+    return out.reshape(a.shape[:-1] + (a.shape[-1] // 2,))
+
+
+def q4_unpack(p):
+    p = _c(p, np.int8)
+    out = np.empty(p.size * 2, dtype=np.int32)
+    lib().orc_q4_unpack(_p(p), _p(out), ctypes.c_long(p.size))
+    return out.reshape(p.shape[:-1] + (p.shape[-1] * 2,))
+
+
+def q4_unpack_scale(p, scale):
+    p = _c(p, np.int8)
+    out = np.empty(p.size * 2, dtype=np.float32)
+    lib().orc_q4_unpack_scale(_p(p), _p(out), ctypes.c_long(p.size), ctypes.c_float(scale))
+    return out.reshape(p.shape[:-1] + (p.shape[-1] * 2,))

@@ -1,0 +1,160 @@
+"""Pins the CPU oracle (oracle/bie_oracle.c) against outputs of the reference itself.
+
+The fixtures under tests/golden/ were produced by oracle/gen_golden.py, which imports the Python
+reference (unpack_qweight / pack_fp_weight / MPQLinearCuda CPU branch, cuda/utils.py, mpq_layer.py)
+and the reference's compiled binary CPU extensions (binary_linear.cpp / binary_conv.cpp).
+Bar: bit-exact for dequant / pack / binary; 1e-3 (norm-wise) for the fp16/bf16 matmul.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+MANIFEST = json.load(open(os.path.join(GOLDEN, "MANIFEST.json")))
+
+
+def _dt(name):
+    return orc.BF16 if "_bf16" in name else orc.F16
+
+
+def _to_f32(a, dt):
+    out = np.empty(a.shape, np.float32)
+    fn = orc.lib().orc_bf16_to_f32 if dt == orc.BF16 else orc.lib().orc_f16_to_f32
+    a = np.ascontiguousarray(a)
+    import ctypes
+    fn(a.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), ctypes.c_long(a.size))
+    return out
+
+
+@pytest.mark.parametrize("name", MANIFEST["mpq_dequant_pack"])
+def test_mpq_dequant_and_pack_bit_exact(name):
+    d = np.load(os.path.join(GOLDEN, name + ".npz"))
+    K, N, gs, w_bit, asym, has_gidx = [int(v) for v in d["meta"]]
+    dt = _dt(name)
+    g_idx = d["g_idx"] if has_gidx else None
+    W = orc.mpq_dequant(d["qweight"], d["scales"], d["zeros"], g_idx, w_bit, gs, asym, dt)
+    assert np.array_equal(W, d["W"]), f"dequant mismatch: {(W != d['W']).sum()} of {W.size}"
+    packed = orc.mpq_pack(d["Wp"], d["scales"], d["zeros"], g_idx, w_bit, gs, asym, dt)
+    assert np.array_equal(packed, d["packed"]), f"pack mismatch: {(packed != d['packed']).sum()} words"
+    # round trip property: pack(unpack(p)) == p  
+    again = orc.mpq_pack(W, d["scales"], d["zeros"], g_idx, w_bit, gs, asym, dt)
+    if dt == orc.F16:  # bf16 cannot hold 8 significant bits of q*s, so only fp16 round-trips
+        assert np.array_equal(again, d["qweight"])
+
+
+def test_gptq_zeros_packing():
+    d = np.load(os.path.join(GOLDEN, "gptq_zeros_packing.npz"))
+    assert np.array_equal(orc.pack_qzeros(d["zq"], 4), d["packed"])
+
+
+@pytest.mark.parametrize("name", MANIFEST["mpq_layers"])
+def test_mpq_layer_forward_vs_reference_cpu_path(name):
+    d = np.load(os.path.join(GOLDEN, f"layer_{name}.npz"))
+    dt = _dt(name)
+    w_bit = 8 if "_w8_" in name else (2 if "_w2_" in name else 4)
+    asym = int("asym" in name or "gptq" in name)
+    qweight = d["sd_qweight"]
+    K = qweight.shape[0] * 32 // w_bit
+    scales, zeros = d["prep_scales"], d["prep_zeros"]
+    gs = K // scales.shape[0]
+    W = orc.mpq_dequant(qweight, scales, zeros, d["sd_g_idx"], w_bit, gs, asym, dt)
+    for M in (33, 64):
+        y = _to_f32(orc.gemm(d[f"x{M}"], W, dt), dt)
+        yr = _to_f32(d[f"y{M}"], dt)
+        # torch CPU matmul accumulates in float in an unspecified order; one output ulp is
+        # 2^-11 (fp16) / 2^-8 (bf16) relative, so compare norm-wise at 1e-3 + 1 ulp of the type
+        ulp = 2.0 ** -8 if dt == orc.BF16 else 2.0 ** -11
+        tol = 1e-3 * np.abs(yr).max() + ulp * np.abs(yr)
+        assert np.all(np.abs(y - yr) <= tol), float(np.abs(y - yr).max())
+        y2 = _to_f32(orc.mpq_forward(d[f"x{M}"], qweight, scales, zeros, d["sd_g_idx"], w_bit, gs, asym, dt), dt)
+        assert np.all(np.abs(y2 - yr) <= tol)
+
+
+def test_exl2_rows_and_group_map_tables():
+    d = np.load(os.path.join(GOLDEN, "exl2_group_maps.npz"))
+    for c in ("q_proj", "k_proj", "w3w2", "all6"):
+        K, groups, rows = [int(v) for v in d[c + "_meta"]]
+        qg = d[c + "_q_groups"]
+        r7 = orc.exl2_rows(qg, K)
+        assert r7[5] == K, r7
+        # group map == (group index, rows left in group) per k : cuda/utils.py:150-187
+        gm = d[c + "_group_map"].reshape(-1, 2)
+        assert gm.shape[0] == K
+        k = 0
+        for i in range(groups):
+            bits = int(qg[2 * i])
+            nxt = int(qg[2 * i + 3]) if i < groups - 1 else rows
+            n = (nxt - int(qg[2 * i + 1])) * 32 // bits
+            assert np.all(gm[k:k + n, 0] == i)
+            assert np.array_equal(gm[k:k + n, 1], np.arange(n, 0, -1))
+            k += n
+
+
+def test_exl2_single_band_equals_mpq_layout():
+    """A single 4-bit (or 2-bit) band covering K is the GPTQ layout: cross-check of the bitstream
+    reader against the (reference-pinned) MPQ unpacker, modulo the fused rounding."""
+    rng = np.random.default_rng(0)
+    K, N, gs = 128, 32, 32
+    for bits in (2, 4, 8):
+        qw = rng.integers(-2 ** 31, 2 ** 31 - 1, (K * bits // 32, N), dtype=np.int64).astype(np.int32)
+        groups = K // gs
+        qg = np.zeros(2 * groups, np.int16)
+        for i in range(groups):
+            qg[2 * i], qg[2 * i + 1] = bits, i * gs * bits // 32
+        s = orc.np.float32(0.01) * np.ones((groups, N), np.float32)
+        import ctypes
+        s16 = np.empty(s.shape, np.uint16)
+        orc.lib().orc_f32_to_f16(s.ctypes.data_as(ctypes.c_void_p), s16.ctypes.data_as(ctypes.c_void_p), ctypes.c_long(s.size))
+        z16 = np.zeros_like(s16)
+        a = orc.exl2_dequant(qw, s16, z16, None, qg, K)
+        b = orc.mpq_dequant(qw, s16, z16, None, bits, gs, 0, orc.F16)  # z = 0 -> one rounding both ways
+        assert np.array_equal(a, b)
+        if bits in (2, 4):
+            c = orc.mbwq_q4_dequant(qw, s16, z16, None, bits, gs)
+            assert np.array_equal(a, c)
+
+
+def test_binary_linear_vs_reference_cpp():
+    d = np.load(os.path.join(GOLDEN, "binary_linear_cpp.npz"))
+    for tag in ("M1N64K128", "M4N96K256", "M33N40K64"):
+        x, w, y, wp = d[tag + "_x"], d[tag + "_w"], d[tag + "_y"], d[tag + "_wpacked"]
+        mine = orc.binary_pack_cols(w)
+        assert np.array_equal(mine, wp), "w_pack layout mismatch"
+        assert np.array_equal(orc.binary_linear(x, mine, w.shape[0]), y)
+        xb, wb = orc.binary_pack_rows(x), orc.binary_pack_rows(w)
+        assert np.array_equal(orc.binary_linear_rowpacked(xb, wb, x.shape[1]), y)
+
+
+def test_binary_conv_vs_reference_cpp():
+    d = np.load(os.path.join(GOLDEN, "binary_conv_cpp.npz"))
+    tags = sorted({k.rsplit("_", 1)[0] for k in d.files})
+    assert len(tags) == 4
+    for tag in tags:
+        st = int(tag.split("s")[1].split("p")[0])
+        pad = int(tag.split("p")[1].split("d")[0])
+        dil = int(tag.split("d")[1])
+        y = orc.binary_conv2d(d[tag + "_x"], d[tag + "_w"], st, pad, dil)
+        assert np.array_equal(y, d[tag + "_y"]), tag
+
+
+def test_unpack_uint8_known_answer():
+    d = np.load(os.path.join(GOLDEN, "kat_unpack_uint8.npz"))
+    out = orc.unpack_u8_scaled(d["bytes"].reshape(1, 4), np.array([1.0], np.float32))
+    assert np.array_equal(out.reshape(-1), d["expected"])
+    assert np.array_equal(orc.pack_sign_u8(d["expected"].reshape(1, 32)).reshape(-1), d["bytes"])
+
+
+def test_q4_pack_roundtrip_and_sign_extension():
+    rng = np.random.default_rng(1)
+    a = rng.integers(-8, 8, (10, 10)).astype(np.int32)
+    p = orc.q4_pack(a)
+    assert p.dtype == np.int8 and p.size * 2 == a.size
+    u = orc.q4_unpack(p)
+    assert np.array_equal(u & 0xF, a & 0xF)
+    assert np.array_equal(orc.q4_unpack_scale(p, 0.5), a.astype(np.float32) * 0.5)
+    # first element lands in the HIGH nibble (functions_cuda_kernel.cu:137-159)
+    assert orc.q4_pack(np.array([[1, 2]], np.int32)).view(np.uint8)[0, 0] == 0x12
