@@ -1,0 +1,64 @@
+"""Shared ctypes plumbing of the binary (XNOR-popcount) extension front-ends."""
+import torch
+
+from bitorch_engine import _hip
+
+_SIGN_DT = {torch.float16: _hip.F16, torch.bfloat16: _hip.BF16, torch.float32: _hip.F32, torch.int8: _hip.I8}
+
+
+def sign_dt(t):
+    try:
+        return _SIGN_DT[t.dtype]
+    except KeyError:
+        raise RuntimeError(f"tensor type not supported: {t.dtype}")
+
+
+def pack_rows(a: torch.Tensor) -> torch.Tensor:
+    """[..., K] values -> [..., K/8] uint8, bit j of byte b = (a[..., 8b+j] >= 0)."""
+    _hip.need_gpu(a)
+    a = a.contiguous()
+    K = a.shape[-1]
+    if K % 8:
+        raise RuntimeError(f"bit packing needs the last dimension ({K}) to be a multiple of 8")
+    rows = a.numel() // K
+    out = torch.empty(a.shape[:-1] + (K // 8,), dtype=torch.uint8, device=a.device)
+    if rows:
+        rc = _hip.lib().bie_binary_pack_rows_u8(_hip.ptr(a), _hip.ptr(out), rows, K, sign_dt(a), _hip.stream())
+        _hip.check(rc, "bie_binary_pack_rows_u8")
+    return out
+
+
+def pack_cols(w: torch.Tensor) -> torch.Tensor:
+    """w [N, K] -> flat uint8 [K/8 * N] column bit-planes (binary_linear_cpp.w_pack layout)."""
+    _hip.need_gpu(w)
+    w = w.contiguous()
+    N, K = w.shape
+    out = torch.empty((K // 8) * N, dtype=torch.uint8, device=w.device)
+    rc = _hip.lib().bie_binary_pack_cols_u8(_hip.ptr(w), _hip.ptr(out), N, K, sign_dt(w), _hip.stream())
+    _hip.check(rc, "bie_binary_pack_cols_u8")
+    return out
+
+
+def xnor_linear(xp: torch.Tensor, wp: torch.Tensor, M: int, N: int, K: int, w_layout: int, scale: float) -> torch.Tensor:
+    """y[M, N] fp32 = (K - 2*popc(x ^ w)) * scale from packed operands."""
+    y = torch.empty((M, N), dtype=torch.float32, device=xp.device)
+    if M and N:
+        rc = _hip.lib().bie_binary_linear_forward(_hip.ptr(xp), _hip.ptr(wp), _hip.ptr(y), M, N, K, w_layout, float(scale), _hip.stream())
+        _hip.check(rc, "bie_binary_linear_forward")
+    return y
+
+
+def conv2d(x, wpacked, OC, ksize, stride, pad, dil, scale):
+    _hip.need_gpu(x, wpacked)
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    OH = (H + 2 * pad - dil * (ksize - 1) - 1) // stride + 1
+    OW = (W + 2 * pad - dil * (ksize - 1) - 1) // stride + 1
+    y = torch.empty((B, OC, OH, OW), dtype=torch.float32, device=x.device)
+    L = _hip.lib()
+    need = L.bie_binary_conv2d_workspace_bytes(B, C, H, W, OC, ksize, stride, pad, dil)
+    ws = _hip.workspace(need, x.device)
+    rc = L.bie_binary_conv2d_forward(_hip.ptr(x), _hip.ptr(wpacked), _hip.ptr(y), _hip.ptr(ws), ws.numel(), B, C, H, W, OC,
+                                     ksize, stride, pad, dil, float(scale), _hip.dt(x), _hip.stream())
+    _hip.check(rc, "bie_binary_conv2d_forward")
+    return y

@@ -1,0 +1,205 @@
+"""Drop-in for the reference's `q_linear_cuda` pybind module
+(layers/qlinear/nbit/cuda/q_linear_cuda.cpp:357-369): same function names and argument order."""
+import torch
+
+from bitorch_engine import _hip
+
+_TRIVIAL_GIDX = {}
+_ZERO_PERM = {}
+
+
+def _group_size(K, scales):
+    G = scales.shape[0]
+    return (K + G - 1) // G
+
+
+def gidx_is_trivial(g_idx, group_size):
+    """True when g_idx[k] == k // group_size (what MPQLinearBase initialises, nbit/layer.py:385-386).
+    One device->host sync per distinct tensor version, then cached."""
+    if g_idx is None:
+        return True
+    key = (g_idx.data_ptr(), g_idx._version, g_idx.numel(), group_size)
+    hit = _TRIVIAL_GIDX.get(key)
+    if hit is None:
+        ref = torch.arange(g_idx.numel(), device=g_idx.device, dtype=torch.int32) // group_size
+        hit = bool(torch.equal(g_idx.to(torch.int32), ref))
+        if len(_TRIVIAL_GIDX) > 4096:
+            _TRIVIAL_GIDX.clear()
+        _TRIVIAL_GIDX[key] = hit
+    return hit
+
+
+def perm_or_none(q_perm):
+    """The reference treats an all-zero q_perm as 'no permutation' with a per-call .item() sync
+    (mbwq_linear_cuda_kernel.cu:671,777); here the answer is cached per tensor version."""
+    if q_perm is None:
+        return None
+    key = (q_perm.data_ptr(), q_perm._version, q_perm.numel())
+    hit = _ZERO_PERM.get(key)
+    if hit is None:
+        hit = bool(torch.all(q_perm == 0).item())
+        if len(_ZERO_PERM) > 4096:
+            _ZERO_PERM.clear()
+        _ZERO_PERM[key] = hit
+    return None if hit else q_perm
+
+
+def mpq_forward_impl(x, qweight, scales, zeros, g_idx, w_bit, asym, group_size, bias=None, trivial_gidx=None):
+    _hip.need_gpu(x, qweight, scales, zeros)
+    x = x.contiguous()
+    M, K = x.shape
+    N = qweight.shape[1]
+    if trivial_gidx is None:
+        trivial_gidx = gidx_is_trivial(g_idx, group_size)
+    gptr = None if trivial_gidx else g_idx.to(torch.int32).contiguous()
+    y = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    if M == 0:
+        return y
+    L = _hip.lib()
+    need = L.bie_mpq_workspace_bytes(M, K, N, w_bit)
+    ws = _hip.workspace(need, x.device)
+    rc = L.bie_mpq_forward(_hip.ptr(x), _hip.ptr(qweight), _hip.ptr(scales.contiguous()), _hip.ptr(zeros.contiguous()),
+                           _hip.ptr(gptr), _hip.ptr(bias), _hip.ptr(y), _hip.ptr(ws), 0 if ws is None else ws.numel(),
+                           M, K, N, w_bit, group_size, int(bool(asym)), _hip.dt(x), _hip.stream())
+    _hip.check(rc, "bie_mpq_forward")
+    return y
+
+
+def mpq_forward(x, qweight, scales, qzeros, g_idx, a_bit, w_bit, asym):
+    if a_bit != 16:
+        raise RuntimeError(f"a_bit:{a_bit} has not been supported yet!")
+    K = x.shape[1]
+    return mpq_forward_impl(x, qweight.data, scales, qzeros, g_idx, w_bit, asym, _group_size(K, scales))
+
+
+def mpq_dequant(qweight, scales, zeros, g_idx, w_bit, asym, group_size):
+    _hip.need_gpu(qweight, scales, zeros)
+    K = qweight.shape[0] * 32 // w_bit
+    N = qweight.shape[1]
+    out = torch.empty((K, N), dtype=scales.dtype, device=qweight.device)
+    gptr = None if g_idx is None else g_idx.to(torch.int32).contiguous()
+    rc = _hip.lib().bie_mpq_dequant(_hip.ptr(qweight), _hip.ptr(scales.contiguous()), _hip.ptr(zeros.contiguous()),
+                                    _hip.ptr(gptr), _hip.ptr(out), K, N, w_bit, group_size, int(bool(asym)),
+                                    _hip.dt(scales), _hip.stream())
+    _hip.check(rc, "bie_mpq_dequant")
+    return out
+
+
+def mpq_pack(weight, scales, zeros, g_idx, w_bit, asym, group_size):
+    _hip.need_gpu(weight, scales, zeros)
+    weight = weight.contiguous()
+    K, N = weight.shape
+    out = torch.empty((K * w_bit // 32, N), dtype=torch.int32, device=weight.device)
+    gptr = None if g_idx is None else g_idx.to(torch.int32).contiguous()
+    rc = _hip.lib().bie_mpq_pack(_hip.ptr(weight), _hip.ptr(scales.contiguous()), _hip.ptr(zeros.contiguous()),
+                                 _hip.ptr(gptr), _hip.ptr(out), K, N, w_bit, group_size, int(bool(asym)),
+                                 _hip.dt(weight), _hip.stream())
+    _hip.check(rc, "bie_mpq_pack")
+    return out
+
+
+def mpq_grad_input(qweight, scales, qzeros, g_idx, grad_out, a_bit, w_bit, asym):
+    _hip.need_gpu(qweight, scales, qzeros, grad_out)
+    grad_out = grad_out.contiguous()
+    M, N = grad_out.shape
+    K = qweight.shape[0] * 32 // w_bit
+    gs = _group_size(K, scales)
+    gptr = None if gidx_is_trivial(g_idx, gs) else g_idx.to(torch.int32).contiguous()
+    gx = torch.empty((M, K), dtype=grad_out.dtype, device=grad_out.device)
+    rc = _hip.lib().bie_mpq_grad_input(_hip.ptr(grad_out), _hip.ptr(qweight), _hip.ptr(scales.contiguous()),
+                                       _hip.ptr(qzeros.contiguous()), _hip.ptr(gptr), _hip.ptr(gx), M, K, N, w_bit, gs,
+                                       int(bool(asym)), _hip.dt(grad_out), _hip.stream())
+    _hip.check(rc, "bie_mpq_grad_input")
+    return gx
+
+
+# ---------------------------------------------------------------------------------------------- MBWQ
+def mbwq_trans_qweight(qweight, q_groups, use_mbw, height, groups, bits):
+    """Returns (qweight, rows[7]).  The reference's in-place shuffle is a no-op (exl2/config.h:16-21);
+    the band table needs q_groups on the host, like the reference's blocking cudaMemcpy (:562)."""
+    import ctypes
+    rows = (ctypes.c_int * 7)()
+    if use_mbw:
+        qg = q_groups.detach().to("cpu", torch.int16).contiguous()
+        rc = _hip.lib().bie_mbwq_rows(qg.data_ptr(), groups, height, ctypes.cast(rows, ctypes.c_void_p))
+        _hip.check(rc, "bie_mbwq_rows")
+        return qweight, list(rows)
+    if bits not in (2, 4):
+        raise RuntimeError(f"Error: weight bit width:{bits} has not been supported yet!")
+    return qweight, []
+
+
+def mbwq_q42fp_weight(qweight, scales, zeros, group_size, bits, q_perm):
+    _hip.need_gpu(qweight, scales, zeros)
+    if scales.dtype != torch.float16:
+        raise RuntimeError("mbwq_q42fp_weight: fp16 scales/zeros required")
+    K = qweight.shape[0] * 32 // bits
+    N = qweight.shape[1]
+    out = torch.empty((K, N), dtype=torch.float16, device=qweight.device)
+    perm = perm_or_none(q_perm)
+    rc = _hip.lib().bie_mbwq_q4_dequant(_hip.ptr(qweight), _hip.ptr(scales.contiguous()), _hip.ptr(zeros.contiguous()),
+                                        _hip.ptr(perm), _hip.ptr(out), K, N, bits, group_size, _hip.stream())
+    _hip.check(rc, "bie_mbwq_q4_dequant")
+    return out
+
+
+def _rows_arg(rows):
+    import ctypes
+    arr = (ctypes.c_int * 7)(*[int(r) for r in rows])
+    return arr, ctypes.cast(arr, ctypes.c_void_p)
+
+
+def mbwq_exl2fp_weight(qweight, scales, zeros, q_perm, q_group_map, rows):
+    _hip.need_gpu(qweight, scales, zeros, q_perm, q_group_map)
+    K = q_perm.shape[0]
+    N = qweight.shape[1]
+    out = torch.empty((K, N), dtype=torch.float16, device=qweight.device)
+    keep, rp = _rows_arg(rows)
+    rc = _hip.lib().bie_mbwq_exl2_dequant(_hip.ptr(qweight), _hip.ptr(scales.contiguous()), _hip.ptr(zeros.contiguous()),
+                                          _hip.ptr(q_perm), _hip.ptr(q_group_map), rp, _hip.ptr(out), K, N,
+                                          scales.shape[0], _hip.stream())
+    _hip.check(rc, "bie_mbwq_exl2_dequant")
+    return out
+
+
+def mbwq_q4_forward(x, qweight, scales, zeros, group_size, q_perm, bits):
+    _hip.need_gpu(x, qweight, scales, zeros)
+    if x.dtype != torch.float16:
+        raise RuntimeError("mbwq_q4_forward: x must be torch.half")
+    x = x.contiguous()
+    M, K = x.shape
+    if K != qweight.shape[0] * (32 // bits):
+        raise RuntimeError("mbwq_q4_forward: x.size(1) != qweight.size(0) * (32 / bits)")
+    N = qweight.shape[1]
+    y = torch.empty((M, N), dtype=torch.float16, device=x.device)
+    if M == 0:
+        return y
+    L = _hip.lib()
+    ws = _hip.workspace(L.bie_mbwq_workspace_bytes(M, K, N), x.device)
+    perm = perm_or_none(q_perm)
+    rc = L.bie_mbwq_q4_forward(_hip.ptr(x), _hip.ptr(qweight), _hip.ptr(scales.contiguous()), _hip.ptr(zeros.contiguous()),
+                               _hip.ptr(perm), _hip.ptr(y), _hip.ptr(ws), 0 if ws is None else ws.numel(), M, K, N, bits,
+                               group_size, _hip.stream())
+    _hip.check(rc, "bie_mbwq_q4_forward")
+    return y
+
+
+def mbwq_exl2_forward(x, qweight, scales, zeros, q_perm, q_group_map, rows, use_cublas=False):
+    _hip.need_gpu(x, qweight, scales, zeros, q_perm, q_group_map)
+    if x.dtype != torch.float16:
+        raise RuntimeError("mbwq_exl2_forward: x must be torch.half")
+    x = x.contiguous()
+    M = x.shape[0]
+    K = q_perm.shape[0]
+    N = qweight.shape[1]
+    y = torch.empty((M, N), dtype=torch.float16, device=x.device)
+    if M == 0:
+        return y
+    L = _hip.lib()
+    ws = _hip.workspace(L.bie_mbwq_workspace_bytes(M, K, N), x.device)
+    keep, rp = _rows_arg(rows)
+    rc = L.bie_mbwq_exl2_forward(_hip.ptr(x), _hip.ptr(qweight), _hip.ptr(scales.contiguous()), _hip.ptr(zeros.contiguous()),
+                                 _hip.ptr(q_perm), _hip.ptr(q_group_map), rp, _hip.ptr(y), _hip.ptr(ws),
+                                 0 if ws is None else ws.numel(), M, K, N, scales.shape[0], _hip.stream())
+    _hip.check(rc, "bie_mbwq_exl2_forward")
+    return y

@@ -1,0 +1,47 @@
+"""BinaryConv2dCutlass: mirror of reference layers/qconv/binary/cutlass/layer.py (activation scale/bias,
+int8 sign carriers, packed weights); see extensions/binary_conv2d_cutlass.py for the output convention."""
+import torch
+
+from bitorch_engine.utils.safe_import import import_extension
+from bitorch_engine.utils.model_helper import init_weight
+from ..layer import BinaryConv2dBase, BinaryConvParameter
+
+binary_conv2d_cutlass = import_extension("binary_conv2d_cutlass")
+
+
+class BinaryConv2dCutlass(BinaryConv2dBase):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.bias_a = torch.nn.Parameter(torch.zeros(self.in_channels, dtype=self.dtype))
+        self.scale_a = torch.nn.Parameter(torch.tensor(0, dtype=torch.float))
+        self.scale_w = torch.nn.Parameter(torch.tensor(1, dtype=torch.float), requires_grad=False)
+
+    def prepare_params(self) -> None:
+        w, s = init_weight(self.weight, cls=BinaryConvParameter)
+        self.weight = w
+        self.scale_w.data = s.to(self.scale_w.dtype).reshape(())
+
+    def generate_quantized_weight(self, qweight_only: bool = False) -> None:
+        self.qweight = torch.nn.Parameter(binary_conv2d_cutlass.w_pack(self.weight.data), requires_grad=False)
+        if qweight_only:
+            self.weight = None
+
+    def set_activation(self, x: torch.Tensor) -> torch.Tensor:
+        if not self.scale_a.is_nonzero():
+            self.scale_a.data = ((2 if self.symmetric else 4) * x.abs().mean()).to(self.scale_a.dtype)
+        return x + self.bias_a.view(1, -1, 1, 1)
+
+    def set_weight_data(self, x: torch.Tensor) -> None:
+        super().set_weight_data(x)
+        self.prepare_params()
+
+    def _check_forward(self, x: torch.Tensor) -> None:
+        assert x.numel() % self.bits_binary_word == 0, "Input tensor dimension must be divisible by {}.".format(self.bits_binary_word)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        self._check_forward(x)
+        x = self.set_activation(x)
+        scale = self.scale_a.item() * self.scale_w.item()
+        out = binary_conv2d_cutlass.forward(x, self.opt_weight.data, scale, self.training, self.kernel_size, self.stride,
+                                            self.padding, self.dilation)
+        return out.to(x.dtype)

@@ -1,0 +1,50 @@
+"""BinaryLinearCuda: mirror of reference layers/qlinear/binary/cuda/layer.py.  out = (K - 2*popc) * scale_a *
+scale_w with the lazily initialised activation scale (2*mean|x|) and learnable activation bias."""
+import torch
+
+from bitorch_engine.utils.safe_import import import_extension
+from bitorch_engine.utils.model_helper import flatten_x, unflatten_x, init_weight
+from ..layer import BinaryLinearBase, BinaryLinearParameter
+from .bmm import BMM
+
+binary_linear_cuda = import_extension("binary_linear_cuda")
+
+
+class BinaryLinearCuda(BinaryLinearBase):
+    def __init__(self, *args, bmm_type: BMM = BMM.ADAPTIVE, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.bmm_type = bmm_type
+        self.bias_a = torch.nn.Parameter(torch.zeros(self.input_features, dtype=self.dtype))
+        self.scale_a = torch.nn.Parameter(torch.tensor(0, dtype=self.dtype))
+        self.register_buffer("scale_w", torch.tensor(1, dtype=self.dtype))
+
+    def prepare_params(self) -> None:
+        w, s = init_weight(self.weight, cls=BinaryLinearParameter)
+        self.weight = w
+        self.scale_w.data = s.to(self.scale_w.dtype).reshape(())
+
+    def generate_quantized_weight(self, qweight_only: bool = False) -> None:
+        self.qweight = torch.nn.Parameter(binary_linear_cuda.w_pack(self.weight.data, self.bmm_type.value, True), requires_grad=False)
+        if qweight_only:
+            self.weight = None
+
+    @staticmethod
+    def w_pack(weights: torch.Tensor, bmm_type: BMM) -> torch.Tensor:
+        return binary_linear_cuda.w_pack(weights, bmm_type.value, True)
+
+    def set_activation(self, x: torch.Tensor) -> torch.Tensor:
+        if not self.scale_a.is_nonzero():
+            self.scale_a.data = ((2 if self.symmetric else 4) * x.abs().mean()).to(self.dtype)
+        return x + self.bias_a.expand_as(x)
+
+    def set_weight_data(self, x: torch.Tensor) -> None:
+        super().set_weight_data(x)
+        self.prepare_params()
+
+    def forward(self, x: torch.Tensor, bmm_type: BMM = BMM.ADAPTIVE) -> torch.Tensor:
+        self._check_forward(x)
+        self.bmm_type = bmm_type
+        x = self.set_activation(x)
+        x2, lead = flatten_x(x)
+        out = binary_linear_cuda.forward(x2, self.opt_weight.data, self.bmm_type.value, True).to(x.dtype)
+        return unflatten_x(out, lead) * self.scale_a * self.scale_w

@@ -1,0 +1,133 @@
+"""MBWQLinearCuda: uniform 4/2-bit (GPTQ-like) and mixed 8/6/5/4/3/2-bit (exl2 layout) fp16 linear.
+API mirror of reference layers/qlinear/nbit/cuda/mbwq_layer.py (Function :14-122, layer :125-372)."""
+import math
+import typing
+
+import torch
+from torch.autograd import Function
+
+from bitorch_engine.layers.qlinear.nbit import MPQLinearBase, MPQWeightParameter
+from bitorch_engine.utils.safe_import import import_extension
+from bitorch_engine.utils.model_helper import flatten_x, unflatten_x
+from .utils import unpack_qweight, make_group_map
+
+q_linear_cuda = import_extension("q_linear_cuda")
+
+
+class MBWQLinearCudaFunction(Function):
+    @staticmethod
+    def forward(ctx, x, qweight, use_mbw, is_train, scales, zeros, group_size, q_perm=None, bits=4,
+                privileged_grad=None, q_group_map=None, rows=None):
+        x2, lead = flatten_x(x)
+        if use_mbw:
+            out = q_linear_cuda.mbwq_exl2_forward(x2, qweight, scales, zeros, q_perm, q_group_map, rows, False)
+        else:
+            out = q_linear_cuda.mbwq_q4_forward(x2, qweight, scales, zeros, group_size, q_perm, bits)
+        if is_train:
+            qweight.scales, qweight.zeros, qweight.q_perm = scales, zeros, q_perm
+            qweight.privileged_grad, qweight.group_size = privileged_grad, group_size
+            qweight.q_group_map, qweight.rows = q_group_map, rows
+            qweight.layer_type, qweight.w_bit, qweight.asym, qweight.g_idx = 2, bits, False, None
+            ctx.save_for_backward(x2, qweight)
+        return unflatten_x(out, lead)
+
+    @staticmethod
+    @typing.no_type_check
+    def backward(ctx, output_gradient):
+        gy, lead = flatten_x(output_gradient)
+        x2, qweight = ctx.saved_tensors
+        gy = gy.to(x2.dtype)
+        gx = gy.mm(unpack_qweight(qweight).to(x2.dtype).t())
+        if qweight.requires_grad:
+            qweight.privileged_grad = x2.t().mm(gy)
+        return (unflatten_x(gx, lead),) + (None,) * 11
+
+
+class MBWQLinearCuda(MPQLinearBase):
+    def __init__(self, *args, use_mbw: bool = True, groups=64, rows_packed=64, **kwargs) -> None:
+        super().__init__(*args, **kwargs)
+        self.qweight.layer_type = 2
+        self.use_mbw, self.groups, self.rows_packed = use_mbw, groups, rows_packed
+        self.rows = [0] * 7  # rows_8, rows_6, rows_5, rows_4, rows_3, rows_2 (cumulative k), kernel_p bit mask
+        self.check_parameters()
+
+    def check_parameters(self) -> None:
+        assert self.dtype == torch.half, f"The value of dtype ({self.dtype}) must be torch.half."
+        self.register_buffer("q_perm", torch.zeros(self.in_channels, dtype=torch.short))
+        self.register_buffer("channel_scale", torch.ones((1, 1, self.in_channels), dtype=self.dtype))
+        if not self.use_mbw:
+            assert self.w_bit in [2, 4], f"The value of w_bit ({self.w_bit}) must be 4 or 2."
+            assert self.group_size >= 32, f"The value of group_size ({self.group_size}) must >= 32."
+            return
+        shape = (math.ceil(self.groups), math.ceil(self.out_channels))
+        self.qweight = MPQWeightParameter(torch.empty((self.rows_packed, self.out_channels), dtype=torch.int32),
+                                          requires_grad=False, layer_type=2)
+        self.register_buffer("q_groups", torch.empty(self.groups * 2, dtype=torch.short))
+        self.register_buffer("zeros", torch.empty(shape, dtype=self.dtype))
+        self.register_buffer("scales", torch.empty(shape, dtype=self.dtype))
+        self.q_group_map = None
+
+    def load_state_dict(self, state_dict, strict=True) -> None:
+        """Like the reference (:205-237): exl2 tensors whose shapes differ from the constructor's guess are
+        adopted as they come."""
+        own = self.state_dict()
+        for name, value in state_dict.items():
+            if name not in own:
+                if strict:
+                    raise KeyError(f"Missing key {name} in own state")
+                continue
+            if own[name].shape == value.shape:
+                own[name].copy_(value)
+            elif name in ("scales", "zeros", "q_perm", "q_groups", "q_group_map", "qweight"):
+                print(f"Warning: Shape mismatch for: {name}, expected: {own[name].shape}, got: {value.shape}. "
+                      f"Use the value in state_dict directly.")
+                own[name].data = value.data
+        if not strict:
+            missing = set(own.keys()) - set(state_dict.keys())
+            if missing:
+                print(f"Warning: Missing keys in state_dict: {missing}")
+
+    def set_scales(self, scales: torch.Tensor = None) -> None:
+        self.scales = scales
+        self.qweight.scales = scales
+
+    def set_zeros(self, zeros: torch.Tensor = None) -> None:
+        self.zeros = zeros
+        self.qweight.zeros = zeros
+
+    def prepare_params(self) -> None:
+        try:
+            self.qweight.scales, self.qweight.zeros, self.qweight.q_perm = self.scales, self.zeros, self.q_perm
+            height, groups = self.q_perm.size(0), self.scales.size(0)
+            if self.use_mbw:
+                self.qweight.data, self.rows = q_linear_cuda.mbwq_trans_qweight(self.qweight, self.q_groups, True,
+                                                                                height, groups, self.w_bit)
+                if self.q_group_map is None:
+                    self.q_group_map = make_group_map(self.q_groups, self.qweight.shape[0])
+                self.qweight.q_group_map, self.qweight.rows = self.q_group_map, self.rows
+            else:
+                q_linear_cuda.mbwq_trans_qweight(self.qweight, None, False, height, groups, self.w_bit)
+            for name in ("qzeros_zeros", "qzeros_scales", "qscales_zeros", "qscales_scales", "qstatistic"):
+                if hasattr(self, name):
+                    delattr(self, name)
+            if self.disable_bias:
+                del self.bias
+            del self.wf
+            del self.g_idx
+        except Exception as e:
+            raise RuntimeError(f"Error occurred during parameter preparation in MBWQLinearCuda layer: {e}")
+
+    @staticmethod
+    def q42fp_weight(qweight, scales, zeros, group_size, bits, q_perm) -> torch.Tensor:
+        return q_linear_cuda.mbwq_q42fp_weight(qweight, scales, zeros, group_size, bits, q_perm)
+
+    @staticmethod
+    def exl2fp_weight(qweight, scales, zeros, q_perm, q_group_map, rows) -> torch.Tensor:
+        return q_linear_cuda.mbwq_exl2fp_weight(qweight, scales, zeros, q_perm, q_group_map, rows)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = x.mul(self.channel_scale)
+        extra = (self.q_group_map, self.rows) if self.use_mbw else ()
+        out = MBWQLinearCudaFunction.apply(x, self.qweight, self.use_mbw, self.training, self.scales, self.zeros,
+                                           self.group_size, self.q_perm, self.w_bit, self.privileged_grad, *extra)
+        return out if self.disable_bias else out + self.bias

@@ -1,0 +1,103 @@
+"""MPQLinearCuda: W{1,2,4,8}A16 linear on MI355X.  API mirror of reference
+layers/qlinear/nbit/cuda/mpq_layer.py (Function :14-121, layer :124-224); the arithmetic is ONE fused
+HIP kernel family for every M (decode GEMV, MFMA GEMM) instead of the reference's
+"kernel for M<=32, else materialise the dense weight + cuBLAS" split (:59-65)."""
+import math
+import typing
+
+import torch
+from torch.autograd import Function
+
+from bitorch_engine.layers.qlinear.nbit import MPQLinearBase
+from bitorch_engine.utils.safe_import import import_extension
+from bitorch_engine.utils.model_helper import flatten_x, unflatten_x
+
+q_linear_cuda = import_extension("q_linear_cuda")
+
+
+class MPQLinearCudaFunction(Function):
+    @staticmethod
+    def forward(ctx, x, qweight, a_bit, w_bit, scales, zeros, g_idx, asym, is_training, privileged_grad=None):
+        x2, lead = flatten_x(x)
+        out = q_linear_cuda.mpq_forward(x2, qweight, scales, zeros, g_idx, a_bit, w_bit, asym)
+        if is_training:
+            qweight.privileged_grad = privileged_grad
+            qweight.scales, qweight.zeros, qweight.g_idx = scales, zeros, g_idx
+            qweight.w_bit, qweight.asym, qweight.layer_type = w_bit, asym, 1
+            ctx.a_bit = a_bit
+            ctx.save_for_backward(x2, qweight)
+        return unflatten_x(out, lead)
+
+    @staticmethod
+    @typing.no_type_check
+    def backward(ctx, output_gradient):
+        gy, lead = flatten_x(output_gradient)
+        x2, qweight = ctx.saved_tensors
+        gy = gy.to(x2.dtype)
+        gx = q_linear_cuda.mpq_grad_input(qweight.data, qweight.scales, qweight.zeros, qweight.g_idx, gy, ctx.a_bit,
+                                          qweight.w_bit, qweight.asym)
+        if qweight.requires_grad:
+            qweight.privileged_grad = x2.t().mm(gy)
+        return (unflatten_x(gx, lead),) + (None,) * 9
+
+
+class MPQLinearCuda(MPQLinearBase):
+    """Mixed-precision quantised linear layer (weights 1/2/4/8 bit, activations fp16/bf16)."""
+
+    def __init__(self, *args, **kwargs) -> None:
+        super().__init__(*args, **kwargs)
+        self.qweight.layer_type = 1
+        self._gidx_trivial = None
+        self.check_parameters()
+
+    def check_parameters(self) -> None:
+        assert self.w_bit in [1, 2, 4, 8], f"The value of w_bit ({self.w_bit}) must be 1, 2, 4 or 8."
+        assert self.a_bit == 16, f"The value of a_bit ({self.a_bit}) must be 16."
+
+    def prepare_params(self) -> None:
+        """Decode the double-quantised statistics into per-group `scales` / `zeros` ([G, N], layer dtype) and
+        drop the load-only buffers -- reference mpq_layer.py:163-204.  Elementwise torch ops in the layer
+        dtype (each op rounds once, like the reference); runs once per layer, on whatever device the
+        buffers live on."""
+        try:
+            if self.use_gba_quant:
+                if self.group_size < 256:  # larger groups are stored without double quantisation
+                    shape = (math.ceil(self.in_channels / self.group_size), self.out_channels)
+                    if self.asym:
+                        codes = self.qscales.unsqueeze(-1) if self.w_bit == 2 else self.qscales
+                        self.zeros = self.qzeros
+                    else:
+                        stat = self.qstatistic.to(torch.uint8)
+                        codes = stat >> 4
+                        zcodes = stat & 0x0F
+                        self.zeros = ((zcodes.to(self.dtype) - self.qzeros_zeros) * self.qzeros_scales).view(shape)
+                    self.scales = ((codes.to(self.dtype) - self.qscales_zeros) * self.qscales_scales).view(shape)
+                for name in ("qscales_zeros", "qscales_scales") + (("qscales",) if self.asym else
+                                                                     ("qstatistic", "qzeros_zeros", "qzeros_scales")):
+                    delattr(self, name)
+            else:
+                self.zeros = self.qzeros
+            if self.disable_bias:
+                del self.bias
+            del self.wf
+            self._gidx_trivial = None
+        except Exception as e:
+            raise RuntimeError(f"Error occurred during parameter preparation in MPQLinearCuda layer: {e}")
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        dev = x.device
+        if not all(t.device == dev for t in (self.qweight, self.scales, self.zeros, self.g_idx)):
+            raise RuntimeError("Some tensors are not on the correct device, please make sure to move the layer to "
+                               "the correct device and call 'finalize_quantized_layers'.")
+        if self.training or torch.is_grad_enabled() and x.requires_grad:
+            out = MPQLinearCudaFunction.apply(x, self.qweight, self.a_bit, self.w_bit, self.scales, self.zeros,
+                                              self.g_idx, self.asym, self.training, self.privileged_grad)
+            return out if self.disable_bias else out + self.bias
+        # inference fast path: bias fused into the kernel epilogue, g_idx triviality checked once
+        if self._gidx_trivial is None:
+            self._gidx_trivial = q_linear_cuda.gidx_is_trivial(self.g_idx, self.group_size)
+        x2, lead = flatten_x(x)
+        out = q_linear_cuda.mpq_forward_impl(x2, self.qweight.data, self.scales, self.zeros, self.g_idx, self.w_bit,
+                                             self.asym, self.group_size, None if self.disable_bias else self.bias,
+                                             self._gidx_trivial)
+        return unflatten_x(out, lead)

@@ -1,0 +1,108 @@
+"""Base types of the W-n / A16 path, mirroring reference layers/qlinear/nbit/layer.py:8-119 (the
+parameter class) and :282-511 (MPQLinearBase): identical constructor arguments, attribute names and
+-- the on-disk contract -- identical state_dict keys / shapes / dtypes (tests/golden/
+state_dict_tables.json holds the reference's tables)."""
+import math
+
+import torch
+from torch import nn
+
+_QATTRS = ("privileged_grad", "scales", "zeros", "g_idx", "w_bit", "asym", "group_size", "layer_type", "q_perm",
+           "qscales_zeros", "qscales_scales", "qzeros_zeros", "qzeros_scales", "q_group_map", "rows")
+_QDEFAULTS = dict(w_bit=-1, asym=False, group_size=-1, layer_type=-1)
+
+
+class MPQWeightParameter(nn.Parameter):
+    """nn.Parameter holding the packed int32 weights plus the quantisation metadata the kernels need
+    (scales, zeros, g_idx, w_bit, asym, group_size, layer_type 1=MPQ / 2=MBWQ, q_perm, q_group_map,
+    rows, ...) as plain attributes."""
+
+    def __new__(cls, data=None, requires_grad: bool = False, **meta):
+        if data is not None and not data.is_floating_point():
+            requires_grad = False  # stock torch: integer tensors cannot require grad
+        return super().__new__(cls, data, requires_grad=requires_grad)
+
+    def __init__(self, data=None, requires_grad: bool = False, **meta):
+        unknown = set(meta) - set(_QATTRS)
+        if unknown:
+            raise TypeError(f"MPQWeightParameter: unexpected arguments {sorted(unknown)}")
+        for name in _QATTRS:
+            setattr(self, name, meta.get(name, _QDEFAULTS.get(name)))
+
+    @staticmethod
+    def update(qweight, *args, **kwargs):
+        raise NotImplementedError("MPQWeightParameter.update (DiodeMix training step, reference "
+                                  "utils/model_helper.py:363-532) is outside the inference hot path of this build")
+
+
+def _groups(k, g):
+    return math.ceil(k / g)
+
+
+class MPQLinearBase(nn.Module):
+    """Allocates the packed weight and the quantisation buffers for GPTQ-style (`use_gba_quant=False`)
+    or GBA-style (double-quantised statistics) checkpoints.  Sub-classes implement
+    check_parameters / prepare_params / forward."""
+
+    def __init__(self, in_channels: int, out_channels: int, a_bit: int = 16, w_bit: int = 4, dtype=torch.half,
+                 group_size=-1, use_gba_quant=True, dq_group_size=-1, dq_mode=2, disable_bias=True, asym=False,
+                 requires_grad=False) -> None:
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.a_bit, self.w_bit, self.dtype = a_bit, w_bit, dtype
+        self.maxq = 2 ** w_bit - 1
+        self.group_size = group_size if group_size > -1 else in_channels
+        self.asym, self.disable_bias = asym, disable_bias
+        self.use_gba_quant, self.dq_group_size, self.dq_mode = use_gba_quant, dq_group_size, dq_mode
+        self.requires_grad = False  # inference build (see package docstring)
+        self.privileged_grad = None
+        self.initialize()
+
+    # ------------------------------------------------------------------ buffers
+    def initialize(self) -> None:
+        K, N, w = self.in_channels, self.out_channels, self.w_bit
+        self.qweight = MPQWeightParameter(torch.empty((K // 32 * w, N), dtype=torch.int32), requires_grad=False,
+                                          w_bit=w, asym=self.asym, group_size=self.group_size)
+        self.register_buffer("g_idx", torch.arange(K, dtype=torch.int32) // self.group_size)
+        self.register_buffer("bias", torch.zeros(N, dtype=self.dtype))
+        self.register_buffer("wf", torch.arange(0, 32, w, dtype=torch.int32).unsqueeze(0))
+        (self.init_gba if self.use_gba_quant else self.init_gptq)()
+
+    def init_gptq(self) -> None:
+        G, N = _groups(self.in_channels, self.group_size), self.out_channels
+        self.register_buffer("qzeros", torch.zeros((G, N // 32 * self.w_bit), dtype=torch.int32))
+        self.register_buffer("scales", torch.ones((G, N), dtype=self.dtype))
+        self.asym = True
+
+    def init_gba(self) -> None:
+        if self.dq_group_size == -1:
+            self.dq_group_size = self.out_channels
+        G, N, dq = _groups(self.in_channels, self.group_size), self.out_channels, self.dq_group_size
+        per_block = (G, math.ceil(N / dq), 1)
+        per_value = (G, math.ceil(N / dq), dq)
+        if self.asym:
+            self.register_buffer("qzeros", torch.zeros((G, N // 32 * self.w_bit), dtype=torch.int32))
+            shape = per_value if self.w_bit == 4 else (G, N)
+            self.register_buffer("qscales", torch.ones(shape, dtype=torch.uint8))
+        else:
+            self.register_buffer("qstatistic", torch.ones(per_value, dtype=torch.uint8))
+            self.register_buffer("qzeros_zeros", torch.zeros(per_block, dtype=self.dtype))
+            self.register_buffer("qzeros_scales", torch.ones(per_block, dtype=self.dtype))
+        dq_shape = (1, N, 1) if self.dq_mode == 1 else per_block
+        self.register_buffer("qscales_zeros", torch.zeros(dq_shape, dtype=self.dtype))
+        self.register_buffer("qscales_scales", torch.ones(dq_shape, dtype=self.dtype))
+        self.register_buffer("scales", torch.ones((G, N), dtype=self.dtype))
+        self.register_buffer("zeros", torch.zeros((G, N), dtype=self.dtype))
+
+    # ------------------------------------------------------------------ protocol
+    def set_qweight_data(self, data: torch.Tensor) -> None:
+        self.qweight.data = data
+
+    def generate_quantized_weight(self, qweight_only: bool = False) -> None:
+        raise NotImplementedError("this method has not been implemented.")
+
+    def check_parameters(self) -> None:
+        raise NotImplementedError("Subclasses should implement this method.")
+
+    def prepare_params(self) -> None:
+        raise NotImplementedError("Subclasses should implement this method.")

@@ -1,0 +1,320 @@
+// 1-bit W / 1-bit A linear + conv2d (XNOR-popcount) and the functions/cuda pack helpers for gfx950.
+// CDNA4 has no 1-bit MFMA, so the contraction runs on the VALU: v_xor_b32 + v_bcnt_u32_b32 (popcount
+// with accumulate) = 2 instructions per 32 binary MACs per lane.
+//   y = (K - 2 * popcount(xbits ^ wbits)) * scale,  bit = (value >= 0)
+// Replaces binary_linear.cpp (_get_binary_row :43-54, _xnor_gemm_unrolled :249-295, forward :494-512),
+// binary_linear_cuda_kernel.cu (BMMAS_new :155-181, BMM32_Arow_Brow_UD :308-393),
+// binary_linear_cutlass_kernel.cu (:44-113), binary_conv.cpp (im2binary_col :319-365, forward :464-530)
+// and functions_cuda_kernel.cu (:73-207).
+#include "bie_common.h"
+
+namespace bie {
+
+template <int DT>
+__device__ __forceinline__ bool sign_bit(const void* p, long i) {
+    if constexpr (DT == 3) return ((const int8_t*)p)[i] >= 0;
+    else return dt_traits<DT>::load(p, i) >= 0.0f;
+}
+
+// ---- packing ---------------------------------------------------------------------------------------------
+// rows x K values -> rows x K/8 bytes, LSB first.  One thread per output byte.
+template <int DT>
+__global__ __launch_bounds__(256) void pack_rows_kernel(const void* __restrict__ a, uint8_t* __restrict__ out, long n_bytes) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_bytes) return;
+    uint32_t v = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) v |= (uint32_t)sign_bit<DT>(a, i * 8 + j) << j;
+    out[i] = (uint8_t)v;
+}
+
+// w [N][K] -> column bit-planes [K/8][N]
+template <int DT>
+__global__ __launch_bounds__(256) void pack_cols_kernel(const void* __restrict__ w, uint8_t* __restrict__ out, long N, long K) {
+    const long n = (long)blockIdx.x * 256 + threadIdx.x;
+    const long kb = blockIdx.y;
+    if (n >= N) return;
+    uint32_t v = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) v |= (uint32_t)sign_bit<DT>(w, n * K + kb * 8 + j) << j;
+    out[kb * N + n] = (uint8_t)v;
+}
+
+// ---- XNOR GEMM on 32-bit words: y[b][m][n] = (Kbits - 2*popc(A[m] ^ B[b][n])) * scale -------------------------
+// 64 x 64 output tile per block, 16 x 16 threads, 4 x 4 outputs per thread, KC words per LDS stage.
+constexpr int XT = 64, XKC = 32;
+
+__global__ __launch_bounds__(256) void xnor_gemm_kernel(const uint32_t* __restrict__ A, const uint32_t* __restrict__ B,
+                                                        float* __restrict__ y, int M, int N, int KW, int Kbits, float scale,
+                                                        long strideA, long strideB, long strideY) {
+    __shared__ uint32_t As[XT][XKC + 1];
+    __shared__ uint32_t Bs[XT][XKC + 1];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int m0 = blockIdx.y * XT, n0 = blockIdx.x * XT;
+    A += (long)blockIdx.z * strideA;
+    B += (long)blockIdx.z * strideB;
+    y += (long)blockIdx.z * strideY;
+    int acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = 0;
+    for (int k0 = 0; k0 < KW; k0 += XKC) {
+        for (int idx = threadIdx.x; idx < XT * XKC; idx += 256) {
+            const int r = idx / XKC, c = idx % XKC;
+            const int k = k0 + c;
+            As[r][c] = (m0 + r < M && k < KW) ? A[(long)(m0 + r) * KW + k] : 0u;
+            Bs[r][c] = (n0 + r < N && k < KW) ? B[(long)(n0 + r) * KW + k] : 0u;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int c = 0; c < XKC; c++) {
+            uint32_t a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) a[i] = As[ty + 16 * i][c];
+#pragma unroll
+            for (int j = 0; j < 4; j++) b[j] = Bs[tx + 16 * j][c];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] += __builtin_popcount(a[i] ^ b[j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int m = m0 + ty + 16 * i, n = n0 + tx + 16 * j;
+            if (m < M && n < N) y[(long)m * N + n] = (float)(Kbits - 2 * acc[i][j]) * scale;
+        }
+}
+
+// Skinny-M variant (decode): one wave per output column n, lanes stride over the K words (coalesced),
+// x rows cached in registers, wave reduction.  M <= 4 per launch.
+template <int MT>
+__global__ __launch_bounds__(256) void xnor_gemv_kernel(const uint32_t* __restrict__ X, const uint32_t* __restrict__ Wt,
+                                                        float* __restrict__ y, int M, int N, int KW, int Kbits, float scale) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= N) return;
+    int acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; m++) acc[m] = 0;
+    for (int k = lane; k < KW; k += 64) {
+        const uint32_t w = Wt[(long)n * KW + k];
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+            if (m < M) acc[m] += __builtin_popcount(w ^ X[(long)m * KW + k]);
+    }
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+        int v = acc[m];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0 && m < M) y[(long)m * N + n] = (float)(Kbits - 2 * v) * scale;
+    }
+}
+
+// byte-granular compatibility kernel: any K % 8 == 0, either weight layout.  One thread per output.
+__global__ __launch_bounds__(256) void xnor_bytes_kernel(const uint8_t* __restrict__ X, const uint8_t* __restrict__ W,
+                                                         float* __restrict__ y, long M, long N, long KB, int w_layout,
+                                                         float scale) {
+    const long n = (long)blockIdx.x * 256 + threadIdx.x;
+    const long m = blockIdx.y;
+    if (n >= N) return;
+    int pc = 0;
+    for (long b = 0; b < KB; b++) {
+        const uint8_t wv = w_layout ? W[b * N + n] : W[n * KB + b];
+        pc += __builtin_popcount((unsigned)(X[m * KB + b] ^ wv));
+    }
+    y[m * N + n] = (float)(KB * 8 - 2 * pc) * scale;
+}
+
+// ---- conv2d: bit-im2col (pad -> bit 0 == -1) into 32-bit words, zero-padded to a word multiple -----------------
+// cols[b][p][KW] with p = oh*OW + ow and k = c*ks*ks + i*ks + j
+template <int DT>
+__global__ __launch_bounds__(256) void im2col_bits_kernel(const void* __restrict__ x, uint32_t* __restrict__ cols, int B, int C,
+                                                          int H, int W, int OH, int OW, int ks, int stride, int pad, int dil,
+                                                          int Kc, int KW) {
+    const long total = (long)B * OH * OW * KW;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int kw = (int)(idx % KW);
+    const long bp = idx / KW;
+    const int p = (int)(bp % (OH * OW));
+    const int b = (int)(bp / (OH * OW));
+    const int oh = p / OW, ow = p % OW;
+    uint32_t v = 0;
+    for (int j = 0; j < 32; j++) {
+        const int k = kw * 32 + j;
+        if (k >= Kc) break;
+        const int wj = k % ks, hi_ = (k / ks) % ks, c = k / (ks * ks);
+        const int h_im = oh * stride - pad + hi_ * dil;
+        const int w_im = ow * stride - pad + wj * dil;
+        if (h_im >= 0 && w_im >= 0 && h_im < H && w_im < W)
+            v |= (uint32_t)sign_bit<DT>(x, (((long)b * C + c) * H + h_im) * W + w_im) << j;
+    }
+    cols[idx] = v;
+}
+
+// row-packed bytes [rows][KB] -> words [rows][KW] zero-padded
+__global__ __launch_bounds__(256) void bytes_to_words_kernel(const uint8_t* __restrict__ in, uint32_t* __restrict__ out, long rows,
+                                                             int KB, int KW) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * KW) return;
+    const long r = idx / KW;
+    const int kw = (int)(idx % KW);
+    uint32_t v = 0;
+    for (int j = 0; j < 4; j++) {
+        const int bidx = kw * 4 + j;
+        if (bidx < KB) v |= (uint32_t)in[r * KB + bidx] << (8 * j);
+    }
+    out[idx] = v;
+}
+
+// ---- functions/cuda helpers -----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void unpack_u8_scaled_kernel(const uint8_t* __restrict__ in, const float* __restrict__ scale,
+                                                               float* __restrict__ out, long n, long packed_dim) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t w = in[i];
+    const float sc = scale[i / packed_dim];
+    float4_t lo, hi;
+    lo.x = (w & 1u) ? sc : -sc; lo.y = (w & 2u) ? sc : -sc; lo.z = (w & 4u) ? sc : -sc; lo.w = (w & 8u) ? sc : -sc;
+    hi.x = (w & 16u) ? sc : -sc; hi.y = (w & 32u) ? sc : -sc; hi.z = (w & 64u) ? sc : -sc; hi.w = (w & 128u) ? sc : -sc;
+    float4_t* o = reinterpret_cast<float4_t*>(out + i * 8);
+    o[0] = lo;
+    o[1] = hi;
+}
+
+__global__ __launch_bounds__(256) void q4_pack_kernel(const int32_t* __restrict__ in, int8_t* __restrict__ out, long n_out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_out) return;
+    out[i] = (int8_t)(((in[2 * i] & 0xF) << 4) | (in[2 * i + 1] & 0xF));
+}
+
+__global__ __launch_bounds__(256) void q4_unpack_kernel(const int8_t* __restrict__ in, int32_t* __restrict__ out, long n_in) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_in) return;
+    const uint32_t v = (uint8_t)in[i];
+    out[2 * i] = (int32_t)(v >> 4);
+    out[2 * i + 1] = (int32_t)(v & 0xF);
+}
+
+__global__ __launch_bounds__(256) void q4_unpack_scale_kernel(const int8_t* __restrict__ in, float* __restrict__ out, long n_in,
+                                                              float scale) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_in) return;
+    const int v = (uint8_t)in[i];
+    int hi = v >> 4, lo = v & 0xF;
+    if (hi > 7) hi -= 16;
+    if (lo > 7) lo -= 16;
+    out[2 * i] = (float)hi * scale;
+    out[2 * i + 1] = (float)lo * scale;
+}
+
+// ---- launchers -------------------------------------------------------------------------------------------------
+#define BIE_DT_SWITCH(dtype, CALL)                 \
+    switch (dtype) {                               \
+        case BIE_F16: { constexpr int DT = BIE_F16; CALL; } break;   \
+        case BIE_BF16: { constexpr int DT = BIE_BF16; CALL; } break; \
+        case BIE_F32: { constexpr int DT = BIE_F32; CALL; } break;   \
+        default: { constexpr int DT = 3; CALL; } break;              \
+    }
+
+int pack_rows_launch(const void* a, uint8_t* out, long n_bytes, int dtype, hipStream_t st) {
+    dim3 grid((unsigned)cdivl(n_bytes, 256));
+    BIE_DT_SWITCH(dtype, hipLaunchKernelGGL(pack_rows_kernel<DT>, grid, dim3(256), 0, st, a, out, n_bytes));
+    return check_launch("pack_rows_kernel");
+}
+
+int pack_cols_launch(const void* w, uint8_t* out, long N, long K, int dtype, hipStream_t st) {
+    dim3 grid((unsigned)cdivl(N, 256), (unsigned)(K / 8));
+    BIE_DT_SWITCH(dtype, hipLaunchKernelGGL(pack_cols_kernel<DT>, grid, dim3(256), 0, st, w, out, N, K));
+    return check_launch("pack_cols_kernel");
+}
+
+int binary_linear_launch(const uint8_t* xp, const uint8_t* wp, float* y, long M, long N, long K, int w_layout, float scale,
+                         hipStream_t st) {
+    const bool words_ok = (K % 32 == 0) && w_layout == 0 && (((uintptr_t)xp | (uintptr_t)wp) & 3) == 0;
+    if (!words_ok) {
+        dim3 grid((unsigned)cdivl(N, 256), (unsigned)M);
+        hipLaunchKernelGGL(xnor_bytes_kernel, grid, dim3(256), 0, st, xp, wp, y, M, N, K / 8, w_layout, scale);
+        return check_launch("xnor_bytes_kernel");
+    }
+    const int KW = (int)(K / 32);
+    if (M <= 4) {
+        dim3 grid((unsigned)cdivl(N, 4));
+        if (M == 1) hipLaunchKernelGGL(xnor_gemv_kernel<1>, grid, dim3(256), 0, st, (const uint32_t*)xp, (const uint32_t*)wp, y, (int)M, (int)N, KW, (int)K, scale);
+        else if (M == 2) hipLaunchKernelGGL(xnor_gemv_kernel<2>, grid, dim3(256), 0, st, (const uint32_t*)xp, (const uint32_t*)wp, y, (int)M, (int)N, KW, (int)K, scale);
+        else hipLaunchKernelGGL(xnor_gemv_kernel<4>, grid, dim3(256), 0, st, (const uint32_t*)xp, (const uint32_t*)wp, y, (int)M, (int)N, KW, (int)K, scale);
+        return check_launch("xnor_gemv_kernel");
+    }
+    dim3 grid((unsigned)cdivl(N, XT), (unsigned)cdivl(M, XT), 1);
+    hipLaunchKernelGGL(xnor_gemm_kernel, grid, dim3(256), 0, st, (const uint32_t*)xp, (const uint32_t*)wp, y, (int)M, (int)N, KW,
+                       (int)K, scale, 0L, 0L, 0L);
+    return check_launch("xnor_gemm_kernel");
+}
+
+size_t binary_conv_workspace_bytes(int B, int C, int H, int W, int OC, int ks, int stride, int pad, int dil) {
+    const int OH = (H + 2 * pad - dil * (ks - 1) - 1) / stride + 1;
+    const int OW = (W + 2 * pad - dil * (ks - 1) - 1) / stride + 1;
+    const int Kc = C * ks * ks;
+    const int KW = cdiv(Kc, 32);
+    return ((size_t)B * OH * OW * KW + (size_t)OC * KW) * 4;
+}
+
+int binary_conv_launch(const void* x, const uint8_t* wpacked, float* y, void* ws, int B, int C, int H, int W, int OC, int ks,
+                       int stride, int pad, int dil, float scale, int dtype, hipStream_t st) {
+    const int OH = (H + 2 * pad - dil * (ks - 1) - 1) / stride + 1;
+    const int OW = (W + 2 * pad - dil * (ks - 1) - 1) / stride + 1;
+    const int P = OH * OW;
+    const int Kc = C * ks * ks;
+    const int KW = cdiv(Kc, 32);
+    uint32_t* wwords = reinterpret_cast<uint32_t*>(ws);
+    uint32_t* cols = wwords + (size_t)OC * KW;
+    {
+        const long total = (long)OC * KW;
+        hipLaunchKernelGGL(bytes_to_words_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, st, wpacked, wwords, (long)OC,
+                           Kc / 8, KW);
+        int rc = check_launch("bytes_to_words_kernel");
+        if (rc) return rc;
+    }
+    {
+        const long total = (long)B * P * KW;
+        dim3 grid((unsigned)cdivl(total, 256));
+        BIE_DT_SWITCH(dtype, hipLaunchKernelGGL(im2col_bits_kernel<DT>, grid, dim3(256), 0, st, x, cols, B, C, H, W, OH, OW, ks, stride,
+                                                pad, dil, Kc, KW));
+        int rc = check_launch("im2col_bits_kernel");
+        if (rc) return rc;
+    }
+    // y[b][oc][p] = (Kc - 2 popc(w[oc] ^ cols[b][p])) * scale : A = weights (shared), B = cols of image b
+    dim3 grid((unsigned)cdiv(P, XT), (unsigned)cdiv(OC, XT), (unsigned)B);
+    hipLaunchKernelGGL(xnor_gemm_kernel, grid, dim3(256), 0, st, wwords, cols, y, OC, P, KW, Kc, scale, 0L, (long)P * KW,
+                       (long)OC * P);
+    return check_launch("xnor_gemm_kernel(conv)");
+}
+
+int pack_sign_launch(const void* a, uint8_t* out, long n_bytes, int dtype, hipStream_t st) {
+    return pack_rows_launch(a, out, n_bytes, dtype, st);
+}
+
+int unpack_u8_scaled_launch(const uint8_t* in, const float* scale, float* out, long n, long packed_dim, hipStream_t st) {
+    hipLaunchKernelGGL(unpack_u8_scaled_kernel, dim3((unsigned)cdivl(n, 256)), dim3(256), 0, st, in, scale, out, n, packed_dim);
+    return check_launch("unpack_u8_scaled_kernel");
+}
+int q4_pack_launch(const int32_t* in, int8_t* out, long n_out, hipStream_t st) {
+    hipLaunchKernelGGL(q4_pack_kernel, dim3((unsigned)cdivl(n_out, 256)), dim3(256), 0, st, in, out, n_out);
+    return check_launch("q4_pack_kernel");
+}
+int q4_unpack_launch(const int8_t* in, int32_t* out, long n_in, hipStream_t st) {
+    hipLaunchKernelGGL(q4_unpack_kernel, dim3((unsigned)cdivl(n_in, 256)), dim3(256), 0, st, in, out, n_in);
+    return check_launch("q4_unpack_kernel");
+}
+int q4_unpack_scale_launch(const int8_t* in, float* out, long n_in, float scale, hipStream_t st) {
+    hipLaunchKernelGGL(q4_unpack_scale_kernel, dim3((unsigned)cdivl(n_in, 256)), dim3(256), 0, st, in, out, n_in, scale);
+    return check_launch("q4_unpack_scale_kernel");
+}
+
+}  // namespace bie

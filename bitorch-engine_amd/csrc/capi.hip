@@ -1,0 +1,284 @@
+// extern "C" surface of libbie_hip.so (see include/bie_hip.h for the contract and the reference
+// functions each entry point replaces).  Argument validation + dispatch only; kernels live in the
+// sibling translation units.
+#include "bie_common.h"
+
+namespace bie {
+const char* get_error();
+// mpq_gemv.hip
+bool mpq_gemv_fast_ok(int M, int K, int N, int w_bit, int group_size, int dtype, bool has_gidx);
+size_t mpq_gemv_workspace_bytes(int M, int K, int N, int w_bit);
+int mpq_gemv_launch(const void* x, const int32_t* qw, const void* scales, const void* zeros, const void* bias, void* y,
+                    float* part, int M, int K, int N, int w_bit, int group_size, int zm, int dtype, const uint16_t* perm,
+                    hipStream_t st);
+int mpq_gemv_generic_launch(const void* x, const int32_t* qw, const void* scales, const void* zeros, const int32_t* g_idx,
+                            const void* bias, void* y, float* part, int M, int K, int N, int w_bit, int group_size,
+                            int asym, int dtype, hipStream_t st);
+// mpq_gemm.hip
+bool mpq_gemm_ok(int M, int K, int N, int w_bit, int group_size, int dtype, bool has_gidx);
+size_t mpq_gemm_workspace_bytes(int M, int K, int N);
+int mpq_gemm_launch(const void* x, const int32_t* qw, const void* scales, const void* zeros, const void* bias, void* y,
+                    float* part, int M, int K, int N, int w_bit, int group_size, int zm, int dtype, const uint16_t* perm,
+                    hipStream_t st);
+// mpq_util.hip
+int mpq_dequant_launch(const int32_t* qw, const void* scales, const void* zeros, const int32_t* g_idx, void* out, int K,
+                       int N, int w_bit, int group_size, int asym, int dtype, hipStream_t st);
+int mpq_pack_launch(const void* weight, const void* scales, const void* zeros, const int32_t* g_idx, int32_t* out, int K,
+                    int N, int w_bit, int group_size, int asym, int dtype, hipStream_t st);
+int mpq_grad_input_launch(const void* gy, const int32_t* qw, const void* scales, const void* zeros, const int32_t* g_idx,
+                          void* gx, int M, int K, int N, int w_bit, int group_size, int asym, int dtype, hipStream_t st);
+// mbwq.hip
+size_t mbwq_workspace_bytes(int M, int K, int N);
+int mbwq_q4_dequant_launch(const int32_t* qw, const void* scales, const void* zeros, const int16_t* perm, void* out, int K,
+                           int N, int bits, int group_size, hipStream_t st);
+int mbwq_exl2_dequant_launch(const int32_t* qw, const void* scales, const void* zeros, const int16_t* perm,
+                             const int16_t* gmap, const int* rows7, void* out, int K, int N, hipStream_t st);
+int mbwq_q4_forward_launch(const void* x, const int32_t* qw, const void* scales, const void* zeros, const int16_t* perm,
+                           void* y, float* part, int M, int K, int N, int bits, int group_size, hipStream_t st);
+int mbwq_exl2_forward_launch(const void* x, const int32_t* qw, const void* scales, const void* zeros, const int16_t* perm,
+                             const int16_t* gmap, const int* rows7, void* y, float* part, int M, int K, int N,
+                             hipStream_t st);
+// binary.hip
+int pack_rows_launch(const void* a, uint8_t* out, long n_bytes, int dtype, hipStream_t st);
+int pack_cols_launch(const void* w, uint8_t* out, long N, long K, int dtype, hipStream_t st);
+int binary_linear_launch(const uint8_t* xp, const uint8_t* wp, float* y, long M, long N, long K, int w_layout, float scale,
+                         hipStream_t st);
+size_t binary_conv_workspace_bytes(int B, int C, int H, int W, int OC, int ks, int stride, int pad, int dil);
+int binary_conv_launch(const void* x, const uint8_t* wpacked, float* y, void* ws, int B, int C, int H, int W, int OC, int ks,
+                       int stride, int pad, int dil, float scale, int dtype, hipStream_t st);
+int unpack_u8_scaled_launch(const uint8_t* in, const float* scale, float* out, long n, long packed_dim, hipStream_t st);
+int q4_pack_launch(const int32_t* in, int8_t* out, long n_out, hipStream_t st);
+int q4_unpack_launch(const int8_t* in, int32_t* out, long n_in, hipStream_t st);
+int q4_unpack_scale_launch(const int8_t* in, float* out, long n_in, float scale, hipStream_t st);
+}  // namespace bie
+
+using namespace bie;
+
+static const int GENERIC_M_CHUNK = 32;
+
+static int validate_mpq(const char* fn, int K, int N, int w_bit, int group_size, int dtype) {
+    BIE_REQUIRE(w_bit == 1 || w_bit == 2 || w_bit == 4 || w_bit == 8, BIE_ERR_UNSUPPORTED,
+                "%s: w_bit=%d is not supported (1, 2, 4, 8)", fn, w_bit);
+    BIE_REQUIRE(dtype == BIE_F16 || dtype == BIE_BF16 || dtype == BIE_F32, BIE_ERR_UNSUPPORTED,
+                "%s: dtype=%d is not supported (0=f16, 1=bf16, 2=f32)", fn, dtype);
+    BIE_REQUIRE(K > 0 && N > 0 && group_size > 0, BIE_ERR_INVALID_ARG, "%s: K=%d N=%d group_size=%d must be positive", fn, K, N, group_size);
+    BIE_REQUIRE(K % (32 / w_bit) == 0, BIE_ERR_INVALID_ARG, "%s: K=%d must be a multiple of %d for w_bit=%d", fn, K, 32 / w_bit, w_bit);
+    return BIE_OK;
+}
+
+extern "C" {
+
+int bie_version(void) { return BIE_VERSION; }
+const char* bie_last_error(void) { return bie::get_error(); }
+
+size_t bie_mpq_workspace_bytes(int M, int K, int N, int w_bit) {
+    if (M <= 0 || K <= 0 || N <= 0 || !(w_bit == 1 || w_bit == 2 || w_bit == 4 || w_bit == 8)) return 0;
+    size_t a = M <= 8 ? mpq_gemv_workspace_bytes(M, K, N, w_bit) : 0;
+    size_t b = mpq_gemm_workspace_bytes(M, K, N);
+    const int mc = M < GENERIC_M_CHUNK ? M : GENERIC_M_CHUNK;
+    size_t c = (size_t)cdiv(K, 512) * mc * N * sizeof(float);
+    size_t r = a > b ? a : b;
+    return r > c ? r : c;
+}
+
+int bie_mpq_forward(const void* x, const int32_t* qweight, const void* scales, const void* zeros,
+                    const int32_t* g_idx, const void* bias, void* y, void* workspace,
+                    size_t workspace_bytes, int M, int K, int N, int w_bit, int group_size, int asym,
+                    int dtype, void* stream) {
+    int rc = validate_mpq("bie_mpq_forward", K, N, w_bit, group_size, dtype);
+    if (rc) return rc;
+    BIE_REQUIRE(x && qweight && scales && zeros && y, BIE_ERR_INVALID_ARG, "bie_mpq_forward: NULL tensor pointer");
+    BIE_REQUIRE(M > 0, BIE_ERR_INVALID_ARG, "bie_mpq_forward: M=%d must be positive", M);
+    if (asym) BIE_REQUIRE(N % (32 / w_bit) == 0, BIE_ERR_INVALID_ARG, "bie_mpq_forward: asym needs N %% %d == 0", 32 / w_bit);
+    const size_t need = bie_mpq_workspace_bytes(M, K, N, w_bit);
+    BIE_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), BIE_ERR_WORKSPACE,
+                "bie_mpq_forward: workspace of %zu bytes required, got %zu", need, workspace_bytes);
+    hipStream_t st = as_stream(stream);
+    float* part = reinterpret_cast<float*>(workspace);
+    const bool has_gidx = g_idx != nullptr;
+    if (M <= 8 && mpq_gemv_fast_ok(M, K, N, w_bit, group_size, dtype, has_gidx))
+        return mpq_gemv_launch(x, qweight, scales, zeros, bias, y, part, M, K, N, w_bit, group_size, asym ? 1 : 0, dtype, nullptr, st);
+    if (mpq_gemm_ok(M, K, N, w_bit, group_size, dtype, has_gidx))
+        return mpq_gemm_launch(x, qweight, scales, zeros, bias, y, part, M, K, N, w_bit, group_size, asym ? 1 : 0, dtype, nullptr, st);
+    // generic path (explicit g_idx / odd shapes / fp32), GENERIC_M_CHUNK rows at a time
+    const size_t esz = dtype == BIE_F32 ? 4 : 2;
+    for (int m0 = 0; m0 < M; m0 += GENERIC_M_CHUNK) {
+        const int mc = (M - m0) < GENERIC_M_CHUNK ? (M - m0) : GENERIC_M_CHUNK;
+        rc = mpq_gemv_generic_launch((const char*)x + (size_t)m0 * K * esz, qweight, scales, zeros, g_idx, bias,
+                                     (char*)y + (size_t)m0 * N * esz, part, mc, K, N, w_bit, group_size, asym, dtype, st);
+        if (rc) return rc;
+    }
+    return BIE_OK;
+}
+
+int bie_mpq_dequant(const int32_t* qweight, const void* scales, const void* zeros, const int32_t* g_idx, void* out,
+                    int K, int N, int w_bit, int group_size, int asym, int dtype, void* stream) {
+    int rc = validate_mpq("bie_mpq_dequant", K, N, w_bit, group_size, dtype);
+    if (rc) return rc;
+    BIE_REQUIRE(qweight && scales && zeros && out, BIE_ERR_INVALID_ARG, "bie_mpq_dequant: NULL tensor pointer");
+    return mpq_dequant_launch(qweight, scales, zeros, g_idx, out, K, N, w_bit, group_size, asym, dtype, as_stream(stream));
+}
+
+int bie_mpq_pack(const void* weight, const void* scales, const void* zeros, const int32_t* g_idx, int32_t* out, int K,
+                 int N, int w_bit, int group_size, int asym, int dtype, void* stream) {
+    int rc = validate_mpq("bie_mpq_pack", K, N, w_bit, group_size, dtype);
+    if (rc) return rc;
+    BIE_REQUIRE(weight && scales && zeros && out, BIE_ERR_INVALID_ARG, "bie_mpq_pack: NULL tensor pointer");
+    return mpq_pack_launch(weight, scales, zeros, g_idx, out, K, N, w_bit, group_size, asym, dtype, as_stream(stream));
+}
+
+int bie_mpq_grad_input(const void* grad_y, const int32_t* qweight, const void* scales, const void* zeros,
+                       const int32_t* g_idx, void* grad_x, int M, int K, int N, int w_bit, int group_size, int asym,
+                       int dtype, void* stream) {
+    int rc = validate_mpq("bie_mpq_grad_input", K, N, w_bit, group_size, dtype);
+    if (rc) return rc;
+    BIE_REQUIRE(grad_y && qweight && scales && zeros && grad_x && M > 0, BIE_ERR_INVALID_ARG, "bie_mpq_grad_input: bad argument");
+    return mpq_grad_input_launch(grad_y, qweight, scales, zeros, g_idx, grad_x, M, K, N, w_bit, group_size, asym, dtype, as_stream(stream));
+}
+
+
+// ---------------------------------------------------------------------------------------------- MBWQ
+int bie_mbwq_rows(const int16_t* q_groups_host, int groups, int K, int* rows7_host) {
+    BIE_REQUIRE(q_groups_host && rows7_host && groups > 0 && K > 0, BIE_ERR_INVALID_ARG, "bie_mbwq_rows: bad argument");
+    int r[6] = {0, 0, 0, 0, 0, 0}, kp = 0, row = 0;
+    for (int i = 0; i < groups; i++) {
+        const int bits = (uint16_t)q_groups_host[2 * i];
+        int band;
+        switch (bits) {
+            case 8: band = 0; break;
+            case 6: band = 1; break;
+            case 5: band = 2; break;
+            case 4: band = 3; break;
+            case 3: band = 4; break;
+            case 2: band = 5; break;
+            default: set_error("bie_mbwq_rows: group %d has unsupported bit width %d", i, bits); return BIE_ERR_UNSUPPORTED;
+        }
+        kp |= 1 << (bits - 1);
+        int rows;
+        if (i < groups - 1) rows = ((uint16_t)q_groups_host[2 * i + 3] - (uint16_t)q_groups_host[2 * i + 1]) * 32 / bits;
+        else rows = K - row;
+        r[band] += rows;
+        row += rows;
+    }
+    for (int b = 1; b < 6; b++) r[b] += r[b - 1];
+    for (int b = 0; b < 6; b++) rows7_host[b] = r[b];
+    rows7_host[6] = kp;
+    return BIE_OK;
+}
+
+size_t bie_mbwq_workspace_bytes(int M, int K, int N) {
+    if (M <= 0 || K <= 0 || N <= 0) return 0;
+    return mbwq_workspace_bytes(M, K, N);
+}
+
+int bie_mbwq_q4_dequant(const int32_t* qweight, const void* scales, const void* zeros, const int16_t* q_perm, void* out, int K,
+                        int N, int bits, int group_size, void* stream) {
+    BIE_REQUIRE(qweight && scales && zeros && out, BIE_ERR_INVALID_ARG, "bie_mbwq_q4_dequant: NULL tensor pointer");
+    BIE_REQUIRE(bits == 2 || bits == 4, BIE_ERR_UNSUPPORTED, "bie_mbwq_q4_dequant: weight bit width %d has not been supported yet", bits);
+    BIE_REQUIRE(K > 0 && N > 0 && group_size > 0 && K % (32 / bits) == 0, BIE_ERR_INVALID_ARG, "bie_mbwq_q4_dequant: bad shape");
+    return mbwq_q4_dequant_launch(qweight, scales, zeros, q_perm, out, K, N, bits, group_size, as_stream(stream));
+}
+
+static int check_rows(const char* fn, const int* rows7, int K) {
+    BIE_REQUIRE(rows7, BIE_ERR_INVALID_ARG, "%s: rows table is NULL", fn);
+    int prev = 0;
+    for (int b = 0; b < 6; b++) {
+        BIE_REQUIRE(rows7[b] >= prev && rows7[b] % 32 == 0, BIE_ERR_UNSUPPORTED,
+                    "%s: band boundary rows[%d]=%d must be a non-decreasing multiple of 32", fn, b, rows7[b]);
+        prev = rows7[b];
+    }
+    BIE_REQUIRE(rows7[5] == K, BIE_ERR_INVALID_ARG, "%s: rows[5]=%d must equal K=%d", fn, rows7[5], K);
+    return BIE_OK;
+}
+
+int bie_mbwq_exl2_dequant(const int32_t* qweight, const void* scales, const void* zeros, const int16_t* q_perm,
+                          const int16_t* q_group_map, const int* rows7_host, void* out, int K, int N, int groups,
+                          void* stream) {
+    BIE_REQUIRE(qweight && scales && zeros && q_group_map && out && K > 0 && N > 0, BIE_ERR_INVALID_ARG, "bie_mbwq_exl2_dequant: bad argument");
+    int rc = check_rows("bie_mbwq_exl2_dequant", rows7_host, K);
+    if (rc) return rc;
+    return mbwq_exl2_dequant_launch(qweight, scales, zeros, q_perm, q_group_map, rows7_host, out, K, N, as_stream(stream));
+}
+
+int bie_mbwq_q4_forward(const void* x, const int32_t* qweight, const void* scales, const void* zeros, const int16_t* q_perm,
+                        void* y, void* workspace, size_t workspace_bytes, int M, int K, int N, int bits, int group_size,
+                        void* stream) {
+    BIE_REQUIRE(x && qweight && scales && zeros && y && M > 0 && K > 0 && N > 0 && group_size > 0, BIE_ERR_INVALID_ARG, "bie_mbwq_q4_forward: bad argument");
+    BIE_REQUIRE(bits == 2 || bits == 4, BIE_ERR_UNSUPPORTED, "bie_mbwq_q4_forward: weight bit width %d has not been supported yet", bits);
+    const size_t need = mbwq_workspace_bytes(M, K, N);
+    BIE_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), BIE_ERR_WORKSPACE, "bie_mbwq_q4_forward: workspace of %zu bytes required, got %zu", need, workspace_bytes);
+    return mbwq_q4_forward_launch(x, qweight, scales, zeros, q_perm, y, (float*)workspace, M, K, N, bits, group_size, as_stream(stream));
+}
+
+int bie_mbwq_exl2_forward(const void* x, const int32_t* qweight, const void* scales, const void* zeros, const int16_t* q_perm,
+                          const int16_t* q_group_map, const int* rows7_host, void* y, void* workspace, size_t workspace_bytes,
+                          int M, int K, int N, int groups, void* stream) {
+    BIE_REQUIRE(x && qweight && scales && zeros && q_group_map && y && M > 0 && K > 0 && N > 0, BIE_ERR_INVALID_ARG, "bie_mbwq_exl2_forward: bad argument");
+    int rc = check_rows("bie_mbwq_exl2_forward", rows7_host, K);
+    if (rc) return rc;
+    const size_t need = mbwq_workspace_bytes(M, K, N);
+    BIE_REQUIRE(workspace && workspace_bytes >= need, BIE_ERR_WORKSPACE, "bie_mbwq_exl2_forward: workspace of %zu bytes required, got %zu", need, workspace_bytes);
+    return mbwq_exl2_forward_launch(x, qweight, scales, zeros, q_perm, q_group_map, rows7_host, y, (float*)workspace, M, K, N, as_stream(stream));
+}
+
+// ---------------------------------------------------------------------------------------------- binary
+int bie_binary_pack_rows_u8(const void* a, uint8_t* out, long rows, long K, int dtype, void* stream) {
+    BIE_REQUIRE(a && out && rows > 0 && K > 0 && K % 8 == 0, BIE_ERR_INVALID_ARG, "bie_binary_pack_rows_u8: rows=%ld K=%ld (K %% 8 == 0 required)", rows, K);
+    BIE_REQUIRE(dtype >= 0 && dtype <= 3, BIE_ERR_UNSUPPORTED, "bie_binary_pack_rows_u8: dtype %d", dtype);
+    return pack_rows_launch(a, out, rows * (K / 8), dtype, as_stream(stream));
+}
+
+int bie_binary_pack_cols_u8(const void* w, uint8_t* out, long N, long K, int dtype, void* stream) {
+    BIE_REQUIRE(w && out && N > 0 && K > 0 && K % 8 == 0, BIE_ERR_INVALID_ARG, "bie_binary_pack_cols_u8: N=%ld K=%ld (K %% 8 == 0 required)", N, K);
+    BIE_REQUIRE(dtype >= 0 && dtype <= 3, BIE_ERR_UNSUPPORTED, "bie_binary_pack_cols_u8: dtype %d", dtype);
+    return pack_cols_launch(w, out, N, K, dtype, as_stream(stream));
+}
+
+int bie_binary_linear_forward(const uint8_t* xpacked, const uint8_t* wpacked, float* y, long M, long N, long K, int w_layout,
+                              float scale, void* stream) {
+    BIE_REQUIRE(xpacked && wpacked && y && M > 0 && N > 0 && K > 0 && K % 8 == 0, BIE_ERR_INVALID_ARG, "bie_binary_linear_forward: M=%ld N=%ld K=%ld (K %% 8 == 0 required)", M, N, K);
+    BIE_REQUIRE(w_layout == 0 || w_layout == 1, BIE_ERR_INVALID_ARG, "bie_binary_linear_forward: w_layout %d", w_layout);
+    return binary_linear_launch(xpacked, wpacked, y, M, N, K, w_layout, scale, as_stream(stream));
+}
+
+size_t bie_binary_conv2d_workspace_bytes(int B, int C, int H, int W, int OC, int ksize, int stride, int pad, int dilation) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || OC <= 0 || ksize <= 0 || stride <= 0 || dilation <= 0 || pad < 0) return 0;
+    return binary_conv_workspace_bytes(B, C, H, W, OC, ksize, stride, pad, dilation);
+}
+
+int bie_binary_conv2d_forward(const void* x, const uint8_t* wpacked, float* y, void* workspace, size_t workspace_bytes, int B,
+                              int C, int H, int W, int OC, int ksize, int stride, int pad, int dilation, float scale, int dtype,
+                              void* stream) {
+    BIE_REQUIRE(x && wpacked && y && workspace, BIE_ERR_INVALID_ARG, "bie_binary_conv2d_forward: NULL tensor pointer");
+    BIE_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && OC > 0 && ksize > 0 && stride > 0 && dilation > 0 && pad >= 0, BIE_ERR_INVALID_ARG, "bie_binary_conv2d_forward: bad geometry");
+    BIE_REQUIRE((C * ksize * ksize) % 8 == 0, BIE_ERR_UNSUPPORTED, "bie_binary_conv2d_forward: C*k*k=%d must be a multiple of 8", C * ksize * ksize);
+    BIE_REQUIRE(dtype >= 0 && dtype <= 2, BIE_ERR_UNSUPPORTED, "bie_binary_conv2d_forward: dtype %d", dtype);
+    const size_t need = binary_conv_workspace_bytes(B, C, H, W, OC, ksize, stride, pad, dilation);
+    BIE_REQUIRE(workspace_bytes >= need, BIE_ERR_WORKSPACE, "bie_binary_conv2d_forward: workspace of %zu bytes required, got %zu", need, workspace_bytes);
+    return binary_conv_launch(x, wpacked, y, workspace, B, C, H, W, OC, ksize, stride, pad, dilation, scale, dtype, as_stream(stream));
+}
+
+// ---------------------------------------------------------------------------------------------- functions
+int bie_pack_sign_u8(const void* a, uint8_t* out, long n_bytes, int dtype, void* stream) {
+    BIE_REQUIRE(a && out && n_bytes > 0, BIE_ERR_INVALID_ARG, "bie_pack_sign_u8: bad argument");
+    BIE_REQUIRE(dtype >= 0 && dtype <= 3, BIE_ERR_UNSUPPORTED, "bie_pack_sign_u8: dtype %d", dtype);
+    return pack_rows_launch(a, out, n_bytes, dtype, as_stream(stream));
+}
+int bie_unpack_u8_scaled(const uint8_t* in, const float* scale, float* out, long n_bytes, long packed_dim, void* stream) {
+    BIE_REQUIRE(in && scale && out && n_bytes > 0 && packed_dim > 0, BIE_ERR_INVALID_ARG, "bie_unpack_u8_scaled: bad argument");
+    return unpack_u8_scaled_launch(in, scale, out, n_bytes, packed_dim, as_stream(stream));
+}
+int bie_q4_pack(const int32_t* in, int8_t* out, long n_out, void* stream) {
+    BIE_REQUIRE(in && out && n_out > 0, BIE_ERR_INVALID_ARG, "bie_q4_pack: bad argument");
+    return q4_pack_launch(in, out, n_out, as_stream(stream));
+}
+int bie_q4_unpack(const int8_t* in, int32_t* out, long n_in, void* stream) {
+    BIE_REQUIRE(in && out && n_in > 0, BIE_ERR_INVALID_ARG, "bie_q4_unpack: bad argument");
+    return q4_unpack_launch(in, out, n_in, as_stream(stream));
+}
+int bie_q4_unpack_scale(const int8_t* in, float* out, long n_in, float scale, void* stream) {
+    BIE_REQUIRE(in && out && n_in > 0, BIE_ERR_INVALID_ARG, "bie_q4_unpack_scale: bad argument");
+    return q4_unpack_scale_launch(in, out, n_in, scale, as_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,288 @@
+// MBWQ (fp16 only): uniform 4/2-bit GPTQ-like weights and the mixed 8/6/5/4/3/2-bit "exl2" layout.
+//   * uniform: same packed layout as MPQ, W = fma(s, q, -z) with ONE rounding and an optional
+//     q_perm gather of x -> served by the MPQ GEMV / MFMA GEMM kernels in ZM_FUSED mode
+//     (replaces gemm_half_q4/q2_half_gptq_kernel, exl2/q_gemm_kernel_gptq.cuh:35-328, and
+//     reconstruct_q4/q2_gptq_kernel, mbwq_linear_cuda_kernel.cu:314-501);
+//   * exl2: K is ordered in bands 8,6,5,4,3,2 bit; inside a band 32 consecutive k of one column are a
+//     `bits`-word LSB-first bitstream down `bits` consecutive packed rows (QMODE=0 dequant primitives,
+//     exl2/quant/qdq_{2,3,4,5,6,8}.cuh).  Replaces reconstruct_exl2_kernel
+//     (mbwq_linear_cuda_kernel.cu:92-308) and gemm_half_q_half_kernel (exl2/q_gemm_kernel.cuh:90-549).
+//     One lane owns one column and walks 32-k chunks: `bits` coalesced dword loads per chunk, bit
+//     extraction with compile-time shifts (v_alignbit for the straddling fields), v_fma_f16 dequant
+//     (exactly the reference's __hfma2), fp32 accumulation.
+#include "bie_common.h"
+
+#pragma clang fp contract(off)
+
+namespace bie {
+
+int mpq_gemv_launch(const void* x, const int32_t* qw, const void* scales, const void* zeros, const void* bias, void* y,
+                    float* part, int M, int K, int N, int w_bit, int group_size, int zm, int dtype, const uint16_t* perm,
+                    hipStream_t st);
+bool mpq_gemv_fast_ok(int M, int K, int N, int w_bit, int group_size, int dtype, bool has_gidx);
+size_t mpq_gemv_workspace_bytes(int M, int K, int N, int w_bit);
+int mpq_gemm_launch(const void* x, const int32_t* qw, const void* scales, const void* zeros, const void* bias, void* y,
+                    float* part, int M, int K, int N, int w_bit, int group_size, int zm, int dtype, const uint16_t* perm,
+                    hipStream_t st);
+bool mpq_gemm_ok(int M, int K, int N, int w_bit, int group_size, int dtype, bool has_gidx);
+size_t mpq_gemm_workspace_bytes(int M, int K, int N);
+
+struct Exl2Rows {
+    int r[6];  // cumulative k boundaries of the 8,6,5,4,3,2-bit bands
+};
+
+__host__ __device__ __forceinline__ int exl2_bits_of_band(int b) {
+    return b == 0 ? 8 : (b == 1 ? 6 : (b == 2 ? 5 : (b == 3 ? 4 : (b == 4 ? 3 : 2))));
+}
+
+// band index and first packed row of the 32-chunk starting at k (k % 32 == 0)
+__device__ __forceinline__ void exl2_locate(const Exl2Rows& rows, int k, int& bits, int& prow) {
+    int row = 0, prev = 0, band = 5;
+    bool found = false;
+#pragma unroll
+    for (int b = 0; b < 6; b++) {
+        const int hi = rows.r[b];
+        const int bb = exl2_bits_of_band(b);
+        if (!found) {
+            if (k < hi) {
+                band = b;
+                row += ((k - prev) >> 5) * bb;
+                found = true;
+            } else {
+                row += ((hi - prev) >> 5) * bb;
+                prev = hi;
+            }
+        }
+    }
+    bits = exl2_bits_of_band(band);
+    prow = row;
+}
+
+// 32 values of one column from BITS consecutive words (LSB-first stream)
+template <int BITS>
+__device__ __forceinline__ void exl2_extract32(const uint32_t (&w)[8], uint32_t (&q)[32]) {
+    constexpr uint32_t mask = (1u << BITS) - 1u;
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int bitpos = j * BITS;
+        const int wi = bitpos >> 5, sh = bitpos & 31;
+        uint32_t v = w[wi] >> sh;
+        if (sh + BITS > 32) v |= w[wi + 1] << (32 - sh);
+        q[j] = v & mask;
+    }
+}
+
+template <int BITS>
+__device__ __forceinline__ void exl2_load_chunk(const uint32_t* __restrict__ qw, long N, int prow, int n, uint32_t (&w)[8]) {
+#pragma unroll
+    for (int i = 0; i < BITS; i++) w[i] = qw[(long)(prow + i) * N + n];
+}
+
+__device__ __forceinline__ uint16_t exl2_dq(uint32_t q, half_t s, half_t z) {
+    const half_t r = __builtin_fmaf16((half_t)(float)q, s, -z);  // v_fma_f16, one rounding == __hfma2
+    return __builtin_bit_cast(uint16_t, r);
+}
+
+// ---- dense reconstruction: out[q_perm[k]][n] ------------------------------------------------------------
+__global__ __launch_bounds__(256) void exl2_dequant_kernel(const uint32_t* __restrict__ qw, const uint16_t* __restrict__ scales,
+                                                           const uint16_t* __restrict__ zeros, const uint16_t* __restrict__ perm,
+                                                           const uint16_t* __restrict__ gmap, uint16_t* __restrict__ out,
+                                                           Exl2Rows rows, int K, int N) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int k0 = blockIdx.y * 32;
+    if (n >= N || k0 >= K) return;
+    int bits, prow;
+    exl2_locate(rows, k0, bits, prow);
+    uint32_t w[8], q[32];
+    switch (bits) {
+        case 8: exl2_load_chunk<8>(qw, N, prow, n, w); exl2_extract32<8>(w, q); break;
+        case 6: exl2_load_chunk<6>(qw, N, prow, n, w); exl2_extract32<6>(w, q); break;
+        case 5: exl2_load_chunk<5>(qw, N, prow, n, w); exl2_extract32<5>(w, q); break;
+        case 4: exl2_load_chunk<4>(qw, N, prow, n, w); exl2_extract32<4>(w, q); break;
+        case 3: exl2_load_chunk<3>(qw, N, prow, n, w); exl2_extract32<3>(w, q); break;
+        default: exl2_load_chunk<2>(qw, N, prow, n, w); exl2_extract32<2>(w, q); break;
+    }
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        const int g = gmap[2 * (k0 + 16 * half)];
+        const half_t s = __builtin_bit_cast(half_t, scales[(long)g * N + n]);
+        const half_t z = __builtin_bit_cast(half_t, zeros[(long)g * N + n]);
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int k = k0 + 16 * half + j;
+            const int orow = perm ? (int)perm[k] : k;
+            out[(long)orow * N + n] = exl2_dq(q[16 * half + j], s, z);
+        }
+    }
+}
+
+// uniform q4/q2: out[q_perm ? q_perm[k] : k][n] = fma(s, q, -z)
+__global__ __launch_bounds__(256) void mbwq_q4_dequant_kernel(const uint32_t* __restrict__ qw, const uint16_t* __restrict__ scales,
+                                                              const uint16_t* __restrict__ zeros, const uint16_t* __restrict__ perm,
+                                                              uint16_t* __restrict__ out, int K, int N, int bits, int group_size) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y;
+    if (n >= N) return;
+    const int nb = 32 / bits;
+    const uint32_t mask = (1u << bits) - 1u;
+    const uint32_t word = qw[(long)r * N + n];
+    for (int j = 0; j < nb; j++) {
+        const int k = r * nb + j;
+        if (k >= K) break;
+        const int g = k / group_size;
+        const half_t s = __builtin_bit_cast(half_t, scales[(long)g * N + n]);
+        const half_t z = __builtin_bit_cast(half_t, zeros[(long)g * N + n]);
+        const int orow = perm ? (int)perm[k] : k;
+        out[(long)orow * N + n] = exl2_dq((word >> (j * bits)) & mask, s, z);
+    }
+}
+
+// ---- exl2 GEMV (M <= 8 per launch): partial[slab][m][n] ---------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(256) void exl2_gemv_kernel(const uint16_t* __restrict__ x, const uint32_t* __restrict__ qw,
+                                                        const uint16_t* __restrict__ scales, const uint16_t* __restrict__ zeros,
+                                                        const uint16_t* __restrict__ perm, const uint16_t* __restrict__ gmap,
+                                                        float* __restrict__ part, Exl2Rows rows, int M, int K, int N,
+                                                        int chunks_per_slab) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [MT][chunks_per_slab*32] fp32
+    const int tid = threadIdx.x;
+    const int n = blockIdx.x * 256 + tid;
+    const int c_begin = blockIdx.y * chunks_per_slab;
+    int c_end = c_begin + chunks_per_slab;
+    const int C = K >> 5;
+    if (c_end > C) c_end = C;
+    const int slab_k = chunks_per_slab * 32;
+    for (int idx = tid; idx < MT * slab_k; idx += 256) {
+        const int m = idx / slab_k, kk = idx - m * slab_k;
+        const int k = c_begin * 32 + kk;
+        float v = 0.f;
+        if (m < M && k < K) v = f16_bits_to_f32(x[(long)m * K + (perm ? (int)perm[k] : k)]);
+        xs[idx] = v;
+    }
+    __syncthreads();
+    float acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; m++) acc[m] = 0.f;
+    if (n < N) {
+        for (int c = c_begin; c < c_end; c++) {
+            const int k0 = c * 32;
+            int bits, prow;
+            exl2_locate(rows, k0, bits, prow);
+            uint32_t w[8], q[32];
+            switch (bits) {
+                case 8: exl2_load_chunk<8>(qw, N, prow, n, w); exl2_extract32<8>(w, q); break;
+                case 6: exl2_load_chunk<6>(qw, N, prow, n, w); exl2_extract32<6>(w, q); break;
+                case 5: exl2_load_chunk<5>(qw, N, prow, n, w); exl2_extract32<5>(w, q); break;
+                case 4: exl2_load_chunk<4>(qw, N, prow, n, w); exl2_extract32<4>(w, q); break;
+                case 3: exl2_load_chunk<3>(qw, N, prow, n, w); exl2_extract32<3>(w, q); break;
+                default: exl2_load_chunk<2>(qw, N, prow, n, w); exl2_extract32<2>(w, q); break;
+            }
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const int g = gmap[2 * (k0 + 16 * half)];
+                const half_t s = __builtin_bit_cast(half_t, scales[(long)g * N + n]);
+                const half_t z = __builtin_bit_cast(half_t, zeros[(long)g * N + n]);
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const float wv = f16_bits_to_f32(exl2_dq(q[16 * half + j], s, z));
+                    const int kk = (c - c_begin) * 32 + 16 * half + j;
+#pragma unroll
+                    for (int m = 0; m < MT; m++) acc[m] = __builtin_fmaf(wv, xs[m * slab_k + kk], acc[m]);
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+            if (m < M) part[((long)blockIdx.y * M + m) * N + n] = acc[m];
+    }
+}
+
+static int exl2_slabs(int K, int N) {
+    const int C = K / 32;
+    int S = cdiv(1024, cdiv(N, 256));
+    if (S > C) S = C;
+    if (S < 1) S = 1;
+    int cps = cdiv(C, S);
+    if (cps > 64) cps = 64;  // LDS: 8 rows x 64 chunks x 32 x 4 B = 64 KiB
+    return cps;
+}
+
+size_t mbwq_workspace_bytes(int M, int K, int N) {
+    size_t a = 0;
+    for (int w : {2, 4}) {
+        size_t t = M <= 8 ? mpq_gemv_workspace_bytes(M, K, N, w) : 0;
+        if (t > a) a = t;
+    }
+    size_t b = mpq_gemm_workspace_bytes(M, K, N);
+    const int cps = exl2_slabs(K, N);
+    const int S = cdiv(K / 32, cps);
+    const int mc = M < 8 ? M : 8;
+    size_t c = (size_t)S * mc * N * sizeof(float);
+    size_t r = a > b ? a : b;
+    return r > c ? r : c;
+}
+
+int mbwq_q4_dequant_launch(const int32_t* qw, const void* scales, const void* zeros, const int16_t* perm, void* out, int K,
+                           int N, int bits, int group_size, hipStream_t st) {
+    dim3 grid(cdiv(N, 256), cdiv(K, 32 / bits));
+    hipLaunchKernelGGL(mbwq_q4_dequant_kernel, grid, dim3(256), 0, st, (const uint32_t*)qw, (const uint16_t*)scales,
+                       (const uint16_t*)zeros, (const uint16_t*)perm, (uint16_t*)out, K, N, bits, group_size);
+    return check_launch("mbwq_q4_dequant_kernel");
+}
+
+int mbwq_exl2_dequant_launch(const int32_t* qw, const void* scales, const void* zeros, const int16_t* perm,
+                             const int16_t* gmap, const int* rows7, void* out, int K, int N, hipStream_t st) {
+    Exl2Rows rows;
+    for (int i = 0; i < 6; i++) rows.r[i] = rows7[i];
+    dim3 grid(cdiv(N, 256), K / 32);
+    hipLaunchKernelGGL(exl2_dequant_kernel, grid, dim3(256), 0, st, (const uint32_t*)qw, (const uint16_t*)scales,
+                       (const uint16_t*)zeros, (const uint16_t*)perm, (const uint16_t*)gmap, (uint16_t*)out, rows, K, N);
+    return check_launch("exl2_dequant_kernel");
+}
+
+int mbwq_q4_forward_launch(const void* x, const int32_t* qw, const void* scales, const void* zeros, const int16_t* perm,
+                           void* y, float* part, int M, int K, int N, int bits, int group_size, hipStream_t st) {
+    const uint16_t* p = (const uint16_t*)perm;
+    if (M <= 8 && mpq_gemv_fast_ok(M, K, N, bits, group_size, BIE_F16, false))
+        return mpq_gemv_launch(x, qw, scales, zeros, nullptr, y, part, M, K, N, bits, group_size, 2, BIE_F16, p, st);
+    if (mpq_gemm_ok(M, K, N, bits, group_size, BIE_F16, false))
+        return mpq_gemm_launch(x, qw, scales, zeros, nullptr, y, part, M, K, N, bits, group_size, 2, BIE_F16, p, st);
+    set_error("bie_mbwq_q4_forward: unsupported shape M=%d K=%d N=%d bits=%d group_size=%d (need K %% 64 == 0, N %% 4 == 0)", M,
+              K, N, bits, group_size);
+    return BIE_ERR_UNSUPPORTED;
+}
+
+int mbwq_exl2_forward_launch(const void* x, const int32_t* qw, const void* scales, const void* zeros, const int16_t* perm,
+                             const int16_t* gmap, const int* rows7, void* y, float* part, int M, int K, int N,
+                             hipStream_t st) {
+    Exl2Rows rows;
+    for (int i = 0; i < 6; i++) rows.r[i] = rows7[i];
+    const int cps = exl2_slabs(K, N);
+    const int S = cdiv(K / 32, cps);
+    dim3 grid(cdiv(N, 256), S);
+    for (int m0 = 0; m0 < M; m0 += 8) {
+        const int mc = (M - m0) < 8 ? (M - m0) : 8;
+        const uint16_t* xm = (const uint16_t*)x + (size_t)m0 * K;
+        const int MT = mc <= 1 ? 1 : (mc <= 2 ? 2 : (mc <= 4 ? 4 : 8));
+        const size_t lds = (size_t)MT * cps * 32 * sizeof(float);
+#define L(MTV)                                                                                                     \
+    hipLaunchKernelGGL(exl2_gemv_kernel<MTV>, grid, dim3(256), lds, st, xm, (const uint32_t*)qw, (const uint16_t*)scales, \
+                       (const uint16_t*)zeros, (const uint16_t*)perm, (const uint16_t*)gmap, part, rows, mc, K, N, cps)
+        switch (MT) {
+            case 1: L(1); break;
+            case 2: L(2); break;
+            case 4: L(4); break;
+            default: L(8); break;
+        }
+#undef L
+        int rc = check_launch("exl2_gemv_kernel");
+        if (rc) return rc;
+        rc = launch_splitk_finalize(part, nullptr, (uint16_t*)y + (size_t)m0 * N, S, mc, N, BIE_F16, st);
+        if (rc) return rc;
+    }
+    return BIE_OK;
+}
+
+}  // namespace bie

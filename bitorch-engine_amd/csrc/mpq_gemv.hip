@@ -1,0 +1,324 @@
+// W{1,2,4,8}A16 decode GEMV / skinny GEMM (M <= 8) for gfx950 -- the bandwidth-bound half of
+// bie_mpq_forward.  Replaces quant_mm_kernel[_asym] (reference
+// layers/qlinear/nbit/cuda/mpq_linear_cuda_kernel.cu:67-451).
+//
+// Design (HBM-bound: every packed word is read exactly once, coalesced, 16 B per lane):
+//   * a wave reads 1 KiB-contiguous pieces of a packed row: lane l owns columns 4l..4l+3 of a
+//     256-column tile (one `global_load_dwordx4`, non-temporal: the weights are streamed once);
+//   * a 256-thread block = 4 waves owns (256 columns) x (one K slab); the waves split the slab's
+//     packed rows and keep U row-loads in flight per lane before the first use;
+//   * dequantisation happens in registers in 16-bit pairs (mpq_dequant.cuh) and feeds
+//     v_dot2_f32_{f16,bf16} with fp32 accumulators -- the activations are wave-uniform and are
+//     read as LDS broadcasts of the (pre-permuted) x slab;
+//   * split-K over blocks (grid.y) fills the 256 CUs for small N; partial sums go to an fp32
+//     workspace and are reduced in fixed order by splitk_finalize (deterministic, no atomics).
+#include "mpq_dequant.cuh"
+
+#pragma clang fp contract(off)
+
+namespace bie {
+
+constexpr int GEMV_THREADS = 256;
+constexpr int GEMV_COLS = 256;  // columns per block: 64 lanes x 4
+
+template <int DT, int WBIT, int MT, int ZM, int U>
+__global__ __launch_bounds__(GEMV_THREADS) void mpq_gemv_kernel(
+    const uint16_t* __restrict__ x, const uint32_t* __restrict__ qw, const uint16_t* __restrict__ scales,
+    const void* __restrict__ zeros, const uint16_t* __restrict__ bias, const uint16_t* __restrict__ perm,
+    float* __restrict__ part, uint16_t* __restrict__ y, int M, int K, int N, int group_size, int rows_per_slab, int R,
+    int S) {
+    constexpr int NB = 32 / WBIT;
+    constexpr int NP = NB / 2;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * GEMV_COLS + lane * 4;
+    const bool n_ok = n0 < N;  // N % 4 == 0 is guaranteed by the launcher
+    const int slab = blockIdx.y;
+    const int r_begin = slab * rows_per_slab;
+    const int slab_k = rows_per_slab * NB;
+
+    // ---- stage the x slab into LDS in pair order (16-bit elements) -----------------------------
+    {
+        uint16_t* xs16 = reinterpret_cast<uint16_t*>(smem);
+        const int total = MT * slab_k;
+        for (int idx = tid; idx < total; idx += GEMV_THREADS) {
+            const int m = idx / slab_k;
+            const int kk = idx - m * slab_k;
+            const int row = kk / NB, p = kk % NB;
+            const int k = (r_begin + row) * NB + pair_src_k<DT, WBIT>(p);
+            uint16_t v = 0;
+            if (m < M && k < K) v = x[(long)m * K + (perm ? (int)perm[k] : k)];
+            xs16[idx] = v;
+        }
+    }
+    __syncthreads();
+
+    float acc[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) acc[m][c] = 0.0f;
+
+    const int rpw = rows_per_slab / 4;
+    const int rw_begin = r_begin + wave * rpw;
+    int rw_end = rw_begin + rpw;
+    if (rw_end > R) rw_end = R;
+
+    if (n_ok) {
+        ColParams<DT, ZM> cp[4];
+        int g_prev = -1;
+        const int zero_width = N / NB;
+        for (int r = rw_begin; r < rw_end; r += U) {
+            uint4_t wq[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (r + u < rw_end) {
+                    const uint4_t* p = reinterpret_cast<const uint4_t*>(qw + (long)(r + u) * N + n0);
+                    wq[u] = __builtin_nontemporal_load(p);
+                }
+            }
+            const int g = (r * NB) / group_size;
+            if (g != g_prev) {
+                g_prev = g;
+                const uint2_t sv = *reinterpret_cast<const uint2_t*>(scales + (long)g * N + n0);
+                const uint32_t sb[4] = {sv.x & 0xffffu, sv.x >> 16, sv.y & 0xffffu, sv.y >> 16};
+                if constexpr (ZM == ZM_ASYM) {
+                    const uint32_t zw = reinterpret_cast<const uint32_t*>(zeros)[(long)g * zero_width + n0 / NB];
+                    constexpr uint32_t M1 = (WBIT == 32) ? 0xffffffffu : ((1u << WBIT) - 1u);
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const uint32_t zq1 = ((zw >> (((n0 % NB) + c) * WBIT)) & M1) + 1u;
+                        cp[c] = make_col_params<DT, WBIT, ZM>(sb[c], zq1);
+                    }
+                } else {
+                    const uint2_t zv = *reinterpret_cast<const uint2_t*>(reinterpret_cast<const uint16_t*>(zeros) + (long)g * N + n0);
+                    const uint32_t zb[4] = {zv.x & 0xffffu, zv.x >> 16, zv.y & 0xffffu, zv.y >> 16};
+#pragma unroll
+                    for (int c = 0; c < 4; c++) cp[c] = make_col_params<DT, WBIT, ZM>(sb[c], zb[c]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (r + u < rw_end) {
+                    const int row_local = r + u - r_begin;
+                    uint32_t xp[MT][NP];
+#pragma unroll
+                    for (int m = 0; m < MT; m++) {
+                        const uint32_t* src = smem + ((m * slab_k) >> 1) + row_local * NP;
+#pragma unroll
+                        for (int i = 0; i < NP; i++) xp[m][i] = src[i];
+                    }
+                    const uint32_t words[4] = {wq[u].x, wq[u].y, wq[u].z, wq[u].w};
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        uint32_t wp[NP];
+                        dequant_word<DT, WBIT, ZM>(words[c], cp[c], wp);
+#pragma unroll
+                        for (int i = 0; i < NP; i++)
+#pragma unroll
+                            for (int m = 0; m < MT; m++) acc[m][c] = dot2_acc<DT>(wp[i], xp[m][i], acc[m][c]);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- reduce the 4 waves through LDS, fixed order ----------------------------------------------
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+        float4_t v = {acc[m][0], acc[m][1], acc[m][2], acc[m][3]};
+        *reinterpret_cast<float4_t*>(red + (wave * MT + m) * GEMV_COLS + lane * 4) = v;
+    }
+    __syncthreads();
+    const int n = blockIdx.x * GEMV_COLS + tid;
+    if (n < N) {
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            if (m < M) {
+                float v = red[(0 * MT + m) * GEMV_COLS + tid];
+                v += red[(1 * MT + m) * GEMV_COLS + tid];
+                v += red[(2 * MT + m) * GEMV_COLS + tid];
+                v += red[(3 * MT + m) * GEMV_COLS + tid];
+                if (S == 1) {
+                    float o = dt_traits<DT>::round(v);
+                    if (bias) o = o + dt_traits<DT>::load(bias, n);
+                    dt_traits<DT>::store(y, (long)m * N + n, o);
+                } else {
+                    part[((long)slab * M + m) * N + n] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---- generic fallback: any N, any group size, explicit g_idx (act-order), fp32 too ---------------
+// One column per lane, one slab of k per block.y, scalar dequant.  Correctness path, not a fast path.
+template <int DT>
+__global__ __launch_bounds__(256) void mpq_gemv_generic_kernel(
+    const void* __restrict__ x, const uint32_t* __restrict__ qw, const void* __restrict__ scales,
+    const void* __restrict__ zeros, const int32_t* __restrict__ g_idx, float* __restrict__ part, int M, int K,
+    int N, int w_bit, int group_size, int asym, int k_per_slab) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int m = blockIdx.z;
+    const int k_begin = blockIdx.y * k_per_slab;
+    int k_end = k_begin + k_per_slab;
+    if (k_end > K) k_end = K;
+    if (n >= N) return;
+    const int nb = 32 / w_bit;
+    const uint32_t mask = (w_bit == 32) ? 0xffffffffu : ((1u << w_bit) - 1u);
+    const int zero_width = N / nb;
+    float acc = 0.0f;
+    for (int k = k_begin; k < k_end; k++) {
+        const int g = g_idx ? g_idx[k] : (k / group_size);
+        const uint32_t word = qw[(long)(k / nb) * N + n];
+        const uint32_t q = (word >> ((k % nb) * w_bit)) & mask;
+        const float s = dt_traits<DT>::load(scales, (long)g * N + n);
+        float w;
+        if (asym) {
+            const uint32_t zw = reinterpret_cast<const uint32_t*>(zeros)[(long)g * zero_width + n / nb];
+            const int zq1 = (int)((zw >> ((n % nb) * w_bit)) & mask) + 1;
+            w = dequant_scalar_asym<DT>(q, s, zq1);
+        } else {
+            w = dequant_scalar_sym<DT>(q, s, dt_traits<DT>::load(zeros, (long)g * N + n));
+        }
+        acc = __builtin_fmaf(w, dt_traits<DT>::load(x, (long)m * K + k), acc);
+    }
+    part[((long)blockIdx.y * M + m) * N + n] = acc;
+}
+
+// ---- launchers -------------------------------------------------------------------------------------
+struct GemvPlan {
+    int U, rows_per_slab, S;
+};
+
+// rows_per_slab is a multiple of 32 (4 waves x 8 rows) so that it does not depend on the group size;
+// S (and with it the workspace size) is a function of (K, N, w_bit, MT) only.
+static GemvPlan plan_gemv(int K, int N, int w_bit, int group_size, int MT) {
+    const int NB = 32 / w_bit;
+    const int R = K / NB;  // packed rows
+    const int rows_per_group = (group_size > K ? K : group_size) / NB;
+    int U = 8;
+    while (U > 1 && (rows_per_group % U) != 0) U >>= 1;
+    const int unit = 32;
+    const int tiles_n = cdiv(N, GEMV_COLS);
+    int S = cdiv(1024, tiles_n);  // aim at ~4 blocks per CU
+    int max_rows = (32768 / (2 * MT)) / NB;  // x slab <= 32 KiB of LDS
+    max_rows = (max_rows / unit) * unit;
+    int rows = cdiv(cdiv(R, S), unit) * unit;
+    if (rows < unit) rows = unit;
+    if (rows > max_rows) rows = max_rows;
+    S = cdiv(R, rows);
+    return GemvPlan{U, rows, S};
+}
+
+template <int DT, int WBIT, int MT, int ZM>
+static int launch_gemv_u(const GemvPlan& pl, const void* x, const int32_t* qw, const void* scales, const void* zeros,
+                         const void* bias, const uint16_t* perm, float* part, void* y, int M, int K, int N, int group_size, hipStream_t st) {
+    constexpr int NB = 32 / WBIT;
+    const int R = K / NB;
+    dim3 grid(cdiv(N, GEMV_COLS), pl.S);
+    size_t lds = (size_t)MT * pl.rows_per_slab * NB * 2;
+    const size_t red = (size_t)4 * MT * GEMV_COLS * sizeof(float);
+    if (lds < red) lds = red;
+#define BIE_GEMV_LAUNCH(UU)                                                                                      \
+    hipLaunchKernelGGL((mpq_gemv_kernel<DT, WBIT, MT, ZM, UU>), grid, dim3(GEMV_THREADS), lds, st,              \
+                       (const uint16_t*)x, (const uint32_t*)qw, (const uint16_t*)scales, zeros, (const uint16_t*)bias, perm, \
+                       part, (uint16_t*)y, M, K, N, group_size, pl.rows_per_slab, R, pl.S)
+    switch (pl.U) {
+        case 8: BIE_GEMV_LAUNCH(8); break;
+        case 4: BIE_GEMV_LAUNCH(4); break;
+        case 2: BIE_GEMV_LAUNCH(2); break;
+        default: BIE_GEMV_LAUNCH(1); break;
+    }
+#undef BIE_GEMV_LAUNCH
+    return check_launch("mpq_gemv_kernel");
+}
+
+template <int DT, int WBIT, int ZM>
+static int launch_gemv_m(const GemvPlan& pl, int MT, const void* x, const int32_t* qw, const void* scales,
+                         const void* zeros, const void* bias, const uint16_t* perm, float* part, void* y, int M, int K, int N, int group_size,
+                         hipStream_t st) {
+    switch (MT) {
+        case 1: return launch_gemv_u<DT, WBIT, 1, ZM>(pl, x, qw, scales, zeros, bias, perm, part, y, M, K, N, group_size, st);
+        case 2: return launch_gemv_u<DT, WBIT, 2, ZM>(pl, x, qw, scales, zeros, bias, perm, part, y, M, K, N, group_size, st);
+        case 4: return launch_gemv_u<DT, WBIT, 4, ZM>(pl, x, qw, scales, zeros, bias, perm, part, y, M, K, N, group_size, st);
+        default: return launch_gemv_u<DT, WBIT, 8, ZM>(pl, x, qw, scales, zeros, bias, perm, part, y, M, K, N, group_size, st);
+    }
+}
+
+template <int DT, int WBIT>
+static int launch_gemv_a(const GemvPlan& pl, int MT, int zm, const void* x, const int32_t* qw, const void* scales,
+                         const void* zeros, const void* bias, const uint16_t* perm, float* part, void* y, int M, int K, int N, int group_size,
+                         hipStream_t st) {
+    if (zm == ZM_ASYM) return launch_gemv_m<DT, WBIT, ZM_ASYM>(pl, MT, x, qw, scales, zeros, bias, perm, part, y, M, K, N, group_size, st);
+    if (zm == ZM_FUSED) return launch_gemv_m<DT, WBIT, ZM_FUSED>(pl, MT, x, qw, scales, zeros, bias, perm, part, y, M, K, N, group_size, st);
+    return launch_gemv_m<DT, WBIT, ZM_SYM>(pl, MT, x, qw, scales, zeros, bias, perm, part, y, M, K, N, group_size, st);
+}
+
+template <int DT>
+static int launch_gemv_w(const GemvPlan& pl, int MT, int w_bit, int zm, const void* x, const int32_t* qw,
+                         const void* scales, const void* zeros, const void* bias, const uint16_t* perm, float* part, void* y, int M, int K,
+                         int N, int group_size, hipStream_t st) {
+    switch (w_bit) {
+        case 1: return launch_gemv_a<DT, 1>(pl, MT, zm, x, qw, scales, zeros, bias, perm, part, y, M, K, N, group_size, st);
+        case 2: return launch_gemv_a<DT, 2>(pl, MT, zm, x, qw, scales, zeros, bias, perm, part, y, M, K, N, group_size, st);
+        case 4: return launch_gemv_a<DT, 4>(pl, MT, zm, x, qw, scales, zeros, bias, perm, part, y, M, K, N, group_size, st);
+        default: return launch_gemv_a<DT, 8>(pl, MT, zm, x, qw, scales, zeros, bias, perm, part, y, M, K, N, group_size, st);
+    }
+}
+
+// Fast path eligibility: fp16/bf16, implicit groups, group rows align with packed rows, N % 4 == 0.
+bool mpq_gemv_fast_ok(int M, int K, int N, int w_bit, int group_size, int dtype, bool has_gidx) {
+    if (dtype != BIE_F16 && dtype != BIE_BF16) return false;
+    if (has_gidx) return false;
+    if (M > 8) return false;
+    const int NB = 32 / w_bit;
+    const int gs = group_size > K ? K : group_size;
+    if (K % NB || gs % NB || (N & 3)) return false;
+    return true;
+}
+
+size_t mpq_gemv_workspace_bytes(int M, int K, int N, int w_bit) {
+    const int MT = M <= 1 ? 1 : (M <= 2 ? 2 : (M <= 4 ? 4 : 8));
+    const GemvPlan pl = plan_gemv(K, N, w_bit, K, MT);
+    const size_t fast = pl.S > 1 ? (size_t)pl.S * M * N * sizeof(float) : 0;
+    const size_t generic = (size_t)cdiv(K, 512) * M * N * sizeof(float);
+    return fast > generic ? fast : generic;
+}
+
+int mpq_gemv_launch(const void* x, const int32_t* qw, const void* scales, const void* zeros, const void* bias, void* y,
+                    float* part, int M, int K, int N, int w_bit, int group_size, int zm, int dtype, const uint16_t* perm,
+                    hipStream_t st) {
+    const int MT = M <= 1 ? 1 : (M <= 2 ? 2 : (M <= 4 ? 4 : 8));
+    const GemvPlan pl = plan_gemv(K, N, w_bit, group_size, MT);
+    int rc;
+    if (dtype == BIE_F16)
+        rc = launch_gemv_w<BIE_F16>(pl, MT, w_bit, zm, x, qw, scales, zeros, pl.S == 1 ? bias : nullptr, perm, part, y, M, K, N, group_size, st);
+    else
+        rc = launch_gemv_w<BIE_BF16>(pl, MT, w_bit, zm, x, qw, scales, zeros, pl.S == 1 ? bias : nullptr, perm, part, y, M, K, N, group_size, st);
+    if (rc) return rc;
+    if (pl.S > 1) return launch_splitk_finalize(part, bias, y, pl.S, M, N, dtype, st);
+    return BIE_OK;
+}
+
+int mpq_gemv_generic_launch(const void* x, const int32_t* qw, const void* scales, const void* zeros, const int32_t* g_idx,
+                            const void* bias, void* y, float* part, int M, int K, int N, int w_bit, int group_size,
+                            int asym, int dtype, hipStream_t st) {
+    const int k_per_slab = 512;
+    const int S = cdiv(K, k_per_slab);
+    dim3 grid(cdiv(N, 256), S, M);
+    if (dtype == BIE_F16)
+        hipLaunchKernelGGL(mpq_gemv_generic_kernel<BIE_F16>, grid, dim3(256), 0, st, x, (const uint32_t*)qw, scales, zeros, g_idx, part, M, K, N, w_bit, group_size, asym, k_per_slab);
+    else if (dtype == BIE_BF16)
+        hipLaunchKernelGGL(mpq_gemv_generic_kernel<BIE_BF16>, grid, dim3(256), 0, st, x, (const uint32_t*)qw, scales, zeros, g_idx, part, M, K, N, w_bit, group_size, asym, k_per_slab);
+    else
+        hipLaunchKernelGGL(mpq_gemv_generic_kernel<BIE_F32>, grid, dim3(256), 0, st, x, (const uint32_t*)qw, scales, zeros, g_idx, part, M, K, N, w_bit, group_size, asym, k_per_slab);
+    int rc = check_launch("mpq_gemv_generic_kernel");
+    if (rc) return rc;
+    return launch_splitk_finalize(part, bias, y, S, M, N, dtype, st);
+}
+
+}  // namespace bie

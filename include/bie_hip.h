@@ -1,0 +1,180 @@
+/*
+ * bie_hip.h -- C ABI of libbie_hip.so: the MI355X (gfx950) low-bit Q-Linear / Q-Conv engine.
+ *
+ * This is the drop-in boundary for the hot path of GreenBitAI/bitorch-engine: every entry point
+ * below replaces one function of the reference's pybind11 extension modules (cited per function,
+ * paths relative to the reference tree).  Rules of the boundary:
+ *   - extern "C", plain device pointers + sizes + enums; no torch / HIP types in signatures
+ *     (`stream` is a hipStream_t passed as void*; NULL = the default stream);
+ *   - the CALLER allocates every output and scratch buffer (torch.empty on the host side);
+ *   - stream-ordered, no hidden synchronisation, no allocation, graph-capturable
+ *     (the reference launches on the legacy default stream and cudaMalloc's per call);
+ *   - returns 0 on success, a negative bie_status otherwise and records a message retrievable with
+ *     bie_last_error() (the reference calls exit(EXIT_FAILURE) on unsupported arguments:
+ *     layers/qlinear/nbit/cuda/mpq_linear_cuda_kernel.cu:506-508,573-576);
+ *   - thread-safe and re-entrant (no global mutable state besides the thread-local error string).
+ *
+ * Tensor conventions (identical to the reference's state_dict layout):
+ *   x        [M, K]            dtype (row-major, K contiguous)
+ *   qweight  [K*w_bit/32, N]   int32; value k of column n = (qweight[k/(32/w)][n] >> ((k%(32/w))*w)) & (2^w-1)
+ *   scales   [G, N]            dtype, G = ceil(K / group_size)
+ *   zeros    [G, N]            dtype (symmetric / GBA)  or  int32 [G, N*w_bit/32] packed along N (asymmetric / GPTQ)
+ *   g_idx    [K]               int32 group of row k, or NULL for the implicit k / group_size
+ *   y        [M, N]            dtype
+ */
+#ifndef BIE_HIP_H
+#define BIE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BIE_VERSION 100 /* 0.1.0 */
+
+typedef enum { BIE_F16 = 0, BIE_BF16 = 1, BIE_F32 = 2 } bie_dtype;
+
+typedef enum {
+    BIE_OK = 0,
+    BIE_ERR_INVALID_ARG = -1, /* NULL pointer, non-positive size, misaligned shape */
+    BIE_ERR_UNSUPPORTED = -2, /* bit width / dtype / shape this build has no kernel for */
+    BIE_ERR_WORKSPACE = -3,   /* scratch buffer smaller than bie_*_workspace_bytes() */
+    BIE_ERR_HIP = -4          /* a HIP runtime call failed (launch error) */
+} bie_status;
+
+int bie_version(void);
+/* message of the last failing call made by THIS thread ("" if none) */
+const char* bie_last_error(void);
+
+/* ------------------------------------------------------------------------------------------ */
+/* MPQ (GPTQ-style) W{1,2,4,8}A16 linear                                                       */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Scratch needed by bie_mpq_forward for split-K partial sums (0 is a valid answer). */
+size_t bie_mpq_workspace_bytes(int M, int K, int N, int w_bit);
+
+/* y = x . dequant(qweight) (+ bias).
+ * Replaces q_linear_cuda.mpq_forward (layers/qlinear/nbit/cuda/q_linear_cuda.cpp:258-270 ->
+ * mpq_linear_cuda_kernel.cu:603-626) AND the M > 32 branch unpack_qweight + torch.matmul
+ * (layers/qlinear/nbit/cuda/mpq_layer.py:59-63): one fused kernel family for every M.
+ * The dequantised weight is rounded exactly like the reference's CPU path
+ * (sym: fl(fl(q*s) - z); asym: fl(s * (q - (zq+1)))), products are accumulated in fp32 and the
+ * result is rounded once to dtype; split-K partials are reduced in a fixed order (deterministic;
+ * the reference uses half-precision atomicAdd, mpq_linear_cuda_kernel.cu:440-450).
+ * bias may be NULL.  workspace may be NULL iff bie_mpq_workspace_bytes(...) == 0. */
+int bie_mpq_forward(const void* x, const int32_t* qweight, const void* scales, const void* zeros,
+                    const int32_t* g_idx, const void* bias, void* y, void* workspace,
+                    size_t workspace_bytes, int M, int K, int N, int w_bit, int group_size, int asym,
+                    int dtype, void* stream);
+
+/* out[K, N] (dtype) = dequantised weight.  Bit-exact twin of unpack_qweight layer_type 1
+ * (layers/qlinear/nbit/cuda/utils.py:30-51). */
+int bie_mpq_dequant(const int32_t* qweight, const void* scales, const void* zeros,
+                    const int32_t* g_idx, void* out, int K, int N, int w_bit, int group_size,
+                    int asym, int dtype, void* stream);
+
+/* out[K*w/32, N] (int32) = packed quantisation of weight[K, N].  Bit-exact twin of pack_fp_weight
+ * (layers/qlinear/nbit/cuda/utils.py:72-147). */
+int bie_mpq_pack(const void* weight, const void* scales, const void* zeros, const int32_t* g_idx,
+                 int32_t* out, int K, int N, int w_bit, int group_size, int asym, int dtype,
+                 void* stream);
+
+/* grad_x[M, K] = grad_y[M, N] . dequant(qweight)^T.  Replaces q_linear_cuda.mpq_grad_input
+ * (mpq_linear_cuda_kernel.cu:1198-1223). */
+int bie_mpq_grad_input(const void* grad_y, const int32_t* qweight, const void* scales,
+                       const void* zeros, const int32_t* g_idx, void* grad_x, int M, int K, int N,
+                       int w_bit, int group_size, int asym, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* MBWQ: uniform 4/2-bit (GPTQ-like) and mixed 8/6/5/4/3/2-bit (exl2 layout) linear, fp16 only   */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Band table rows[7] = {rows_8, rows_6, rows_5, rows_4, rows_3, rows_2 (cumulative k), kernel_p}
+ * from the (bits, first packed row) pairs in q_groups.  HOST pointers, pure host code.
+ * Replaces the table computation of q_linear_cuda.mbwq_trans_qweight
+ * (mbwq_linear_cuda_kernel.cu:559-600; its shuffle kernel is a no-op, exl2/config.h:16-21). */
+int bie_mbwq_rows(const int16_t* q_groups_host, int groups, int K, int* rows7_host);
+
+/* out[K, N] fp16: W[q_perm ? q_perm[k] : k][n] = fma(s, q, -z).  Replaces
+ * q_linear_cuda.mbwq_q42fp_weight (mbwq_linear_cuda_kernel.cu:656-710, kernels :314-501). */
+int bie_mbwq_q4_dequant(const int32_t* qweight, const void* scales, const void* zeros,
+                        const int16_t* q_perm, void* out, int K, int N, int bits, int group_size,
+                        void* stream);
+
+/* out[K, N] fp16 for the mixed-bit layout, addressed exactly like the reference kernels do:
+ * q_group_map is the DEVICE int16[2K] array of (group, rows-left-in-group) pairs built by
+ * make_group_map (layers/qlinear/nbit/cuda/utils.py:150-187); rows7_host the HOST band table of
+ * bie_mbwq_rows.  Replaces q_linear_cuda.mbwq_exl2fp_weight
+ * (mbwq_linear_cuda_kernel.cu:849-897, kernel :92-308). */
+int bie_mbwq_exl2_dequant(const int32_t* qweight, const void* scales, const void* zeros,
+                          const int16_t* q_perm, const int16_t* q_group_map, const int* rows7_host,
+                          void* out, int K, int N, int groups, void* stream);
+
+size_t bie_mbwq_workspace_bytes(int M, int K, int N);
+
+/* y[M, N] fp16 = x[:, q_perm] . dequant.  Replace q_linear_cuda.mbwq_q4_forward
+ * (mbwq_linear_cuda_kernel.cu:742-825) and q_linear_cuda.mbwq_exl2_forward (:926-1007). */
+int bie_mbwq_q4_forward(const void* x, const int32_t* qweight, const void* scales,
+                        const void* zeros, const int16_t* q_perm, void* y, void* workspace,
+                        size_t workspace_bytes, int M, int K, int N, int bits, int group_size,
+                        void* stream);
+int bie_mbwq_exl2_forward(const void* x, const int32_t* qweight, const void* scales,
+                          const void* zeros, const int16_t* q_perm, const int16_t* q_group_map,
+                          const int* rows7_host, void* y, void* workspace, size_t workspace_bytes,
+                          int M, int K, int N, int groups, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Binary (1-bit W / 1-bit A) linear + conv2d, XNOR-popcount                                     */
+/* ------------------------------------------------------------------------------------------ */
+
+/* out[rows, K/8] uint8, bit j of byte b = (a[r][8b+j] >= 0).  Row packing of
+ * binary_linear.cpp:43-54 (_get_binary_row) == binary_linear_cutlass_kernel.cu:44-90. */
+int bie_binary_pack_rows_u8(const void* a, uint8_t* out, long rows, long K, int dtype, void* stream);
+
+/* out[K/8, N] uint8 column bit-planes of w[N, K]: byte[kb*N + n] bit j = (w[n][8kb+j] >= 0).
+ * Replaces binary_linear_cpp.w_pack (binary_linear.cpp:454-465). */
+int bie_binary_pack_cols_u8(const void* w, uint8_t* out, long N, long K, int dtype, void* stream);
+
+/* y[M, N] fp32 = (K - 2*popcount(xbits ^ wbits)) * scale.
+ * w_layout 0: wpacked is row-packed [N, K/8] (binary_linear_cutlass / our native layout)
+ * w_layout 1: wpacked is column bit-planes [K/8, N] (binary_linear_cpp.w_pack layout).
+ * xpacked [M, K/8] row-packed.  Replaces binary_linear_cpp.forward (binary_linear.cpp:494-512),
+ * binary_linear_cuda.forward (binary_linear_cuda_kernel.cu:629-660) and
+ * binary_linear_cutlass.forward (binary_linear_cutlass_kernel.cu:604-625). */
+int bie_binary_linear_forward(const uint8_t* xpacked, const uint8_t* wpacked, float* y, long M,
+                              long N, long K, int w_layout, float scale, void* stream);
+
+/* y[B, OC, OH, OW] fp32 = scale * sum over (c,i,j) of sign(x)*sign(w), padding counted as -1.
+ * x [B, C, H, W] dtype; wpacked [OC, C*k*k/8] row-packed over the flattened (c,i,j) index
+ * (C*k*k % 8 == 0).  workspace holds the bit-im2col image (bie_binary_conv2d_workspace_bytes).
+ * Replaces binary_conv_cpp.forward (layers/qconv/binary/cpp/binary_conv.cpp:464-530,
+ * im2binary_col :319-365). */
+size_t bie_binary_conv2d_workspace_bytes(int B, int C, int H, int W, int OC, int ksize, int stride,
+                                         int pad, int dilation);
+int bie_binary_conv2d_forward(const void* x, const uint8_t* wpacked, float* y, void* workspace,
+                              size_t workspace_bytes, int B, int C, int H, int W, int OC, int ksize,
+                              int stride, int pad, int dilation, float scale, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* functions/cuda pack / unpack helpers (functions/cuda/functions_cuda_kernel.cu)                */
+/* ------------------------------------------------------------------------------------------ */
+
+/* sign -> uint8, LSB first (tensor_pack_to_uint8, :107-117, hosts :290-297). dtype may also be
+ * 3 = int8 sign carriers. */
+int bie_pack_sign_u8(const void* a, uint8_t* out, long n_bytes, int dtype, void* stream);
+/* uint8 -> +-1 * scale[i / packed_dim] (uint8_to_unpacked_tensor, :121-134) */
+int bie_unpack_u8_scaled(const uint8_t* in, const float* scale, float* out, long n_bytes,
+                         long packed_dim, void* stream);
+/* two int32 -> one int8, FIRST element in the HIGH nibble (q4_pack, :137-159) */
+int bie_q4_pack(const int32_t* in, int8_t* out, long n_out, void* stream);
+/* int8 -> two unsigned nibbles as int32 (q4_unpack, :162-181) */
+int bie_q4_unpack(const int8_t* in, int32_t* out, long n_in, void* stream);
+/* int8 -> two sign-extended nibbles * scale, fp32 (q4_unpack_and_scaling, :184-207) */
+int bie_q4_unpack_scale(const int8_t* in, float* out, long n_in, float scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BIE_HIP_H */
