@@ -103,7 +103,7 @@ def main():
     y_all = torch.empty((LAYERS, N), dtype=torch.bfloat16, device=dev)  # row l = output of layer l
     gathered = torch.empty((world, LAYERS, N), dtype=torch.bfloat16, device=dev) if distributed else None
     ws_bytes = L.bie_mpq_workspace_bytes(1, K, N, WBIT)
-    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+    ws = torch.zeros(max(ws_bytes, 16), dtype=torch.uint8, device=dev)  # 4 KiB head of split-K counters starts at zero
 
     def run_layers(stream_ptr):
         for l, (qw, sc, ze) in enumerate(layers):
@@ -181,7 +181,7 @@ def main():
         xg = torch.randn((M, K), generator=torch.Generator().manual_seed(7)).to(torch.bfloat16).to(dev)
         yg = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
         wsg_b = L.bie_mpq_workspace_bytes(M, K, N, WBIT)
-        wsg = torch.empty(max(wsg_b, 16), dtype=torch.uint8, device=dev)
+        wsg = torch.zeros(max(wsg_b, 16), dtype=torch.uint8, device=dev)
         st = torch.cuda.current_stream().cuda_stream
 
         def gemm(l):

@@ -101,6 +101,6 @@ def workspace(nbytes: int, device) -> torch.Tensor:
     key = (device.index if device.index is not None else torch.cuda.current_device(), stream())
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        buf = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)  # head = split-K counters, must start at 0
         _WS[key] = buf
     return buf

@@ -4,44 +4,44 @@ import torch
 
 from bitorch_engine import _hip
 
-_TRIVIAL_GIDX = {}
-_ZERO_PERM = {}
-
-
 def _group_size(K, scales):
     G = scales.shape[0]
     return (K + G - 1) // G
 
 
+def _cached(t, key, compute):
+    """Memoise a property of tensor `t` ON the tensor object, invalidated by in-place modification (`_version`)
+    or re-pointing (`data_ptr`).  (A process-wide dict keyed by address would alias recycled allocations.)"""
+    tag = (key, t._version, t.data_ptr())
+    hit = getattr(t, "_bie_memo", None)
+    if hit is None or hit[0] != tag:
+        hit = (tag, compute())
+        try:
+            t._bie_memo = hit
+        except Exception:
+            pass
+    return hit[1]
+
+
 def gidx_is_trivial(g_idx, group_size):
     """True when g_idx[k] == k // group_size (what MPQLinearBase initialises, nbit/layer.py:385-386).
-    One device->host sync per distinct tensor version, then cached."""
+    One device->host sync per distinct tensor version, then remembered on the tensor."""
     if g_idx is None:
         return True
-    key = (g_idx.data_ptr(), g_idx._version, g_idx.numel(), group_size)
-    hit = _TRIVIAL_GIDX.get(key)
-    if hit is None:
+
+    def compute():
         ref = torch.arange(g_idx.numel(), device=g_idx.device, dtype=torch.int32) // group_size
-        hit = bool(torch.equal(g_idx.to(torch.int32), ref))
-        if len(_TRIVIAL_GIDX) > 4096:
-            _TRIVIAL_GIDX.clear()
-        _TRIVIAL_GIDX[key] = hit
-    return hit
+        return bool(torch.equal(g_idx.to(torch.int32), ref))
+    return _cached(g_idx, ("trivial", group_size), compute)
 
 
 def perm_or_none(q_perm):
     """The reference treats an all-zero q_perm as 'no permutation' with a per-call .item() sync
-    (mbwq_linear_cuda_kernel.cu:671,777); here the answer is cached per tensor version."""
+    (mbwq_linear_cuda_kernel.cu:671,777); here the answer is remembered per tensor version."""
     if q_perm is None:
         return None
-    key = (q_perm.data_ptr(), q_perm._version, q_perm.numel())
-    hit = _ZERO_PERM.get(key)
-    if hit is None:
-        hit = bool(torch.all(q_perm == 0).item())
-        if len(_ZERO_PERM) > 4096:
-            _ZERO_PERM.clear()
-        _ZERO_PERM[key] = hit
-    return None if hit else q_perm
+    zero = _cached(q_perm, "allzero", lambda: bool(torch.all(q_perm == 0).item()))
+    return None if zero else q_perm
 
 
 def mpq_forward_impl(x, qweight, scales, zeros, g_idx, w_bit, asym, group_size, bias=None, trivial_gidx=None):

@@ -55,6 +55,9 @@ int q4_unpack_scale_launch(const int8_t* in, float* out, long n_in, float scale,
 using namespace bie;
 
 static const int GENERIC_M_CHUNK = 32;
+// The first 4 KiB of every workspace hold the GEMV's split-K arrival counters (zero on first use, returned to zero by
+// the kernel); every other scratch user starts behind them.
+static const size_t WS_HEAD = 4096;
 
 static int validate_mpq(const char* fn, int K, int N, int w_bit, int group_size, int dtype) {
     BIE_REQUIRE(w_bit == 1 || w_bit == 2 || w_bit == 4 || w_bit == 8, BIE_ERR_UNSUPPORTED,
@@ -78,7 +81,7 @@ size_t bie_mpq_workspace_bytes(int M, int K, int N, int w_bit) {
     const int mc = M < GENERIC_M_CHUNK ? M : GENERIC_M_CHUNK;
     size_t c = (size_t)cdiv(K, 512) * mc * N * sizeof(float);
     size_t r = a > b ? a : b;
-    return r > c ? r : c;
+    return WS_HEAD + (r > c ? r : c);
 }
 
 int bie_mpq_forward(const void* x, const int32_t* qweight, const void* scales, const void* zeros,
@@ -94,10 +97,11 @@ int bie_mpq_forward(const void* x, const int32_t* qweight, const void* scales, c
     BIE_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), BIE_ERR_WORKSPACE,
                 "bie_mpq_forward: workspace of %zu bytes required, got %zu", need, workspace_bytes);
     hipStream_t st = as_stream(stream);
-    float* part = reinterpret_cast<float*>(workspace);
+    float* head = reinterpret_cast<float*>(workspace);
+    float* part = head + WS_HEAD / sizeof(float);
     const bool has_gidx = g_idx != nullptr;
     if (M <= 8 && mpq_gemv_fast_ok(M, K, N, w_bit, group_size, dtype, has_gidx))
-        return mpq_gemv_launch(x, qweight, scales, zeros, bias, y, part, M, K, N, w_bit, group_size, asym ? 1 : 0, dtype, nullptr, st);
+        return mpq_gemv_launch(x, qweight, scales, zeros, bias, y, head, M, K, N, w_bit, group_size, asym ? 1 : 0, dtype, nullptr, st);
     if (mpq_gemm_ok(M, K, N, w_bit, group_size, dtype, has_gidx))
         return mpq_gemm_launch(x, qweight, scales, zeros, bias, y, part, M, K, N, w_bit, group_size, asym ? 1 : 0, dtype, nullptr, st);
     // generic path (explicit g_idx / odd shapes / fp32), GENERIC_M_CHUNK rows at a time
@@ -168,7 +172,7 @@ int bie_mbwq_rows(const int16_t* q_groups_host, int groups, int K, int* rows7_ho
 
 size_t bie_mbwq_workspace_bytes(int M, int K, int N) {
     if (M <= 0 || K <= 0 || N <= 0) return 0;
-    return mbwq_workspace_bytes(M, K, N);
+    return WS_HEAD + mbwq_workspace_bytes(M, K, N);
 }
 
 int bie_mbwq_q4_dequant(const int32_t* qweight, const void* scales, const void* zeros, const int16_t* q_perm, void* out, int K,
@@ -205,7 +209,7 @@ int bie_mbwq_q4_forward(const void* x, const int32_t* qweight, const void* scale
                         void* stream) {
     BIE_REQUIRE(x && qweight && scales && zeros && y && M > 0 && K > 0 && N > 0 && group_size > 0, BIE_ERR_INVALID_ARG, "bie_mbwq_q4_forward: bad argument");
     BIE_REQUIRE(bits == 2 || bits == 4, BIE_ERR_UNSUPPORTED, "bie_mbwq_q4_forward: weight bit width %d has not been supported yet", bits);
-    const size_t need = mbwq_workspace_bytes(M, K, N);
+    const size_t need = WS_HEAD + mbwq_workspace_bytes(M, K, N);
     BIE_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), BIE_ERR_WORKSPACE, "bie_mbwq_q4_forward: workspace of %zu bytes required, got %zu", need, workspace_bytes);
     return mbwq_q4_forward_launch(x, qweight, scales, zeros, q_perm, y, (float*)workspace, M, K, N, bits, group_size, as_stream(stream));
 }
@@ -216,9 +220,9 @@ int bie_mbwq_exl2_forward(const void* x, const int32_t* qweight, const void* sca
     BIE_REQUIRE(x && qweight && scales && zeros && q_group_map && y && M > 0 && K > 0 && N > 0, BIE_ERR_INVALID_ARG, "bie_mbwq_exl2_forward: bad argument");
     int rc = check_rows("bie_mbwq_exl2_forward", rows7_host, K);
     if (rc) return rc;
-    const size_t need = mbwq_workspace_bytes(M, K, N);
+    const size_t need = WS_HEAD + mbwq_workspace_bytes(M, K, N);
     BIE_REQUIRE(workspace && workspace_bytes >= need, BIE_ERR_WORKSPACE, "bie_mbwq_exl2_forward: workspace of %zu bytes required, got %zu", need, workspace_bytes);
-    return mbwq_exl2_forward_launch(x, qweight, scales, zeros, q_perm, q_group_map, rows7_host, y, (float*)workspace, M, K, N, as_stream(stream));
+    return mbwq_exl2_forward_launch(x, qweight, scales, zeros, q_perm, q_group_map, rows7_host, y, (float*)workspace + WS_HEAD / sizeof(float), M, K, N, as_stream(stream));
 }
 
 // ---------------------------------------------------------------------------------------------- binary

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void mpq_gemm_kernel(const uint16_t* __restric
                                                        const uint16_t* __restrict__ scales, const void* __restrict__ zeros,
                                                        const uint16_t* __restrict__ bias, const uint16_t* __restrict__ perm,
                                                        float* __restrict__ part, uint16_t* __restrict__ y, int M, int K, int N,
-                                                       int group_size, int tiles_per_split, int S) {
+                                                       int group_size, int tiles_per_split, int S, int m_tiles, int n_tiles) {
     constexpr int TM = BM / 32;              // 32x32 accumulators per wave
     constexpr int A_CHUNKS = BM * 8 / 256;   // 16-byte chunks staged per thread per tile
     constexpr int A_BYTES = BM * GEMM_BK * 2;
@@ -202,11 +202,25 @@ __global__ __launch_bounds__(256) void mpq_gemm_kernel(const uint16_t* __restric
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, j = lane & 31;
-    const int m0 = blockIdx.x * BM;
-    const int n_base = blockIdx.y * GEMM_BN + wave * 32;
+    // XCD-aware tile order: the dispatcher places block b on XCD b % 8 (speed only, never correctness).  Give each XCD
+    // a contiguous chunk of the m-major tile order so that the ~64 blocks co-resident on an XCD share 1-2 x row-tiles
+    // (2 MB each at K=4096) in that XCD's 4 MiB L2 instead of every XCD cycling through all of x.
+    int m_tile, n_tile;
+    {
+        const int T = m_tiles * n_tiles;
+        const int b = blockIdx.x;
+        const int xcd = b & 7, i = b >> 3;
+        const int q = T >> 3, r = T & 7;
+        const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        const int t = start + i;
+        m_tile = t / n_tiles;
+        n_tile = t - m_tile * n_tiles;
+    }
+    const int m0 = m_tile * BM;
+    const int n_base = n_tile * GEMM_BN + wave * 32;
     const int n = n_base + j;
     const int n_ld = n < N ? n : N - 1;  // clamp loads of out-of-range columns (never stored)
-    const int split = blockIdx.z;
+    const int split = blockIdx.y;
     const int T_total = K / GEMM_BK;
     const int t_begin = split * tiles_per_split;
     int t_end = t_begin + tiles_per_split;
@@ -350,12 +364,13 @@ size_t mpq_gemm_workspace_bytes(int M, int K, int N) {
 template <int DT, int WBIT, int ZM>
 static int gemm_launch_bm(const GemmPlan& p, const void* x, const int32_t* qw, const void* scales, const void* zeros,
                           const void* bias, const uint16_t* perm, float* part, void* y, int M, int K, int N, int group_size, hipStream_t st) {
-    dim3 grid(cdiv(M, p.BM), cdiv(N, GEMM_BN), p.S);
+    const int m_tiles = cdiv(M, p.BM), n_tiles = cdiv(N, GEMM_BN);
+    dim3 grid(m_tiles * n_tiles, p.S);
     const size_t lds = (size_t)2 * p.BM * GEMM_BK * 2;
 #define L(BMV)                                                                                                        \
     hipLaunchKernelGGL((mpq_gemm_kernel<DT, WBIT, ZM, BMV>), grid, dim3(256), lds, st, (const uint16_t*)x,           \
                        (const uint32_t*)qw, (const uint16_t*)scales, zeros, (const uint16_t*)bias, perm, part, (uint16_t*)y, \
-                       M, K, N, group_size, p.tiles_per_split, p.S)
+                       M, K, N, group_size, p.tiles_per_split, p.S, m_tiles, n_tiles)
     switch (p.BM) {
         case 32: L(32); break;
         case 64: L(64); break;

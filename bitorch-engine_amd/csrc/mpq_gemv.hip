@@ -13,6 +13,7 @@
 //   * split-K over blocks (grid.y) fills the 256 CUs for small N; partial sums go to an fp32
 //     workspace and are reduced in fixed order by splitk_finalize (deterministic, no atomics).
 #include "mpq_dequant.cuh"
+#include <stdlib.h>
 
 #pragma clang fp contract(off)
 
@@ -20,13 +21,14 @@ namespace bie {
 
 constexpr int GEMV_THREADS = 256;
 constexpr int GEMV_COLS = 256;  // columns per block: 64 lanes x 4
+constexpr int GEMV_COUNTER_FLOATS = 1024;  // head of the workspace: one arrival counter per column tile (4 KiB)
 
 template <int DT, int WBIT, int MT, int ZM, int U>
 __global__ __launch_bounds__(GEMV_THREADS) void mpq_gemv_kernel(
     const uint16_t* __restrict__ x, const uint32_t* __restrict__ qw, const uint16_t* __restrict__ scales,
     const void* __restrict__ zeros, const uint16_t* __restrict__ bias, const uint16_t* __restrict__ perm,
-    float* __restrict__ part, uint16_t* __restrict__ y, int M, int K, int N, int group_size, int rows_per_slab, int R,
-    int S) {
+    float* __restrict__ part, unsigned* __restrict__ counters, uint16_t* __restrict__ y, int M, int K, int N,
+    int group_size, int rows_per_slab, int R, int S) {
     constexpr int NB = 32 / WBIT;
     constexpr int NP = NB / 2;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -37,6 +39,24 @@ __global__ __launch_bounds__(GEMV_THREADS) void mpq_gemv_kernel(
     const int slab = blockIdx.y;
     const int r_begin = slab * rows_per_slab;
     const int slab_k = rows_per_slab * NB;
+
+    const int rpw = rows_per_slab / 4;
+    const int rw_begin = r_begin + wave * rpw;
+    int rw_end = rw_begin + rpw;
+    if (rw_end > R) rw_end = R;
+
+    // ---- weights first: the first U row loads are in flight while x is staged (nothing below depends on LDS yet)
+    uint4_t wq[U];
+    auto load_rows = [&](uint4_t (&dst)[U], int r) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (n_ok && r + u < rw_end) {
+                const uint4_t* p = reinterpret_cast<const uint4_t*>(qw + (long)(r + u) * N + n0);
+                dst[u] = __builtin_nontemporal_load(p);
+            }
+        }
+    };
+    load_rows(wq, rw_begin);
 
     // ---- stage the x slab into LDS in pair order (16-bit elements) -----------------------------
     {
@@ -60,24 +80,13 @@ __global__ __launch_bounds__(GEMV_THREADS) void mpq_gemv_kernel(
 #pragma unroll
         for (int c = 0; c < 4; c++) acc[m][c] = 0.0f;
 
-    const int rpw = rows_per_slab / 4;
-    const int rw_begin = r_begin + wave * rpw;
-    int rw_end = rw_begin + rpw;
-    if (rw_end > R) rw_end = R;
-
     if (n_ok) {
         ColParams<DT, ZM> cp[4];
         int g_prev = -1;
         const int zero_width = N / NB;
         for (int r = rw_begin; r < rw_end; r += U) {
-            uint4_t wq[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                if (r + u < rw_end) {
-                    const uint4_t* p = reinterpret_cast<const uint4_t*>(qw + (long)(r + u) * N + n0);
-                    wq[u] = __builtin_nontemporal_load(p);
-                }
-            }
+            uint4_t wn[U];
+            if (r + U < rw_end) load_rows(wn, r + U);  // prefetch the next step
             const int g = (r * NB) / group_size;
             if (g != g_prev) {
                 g_prev = g;
@@ -121,6 +130,8 @@ __global__ __launch_bounds__(GEMV_THREADS) void mpq_gemv_kernel(
                     }
                 }
             }
+#pragma unroll
+            for (int u = 0; u < U; u++) wq[u] = wn[u];
         }
     }
 
@@ -134,21 +145,65 @@ __global__ __launch_bounds__(GEMV_THREADS) void mpq_gemv_kernel(
     }
     __syncthreads();
     const int n = blockIdx.x * GEMV_COLS + tid;
+    float tot[MT];
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+        float v = red[(0 * MT + m) * GEMV_COLS + tid];
+        v += red[(1 * MT + m) * GEMV_COLS + tid];
+        v += red[(2 * MT + m) * GEMV_COLS + tid];
+        v += red[(3 * MT + m) * GEMV_COLS + tid];
+        tot[m] = v;
+    }
+    if (S == 1) {
+        if (n < N) {
+#pragma unroll
+            for (int m = 0; m < MT; m++)
+                if (m < M) {
+                    float o = dt_traits<DT>::round(tot[m]);
+                    if (bias) o = o + dt_traits<DT>::load(bias, n);
+                    dt_traits<DT>::store(y, (long)m * N + n, o);
+                }
+        }
+        return;
+    }
+    // ---- split-K: publish this slab's partial write-through (sc1), take a ticket; the LAST arriver of the column tile
+    // sums the S slabs in slab order (deterministic) and writes y.  Placement-independent hand-off (agent scope):
+    // sc1 stores + per-wave vmcnt(0) drain + barrier + one relaxed agent ticket; the reducer reads with sc1 loads.
+    if (n < N) {
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+            if (m < M) __hip_atomic_store(part + ((long)slab * M + m) * N + n, tot[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // also: every wave is done reading `red`
+    if (tid == 0) {
+        const unsigned ticket = __hip_atomic_fetch_add(counters + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        smem[0] = ticket;
+    }
+    __syncthreads();
+    if (smem[0] != (unsigned)(S - 1)) return;
+    if (tid == 0) __hip_atomic_store(counters + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next call
     if (n < N) {
 #pragma unroll
         for (int m = 0; m < MT; m++) {
             if (m < M) {
-                float v = red[(0 * MT + m) * GEMV_COLS + tid];
-                v += red[(1 * MT + m) * GEMV_COLS + tid];
-                v += red[(2 * MT + m) * GEMV_COLS + tid];
-                v += red[(3 * MT + m) * GEMV_COLS + tid];
-                if (S == 1) {
-                    float o = dt_traits<DT>::round(v);
-                    if (bias) o = o + dt_traits<DT>::load(bias, n);
-                    dt_traits<DT>::store(y, (long)m * N + n, o);
-                } else {
-                    part[((long)slab * M + m) * N + n] = v;
+                // 16 independent sc1 loads in flight per batch (a dependent load-add chain costs one memory round
+                // trip PER slab), summed in slab order
+                float v = 0.0f;
+                for (int s0 = 0; s0 < S; s0 += 16) {
+                    float t[16];
+#pragma unroll
+                    for (int jj = 0; jj < 16; jj++) {
+                        const int sidx = (s0 + jj < S) ? s0 + jj : S - 1;
+                        t[jj] = __hip_atomic_load(part + ((long)sidx * M + m) * N + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < 16; jj++)
+                        if (s0 + jj < S) v += t[jj];
                 }
+                float o = dt_traits<DT>::round(v);
+                if (bias) o = o + dt_traits<DT>::load(bias, n);
+                dt_traits<DT>::store(y, (long)m * N + n, o);
             }
         }
     }
@@ -204,7 +259,8 @@ static GemvPlan plan_gemv(int K, int N, int w_bit, int group_size, int MT) {
     while (U > 1 && (rows_per_group % U) != 0) U >>= 1;
     const int unit = 32;
     const int tiles_n = cdiv(N, GEMV_COLS);
-    int S = cdiv(1024, tiles_n);  // aim at ~4 blocks per CU
+    static const int target = []() { const char* e = getenv("BIE_GEMV_TARGET_BLOCKS"); return e ? atoi(e) : 1024; }();
+    int S = cdiv(target, tiles_n);  // aim at ~4 blocks per CU
     int max_rows = (32768 / (2 * MT)) / NB;  // x slab <= 32 KiB of LDS
     max_rows = (max_rows / unit) * unit;
     int rows = cdiv(cdiv(R, S), unit) * unit;
@@ -226,7 +282,7 @@ static int launch_gemv_u(const GemvPlan& pl, const void* x, const int32_t* qw, c
 #define BIE_GEMV_LAUNCH(UU)                                                                                      \
     hipLaunchKernelGGL((mpq_gemv_kernel<DT, WBIT, MT, ZM, UU>), grid, dim3(GEMV_THREADS), lds, st,              \
                        (const uint16_t*)x, (const uint32_t*)qw, (const uint16_t*)scales, zeros, (const uint16_t*)bias, perm, \
-                       part, (uint16_t*)y, M, K, N, group_size, pl.rows_per_slab, R, pl.S)
+                       part + GEMV_COUNTER_FLOATS, reinterpret_cast<unsigned*>(part), (uint16_t*)y, M, K, N, group_size, pl.rows_per_slab, R, pl.S)
     switch (pl.U) {
         case 8: BIE_GEMV_LAUNCH(8); break;
         case 4: BIE_GEMV_LAUNCH(4); break;
@@ -278,13 +334,14 @@ bool mpq_gemv_fast_ok(int M, int K, int N, int w_bit, int group_size, int dtype,
     const int NB = 32 / w_bit;
     const int gs = group_size > K ? K : group_size;
     if (K % NB || gs % NB || (N & 3)) return false;
+    if (cdiv(N, GEMV_COLS) > GEMV_COUNTER_FLOATS) return false;
     return true;
 }
 
 size_t mpq_gemv_workspace_bytes(int M, int K, int N, int w_bit) {
     const int MT = M <= 1 ? 1 : (M <= 2 ? 2 : (M <= 4 ? 4 : 8));
     const GemvPlan pl = plan_gemv(K, N, w_bit, K, MT);
-    const size_t fast = pl.S > 1 ? (size_t)pl.S * M * N * sizeof(float) : 0;
+    const size_t fast = pl.S > 1 ? (size_t)pl.S * M * N * sizeof(float) + GEMV_COUNTER_FLOATS * sizeof(float) : 0;
     const size_t generic = (size_t)cdiv(K, 512) * M * N * sizeof(float);
     return fast > generic ? fast : generic;
 }
@@ -296,12 +353,10 @@ int mpq_gemv_launch(const void* x, const int32_t* qw, const void* scales, const 
     const GemvPlan pl = plan_gemv(K, N, w_bit, group_size, MT);
     int rc;
     if (dtype == BIE_F16)
-        rc = launch_gemv_w<BIE_F16>(pl, MT, w_bit, zm, x, qw, scales, zeros, pl.S == 1 ? bias : nullptr, perm, part, y, M, K, N, group_size, st);
+        rc = launch_gemv_w<BIE_F16>(pl, MT, w_bit, zm, x, qw, scales, zeros, bias, perm, part, y, M, K, N, group_size, st);
     else
-        rc = launch_gemv_w<BIE_BF16>(pl, MT, w_bit, zm, x, qw, scales, zeros, pl.S == 1 ? bias : nullptr, perm, part, y, M, K, N, group_size, st);
-    if (rc) return rc;
-    if (pl.S > 1) return launch_splitk_finalize(part, bias, y, pl.S, M, N, dtype, st);
-    return BIE_OK;
+        rc = launch_gemv_w<BIE_BF16>(pl, MT, w_bit, zm, x, qw, scales, zeros, bias, perm, part, y, M, K, N, group_size, st);
+    return rc;
 }
 
 int mpq_gemv_generic_launch(const void* x, const int32_t* qw, const void* scales, const void* zeros, const int32_t* g_idx,

@@ -31,8 +31,15 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __res
                                                               void* __restrict__ y, int S, long MN, int N) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= MN) return;
-    float v = part[i];
-    for (int s = 1; s < S; s++) v += part[(long)s * MN + i];
+    float v = 0.0f;
+    for (int s0 = 0; s0 < S; s0 += 8) {  // 8 independent loads in flight, summed in slab order
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) t[j] = part[(long)((s0 + j < S) ? s0 + j : S - 1) * MN + i];
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (s0 + j < S) v += t[j];
+    }
     float o = dt_traits<DT>::round(v);
     if (bias) o = o + dt_traits<DT>::load(bias, i % N);
     dt_traits<DT>::store(y, i, o);

@@ -52,7 +52,9 @@ const char* bie_last_error(void);
 /* MPQ (GPTQ-style) W{1,2,4,8}A16 linear                                                       */
 /* ------------------------------------------------------------------------------------------ */
 
-/* Scratch needed by bie_mpq_forward for split-K partial sums (0 is a valid answer). */
+/* Scratch needed by bie_mpq_forward (split-K partial sums behind a 4 KiB head of arrival counters).
+ * CONTRACT: the first 4096 bytes of a workspace must be ZERO the first time it is used; the kernels
+ * return them to zero, so one memset at allocation time is enough.  One workspace per stream. */
 size_t bie_mpq_workspace_bytes(int M, int K, int N, int w_bit);
 
 /* y = x . dequant(qweight) (+ bias).
