@@ -36,6 +36,18 @@ __host__ __device__ constexpr int pair_src_k(int p) {
     }
 }
 
+// byte B of v -> float (v_cvt_f32_ubyteB).  hipcc folds the shift/mask forms back into per-value v_bfe + ubyte0,
+// so the instruction is named explicitly (plain asm: schedulable, no side effects).
+template <int B>
+__device__ __forceinline__ float cvt_ubyte(uint32_t v) {
+    float f;
+    if constexpr (B == 0) asm("v_cvt_f32_ubyte0_e32 %0, %1" : "=v"(f) : "v"(v));
+    else if constexpr (B == 1) asm("v_cvt_f32_ubyte1_e32 %0, %1" : "=v"(f) : "v"(v));
+    else if constexpr (B == 2) asm("v_cvt_f32_ubyte2_e32 %0, %1" : "=v"(f) : "v"(v));
+    else asm("v_cvt_f32_ubyte3_e32 %0, %1" : "=v"(f) : "v"(v));
+    return f;
+}
+
 // Per-column dequant constants held in registers for the current group.
 template <int DT, int ZM> struct ColParams;
 
@@ -99,10 +111,10 @@ __device__ __forceinline__ void dequant_word(uint32_t w, const ColParams<DT, ZM>
         for (int i = 0; i < VPB; i++) {
             const uint32_t t = (w >> (WBIT * i)) & BMASK;  // bytes b=0..3 hold value index b*VPB + i
             float q[4];
-            q[0] = (float)(t & 0xffu);
-            q[1] = (float)((t >> 8) & 0xffu);
-            q[2] = (float)((t >> 16) & 0xffu);
-            q[3] = (float)(t >> 24);
+            q[0] = cvt_ubyte<0>(t);
+            q[1] = cvt_ubyte<1>(t);
+            q[2] = cvt_ubyte<2>(t);
+            q[3] = cvt_ubyte<3>(t);
 #pragma unroll
             for (int ph = 0; ph < 2; ph++) {
                 float a = q[2 * ph], b = q[2 * ph + 1];

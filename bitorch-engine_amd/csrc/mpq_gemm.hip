@@ -17,12 +17,15 @@
 //   * accumulation in fp32 (AGPR/VGPR unified file), one rounding to fp16/bf16 at the store;
 //   * optional split-K (grid.z) for skinny M; partials reduced in fixed order by splitk_finalize.
 #include "mpq_dequant.cuh"
+#ifndef BIE_GEMM_LAB
+#define BIE_GEMM_LAB 0  // compile-time ablation switch used by tools/ (0 = product code)
+#endif
 
 #pragma clang fp contract(off)
 
 namespace bie {
 
-constexpr int GEMM_BN = 128;
+constexpr int GEMM_BN = 256;  // 4 waves x 64 columns
 constexpr int GEMM_BK = 64;
 
 // ---- 8-value chunk dequant -> 4 dwords (MFMA operand order) ---------------------------------------
@@ -91,16 +94,12 @@ __device__ __forceinline__ uint4_t dequant8(uint2_t raw, int c8, const ColParams
     } else {
         float q[8];
         if constexpr (WBIT == 8) {
-            q[0] = (float)(raw.x & 0xffu); q[1] = (float)((raw.x >> 8) & 0xffu);
-            q[2] = (float)((raw.x >> 16) & 0xffu); q[3] = (float)(raw.x >> 24);
-            q[4] = (float)(raw.y & 0xffu); q[5] = (float)((raw.y >> 8) & 0xffu);
-            q[6] = (float)((raw.y >> 16) & 0xffu); q[7] = (float)(raw.y >> 24);
+            q[0] = cvt_ubyte<0>(raw.x); q[1] = cvt_ubyte<1>(raw.x); q[2] = cvt_ubyte<2>(raw.x); q[3] = cvt_ubyte<3>(raw.x);
+            q[4] = cvt_ubyte<0>(raw.y); q[5] = cvt_ubyte<1>(raw.y); q[6] = cvt_ubyte<2>(raw.y); q[7] = cvt_ubyte<3>(raw.y);
         } else if constexpr (WBIT == 4) {
             const uint32_t lo = raw.x & 0x0f0f0f0fu, hi = (raw.x >> 4) & 0x0f0f0f0fu;
-            q[0] = (float)(lo & 0xffu); q[2] = (float)((lo >> 8) & 0xffu);
-            q[4] = (float)((lo >> 16) & 0xffu); q[6] = (float)(lo >> 24);
-            q[1] = (float)(hi & 0xffu); q[3] = (float)((hi >> 8) & 0xffu);
-            q[5] = (float)((hi >> 16) & 0xffu); q[7] = (float)(hi >> 24);
+            q[0] = cvt_ubyte<0>(lo); q[2] = cvt_ubyte<1>(lo); q[4] = cvt_ubyte<2>(lo); q[6] = cvt_ubyte<3>(lo);
+            q[1] = cvt_ubyte<0>(hi); q[3] = cvt_ubyte<1>(hi); q[5] = cvt_ubyte<2>(hi); q[7] = cvt_ubyte<3>(hi);
         } else {
             constexpr int CPW = 4 / WBIT;
             constexpr uint32_t CM = (1u << (8 * WBIT)) - 1u;
@@ -160,51 +159,128 @@ __device__ __forceinline__ float16_t mfma32(uint4_t a, uint4_t b, float16_t c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
-template <int DT, int WBIT, int ZM>
-struct WTile {  // one K tile (64) worth of this lane's weights + dequant constants
-    uint2_t raw[4];
-    uint32_t sb[4];
-    uint32_t zb[4];  // sym: z bits ; asym: zq + 1
+// ---- hand-issued LDS fragment reads ---------------------------------------------------------------------------
+// hipcc schedules ds_read -> MFMA pairs just-in-time through one or two register sets (every MFMA then waits a full
+// LDS round trip).  The A fragments of the NEXT k16 step are therefore issued explicitly (asm volatile keeps program
+// order), left in flight under the current step's MFMAs + dequant VALU, and collected by ONE counted wait that names
+// every destination register (so no consumer can be scheduled above it).
+template <int TM>
+__device__ __forceinline__ void lds_issue_frags(uint4_t (&af)[TM], uint32_t addr) {
+#if BIE_GEMM_LAB == 4
+#pragma unroll
+    for (int t = 0; t < TM; t++) af[t] = uint4_t{addr, addr + t, 0x3c003c00u, 0x3c003c00u};
+    return;
+#endif
+    asm volatile("ds_read_b128 %0, %1" : "=v"(af[0]) : "v"(addr));
+    if constexpr (TM > 1) asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(af[1]) : "v"(addr));
+    if constexpr (TM > 2) {
+        asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(af[2]) : "v"(addr));
+        asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(af[3]) : "v"(addr));
+    }
+    if constexpr (TM > 4) {
+        asm volatile("ds_read_b128 %0, %1 offset:16384" : "=v"(af[4]) : "v"(addr));
+        asm volatile("ds_read_b128 %0, %1 offset:20480" : "=v"(af[5]) : "v"(addr));
+        asm volatile("ds_read_b128 %0, %1 offset:24576" : "=v"(af[6]) : "v"(addr));
+        asm volatile("ds_read_b128 %0, %1 offset:28672" : "=v"(af[7]) : "v"(addr));
+    }
+}
+template <int TM>
+__device__ __forceinline__ void lds_wait_frags(uint4_t (&af)[TM]) {
+    if constexpr (TM == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0])::"memory");
+    else if constexpr (TM == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1])::"memory");
+    else if constexpr (TM == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3])::"memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)"
+                      : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]), "+v"(af[6]), "+v"(af[7])::"memory");
+}
+
+constexpr int GEMM_NF = 2;  // 32-column B fragments per wave (wave tile = BM x 64)
+
+template <int WBIT>
+struct RawChunk {
+    using type = uint32_t;
+};
+template <>
+struct RawChunk<8> {
+    using type = uint2_t;
 };
 
-template <int DT, int WBIT, int ZM>
-__device__ __forceinline__ void load_wtile(WTile<DT, WBIT, ZM>& t, const uint32_t* __restrict__ qw,
-                                           const uint16_t* __restrict__ scales, const void* __restrict__ zeros, int k0,
-                                           int h, int n, int N, int group_size) {
+template <int WBIT>
+__device__ __forceinline__ uint2_t raw_as_u2(typename RawChunk<WBIT>::type r) {
+    if constexpr (WBIT == 8) return r;
+    else return uint2_t{r, 0u};
+}
+
+// GPT ("group per tile"): group_size % 64 == 0, one (scale, zero) pair per fragment per K tile; otherwise one per
+// k16 step (group_size 16 / 32).  group_size is a power of two on this path (1 << gshift).
+template <int DT, int WBIT, int ZM, bool GPT>
+struct WTile {  // one K tile (64) worth of this lane's weights + dequant constants, per fragment
+    static constexpr int NG = GPT ? 1 : 4;
+    typename RawChunk<WBIT>::type raw[GEMM_NF][4];
+    uint32_t sb[GEMM_NF][NG];
+    uint32_t zb[GEMM_NF][NG];  // sym: z bits ; asym: packed qzeros word (field extracted at use)
+};
+
+// Per-lane base pointers (64-bit, computed once); everything added per tile / k16 step is wave-uniform, so the
+// loop's address arithmetic stays on the scalar unit (global_load ... v[base], s[offset]).
+template <int WBIT>
+struct WPtrs {
+    const uint32_t* w[GEMM_NF];    // qweight + lane row part + column
+    const uint16_t* s[GEMM_NF];    // scales + column
+    const uint16_t* z[GEMM_NF];    // fp zeros + column            (sym)
+    const uint32_t* zq[GEMM_NF];   // packed qzeros + column / NB  (asym)
+    int zshift[GEMM_NF];           // bit offset of this column's field in the qzeros word
+};
+
+template <int DT, int WBIT, int ZM, bool GPT>
+__device__ __forceinline__ void load_wtile(WTile<DT, WBIT, ZM, GPT>& t, const WPtrs<WBIT>& p, int k0, int N, int gshift) {
     constexpr int NB = 32 / WBIT;
+    constexpr int NG = GPT ? 1 : 4;
 #pragma unroll
-    for (int kk = 0; kk < 4; kk++) {
-        const int k = k0 + kk * 16 + h * 8;
-        const int c8 = k >> 3;
-        t.raw[kk] = load_chunk<WBIT>(qw, c8, n, N);
-        const int g = k / group_size;
-        t.sb[kk] = scales[(long)g * N + n];
-        if constexpr (ZM == ZM_ASYM) {
-            constexpr uint32_t M1 = (WBIT == 32) ? 0xffffffffu : ((1u << WBIT) - 1u);
-            const uint32_t zw = reinterpret_cast<const uint32_t*>(zeros)[(long)g * (N / NB) + n / NB];
-            t.zb[kk] = ((zw >> ((n % NB) * WBIT)) & M1) + 1u;
-        } else {
-            t.zb[kk] = reinterpret_cast<const uint16_t*>(zeros)[(long)g * N + n];
+    for (int f = 0; f < GEMM_NF; f++) {
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            const int c8u = (k0 >> 3) + kk * 2;  // uniform part of the chunk index (the lane adds h)
+            if constexpr (WBIT == 8) {
+                const long row = (long)(2 * c8u) * N;
+                t.raw[f][kk] = uint2_t{p.w[f][row], p.w[f][row + N]};
+            } else {
+                constexpr int CPW = 4 / WBIT;  // chunks per word: w4 1, w2 2, w1 4
+                t.raw[f][kk] = p.w[f][(long)(c8u / CPW) * N];
+            }
+        }
+#pragma unroll
+        for (int gi = 0; gi < NG; gi++) {
+            const long g = (k0 + gi * 16) >> gshift;  // group_size >= 16: both lane halves of a step share the group
+            t.sb[f][gi] = p.s[f][g * N];
+            if constexpr (ZM == ZM_ASYM) t.zb[f][gi] = p.zq[f][g * (N / NB)];
+            else t.zb[f][gi] = p.z[f][g * N];
         }
     }
 }
 
-template <int DT, int WBIT, int ZM, int BM>
-__global__ __launch_bounds__(256) void mpq_gemm_kernel(const uint16_t* __restrict__ x, const uint32_t* __restrict__ qw,
-                                                       const uint16_t* __restrict__ scales, const void* __restrict__ zeros,
-                                                       const uint16_t* __restrict__ bias, const uint16_t* __restrict__ perm,
-                                                       float* __restrict__ part, uint16_t* __restrict__ y, int M, int K, int N,
-                                                       int group_size, int tiles_per_split, int S, int m_tiles, int n_tiles) {
-    constexpr int TM = BM / 32;              // 32x32 accumulators per wave
+// One wave per SIMD (512 registers per lane: 2*TM 32x32 accumulators, double-buffered A fragments, prefetched weight
+// tiles), so the MFMA stream of a wave is covered by ITS OWN independent LDS reads / dequant VALU issued in the
+// 32-cycle MFMA shadows.  The wave tile is BM x 64: every A fragment read from LDS feeds two MFMAs, which halves the
+// LDS read traffic per flop (with BM x 32 wave tiles the LDS pipe -- 4 waves re-reading the whole x tile plus the
+// staging writes -- was as busy as the matrix pipe).
+template <int DT, int WBIT, int ZM, int BM, bool PERM, bool GPT>
+__global__ __launch_bounds__(256, 1) void mpq_gemm_kernel(const uint16_t* __restrict__ x, const uint32_t* __restrict__ qw,
+                                                          const uint16_t* __restrict__ scales, const void* __restrict__ zeros,
+                                                          const uint16_t* __restrict__ bias, const uint16_t* __restrict__ perm,
+                                                          float* __restrict__ part, uint16_t* __restrict__ y, int M, int K, int N,
+                                                          int gshift, int tiles_per_split, int S, int m_tiles, int n_tiles) {
+    constexpr int TM = BM / 32;              // 32-row accumulator tiles per wave
+    constexpr int NF = GEMM_NF;
     constexpr int A_CHUNKS = BM * 8 / 256;   // 16-byte chunks staged per thread per tile
     constexpr int A_BYTES = BM * GEMM_BK * 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, j = lane & 31;
     // XCD-aware tile order: the dispatcher places block b on XCD b % 8 (speed only, never correctness).  Give each XCD
-    // a contiguous chunk of the m-major tile order so that the ~64 blocks co-resident on an XCD share 1-2 x row-tiles
-    // (2 MB each at K=4096) in that XCD's 4 MiB L2 instead of every XCD cycling through all of x.
+    // a contiguous chunk of the m-major tile order so that the blocks co-resident on an XCD share few x row-tiles in
+    // that XCD's 4 MiB L2 instead of every XCD cycling through all of x.
     int m_tile, n_tile;
     {
         const int T = m_tiles * n_tiles;
@@ -217,106 +293,188 @@ __global__ __launch_bounds__(256) void mpq_gemm_kernel(const uint16_t* __restric
         n_tile = t - m_tile * n_tiles;
     }
     const int m0 = m_tile * BM;
-    const int n_base = n_tile * GEMM_BN + wave * 32;
-    const int n = n_base + j;
-    const int n_ld = n < N ? n : N - 1;  // clamp loads of out-of-range columns (never stored)
+    int ncol[NF], ncol_ld[NF];
+#pragma unroll
+    for (int f = 0; f < NF; f++) {
+        ncol[f] = n_tile * GEMM_BN + wave * (32 * NF) + f * 32 + j;
+        ncol_ld[f] = ncol[f] < N ? ncol[f] : N - 1;  // clamp loads of out-of-range columns (never stored)
+    }
+    WPtrs<WBIT> wp;
+    {
+        constexpr int NB = 32 / WBIT;
+        constexpr uint32_t dummy = 0;
+        (void)dummy;
+        const int hrow = (WBIT == 4) ? h : (WBIT == 8 ? 2 * h : 0);  // lane-dependent packed-row offset of chunk c8u + h
+#pragma unroll
+        for (int f = 0; f < NF; f++) {
+            const int n = ncol_ld[f];
+            wp.w[f] = qw + (long)hrow * N + n;
+            wp.s[f] = scales + n;
+            wp.z[f] = reinterpret_cast<const uint16_t*>(zeros) + n;
+            wp.zq[f] = reinterpret_cast<const uint32_t*>(zeros) + n / NB;
+            wp.zshift[f] = (n % NB) * WBIT;
+        }
+    }
     const int split = blockIdx.y;
     const int T_total = K / GEMM_BK;
     const int t_begin = split * tiles_per_split;
     int t_end = t_begin + tiles_per_split;
     if (t_end > T_total) t_end = T_total;
 
-    float16_t acc[TM];
+    float16_t acc[NF][TM];
 #pragma unroll
-    for (int t = 0; t < TM; t++)
+    for (int f = 0; f < NF; f++)
 #pragma unroll
-        for (int e = 0; e < 16; e++) acc[t][e] = 0.0f;
+        for (int t = 0; t < TM; t++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[f][t][e] = 0.0f;
 
-    // A staging assignment: chunk c = tid + i*256 -> row = c / 8, slot = c % 8
+    // A staging assignment: chunk c = tid + i*256 -> row = c / 8, slot = c % 8.  Rows past M are clamped to M-1: they
+    // are computed but never stored (branch-free loads).
     uint4_t areg[A_CHUNKS];
+    const uint16_t* arow[A_CHUNKS];
+    int aoff[A_CHUNKS];
+#pragma unroll
+    for (int i = 0; i < A_CHUNKS; i++) {
+        const int c = tid + i * 256;
+        const int row = c >> 3, s = c & 7;
+        int m = m0 + row;
+        if (m > M - 1) m = M - 1;
+        arow[i] = x + (long)m * K + (PERM ? 0 : s * 8);
+        aoff[i] = a_lds_off(row, s);
+    }
     auto load_a = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < A_CHUNKS; i++) {
-            const int c = tid + i * 256;
-            const int row = c >> 3, s = c & 7;
-            const int m = m0 + row;
-            uint4_t v = uint4_t{0u, 0u, 0u, 0u};
-            if (m < M) {
-                if (perm == nullptr) {
-                    v = *reinterpret_cast<const uint4_t*>(x + (long)m * K + (long)kt * GEMM_BK + s * 8);
-                } else {  // MBWQ act-order: gather x[m][q_perm[k]]
-                    const uint16_t* pp = perm + kt * GEMM_BK + s * 8;
-                    const uint16_t* xr = x + (long)m * K;
-                    v.x = (uint32_t)xr[pp[0]] | ((uint32_t)xr[pp[1]] << 16);
-                    v.y = (uint32_t)xr[pp[2]] | ((uint32_t)xr[pp[3]] << 16);
-                    v.z = (uint32_t)xr[pp[4]] | ((uint32_t)xr[pp[5]] << 16);
-                    v.w = (uint32_t)xr[pp[6]] | ((uint32_t)xr[pp[7]] << 16);
-                }
+            if constexpr (!PERM) {
+                areg[i] = *reinterpret_cast<const uint4_t*>(arow[i] + kt * GEMM_BK);
+            } else {  // MBWQ act-order: gather x[m][q_perm[k]]
+                const int s = (tid + i * 256) & 7;
+                const uint16_t* pp = perm + kt * GEMM_BK + s * 8;
+                const uint16_t* xr = arow[i];
+                uint4_t v;
+                v.x = (uint32_t)xr[pp[0]] | ((uint32_t)xr[pp[1]] << 16);
+                v.y = (uint32_t)xr[pp[2]] | ((uint32_t)xr[pp[3]] << 16);
+                v.z = (uint32_t)xr[pp[4]] | ((uint32_t)xr[pp[5]] << 16);
+                v.w = (uint32_t)xr[pp[6]] | ((uint32_t)xr[pp[7]] << 16);
+                areg[i] = v;
             }
-            areg[i] = v;
         }
     };
     auto store_a = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < A_CHUNKS; i++) {
-            const int c = tid + i * 256;
-            const int row = c >> 3, s = c & 7;
-            *reinterpret_cast<uint4_t*>(lds + buf * A_BYTES + a_lds_off(row, s)) = permute_a_chunk<DT, WBIT>(areg[i]);
+        for (int i = 0; i < A_CHUNKS; i++)
+            *reinterpret_cast<uint4_t*>(lds + buf * A_BYTES + aoff[i]) = permute_a_chunk<DT, WBIT>(areg[i]);
+    };
+
+    // A fragment LDS byte addresses of this lane: k16-step kk -> slot kk*2 + h of row j (+ t * 4096 bytes per 32 rows)
+    const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
+    uint32_t foff[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) foff[kk] = lds_base + (uint32_t)a_lds_off(j, kk * 2 + h);
+
+    auto dequant_step = [&](const WTile<DT, WBIT, ZM, GPT>& w, int kt, int kk, uint4_t (&bf)[NF]) {
+        constexpr uint32_t M1 = (1u << WBIT) - 1u;
+        const int gi = GPT ? 0 : kk;
+#pragma unroll
+        for (int f = 0; f < NF; f++) {
+            uint32_t zb = w.zb[f][gi];
+            if constexpr (ZM == ZM_ASYM) zb = ((zb >> wp.zshift[f]) & M1) + 1u;
+#if BIE_GEMM_LAB == 2
+            bf[f] = uint4_t{raw_as_u2<WBIT>(w.raw[f][kk]).x, w.sb[f][gi], zb, 0x3c003c00u};
+#else
+            bf[f] = dequant8<DT, WBIT, ZM>(raw_as_u2<WBIT>(w.raw[f][kk]), (kt * GEMM_BK + kk * 16 + h * 8) >> 3,
+                                           make_col_params<DT, WBIT, ZM>(w.sb[f][gi], zb));
+#endif
         }
     };
 
-    WTile<DT, WBIT, ZM> wcur, wnext;
+    WTile<DT, WBIT, ZM, GPT> wcur, wnext;
+    const int t_last = t_end - 1;
     if (t_begin < t_end) {
         load_a(t_begin);
-        load_wtile<DT, WBIT, ZM>(wcur, qw, scales, zeros, t_begin * GEMM_BK, h, n_ld, N, group_size);
+        load_wtile<DT, WBIT, ZM, GPT>(wcur, wp, t_begin * GEMM_BK, N, gshift);
         store_a(0);
     }
     __syncthreads();
 
     int cur = 0;
+    uint4_t af0[TM], af1[TM];
     for (int kt = t_begin; kt < t_end; kt++) {
-        const bool has_next = (kt + 1 < t_end);
-        if (has_next) {
-            load_a(kt + 1);
-            load_wtile<DT, WBIT, ZM>(wnext, qw, scales, zeros, (kt + 1) * GEMM_BK, h, n_ld, N, group_size);
-        }
-        const unsigned char* abuf = lds + cur * A_BYTES;
+        // Branch-free body: the look-ahead tile index is clamped to the last tile.
+        const int ktn = (kt + 1 < t_end) ? kt + 1 : t_last;
+        const uint32_t abase = (uint32_t)(cur * A_BYTES);
+        lds_issue_frags<TM>(af0, foff[0] + abase);
+#if BIE_GEMM_LAB != 5
+        load_a(ktn);
+#endif
+        load_wtile<DT, WBIT, ZM, GPT>(wnext, wp, ktn * GEMM_BK, N, gshift);
+        uint4_t bfrag[NF], bnext[NF];
+        dequant_step(wcur, kt, 0, bfrag);
+        lds_wait_frags<TM>(af0);
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
-            const ColParams<DT, ZM> cp = make_col_params<DT, WBIT, ZM>(wcur.sb[kk], wcur.zb[kk]);
-            const int c8 = (kt * GEMM_BK + kk * 16 + h * 8) >> 3;
-            const uint4_t bfrag = dequant8<DT, WBIT, ZM>(wcur.raw[kk], c8, cp);
+            // software pipeline: while the 2*TM MFMAs of step kk run, step kk+1's A fragments are in flight from LDS
+            // and its B fragments are dequantised (both independent of the MFMAs)
+            if (kk < 3) {
+                if (kk & 1) lds_issue_frags<TM>(af0, foff[kk + 1] + abase);
+                else lds_issue_frags<TM>(af1, foff[kk + 1] + abase);
+                __builtin_amdgcn_sched_barrier(0);  // keep the MFMAs below the issue point
+                dequant_step(wcur, kt, kk + 1, bnext);
+            }
 #pragma unroll
             for (int t = 0; t < TM; t++) {
-                const uint4_t afrag = *reinterpret_cast<const uint4_t*>(abuf + a_lds_off(t * 32 + j, kk * 2 + h));
-                acc[t] = mfma32<DT>(afrag, bfrag, acc[t]);
+#pragma unroll
+                for (int f = 0; f < NF; f++) {
+#if BIE_GEMM_LAB == 3
+                    acc[f][t][0] += __uint_as_float(((kk & 1) ? af1[t].x : af0[t].x) ^ bfrag[f].x ^ bfrag[f].y ^ bfrag[f].z ^ bfrag[f].w);
+#else
+                    if (kk & 1) acc[f][t] = mfma32<DT>(af1[t], bfrag[f], acc[f][t]);
+                    else acc[f][t] = mfma32<DT>(af0[t], bfrag[f], acc[f][t]);
+#endif
+                }
+            }
+            if (kk < 3) {
+                if (kk & 1) lds_wait_frags<TM>(af0);
+                else lds_wait_frags<TM>(af1);
+#pragma unroll
+                for (int f = 0; f < NF; f++) bfrag[f] = bnext[f];
             }
         }
-        if (has_next) {
-            store_a(cur ^ 1);
-            wcur = wnext;
-        }
+#if BIE_GEMM_LAB != 5
+        store_a(cur ^ 1);
+#endif
+        wcur = wnext;
+#if BIE_GEMM_LAB != 6
         __syncthreads();
+#endif
         cur ^= 1;
     }
 
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
-    if (n < N) {
-        float bv = 0.0f;
-        const bool use_bias = (S == 1) && (bias != nullptr);
-        if (use_bias) bv = dt_traits<DT>::load(bias, n);
+#if BIE_GEMM_LAB == 1
+    if (acc[0][0][0] == 123.456f)
+#endif
 #pragma unroll
-        for (int t = 0; t < TM; t++) {
+    for (int f = 0; f < NF; f++) {
+        const int n = ncol[f];
+        if (n < N) {
+            float bv = 0.0f;
+            const bool use_bias = (S == 1) && (bias != nullptr);
+            if (use_bias) bv = dt_traits<DT>::load(bias, n);
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int row = m0 + t * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (row < M) {
-                    if (S == 1) {
-                        float o = dt_traits<DT>::round(acc[t][e]);
-                        if (use_bias) o = o + bv;
-                        dt_traits<DT>::store(y, (long)row * N + n, o);
-                    } else {
-                        part[((long)split * M + row) * N + n] = acc[t][e];
+            for (int t = 0; t < TM; t++) {
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int row = m0 + t * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (row < M) {
+                        if (S == 1) {
+                            float o = dt_traits<DT>::round(acc[f][t][e]);
+                            if (use_bias) o = o + bv;
+                            dt_traits<DT>::store(y, (long)row * N + n, o);
+                        } else {
+                            part[((long)split * M + row) * N + n] = acc[f][t][e];
+                        }
                     }
                 }
             }
@@ -346,11 +504,13 @@ static GemmPlan plan_gemm(int M, int K, int N) {
     return p;
 }
 
+static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
 bool mpq_gemm_ok(int M, int K, int N, int w_bit, int group_size, int dtype, bool has_gidx) {
     if (dtype != BIE_F16 && dtype != BIE_BF16) return false;
     if (has_gidx) return false;
-    const int gs = group_size > K ? K : group_size;
-    if (K % GEMM_BK || gs % 8) return false;
+    if (K % GEMM_BK) return false;
+    if (group_size < K && !(is_pow2(group_size) && group_size >= 16)) return false;
     if (N % (32 / w_bit)) return false;
     return true;
 }
@@ -361,16 +521,21 @@ size_t mpq_gemm_workspace_bytes(int M, int K, int N) {
     return p.S > 1 ? (size_t)p.S * M * N * sizeof(float) : 0;
 }
 
-template <int DT, int WBIT, int ZM>
-static int gemm_launch_bm(const GemmPlan& p, const void* x, const int32_t* qw, const void* scales, const void* zeros,
-                          const void* bias, const uint16_t* perm, float* part, void* y, int M, int K, int N, int group_size, hipStream_t st) {
-    const int m_tiles = cdiv(M, p.BM), n_tiles = cdiv(N, GEMM_BN);
+struct GemmArgs {
+    const void* x; const int32_t* qw; const void* scales; const void* zeros; const void* bias; const uint16_t* perm;
+    float* part; void* y; int M, K, N, gshift;
+    hipStream_t st;
+};
+
+template <int DT, int WBIT, int ZM, bool PERM, bool GPT>
+static int gemm_launch_bm(const GemmPlan& p, const GemmArgs& a) {
+    const int m_tiles = cdiv(a.M, p.BM), n_tiles = cdiv(a.N, GEMM_BN);
     dim3 grid(m_tiles * n_tiles, p.S);
     const size_t lds = (size_t)2 * p.BM * GEMM_BK * 2;
-#define L(BMV)                                                                                                        \
-    hipLaunchKernelGGL((mpq_gemm_kernel<DT, WBIT, ZM, BMV>), grid, dim3(256), lds, st, (const uint16_t*)x,           \
-                       (const uint32_t*)qw, (const uint16_t*)scales, zeros, (const uint16_t*)bias, perm, part, (uint16_t*)y, \
-                       M, K, N, group_size, p.tiles_per_split, p.S, m_tiles, n_tiles)
+#define L(BMV)                                                                                                          \
+    hipLaunchKernelGGL((mpq_gemm_kernel<DT, WBIT, ZM, BMV, PERM, GPT>), grid, dim3(256), lds, a.st, (const uint16_t*)a.x, \
+                       (const uint32_t*)a.qw, (const uint16_t*)a.scales, a.zeros, (const uint16_t*)a.bias, a.perm, a.part, \
+                       (uint16_t*)a.y, a.M, a.K, a.N, a.gshift, p.tiles_per_split, p.S, m_tiles, n_tiles)
     switch (p.BM) {
         case 32: L(32); break;
         case 64: L(64); break;
@@ -381,24 +546,19 @@ static int gemm_launch_bm(const GemmPlan& p, const void* x, const int32_t* qw, c
     return check_launch("mpq_gemm_kernel");
 }
 
-template <int DT, int WBIT>
-static int gemm_launch_a(const GemmPlan& p, int zm, const void* x, const int32_t* qw, const void* scales,
-                         const void* zeros, const void* bias, const uint16_t* perm, float* part, void* y, int M, int K, int N, int group_size,
-                         hipStream_t st) {
-    if (zm == ZM_ASYM) return gemm_launch_bm<DT, WBIT, ZM_ASYM>(p, x, qw, scales, zeros, bias, perm, part, y, M, K, N, group_size, st);
-    if (zm == ZM_FUSED) return gemm_launch_bm<DT, WBIT, ZM_FUSED>(p, x, qw, scales, zeros, bias, perm, part, y, M, K, N, group_size, st);
-    return gemm_launch_bm<DT, WBIT, ZM_SYM>(p, x, qw, scales, zeros, bias, perm, part, y, M, K, N, group_size, st);
+template <int DT, int WBIT, int ZM, bool PERM>
+static int gemm_launch_g(const GemmPlan& p, const GemmArgs& a, bool gpt) {
+    return gpt ? gemm_launch_bm<DT, WBIT, ZM, PERM, true>(p, a) : gemm_launch_bm<DT, WBIT, ZM, PERM, false>(p, a);
 }
 
-template <int DT>
-static int gemm_launch_w(const GemmPlan& p, int w_bit, int zm, const void* x, const int32_t* qw, const void* scales,
-                         const void* zeros, const void* bias, const uint16_t* perm, float* part, void* y, int M, int K, int N, int group_size,
-                         hipStream_t st) {
+// MPQ flavours: {f16, bf16} x {1,2,4,8} x {sym, asym}, no x gather
+template <int DT, int ZM>
+static int gemm_launch_mpq_w(const GemmPlan& p, const GemmArgs& a, int w_bit, bool gpt) {
     switch (w_bit) {
-        case 1: return gemm_launch_a<DT, 1>(p, zm, x, qw, scales, zeros, bias, perm, part, y, M, K, N, group_size, st);
-        case 2: return gemm_launch_a<DT, 2>(p, zm, x, qw, scales, zeros, bias, perm, part, y, M, K, N, group_size, st);
-        case 4: return gemm_launch_a<DT, 4>(p, zm, x, qw, scales, zeros, bias, perm, part, y, M, K, N, group_size, st);
-        default: return gemm_launch_a<DT, 8>(p, zm, x, qw, scales, zeros, bias, perm, part, y, M, K, N, group_size, st);
+        case 1: return gemm_launch_g<DT, 1, ZM, false>(p, a, gpt);
+        case 2: return gemm_launch_g<DT, 2, ZM, false>(p, a, gpt);
+        case 4: return gemm_launch_g<DT, 4, ZM, false>(p, a, gpt);
+        default: return gemm_launch_g<DT, 8, ZM, false>(p, a, gpt);
     }
 }
 
@@ -406,12 +566,30 @@ int mpq_gemm_launch(const void* x, const int32_t* qw, const void* scales, const 
                     float* part, int M, int K, int N, int w_bit, int group_size, int zm, int dtype, const uint16_t* perm,
                     hipStream_t st) {
     const GemmPlan p = plan_gemm(M, K, N);
-    const int gs = group_size > K ? K : group_size;
+    int gshift = 31;  // group_size >= K: a single group
+    bool gpt = true;
+    if (group_size < K) {
+        gshift = 0;
+        while ((1 << gshift) < group_size) gshift++;
+        gpt = (group_size % GEMM_BK) == 0;
+    }
+    const GemmArgs a{x, qw, scales, zeros, bias, perm, part, y, M, K, N, gshift, st};
     int rc;
-    if (dtype == BIE_F16)
-        rc = gemm_launch_w<BIE_F16>(p, w_bit, zm, x, qw, scales, zeros, bias, perm, part, y, M, K, N, gs, st);
-    else
-        rc = gemm_launch_w<BIE_BF16>(p, w_bit, zm, x, qw, scales, zeros, bias, perm, part, y, M, K, N, gs, st);
+    if (zm == ZM_FUSED) {  // MBWQ uniform: fp16, 2/4 bit, optional q_perm gather
+        if (dtype != BIE_F16 || !(w_bit == 2 || w_bit == 4)) {
+            set_error("mpq_gemm_launch: fused-rounding (MBWQ) mode needs fp16 and 2/4-bit weights");
+            return BIE_ERR_UNSUPPORTED;
+        }
+        if (w_bit == 4) rc = perm ? gemm_launch_g<BIE_F16, 4, ZM_FUSED, true>(p, a, gpt) : gemm_launch_g<BIE_F16, 4, ZM_FUSED, false>(p, a, gpt);
+        else rc = perm ? gemm_launch_g<BIE_F16, 2, ZM_FUSED, true>(p, a, gpt) : gemm_launch_g<BIE_F16, 2, ZM_FUSED, false>(p, a, gpt);
+    } else {
+        if (perm) {
+            set_error("mpq_gemm_launch: q_perm is only supported in MBWQ mode");
+            return BIE_ERR_UNSUPPORTED;
+        }
+        if (dtype == BIE_F16) rc = zm == ZM_ASYM ? gemm_launch_mpq_w<BIE_F16, ZM_ASYM>(p, a, w_bit, gpt) : gemm_launch_mpq_w<BIE_F16, ZM_SYM>(p, a, w_bit, gpt);
+        else rc = zm == ZM_ASYM ? gemm_launch_mpq_w<BIE_BF16, ZM_ASYM>(p, a, w_bit, gpt) : gemm_launch_mpq_w<BIE_BF16, ZM_SYM>(p, a, w_bit, gpt);
+    }
     if (rc) return rc;
     if (p.S > 1) return launch_splitk_finalize(part, bias, y, p.S, M, N, dtype, st);
     return BIE_OK;

@@ -19,6 +19,11 @@
 
 namespace bie {
 
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
 constexpr int GEMV_THREADS = 256;
 constexpr int GEMV_COLS = 256;  // columns per block: 64 lanes x 4
 constexpr int GEMV_COUNTER_FLOATS = 1024;  // head of the workspace: one arrival counter per column tile (4 KiB)
@@ -28,7 +33,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void mpq_gemv_kernel(
     const uint16_t* __restrict__ x, const uint32_t* __restrict__ qw, const uint16_t* __restrict__ scales,
     const void* __restrict__ zeros, const uint16_t* __restrict__ bias, const uint16_t* __restrict__ perm,
     float* __restrict__ part, unsigned* __restrict__ counters, uint16_t* __restrict__ y, int M, int K, int N,
-    int group_size, int rows_per_slab, int R, int S) {
+    int group_size, int rows_per_slab, int R, int S, int lab) {
     constexpr int NB = 32 / WBIT;
     constexpr int NP = NB / 2;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -107,6 +112,11 @@ __global__ __launch_bounds__(GEMV_THREADS) void mpq_gemv_kernel(
                     for (int c = 0; c < 4; c++) cp[c] = make_col_params<DT, WBIT, ZM>(sb[c], zb[c]);
                 }
             }
+            if (lab) {
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                    if (r + u < rw_end) acc[0][0] += __uint_as_float((wq[u].x ^ wq[u].y ^ wq[u].z ^ wq[u].w) & 0x3f7fffffu);
+            } else
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 if (r + u < rw_end) {
@@ -209,6 +219,249 @@ __global__ __launch_bounds__(GEMV_THREADS) void mpq_gemv_kernel(
     }
 }
 
+// =====================================================================================================
+// v3 decode kernel: one COLUMN per lane, a wave owns 64 columns x a contiguous K range.
+//   * the activations of a packed row are wave-uniform -> the compiler fetches them with scalar loads
+//     (s_load_dwordx4, scalar cache) and feeds v_dot2 from SGPRs: no LDS staging, no barrier in front of
+//     the weight stream;
+//   * each lane streams dwords (a wave-row = 256 contiguous bytes), 16 loads in flight per lane, double
+//     buffered; the block's NW waves split K, are reduced through LDS, and when the grid would be too
+//     small the K range is additionally split over blockIdx.y with the ticketed (sc1) last-arriver sum.
+// =====================================================================================================
+constexpr int G3_U = 8;  // rows per batch; two batches (16 row loads) in flight per lane
+
+template <int DT, int WBIT>
+__device__ __forceinline__ void load_x_pairs(const uint16_t* __restrict__ xrow, uint32_t (&xp)[16 / WBIT]) {
+    // xrow points at the NB activations of one packed row (wave-uniform address -> scalar loads); pair order
+    constexpr int NB = 32 / WBIT, NP = NB / 2;
+    const uint32_t* xd = reinterpret_cast<const uint32_t*>(xrow);
+    uint32_t d[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) d[i] = xd[i];
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const int ka = pair_src_k<DT, WBIT>(2 * i), kb = pair_src_k<DT, WBIT>(2 * i + 1);
+        const uint32_t a = (ka & 1) ? (d[ka >> 1] >> 16) : (d[ka >> 1] & 0xffffu);
+        const uint32_t b = (kb & 1) ? (d[kb >> 1] & 0xffff0000u) : (d[kb >> 1] << 16);
+        xp[i] = a | b;
+    }
+}
+
+// Requirements (checked by the launcher): R % 8 == 0, rows_per_wave % 8 == 0, rows-per-group % 8 == 0, so that a
+// batch of 8 rows is all-or-nothing and lies inside one quantisation group.
+template <int DT, int WBIT, int MT, int ZM, int NW>
+__global__ __launch_bounds__(NW * 64) void mpq_gemv3_kernel(
+    const uint16_t* __restrict__ x, const uint32_t* __restrict__ qw, const uint16_t* __restrict__ scales,
+    const void* __restrict__ zeros, const uint16_t* __restrict__ bias, float* __restrict__ part,
+    unsigned* __restrict__ counters, uint16_t* __restrict__ y, int M, int K, int N, int rows_per_group, int rows_per_wave,
+    int R, int S, int lab) {
+    constexpr int NB = 32 / WBIT;
+    constexpr int NP = NB / 2;
+    constexpr int U = G3_U;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = blockIdx.x * 64 + lane;
+    const int nl = n < N ? n : N - 1;  // clamp: out-of-range lanes load valid memory and are never stored
+    const int slab = blockIdx.y;
+    const int rb = (slab * NW + wave) * rows_per_wave;
+    int re = rb + rows_per_wave;
+    if (re > R) re = R;
+
+    float acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; m++) acc[m] = 0.0f;
+
+    const uint32_t* wcol = qw + nl;
+    auto load_batch = [&](uint32_t (&dst)[U], int r) {
+#pragma unroll
+        for (int u = 0; u < U; u++) dst[u] = __builtin_nontemporal_load(wcol + (long)(r + u) * N);
+    };
+    const int zero_width = N / NB;
+    auto load_params = [&](int g, uint32_t& sb, uint32_t& zb) {
+        sb = scales[(long)g * N + nl];
+        if constexpr (ZM == ZM_ASYM) {
+            constexpr uint32_t M1 = (WBIT == 32) ? 0xffffffffu : ((1u << WBIT) - 1u);
+            const uint32_t zw = reinterpret_cast<const uint32_t*>(zeros)[(long)g * zero_width + nl / NB];
+            zb = ((zw >> ((nl % NB) * WBIT)) & M1) + 1u;
+        } else {
+            zb = reinterpret_cast<const uint16_t*>(zeros)[(long)g * N + nl];
+        }
+    };
+
+    ColParams<DT, ZM> cp;
+    uint32_t sb_next = 0, zb_next = 0;
+    int g_cur = -1;
+    int switch_row = rb;  // first row of the next group
+    const int g_last = (R - 1) / rows_per_group;
+    auto compute_batch = [&](const uint32_t (&w)[U], int r) {
+        if (r >= switch_row) {  // wave-uniform; a batch never straddles a group
+            const int g = r / rows_per_group;
+            uint32_t sb, zb;
+            if (g == g_cur + 1 && g_cur >= 0) { sb = sb_next; zb = zb_next; }
+            else load_params(g, sb, zb);
+            cp = make_col_params<DT, WBIT, ZM>(sb, zb);
+            g_cur = g;
+            switch_row = (g + 1) * rows_per_group;
+            if (g < g_last) load_params(g + 1, sb_next, zb_next);  // prefetch the next group's constants
+        }
+        if (lab) {  // tuning aid (BIE_GEMV_LAB=1): stream only, no dequant / dot -- measures the memory side alone
+#pragma unroll
+            for (int u = 0; u < U; u++) acc[0] += __uint_as_float(w[u] & 0x3f7fffffu);
+            return;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            uint32_t wp[NP];
+            dequant_word<DT, WBIT, ZM>(w[u], cp, wp);
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                if (m < M) {
+                    uint32_t xp[NP];
+                    load_x_pairs<DT, WBIT>(x + (long)m * K + (long)(r + u) * NB, xp);
+#pragma unroll
+                    for (int i = 0; i < NP; i++) acc[m] = dot2_acc<DT>(wp[i], xp[i], acc[m]);
+                }
+            }
+        }
+    };
+
+    if (rb < re) {
+        uint32_t wa[U], wb[U];
+        load_batch(wa, rb);
+        for (int r = rb; r < re; r += 2 * U) {
+            const bool has_b = r + U < re;
+            if (has_b) load_batch(wb, r + U);
+            compute_batch(wa, r);
+            if (r + 2 * U < re) load_batch(wa, r + 2 * U);
+            if (has_b) compute_batch(wb, r + U);
+        }
+    }
+
+    // ---- block reduction over the NW waves (fixed order) ----------------------------------------------------
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int m = 0; m < MT; m++) red[(wave * MT + m) * 64 + lane] = acc[m];
+    __syncthreads();
+    // thread t < 64*MT handles (m = t / 64, column = t % 64)
+    const int om = tid >> 6, ol = tid & 63;
+    const int on = blockIdx.x * 64 + ol;
+    const bool owner = (tid < 64 * MT) && (om < M) && (on < N);
+    float tot = 0.0f;
+    if (tid < 64 * MT) {
+#pragma unroll
+        for (int w = 0; w < NW; w++) tot += red[(w * MT + om) * 64 + ol];
+    }
+    if (S == 1) {
+        if (owner) {
+            float o = dt_traits<DT>::round(tot);
+            if (bias) o = o + dt_traits<DT>::load(bias, on);
+            dt_traits<DT>::store(y, (long)om * N + on, o);
+        }
+        return;
+    }
+    if (owner) __hip_atomic_store(part + ((long)slab * M + om) * N + on, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned ticket = __hip_atomic_fetch_add(counters + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        smem[0] = ticket;
+    }
+    __syncthreads();
+    if (smem[0] != (unsigned)(S - 1)) return;
+    if (tid == 0) __hip_atomic_store(counters + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (owner) {
+        float v = 0.0f;
+        for (int s0 = 0; s0 < S; s0 += 8) {
+            float t[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++) {
+                const int sidx = (s0 + jj < S) ? s0 + jj : S - 1;
+                t[jj] = __hip_atomic_load(part + ((long)sidx * M + om) * N + on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++)
+                if (s0 + jj < S) v += t[jj];
+        }
+        float o = dt_traits<DT>::round(v);
+        if (bias) o = o + dt_traits<DT>::load(bias, on);
+        dt_traits<DT>::store(y, (long)om * N + on, o);
+    }
+}
+
+struct Gemv3Plan {
+    int NW, S, rows_per_wave;
+};
+
+// S (and with it the workspace) depends on (K, N, w_bit) only.
+static Gemv3Plan plan_gemv3(int K, int N, int w_bit) {
+    static const int nw_env = env_int("BIE_GEMV3_NW", 16);
+    static const int blocks_env = env_int("BIE_GEMV3_MIN_BLOCKS", 160);
+    const int NB = 32 / w_bit;
+    const int R = K / NB;
+    Gemv3Plan p;
+    p.NW = nw_env == 8 ? 8 : 16;
+    const int tiles = cdiv(N, 64);
+    int S = 1;
+    if (tiles < blocks_env) S = cdiv(blocks_env, tiles);
+    int rpw = cdiv(cdiv(R, p.NW * S), 8) * 8;  // whole batches of 8 rows
+    if (rpw < 8) rpw = 8;
+    p.rows_per_wave = rpw;
+    p.S = cdiv(R, rpw * p.NW);
+    return p;
+}
+
+template <int DT, int WBIT, int MT, int ZM>
+static int launch_gemv3(const Gemv3Plan& pl, const void* x, const int32_t* qw, const void* scales, const void* zeros,
+                        const void* bias, float* ws, void* y, int M, int K, int N, int group_size, hipStream_t st) {
+    constexpr int NB = 32 / WBIT;
+    const int R = K / NB;
+    dim3 grid(cdiv(N, 64), pl.S);
+    float* part = ws + GEMV_COUNTER_FLOATS;
+    unsigned* counters = reinterpret_cast<unsigned*>(ws);
+    static const int lab = env_int("BIE_GEMV_LAB", 0);
+#define BIE_G3(NWV)                                                                                                    \
+    hipLaunchKernelGGL((mpq_gemv3_kernel<DT, WBIT, MT, ZM, NWV>), grid, dim3(NWV * 64), (size_t)NWV * MT * 64 * sizeof(float), \
+                       st, (const uint16_t*)x, (const uint32_t*)qw, (const uint16_t*)scales, zeros, (const uint16_t*)bias,  \
+                       part, counters, (uint16_t*)y, M, K, N, (group_size > K ? K : group_size) / NB, pl.rows_per_wave, R, pl.S, lab)
+    if (pl.NW == 8) BIE_G3(8); else BIE_G3(16);
+#undef BIE_G3
+    return check_launch("mpq_gemv3_kernel");
+}
+
+template <int DT, int WBIT, int ZM>
+static int launch_gemv3_m(const Gemv3Plan& pl, int MT, const void* x, const int32_t* qw, const void* scales, const void* zeros,
+                          const void* bias, float* ws, void* y, int M, int K, int N, int group_size, hipStream_t st) {
+    switch (MT) {
+        case 1: return launch_gemv3<DT, WBIT, 1, ZM>(pl, x, qw, scales, zeros, bias, ws, y, M, K, N, group_size, st);
+        case 2: return launch_gemv3<DT, WBIT, 2, ZM>(pl, x, qw, scales, zeros, bias, ws, y, M, K, N, group_size, st);
+        case 4: return launch_gemv3<DT, WBIT, 4, ZM>(pl, x, qw, scales, zeros, bias, ws, y, M, K, N, group_size, st);
+        default: return launch_gemv3<DT, WBIT, 8, ZM>(pl, x, qw, scales, zeros, bias, ws, y, M, K, N, group_size, st);
+    }
+}
+
+template <int DT, int WBIT>
+static int launch_gemv3_z(const Gemv3Plan& pl, int MT, int zm, const void* x, const int32_t* qw, const void* scales,
+                          const void* zeros, const void* bias, float* ws, void* y, int M, int K, int N, int group_size,
+                          hipStream_t st) {
+    if (zm == ZM_ASYM) return launch_gemv3_m<DT, WBIT, ZM_ASYM>(pl, MT, x, qw, scales, zeros, bias, ws, y, M, K, N, group_size, st);
+    if (zm == ZM_FUSED) return launch_gemv3_m<DT, WBIT, ZM_FUSED>(pl, MT, x, qw, scales, zeros, bias, ws, y, M, K, N, group_size, st);
+    return launch_gemv3_m<DT, WBIT, ZM_SYM>(pl, MT, x, qw, scales, zeros, bias, ws, y, M, K, N, group_size, st);
+}
+
+template <int DT>
+static int launch_gemv3_w(const Gemv3Plan& pl, int MT, int w_bit, int zm, const void* x, const int32_t* qw, const void* scales,
+                          const void* zeros, const void* bias, float* ws, void* y, int M, int K, int N, int group_size,
+                          hipStream_t st) {
+    switch (w_bit) {
+        case 1: return launch_gemv3_z<DT, 1>(pl, MT, zm, x, qw, scales, zeros, bias, ws, y, M, K, N, group_size, st);
+        case 2: return launch_gemv3_z<DT, 2>(pl, MT, zm, x, qw, scales, zeros, bias, ws, y, M, K, N, group_size, st);
+        case 4: return launch_gemv3_z<DT, 4>(pl, MT, zm, x, qw, scales, zeros, bias, ws, y, M, K, N, group_size, st);
+        default: return launch_gemv3_z<DT, 8>(pl, MT, zm, x, qw, scales, zeros, bias, ws, y, M, K, N, group_size, st);
+    }
+}
+
 // ---- generic fallback: any N, any group size, explicit g_idx (act-order), fp32 too ---------------
 // One column per lane, one slab of k per block.y, scalar dequant.  Correctness path, not a fast path.
 template <int DT>
@@ -279,10 +532,11 @@ static int launch_gemv_u(const GemvPlan& pl, const void* x, const int32_t* qw, c
     size_t lds = (size_t)MT * pl.rows_per_slab * NB * 2;
     const size_t red = (size_t)4 * MT * GEMV_COLS * sizeof(float);
     if (lds < red) lds = red;
+    static const int lab = env_int("BIE_GEMV_LAB", 0);
 #define BIE_GEMV_LAUNCH(UU)                                                                                      \
     hipLaunchKernelGGL((mpq_gemv_kernel<DT, WBIT, MT, ZM, UU>), grid, dim3(GEMV_THREADS), lds, st,              \
                        (const uint16_t*)x, (const uint32_t*)qw, (const uint16_t*)scales, zeros, (const uint16_t*)bias, perm, \
-                       part + GEMV_COUNTER_FLOATS, reinterpret_cast<unsigned*>(part), (uint16_t*)y, M, K, N, group_size, pl.rows_per_slab, R, pl.S)
+                       part + GEMV_COUNTER_FLOATS, reinterpret_cast<unsigned*>(part), (uint16_t*)y, M, K, N, group_size, pl.rows_per_slab, R, pl.S, lab)
     switch (pl.U) {
         case 8: BIE_GEMV_LAUNCH(8); break;
         case 4: BIE_GEMV_LAUNCH(4); break;
@@ -341,7 +595,10 @@ bool mpq_gemv_fast_ok(int M, int K, int N, int w_bit, int group_size, int dtype,
 size_t mpq_gemv_workspace_bytes(int M, int K, int N, int w_bit) {
     const int MT = M <= 1 ? 1 : (M <= 2 ? 2 : (M <= 4 ? 4 : 8));
     const GemvPlan pl = plan_gemv(K, N, w_bit, K, MT);
-    const size_t fast = pl.S > 1 ? (size_t)pl.S * M * N * sizeof(float) + GEMV_COUNTER_FLOATS * sizeof(float) : 0;
+    size_t fast = pl.S > 1 ? (size_t)pl.S * M * N * sizeof(float) + GEMV_COUNTER_FLOATS * sizeof(float) : 0;
+    const Gemv3Plan p3 = plan_gemv3(K, N, w_bit);
+    const size_t fast3 = p3.S > 1 ? (size_t)p3.S * M * N * sizeof(float) + GEMV_COUNTER_FLOATS * sizeof(float) : 0;
+    if (fast3 > fast) fast = fast3;
     const size_t generic = (size_t)cdiv(K, 512) * M * N * sizeof(float);
     return fast > generic ? fast : generic;
 }
@@ -350,6 +607,14 @@ int mpq_gemv_launch(const void* x, const int32_t* qw, const void* scales, const 
                     float* part, int M, int K, int N, int w_bit, int group_size, int zm, int dtype, const uint16_t* perm,
                     hipStream_t st) {
     const int MT = M <= 1 ? 1 : (M <= 2 ? 2 : (M <= 4 ? 4 : 8));
+    static const int use_v3 = env_int("BIE_GEMV_V3", 1);
+    const int NBv = 32 / w_bit;
+    const int rpg = (group_size > K ? K : group_size) / NBv;
+    if (perm == nullptr && use_v3 && (K / NBv) % 8 == 0 && rpg % 8 == 0 && (K & 1) == 0) {
+        const Gemv3Plan p3 = plan_gemv3(K, N, w_bit);
+        if (dtype == BIE_F16) return launch_gemv3_w<BIE_F16>(p3, MT, w_bit, zm, x, qw, scales, zeros, bias, part, y, M, K, N, group_size, st);
+        return launch_gemv3_w<BIE_BF16>(p3, MT, w_bit, zm, x, qw, scales, zeros, bias, part, y, M, K, N, group_size, st);
+    }
     const GemvPlan pl = plan_gemv(K, N, w_bit, group_size, MT);
     int rc;
     if (dtype == BIE_F16)
