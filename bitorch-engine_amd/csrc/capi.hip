@@ -100,9 +100,12 @@ int bie_mpq_forward(const void* x, const int32_t* qweight, const void* scales, c
     float* head = reinterpret_cast<float*>(workspace);
     float* part = head + WS_HEAD / sizeof(float);
     const bool has_gidx = g_idx != nullptr;
-    if (M <= 8 && mpq_gemv_fast_ok(M, K, N, w_bit, group_size, dtype, has_gidx))
+    // M <= 2: the dot2 GEMV; 3 <= M: the MFMA kernel (its dequant cost does not grow with M; measured faster from M = 3).
+    // The GEMV also serves M <= 8 for shapes the MFMA tiling cannot take.
+    const bool gemm_ok = mpq_gemm_ok(M, K, N, w_bit, group_size, dtype, has_gidx);
+    if (M <= 8 && (M <= 2 || !gemm_ok) && mpq_gemv_fast_ok(M, K, N, w_bit, group_size, dtype, has_gidx))
         return mpq_gemv_launch(x, qweight, scales, zeros, bias, y, head, M, K, N, w_bit, group_size, asym ? 1 : 0, dtype, nullptr, st);
-    if (mpq_gemm_ok(M, K, N, w_bit, group_size, dtype, has_gidx))
+    if (gemm_ok)
         return mpq_gemm_launch(x, qweight, scales, zeros, bias, y, part, M, K, N, w_bit, group_size, asym ? 1 : 0, dtype, nullptr, st);
     // generic path (explicit g_idx / odd shapes / fp32), GENERIC_M_CHUNK rows at a time
     const size_t esz = dtype == BIE_F32 ? 4 : 2;

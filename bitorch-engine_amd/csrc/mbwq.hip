@@ -245,9 +245,10 @@ int mbwq_exl2_dequant_launch(const int32_t* qw, const void* scales, const void* 
 int mbwq_q4_forward_launch(const void* x, const int32_t* qw, const void* scales, const void* zeros, const int16_t* perm,
                            void* y, float* part, int M, int K, int N, int bits, int group_size, hipStream_t st) {
     const uint16_t* p = (const uint16_t*)perm;
-    if (M <= 8 && mpq_gemv_fast_ok(M, K, N, bits, group_size, BIE_F16, false))
+    const bool gemm_ok = mpq_gemm_ok(M, K, N, bits, group_size, BIE_F16, false);
+    if (M <= 8 && (M <= 2 || !gemm_ok) && mpq_gemv_fast_ok(M, K, N, bits, group_size, BIE_F16, false))
         return mpq_gemv_launch(x, qw, scales, zeros, nullptr, y, part, M, K, N, bits, group_size, 2, BIE_F16, p, st);
-    if (mpq_gemm_ok(M, K, N, bits, group_size, BIE_F16, false))
+    if (gemm_ok)
         return mpq_gemm_launch(x, qw, scales, zeros, nullptr, y, part + 1024, M, K, N, bits, group_size, 2, BIE_F16, p, st);
     set_error("bie_mbwq_q4_forward: unsupported shape M=%d K=%d N=%d bits=%d group_size=%d (need K %% 64 == 0, N %% 4 == 0)", M,
               K, N, bits, group_size);

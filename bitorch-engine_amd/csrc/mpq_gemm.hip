@@ -429,8 +429,8 @@ __global__ __launch_bounds__(256, 1) void mpq_gemm_kernel(const uint16_t* __rest
 #if BIE_GEMM_LAB == 3
                     acc[f][t][0] += __uint_as_float(((kk & 1) ? af1[t].x : af0[t].x) ^ bfrag[f].x ^ bfrag[f].y ^ bfrag[f].z ^ bfrag[f].w);
 #else
-                    if (kk & 1) acc[f][t] = mfma32<DT>(af1[t], bfrag[f], acc[f][t]);
-                    else acc[f][t] = mfma32<DT>(af0[t], bfrag[f], acc[f][t]);
+                    if (kk & 1) acc[f][t] = mfma32<DT>(bfrag[f], af1[t], acc[f][t]);
+                    else acc[f][t] = mfma32<DT>(bfrag[f], af0[t], acc[f][t]);
 #endif
                 }
             }
@@ -451,30 +451,43 @@ __global__ __launch_bounds__(256, 1) void mpq_gemm_kernel(const uint16_t* __rest
         cur ^= 1;
     }
 
-    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    // ---- epilogue.  The MFMAs were issued as D = W_frag (A operand, rows = n) x x_frag (B operand, cols = m), so in the
+    // 32x32 C/D layout (col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)) a lane holds ONE output row m = t*32 + j
+    // and, per group of four registers, FOUR CONSECUTIVE columns n = 8*q + 4*h + (0..3): one 8-byte store per group
+    // (4 per tile instead of 16 two-byte stores); the two lane halves complete 16 contiguous bytes per row.
 #if BIE_GEMM_LAB == 1
     if (acc[0][0][0] == 123.456f)
 #endif
 #pragma unroll
     for (int f = 0; f < NF; f++) {
-        const int n = ncol[f];
-        if (n < N) {
-            float bv = 0.0f;
-            const bool use_bias = (S == 1) && (bias != nullptr);
-            if (use_bias) bv = dt_traits<DT>::load(bias, n);
+        const int nf0 = n_tile * GEMM_BN + wave * (32 * NF) + f * 32;  // first column of this fragment (wave-uniform)
+        const bool use_bias = (S == 1) && (bias != nullptr);
 #pragma unroll
-            for (int t = 0; t < TM; t++) {
+        for (int t = 0; t < TM; t++) {
+            const int row = m0 + t * 32 + j;
 #pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    const int row = m0 + t * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    if (row < M) {
-                        if (S == 1) {
-                            float o = dt_traits<DT>::round(acc[f][t][e]);
-                            if (use_bias) o = o + bv;
-                            dt_traits<DT>::store(y, (long)row * N + n, o);
-                        } else {
-                            part[((long)split * M + row) * N + n] = acc[f][t][e];
+            for (int q = 0; q < 4; q++) {
+                const int n0 = nf0 + 8 * q + 4 * h;
+                if (row < M && n0 < N) {  // N % 4 == 0 on this path: a group of 4 columns is all-or-nothing
+                    if (S == 1) {
+                        float o[4];
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            o[c] = dt_traits<DT>::round(acc[f][t][4 * q + c]);
+                            if (use_bias) o[c] = o[c] + dt_traits<DT>::load(bias, n0 + c);
                         }
+                        uint2_t pk;
+                        if constexpr (DT == BIE_F16) {
+                            pk.x = f32_to_f16_bits(o[0]) | (f32_to_f16_bits(o[1]) << 16);
+                            pk.y = f32_to_f16_bits(o[2]) | (f32_to_f16_bits(o[3]) << 16);
+                        } else {
+                            pk.x = pack_bf16x2(o[0], o[1]);
+                            pk.y = pack_bf16x2(o[2], o[3]);
+                        }
+                        *reinterpret_cast<uint2_t*>(y + (long)row * N + n0) = pk;
+                    } else {
+                        float4_t v = {acc[f][t][4 * q], acc[f][t][4 * q + 1], acc[f][t][4 * q + 2], acc[f][t][4 * q + 3]};
+                        *reinterpret_cast<float4_t*>(part + ((long)split * M + row) * N + n0) = v;
                     }
                 }
             }
@@ -511,7 +524,7 @@ bool mpq_gemm_ok(int M, int K, int N, int w_bit, int group_size, int dtype, bool
     if (has_gidx) return false;
     if (K % GEMM_BK) return false;
     if (group_size < K && !(is_pow2(group_size) && group_size >= 16)) return false;
-    if (N % (32 / w_bit)) return false;
+    if (N % (32 / w_bit) || (N & 3)) return false;
     return true;
 }
 
