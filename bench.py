@@ -101,7 +101,7 @@ def main():
     layers = [make_layer(dev, gen) for _ in range(LAYERS)]
     x = torch.randn((1, K), generator=gen).to(torch.bfloat16).to(dev)
     y_all = torch.empty((LAYERS, N), dtype=torch.bfloat16, device=dev)  # row l = output of layer l
-    gathered = torch.empty((world, LAYERS, N), dtype=torch.bfloat16, device=dev) if distributed else None
+    gathered = torch.empty((world * LAYERS, N), dtype=torch.bfloat16, device=dev) if distributed else None  # rank-major
     ws_bytes = L.bie_mpq_workspace_bytes(1, K, N, WBIT)
     ws = torch.zeros(max(ws_bytes, 16), dtype=torch.uint8, device=dev)  # 4 KiB head of split-K counters starts at zero
 
