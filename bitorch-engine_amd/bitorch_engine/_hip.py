@@ -43,6 +43,9 @@ SIGNATURES = {
     "bie_q4_pack": (_i, [_vp, _vp, _l, _vp]),
     "bie_q4_unpack": (_i, [_vp, _vp, _l, _vp]),
     "bie_q4_unpack_scale": (_i, [_vp, _vp, _l, _f, _vp]),
+    "bie_q4_quantize_pack": (_i, [_vp, _vp, _l, _f, _i, _vp]),
+    "bie_q4_gemm": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _i, _l, _l, _l, _vp]),
+    "bie_q8_gemm": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _vp]),
 }
 
 

@@ -1,1 +1,1 @@
-from .layer import MPQWeightParameter, MPQLinearBase
+from .layer import MPQWeightParameter, MPQLinearBase, nBitLinearBase, nBitLinearParameter

@@ -106,3 +106,51 @@ class MPQLinearBase(nn.Module):
 
     def prepare_params(self) -> None:
         raise NotImplementedError("Subclasses should implement this method.")
+
+
+class nBitLinearParameter(nn.Parameter):
+    def __new__(cls, data: torch.Tensor = None, requires_grad: bool = False):
+        if data is not None and not data.is_floating_point():
+            requires_grad = False
+        return super().__new__(cls, data, requires_grad=requires_grad)
+
+    @staticmethod
+    def update(qweight, *args, **kwargs):
+        raise NotImplementedError("nBitLinearParameter.update (training) is outside the inference hot path of this build")
+
+
+class nBitLinearBase(nn.Module):
+    """Base of the W-n / A-n integer layers (W4A4, W8A8); mirror of reference nbit/layer.py:122-280."""
+
+    def __init__(self, in_channels: int, out_channels: int, a_bit: int = 4, w_bit: int = 4, device=None, dtype=torch.float) -> None:
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.device, self.dtype, self.a_bit, self.w_bit = device, dtype, a_bit, w_bit
+        self.qweight = None
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        w = torch.empty((self.out_channels, self.in_channels))
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        self.weight = nn.Parameter(w)
+
+    def set_weight_data(self, x: torch.Tensor) -> None:
+        self.weight = nn.Parameter(x, requires_grad=False)
+
+    def prepare_params(self) -> None:
+        raise NotImplementedError("Subclasses should implement this method.")
+
+    def set_quantized_weight_data(self, x: torch.Tensor) -> None:
+        self.qweight = nn.Parameter(x, requires_grad=False)
+
+    def generate_quantized_weight(self, qweight_only: bool = False) -> None:
+        raise NotImplementedError("Subclasses should implement this method.")
+
+    def _check_forward(self, x: torch.Tensor) -> None:
+        raise NotImplementedError("Subclasses should implement this method.")
+
+    @property
+    def opt_weight(self):
+        if not self.training and self.qweight is None:
+            self.generate_quantized_weight()
+        return self.weight if self.training else self.qweight

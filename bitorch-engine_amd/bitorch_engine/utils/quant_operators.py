@@ -45,3 +45,17 @@ def q4_quantization(input: torch.Tensor, scale_a: torch.Tensor = None, eps: torc
     scale_a = torch.where(scale_a > eps, scale_a, eps)
     q = (x / scale_a).round().clamp(-8, 7)
     return (q, scale_a) if derive else q
+
+
+def q8_quantization(input: torch.Tensor, scale_a: torch.Tensor = None, eps: torch.Tensor = None):
+    """Symmetric 8-bit quantisation clamp(round(x / scale), -128, 127); returns (q, scale) when the scale is derived here
+    (2*mean|x| / 11.269), else q (reference :234-271)."""
+    derive = scale_a is None
+    x = input.to(torch.float32)
+    if derive:
+        scale_a = 2 * x.abs().mean() / 11.269
+    if eps is None:
+        eps = torch.tensor(0.00001, dtype=x.dtype, device=x.device)
+    scale_a = torch.where(scale_a > eps, scale_a, eps.to(scale_a.dtype))
+    q = (x / scale_a).round().clamp(-128, 127)
+    return (q, scale_a) if derive else q

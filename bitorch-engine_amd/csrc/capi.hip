@@ -50,6 +50,10 @@ int unpack_u8_scaled_launch(const uint8_t* in, const float* scale, float* out, l
 int q4_pack_launch(const int32_t* in, int8_t* out, long n_out, hipStream_t st);
 int q4_unpack_launch(const int8_t* in, int32_t* out, long n_in, hipStream_t st);
 int q4_unpack_scale_launch(const int8_t* in, float* out, long n_in, float scale, hipStream_t st);
+// intgemm.hip
+int int_gemm_launch(int mode, const void* A, const void* W, void* y, int M, int N, int K, float sa, float sw, int dtype, int batch,
+                    long strideA, long strideW, long strideY, hipStream_t st);
+int q4_quantize_pack_launch(const void* x, int8_t* out, long n_out, float scale, int dtype, hipStream_t st);
 }  // namespace bie
 
 using namespace bie;
@@ -286,6 +290,28 @@ int bie_q4_unpack(const int8_t* in, int32_t* out, long n_in, void* stream) {
 int bie_q4_unpack_scale(const int8_t* in, float* out, long n_in, float scale, void* stream) {
     BIE_REQUIRE(in && out && n_in > 0, BIE_ERR_INVALID_ARG, "bie_q4_unpack_scale: bad argument");
     return q4_unpack_scale_launch(in, out, n_in, scale, as_stream(stream));
+}
+
+
+// ---------------------------------------------------------------------------------------------- W4A4 / W8A8
+int bie_q4_quantize_pack(const void* x, int8_t* out, long n_out, float scale, int dtype, void* stream) {
+    BIE_REQUIRE(x && out && n_out > 0, BIE_ERR_INVALID_ARG, "bie_q4_quantize_pack: bad argument");
+    BIE_REQUIRE(dtype >= 0 && dtype <= 2, BIE_ERR_UNSUPPORTED, "bie_q4_quantize_pack: tensor type not supported: %d", dtype);
+    return q4_quantize_pack_launch(x, out, n_out, scale, dtype, as_stream(stream));
+}
+
+int bie_q4_gemm(const int8_t* a_packed, const int8_t* w_packed, void* y, int M, int N, int K, float scale_a, float scale_w,
+                int dtype, int batch, long stride_a, long stride_w, long stride_y, void* stream) {
+    BIE_REQUIRE(a_packed && w_packed && y && M > 0 && N > 0 && K > 0 && batch > 0, BIE_ERR_INVALID_ARG, "bie_q4_gemm: bad argument");
+    BIE_REQUIRE(K % 64 == 0 && N % 4 == 0, BIE_ERR_UNSUPPORTED, "bie_q4_gemm: K=%d must be a multiple of 64 and N=%d of 4", K, N);
+    BIE_REQUIRE(dtype >= 0 && dtype <= 2, BIE_ERR_UNSUPPORTED, "bie_q4_gemm: tensor type not supported: %d", dtype);
+    return int_gemm_launch(0, a_packed, w_packed, y, M, N, K, scale_a, scale_w, dtype, batch, stride_a, stride_w, stride_y, as_stream(stream));
+}
+
+int bie_q8_gemm(const int8_t* a, const int8_t* w, float* y, int M, int N, int K, float scale_a, float scale_w, void* stream) {
+    BIE_REQUIRE(a && w && y && M > 0 && N > 0 && K > 0, BIE_ERR_INVALID_ARG, "bie_q8_gemm: bad argument");
+    BIE_REQUIRE(K % 64 == 0 && N % 4 == 0, BIE_ERR_UNSUPPORTED, "bie_q8_gemm: K=%d must be a multiple of 64 and N=%d of 4", K, N);
+    return int_gemm_launch(1, a, w, y, M, N, K, scale_a, scale_w, BIE_F32, 1, 0, 0, 0, as_stream(stream));
 }
 
 }  // extern "C"

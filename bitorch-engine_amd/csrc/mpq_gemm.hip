@@ -273,6 +273,7 @@ __global__ __launch_bounds__(256, 1) void mpq_gemm_kernel(const uint16_t* __rest
     constexpr int NF = GEMM_NF;
     constexpr int A_CHUNKS = BM * 8 / 256;   // 16-byte chunks staged per thread per tile
     constexpr int A_BYTES = BM * GEMM_BK * 2;
+    constexpr int VALU_PER_MFMA = ((DT == BIE_BF16 ? 48 : 28) + TM - 1) / TM;  // dequant VALU of NF fragments spread over TM*NF MFMAs
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -435,6 +436,14 @@ __global__ __launch_bounds__(256, 1) void mpq_gemm_kernel(const uint16_t* __rest
                 }
             }
             if (kk < 3) {
+                // One wave per SIMD issues in order: an MFMA issued while the matrix pipe is busy blocks everything
+                // behind it, so the next step's dequant VALU must sit BETWEEN this step's MFMAs (1 MFMA : ~7 others fills
+                // the 32-cycle MFMA shadow) -- ask the scheduler for exactly that interleave.
+#pragma unroll
+                for (int i = 0; i < TM * NF; i++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);  // then VALU
+                }
                 if (kk & 1) lds_wait_frags<TM>(af0);
                 else lds_wait_frags<TM>(af1);
 #pragma unroll

@@ -328,14 +328,18 @@ __global__ __launch_bounds__(NW * 64) void mpq_gemv3_kernel(
     };
 
     if (rb < re) {
-        uint32_t wa[U], wb[U];
+        // three batches (24 row loads, 6 KiB per wave) in flight: the HBM stream keeps running while a batch is
+        // dequantised
+        uint32_t wa[U], wb[U], wc[U];
         load_batch(wa, rb);
-        for (int r = rb; r < re; r += 2 * U) {
-            const bool has_b = r + U < re;
-            if (has_b) load_batch(wb, r + U);
+        if (rb + U < re) load_batch(wb, rb + U);
+        for (int r = rb; r < re; r += 3 * U) {
+            if (r + 2 * U < re) load_batch(wc, r + 2 * U);
             compute_batch(wa, r);
-            if (r + 2 * U < re) load_batch(wa, r + 2 * U);
-            if (has_b) compute_batch(wb, r + U);
+            if (r + 3 * U < re) load_batch(wa, r + 3 * U);
+            if (r + U < re) compute_batch(wb, r + U);
+            if (r + 4 * U < re) load_batch(wb, r + 4 * U);
+            if (r + 2 * U < re) compute_batch(wc, r + 2 * U);
         }
     }
 

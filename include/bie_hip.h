@@ -176,6 +176,27 @@ int bie_q4_unpack(const int8_t* in, int32_t* out, long n_in, void* stream);
 /* int8 -> two sign-extended nibbles * scale, fp32 (q4_unpack_and_scaling, :184-207) */
 int bie_q4_unpack_scale(const int8_t* in, float* out, long n_in, float scale, void* stream);
 
+/* ------------------------------------------------------------------------------------------ */
+/* W4A4 / W8A8 integer GEMM (the reference's CUTLASS int4 / int8 path) */
+/* ------------------------------------------------------------------------------------------ */
+
+/* q = clamp(round_half_away(x / max(scale, 1e-5)), -8, 7), two values per int8, FIRST value in the
+ * high nibble.  Replaces q4_quantization_and_bit_packing_kernel / q_linear_cutlass.q4_w_pack
+ * (layers/qlinear/nbit/cutlass/q4_linear_cutlass_kernel.cu:74-170, 418-470). */
+int bie_q4_quantize_pack(const void* x, int8_t* out, long n_out, float scale, int dtype, void* stream);
+
+/* y[b][M, N] (dtype) = fl( fl( sum_k a[m][k] * w[n][k] ) * fl(scale_a * scale_w) ) on nibble-packed operands
+ * a [batch][M, K/2], w [batch][N, K/2] (K % 64 == 0, N % 4 == 0); batch strides in elements of each tensor.
+ * Replaces q_linear_cutlass.q4_forward / q4_matmul (q4_linear_cutlass_kernel.cu:520-680). */
+int bie_q4_gemm(const int8_t* a_packed, const int8_t* w_packed, void* y, int M, int N, int K, float scale_a,
+                float scale_w, int dtype, int batch, long stride_a, long stride_w, long stride_y,
+                void* stream);
+
+/* y[M, N] fp32 = ((float) sum_k a[m][k] * w[n][k]) * scale_a * scale_w on int8 operands a [M, K], w [N, K].
+ * Replaces q_linear_cutlass.q8_forward (q8_linear_cutlass_kernel.cu:186-230). */
+int bie_q8_gemm(const int8_t* a, const int8_t* w, float* y, int M, int N, int K, float scale_a, float scale_w,
+                void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -262,6 +262,23 @@ def main():
     kat_expected = np.array([-1] * 8 + [-1, -1, -1, +1, -1, -1, -1, -1][::-1] + [-1, -1, +1, -1, -1, -1, +1, +1][::-1] + [1] * 8, np.float32)
     np.savez_compressed(os.path.join(OUT, "kat_unpack_uint8.npz"), bytes=kat_bytes, expected=kat_expected)
 
+    # ------------------------------------------------------------------ 5. W4A4 / W8A8 quantisers (python reference)
+    # utils/quant_operators.py:234-305.  The CUDA kernels round half AWAY from zero (roundf) where torch.round is
+    # half-to-even, so exact .5 ties are excluded from the vectors (flagged in `tie`).
+    from bitorch_engine.utils.quant_operators import q4_quantization, q8_quantization
+    qq = {}
+    x = torch.randn((24, 64), generator=g) * 1.7
+    eps = torch.tensor(0.00001)
+    q4d, s4 = q4_quantization(x, None, eps)
+    q8d, s8 = q8_quantization(x, None, eps)
+    sa = torch.tensor(0.37)
+    qq["x"], qq["q4_derived"], qq["scale4"], qq["q8_derived"], qq["scale8"] = tonp(x), tonp(q4d), tonp(s4), tonp(q8d), tonp(s8)
+    qq["scale_given"] = tonp(sa)
+    qq["q4_given"], qq["q8_given"] = tonp(q4_quantization(x, sa, eps)), tonp(q8_quantization(x, sa, eps))
+    r = x / s4
+    qq["tie"] = tonp((r - r.floor()) == 0.5)
+    np.savez_compressed(os.path.join(OUT, "q4_q8_quantization.npz"), **qq)
+
     with open(os.path.join(OUT, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))

@@ -235,3 +235,27 @@ def q4_unpack_scale(p, scale):
     out = np.empty(p.size * 2, dtype=np.float32)
     lib().orc_q4_unpack_scale(_p(p), _p(out), ctypes.c_long(p.size), ctypes.c_float(scale))
     return out.reshape(p.shape[:-1] + (p.shape[-1] * 2,))
+
+
+def q4_quantize_pack(x, scale, dt):
+    x = _c(x)
+    out = np.empty(x.shape[:-1] + (x.shape[-1] // 2,), dtype=np.int8)
+    lib().orc_q4_quantize_pack(_p(x), _p(out), ctypes.c_long(out.size), ctypes.c_float(scale), dt)
+    return out
+
+
+def q4_gemm(a, w, K, scale_a, scale_w, dt):
+    a, w = _c(a, np.int8), _c(w, np.int8)
+    M, N = a.shape[0], w.shape[0]
+    y = _out((M, N), dt)
+    lib().orc_q4_gemm(_p(a), _p(w), _p(y), M, N, K, ctypes.c_float(scale_a), ctypes.c_float(scale_w), dt)
+    return y
+
+
+def q8_gemm(a, w, scale_a, scale_w):
+    a, w = _c(a, np.int8), _c(w, np.int8)
+    M, K = a.shape
+    N = w.shape[0]
+    y = np.empty((M, N), dtype=np.float32)
+    lib().orc_q8_gemm(_p(a), _p(w), _p(y), M, N, K, ctypes.c_float(scale_a), ctypes.c_float(scale_w))
+    return y

@@ -431,3 +431,99 @@ def test_c_abi_error_codes_on_device():
     assert rc == -2 and b"w_bit" in L.bie_last_error()
     rc = L.bie_mpq_forward(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), None, None, x.data_ptr(), None, 0, 1, 4096, 4096, 4, 128, 0, 0, None)
     assert rc == -3 and b"workspace" in L.bie_last_error()
+
+
+# ------------------------------------------------------------------ W4A4 / W8A8 on the i8 matrix cores
+_TDT = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16", "f32"])
+def test_q4_quantize_pack_bit_exact(dt):
+    from bitorch_engine.extensions import q_linear_cutlass as qc
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn((37, 192), generator=g) * 2).to(_TDT[dt])
+    x[0, :8] = torch.tensor([0.5, -0.5, 1.5, -1.5, 2.5, 100.0, -100.0, 0.0]).to(_TDT[dt])  # ties and clamps
+    for scale in (1.0, 0.37, 1e-7):
+        want = orc.q4_quantize_pack(orc.torch_to_np(x), scale, orc.dt_code(_TDT[dt]))
+        got = qc.q4_w_pack(x.to(DEV), scale).cpu().numpy()
+        assert np.array_equal(got, want), (dt, scale)
+    # transposed weights ([k, n] storage)
+    got = qc.q4_w_pack(x.t().contiguous().to(DEV), 0.37, True).cpu().numpy()
+    assert np.array_equal(got, orc.q4_quantize_pack(orc.torch_to_np(x), 0.37, orc.dt_code(_TDT[dt])))
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16", "f32"])
+@pytest.mark.parametrize("M,N,K", [(1, 4, 64), (5, 36, 128), (128, 128, 256), (130, 260, 192), (257, 124, 1024)])
+def test_q4_forward_bit_exact_vs_oracle(dt, M, N, K):
+    from bitorch_engine.extensions import q_linear_cutlass as qc
+    g = torch.Generator().manual_seed(M * 131 + N)
+    x = torch.randn((M, K), generator=g).to(_TDT[dt])
+    w = (torch.randn((N, K), generator=g) * 0.05).to(_TDT[dt])
+    sa, sw = float(2 * x.float().abs().mean() / 11.269), float(2 * w.float().abs().mean() / 5.6345)
+    code = orc.dt_code(_TDT[dt])
+    pa, pw = orc.q4_quantize_pack(orc.torch_to_np(x), sa, code), orc.q4_quantize_pack(orc.torch_to_np(w), sw, code)
+    want = orc.q4_gemm(pa, pw, K, sa, sw, code)
+    out, qa, qw = qc.q4_forward(x.to(DEV), w.to(DEV), torch.tensor(sa), torch.tensor(sw), False, False)
+    assert np.array_equal(qa.cpu().numpy(), pa) and np.array_equal(qw.cpu().numpy(), pw)
+    assert np.array_equal(orc.torch_to_np(out), want)
+    # the packed-weight (inference) call gives the same bits, as the reference's own test asserts (test_nbit_linear.py:69)
+    out2 = qc.q4_forward(x.to(DEV), qw, sa, sw, False, False)[0]
+    assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 4, 64), (33, 100, 320), (256, 384, 512), (129, 132, 4096)])
+def test_q8_forward_bit_exact_vs_oracle(M, N, K):
+    from bitorch_engine.extensions import q_linear_cutlass as qc
+    rng = np.random.default_rng(M + N)
+    a = rng.integers(-128, 128, (M, K)).astype(np.int8)
+    w = rng.integers(-128, 128, (N, K)).astype(np.int8)
+    want = orc.q8_gemm(a, w, 0.013, 0.0021)
+    got = qc.q8_forward(torch.from_numpy(a).to(DEV), torch.from_numpy(w).to(DEV), False, torch.tensor(0.013), torch.tensor(0.0021))
+    assert np.array_equal(got.cpu().numpy(), want)
+    got_t = qc.q8_forward(torch.from_numpy(a).to(DEV), torch.from_numpy(w).t().contiguous().to(DEV), True, 0.013, 0.0021)
+    assert torch.equal(got, got_t)
+
+
+def test_q4_matmul_batched_vs_oracle():
+    from bitorch_engine.extensions import q_linear_cutlass as qc
+    g = torch.Generator().manual_seed(3)
+    B, H, S, D = 2, 3, 40, 64
+    x = torch.randn((B, H, S, D), generator=g).half()
+    y = torch.randn((B, H, 72, D), generator=g).half()
+    out, qx, qy = qc.q4_matmul(x.to(DEV), y.to(DEV), torch.tensor(0.3), torch.tensor(0.4))
+    assert out.shape == (B, H, S, 72)
+    for b in range(B):
+        for h in range(H):
+            pa = orc.q4_quantize_pack(orc.torch_to_np(x[b, h]), 0.3, orc.F16)
+            pb = orc.q4_quantize_pack(orc.torch_to_np(y[b, h]), 0.4, orc.F16)
+            assert np.array_equal(qx[b, h].cpu().numpy(), pa)
+            assert np.array_equal(orc.torch_to_np(out[b, h]), orc.q4_gemm(pa, pb, D, 1.0, 1.0, orc.F16))
+
+
+def test_q4_q8_cutlass_layers_train_eval_equivalence():
+    """The reference's own check (tests/layers/test_nbit_linear.py:28-69, 149-190): the layer evaluated from its packed
+    weight gives exactly the result computed from the float weight, and tracks the float linear layer."""
+    from bitorch_engine.layers.qlinear.nbit.cutlass import Q4LinearCutlass, Q8LinearCutlass
+    torch.manual_seed(0)
+    x = torch.randn((48, 512)).half()
+    for cls, tol in ((Q4LinearCutlass, 0.5), (Q8LinearCutlass, 0.05)):
+        layer = cls(in_channels=512, out_channels=256, dtype=torch.half).to(DEV)
+        layer.prepare_params()
+        wfloat = layer.weight.data.clone()
+        with torch.no_grad():
+            y = layer.train()(x.to(DEV))  # float weight quantised inside the call
+        layer.generate_quantized_weight(qweight_only=True)
+        assert layer.weight is None and layer.qweight.dtype == torch.int8
+        y2 = layer.eval()(x.to(DEV))
+        assert torch.equal(y, y2)
+        ref = x.float() @ wfloat.float().cpu().t()
+        rel = (y.float().cpu() - ref).norm() / ref.norm()
+        assert rel < tol, (cls.__name__, float(rel))
+
+
+def test_q4_gemm_error_codes():
+    from bitorch_engine import _hip
+    a = torch.zeros((4, 24), dtype=torch.int8, device=DEV)
+    y = torch.zeros((4, 4), dtype=torch.float16, device=DEV)
+    rc = _hip.lib().bie_q4_gemm(_hip.ptr(a), _hip.ptr(a), _hip.ptr(y), 4, 4, 48, 1.0, 1.0, 0, 1, 0, 0, 0, None)
+    assert rc != 0 and b"multiple of 64" in _hip.lib().bie_last_error()

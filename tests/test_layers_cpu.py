@@ -112,3 +112,28 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cuh")):
                 text = open(os.path.join(root, f), errors="ignore").read()
                 assert "oracle" not in text.replace("# oracle", ""), f"{f} mentions the oracle"
+
+
+def test_q8_quantization_matches_reference_vectors():
+    import numpy as np
+    import os
+    from bitorch_engine.utils.quant_operators import q8_quantization
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "q4_q8_quantization.npz"))
+    x = torch.from_numpy(z["x"])
+    q, s = q8_quantization(x, None, torch.tensor(0.00001))
+    assert np.array_equal(q.numpy(), z["q8_derived"]) and float(s) == float(z["scale8"])
+    q = q8_quantization(x, torch.tensor(float(z["scale_given"])), torch.tensor(0.00001))
+    assert np.array_equal(q.numpy(), z["q8_given"])
+
+
+def test_cutlass_layer_classes_mirror_reference_api():
+    from bitorch_engine.layers.qlinear.nbit.cutlass import Q4LinearCutlass, Q8LinearCutlass, Q4MatMul
+    l4 = Q4LinearCutlass(in_channels=64, out_channels=32, dtype=torch.half)
+    assert l4.weight.shape == (32, 64) and l4.bias_a.shape == (64,) and float(l4.scale_a) == 0
+    l4.prepare_params()
+    assert abs(float(l4.scale_w) - float(2 * l4.weight.abs().mean() / 5.6345)) < 1e-6
+    l8 = Q8LinearCutlass(in_channels=64, out_channels=32)
+    l8.eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        l4.eval()(torch.randn(2, 64).half())
+    assert Q4MatMul(dtype=torch.half).x_clip.dtype == torch.half

@@ -158,3 +158,35 @@ def test_q4_pack_roundtrip_and_sign_extension():
     assert np.array_equal(orc.q4_unpack_scale(p, 0.5), a.astype(np.float32) * 0.5)
     # first element lands in the HIGH nibble (functions_cuda_kernel.cu:137-159)
     assert orc.q4_pack(np.array([[1, 2]], np.int32)).view(np.uint8)[0, 0] == 0x12
+
+
+# ------------------------------------------------------------------ W4A4 / W8A8
+def _unpack_hi_lo(p):
+    u = p.astype(np.uint8)
+    hi, lo = (u >> 4).astype(np.int32), (u & 15).astype(np.int32)
+    hi[hi > 7] -= 16
+    lo[lo > 7] -= 16
+    return np.stack([hi, lo], axis=-1).reshape(p.shape[:-1] + (p.shape[-1] * 2,))
+
+
+def test_q4_quantize_pack_matches_reference_quantiser():
+    z = np.load(os.path.join(GOLDEN, "q4_q8_quantization.npz"))
+    x = z["x"]
+    for scale, want in ((float(z["scale4"]), z["q4_derived"]), (float(z["scale_given"]), z["q4_given"])):
+        got = _unpack_hi_lo(orc.q4_quantize_pack(x, scale, orc.F32))
+        r = x / np.float32(scale)
+        keep = (r - np.floor(r)) != 0.5  # CUDA roundf (half away) vs torch.round (half even) differ only on ties
+        assert np.array_equal(got[keep], want.astype(np.int32)[keep])
+
+
+def test_q4_q8_gemm_oracle_is_exact_integer_gemm():
+    rng = np.random.default_rng(5)
+    M, N, K = 7, 12, 128
+    a4, w4 = rng.integers(-8, 8, (M, K)), rng.integers(-8, 8, (N, K))
+    pa = ((a4[:, 0::2] & 15) << 4 | (a4[:, 1::2] & 15)).astype(np.uint8).view(np.int8)
+    pw = ((w4[:, 0::2] & 15) << 4 | (w4[:, 1::2] & 15)).astype(np.uint8).view(np.int8)
+    y = orc.q4_gemm(pa, pw, K, 0.5, 0.25, orc.F32)
+    assert np.array_equal(y, (a4 @ w4.T).astype(np.float32) * np.float32(0.125))
+    a8, w8 = rng.integers(-128, 128, (M, K)).astype(np.int8), rng.integers(-128, 128, (N, K)).astype(np.int8)
+    y8 = orc.q8_gemm(a8, w8, 0.5, 0.25)
+    assert np.array_equal(y8, (a8.astype(np.int64) @ w8.astype(np.int64).T).astype(np.float32) * np.float32(0.125))
