@@ -72,6 +72,16 @@ def cpu_baseline(budget_s=12.0):
             "sample": f"{n} of {LAYERS} layer GEMVs (M=1, 4096x11008 w4 g128 bf16), oracle/bie_oracle.c orc_mpq_forward_f32acc, OpenMP"}
 
 
+def pmc_traffic():
+    """HBM bytes per GEMV launch from the committed PMC passes (profiles/r01_pmc_gemv.json, produced by tools/gpu_final.sh:
+    separate FETCH_SIZE and WRITE_SIZE passes, corrected as DESIGN.md section 6 describes); None when the file is absent."""
+    p = os.path.join(ROOT, "profiles", "r01_pmc_gemv.json")
+    try:
+        return json.load(open(p))["gemv_hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,8 +180,8 @@ def main():
             "config": {"workload": "BASELINE.json configs[1]: W4A16 qlinear 4096x11008 g128 bf16, M=1 decode pass over 64 distinct layers (1.44 GB of packed weights, HIP-graph replay)",
                        "layers_per_step": LAYERS, "parallelism": "output-column sharding x%d + 1 all-gather/step" % world if distributed else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "bie::mpq_gemv_kernel<bf16,w4,M=1>", "avg_launch_us": round(avg_us, 3),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(),
+                         "kernel": "bie::mpq_gemv3_kernel<bf16,w4,M=1> (in-kernel split-K, no finalize launch)", "avg_launch_us": round(avg_us, 3),
                          "alg_bytes_per_launch": alg_bytes(1)},
         }
 
@@ -204,7 +214,7 @@ def main():
         tf = 2.0 * M * K * N / (us * 1e-6) / 1e12
         out["gemm"] = {"M": M, "us_per_call": round(us, 2), "TFLOP/s": round(tf, 1), "GB/s_algorithmic": round(alg_bytes(M) / (us * 1e-6) / 1e9, 1)}
         out["roofline_gemm"] = {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "traffic": None, "kernel": "bie::mpq_gemm_kernel<bf16,w4,BM=256>"}
+                                "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "traffic": None, "kernel": "bie::mpq_gemm_kernel<bf16,w4,256x256x64 tile>"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

@@ -506,7 +506,7 @@ def test_q4_q8_cutlass_layers_train_eval_equivalence():
     from bitorch_engine.layers.qlinear.nbit.cutlass import Q4LinearCutlass, Q8LinearCutlass
     torch.manual_seed(0)
     x = torch.randn((48, 512)).half()
-    for cls, tol in ((Q4LinearCutlass, 0.5), (Q8LinearCutlass, 0.05)):
+    for cls, tol in ((Q4LinearCutlass, 0.5), (Q8LinearCutlass, 0.1)):
         layer = cls(in_channels=512, out_channels=256, dtype=torch.half).to(DEV)
         layer.prepare_params()
         wfloat = layer.weight.data.clone()
