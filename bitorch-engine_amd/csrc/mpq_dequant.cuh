@@ -11,8 +11,12 @@
 // chosen per (dtype, WBIT) so that the extraction is cheapest:
 //   fp16 : dword i = (k=i, k=i+NB/2)  -- one v_and_or_b32 per pair with the 0x6400 magic
 //          ((q | 0x6400) is the fp16 number 1024+q), then v_pk_add/mul/add_f16.
-//   bf16 : no packed bf16 ALU on gfx950, so values go through fp32: byte-sliced
-//          v_cvt_f32_ubyteN, v_pk_mul_f32, v_cvt_pk_bf16_f32 (RNE) twice.
+//   bf16 : no packed bf16 ALU on gfx950, so values go through fp32.  The byte-sliced fields (0..15) are read as
+//          fp8 e4m3: bytes 0x00..0x0f are the subnormals and the first normal binade, i.e. exactly q * 2^-9, so
+//          v_cvt_pk_f32_fp8 turns two fields into two floats in ONE instruction (measured on gfx950,
+//          tools/probe/probe_cvt.hip); the factor 2^9 is folded into the scale (exact).  Then v_pk_mul_f32,
+//          v_cvt_pk_bf16_f32 (RNE), and for the second rounding of ZM_SYM v_dot2_f32_bf16 with a (1,0) / (0,1)
+//          selector and C = -z as a fused unpack-and-subtract.  W8 keeps v_cvt_f32_ubyteN.
 //          dword index p = 2*i + ph holds values (2ph)*(8/WBIT)+i and (2ph+1)*(8/WBIT)+i.
 // The activation vector is staged in the same order (`pair_src_k`), so the order is invisible
 // outside the kernel.
@@ -36,6 +40,30 @@ __host__ __device__ constexpr int pair_src_k(int p) {
     }
 }
 
+// bf16 pair (1, 0) or (0, 1) in a VGPR, opaque to the optimiser (as immediates hipcc mis-encodes them, probe_cvt.hip)
+template <int HI>
+__device__ __forceinline__ uint32_t sel_lo_hi() {
+    uint32_t v;
+    if constexpr (HI == 0) asm("v_mov_b32 %0, 0x3f80" : "=v"(v));
+    else asm("v_mov_b32 %0, 0x3f800000" : "=v"(v));
+    return v;
+}
+
+// fl32(t - z) of the four bf16 values in two packed pairs, ONE instruction each: 1*t.lo + 0*t.hi + (-z) on the dot unit
+// (v_dot2_f32_bf16 with the (1,0) / (0,1) selectors) instead of unpack (2 ops) + v_pk_add_f32 (1 op) per pair.
+// The VOP3P form is spelled out because hipcc otherwise picks v_dot2c (accumulator tied to the destination) and pays a
+// v_mov_b32 per use to seed it.  gfx940+ needs 3 wait states between a DOT write and a different VALU reading it, and
+// the hazard recogniser cannot see into inline asm -- so the block carries its own s_nop (3 cycles per 4 values).
+__device__ __forceinline__ void bf16_pairs_sub(uint32_t t0, uint32_t t1, uint32_t sel0, uint32_t sel1, float neg_z, float (&r)[4]) {
+    asm("v_dot2_f32_bf16 %0, %4, %6, %8\n\t"
+        "v_dot2_f32_bf16 %1, %4, %7, %8\n\t"
+        "v_dot2_f32_bf16 %2, %5, %6, %8\n\t"
+        "v_dot2_f32_bf16 %3, %5, %7, %8\n\t"
+        "s_nop 2"
+        : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
+        : "v"(t0), "v"(t1), "v"(sel0), "v"(sel1), "v"(neg_z));
+}
+
 // byte B of v -> float (v_cvt_f32_ubyteB).  hipcc folds the shift/mask forms back into per-value v_bfe + ubyte0,
 // so the instruction is named explicitly (plain asm: schedulable, no side effects).
 template <int B>
@@ -54,11 +82,12 @@ template <int DT, int ZM> struct ColParams;
 template <> struct ColParams<BIE_F16, ZM_SYM> { half2_t s2, z2; };
 template <> struct ColParams<BIE_F16, ZM_FUSED> { half2_t s2, z2; };
 template <> struct ColParams<BIE_F16, ZM_ASYM> { half2_t s2, zoff2; };  // zoff = 1024 + (zq + 1)
-template <> struct ColParams<BIE_BF16, ZM_SYM> { float s, z; };
+template <> struct ColParams<BIE_BF16, ZM_SYM> { float s, z, nz; uint32_t sel0, sel1; };  // s carries 2^9 when FP8READ
 template <> struct ColParams<BIE_BF16, ZM_FUSED> { float s, z; };
 template <> struct ColParams<BIE_BF16, ZM_ASYM> { float s, zq1; };
 
-template <int DT, int WBIT, int ZM>
+// FP8READ: the consumer reads the fields as fp8 (q * 2^-9, see dequant_word), so the factor 2^9 goes into s / zq1
+template <int DT, int WBIT, int ZM, bool FP8READ = (WBIT < 8)>
 __device__ __forceinline__ ColParams<DT, ZM> make_col_params(uint32_t s_bits, uint32_t z_bits_or_zq1) {
     ColParams<DT, ZM> p;
     if constexpr (DT == BIE_F16) {
@@ -72,9 +101,11 @@ __device__ __forceinline__ ColParams<DT, ZM> make_col_params(uint32_t s_bits, ui
             p.z2 = half2_t{z, z};
         }
     } else {
-        p.s = bf16_bits_to_f32(s_bits);
-        if constexpr (ZM == ZM_ASYM) p.zq1 = (float)z_bits_or_zq1;
+        constexpr float QS = FP8READ ? 512.0f : 1.0f;
+        p.s = bf16_bits_to_f32(s_bits) * QS;
+        if constexpr (ZM == ZM_ASYM) p.zq1 = (float)z_bits_or_zq1 * (1.0f / QS);
         else p.z = bf16_bits_to_f32(z_bits_or_zq1);
+        if constexpr (ZM == ZM_SYM) { p.nz = -p.z; p.sel0 = sel_lo_hi<0>(); p.sel1 = sel_lo_hi<1>(); }
     }
     return p;
 }
@@ -111,24 +142,28 @@ __device__ __forceinline__ void dequant_word(uint32_t w, const ColParams<DT, ZM>
         for (int i = 0; i < VPB; i++) {
             const uint32_t t = (w >> (WBIT * i)) & BMASK;  // bytes b=0..3 hold value index b*VPB + i
             float q[4];
-            q[0] = cvt_ubyte<0>(t);
-            q[1] = cvt_ubyte<1>(t);
-            q[2] = cvt_ubyte<2>(t);
-            q[3] = cvt_ubyte<3>(t);
+            if constexpr (WBIT < 8) {  // two fields per instruction, values q * 2^-9
+                const float2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8(t, false), hi = __builtin_amdgcn_cvt_pk_f32_fp8(t, true);
+                q[0] = lo.x; q[1] = lo.y; q[2] = hi.x; q[3] = hi.y;
+            } else {
+                q[0] = cvt_ubyte<0>(t);
+                q[1] = cvt_ubyte<1>(t);
+                q[2] = cvt_ubyte<2>(t);
+                q[3] = cvt_ubyte<3>(t);
+            }
+            if constexpr (ZM == ZM_SYM) {
+                const uint32_t t0 = pack_bf16x2(q[0] * cp.s, q[1] * cp.s), t1 = pack_bf16x2(q[2] * cp.s, q[3] * cp.s);  // fl16(q*s)
+                float d[4];
+                bf16_pairs_sub(t0, t1, cp.sel0, cp.sel1, cp.nz, d);
+                out[2 * i] = pack_bf16x2(d[0], d[1]);  // fl16(. - z)
+                out[2 * i + 1] = pack_bf16x2(d[2], d[3]);
+            } else {
 #pragma unroll
-            for (int ph = 0; ph < 2; ph++) {
-                float a = q[2 * ph], b = q[2 * ph + 1];
-                uint32_t r;
-                if constexpr (ZM == ZM_ASYM) {
-                    r = pack_bf16x2(cp.s * (a - cp.zq1), cp.s * (b - cp.zq1));
-                } else if constexpr (ZM == ZM_FUSED) {
-                    r = pack_bf16x2(__builtin_fmaf(a, cp.s, -cp.z), __builtin_fmaf(b, cp.s, -cp.z));
-                } else {
-                    const uint32_t t1 = pack_bf16x2(a * cp.s, b * cp.s);  // fl16(q*s)
-                    const float ta = __uint_as_float(t1 << 16), tb = __uint_as_float(t1 & 0xffff0000u);
-                    r = pack_bf16x2(ta - cp.z, tb - cp.z);  // fl16(. - z)
+                for (int ph = 0; ph < 2; ph++) {
+                    const float a = q[2 * ph], b = q[2 * ph + 1];
+                    if constexpr (ZM == ZM_ASYM) out[2 * i + ph] = pack_bf16x2(cp.s * (a - cp.zq1), cp.s * (b - cp.zq1));
+                    else out[2 * i + ph] = pack_bf16x2(__builtin_fmaf(a, cp.s, -cp.z), __builtin_fmaf(b, cp.s, -cp.z));
                 }
-                out[2 * i + ph] = r;
             }
         }
     }

@@ -97,9 +97,13 @@ __device__ __forceinline__ uint4_t dequant8(uint2_t raw, int c8, const ColParams
             q[0] = cvt_ubyte<0>(raw.x); q[1] = cvt_ubyte<1>(raw.x); q[2] = cvt_ubyte<2>(raw.x); q[3] = cvt_ubyte<3>(raw.x);
             q[4] = cvt_ubyte<0>(raw.y); q[5] = cvt_ubyte<1>(raw.y); q[6] = cvt_ubyte<2>(raw.y); q[7] = cvt_ubyte<3>(raw.y);
         } else if constexpr (WBIT == 4) {
+            // nibbles -> bytes in natural k order (two v_perm_b32), then four v_cvt_pk_f32_fp8: bytes 0..15 read as fp8 e4m3
+            // are q * 2^-9 exactly (mpq_dequant.cuh); 2^9 sits in cp.s / cp.zq1 (make_col_params<.., FP8READ = true>)
             const uint32_t lo = raw.x & 0x0f0f0f0fu, hi = (raw.x >> 4) & 0x0f0f0f0fu;
-            q[0] = cvt_ubyte<0>(lo); q[2] = cvt_ubyte<1>(lo); q[4] = cvt_ubyte<2>(lo); q[6] = cvt_ubyte<3>(lo);
-            q[1] = cvt_ubyte<0>(hi); q[3] = cvt_ubyte<1>(hi); q[5] = cvt_ubyte<2>(hi); q[7] = cvt_ubyte<3>(hi);
+            const uint32_t p01 = __builtin_amdgcn_perm(hi, lo, 0x05010400u), p23 = __builtin_amdgcn_perm(hi, lo, 0x07030602u);
+            const float2_t f0 = __builtin_amdgcn_cvt_pk_f32_fp8(p01, false), f1 = __builtin_amdgcn_cvt_pk_f32_fp8(p01, true);
+            const float2_t f2 = __builtin_amdgcn_cvt_pk_f32_fp8(p23, false), f3 = __builtin_amdgcn_cvt_pk_f32_fp8(p23, true);
+            q[0] = f0.x; q[1] = f0.y; q[2] = f1.x; q[3] = f1.y; q[4] = f2.x; q[5] = f2.y; q[6] = f3.x; q[7] = f3.y;
         } else {
             constexpr int CPW = 4 / WBIT;
             constexpr uint32_t CM = (1u << (8 * WBIT)) - 1u;
@@ -116,7 +120,7 @@ __device__ __forceinline__ uint4_t dequant8(uint2_t raw, int c8, const ColParams
             } else if constexpr (ZM == ZM_FUSED) {
                 o[i] = pack_bf16x2(__builtin_fmaf(a, cp.s, -cp.z), __builtin_fmaf(b, cp.s, -cp.z));
             } else {
-                const uint32_t t1 = pack_bf16x2(a * cp.s, b * cp.s);
+                const uint32_t t1 = pack_bf16x2(a * cp.s, b * cp.s);  // fl16(q*s)
                 const float ta = __uint_as_float(t1 << 16), tb = __uint_as_float(t1 & 0xffff0000u);
                 o[i] = pack_bf16x2(ta - cp.z, tb - cp.z);
             }
@@ -385,7 +389,7 @@ __global__ __launch_bounds__(256, 1) void mpq_gemm_kernel(const uint16_t* __rest
             bf[f] = uint4_t{raw_as_u2<WBIT>(w.raw[f][kk]).x, w.sb[f][gi], zb, 0x3c003c00u};
 #else
             bf[f] = dequant8<DT, WBIT, ZM>(raw_as_u2<WBIT>(w.raw[f][kk]), (kt * GEMM_BK + kk * 16 + h * 8) >> 3,
-                                           make_col_params<DT, WBIT, ZM>(w.sb[f][gi], zb));
+                                           make_col_params<DT, WBIT, ZM, (WBIT == 4)>(w.sb[f][gi], zb));
 #endif
         }
     };

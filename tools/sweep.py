@@ -64,6 +64,11 @@ if __name__ == "__main__":
                 for M in (1, 4, 8):
                     out.append(time_case(M, K, N, dt))
                     print(json.dumps(out[-1]), flush=True)
+    if which == "ab":
+        for dt in (_hip.BF16, _hip.F16):
+            out.append(time_case(1, 4096, 11008, dt)); print(json.dumps(out[-1]), flush=True)
+            out.append(time_case(2, 4096, 11008, dt)); print(json.dumps(out[-1]), flush=True)
+            out.append(time_case(4096, 4096, 11008, dt, layers=4, reps=5)); print(json.dumps(out[-1]), flush=True)
     if which in ("all", "gemm"):
         for dt in (_hip.BF16, _hip.F16):
             for (M, K, N) in ((4096, 4096, 11008), (4096, 4096, 4096), (512, 4096, 11008), (64, 4096, 11008), (16, 4096, 11008)):
