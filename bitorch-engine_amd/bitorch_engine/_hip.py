@@ -46,6 +46,8 @@ SIGNATURES = {
     "bie_q4_quantize_pack": (_i, [_vp, _vp, _l, _f, _i, _vp]),
     "bie_q4_gemm": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _i, _l, _l, _l, _vp]),
     "bie_q8_gemm": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _vp]),
+    "bie_q4_conv2d_workspace_bytes": (_sz, [_i] * 9),
+    "bie_q4_conv2d_forward": (_i, [_vp, _vp, _vp, _vp, _sz] + [_i] * 9 + [_f, _f, _i, _vp]),
 }
 
 

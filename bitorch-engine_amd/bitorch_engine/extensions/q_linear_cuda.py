@@ -184,6 +184,9 @@ def mbwq_q4_forward(x, qweight, scales, zeros, group_size, q_perm, bits):
     return y
 
 
+EXL2_GEMV_MAX_M = 32  # rows of x served by the streaming exl2 kernel (4 passes over the packed weight)
+
+
 def mbwq_exl2_forward(x, qweight, scales, zeros, q_perm, q_group_map, rows, use_cublas=False):
     _hip.need_gpu(x, qweight, scales, zeros, q_perm, q_group_map)
     if x.dtype != torch.float16:
@@ -195,6 +198,11 @@ def mbwq_exl2_forward(x, qweight, scales, zeros, q_perm, q_group_map, rows, use_
     y = torch.empty((M, N), dtype=torch.float16, device=x.device)
     if M == 0:
         return y
+    if use_cublas or M > EXL2_GEMV_MAX_M:
+        # prefill: reconstruct the fp16 weight once with the HIP kernel and hand the plain dense GEMM to the vendor library,
+        # the same split the reference makes (mbwq_linear_cuda_kernel.cu:968-1002: reconstruct + at::matmul); the streaming
+        # kernel below re-reads the packed weight once per 8 rows of x and is the decode path
+        return torch.matmul(x, mbwq_exl2fp_weight(qweight, scales, zeros, q_perm, q_group_map, rows))
     L = _hip.lib()
     ws = _hip.workspace(L.bie_mbwq_workspace_bytes(M, K, N), x.device)
     keep, rp = _rows_arg(rows)

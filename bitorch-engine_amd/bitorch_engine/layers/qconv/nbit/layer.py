@@ -1,0 +1,53 @@
+"""nBitConv2dBase / nBitConvParameter: mirror of reference layers/qconv/nbit/layer.py:6-150 (inference path)."""
+import math
+
+import torch
+from torch import nn
+
+
+class nBitConvParameter(nn.Parameter):
+    def __new__(cls, data: torch.Tensor = None, requires_grad: bool = True):
+        if data is not None and not data.is_floating_point():
+            requires_grad = False
+        return super().__new__(cls, data, requires_grad=requires_grad)
+
+    @staticmethod
+    def update(qweight, *args, **kwargs):
+        raise NotImplementedError("nBitConvParameter.update (training) is outside the inference hot path of this build")
+
+
+class nBitConv2dBase(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int, stride: int = 1, padding: int = 0, dilation: int = 1,
+                 a_bit: int = 4, w_bit: int = 4, device=None, dtype=torch.float):
+        super().__init__()
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, kernel_size
+        self.stride, self.padding, self.dilation = stride, padding, dilation
+        self.device, self.dtype, self.a_bit, self.w_bit = device, dtype, a_bit, w_bit
+        self.weight = None
+        self.qweight = None
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        self.weight = nn.Parameter(torch.empty((self.out_channels, self.in_channels, self.kernel_size, self.kernel_size), dtype=self.dtype))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+
+    def prepare_params(self) -> None:
+        raise NotImplementedError("Subclasses should implement this method.")
+
+    def set_weight_data(self, x: torch.Tensor) -> None:
+        self.weight = nn.Parameter(x, requires_grad=False)
+
+    def set_quantized_weight_data(self, x: torch.Tensor) -> None:
+        self.qweight = nn.Parameter(x, requires_grad=False)
+
+    def generate_quantized_weight(self, qweight_only: bool = False) -> None:
+        raise NotImplementedError("Subclasses should implement this method.")
+
+    def _check_forward(self, x: torch.Tensor) -> None:
+        raise NotImplementedError("Subclasses should implement this method.")
+
+    @property
+    def opt_weight(self):
+        if not self.training and self.qweight is None:
+            self.generate_quantized_weight()
+        return self.weight if self.training else self.qweight

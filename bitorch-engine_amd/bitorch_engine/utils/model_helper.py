@@ -36,9 +36,10 @@ def prepare_bie_layers(model: torch.nn.Module, layers=None) -> None:
     """Call prepare_params() on every BIE layer of `model` (decode double-quantised statistics, build
     band tables, ...).  `layers` optionally restricts the layer classes."""
     from bitorch_engine.layers.qlinear.nbit import MPQLinearBase, nBitLinearBase
+    from bitorch_engine.layers.qconv.nbit import nBitConv2dBase
     from bitorch_engine.layers.qlinear.binary import BinaryLinearBase
     from bitorch_engine.layers.qconv.binary import BinaryConv2dBase
-    kinds = tuple(layers) if layers else (MPQLinearBase, nBitLinearBase, BinaryLinearBase, BinaryConv2dBase)
+    kinds = tuple(layers) if layers else (MPQLinearBase, nBitLinearBase, nBitConv2dBase, BinaryLinearBase, BinaryConv2dBase)
     for module in model.modules():
         if isinstance(module, kinds):
             module.prepare_params()

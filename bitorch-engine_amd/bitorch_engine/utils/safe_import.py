@@ -4,7 +4,7 @@ extension objects are thin ctypes front-ends; a missing/unbuilt libbie_hip.so ra
 import importlib
 
 KNOWN = ("q_linear_cuda", "binary_linear_cpp", "binary_linear_cuda", "binary_linear_cutlass",
-         "binary_conv_cpp", "binary_conv2d_cutlass", "functions_cuda", "q_linear_cutlass")
+         "binary_conv_cpp", "binary_conv2d_cutlass", "functions_cuda", "q_linear_cutlass", "q4_conv_cutlass")
 
 
 class ExtensionModulePlaceholder:

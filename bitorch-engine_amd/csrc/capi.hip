@@ -54,6 +54,9 @@ int q4_unpack_scale_launch(const int8_t* in, float* out, long n_in, float scale,
 int int_gemm_launch(int mode, const void* A, const void* W, void* y, int M, int N, int K, float sa, float sw, int dtype, int batch,
                     long strideA, long strideW, long strideY, hipStream_t st);
 int q4_quantize_pack_launch(const void* x, int8_t* out, long n_out, float scale, int dtype, hipStream_t st);
+size_t q4_conv2d_workspace_bytes(int B, int H, int W, int C, int OC, int KS, int stride, int pad, int dil);
+int q4_conv2d_launch(const int8_t* a_packed, const int8_t* w_packed, void* y, void* workspace, int B, int H, int W, int C, int OC,
+                     int KS, int stride, int pad, int dil, float sa, float sw, int dtype, hipStream_t st);
 }  // namespace bie
 
 using namespace bie;
@@ -312,6 +315,24 @@ int bie_q8_gemm(const int8_t* a, const int8_t* w, float* y, int M, int N, int K,
     BIE_REQUIRE(a && w && y && M > 0 && N > 0 && K > 0, BIE_ERR_INVALID_ARG, "bie_q8_gemm: bad argument");
     BIE_REQUIRE(K % 64 == 0 && N % 4 == 0, BIE_ERR_UNSUPPORTED, "bie_q8_gemm: K=%d must be a multiple of 64 and N=%d of 4", K, N);
     return int_gemm_launch(1, a, w, y, M, N, K, scale_a, scale_w, BIE_F32, 1, 0, 0, 0, as_stream(stream));
+}
+
+size_t bie_q4_conv2d_workspace_bytes(int B, int H, int W, int C, int OC, int ksize, int stride, int pad, int dilation) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || OC <= 0 || ksize <= 0 || stride <= 0 || dilation <= 0 || pad < 0) return 0;
+    return q4_conv2d_workspace_bytes(B, H, W, C, OC, ksize, stride, pad, dilation);
+}
+
+int bie_q4_conv2d_forward(const int8_t* a_packed, const int8_t* w_packed, void* y, void* workspace, size_t workspace_bytes, int B, int H,
+                          int W, int C, int OC, int ksize, int stride, int pad, int dilation, float scale_a, float scale_w, int dtype,
+                          void* stream) {
+    BIE_REQUIRE(a_packed && w_packed && y && workspace, BIE_ERR_INVALID_ARG, "bie_q4_conv2d_forward: NULL tensor pointer");
+    BIE_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && OC > 0 && ksize > 0 && stride > 0 && dilation > 0 && pad >= 0, BIE_ERR_INVALID_ARG, "bie_q4_conv2d_forward: bad geometry");
+    BIE_REQUIRE(C % 8 == 0 && OC % 4 == 0, BIE_ERR_UNSUPPORTED, "bie_q4_conv2d_forward: C=%d must be a multiple of 8 and OC=%d of 4", C, OC);
+    BIE_REQUIRE(dtype >= 0 && dtype <= 2, BIE_ERR_UNSUPPORTED, "bie_q4_conv2d_forward: tensor type not supported: %d", dtype);
+    const size_t need = q4_conv2d_workspace_bytes(B, H, W, C, OC, ksize, stride, pad, dilation);
+    BIE_REQUIRE(need > 0, BIE_ERR_INVALID_ARG, "bie_q4_conv2d_forward: empty output");
+    BIE_REQUIRE(workspace_bytes >= need, BIE_ERR_WORKSPACE, "bie_q4_conv2d_forward: workspace of %zu bytes required, got %zu", need, workspace_bytes);
+    return q4_conv2d_launch(a_packed, w_packed, y, workspace, B, H, W, C, OC, ksize, stride, pad, dilation, scale_a, scale_w, dtype, as_stream(stream));
 }
 
 }  // extern "C"

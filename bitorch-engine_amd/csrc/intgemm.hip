@@ -154,6 +154,31 @@ __global__ __launch_bounds__(256) void q4_quantize_pack_kernel(const void* __res
     out[i] = (int8_t)((q[0] << 4) | q[1]);
 }
 
+// NHWC nibble-packed activations [B, H, W, C/2] -> im2col rows [B*OH*OW, Kp/2], k = (kh*KS + kw)*C + c (c fastest, the order
+// of the [OC, KS, KS, C/2] packed filter), zero nibbles for padding taps and for the tail up to Kp (multiple of 64 values).
+// One thread per 4 bytes (8 values); C % 8 == 0.
+__global__ __launch_bounds__(256) void q4_im2col_kernel(const uint32_t* __restrict__ a, uint32_t* __restrict__ col, int B, int H, int W,
+                                                        int C, int OH, int OW, int KS, int stride, int pad, int dil, int Kp) {
+    const int wpr = Kp / 8;  // dwords per im2col row
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)B * OH * OW * wpr;
+    if (idx >= total) return;
+    const int kw8 = (int)(idx % wpr);
+    const long row = idx / wpr;
+    const int ow = (int)(row % OW), oh = (int)((row / OW) % OH), b = (int)(row / ((long)OW * OH));
+    const int k = kw8 * 8;
+    uint32_t v = 0;
+    if (k < KS * KS * C) {
+        const int tap = k / C, c = k % C;
+        const int ih = oh * stride - pad + (tap / KS) * dil, iw = ow * stride - pad + (tap % KS) * dil;
+        if (ih >= 0 && ih < H && iw >= 0 && iw < W) v = a[(((long)b * H + ih) * W + iw) * (C / 8) + c / 8];
+    }
+    col[idx] = v;
+}
+
+int q4_conv2d_launch(const int8_t* a_packed, const int8_t* w_packed, void* y, void* workspace, int B, int H, int W, int C, int OC,
+                     int KS, int stride, int pad, int dil, float sa, float sw, int dtype, hipStream_t st);
+
 int int_gemm_launch(int mode, const void* A, const void* W, void* y, int M, int N, int K, float sa, float sw, int dtype, int batch,
                     long strideA, long strideW, long strideY, hipStream_t st) {
     dim3 grid(cdiv(N, IG_BN), cdiv(M, IG_BM), batch);
@@ -164,6 +189,45 @@ int int_gemm_launch(int mode, const void* A, const void* W, void* y, int M, int 
     else L(0, BIE_F32);
 #undef L
     return check_launch("int_gemm_kernel");
+}
+
+size_t q4_conv2d_workspace_bytes(int B, int H, int W, int C, int OC, int KS, int stride, int pad, int dil) {
+    const int OH = (H + 2 * pad - dil * (KS - 1) - 1) / stride + 1, OW = (W + 2 * pad - dil * (KS - 1) - 1) / stride + 1;
+    if (OH <= 0 || OW <= 0) return 0;
+    const int K = KS * KS * C, Kp = cdiv(K, 64) * 64;
+    size_t bytes = (size_t)B * OH * OW * (Kp / 2);
+    if (Kp != K) bytes += (size_t)OC * (Kp / 2);  // zero-padded copy of the filter
+    return (bytes + 255) / 256 * 256;
+}
+
+__global__ __launch_bounds__(256) void q4_pad_rows_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, long rows, int wi, int wo) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * wo) return;
+    const int c = (int)(idx % wo);
+    out[idx] = c < wi ? in[(idx / wo) * wi + c] : 0u;
+}
+
+int q4_conv2d_launch(const int8_t* a_packed, const int8_t* w_packed, void* y, void* workspace, int B, int H, int W, int C, int OC,
+                     int KS, int stride, int pad, int dil, float sa, float sw, int dtype, hipStream_t st) {
+    const int OH = (H + 2 * pad - dil * (KS - 1) - 1) / stride + 1, OW = (W + 2 * pad - dil * (KS - 1) - 1) / stride + 1;
+    const int K = KS * KS * C, Kp = cdiv(K, 64) * 64;
+    const long rows = (long)B * OH * OW;
+    uint32_t* col = reinterpret_cast<uint32_t*>(workspace);
+    const long total = rows * (Kp / 8);
+    hipLaunchKernelGGL(q4_im2col_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, st, (const uint32_t*)a_packed, col, B, H, W, C, OH, OW,
+                       KS, stride, pad, dil, Kp);
+    int rc = check_launch("q4_im2col_kernel");
+    if (rc) return rc;
+    const int8_t* wp = w_packed;
+    if (Kp != K) {
+        uint32_t* wpad = col + total;
+        hipLaunchKernelGGL(q4_pad_rows_kernel, dim3((unsigned)cdivl((long)OC * (Kp / 8), 256)), dim3(256), 0, st, (const uint32_t*)w_packed, wpad,
+                           (long)OC, K / 8, Kp / 8);
+        rc = check_launch("q4_pad_rows_kernel");
+        if (rc) return rc;
+        wp = reinterpret_cast<const int8_t*>(wpad);
+    }
+    return int_gemm_launch(0, col, wp, y, (int)rows, OC, Kp, sa, sw, dtype, 1, 0, 0, 0, st);
 }
 
 int q4_quantize_pack_launch(const void* x, int8_t* out, long n_out, float scale, int dtype, hipStream_t st) {

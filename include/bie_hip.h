@@ -197,6 +197,15 @@ int bie_q4_gemm(const int8_t* a_packed, const int8_t* w_packed, void* y, int M, 
 int bie_q8_gemm(const int8_t* a, const int8_t* w, float* y, int M, int N, int K, float scale_a, float scale_w,
                 void* stream);
 
+/* W4A4 convolution on nibble-packed NHWC operands: a [B, H, W, C/2], w [OC, KS, KS, C/2] (C % 8 == 0, OC % 4 == 0), zero padding,
+ * y [B, OH, OW, OC] (dtype) with the bie_q4_gemm epilogue; OH = (H + 2*pad - dil*(KS-1) - 1)/stride + 1.  The workspace holds the
+ * packed im2col matrix (no counters, need not be zeroed).  Replaces q4_conv_cutlass.forward
+ * (layers/qconv/nbit/cutlass/q4_conv_cutlass_kernel.cu:441-510; the CUTLASS implicit-GEMM :178-345). */
+size_t bie_q4_conv2d_workspace_bytes(int B, int H, int W, int C, int OC, int ksize, int stride, int pad, int dilation);
+int bie_q4_conv2d_forward(const int8_t* a_packed, const int8_t* w_packed, void* y, void* workspace, size_t workspace_bytes, int B,
+                          int H, int W, int C, int OC, int ksize, int stride, int pad, int dilation, float scale_a, float scale_w,
+                          int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -259,3 +259,16 @@ def q8_gemm(a, w, scale_a, scale_w):
     y = np.empty((M, N), dtype=np.float32)
     lib().orc_q8_gemm(_p(a), _p(w), _p(y), M, N, K, ctypes.c_float(scale_a), ctypes.c_float(scale_w))
     return y
+
+
+def q4_conv2d(a, w, ksize, stride, pad, dil, scale_a, scale_w, dt):
+    """a: int8 [B, H, W, C/2], w: int8 [OC, KS, KS, C/2] -> [B, OH, OW, OC]"""
+    a, w = _c(a, np.int8), _c(w, np.int8)
+    B, H, W, C2 = a.shape
+    OC = w.shape[0]
+    OH = (H + 2 * pad - dil * (ksize - 1) - 1) // stride + 1
+    OW = (W + 2 * pad - dil * (ksize - 1) - 1) // stride + 1
+    y = _out((B, OH, OW, OC), dt)
+    lib().orc_q4_conv2d(_p(a), _p(w), _p(y), B, H, W, C2 * 2, OC, ksize, stride, pad, dil, ctypes.c_float(scale_a),
+                        ctypes.c_float(scale_w), dt)
+    return y

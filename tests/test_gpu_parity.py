@@ -256,7 +256,7 @@ def test_mbwq_q4_dequant_and_forward(bits, M, perm):
 
 
 @pytest.mark.parametrize("cfg", ["q_proj", "k_proj", "w3w2", "all6"])
-@pytest.mark.parametrize("M", [1, 2, 11])
+@pytest.mark.parametrize("M", [1, 2, 11, 70])  # 70 > EXL2_GEMV_MAX_M: reconstruct + library GEMM branch
 def test_mbwq_exl2_dequant_and_forward(cfg, M):
     from bitorch_engine.extensions import q_linear_cuda
     from bitorch_engine.layers.qlinear.nbit.cuda.utils import make_group_map
@@ -527,3 +527,37 @@ def test_q4_gemm_error_codes():
     y = torch.zeros((4, 4), dtype=torch.float16, device=DEV)
     rc = _hip.lib().bie_q4_gemm(_hip.ptr(a), _hip.ptr(a), _hip.ptr(y), 4, 4, 48, 1.0, 1.0, 0, 1, 0, 0, 0, None)
     assert rc != 0 and b"multiple of 64" in _hip.lib().bie_last_error()
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16", "f32"])
+@pytest.mark.parametrize("B,C,H,OC,ks,st,pad,dil", [(2, 64, 14, 64, 3, 1, 1, 1), (1, 32, 9, 36, 3, 2, 1, 1), (3, 8, 7, 4, 1, 1, 0, 1),
+                                                     (1, 32, 11, 32, 3, 1, 2, 2), (2, 128, 7, 256, 3, 1, 1, 1)])
+def test_q4_conv2d_bit_exact_vs_oracle(dt, B, C, H, OC, ks, st, pad, dil):
+    from bitorch_engine.extensions import q4_conv_cutlass as qc
+    g = torch.Generator().manual_seed(B * 7 + C)
+    x = torch.randn((B, C, H, H), generator=g).to(_TDT[dt])
+    w = (torch.randn((OC, C, ks, ks), generator=g) * 0.1).to(_TDT[dt])
+    sa, sw = float(2 * x.float().abs().mean() / 11.269), float(2 * w.float().abs().mean() / 5.6345)
+    code = orc.dt_code(_TDT[dt])
+    # the reference VIEWS the NCHW buffers as NHWC (q4_conv_cutlass_kernel.cu:474-480)
+    pa = orc.q4_quantize_pack(orc.torch_to_np(x.view(B, H, H, C)), sa, code)
+    pw = orc.q4_quantize_pack(orc.torch_to_np(w.view(OC, ks, ks, C)), sw, code)
+    want = orc.q4_conv2d(pa, pw, ks, st, pad, dil, sa, sw, code)
+    out, qa, qw = qc.forward(x.to(DEV), w.to(DEV), torch.tensor(sa), torch.tensor(sw), False, ks, st, pad, dil)
+    assert np.array_equal(qa.cpu().numpy(), pa) and np.array_equal(qw.cpu().numpy(), pw)
+    assert np.array_equal(qc.w_pack(w.to(DEV), sw).cpu().numpy(), pw)
+    assert out.shape == want.shape and np.array_equal(orc.torch_to_np(out), want)
+
+
+def test_q4_conv_layer_train_eval_equivalence():
+    """reference check (tests/layers/test_nbit_conv.py): result from the packed weight == result from the float weight"""
+    from bitorch_engine.layers.qconv.nbit.cutlass import Q4Conv2dCutlass
+    torch.manual_seed(1)
+    layer = Q4Conv2dCutlass(in_channels=64, out_channels=32, kernel_size=3, stride=1, padding=1, dilation=1, dtype=torch.half).to(DEV)
+    layer.prepare_params()
+    x = torch.randn((2, 64, 10, 10)).half().to(DEV)
+    with torch.no_grad():
+        y = layer.train()(x)
+    layer.generate_quantized_weight(qweight_only=True)
+    y2 = layer.eval()(x)
+    assert y.shape == (2, 32, 10, 10) and torch.equal(y, y2)

@@ -190,3 +190,17 @@ def test_q4_q8_gemm_oracle_is_exact_integer_gemm():
     a8, w8 = rng.integers(-128, 128, (M, K)).astype(np.int8), rng.integers(-128, 128, (N, K)).astype(np.int8)
     y8 = orc.q8_gemm(a8, w8, 0.5, 0.25)
     assert np.array_equal(y8, (a8.astype(np.int64) @ w8.astype(np.int64).T).astype(np.float32) * np.float32(0.125))
+
+
+def test_q4_conv2d_oracle_equals_torch_conv_on_the_integers():
+    import torch
+    rng = np.random.default_rng(9)
+    for (B, C, H, OC, ks, st, pad, dil) in ((2, 8, 6, 4, 3, 1, 1, 1), (1, 16, 7, 8, 3, 2, 1, 1), (1, 8, 5, 4, 1, 1, 0, 1), (1, 8, 9, 4, 3, 1, 2, 2)):
+        a = rng.integers(-8, 8, (B, H, H, C))
+        w = rng.integers(-8, 8, (OC, ks, ks, C))
+        pa = (((a[..., 0::2] & 15) << 4) | (a[..., 1::2] & 15)).astype(np.uint8).view(np.int8)
+        pw = (((w[..., 0::2] & 15) << 4) | (w[..., 1::2] & 15)).astype(np.uint8).view(np.int8)
+        y = orc.q4_conv2d(pa, pw, ks, st, pad, dil, 0.5, 0.5, orc.F32)
+        ref = torch.nn.functional.conv2d(torch.from_numpy(a).permute(0, 3, 1, 2).double(), torch.from_numpy(w).permute(0, 3, 1, 2).double(),
+                                         stride=st, padding=pad, dilation=dil).permute(0, 2, 3, 1).numpy()
+        assert np.array_equal(y, (ref * 0.25).astype(np.float32))
