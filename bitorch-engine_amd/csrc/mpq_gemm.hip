@@ -513,20 +513,39 @@ struct GemmPlan {
     int BM, S, tiles_per_split;
 };
 
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+// Tile height and split-K factor from a measured cost model (tools/gemm_plan_sweep.py, profiles/r01_e_gemm_plan_sweep.log):
+//   one block per CU (512 registers per wave), so a launch runs ceil(blocks / 256) rounds of ceil(T / S) K-tiles each;
+//   a K-tile (64 k) of a BM x 256 tile costs c(BM) us (dequant of the 256 columns is paid per tile whatever BM is, hence
+//   the weak dependence on BM); split-K adds S fp32 partial slabs written and re-read (~4 TB/s) and the finalize launch.
+// The plan depends on (M, K, N) only: bie_mpq_workspace_bytes has to reproduce it without knowing dtype or bit width.
 static GemmPlan plan_gemm(int M, int K, int N) {
-    GemmPlan p;
-    p.BM = M <= 32 ? 32 : (M <= 64 ? 64 : (M <= 128 ? 128 : 256));
-    const int tiles = cdiv(M, p.BM) * cdiv(N, GEMM_BN);
+    static const int force_bm = env_int("BIE_GEMM_BM", 0), force_s = env_int("BIE_GEMM_S", 0);  // tuning knobs
     const int T = K / GEMM_BK;
-    int S = 1;
-    if (tiles < 256) {
-        S = cdiv(512, tiles);
-        const int max_s = T / 4 > 0 ? T / 4 : 1;  // keep >= 4 K tiles per split
-        if (S > max_s) S = max_s;
-        if (S > 16) S = 16;
+    const int bms[4] = {32, 64, 128, 256};
+    const double ctile[4] = {0.95, 1.10, 1.50, 2.35};
+    double best = 1e30;
+    GemmPlan p{256, 1, T};
+    for (int i = 0; i < 4; i++) {
+        const int BM = bms[i];
+        if (force_bm ? (BM != force_bm) : (BM > 32 && BM >= 2 * M)) continue;
+        const long tiles = (long)cdiv(M, BM) * cdiv(N, GEMM_BN);
+        for (int S = 1; S <= 16; S++) {
+            if (force_s ? (S != (force_s > T ? T : force_s)) : (S > 1 && T / S < 2)) continue;
+            const int tps = cdiv(T, S), Sr = cdiv(T, tps);
+            if (Sr != S && !force_s) continue;  // an equivalent smaller S exists
+            const long blocks = tiles * Sr;
+            const long rounds = (blocks + 255) / 256;
+            const double busy = (double)blocks / (double)(rounds * 256);
+            double t = (double)rounds * tps * ctile[i] * (busy > 0.9 ? 1.15 : 1.0);
+            if (Sr > 1) t += 6.0 + (double)Sr * M * N * 8.0 / 4.0e6;
+            if (t < best) { best = t; p.BM = BM; p.S = Sr; p.tiles_per_split = tps; }
+        }
     }
-    p.tiles_per_split = cdiv(T, S);
-    p.S = cdiv(T, p.tiles_per_split);
     return p;
 }
 

@@ -69,6 +69,10 @@ if __name__ == "__main__":
             out.append(time_case(1, 4096, 11008, dt)); print(json.dumps(out[-1]), flush=True)
             out.append(time_case(2, 4096, 11008, dt)); print(json.dumps(out[-1]), flush=True)
             out.append(time_case(4096, 4096, 11008, dt, layers=4, reps=5)); print(json.dumps(out[-1]), flush=True)
+    if which == "midm":
+        for (K, N) in ((4096, 11008), (4096, 4096), (11008, 4096)):
+            for M in (4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096):
+                out.append(time_case(M, K, N, _hip.BF16, layers=4, reps=5)); print(json.dumps(out[-1]), flush=True)
     if which in ("all", "gemm"):
         for dt in (_hip.BF16, _hip.F16):
             for (M, K, N) in ((4096, 4096, 11008), (4096, 4096, 4096), (512, 4096, 11008), (64, 4096, 11008), (16, 4096, 11008)):
