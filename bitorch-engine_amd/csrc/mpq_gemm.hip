@@ -268,7 +268,7 @@ __device__ __forceinline__ void load_wtile(WTile<DT, WBIT, ZM, GPT>& t, const WP
 // LDS read traffic per flop (with BM x 32 wave tiles the LDS pipe -- 4 waves re-reading the whole x tile plus the
 // staging writes -- was as busy as the matrix pipe).
 template <int DT, int WBIT, int ZM, int BM, bool PERM, bool GPT>
-__global__ __launch_bounds__(256, 1) void mpq_gemm_kernel(const uint16_t* __restrict__ x, const uint32_t* __restrict__ qw,
+__global__ __launch_bounds__(256, (BM <= 128 ? 2 : 1)) void mpq_gemm_kernel(const uint16_t* __restrict__ x, const uint32_t* __restrict__ qw,
                                                           const uint16_t* __restrict__ scales, const void* __restrict__ zeros,
                                                           const uint16_t* __restrict__ bias, const uint16_t* __restrict__ perm,
                                                           float* __restrict__ part, uint16_t* __restrict__ y, int M, int K, int N,
@@ -371,6 +371,37 @@ __global__ __launch_bounds__(256, 1) void mpq_gemm_kernel(const uint16_t* __rest
         for (int i = 0; i < A_CHUNKS; i++)
             *reinterpret_cast<uint4_t*>(lds + buf * A_BYTES + aoff[i]) = permute_a_chunk<DT, WBIT>(areg[i]);
     };
+    // Direct global -> LDS staging of the x tile (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass -- the
+    // ds_write_b128 pass alone cost ~600-900 of ~4500 cycles per K tile, profiles/r01_f_gemm_phase_cycles.txt).  One
+    // wave-instruction fills 1 KiB of LDS lane-linearly (lane l -> bytes 16*l), i.e. 8 tile rows of the swizzled image;
+    // the XOR swizzle is realised on the SOURCE side: lane l fetches the global chunk that belongs in LDS slot l.
+    // Only where the x chunk needs no in-flight re-ordering (bf16 fragments are in natural k order; no q_perm gather).
+    constexpr bool GLDS = (DT == BIE_BF16) && !PERM && BM >= 32;
+    constexpr int A_PIECES = BM / 32;  // 1 KiB pieces per wave per tile
+    const uint16_t* asrc[A_PIECES];
+    if constexpr (GLDS) {
+#pragma unroll
+        for (int i = 0; i < A_PIECES; i++) {
+            const int piece = wave * A_PIECES + i;
+            const int rp = piece * 4 + (lane >> 4), slot16 = lane & 15;
+            const int row = 2 * rp + (slot16 >> 3), sl = (slot16 & 7) ^ (rp & 7);
+            int m = m0 + row;
+            if (m > M - 1) m = M - 1;
+            asrc[i] = x + (long)m * K + sl * 8;
+        }
+    }
+    auto glds_a = [&](int kt, int buf) {
+        if constexpr (GLDS) {
+            auto* dst = (__attribute__((address_space(3))) unsigned char*)lds + buf * A_BYTES + wave * (A_PIECES * 1024);
+#if defined(__HIP_DEVICE_COMPILE__)  // device-only builtin: the host pass must still see a well-formed body to emit the launch stub
+#pragma unroll
+            for (int i = 0; i < A_PIECES; i++)
+                __builtin_amdgcn_global_load_lds(asrc[i] + kt * GEMM_BK, dst + i * 1024, 16, 0, 0);
+#else
+            (void)dst;
+#endif
+        }
+    };
 
     // A fragment LDS byte addresses of this lane: k16-step kk -> slot kk*2 + h of row j (+ t * 4096 bytes per 32 rows)
     const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
@@ -394,81 +425,104 @@ __global__ __launch_bounds__(256, 1) void mpq_gemm_kernel(const uint16_t* __rest
         }
     };
 
-    WTile<DT, WBIT, ZM, GPT> wcur, wnext;
-    const int t_last = t_end - 1;
-    if (t_begin < t_end) {
-        load_a(t_begin);
-        load_wtile<DT, WBIT, ZM, GPT>(wcur, wp, t_begin * GEMM_BK, N, gshift);
-        store_a(0);
-    }
-    __syncthreads();
-
-    int cur = 0;
-    uint4_t af0[TM], af1[TM];
-    for (int kt = t_begin; kt < t_end; kt++) {
-        // Branch-free body: the look-ahead tile index is clamped to the last tile.
-        const int ktn = (kt + 1 < t_end) ? kt + 1 : t_last;
-        const uint32_t abase = (uint32_t)(cur * A_BYTES);
-        lds_issue_frags<TM>(af0, foff[0] + abase);
-#if BIE_GEMM_LAB != 5
-        load_a(ktn);
-#endif
-        load_wtile<DT, WBIT, ZM, GPT>(wnext, wp, ktn * GEMM_BK, N, gshift);
-        uint4_t bfrag[NF], bnext[NF];
-        dequant_step(wcur, kt, 0, bfrag);
-        lds_wait_frags<TM>(af0);
+    // MFMAs of k16 step kk (2*TM of them) with the scheduler asked to drop VALU_PER_MFMA of the independent VALU work
+    // queued before them (the next step's dequant) into every 32-cycle MFMA shadow.  One wave per SIMD issues in order:
+    // an MFMA issued while the matrix pipe is busy blocks everything behind it, a run of VALU leaves the pipe idle.
+    auto mfma_step = [&](const uint4_t (&af)[TM], const uint4_t (&bf)[NF]) {
 #pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
-            // software pipeline: while the 2*TM MFMAs of step kk run, step kk+1's A fragments are in flight from LDS
-            // and its B fragments are dequantised (both independent of the MFMAs)
-            if (kk < 3) {
-                if (kk & 1) lds_issue_frags<TM>(af0, foff[kk + 1] + abase);
-                else lds_issue_frags<TM>(af1, foff[kk + 1] + abase);
-                __builtin_amdgcn_sched_barrier(0);  // keep the MFMAs below the issue point
-                dequant_step(wcur, kt, kk + 1, bnext);
-            }
+        for (int t = 0; t < TM; t++) {
 #pragma unroll
-            for (int t = 0; t < TM; t++) {
-#pragma unroll
-                for (int f = 0; f < NF; f++) {
+            for (int f = 0; f < NF; f++) {
 #if BIE_GEMM_LAB == 3
-                    acc[f][t][0] += __uint_as_float(((kk & 1) ? af1[t].x : af0[t].x) ^ bfrag[f].x ^ bfrag[f].y ^ bfrag[f].z ^ bfrag[f].w);
+                acc[f][t][0] += __uint_as_float(af[t].x ^ bf[f].x ^ bf[f].y ^ bf[f].z ^ bf[f].w);
 #else
-                    if (kk & 1) acc[f][t] = mfma32<DT>(bfrag[f], af1[t], acc[f][t]);
-                    else acc[f][t] = mfma32<DT>(bfrag[f], af0[t], acc[f][t]);
+                acc[f][t] = mfma32<DT>(bf[f], af[t], acc[f][t]);
 #endif
-                }
-            }
-            if (kk < 3) {
-                // One wave per SIMD issues in order: an MFMA issued while the matrix pipe is busy blocks everything
-                // behind it, so the next step's dequant VALU must sit BETWEEN this step's MFMAs (1 MFMA : ~7 others fills
-                // the 32-cycle MFMA shadow) -- ask the scheduler for exactly that interleave.
-#pragma unroll
-                for (int i = 0; i < TM * NF; i++) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);  // then VALU
-                }
-                if (kk & 1) lds_wait_frags<TM>(af0);
-                else lds_wait_frags<TM>(af1);
-#pragma unroll
-                for (int f = 0; f < NF; f++) bfrag[f] = bnext[f];
             }
         }
-#if BIE_GEMM_LAB != 5
-        store_a(cur ^ 1);
-#endif
-        wcur = wnext;
-#if BIE_GEMM_LAB != 6
+#pragma unroll
+        for (int i = 0; i < TM * NF; i++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);  // then VALU
+        }
+    };
+
+    // Software pipeline, rotated across the K-tile boundary: EVERY MFMA group has the next group's A fragments in flight
+    // from LDS and the next group's B fragments being dequantised -- including the last group of a tile, which covers
+    // the staging of the next x tile (registers -> LDS, barrier) and the dequant of the next tile's first step.  The
+    // global loads of tile kt+1 (x rows into registers, packed weights + group constants) are issued under the FIRST MFMA
+    // group of tile kt and consumed under its last one, so nothing loaded is pending across the loop's back edge (the
+    // compiler would otherwise have to wait for fresh loads before it can copy them into the loop-carried registers).
+    WTile<DT, WBIT, ZM, GPT> wcur, wnext;
+    const int t_last = t_end - 1;
+    int cur = 0;
+    uint4_t af0[TM], af1[TM];
+    uint4_t bfrag[NF], bnext[NF];
+    if (t_begin < t_end) {
+        if constexpr (GLDS) glds_a(t_begin, 0);
+        else load_a(t_begin);
+        load_wtile<DT, WBIT, ZM, GPT>(wcur, wp, t_begin * GEMM_BK, N, gshift);
+        if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else store_a(0);
         __syncthreads();
+        lds_issue_frags<TM>(af0, foff[0]);
+        dequant_step(wcur, t_begin, 0, bfrag);
+        lds_wait_frags<TM>(af0);
+    }
+#if BIE_GEMM_LAB == 7
+    unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+    unsigned stamp_sum[6] = {0, 0, 0, 0, 0, 0};
+#define BIE_STAMP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stamp_sum[i] += (unsigned)(now_ - stamp_prev); stamp_prev = now_; }
+#else
+#define BIE_STAMP(i)
 #endif
+    for (int kt = t_begin; kt < t_end; kt++) {
+        // Branch-free body: the look-ahead tile index is clamped to the last tile (a harmless re-load at the end).
+        const int ktn = (kt + 1 < t_end) ? kt + 1 : t_last;
+        const uint32_t abase = (uint32_t)(cur * A_BYTES), abase_n = (uint32_t)((cur ^ 1) * A_BYTES);
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) {
+            if (kk & 1) lds_issue_frags<TM>(af0, foff[kk + 1] + abase);
+            else lds_issue_frags<TM>(af1, foff[kk + 1] + abase);
+            if (kk == 0) {
+                if constexpr (GLDS) glds_a(ktn, cur ^ 1);  // the other buffer: its last readers finished before the previous barrier
+                else load_a(ktn);
+                load_wtile<DT, WBIT, ZM, GPT>(wnext, wp, ktn * GEMM_BK, N, gshift);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the MFMAs below the issue point
+            dequant_step(wcur, kt, kk + 1, bnext);
+            if (kk & 1) mfma_step(af1, bfrag);
+            else mfma_step(af0, bfrag);
+            if (kk & 1) lds_wait_frags<TM>(af0);
+            else lds_wait_frags<TM>(af1);
+#pragma unroll
+            for (int f = 0; f < NF; f++) bfrag[f] = bnext[f];
+            BIE_STAMP(kk)
+        }
+        // last step of the tile (A fragments in af1): x tile kt+1 goes to the other LDS buffer -- its last readers finished
+        // before the previous barrier -- and the pipeline is primed for it
+        if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA pieces have landed
+        else store_a(cur ^ 1);
+        BIE_STAMP(3)
+        __syncthreads();
+        BIE_STAMP(4)
+        lds_issue_frags<TM>(af0, foff[0] + abase_n);
+        __builtin_amdgcn_sched_barrier(0);
+        dequant_step(wnext, ktn, 0, bnext);
+        mfma_step(af1, bfrag);
+        lds_wait_frags<TM>(af0);
+#pragma unroll
+        for (int f = 0; f < NF; f++) bfrag[f] = bnext[f];
+        wcur = wnext;
         cur ^= 1;
+        BIE_STAMP(5)
     }
 
     // ---- epilogue.  The MFMAs were issued as D = W_frag (A operand, rows = n) x x_frag (B operand, cols = m), so in the
     // 32x32 C/D layout (col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)) a lane holds ONE output row m = t*32 + j
     // and, per group of four registers, FOUR CONSECUTIVE columns n = 8*q + 4*h + (0..3): one 8-byte store per group
     // (4 per tile instead of 16 two-byte stores); the two lane halves complete 16 contiguous bytes per row.
-#if BIE_GEMM_LAB == 1
+#if BIE_GEMM_LAB == 1 || BIE_GEMM_LAB == 7
     if (acc[0][0][0] == 123.456f)
 #endif
 #pragma unroll
@@ -506,6 +560,15 @@ __global__ __launch_bounds__(256, 1) void mpq_gemm_kernel(const uint16_t* __rest
             }
         }
     }
+#if BIE_GEMM_LAB == 7
+    // timing build only: the LAST row of y receives, per wave of block 0, the six phase cycle sums (y is garbage there)
+    __syncthreads();
+    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) {
+        uint32_t* dbg = reinterpret_cast<uint32_t*>(y + (long)(M - 1) * N) + wave * 8;
+        for (int i = 0; i < 6; i++) dbg[i] = stamp_sum[i];
+        dbg[6] = (uint32_t)(t_end - t_begin);
+    }
+#endif
 }
 
 // ---- launch plumbing ---------------------------------------------------------------------------------
