@@ -30,13 +30,12 @@ constexpr int GEMM_BK = 64;
 
 // ---- 8-value chunk dequant -> 4 dwords (MFMA operand order) ---------------------------------------
 // element order e (0..7) of the produced fragment -> k offset inside the chunk
+// Both dtypes produce the fragment in NATURAL k order, so the x tile needs no re-ordering on its way into LDS and can be
+// staged by LDS-DMA (global_load_lds).  (An earlier fp16 variant used the cheaper (k, k+4) pairing of the 0x6400 trick and
+// paid ~80 VALU per thread per K tile to permute x instead.)
 template <int DT, int WBIT>
 __host__ __device__ constexpr int frag_src_k(int e) {
-    if (DT == BIE_F16) {
-        if (WBIT == 8) return ((e >> 1) & 1) + ((e & 1) << 1) + (e & 4);  // (0,2,1,3,4,6,5,7)
-        return (e >> 1) + (e & 1) * 4;                                      // (0,4,1,5,2,6,3,7)
-    }
-    return e;  // bf16: natural
+    return e;
 }
 
 // raw bits of chunk c8 (8 consecutive k) of column n.  WBIT<=4: returned in .x (low 8*WBIT bits), WBIT==8: two words
@@ -59,27 +58,32 @@ __device__ __forceinline__ uint4_t dequant8(uint2_t raw, int c8, const ColParams
     uint32_t o[4];
     if constexpr (DT == BIE_F16) {
         const half2_t k1024 = half2_t{(half_t)1024.0f, (half_t)1024.0f};
+        // P[i] = fp16 pair (1024 + q[2i], 1024 + q[2i+1]): the field value sits in the mantissa of 0x6400
         uint32_t P[4];
-        if constexpr (WBIT == 8) {
-            P[0] = (raw.x & 0x00ff00ffu);
-            P[1] = ((raw.x >> 8) & 0x00ff00ffu);
-            P[2] = (raw.y & 0x00ff00ffu);
-            P[3] = ((raw.y >> 8) & 0x00ff00ffu);
-        } else if constexpr (WBIT == 4) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) P[i] = (raw.x >> (4 * i)) & 0x000f000fu;
+        if constexpr (WBIT == 8) {  // byte pairs -> (b0, 0x64, b1, 0x64) with one v_perm_b32 each
+            P[0] = __builtin_amdgcn_perm(0x64646464u, raw.x, 0x04010400u);
+            P[1] = __builtin_amdgcn_perm(0x64646464u, raw.x, 0x04030402u);
+            P[2] = __builtin_amdgcn_perm(0x64646464u, raw.y, 0x04010400u);
+            P[3] = __builtin_amdgcn_perm(0x64646464u, raw.y, 0x04030402u);
+        } else if constexpr (WBIT == 4) {  // nibbles -> bytes in natural order (2 masks + 2 perms), then as for 8 bit
+            const uint32_t lo = raw.x & 0x0f0f0f0fu, hi = (raw.x >> 4) & 0x0f0f0f0fu;
+            const uint32_t b03 = __builtin_amdgcn_perm(hi, lo, 0x05010400u), b47 = __builtin_amdgcn_perm(hi, lo, 0x07030602u);
+            P[0] = __builtin_amdgcn_perm(0x64646464u, b03, 0x04010400u);
+            P[1] = __builtin_amdgcn_perm(0x64646464u, b03, 0x04030402u);
+            P[2] = __builtin_amdgcn_perm(0x64646464u, b47, 0x04010400u);
+            P[3] = __builtin_amdgcn_perm(0x64646464u, b47, 0x04030402u);
         } else {
             constexpr int CPW = 4 / WBIT;
             constexpr uint32_t CM = (1u << (8 * WBIT)) - 1u;
             const uint32_t sub = (raw.x >> ((c8 % CPW) * 8 * WBIT)) & CM;
-            const uint32_t T = sub | (sub << (16 - 4 * WBIT));  // value i+4 lands 16 bits above value i
+            const uint32_t T = sub | (sub << (16 - WBIT));  // value 2i+1 lands 16 bits above value 2i (overlap bits are never read)
             constexpr uint32_t M1 = (1u << WBIT) - 1u;
 #pragma unroll
-            for (int i = 0; i < 4; i++) P[i] = (T >> (WBIT * i)) & (M1 | (M1 << 16));
+            for (int i = 0; i < 4; i++) P[i] = ((T >> (2 * WBIT * i)) & (M1 | (M1 << 16))) | 0x64006400u;
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const half2_t q = __builtin_bit_cast(half2_t, P[i] | 0x64006400u);
+            const half2_t q = __builtin_bit_cast(half2_t, P[i]);
             half2_t r;
             if constexpr (ZM == ZM_ASYM) {
                 r = (q - cp.zoff2) * cp.s2;
@@ -375,8 +379,8 @@ __global__ __launch_bounds__(256, (BM <= 128 ? 2 : 1)) void mpq_gemm_kernel(cons
     // ds_write_b128 pass alone cost ~600-900 of ~4500 cycles per K tile, profiles/r01_f_gemm_phase_cycles.txt).  One
     // wave-instruction fills 1 KiB of LDS lane-linearly (lane l -> bytes 16*l), i.e. 8 tile rows of the swizzled image;
     // the XOR swizzle is realised on the SOURCE side: lane l fetches the global chunk that belongs in LDS slot l.
-    // Only where the x chunk needs no in-flight re-ordering (bf16 fragments are in natural k order; no q_perm gather).
-    constexpr bool GLDS = (DT == BIE_BF16) && !PERM && BM >= 32;
+    // (The MBWQ q_perm gather of x stays on the register path.)
+    constexpr bool GLDS = !PERM && BM >= 32;
     constexpr int A_PIECES = BM / 32;  // 1 KiB pieces per wave per tile
     const uint16_t* asrc[A_PIECES];
     if constexpr (GLDS) {
@@ -390,13 +394,15 @@ __global__ __launch_bounds__(256, (BM <= 128 ? 2 : 1)) void mpq_gemm_kernel(cons
             asrc[i] = x + (long)m * K + sl * 8;
         }
     }
-    auto glds_a = [&](int kt, int buf) {
+    // the tile's pieces are issued in two portions, under the first two MFMA groups of the previous tile (the third group is left so that they land before the barrier)
+    // (an LDS-DMA issue costs 60-180 cycles beside MFMAs, MI355X_MICROARCH.md; all eight in one group starved it)
+    auto glds_a = [&](int kt, int buf, int part) {
         if constexpr (GLDS) {
             auto* dst = (__attribute__((address_space(3))) unsigned char*)lds + buf * A_BYTES + wave * (A_PIECES * 1024);
 #if defined(__HIP_DEVICE_COMPILE__)  // device-only builtin: the host pass must still see a well-formed body to emit the launch stub
 #pragma unroll
             for (int i = 0; i < A_PIECES; i++)
-                __builtin_amdgcn_global_load_lds(asrc[i] + kt * GEMM_BK, dst + i * 1024, 16, 0, 0);
+                if (part < 0 || (i * 2) / A_PIECES == part) __builtin_amdgcn_global_load_lds(asrc[i] + kt * GEMM_BK, dst + i * 1024, 16, 0, 0);
 #else
             (void)dst;
 #endif
@@ -459,7 +465,7 @@ __global__ __launch_bounds__(256, (BM <= 128 ? 2 : 1)) void mpq_gemm_kernel(cons
     uint4_t af0[TM], af1[TM];
     uint4_t bfrag[NF], bnext[NF];
     if (t_begin < t_end) {
-        if constexpr (GLDS) glds_a(t_begin, 0);
+        if constexpr (GLDS) glds_a(t_begin, 0, -1);
         else load_a(t_begin);
         load_wtile<DT, WBIT, ZM, GPT>(wcur, wp, t_begin * GEMM_BK, N, gshift);
         if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -484,9 +490,9 @@ __global__ __launch_bounds__(256, (BM <= 128 ? 2 : 1)) void mpq_gemm_kernel(cons
         for (int kk = 0; kk < 3; kk++) {
             if (kk & 1) lds_issue_frags<TM>(af0, foff[kk + 1] + abase);
             else lds_issue_frags<TM>(af1, foff[kk + 1] + abase);
+            if constexpr (GLDS) glds_a(ktn, cur ^ 1, kk);  // the other buffer: its last readers finished before the previous barrier
             if (kk == 0) {
-                if constexpr (GLDS) glds_a(ktn, cur ^ 1);  // the other buffer: its last readers finished before the previous barrier
-                else load_a(ktn);
+                if constexpr (!GLDS) load_a(ktn);
                 load_wtile<DT, WBIT, ZM, GPT>(wnext, wp, ktn * GEMM_BK, N, gshift);
             }
             __builtin_amdgcn_sched_barrier(0);  // keep the MFMAs below the issue point
@@ -581,31 +587,39 @@ static int env_int(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
-// Tile height and split-K factor from a measured cost model (tools/gemm_plan_sweep.py, profiles/r01_e_gemm_plan_sweep.log):
-//   one block per CU (512 registers per wave), so a launch runs ceil(blocks / 256) rounds of ceil(T / S) K-tiles each;
-//   a K-tile (64 k) of a BM x 256 tile costs c(BM) us (dequant of the 256 columns is paid per tile whatever BM is, hence
-//   the weak dependence on BM); split-K adds S fp32 partial slabs written and re-read (~4 TB/s) and the finalize launch.
-// The plan depends on (M, K, N) only: bie_mpq_workspace_bytes has to reproduce it without knowing dtype or bit width.
+// Tile height and split-K factor from a measured cost model (tools/gemm_plan_sweep2.py,
+// profiles/r01_g_gemm_plan_sweep_after_glds.log).  A K tile (64 k) of a BM x 256 block tile costs c0(BM) us on an otherwise
+// idle chip (the dequant of the 256 columns is paid per tile whatever BM is, hence the weak dependence on BM) and up to
+// 35 % more with all CUs busy; BM = 256 runs one block per CU (512 registers per wave), BM <= 128 two (a co-resident pair
+// takes ~1.7x one block).  A launch is a sequence of rounds of `cap` blocks; split-K adds S fp32 partial slabs written and
+// re-read plus the finalize launch.  The plan depends on (M, K, N) only: bie_mpq_workspace_bytes has to reproduce it
+// without knowing dtype or bit width.
 static GemmPlan plan_gemm(int M, int K, int N) {
-    static const int force_bm = env_int("BIE_GEMM_BM", 0), force_s = env_int("BIE_GEMM_S", 0);  // tuning knobs
+    const int force_bm = env_int("BIE_GEMM_BM", 0), force_s = env_int("BIE_GEMM_S", 0);  // tuning knobs (read per call: in-process sweeps)
     const int T = K / GEMM_BK;
     const int bms[4] = {32, 64, 128, 256};
-    const double ctile[4] = {0.95, 1.10, 1.50, 2.35};
+    const double c0[4] = {0.93, 1.00, 1.19, 1.53};
     double best = 1e30;
     GemmPlan p{256, 1, T};
     for (int i = 0; i < 4; i++) {
         const int BM = bms[i];
         if (force_bm ? (BM != force_bm) : (BM > 32 && BM >= 2 * M)) continue;
         const long tiles = (long)cdiv(M, BM) * cdiv(N, GEMM_BN);
+        const long cap = BM <= 128 ? 512 : 256;
         for (int S = 1; S <= 16; S++) {
             if (force_s ? (S != (force_s > T ? T : force_s)) : (S > 1 && T / S < 2)) continue;
             const int tps = cdiv(T, S), Sr = cdiv(T, tps);
             if (Sr != S && !force_s) continue;  // an equivalent smaller S exists
             const long blocks = tiles * Sr;
-            const long rounds = (blocks + 255) / 256;
-            const double busy = (double)blocks / (double)(rounds * 256);
-            double t = (double)rounds * tps * ctile[i] * (busy > 0.9 ? 1.15 : 1.0);
-            if (Sr > 1) t += 6.0 + (double)Sr * M * N * 8.0 / 4.0e6;
+            double units = 0.0;  // in K-tile times of one lone block
+            for (long left = blocks; left > 0; left -= cap) {
+                const long r = left < cap ? left : cap;
+                const double busy = r < 256 ? (double)r / 256.0 : 1.0;
+                const double pair = r > 256 ? 1.7 : 1.0;  // the round lasts as long as its busiest CU
+                units += (1.0 + 0.35 * busy) * pair;
+            }
+            double t = units * (tps + 3) * c0[i];  // + pipeline fill and epilogue of a block, about three K tiles
+            if (Sr > 1) t += 5.0 + (double)Sr * M * N * 8.0 / 6.0e6;
             if (t < best) { best = t; p.BM = BM; p.S = Sr; p.tiles_per_split = tps; }
         }
     }
