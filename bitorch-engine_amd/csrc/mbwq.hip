@@ -74,6 +74,28 @@ __device__ __forceinline__ void exl2_extract32(const uint32_t (&w)[8], uint32_t 
     }
 }
 
+// 16 fp16 pairs (1024 + q[2i], 1024 + q[2i+1]) of a chunk straight from the bitstream: a 32-bit window holding both
+// fields (funnel shift when it straddles two words), AND to the 2*BITS field bits, (t << (16-BITS)) | t puts the second
+// field at bit 16 (OR, not ADD: the overlap garbage lies outside the masks and cannot carry), AND-OR applies the field masks
+// and the 0x6400 exponent.  3-4 VALU per pair.
+template <int BITS>
+__device__ __forceinline__ void exl2_pairs16(const uint32_t (&w)[8], uint32_t (&P)[16]) {
+    constexpr uint32_t mask = (1u << BITS) - 1u;
+    constexpr uint32_t mask2 = (BITS == 16) ? 0xffffffffu : ((1u << (2 * BITS)) - 1u);
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int bitpos = 2 * i * BITS;
+        const int wi = bitpos >> 5, sh = bitpos & 31;
+        uint32_t v;
+        if (sh == 0) v = w[wi];
+        else if (sh + 2 * BITS <= 32) v = w[wi] >> sh;
+        else v = __builtin_amdgcn_alignbit(w[wi + 1], w[wi], sh);
+        const uint32_t t = v & mask2;
+        const uint32_t u = (t << (16 - BITS)) | t;
+        P[i] = (u & (mask | (mask << 16))) | 0x64006400u;
+    }
+}
+
 template <int BITS>
 __device__ __forceinline__ void exl2_load_chunk(const uint32_t* __restrict__ qw, long N, int prow, int n, uint32_t (&w)[8]) {
 #pragma unroll
@@ -199,6 +221,138 @@ __global__ __launch_bounds__(256) void exl2_gemv_kernel(const uint16_t* __restri
     }
 }
 
+// ---- exl2 decode GEMV (M <= 2): one column per lane, 16 waves per block interleave the 32-k chunks of the block's K slab ----
+// Per chunk: `bits` coalesced dword loads, pair extraction (exl2_pairs16), then the dequant and the dot product run on PACKED
+// fp16: the pairs are the halves 1024+q, v_pk_add_f16 / v_pk_fma_f16 reproduce the
+// reference's single-rounding __hfma2(q, s, -z) exactly, v_dot2_f32_f16 accumulates in fp32 against x pairs broadcast from
+// LDS (x is gathered through q_perm once per block, as fp16).  ~3.5 VALU per weight instead of ~6.5 in the scalar-fp32
+// kernel below, and no finalize launch when one slab covers K.
+constexpr int EX2_NW = 16;
+template <int MT>
+__global__ __launch_bounds__(EX2_NW * 64) void exl2_gemv2_kernel(const uint16_t* __restrict__ x, const uint32_t* __restrict__ qw,
+                                                                 const uint16_t* __restrict__ scales, const uint16_t* __restrict__ zeros,
+                                                                 const uint16_t* __restrict__ perm, const uint16_t* __restrict__ gmap,
+                                                                 float* __restrict__ part, uint16_t* __restrict__ y, Exl2Rows rows, int M,
+                                                                 int K, int N, int chunks_per_slab, int S) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem2[];
+    uint16_t* xs = reinterpret_cast<uint16_t*>(smem2);  // [MT][slab_k] fp16, q_perm applied
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = blockIdx.x * 64 + lane;
+    const int nl = n < N ? n : N - 1;
+    const int C = K >> 5;
+    const int c_begin = blockIdx.y * chunks_per_slab;
+    int c_end = c_begin + chunks_per_slab;
+    if (c_end > C) c_end = C;
+    const int slab_k = chunks_per_slab * 32;
+    float acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; m++) acc[m] = 0.f;
+    const half2_t k1024 = half2_t{(half_t)1024.0f, (half_t)1024.0f};
+    // A chunk's loads (packed words, group constants) are issued one chunk ahead of its arithmetic; the two register sets
+    // alternate (no copies: a copied load result would have to be waited for at the loop's back edge).
+    struct Chunk {
+        uint32_t w[8];
+        uint32_t s[2], z[2];
+        int bits;
+    };
+    auto issue = [&](int c, Chunk& ch) {
+        const int k0 = c * 32;
+        int bits, prow;
+        exl2_locate(rows, k0, bits, prow);
+        ch.bits = bits;
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if (i < bits) ch.w[i] = __builtin_nontemporal_load(qw + (long)(prow + i) * N + nl);
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int g = gmap[2 * (k0 + 16 * half)];
+            ch.s[half] = scales[(long)g * N + nl];
+            ch.z[half] = zeros[(long)g * N + nl];
+        }
+    };
+    auto compute = [&](int c, const Chunk& ch) {
+        uint32_t P[16];
+        switch (ch.bits) {
+            case 8: exl2_pairs16<8>(ch.w, P); break;
+            case 6: exl2_pairs16<6>(ch.w, P); break;
+            case 5: exl2_pairs16<5>(ch.w, P); break;
+            case 4: exl2_pairs16<4>(ch.w, P); break;
+            case 3: exl2_pairs16<3>(ch.w, P); break;
+            default: exl2_pairs16<2>(ch.w, P); break;
+        }
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const half_t sh = __builtin_bit_cast(half_t, (uint16_t)ch.s[half]);
+            const half_t zh = __builtin_bit_cast(half_t, (uint16_t)ch.z[half]);
+            const half2_t s2 = half2_t{sh, sh}, nz2 = half2_t{(half_t)-zh, (half_t)-zh};
+            uint4_t xv[MT][2];
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                const uint4_t* xp = reinterpret_cast<const uint4_t*>(xs + m * slab_k + (c - c_begin) * 32 + 16 * half);
+                xv[m][0] = xp[0];
+                xv[m][1] = xp[1];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const half2_t qh = __builtin_bit_cast(half2_t, P[8 * half + i]) - k1024;  // exact
+                const half2_t r = __builtin_elementwise_fma(qh, s2, nz2);           // one rounding == __hfma2(q, s, -z)
+#pragma unroll
+                for (int m = 0; m < MT; m++) {
+                    const uint4_t xq = xv[m][i >> 2];
+                    const uint32_t xpair = (i & 3) == 0 ? xq.x : ((i & 3) == 1 ? xq.y : ((i & 3) == 2 ? xq.z : xq.w));
+                    acc[m] = __builtin_amdgcn_fdot2(r, __builtin_bit_cast(half2_t, xpair), acc[m], false);
+                }
+            }
+        }
+    };
+    {
+        Chunk ca, cb, cc, cd;
+        int c = c_begin + wave;
+        constexpr int W1 = EX2_NW;
+        // the weight stream starts before x is gathered (q_perm -> x is a dependent load chain): four chunks per wave in
+        // flight (16 waves x 4 chunks x `bits` rows x 256 B per CU; with two, the bytes in flight capped the rate near 1 TB/s)
+        if (c < c_end) issue(c, ca);
+        if (c + W1 < c_end) issue(c + W1, cb);
+        if (c + 2 * W1 < c_end) issue(c + 2 * W1, cc);
+        if (c + 3 * W1 < c_end) issue(c + 3 * W1, cd);
+        for (int idx = tid; idx < MT * slab_k; idx += EX2_NW * 64) {
+            const int m = idx / slab_k, kk = idx - m * slab_k;
+            const int k = c_begin * 32 + kk;
+            uint16_t v = 0;
+            if (m < M && k < K) v = x[(long)m * K + (perm ? (int)perm[k] : k)];
+            xs[idx] = v;
+        }
+        __syncthreads();
+        for (; c < c_end; c += 4 * W1) {
+            compute(c, ca);
+            if (c + 4 * W1 < c_end) issue(c + 4 * W1, ca);
+            if (c + W1 < c_end) compute(c + W1, cb);
+            if (c + 5 * W1 < c_end) issue(c + 5 * W1, cb);
+            if (c + 2 * W1 < c_end) compute(c + 2 * W1, cc);
+            if (c + 6 * W1 < c_end) issue(c + 6 * W1, cc);
+            if (c + 3 * W1 < c_end) compute(c + 3 * W1, cd);
+            if (c + 7 * W1 < c_end) issue(c + 7 * W1, cd);
+        }
+    }
+    // block reduction over the waves in wave order (deterministic)
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem2);
+#pragma unroll
+    for (int m = 0; m < MT; m++) red[(wave * MT + m) * 64 + lane] = acc[m];
+    __syncthreads();
+    if (tid < 64 * MT) {
+        const int om = tid >> 6, ol = tid & 63, on = blockIdx.x * 64 + ol;
+        float tot = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < EX2_NW; wv++) tot += red[(wv * MT + om) * 64 + ol];
+        if (om < M && on < N) {
+            if (S == 1) y[(long)om * N + on] = f32_to_f16_bits(tot);
+            else part[((long)blockIdx.y * M + om) * N + on] = tot;
+        }
+    }
+}
+
 static int exl2_slabs(int K, int N) {
     const int C = K / 32;
     int S = cdiv(1024, cdiv(N, 256));
@@ -260,6 +414,29 @@ int mbwq_exl2_forward_launch(const void* x, const int32_t* qw, const void* scale
                              hipStream_t st) {
     Exl2Rows rows;
     for (int i = 0; i < 6; i++) rows.r[i] = rows7[i];
+    if (M <= 2) {  // decode path
+        const int C = K / 32, colblocks = cdiv(N, 64);
+        int S = colblocks >= 160 ? 1 : cdiv(256, colblocks);
+        if (S > C / 4) S = C / 4 > 0 ? C / 4 : 1;  // keep a few chunks per slab
+        int cps2 = cdiv(C, S);
+        if (cps2 > 512) cps2 = 512;  // x slab in LDS: 2 rows x 512 chunks x 32 x 2 B = 64 KiB
+        S = cdiv(C, cps2);
+        const int MT = M;
+        size_t lds2 = (size_t)MT * cps2 * 32 * sizeof(uint16_t);
+        const size_t red = (size_t)EX2_NW * MT * 64 * sizeof(float);
+        if (lds2 < red) lds2 = red;
+        dim3 grid2(colblocks, S);
+#define L2(MTV)                                                                                                            \
+    hipLaunchKernelGGL(exl2_gemv2_kernel<MTV>, grid2, dim3(EX2_NW * 64), lds2, st, (const uint16_t*)x, (const uint32_t*)qw,    \
+                       (const uint16_t*)scales, (const uint16_t*)zeros, (const uint16_t*)perm, (const uint16_t*)gmap, part,      \
+                       (uint16_t*)y, rows, M, K, N, cps2, S)
+        if (MT == 1) L2(1); else L2(2);
+#undef L2
+        int rc = check_launch("exl2_gemv2_kernel");
+        if (rc) return rc;
+        if (S > 1) return launch_splitk_finalize(part, nullptr, (uint16_t*)y, S, M, N, BIE_F16, st);
+        return BIE_OK;
+    }
     const int cps = exl2_slabs(K, N);
     const int S = cdiv(K / 32, cps);
     dim3 grid(cdiv(N, 256), S);
