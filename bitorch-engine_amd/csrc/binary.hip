@@ -44,45 +44,47 @@ __global__ __launch_bounds__(256) void pack_cols_kernel(const void* __restrict__
 // 64 x 64 output tile per block, 16 x 16 threads, 4 x 4 outputs per thread, KC words per LDS stage.
 constexpr int XT = 64, XKC = 32;
 
+template <int RM>  // rows per thread: the block tile is 16*RM rows x 64 columns (RM = 1 for skinny M: 4x the blocks)
 __global__ __launch_bounds__(256) void xnor_gemm_kernel(const uint32_t* __restrict__ A, const uint32_t* __restrict__ B,
                                                         float* __restrict__ y, int M, int N, int KW, int Kbits, float scale,
                                                         long strideA, long strideB, long strideY) {
-    __shared__ uint32_t As[XT][XKC + 1];
+    constexpr int XTM = 16 * RM;
+    __shared__ uint32_t As[XTM][XKC + 1];
     __shared__ uint32_t Bs[XT][XKC + 1];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int m0 = blockIdx.y * XT, n0 = blockIdx.x * XT;
+    const int m0 = blockIdx.y * XTM, n0 = blockIdx.x * XT;
     A += (long)blockIdx.z * strideA;
     B += (long)blockIdx.z * strideB;
     y += (long)blockIdx.z * strideY;
-    int acc[4][4];
+    int acc[RM][4];
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < RM; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = 0;
     for (int k0 = 0; k0 < KW; k0 += XKC) {
         for (int idx = threadIdx.x; idx < XT * XKC; idx += 256) {
             const int r = idx / XKC, c = idx % XKC;
             const int k = k0 + c;
-            As[r][c] = (m0 + r < M && k < KW) ? A[(long)(m0 + r) * KW + k] : 0u;
+            if (r < XTM) As[r][c] = (m0 + r < M && k < KW) ? A[(long)(m0 + r) * KW + k] : 0u;
             Bs[r][c] = (n0 + r < N && k < KW) ? B[(long)(n0 + r) * KW + k] : 0u;
         }
         __syncthreads();
 #pragma unroll 8
         for (int c = 0; c < XKC; c++) {
-            uint32_t a[4], b[4];
+            uint32_t a[RM], b[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) a[i] = As[ty + 16 * i][c];
+            for (int i = 0; i < RM; i++) a[i] = As[ty + 16 * i][c];
 #pragma unroll
             for (int j = 0; j < 4; j++) b[j] = Bs[tx + 16 * j][c];
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+            for (int i = 0; i < RM; i++)
 #pragma unroll
                 for (int j = 0; j < 4; j++) acc[i][j] += __builtin_popcount(a[i] ^ b[j]);
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < RM; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int m = m0 + ty + 16 * i, n = n0 + tx + 16 * j;
@@ -129,6 +131,44 @@ __global__ __launch_bounds__(256) void xnor_bytes_kernel(const uint8_t* __restri
         pc += __builtin_popcount((unsigned)(X[m * KB + b] ^ wv));
     }
     y[m * N + n] = (float)(KB * 8 - 2 * pc) * scale;
+}
+
+// column bit-plane weights (the binary_linear_cpp layout: byte [b*N + n] holds k = 8b..8b+7 of output n): a lane owns 4
+// consecutive columns (one dword per plane), the 16 waves of a block interleave the K/8 planes, x bytes are wave-uniform
+// (scalar loads); one block row per x row.
+__global__ __launch_bounds__(1024) void xnor_planes_kernel(const uint8_t* __restrict__ X, const uint8_t* __restrict__ W,
+                                                           float* __restrict__ y, long M, long N, long KB, float scale) {
+    __shared__ int red[16][64][4];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long m = blockIdx.y;
+    const long n4 = ((long)blockIdx.x * 64 + lane) * 4;
+    const long nl = n4 < N ? n4 : N - 4;
+    int acc[4] = {0, 0, 0, 0};
+    const uint8_t* xr = X + m * KB;
+    for (long b = wave; b < KB; b += 16) {
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(W + b * N + nl);
+        const uint32_t v = w ^ ((uint32_t)xr[b] * 0x01010101u);
+        acc[0] += __builtin_popcount(v & 0xffu);
+        acc[1] += __builtin_popcount(v & 0xff00u);
+        acc[2] += __builtin_popcount(v & 0xff0000u);
+        acc[3] += __builtin_popcount(v & 0xff000000u);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) red[wave][lane][j] = acc[j];
+    __syncthreads();
+    if (wave == 0 && n4 < N) {
+        float4_t o;
+        int t[4] = {0, 0, 0, 0};
+        for (int wv = 0; wv < 16; wv++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) t[j] += red[wv][lane][j];
+        o.x = (float)(KB * 8 - 2 * t[0]) * scale;
+        o.y = (float)(KB * 8 - 2 * t[1]) * scale;
+        o.z = (float)(KB * 8 - 2 * t[2]) * scale;
+        o.w = (float)(KB * 8 - 2 * t[3]) * scale;
+        *reinterpret_cast<float4_t*>(y + m * N + n4) = o;
+    }
 }
 
 // ---- conv2d: bit-im2col (pad -> bit 0 == -1) into 32-bit words, zero-padded to a word multiple -----------------
@@ -238,6 +278,11 @@ int pack_cols_launch(const void* w, uint8_t* out, long N, long K, int dtype, hip
 int binary_linear_launch(const uint8_t* xp, const uint8_t* wp, float* y, long M, long N, long K, int w_layout, float scale,
                          hipStream_t st) {
     const bool words_ok = (K % 32 == 0) && w_layout == 0 && (((uintptr_t)xp | (uintptr_t)wp) & 3) == 0;
+    if (w_layout == 1 && N % 4 == 0 && N >= 4 && ((uintptr_t)wp & 3) == 0 && ((uintptr_t)y & 15) == 0 && M <= 65535) {
+        dim3 grid((unsigned)cdivl(N, 256), (unsigned)M);
+        hipLaunchKernelGGL(xnor_planes_kernel, grid, dim3(1024), 0, st, xp, wp, y, M, N, K / 8, scale);
+        return check_launch("xnor_planes_kernel");
+    }
     if (!words_ok) {
         dim3 grid((unsigned)cdivl(N, 256), (unsigned)M);
         hipLaunchKernelGGL(xnor_bytes_kernel, grid, dim3(256), 0, st, xp, wp, y, M, N, K / 8, w_layout, scale);
@@ -251,9 +296,15 @@ int binary_linear_launch(const uint8_t* xp, const uint8_t* wp, float* y, long M,
         else hipLaunchKernelGGL(xnor_gemv_kernel<4>, grid, dim3(256), 0, st, (const uint32_t*)xp, (const uint32_t*)wp, y, (int)M, (int)N, KW, (int)K, scale);
         return check_launch("xnor_gemv_kernel");
     }
-    dim3 grid((unsigned)cdivl(N, XT), (unsigned)cdivl(M, XT), 1);
-    hipLaunchKernelGGL(xnor_gemm_kernel, grid, dim3(256), 0, st, (const uint32_t*)xp, (const uint32_t*)wp, y, (int)M, (int)N, KW,
-                       (int)K, scale, 0L, 0L, 0L);
+    if (cdivl(N, XT) * cdivl(M, XT) < 192) {  // skinny M: 16-row tiles, 4x the blocks
+        dim3 grid((unsigned)cdivl(N, XT), (unsigned)cdivl(M, 16), 1);
+        hipLaunchKernelGGL(xnor_gemm_kernel<1>, grid, dim3(256), 0, st, (const uint32_t*)xp, (const uint32_t*)wp, y, (int)M, (int)N, KW,
+                           (int)K, scale, 0L, 0L, 0L);
+    } else {
+        dim3 grid((unsigned)cdivl(N, XT), (unsigned)cdivl(M, XT), 1);
+        hipLaunchKernelGGL(xnor_gemm_kernel<4>, grid, dim3(256), 0, st, (const uint32_t*)xp, (const uint32_t*)wp, y, (int)M, (int)N, KW,
+                           (int)K, scale, 0L, 0L, 0L);
+    }
     return check_launch("xnor_gemm_kernel");
 }
 
@@ -290,9 +341,15 @@ int binary_conv_launch(const void* x, const uint8_t* wpacked, float* y, void* ws
         if (rc) return rc;
     }
     // y[b][oc][p] = (Kc - 2 popc(w[oc] ^ cols[b][p])) * scale : A = weights (shared), B = cols of image b
-    dim3 grid((unsigned)cdiv(P, XT), (unsigned)cdiv(OC, XT), (unsigned)B);
-    hipLaunchKernelGGL(xnor_gemm_kernel, grid, dim3(256), 0, st, wwords, cols, y, OC, P, KW, Kc, scale, 0L, (long)P * KW,
-                       (long)OC * P);
+    if ((long)cdiv(P, XT) * cdiv(OC, XT) * B < 192) {  // few tiles (7x7 maps, small batch): 16-row tiles give 4x the blocks
+        dim3 grid((unsigned)cdiv(P, XT), (unsigned)cdiv(OC, 16), (unsigned)B);
+        hipLaunchKernelGGL(xnor_gemm_kernel<1>, grid, dim3(256), 0, st, wwords, cols, y, OC, P, KW, Kc, scale, 0L, (long)P * KW,
+                           (long)OC * P);
+    } else {
+        dim3 grid((unsigned)cdiv(P, XT), (unsigned)cdiv(OC, XT), (unsigned)B);
+        hipLaunchKernelGGL(xnor_gemm_kernel<4>, grid, dim3(256), 0, st, wwords, cols, y, OC, P, KW, Kc, scale, 0L, (long)P * KW,
+                           (long)OC * P);
+    }
     return check_launch("xnor_gemm_kernel(conv)");
 }
 
