@@ -200,10 +200,10 @@ def main():
                                    wsg.data_ptr(), wsg.numel(), M, K, N, WBIT, GROUP, 0, _hip.BF16, st)
             if rc:
                 raise RuntimeError(L.bie_last_error().decode())
-        for i in range(3):
+        for i in range(8):
             gemm(i)
         torch.cuda.synchronize()
-        reps = 20
+        reps = 32
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for i in range(reps):
