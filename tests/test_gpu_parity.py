@@ -120,6 +120,25 @@ def test_mpq_forward_vs_oracle(dt, w_bit, asym, M):
     assert_close(y, ref, dt, f"dt={dt} w{w_bit} asym={asym} M={M}")
 
 
+@pytest.mark.parametrize("bm", [32, 64, 128, 256])
+@pytest.mark.parametrize("S", [1, 2, 3, 5])
+def test_mfma_gemm_every_tile_height_and_split(bm, S, monkeypatch):
+    """The launcher picks (tile height, split-K factor) from a cost model; force every combination through the tuning knobs
+    (read per call) so that no plan the model could ever choose is untested: odd tile counts per split, clamped rows,
+    a ragged last column tile, both dtypes, sym and asym."""
+    monkeypatch.setenv("BIE_GEMM_BM", str(bm))
+    monkeypatch.setenv("BIE_GEMM_S", str(S))
+    M, K, N, gs = 300, 1088, 520, 64  # 17 K tiles, 3 column tiles (the last one 8 columns wide)
+    for dt in (orc.BF16, orc.F16):
+        for asym in (0, 1):
+            rng = np.random.default_rng(bm + 7 * S + dt + 3 * asym)
+            qw, scales, zeros, gen = rand_case(rng, K, N, 4, gs, dt, asym)
+            x = torch.randn((M, K), generator=gen).to(TDT[dt])
+            y = hip_forward(x, qw, scales, zeros, None, 4, gs, asym)
+            ref = oracle_forward(x, qw, scales, zeros, None, 4, gs, asym, dt)
+            assert_close(y, ref, dt, f"BM={bm} S={S} dt={dt} asym={asym}")
+
+
 @pytest.mark.parametrize("K,N,gs,M", [(128, 64, 32, 1), (256, 260, 64, 4), (4096, 128, 128, 1), (1024, 2048, 1024, 2),
                                       (192, 132, 64, 16), (4096, 512, 32, 48), (2048, 1000, 128, 130), (64, 32, 64, 5)])
 @pytest.mark.parametrize("dt", [orc.F16, orc.BF16])
