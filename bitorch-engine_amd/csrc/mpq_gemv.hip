@@ -401,14 +401,29 @@ struct Gemv3Plan {
 // S (and with it the workspace) depends on (K, N, w_bit) only.
 static Gemv3Plan plan_gemv3(int K, int N, int w_bit) {
     static const int nw_env = env_int("BIE_GEMV3_NW", 16);
-    static const int blocks_env = env_int("BIE_GEMV3_MIN_BLOCKS", 160);
+    static const int force_s = env_int("BIE_GEMV3_S", 0);  // tuning knob
     const int NB = 32 / w_bit;
     const int R = K / NB;
     Gemv3Plan p;
     p.NW = nw_env == 8 ? 8 : 16;
     const int tiles = cdiv(N, 64);
+    // Split K over blockIdx.y so that the busiest CU gets the smallest share of a column block: with `tiles * S` blocks on
+    // 256 CUs that share is ceil(tiles * S / 256) / S (N = 11008: 172 tiles -> 1.0 unsplit, 0.75 at S = 4; N = 4096:
+    // 64 tiles -> 0.25 at S = 4).  The ticketed in-kernel reduction costs about a microsecond, modelled as a flat penalty
+    // (measured, tools/gemv_split_n11008.sh / gemv_small_n.sh: 4096x11008 14.8 -> 13.0 us, 4096x4096 9.6 -> 7.8 us,
+    // 11008x4096 16.3 -> 14.2 us).  A wave needs at least one batch of 8 packed rows.
     int S = 1;
-    if (tiles < blocks_env) S = cdiv(blocks_env, tiles);
+    if (force_s > 0) {
+        S = force_s;
+    } else {
+        double best = 1e30;
+        for (int s = 1; s <= 16; s++) {
+            if (s > 1 && R / (8 * p.NW * s) < 1) break;
+            const double share = (double)cdiv(tiles * s, 256) / s;
+            const double cost = share + (s > 1 ? 0.08 + 0.005 * s : 0.0);
+            if (cost < best - 1e-9) { best = cost; S = s; }
+        }
+    }
     int rpw = cdiv(cdiv(R, p.NW * S), 8) * 8;  // whole batches of 8 rows
     if (rpw < 8) rpw = 8;
     p.rows_per_wave = rpw;
