@@ -110,7 +110,8 @@ int bie_mpq_forward(const void* x, const int32_t* qweight, const void* scales, c
     // M <= 2: the dot2 GEMV; 3 <= M: the MFMA kernel (its dequant cost does not grow with M; measured faster from M = 3).
     // The GEMV also serves M <= 8 for shapes the MFMA tiling cannot take.
     const bool gemm_ok = mpq_gemm_ok(M, K, N, w_bit, group_size, dtype, has_gidx);
-    if (M <= 8 && (M <= 2 || !gemm_ok) && mpq_gemv_fast_ok(M, K, N, w_bit, group_size, dtype, has_gidx))
+    static const int gemv_max_m = []() { const char* e = getenv("BIE_GEMV_MAX_M"); return e ? atoi(e) : 2; }();  // tuning knob
+    if (M <= 8 && (M <= gemv_max_m || !gemm_ok) && mpq_gemv_fast_ok(M, K, N, w_bit, group_size, dtype, has_gidx))
         return mpq_gemv_launch(x, qweight, scales, zeros, bias, y, head, M, K, N, w_bit, group_size, asym ? 1 : 0, dtype, nullptr, st);
     if (gemm_ok)
         return mpq_gemm_launch(x, qweight, scales, zeros, bias, y, part, M, K, N, w_bit, group_size, asym ? 1 : 0, dtype, nullptr, st);
