@@ -2,16 +2,18 @@
 // bie_mpq_forward.  Replaces quant_mm_kernel[_asym] (reference
 // layers/qlinear/nbit/cuda/mpq_linear_cuda_kernel.cu:67-451).
 //
-// Design (HBM-bound: every packed word is read exactly once, coalesced, 16 B per lane):
-//   * a wave reads 1 KiB-contiguous pieces of a packed row: lane l owns columns 4l..4l+3 of a
-//     256-column tile (one `global_load_dwordx4`, non-temporal: the weights are streamed once);
-//   * a 256-thread block = 4 waves owns (256 columns) x (one K slab); the waves split the slab's
-//     packed rows and keep U row-loads in flight per lane before the first use;
-//   * dequantisation happens in registers in 16-bit pairs (mpq_dequant.cuh) and feeds
-//     v_dot2_f32_{f16,bf16} with fp32 accumulators -- the activations are wave-uniform and are
-//     read as LDS broadcasts of the (pre-permuted) x slab;
-//   * split-K over blocks (grid.y) fills the 256 CUs for small N; partial sums go to an fp32
-//     workspace and are reduced in fixed order by splitk_finalize (deterministic, no atomics).
+// Three kernels, every packed word read exactly once and coalesced:
+//   * mpq_gemv3_kernel -- the decode path (no q_perm, whole 8-row batches inside one group).  One column per lane, a wave
+//     owns 64 columns x a K range, 16 waves per block; dword non-temporal loads, up to three 8-row batches in flight; x is
+//     wave-uniform and comes through scalar loads (no LDS staging, no barrier before the weight stream); dequantisation in
+//     registers in 16-bit pairs (mpq_dequant.cuh) feeding v_dot2_f32_{f16,bf16} with fp32 accumulators; block reduction
+//     through LDS.  K is also split over blockIdx.y (plan_gemv3: the split minimising the busiest CU's share of a column
+//     block -- the dispatcher balances the small equal blocks dynamically); the last block to arrive at a column tile
+//     (relaxed agent-scope ticket, write-through partials, per-wave vmcnt(0) drain, batched bypassing reads) sums the
+//     slabs in slab order and writes y: deterministic, no finalize launch.
+//   * mpq_gemv_kernel -- the earlier 4-columns-per-lane variant (dwordx4 loads, x slab staged in LDS, optionally gathered
+//     through q_perm): MBWQ act-order and the shapes the v3 kernel does not take.
+//   * mpq_gemv_generic_kernel -- any N / group size, explicit g_idx, fp32: correctness path (partials + splitk_finalize).
 #include "mpq_dequant.cuh"
 #include <stdlib.h>
 
