@@ -1,21 +1,24 @@
-// W{1,2,4,8}A16 fused dequant + MFMA GEMM for gfx950 (M > 8) -- the compute-bound half of
+// W{1,2,4,8}A16 fused dequant + MFMA GEMM for gfx950 (M >= 3) -- the compute-bound half of
 // bie_mpq_forward.  Replaces the reference's "materialise the whole K x N fp16 weight, then cuBLAS"
 // branch (layers/qlinear/nbit/cuda/mpq_layer.py:59-63, unpack_qweight utils.py:30-51).
 //
-// Key observation: for v_mfma_f32_32x32x16_{f16,bf16} the B fragment of lane l is the 8 consecutive-k
+// Key observation: for v_mfma_f32_32x32x16_{f16,bf16} the operand fragment of lane l is the 8 consecutive-k
 // values (k = 8*(l>>5) .. +7) of ONE output column (n = l&31) -- which in the reference's packed
 // layout qweight[k/(32/w)][n] is 8*w contiguous bits of one int32 word.  So the packed weights go
-//     HBM -> one dword per lane -> dequant in registers -> MFMA B operand
-// with no LDS round trip and no transposition, and each wave dequantises ONLY its own 32 columns:
-//   * block = 4 waves, block tile BM x 128 (each wave: all BM rows x 32 columns, BM/32 accumulators
-//     of 32x32), so the VALU dequant cost per MFMA shrinks with BM (BM=256: 8 MFMAs per fragment);
-//   * x (the A operand) is the operand shared by the 4 waves: staged global -> registers -> LDS in
-//     [BM][64] tiles, double buffered, one barrier per K tile; the LDS image is XOR-swizzled so the
-//     ds_read_b128 fragment reads are bank-conflict free; the staging pass also applies the 8-element
-//     k permutation that the dequant's pair order implies (mpq_dequant.cuh) -- the contraction is
-//     invariant under a consistent permutation of k on both operands;
-//   * accumulation in fp32 (AGPR/VGPR unified file), one rounding to fp16/bf16 at the store;
-//   * optional split-K (grid.z) for skinny M; partials reduced in fixed order by splitk_finalize.
+//     HBM -> one dword per lane -> dequant in registers -> MFMA operand
+// with no LDS round trip and no transposition, and each wave dequantises ONLY its own 64 columns:
+//   * block = 4 waves, block tile BM x 256 (each wave: all BM rows x 64 columns, 2*BM/32 accumulators of 32x32), so the
+//     VALU dequant cost per MFMA shrinks with BM (BM = 256: one wave per SIMD with the 512-register budget);
+//   * x is the operand shared by the 4 waves: global_load_lds_dwordx4 straight into an XOR-swizzled [BM][64] LDS image
+//     (swizzle applied on the source address), double buffered, one barrier per K tile; ds_read_b128 fragment reads are
+//     bank-conflict free; both dtypes produce the weight fragment in natural k order, so x needs no re-ordering (the MBWQ
+//     q_perm gather of x is the one case that still goes global -> registers -> LDS);
+//   * the K loop is software-pipelined across the tile boundary: every MFMA group has the next group's A fragments in
+//     flight and the next group's B fragments being dequantised; loads of the next tile are issued under the first groups;
+//   * MFMAs are issued as D = W_frag . x_frag: a lane owns 4 consecutive output columns -> 8-byte row-contiguous stores;
+//   * accumulation in fp32, one rounding to fp16/bf16 at the store;
+//   * tile height and split-K factor from a measured cost model (plan_gemm); partials reduced in fixed order by
+//     splitk_finalize (an in-kernel ticketed reduction was measured 5-8x slower at GEMM partial volumes).
 #include "mpq_dequant.cuh"
 #ifndef BIE_GEMM_LAB
 #define BIE_GEMM_LAB 0  // compile-time ablation switch used by tools/ (0 = product code)
