@@ -8,8 +8,11 @@
 //     exl2/quant/qdq_{2,3,4,5,6,8}.cuh).  Replaces reconstruct_exl2_kernel
 //     (mbwq_linear_cuda_kernel.cu:92-308) and gemm_half_q_half_kernel (exl2/q_gemm_kernel.cuh:90-549).
 //     One lane owns one column and walks 32-k chunks: `bits` coalesced dword loads per chunk, bit
-//     extraction with compile-time shifts (v_alignbit for the straddling fields), v_fma_f16 dequant
-//     (exactly the reference's __hfma2), fp32 accumulation.
+//     extraction with compile-time shifts (v_alignbit for the straddling fields), fp16 fma dequant
+//     (exactly the reference's single-rounding __hfma2), fp32 accumulation.  Decode (M <= 2) runs
+//     exl2_gemv2_kernel (packed fp16 pairs, v_dot2_f32_f16, loads issued chunks ahead); 3 <= M <= 32
+//     the scalar exl2_gemv_kernel in passes of 8 rows; larger M is routed by the Python front-end to
+//     reconstruct + library GEMM like the reference.
 #include "bie_common.h"
 
 #pragma clang fp contract(off)
