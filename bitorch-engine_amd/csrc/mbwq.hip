@@ -238,16 +238,17 @@ __global__ __launch_bounds__(EX2_NW * 64) void exl2_gemv2_kernel(const uint16_t*
                                                                  float* __restrict__ part, uint16_t* __restrict__ y, Exl2Rows rows, int M,
                                                                  int K, int N, int chunks_per_slab, int S) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem2[];
-    uint16_t* xs = reinterpret_cast<uint16_t*>(smem2);  // [MT][slab_k] fp16, q_perm applied
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // wave-private x chunk buffers [wave][set 0..3][MT][32] fp16 (q_perm applied): each wave gathers the 32 activations of
+    // its own chunk together with the chunk's loads -- no block-wide x slab, no barrier before the weight stream
+    uint16_t* xs = reinterpret_cast<uint16_t*>(smem2) + wave * (4 * MT * 32);
     const int n = blockIdx.x * 64 + lane;
     const int nl = n < N ? n : N - 1;
     const int C = K >> 5;
     const int c_begin = blockIdx.y * chunks_per_slab;
     int c_end = c_begin + chunks_per_slab;
     if (c_end > C) c_end = C;
-    const int slab_k = chunks_per_slab * 32;
     float acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; m++) acc[m] = 0.f;
@@ -257,9 +258,15 @@ __global__ __launch_bounds__(EX2_NW * 64) void exl2_gemv2_kernel(const uint16_t*
     struct Chunk {
         uint32_t w[8];
         uint32_t s[2], z[2];
+        int g[2];
         int bits;
+        int pidx;           // q_perm[k0 + lane % 32]
+        uint32_t xraw[MT];  // x[m][pidx]
     };
-    auto issue = [&](int c, Chunk& ch) {
+    // issue_w: the packed words and the two group-map entries (scalar loads) of a chunk; issue_sz: the group constants, which
+    // need the map entries -- called one compute() later, so the scalar-load latency is never waited for (PMC of the first
+    // version: VALU busy 11 %, 56 % of the wave time in s_waitcnt, most of it on these dependent scalar loads).
+    auto issue_w = [&](int c, Chunk& ch) {
         const int k0 = c * 32;
         int bits, prow;
         exl2_locate(rows, k0, bits, prow);
@@ -267,14 +274,33 @@ __global__ __launch_bounds__(EX2_NW * 64) void exl2_gemv2_kernel(const uint16_t*
 #pragma unroll
         for (int i = 0; i < 8; i++)
             if (i < bits) ch.w[i] = __builtin_nontemporal_load(qw + (long)(prow + i) * N + nl);
-#pragma unroll
-        for (int half = 0; half < 2; half++) {
-            const int g = gmap[2 * (k0 + 16 * half)];
-            ch.s[half] = scales[(long)g * N + nl];
-            ch.z[half] = zeros[(long)g * N + nl];
-        }
+        ch.g[0] = gmap[2 * k0];
+        ch.g[1] = gmap[2 * (k0 + 16)];
+        ch.pidx = perm ? (int)perm[k0 + (lane & 31)] : k0 + (lane & 31);
     };
-    auto compute = [&](int c, const Chunk& ch) {
+    auto issue_sz = [&](Chunk& ch) {
+        ch.s[0] = scales[(long)ch.g[0] * N + nl];
+        ch.z[0] = zeros[(long)ch.g[0] * N + nl];
+        if (ch.g[1] != ch.g[0]) {  // wave-uniform; groups of >= 32 k share the constants between the two halves of a chunk
+            ch.s[1] = scales[(long)ch.g[1] * N + nl];
+            ch.z[1] = zeros[(long)ch.g[1] * N + nl];
+        } else {
+            ch.s[1] = ch.s[0];
+            ch.z[1] = ch.z[0];
+        }
+#pragma unroll
+        for (int m = 0; m < MT; m++) ch.xraw[m] = (m < M) ? x[(long)m * K + ch.pidx] : 0;
+    };
+    auto compute = [&](int set, const Chunk& ch) {
+        uint16_t* xw = xs + set * (MT * 32);
+        if (lane < 32) {
+#pragma unroll
+            for (int m = 0; m < MT; m++) xw[m * 32 + lane] = (uint16_t)ch.xraw[m];
+        }
+        // same wave writes then reads: the LDS pipe keeps a wave's operations in order, the compiler must too (the 2-byte
+        // stores and the 16-byte loads below have different types)
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
         uint32_t P[16];
         switch (ch.bits) {
             case 8: exl2_pairs16<8>(ch.w, P); break;
@@ -292,7 +318,7 @@ __global__ __launch_bounds__(EX2_NW * 64) void exl2_gemv2_kernel(const uint16_t*
             uint4_t xv[MT][2];
 #pragma unroll
             for (int m = 0; m < MT; m++) {
-                const uint4_t* xp = reinterpret_cast<const uint4_t*>(xs + m * slab_k + (c - c_begin) * 32 + 16 * half);
+                const uint4_t* xp = reinterpret_cast<const uint4_t*>(xw + m * 32 + 16 * half);
                 xv[m][0] = xp[0];
                 xv[m][1] = xp[1];
             }
@@ -313,29 +339,29 @@ __global__ __launch_bounds__(EX2_NW * 64) void exl2_gemv2_kernel(const uint16_t*
         Chunk ca, cb, cc, cd;
         int c = c_begin + wave;
         constexpr int W1 = EX2_NW;
-        // the weight stream starts before x is gathered (q_perm -> x is a dependent load chain): four chunks per wave in
-        // flight (16 waves x 4 chunks x `bits` rows x 256 B per CU; with two, the bytes in flight capped the rate near 1 TB/s)
-        if (c < c_end) issue(c, ca);
-        if (c + W1 < c_end) issue(c + W1, cb);
-        if (c + 2 * W1 < c_end) issue(c + 2 * W1, cc);
-        if (c + 3 * W1 < c_end) issue(c + 3 * W1, cd);
-        for (int idx = tid; idx < MT * slab_k; idx += EX2_NW * 64) {
-            const int m = idx / slab_k, kk = idx - m * slab_k;
-            const int k = c_begin * 32 + kk;
-            uint16_t v = 0;
-            if (m < M && k < K) v = x[(long)m * K + (perm ? (int)perm[k] : k)];
-            xs[idx] = v;
-        }
-        __syncthreads();
+        // four chunks per wave in flight
+        if (c < c_end) issue_w(c, ca);
+        if (c + W1 < c_end) issue_w(c + W1, cb);
+        if (c + 2 * W1 < c_end) issue_w(c + 2 * W1, cc);
+        if (c + 3 * W1 < c_end) issue_w(c + 3 * W1, cd);
+        if (c < c_end) issue_sz(ca);
+        if (c + W1 < c_end) issue_sz(cb);
+        if (c + 2 * W1 < c_end) issue_sz(cc);
+        // step i: compute chunk i, then the group constants of chunk i+3 (its map entries were requested a step ago), then
+        // the words + map entries of chunk i+4 into the set just consumed
         for (; c < c_end; c += 4 * W1) {
-            compute(c, ca);
-            if (c + 4 * W1 < c_end) issue(c + 4 * W1, ca);
-            if (c + W1 < c_end) compute(c + W1, cb);
-            if (c + 5 * W1 < c_end) issue(c + 5 * W1, cb);
-            if (c + 2 * W1 < c_end) compute(c + 2 * W1, cc);
-            if (c + 6 * W1 < c_end) issue(c + 6 * W1, cc);
-            if (c + 3 * W1 < c_end) compute(c + 3 * W1, cd);
-            if (c + 7 * W1 < c_end) issue(c + 7 * W1, cd);
+            compute(0, ca);
+            if (c + 3 * W1 < c_end) issue_sz(cd);
+            if (c + 4 * W1 < c_end) issue_w(c + 4 * W1, ca);
+            if (c + W1 < c_end) compute(1, cb);
+            if (c + 4 * W1 < c_end) issue_sz(ca);
+            if (c + 5 * W1 < c_end) issue_w(c + 5 * W1, cb);
+            if (c + 2 * W1 < c_end) compute(2, cc);
+            if (c + 5 * W1 < c_end) issue_sz(cb);
+            if (c + 6 * W1 < c_end) issue_w(c + 6 * W1, cc);
+            if (c + 3 * W1 < c_end) compute(3, cd);
+            if (c + 6 * W1 < c_end) issue_sz(cc);
+            if (c + 7 * W1 < c_end) issue_w(c + 7 * W1, cd);
         }
     }
     // block reduction over the waves in wave order (deterministic)
@@ -422,10 +448,9 @@ int mbwq_exl2_forward_launch(const void* x, const int32_t* qw, const void* scale
         int S = colblocks >= 160 ? 1 : cdiv(256, colblocks);
         if (S > C / 4) S = C / 4 > 0 ? C / 4 : 1;  // keep a few chunks per slab
         int cps2 = cdiv(C, S);
-        if (cps2 > 512) cps2 = 512;  // x slab in LDS: 2 rows x 512 chunks x 32 x 2 B = 64 KiB
         S = cdiv(C, cps2);
         const int MT = M;
-        size_t lds2 = (size_t)MT * cps2 * 32 * sizeof(uint16_t);
+        size_t lds2 = (size_t)EX2_NW * 4 * MT * 32 * sizeof(uint16_t);  // wave-private x chunk buffers
         const size_t red = (size_t)EX2_NW * MT * 64 * sizeof(float);
         if (lds2 < red) lds2 = red;
         dim3 grid2(colblocks, S);

@@ -1,0 +1,18 @@
+#!/bin/bash
+# PMC passes over an arbitrary python workload: CMD="tools/other_bench_exl2.py" bash tools/gpu_pmc_any.sh ; prints per-kernel averages
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
+R=$PWD; cd /tmp
+pass() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d /tmp/pmcx_$name -o p -- python $R/$CMD > /tmp/pmcx_$name.log 2>&1; f=$(find /tmp/pmcx_$name -name "*counter_collection.csv" | head -1); echo "== $name"; python - "$f" <<'PY'
+import csv, sys, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(sys.argv[1])):
+    k = r.get("Kernel_Name", "")
+    if "bie::" not in k: continue
+    agg[k[:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, d in agg.items():
+    print(k, {c: round(sum(v) / len(v), 1) for c, v in d.items()}, "n=", len(next(iter(d.values()))))
+PY
+}
+pass a SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD
+pass b SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU
+pass c FETCH_SIZE
