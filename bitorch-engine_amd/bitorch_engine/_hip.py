@@ -6,6 +6,7 @@ or a call fails, a RuntimeError carrying bie_last_error() is raised.
 """
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -24,6 +25,9 @@ SIGNATURES = {
     "bie_last_error": (ctypes.c_char_p, []),
     "bie_mpq_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "bie_mpq_forward": (_i, [_vp] * 8 + [_sz] + [_i] * 7 + [_vp]),
+    "bie_workspace_init": (_i, [_vp, _sz, _vp]),
+    "bie_mpq_grouped_workspace_bytes": (_sz, [_i, _vp, _i, _i, _i]),
+    "bie_mpq_forward_grouped": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz] + [_i] * 6 + [_vp]),
     "bie_mpq_dequant": (_i, [_vp] * 5 + [_i] * 6 + [_vp]),
     "bie_mpq_pack": (_i, [_vp] * 5 + [_i] * 6 + [_vp]),
     "bie_mpq_grad_input": (_i, [_vp] * 6 + [_i] * 7 + [_vp]),
@@ -60,12 +64,36 @@ def lib():
                 f"bitorch_engine (MI355X build): {LIB_PATH} not found. Build it with "
                 f"`make -C {os.path.dirname(os.path.dirname(LIB_PATH))}` or `python -c 'import __graft_entry__ as g; g.build()'`.")
         l = ctypes.CDLL(LIB_PATH)
+        ns = _Lib()
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        _lib = l
+            launches = not (name.endswith("_bytes") or name in ("bie_version", "bie_last_error", "bie_mbwq_rows"))
+            setattr(ns, name, _guarded(fn) if launches else fn)
+        _lib = ns
     return _lib
+
+
+class _Lib:
+    """Namespace of the bound entry points (launching ones wrapped in the device guard)."""
+
+
+_tls = threading.local()
+
+
+def _guarded(fn):
+    """Device guard: the C ABI launches on the CURRENT HIP device, the tensors of a call may live on another one
+    (device_map='auto', pipeline-split models).  need_gpu() records the device of the call's tensors; if it is not the
+    current device the call is made under torch.cuda.device(...) -- what the reference's
+    at::cuda::OptionalCUDAGuard(device_of(x)) does (mpq_linear_cuda_kernel.cu:612)."""
+    def call(*args):
+        d = getattr(_tls, "device", None)
+        if d is not None and d.index is not None and d.index != torch.cuda.current_device():
+            with torch.cuda.device(d):
+                return fn(*args)
+        return fn(*args)
+    return call
 
 
 def dt(t: torch.Tensor) -> int:
@@ -80,14 +108,26 @@ def ptr(t):
 
 
 def stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """The current stream of the device the call's tensors live on (see need_gpu)."""
+    return torch.cuda.current_stream(getattr(_tls, "device", None)).cuda_stream
 
 
 def need_gpu(*tensors):
+    """Every entry point calls this first: all tensors on ONE GPU (the reference checks the same,
+    mpq_layer.py:45-48); remembers that device for stream() / workspace() / the device guard."""
+    dev = None
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError("bitorch_engine (MI355X build): tensors must live on the GPU; "
                                "there is no CPU fallback (move the layer with .to('cuda'))")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"bitorch_engine: tensors of one call live on different devices ({dev} and {t.device})")
+    _tls.device = dev
+    return dev
 
 
 def check(rc: int, what: str):
@@ -97,15 +137,27 @@ def check(rc: int, what: str):
 
 
 _WS = {}
+_WS_RETIRED = []  # superseded buffers are kept alive: a captured HIP graph may have their address baked in
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
-    """Per-(device, stream) scratch buffer, grown on demand and reused (stream-ordered reuse is safe)."""
+    """Per-(device, stream) scratch buffer, grown on demand and reused (stream-ordered reuse is safe).
+    A buffer that is outgrown is retired, never freed: graph replays that captured its pointer keep writing their
+    split-K slabs and tickets into memory nobody else owns.  presize_workspace() avoids the regrowth altogether."""
     if nbytes == 0:
         return None
-    key = (device.index if device.index is not None else torch.cuda.current_device(), stream())
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            _WS_RETIRED.append(buf)
         buf = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)  # head = split-K counters, must start at 0
         _WS[key] = buf
     return buf
+
+
+def presize_workspace(nbytes: int, device=None):
+    """Allocate the current stream's scratch buffer up front (e.g. for the largest prefill) so that it never regrows
+    after a decode graph has been captured."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    return workspace(nbytes, device)

@@ -41,6 +41,7 @@ def pack_cols(w: torch.Tensor) -> torch.Tensor:
 
 def xnor_linear(xp: torch.Tensor, wp: torch.Tensor, M: int, N: int, K: int, w_layout: int, scale: float) -> torch.Tensor:
     """y[M, N] fp32 = (K - 2*popc(x ^ w)) * scale from packed operands."""
+    _hip.need_gpu(xp, wp)
     y = torch.empty((M, N), dtype=torch.float32, device=xp.device)
     if M and N:
         rc = _hip.lib().bie_binary_linear_forward(_hip.ptr(xp), _hip.ptr(wp), _hip.ptr(y), M, N, K, w_layout, float(scale), _hip.stream())

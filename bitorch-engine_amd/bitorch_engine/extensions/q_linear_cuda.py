@@ -65,6 +65,34 @@ def mpq_forward_impl(x, qweight, scales, zeros, g_idx, w_bit, asym, group_size, 
     return y
 
 
+def mpq_forward_grouped_impl(x, sets, w_bit, asym, group_size):
+    """Several layers that share x (q/k/v, gate/up) in ONE decode launch (bie_mpq_forward_grouped).
+    sets: list of (qweight, scales, zeros, bias_or_None); returns the list of outputs [M, N_i]."""
+    import ctypes
+    tensors = [t for s in sets for t in s[:3]]
+    _hip.need_gpu(x, *tensors)
+    x = x.contiguous()
+    M, K = x.shape
+    n = len(sets)
+    Ns = [int(s[0].shape[1]) for s in sets]
+    ys = [torch.empty((M, Ni), dtype=x.dtype, device=x.device) for Ni in Ns]
+    if M == 0:
+        return ys
+    L = _hip.lib()
+    keep = [(s[1].contiguous(), s[2].contiguous()) for s in sets]
+    arr = lambda ptrs: (ctypes.c_void_p * n)(*ptrs)
+    Narr = (ctypes.c_int * n)(*Ns)
+    need = L.bie_mpq_grouped_workspace_bytes(n, Narr, M, K, w_bit)
+    ws = _hip.workspace(need, x.device)
+    has_bias = any(s[3] is not None for s in sets)
+    rc = L.bie_mpq_forward_grouped(_hip.ptr(x), n, arr([_hip.ptr(s[0]) for s in sets]), arr([_hip.ptr(k[0]) for k in keep]),
+                                   arr([_hip.ptr(k[1]) for k in keep]), arr([_hip.ptr(s[3]) for s in sets]) if has_bias else None,
+                                   arr([_hip.ptr(y) for y in ys]), Narr, _hip.ptr(ws), 0 if ws is None else ws.numel(),
+                                   M, K, w_bit, group_size, int(bool(asym)), _hip.dt(x), _hip.stream())
+    _hip.check(rc, "bie_mpq_forward_grouped")
+    return ys
+
+
 def mpq_forward(x, qweight, scales, qzeros, g_idx, a_bit, w_bit, asym):
     if a_bit != 16:
         raise RuntimeError(f"a_bit:{a_bit} has not been supported yet!")

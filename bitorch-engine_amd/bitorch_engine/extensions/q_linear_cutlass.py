@@ -21,6 +21,7 @@ def q4_w_pack(weight: torch.Tensor, scale, is_transpose: bool = False) -> torch.
 
 
 def _q4_gemm(pa, pw, M, N, K, sa, sw, dtype, batch=1):
+    _hip.need_gpu(pa, pw)
     y = torch.empty((batch, M, N) if batch > 1 else (M, N), dtype=dtype, device=pa.device)
     rc = _hip.lib().bie_q4_gemm(_hip.ptr(pa), _hip.ptr(pw), _hip.ptr(y), M, N, K, sa, sw, _hip._DT[dtype], batch,
                                 M * (K // 2), N * (K // 2), M * N, _hip.stream())

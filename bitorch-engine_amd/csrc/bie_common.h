@@ -74,6 +74,11 @@ template <> struct dt_traits<BIE_F32> {
     static constexpr int bytes = 4;
 };
 
+// Every workspace starts with a head of split-K arrival counters (one 32-bit ticket per 64-column output tile; zero on first
+// use, returned to zero by the last arriver); every scratch user starts behind it.
+constexpr size_t BIE_WS_HEAD_BYTES = 16384;
+constexpr int BIE_WS_COUNTERS = (int)(BIE_WS_HEAD_BYTES / 4);  // 4096 tiles = 262144 output columns per launch
+
 // shared split-K epilogue (splitk.hip): y[m][n] = dt( sum_s part[s][m][n] ) (+ bias[n])
 int launch_splitk_finalize(const float* part, const void* bias, void* y, int S, int M, int N, int dtype,
                            hipStream_t stream);

@@ -14,6 +14,12 @@ int mpq_gemv_launch(const void* x, const int32_t* qw, const void* scales, const 
 int mpq_gemv_generic_launch(const void* x, const int32_t* qw, const void* scales, const void* zeros, const int32_t* g_idx,
                             const void* bias, void* y, float* part, int M, int K, int N, int w_bit, int group_size,
                             int asym, int dtype, hipStream_t st);
+// mpq_gemv_lut.hip
+bool mpq_gemv_lut_ok(int M, int K, int w_bit, int group_size, int dtype, bool has_gidx);
+size_t mpq_gemv_lut_part_floats(int M, int K, int group_size, int tiles_total);
+int mpq_gemv_lut_launch(int nsets, const int32_t* const* qw, const void* const* scales, const void* const* zeros,
+                        const void* const* bias, void* const* y, const int* N, const void* x, unsigned* counters, float* part,
+                        int M, int K, int group_size, int zm, hipStream_t st);
 // mpq_gemm.hip
 bool mpq_gemm_ok(int M, int K, int N, int w_bit, int group_size, int dtype, bool has_gidx);
 size_t mpq_gemm_workspace_bytes(int M, int K, int N);
@@ -62,9 +68,9 @@ int q4_conv2d_launch(const int8_t* a_packed, const int8_t* w_packed, void* y, vo
 using namespace bie;
 
 static const int GENERIC_M_CHUNK = 32;
-// The first 4 KiB of every workspace hold the GEMV's split-K arrival counters (zero on first use, returned to zero by
+// The first 16 KiB (BIE_WS_HEAD_BYTES) of every workspace hold the GEMV's split-K arrival counters (zero on first use, returned to zero by
 // the kernel); every other scratch user starts behind them.
-static const size_t WS_HEAD = 4096;
+static const size_t WS_HEAD = BIE_WS_HEAD_BYTES;
 
 static int validate_mpq(const char* fn, int K, int N, int w_bit, int group_size, int dtype) {
     BIE_REQUIRE(w_bit == 1 || w_bit == 2 || w_bit == 4 || w_bit == 8, BIE_ERR_UNSUPPORTED,
@@ -121,6 +127,67 @@ int bie_mpq_forward(const void* x, const int32_t* qweight, const void* scales, c
         const int mc = (M - m0) < GENERIC_M_CHUNK ? (M - m0) : GENERIC_M_CHUNK;
         rc = mpq_gemv_generic_launch((const char*)x + (size_t)m0 * K * esz, qweight, scales, zeros, g_idx, bias,
                                      (char*)y + (size_t)m0 * N * esz, part, mc, K, N, w_bit, group_size, asym, dtype, st);
+        if (rc) return rc;
+    }
+    return BIE_OK;
+}
+
+int bie_workspace_init(void* workspace, size_t workspace_bytes, void* stream) {
+    BIE_REQUIRE(workspace && workspace_bytes >= WS_HEAD, BIE_ERR_WORKSPACE, "bie_workspace_init: a workspace holds at least %zu bytes", WS_HEAD);
+    const hipError_t e = hipMemsetAsync(workspace, 0, WS_HEAD, as_stream(stream));
+    BIE_REQUIRE(e == hipSuccess, BIE_ERR_HIP, "bie_workspace_init: hipMemsetAsync: %s", hipGetErrorString(e));
+    return BIE_OK;
+}
+
+static int grouped_tiles(int n_sets, const int* N) {
+    int tiles = 0;
+    for (int i = 0; i < n_sets; i++) tiles += cdiv(N[i], 64);
+    return tiles;
+}
+
+size_t bie_mpq_grouped_workspace_bytes(int n_sets, const int* N, int M, int K, int w_bit) {
+    if (n_sets <= 0 || n_sets > BIE_MAX_GROUPED_SETS || !N || M <= 0 || K <= 0) return 0;
+    size_t need = 0;
+    for (int i = 0; i < n_sets; i++) {
+        const size_t b = bie_mpq_workspace_bytes(M, K, N[i], w_bit);
+        if (b > need) need = b;
+    }
+    if (w_bit == 4 && M <= 2) {
+        const int tiles = grouped_tiles(n_sets, N);
+        for (int gs = 32; gs <= 256; gs *= 2)
+            if (K % gs == 0) {
+                const size_t b = WS_HEAD + mpq_gemv_lut_part_floats(M, K, gs, tiles) * sizeof(float);
+                if (b > need) need = b;
+            }
+    }
+    return need;
+}
+
+int bie_mpq_forward_grouped(const void* x, int n_sets, const int32_t* const* qweight, const void* const* scales,
+                            const void* const* zeros, const void* const* bias, void* const* y, const int* N,
+                            void* workspace, size_t workspace_bytes, int M, int K, int w_bit, int group_size,
+                            int asym, int dtype, void* stream) {
+    BIE_REQUIRE(n_sets > 0 && n_sets <= BIE_MAX_GROUPED_SETS, BIE_ERR_INVALID_ARG, "bie_mpq_forward_grouped: n_sets=%d must be 1..%d", n_sets, BIE_MAX_GROUPED_SETS);
+    BIE_REQUIRE(x && qweight && scales && zeros && y && N, BIE_ERR_INVALID_ARG, "bie_mpq_forward_grouped: NULL argument");
+    for (int i = 0; i < n_sets; i++) {
+        int rc = validate_mpq("bie_mpq_forward_grouped", K, N[i], w_bit, group_size, dtype);
+        if (rc) return rc;
+        BIE_REQUIRE(qweight[i] && scales[i] && zeros[i] && y[i], BIE_ERR_INVALID_ARG, "bie_mpq_forward_grouped: NULL tensor pointer in set %d", i);
+        if (asym) BIE_REQUIRE(N[i] % (32 / w_bit) == 0, BIE_ERR_INVALID_ARG, "bie_mpq_forward_grouped: asym needs N %% %d == 0", 32 / w_bit);
+    }
+    BIE_REQUIRE(M > 0, BIE_ERR_INVALID_ARG, "bie_mpq_forward_grouped: M=%d must be positive", M);
+    const size_t need = bie_mpq_grouped_workspace_bytes(n_sets, N, M, K, w_bit);
+    BIE_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), BIE_ERR_WORKSPACE,
+                "bie_mpq_forward_grouped: workspace of %zu bytes required, got %zu", need, workspace_bytes);
+    const int tiles = grouped_tiles(n_sets, N);
+    if (tiles <= BIE_WS_COUNTERS && mpq_gemv_lut_ok(M, K, w_bit, group_size, dtype, false)) {
+        float* head = reinterpret_cast<float*>(workspace);
+        return mpq_gemv_lut_launch(n_sets, qweight, scales, zeros, bias, y, N, x, reinterpret_cast<unsigned*>(head),
+                                   head + WS_HEAD / sizeof(float), M, K, group_size, asym ? 1 : 0, as_stream(stream));
+    }
+    for (int i = 0; i < n_sets; i++) {  // every other case: one launch per set (same results)
+        int rc = bie_mpq_forward(x, qweight[i], scales[i], zeros[i], nullptr, bias ? bias[i] : nullptr, y[i], workspace,
+                                 workspace_bytes, M, K, N[i], w_bit, group_size, asym, dtype, stream);
         if (rc) return rc;
     }
     return BIE_OK;
@@ -258,7 +325,7 @@ int bie_binary_linear_forward(const uint8_t* xpacked, const uint8_t* wpacked, fl
 
 size_t bie_binary_conv2d_workspace_bytes(int B, int C, int H, int W, int OC, int ksize, int stride, int pad, int dilation) {
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || OC <= 0 || ksize <= 0 || stride <= 0 || dilation <= 0 || pad < 0) return 0;
-    return binary_conv_workspace_bytes(B, C, H, W, OC, ksize, stride, pad, dilation);
+    return WS_HEAD + binary_conv_workspace_bytes(B, C, H, W, OC, ksize, stride, pad, dilation);  // scratch starts behind the counter head
 }
 
 int bie_binary_conv2d_forward(const void* x, const uint8_t* wpacked, float* y, void* workspace, size_t workspace_bytes, int B,
@@ -268,9 +335,10 @@ int bie_binary_conv2d_forward(const void* x, const uint8_t* wpacked, float* y, v
     BIE_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && OC > 0 && ksize > 0 && stride > 0 && dilation > 0 && pad >= 0, BIE_ERR_INVALID_ARG, "bie_binary_conv2d_forward: bad geometry");
     BIE_REQUIRE((C * ksize * ksize) % 8 == 0, BIE_ERR_UNSUPPORTED, "bie_binary_conv2d_forward: C*k*k=%d must be a multiple of 8", C * ksize * ksize);
     BIE_REQUIRE(dtype >= 0 && dtype <= 2, BIE_ERR_UNSUPPORTED, "bie_binary_conv2d_forward: dtype %d", dtype);
-    const size_t need = binary_conv_workspace_bytes(B, C, H, W, OC, ksize, stride, pad, dilation);
+    const size_t need = WS_HEAD + binary_conv_workspace_bytes(B, C, H, W, OC, ksize, stride, pad, dilation);
     BIE_REQUIRE(workspace_bytes >= need, BIE_ERR_WORKSPACE, "bie_binary_conv2d_forward: workspace of %zu bytes required, got %zu", need, workspace_bytes);
-    return binary_conv_launch(x, wpacked, y, workspace, B, C, H, W, OC, ksize, stride, pad, dilation, scale, dtype, as_stream(stream));
+    // a shared per-stream workspace also serves the GEMV kernels: never touch its head of split-K tickets
+    return binary_conv_launch(x, wpacked, y, static_cast<char*>(workspace) + WS_HEAD, B, C, H, W, OC, ksize, stride, pad, dilation, scale, dtype, as_stream(stream));
 }
 
 // ---------------------------------------------------------------------------------------------- functions

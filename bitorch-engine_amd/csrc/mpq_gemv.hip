@@ -21,6 +21,13 @@
 
 namespace bie {
 
+// mpq_gemv_lut.hip
+bool mpq_gemv_lut_ok(int M, int K, int w_bit, int group_size, int dtype, bool has_gidx);
+size_t mpq_gemv_lut_part_floats(int M, int K, int group_size, int tiles_total);
+int mpq_gemv_lut_launch(int nsets, const int32_t* const* qw, const void* const* scales, const void* const* zeros,
+                        const void* const* bias, void* const* y, const int* N, const void* x, unsigned* counters, float* part,
+                        int M, int K, int group_size, int zm, hipStream_t st);
+
 static int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
@@ -28,7 +35,7 @@ static int env_int(const char* name, int dflt) {
 
 constexpr int GEMV_THREADS = 256;
 constexpr int GEMV_COLS = 256;  // columns per block: 64 lanes x 4
-constexpr int GEMV_COUNTER_FLOATS = 1024;  // head of the workspace: one arrival counter per column tile (4 KiB)
+constexpr int GEMV_COUNTER_FLOATS = BIE_WS_COUNTERS;  // head of the workspace: one arrival counter per column tile
 
 template <int DT, int WBIT, int MT, int ZM, int U>
 __global__ __launch_bounds__(GEMV_THREADS) void mpq_gemv_kernel(
@@ -609,17 +616,26 @@ bool mpq_gemv_fast_ok(int M, int K, int N, int w_bit, int group_size, int dtype,
     const int NB = 32 / w_bit;
     const int gs = group_size > K ? K : group_size;
     if (K % NB || gs % NB || (N & 3)) return false;
-    if (cdiv(N, GEMV_COLS) > GEMV_COUNTER_FLOATS) return false;
+    if (cdiv(N, 64) > GEMV_COUNTER_FLOATS) return false;  // one ticket per 64-column tile (v3 / LUT kernels)
     return true;
 }
 
 size_t mpq_gemv_workspace_bytes(int M, int K, int N, int w_bit) {
+    size_t lut = 0;  // the group size is not known here: take the largest slab count any supported group size gives
+    if (w_bit == 4 && M <= 2)
+        for (int gs = 32; gs <= 256; gs *= 2)
+            if (K % gs == 0) {
+                const size_t f = mpq_gemv_lut_part_floats(M, K, gs, cdiv(N, 64));
+                if (f > lut) lut = f;
+            }
+    lut = lut ? lut * sizeof(float) + GEMV_COUNTER_FLOATS * sizeof(float) : 0;
     const int MT = M <= 1 ? 1 : (M <= 2 ? 2 : (M <= 4 ? 4 : 8));
     const GemvPlan pl = plan_gemv(K, N, w_bit, K, MT);
     size_t fast = pl.S > 1 ? (size_t)pl.S * M * N * sizeof(float) + GEMV_COUNTER_FLOATS * sizeof(float) : 0;
     const Gemv3Plan p3 = plan_gemv3(K, N, w_bit);
     const size_t fast3 = p3.S > 1 ? (size_t)p3.S * M * N * sizeof(float) + GEMV_COUNTER_FLOATS * sizeof(float) : 0;
     if (fast3 > fast) fast = fast3;
+    if (lut > fast) fast = lut;
     const size_t generic = (size_t)cdiv(K, 512) * M * N * sizeof(float);
     return fast > generic ? fast : generic;
 }
@@ -627,6 +643,14 @@ size_t mpq_gemv_workspace_bytes(int M, int K, int N, int w_bit) {
 int mpq_gemv_launch(const void* x, const int32_t* qw, const void* scales, const void* zeros, const void* bias, void* y,
                     float* part, int M, int K, int N, int w_bit, int group_size, int zm, int dtype, const uint16_t* perm,
                     hipStream_t st) {
+    if (perm == nullptr && mpq_gemv_lut_ok(M, K, w_bit, group_size, dtype, false)) {  // bf16 W4: table-lookup kernel
+        const void* sc1[1] = {scales};
+        const void* ze1[1] = {zeros};
+        const void* bi1[1] = {bias};
+        void* y1[1] = {y};
+        return mpq_gemv_lut_launch(1, &qw, sc1, ze1, bias ? bi1 : nullptr, y1, &N, x, reinterpret_cast<unsigned*>(part),
+                                   part + GEMV_COUNTER_FLOATS, M, K, group_size, zm, st);
+    }
     const int MT = M <= 1 ? 1 : (M <= 2 ? 2 : (M <= 4 ? 4 : 8));
     static const int use_v3 = env_int("BIE_GEMV_V3", 1);
     const int NBv = 32 / w_bit;

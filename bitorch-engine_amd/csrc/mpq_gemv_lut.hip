@@ -1,0 +1,439 @@
+// W4A16 decode GEMV (M <= 2) by TABLE LOOKUP -- the bandwidth-bound half of bie_mpq_forward for bf16 layers.
+// Replaces quant_mm_kernel[_asym] (reference layers/qlinear/nbit/cuda/mpq_linear_cuda_kernel.cu:67-451).
+//
+// Why a table.  The reference's CPU path rounds every dequantised weight twice to the layer dtype
+// (fl(fl(q*s) - z), layers/qlinear/nbit/cuda/utils.py:36-51); gfx950 has no packed bf16 ALU, so reproducing the two
+// roundings per weight costs ~5 VALU instructions per weight and made the dot2 kernel (mpq_gemv.hip) VALU-issue bound at
+// 0.24 of the HBM roofline.  But inside one (group, column) a 4-bit weight takes only 16 values: a lane (= one output
+// column) computes the 16 doubly-rounded values ONCE per group (128 k), parks them in LDS as fp32 (bf16 << 16), and every
+// weight then costs
+//     1 VALU  v_mov_b32_sdwa   byte_k(w') -> byte 1 of the LDS address register ((wave*16 + q)*256 + lane*4; nothing else
+//                              of the register changes: no shift, no add, no re-initialisation).  w' = the word with the
+//                              other nibble of every byte replaced by the wave index: 3 VALU per word, i.e. per 8 weights
+//     1 LDS   ds_read_b32      tab[wave][q][lane]: bank = lane mod 32 whatever q is -> conflict-free by construction
+//     1 VALU  v_fma_f32        acc += x_k * T[q], x_k wave-uniform (SGPR operand), full-rate fp32 FMA
+// The table holds the exact reference values, so the result is the reference's up to fp32 summation order.
+//
+// Shape of the launch.  A workgroup = NW waves on one 64-column tile; each wave owns a run of whole groups (normally ONE:
+// 16 packed rows, all loaded up front: dword non-temporal loads, a wave-row = 256 contiguous bytes), builds its own 4 KiB
+// table, and the waves are summed through LDS in wave order.  K is additionally split over the grid (slice-major block
+// ids).  Cross-workgroup reduction WITHOUT atomics or drains: slices 0..S-2 publish their column sums as 8-byte
+// {value, tag} granules with one write-through (sc1) store and retire; the workgroup of the LAST slice (highest block
+// ids: dispatched after every publisher, so the wait cannot starve them) polls the granules with bypassing loads until
+// every tag equals this launch's tag, adds them in slice order (deterministic) and writes y.  The tag is the tile's
+// generation word in the workspace head + 1; the reducer advances the generation when it is done, so nothing ever has to
+// be reset and a captured graph replays correctly.  `bie_mpq_forward_grouped` passes several weight sets that share x
+// (q/k/v, gate/up): their column tiles are concatenated into one grid.
+#include "mpq_dequant.cuh"
+#include <stdlib.h>
+
+#pragma clang fp contract(off)
+
+namespace bie {
+
+constexpr int LUT_MAX_SETS = 8;
+
+struct LutSet {
+    const uint32_t* qw;
+    const uint16_t* scales;
+    const void* zeros;
+    const uint16_t* bias;
+    uint16_t* y;
+    int N;
+    int tile_begin;  // first column tile of this set in the concatenated grid
+};
+
+struct LutArgs {
+    LutSet set[LUT_MAX_SETS];
+    const uint16_t* x;
+    unsigned long long* gran;  // [S-1][M][tiles_total * 64] {fp32 partial, tag}
+    unsigned* gen;             // generation word per column tile (workspace head)
+    int nsets, M, K, G, tiles_total, S, groups_per_wave;
+};
+
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+// constant address space: x is never written by this kernel, and uniform loads from it always take the scalar path
+typedef const __attribute__((address_space(4))) uint32_t const_u32;
+
+// byte BYTE of w -> byte 1 of the address register (everything else of `a` is preserved)
+template <int BYTE>
+__device__ __forceinline__ void lut_addr(uint32_t& a, uint32_t w) {
+    if constexpr (BYTE == 0) asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0" : "+v"(a) : "v"(w));
+    else if constexpr (BYTE == 1) asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1" : "+v"(a) : "v"(w));
+    else if constexpr (BYTE == 2) asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2" : "+v"(a) : "v"(w));
+    else asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3" : "+v"(a) : "v"(w));
+}
+
+__device__ __forceinline__ float lds_f32(uint32_t byte_addr) {
+    return __uint_as_float(*reinterpret_cast<const lds_u32*>(byte_addr));
+}
+
+// the 16 values a 4-bit weight of this (group, column) can take, rounded exactly like the reference
+template <int DT, int ZM>
+__device__ __forceinline__ float lut_entry(uint32_t q, float s, float z, int zq1) {
+    if constexpr (ZM == ZM_ASYM) return dequant_scalar_asym<DT>(q, s, zq1);
+    else if constexpr (ZM == ZM_FUSED) return dt_traits<DT>::round(__builtin_fmaf((float)q, s, -z));
+    else return dequant_scalar_sym<DT>(q, s, z);
+}
+
+// MT == M (1 or 2); RPG = packed rows per quantisation group (group_size / 8); NW = waves per workgroup;
+// LAB = 2: stream only (tuning aid)
+template <int DT, int ZM, int MT, int RPG, int NW, int LAB>
+__global__ __launch_bounds__(NW * 64) void mpq_gemv_lut_kernel(const LutArgs a) {
+    constexpr int NB = 8;  // W4: 8 weights per packed word
+    __shared__ __attribute__((aligned(4096))) uint32_t tab[NW * 16 * 64];  // the only LDS object: starts at LDS address 0
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = blockIdx.x % a.tiles_total;
+    const int slice = blockIdx.x / a.tiles_total;
+    int si = 0;
+#pragma unroll
+    for (int i = 1; i < LUT_MAX_SETS; i++)
+        if (i < a.nsets && tile >= a.set[i].tile_begin) si = i;
+    const LutSet& ls = a.set[si];
+    const int N = ls.N;
+    const int n = (tile - ls.tile_begin) * 64 + lane;
+    const int nl = n < N ? n : N - 1;  // clamp: out-of-range lanes load valid memory and are never stored
+    const int g0 = (slice * NW + wave) * a.groups_per_wave;
+    int g1 = g0 + a.groups_per_wave;
+    if (g1 > a.G) g1 = a.G;
+    unsigned tag = 0;
+    if (a.S > 1) tag = a.gen[tile] + 1u;  // uniform; the generation only changes when this launch's reducer is done
+
+    const uint32_t* wcol = ls.qw + nl;
+    auto load_group = [&](uint32_t (&dst)[RPG], int g) {
+#pragma unroll
+        for (int u = 0; u < RPG; u++) dst[u] = __builtin_nontemporal_load(wcol + (long)(g * RPG + u) * N);
+    };
+    const int zero_width = N / NB;
+    auto load_params = [&](int g, uint32_t& sb, uint32_t& zb) {
+        sb = ls.scales[(long)g * N + nl];
+        if constexpr (ZM == ZM_ASYM) {
+            const uint32_t zw = reinterpret_cast<const uint32_t*>(ls.zeros)[(long)g * zero_width + nl / NB];
+            zb = ((zw >> ((nl % NB) * 4)) & 15u) + 1u;
+        } else {
+            zb = reinterpret_cast<const uint16_t*>(ls.zeros)[(long)g * N + nl];
+        }
+    };
+
+    float acc[MT][2];  // even / odd nibbles: two independent FMA chains
+#pragma unroll
+    for (int m = 0; m < MT; m++) acc[m][0] = acc[m][1] = 0.0f;
+
+    // LDS byte address of tab[wave][q][lane] = ((wave * 16 + q) << 8) | (lane << 2): byte 1 carries (wave, q)
+    const uint32_t lane_addr = lane * 4;
+    uint32_t a0 = lane_addr, a1 = lane_addr, a2 = lane_addr, a3 = lane_addr;
+    const uint32_t wavepat = (uint32_t)wave * 0x10101010u;
+    uint32_t* mytab = tab + wave * (16 * 64) + lane;
+    uint32_t m0f;  // VOP3 takes no 32-bit literal: the nibble mask lives in a register
+    asm("v_mov_b32 %0, 0x0f0f0f0f" : "=v"(m0f));
+
+    auto process_group = [&](const uint32_t (&w)[RPG], int g, uint32_t sb, uint32_t zb) {
+        // the activations of the group are wave-uniform: scalar loads, issued before the table is built so that nothing
+        // but LDS traffic is pending in the lookup phase
+        uint32_t xs[MT][RPG * 4];
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            const_u32* xd = (const_u32*)(uintptr_t)(a.x + (long)m * a.K + (long)g * (RPG * NB));
+#pragma unroll
+            for (int i = 0; i < RPG * 4; i++) xs[m][i] = xd[i];
+        }
+        // ---- the 16-entry table of this (group, column)
+        if constexpr (LAB == 0) {
+            if constexpr (DT == BIE_BF16 && ZM == ZM_SYM) {
+                // a_q = fl(q*s): v_mul_f32 (exact) + v_cvt_pk_bf16_f32; T_q = fl(a_q - z): unpack-and-subtract on the dot unit
+                // (bf16_pairs_sub) + v_cvt_pk_bf16_f32; the halves go to the upper 16 bits of the table dwords (the lower
+                // halves were zeroed once), i.e. the entry read back is the fp32 value of the bf16 weight
+                const float s = bf16_bits_to_f32(sb), nz = -bf16_bits_to_f32(zb);
+                const uint32_t sel0 = sel_lo_hi<0>(), sel1 = sel_lo_hi<1>();
+                uint16_t* t16 = reinterpret_cast<uint16_t*>(mytab) + 1;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t A0 = pack_bf16x2((float)(4 * j) * s, (float)(4 * j + 1) * s);
+                    const uint32_t A1 = pack_bf16x2((float)(4 * j + 2) * s, (float)(4 * j + 3) * s);
+                    float d[4];
+                    bf16_pairs_sub(A0, A1, sel0, sel1, nz, d);
+                    const uint32_t T0 = pack_bf16x2(d[0], d[1]), T1 = pack_bf16x2(d[2], d[3]);
+                    t16[(4 * j + 0) * 128] = (uint16_t)(T0 & 0xffffu);
+                    t16[(4 * j + 1) * 128] = (uint16_t)(T0 >> 16);
+                    t16[(4 * j + 2) * 128] = (uint16_t)(T1 & 0xffffu);
+                    t16[(4 * j + 3) * 128] = (uint16_t)(T1 >> 16);
+                }
+            } else {
+                float s, z = 0.0f;
+                int zq1 = 0;
+                if constexpr (DT == BIE_BF16) s = bf16_bits_to_f32(sb); else s = f16_bits_to_f32(sb);
+                if constexpr (ZM == ZM_ASYM) zq1 = (int)zb;
+                else if constexpr (DT == BIE_BF16) z = bf16_bits_to_f32(zb); else z = f16_bits_to_f32(zb);
+#pragma unroll
+                for (int q = 0; q < 16; q++) mytab[q * 64] = __float_as_uint(lut_entry<DT, ZM>((uint32_t)q, s, z, zq1));
+            }
+        }
+        // the activations have landed (in SGPRs) before the first lookup is issued: no scalar load is pending in the lookup
+        // phase, so the LDS reads can be waited for with counted lgkmcnt
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+#pragma unroll
+            for (int i = 0; i < RPG * 4; i += 8)
+                asm volatile("" ::"s"(xs[m][i]), "s"(xs[m][i + 1]), "s"(xs[m][i + 2]), "s"(xs[m][i + 3]), "s"(xs[m][i + 4]), "s"(xs[m][i + 5]),
+                             "s"(xs[m][i + 6]), "s"(xs[m][i + 7]));
+        if constexpr (LAB != 0) {  // tuning aid: stream only
+#pragma unroll
+            for (int u = 0; u < RPG; u++) acc[0][0] += __uint_as_float(w[u] & 0x3f7fffffu) + __uint_as_float(sb << 16) + __uint_as_float(xs[0][u]);
+            return;
+        }
+        // ---- 8 lookups + FMAs per packed word, one row ahead (lgkmcnt is a 4-bit counter: at most 15 LDS reads can be
+        // waited for individually)
+        auto lookup = [&](float (&t)[8], int u) {
+            uint32_t we, wo;  // bytes (wave, q) of the even / odd nibbles: (w & 0x0f0f0f0f) | wavepat in ONE v_and_or_b32
+            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(we) : "v"(w[u]), "v"(m0f), "s"(wavepat));
+            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(wo) : "v"(w[u] >> 4), "v"(m0f), "s"(wavepat));
+            lut_addr<0>(a0, we); t[0] = lds_f32(a0);
+            lut_addr<0>(a1, wo); t[1] = lds_f32(a1);
+            lut_addr<1>(a2, we); t[2] = lds_f32(a2);
+            lut_addr<1>(a3, wo); t[3] = lds_f32(a3);
+            lut_addr<2>(a0, we); t[4] = lds_f32(a0);
+            lut_addr<2>(a1, wo); t[5] = lds_f32(a1);
+            lut_addr<3>(a2, we); t[6] = lds_f32(a2);
+            lut_addr<3>(a3, wo); t[7] = lds_f32(a3);
+        };
+        auto fmas = [&](const float (&t)[8], int u) {
+#pragma unroll
+            for (int m = 0; m < MT; m++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t p = xs[m][u * 4 + i];
+                    float xlo, xhi;
+                    if constexpr (DT == BIE_BF16) { xlo = __uint_as_float(p << 16); xhi = __uint_as_float(p & 0xffff0000u); }
+                    else { xlo = f16_bits_to_f32(p & 0xffffu); xhi = f16_bits_to_f32(p >> 16); }
+                    acc[m][0] = __builtin_fmaf(xlo, t[2 * i], acc[m][0]);
+                    acc[m][1] = __builtin_fmaf(xhi, t[2 * i + 1], acc[m][1]);
+                }
+        };
+        // pin(): the DAG linearisation is free to sink the (unchained) FMAs below every later LDS read; a volatile asm that
+        // consumes the accumulators keeps row u's FMAs between the reads of row u+1 and those of row u+2
+        auto pin = [&]() {
+#pragma unroll
+            for (int m = 0; m < MT; m++) asm volatile("" : "+v"(acc[m][0]), "+v"(acc[m][1]));
+        };
+        float ta[8], tb[8];
+        lookup(ta, 0);
+#pragma unroll
+        for (int u = 0; u < RPG; u += 2) {
+            if (u + 1 < RPG) lookup(tb, u + 1);
+            fmas(ta, u);
+            pin();
+            if (u + 1 < RPG) {
+                if (u + 2 < RPG) lookup(ta, u + 2);
+                fmas(tb, u + 1);
+                pin();
+            }
+        }
+    };
+
+    uint32_t wa[RPG], wb[RPG];
+    uint32_t sa = 0, za = 0, sb2 = 0, zb2 = 0;
+    if (g0 < g1) {
+        load_group(wa, g0);
+        load_params(g0, sa, za);
+        if (g0 + 1 < g1) { load_group(wb, g0 + 1); load_params(g0 + 1, sb2, zb2); }
+    }
+    if constexpr (LAB == 0 && DT == BIE_BF16 && ZM == ZM_SYM) {  // lower halves of the table dwords: zero, once
+#pragma unroll
+        for (int q = 0; q < 16; q++) mytab[q * 64] = 0u;
+    }
+    for (int g = g0; g < g1; g += 2) {
+        process_group(wa, g, sa, za);
+        if (g + 2 < g1) { load_group(wa, g + 2); load_params(g + 2, sa, za); }
+        if (g + 1 < g1) {
+            process_group(wb, g + 1, sb2, zb2);
+            if (g + 3 < g1) { load_group(wb, g + 3); load_params(g + 3, sb2, zb2); }
+        }
+    }
+
+    // ---- workgroup reduction through LDS (the tables are dead), wave order --------------------------------------
+    float tot[MT];
+    if constexpr (NW > 1) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(tab);
+#pragma unroll
+        for (int m = 0; m < MT; m++) red[(wave * MT + m) * 64 + lane] = acc[m][0] + acc[m][1];
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            float v = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; w++) v += red[(w * MT + m) * 64 + lane];
+            tot[m] = v;
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < MT; m++) tot[m] = acc[m][0] + acc[m][1];
+    }
+
+    // ---- cross-workgroup reduction (wave 0 only) -----------------------------------------------------------------
+    const bool owner = n < N;
+    const long ncat = (long)a.tiles_total * 64;
+    const long col = (long)tile * 64 + lane;
+    if (a.S > 1 && LAB == 0) {
+        if (slice != a.S - 1) {  // publisher: one 8-byte write-through store per column, no drain, no atomic
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                const unsigned long long gval = ((unsigned long long)tag << 32) | __float_as_uint(tot[m]);
+                __hip_atomic_store(a.gran + ((long)slice * MT + m) * ncat + col, gval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+        // reducer: poll until every granule of this column carries this launch's tag, then add in slice order
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            float v = 0.0f;
+            for (int s0 = 0; s0 < a.S - 1; s0 += 8) {
+                unsigned long long gv[8];
+                bool ready;
+                int spins = 0;
+                do {
+#pragma unroll
+                    for (int jj = 0; jj < 8; jj++) {
+                        const int sidx = (s0 + jj < a.S - 1) ? s0 + jj : a.S - 2;
+                        gv[jj] = __hip_atomic_load(a.gran + ((long)sidx * MT + m) * ncat + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    ready = true;
+#pragma unroll
+                    for (int jj = 0; jj < 8; jj++) ready = ready && ((unsigned)(gv[jj] >> 32) == tag);
+                    ready = __builtin_amdgcn_ballot_w64(!ready) == 0;  // wave-uniform: every lane's granules are in
+                    if (!ready) __builtin_amdgcn_s_sleep(2);
+                } while (!ready && ++spins < (1 << 24));  // bounded: publishers have lower block ids and never wait
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++)
+                    if (s0 + jj < a.S - 1) v += __uint_as_float((unsigned)gv[jj]);
+            }
+            tot[m] = v + tot[m];
+        }
+        if (lane == 0) a.gen[tile] = tag;  // next launch's tag differs; visible at the kernel boundary
+    }
+    if (owner) {
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            float o = dt_traits<DT>::round(tot[m]);
+            if (ls.bias) o = o + dt_traits<DT>::load(ls.bias, n);
+            dt_traits<DT>::store(ls.y, (long)m * N + n, o);
+        }
+    }
+}
+
+// ---- host side --------------------------------------------------------------------------------------------
+static int lut_env(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+// bf16, W4, implicit groups of 32 / 64 / 128 / 256 that tile K exactly, M <= 2
+bool mpq_gemv_lut_ok(int M, int K, int w_bit, int group_size, int dtype, bool has_gidx) {
+    static const int enabled = lut_env("BIE_GEMV_LUT", 1);
+    if (!enabled || has_gidx || dtype != BIE_BF16 || w_bit != 4 || M < 1 || M > 2) return false;
+    const int gs = group_size > K ? K : group_size;
+    if (gs != 32 && gs != 64 && gs != 128 && gs != 256) return false;
+    return K % gs == 0;
+}
+
+struct LutPlan {
+    int rpg, G, gpw, nw, S;
+};
+
+// A wave takes at least BIE_LUT_ROWS (16) packed rows, i.e. one group of 128; NW (8) waves per workgroup; the grid is
+// bounded to ~BIE_LUT_MAX_WG workgroups by giving a wave more groups (bounds the granule traffic of big layers).
+static LutPlan lut_plan(int K, int group_size, int tiles_total) {
+    static const int min_rows = lut_env("BIE_LUT_ROWS", 16);
+    static const int nw_env = lut_env("BIE_LUT_NW", 8);
+    static const int max_wg = lut_env("BIE_LUT_MAX_WG", 2048);
+    LutPlan p;
+    const int gs = group_size > K ? K : group_size;
+    p.rpg = gs / 8;
+    p.G = K / gs;
+    p.nw = nw_env == 4 ? 4 : (nw_env == 16 ? 16 : 8);
+    int gpw = cdiv(min_rows, p.rpg);
+    const int by_grid = (int)cdivl((long)tiles_total * p.G, (long)max_wg * p.nw);
+    if (by_grid > gpw) gpw = by_grid;
+    if (gpw > p.G) gpw = p.G;
+    p.gpw = gpw;
+    p.S = cdiv(p.G, gpw * p.nw);
+    return p;
+}
+
+// granule area behind the workspace head, counted in floats (a granule = 8 bytes)
+size_t mpq_gemv_lut_part_floats(int M, int K, int group_size, int tiles_total) {
+    const LutPlan p = lut_plan(K, group_size, tiles_total);
+    return p.S > 1 ? (size_t)(p.S - 1) * M * tiles_total * 64 * 2 : 0;
+}
+
+template <int DT, int ZM, int MT, int NW>
+static void lut_launch_rpg(const LutArgs& a, int rpg, int grid, hipStream_t st) {
+    static const int lab = lut_env("BIE_GEMV_LAB", 0);
+#define BIE_LUT(RPGV)                                                                                                       \
+    do {                                                                                                                    \
+        if (lab == 0 || RPGV != 16 || MT != 1 || ZM != ZM_SYM)                                                              \
+            hipLaunchKernelGGL((mpq_gemv_lut_kernel<DT, ZM, MT, RPGV, NW, 0>), dim3(grid), dim3(NW * 64), 0, st, a);        \
+        else                                                                                                                \
+            hipLaunchKernelGGL((mpq_gemv_lut_kernel<DT, ZM_SYM, 1, 16, NW, 2>), dim3(grid), dim3(NW * 64), 0, st, a);       \
+    } while (0)
+    switch (rpg) {
+        case 4: BIE_LUT(4); break;
+        case 8: BIE_LUT(8); break;
+        case 16: BIE_LUT(16); break;
+        default: BIE_LUT(32); break;
+    }
+#undef BIE_LUT
+}
+
+template <int NW>
+static void lut_launch_nw(const LutArgs& a, int rpg, int grid, int M, int zm, hipStream_t st) {
+    if (M == 1) {
+        if (zm == ZM_ASYM) lut_launch_rpg<BIE_BF16, ZM_ASYM, 1, NW>(a, rpg, grid, st);
+        else if (zm == ZM_FUSED) lut_launch_rpg<BIE_BF16, ZM_FUSED, 1, NW>(a, rpg, grid, st);
+        else lut_launch_rpg<BIE_BF16, ZM_SYM, 1, NW>(a, rpg, grid, st);
+    } else {
+        if (zm == ZM_ASYM) lut_launch_rpg<BIE_BF16, ZM_ASYM, 2, NW>(a, rpg, grid, st);
+        else if (zm == ZM_FUSED) lut_launch_rpg<BIE_BF16, ZM_FUSED, 2, NW>(a, rpg, grid, st);
+        else lut_launch_rpg<BIE_BF16, ZM_SYM, 2, NW>(a, rpg, grid, st);
+    }
+}
+
+// sets: n weight sets sharing x (one for a plain forward).  `gen` = the workspace's head, `gran` = granule area.
+int mpq_gemv_lut_launch(int nsets, const int32_t* const* qw, const void* const* scales, const void* const* zeros,
+                        const void* const* bias, void* const* y, const int* N, const void* x, unsigned* gen, float* gran,
+                        int M, int K, int group_size, int zm, hipStream_t st) {
+    LutArgs a;
+    int tiles = 0;
+    for (int i = 0; i < LUT_MAX_SETS; i++) {
+        const int j = i < nsets ? i : nsets - 1;
+        a.set[i].qw = reinterpret_cast<const uint32_t*>(qw[j]);
+        a.set[i].scales = reinterpret_cast<const uint16_t*>(scales[j]);
+        a.set[i].zeros = zeros[j];
+        a.set[i].bias = bias ? reinterpret_cast<const uint16_t*>(bias[j]) : nullptr;  // entries may be NULL too
+        a.set[i].y = reinterpret_cast<uint16_t*>(y[j]);
+        a.set[i].N = N[j];
+        a.set[i].tile_begin = tiles;
+        if (i < nsets) tiles += cdiv(N[j], 64);
+    }
+    const LutPlan p = lut_plan(K, group_size, tiles);
+    a.x = reinterpret_cast<const uint16_t*>(x);
+    a.gran = reinterpret_cast<unsigned long long*>(gran);
+    a.gen = gen;
+    a.nsets = nsets;
+    a.M = M;
+    a.K = K;
+    a.G = p.G;
+    a.tiles_total = tiles;
+    a.S = p.S;
+    a.groups_per_wave = p.gpw;
+    const int grid = tiles * p.S;
+    if (p.nw == 4) lut_launch_nw<4>(a, p.rpg, grid, M, zm, st);
+    else if (p.nw == 16) lut_launch_nw<16>(a, p.rpg, grid, M, zm, st);
+    else lut_launch_nw<8>(a, p.rpg, grid, M, zm, st);
+    return check_launch("mpq_gemv_lut_kernel");
+}
+
+}  // namespace bie

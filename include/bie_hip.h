@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BIE_VERSION 100 /* 0.1.0 */
+#define BIE_VERSION 200 /* 0.2.0 */
 
 typedef enum { BIE_F16 = 0, BIE_BF16 = 1, BIE_F32 = 2 } bie_dtype;
 
@@ -52,9 +52,14 @@ const char* bie_last_error(void);
 /* MPQ (GPTQ-style) W{1,2,4,8}A16 linear                                                       */
 /* ------------------------------------------------------------------------------------------ */
 
-/* Scratch needed by bie_mpq_forward (split-K partial sums behind a 4 KiB head of arrival counters).
- * CONTRACT: the first 4096 bytes of a workspace must be ZERO the first time it is used; the kernels
- * return them to zero, so one memset at allocation time is enough.  One workspace per stream. */
+/* Scratch needed by bie_mpq_forward (split-K partial sums behind a 16 KiB head of arrival counters).
+ * CONTRACT: the first BIE_WORKSPACE_HEAD_BYTES of a workspace must be ZERO the first time it is used;
+ * the kernels return them to zero, so one memset at allocation time (or bie_workspace_init) is enough.
+ * One workspace per stream (two launches that may run concurrently must not share one). */
+#define BIE_WORKSPACE_HEAD_BYTES 16384
+/* Stream-ordered memset of the counter head: call once after allocating a workspace that is not already
+ * zero-filled, or to recover a workspace after a launch that did not complete (device reset, aborted graph). */
+int bie_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
 size_t bie_mpq_workspace_bytes(int M, int K, int N, int w_bit);
 
 /* y = x . dequant(qweight) (+ bias).
@@ -70,6 +75,20 @@ int bie_mpq_forward(const void* x, const int32_t* qweight, const void* scales, c
                     const int32_t* g_idx, const void* bias, void* y, void* workspace,
                     size_t workspace_bytes, int M, int K, int N, int w_bit, int group_size, int asym,
                     int dtype, void* stream);
+
+/* Several weight sets that share ONE activation x[M, K] (q/k/v projections, gate/up of an MLP): set i has
+ * qweight[i] [K*w/32, N[i]], scales[i] / zeros[i] [G, N[i]], bias[i] (array or entry may be NULL), y[i] [M, N[i]].
+ * Semantically n_sets calls of bie_mpq_forward with g_idx = NULL; for decode (M <= 2, bf16, W4) the column tiles of
+ * all sets are concatenated into ONE launch, which amortises the fixed per-launch cost of a memory-bound kernel that
+ * only lasts a few microseconds.  The pointer arrays live in HOST memory and are consumed during the call.
+ * No reference counterpart: the reference launches one quant_mm_kernel per layer
+ * (layers/qlinear/nbit/cuda/mpq_layer.py:65); this is the MI355X-side answer to its per-launch overhead. */
+#define BIE_MAX_GROUPED_SETS 8
+size_t bie_mpq_grouped_workspace_bytes(int n_sets, const int* N, int M, int K, int w_bit);
+int bie_mpq_forward_grouped(const void* x, int n_sets, const int32_t* const* qweight, const void* const* scales,
+                            const void* const* zeros, const void* const* bias, void* const* y, const int* N,
+                            void* workspace, size_t workspace_bytes, int M, int K, int w_bit, int group_size,
+                            int asym, int dtype, void* stream);
 
 /* out[K, N] (dtype) = dequantised weight.  Bit-exact twin of unpack_qweight layer_type 1
  * (layers/qlinear/nbit/cuda/utils.py:30-51). */

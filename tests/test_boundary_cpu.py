@@ -27,7 +27,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"libbie_hip.so does not export {s}"
     assert sorted(_hip.SIGNATURES) == syms, "ctypes signature table out of sync with include/bie_hip.h"
-    assert lib.bie_version() == 100
+    assert lib.bie_version() == 200
 
 
 def test_argument_validation_happens_before_any_device_work():
@@ -42,7 +42,12 @@ def test_argument_validation_happens_before_any_device_work():
     assert L.bie_mpq_workspace_bytes(1, 4096, 11008, 4) > 0
     assert L.bie_mpq_workspace_bytes(4096, 4096, 11008, 4) >= 0
     assert L.bie_mpq_workspace_bytes(0, 4096, 11008, 4) == 0
-    assert L.bie_binary_conv2d_workspace_bytes(32, 512, 7, 7, 512, 3, 1, 1, 1) == (32 * 49 * 144 + 512 * 144) * 4
+    assert L.bie_mpq_forward_grouped(None, 9, None, None, None, None, None, None, None, 0, 1, 64, 4, 32, 0, 1, None) == -1
+    assert L.bie_mpq_forward_grouped(None, 2, None, None, None, None, None, None, None, 0, 1, 64, 4, 32, 0, 1, None) == -1
+    assert L.bie_workspace_init(None, 0, None) == -3
+    n2 = (ctypes.c_int * 2)(4096, 11008)
+    assert L.bie_mpq_grouped_workspace_bytes(2, n2, 1, 4096, 4) >= L.bie_mpq_workspace_bytes(1, 4096, 11008, 4)
+    assert L.bie_binary_conv2d_workspace_bytes(32, 512, 7, 7, 512, 3, 1, 1, 1) == 16384 + (32 * 49 * 144 + 512 * 144) * 4  # behind the counter head
 
 
 def test_mbwq_rows_host_function_matches_oracle_and_reference_tables(golden_dir):

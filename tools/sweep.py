@@ -55,7 +55,7 @@ def time_case(M, K, N, dt, layers=32, reps=20, w_bit=4, gs=128, graph=True):
             "TFLOP/s": round(2.0 * M * K * N / us / 1e6, 1), "layers": nl}
 
 
-if __name__ == "__main__":
+if __name__ == "__main__":  # noqa
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     out = []
     if which in ("all", "gemv"):
