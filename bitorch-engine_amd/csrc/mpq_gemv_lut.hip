@@ -7,9 +7,9 @@
 // 0.24 of the HBM roofline.  But inside one (group, column) a 4-bit weight takes only 16 values: a lane (= one output
 // column) computes the 16 doubly-rounded values ONCE per group (128 k), parks them in LDS as fp32 (bf16 << 16), and every
 // weight then costs
-//     1 VALU  v_mov_b32_sdwa   byte_k(w') -> byte 1 of the LDS address register ((wave*16 + q)*256 + lane*4; nothing else
-//                              of the register changes: no shift, no add, no re-initialisation).  w' = the word with the
-//                              other nibble of every byte replaced by the wave index: 3 VALU per word, i.e. per 8 weights
+//     1 VALU  v_perm_b32       {lane*4, byte_k(w'), 0, 0} = the LDS address (wave*16 + q)*256 + lane*4: no shift, no add.
+//                              w' = the word with the other nibble of every byte replaced by the wave index: 3 VALU per
+//                              word, i.e. per 8 weights
 //     1 LDS   ds_read_b32      tab[wave][q][lane]: bank = lane mod 32 whatever q is -> conflict-free by construction
 //     1 VALU  v_fma_f32        acc += x_k * T[q], x_k wave-uniform (SGPR operand), full-rate fp32 FMA
 // The table holds the exact reference values, so the result is the reference's up to fp32 summation order.
@@ -51,17 +51,18 @@ struct LutArgs {
     int nsets, M, K, G, tiles_total, S, groups_per_wave;
 };
 
+// tuning aid (BIE_GEMV_LAB=5): per-wave timestamps {start, weights landed, compute done, end, xcc/cu id} of the last launch
+__device__ unsigned long long g_lut_stamps[65536 * 5];
+
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 // constant address space: x is never written by this kernel, and uniform loads from it always take the scalar path
 typedef const __attribute__((address_space(4))) uint32_t const_u32;
 
-// byte BYTE of w -> byte 1 of the address register (everything else of `a` is preserved)
+// LDS byte address {byte 0 = lane * 4, byte 1 = byte BYTE of w (= wave * 16 + q), bytes 2-3 = 0} in ONE v_perm_b32
+// (selector 0x0c = the constant 0x00; the SDWA form with dst_unused:UNUSED_PRESERVE measured ~3x slower on gfx950)
 template <int BYTE>
-__device__ __forceinline__ void lut_addr(uint32_t& a, uint32_t w) {
-    if constexpr (BYTE == 0) asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0" : "+v"(a) : "v"(w));
-    else if constexpr (BYTE == 1) asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1" : "+v"(a) : "v"(w));
-    else if constexpr (BYTE == 2) asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2" : "+v"(a) : "v"(w));
-    else asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3" : "+v"(a) : "v"(w));
+__device__ __forceinline__ uint32_t lut_addr(uint32_t lane_addr, uint32_t w) {
+    return __builtin_amdgcn_perm(w, lane_addr, 0x0c0c0400u + ((uint32_t)BYTE << 8));
 }
 
 __device__ __forceinline__ float lds_f32(uint32_t byte_addr) {
@@ -77,8 +78,11 @@ __device__ __forceinline__ float lut_entry(uint32_t q, float s, float z, int zq1
 }
 
 // MT == M (1 or 2); RPG = packed rows per quantisation group (group_size / 8); NW = waves per workgroup;
-// LAB = 2: stream only (tuning aid)
-template <int DT, int ZM, int MT, int RPG, int NW, int LAB>
+// LAB (tuning aids): 2 = stream only, 3 = no cross-workgroup reduction, 4 = stream + reduction (no tables / lookups)
+// RD = rows of every group dequantised directly on the VALU (mpq_dequant.cuh) instead of through the table: the table path is
+// LDS-throughput bound (one ds_read_b32 per weight, 32 lookups per clock per CU), the direct path VALU bound; splitting the
+// rows between them balances the two pipes
+template <int DT, int ZM, int MT, int RPG, int NW, int LAB, int RD = 0>
 __global__ __launch_bounds__(NW * 64) void mpq_gemv_lut_kernel(const LutArgs a) {
     constexpr int NB = 8;  // W4: 8 weights per packed word
     __shared__ __attribute__((aligned(4096))) uint32_t tab[NW * 16 * 64];  // the only LDS object: starts at LDS address 0
@@ -123,7 +127,6 @@ __global__ __launch_bounds__(NW * 64) void mpq_gemv_lut_kernel(const LutArgs a) 
 
     // LDS byte address of tab[wave][q][lane] = ((wave * 16 + q) << 8) | (lane << 2): byte 1 carries (wave, q)
     const uint32_t lane_addr = lane * 4;
-    uint32_t a0 = lane_addr, a1 = lane_addr, a2 = lane_addr, a3 = lane_addr;
     const uint32_t wavepat = (uint32_t)wave * 0x10101010u;
     uint32_t* mytab = tab + wave * (16 * 64) + lane;
     uint32_t m0f;  // VOP3 takes no 32-bit literal: the nibble mask lives in a register
@@ -140,14 +143,12 @@ __global__ __launch_bounds__(NW * 64) void mpq_gemv_lut_kernel(const LutArgs a) 
             for (int i = 0; i < RPG * 4; i++) xs[m][i] = xd[i];
         }
         // ---- the 16-entry table of this (group, column)
-        if constexpr (LAB == 0) {
+        if constexpr (LAB == 0 || LAB == 3 || LAB == 5) {
             if constexpr (DT == BIE_BF16 && ZM == ZM_SYM) {
                 // a_q = fl(q*s): v_mul_f32 (exact) + v_cvt_pk_bf16_f32; T_q = fl(a_q - z): unpack-and-subtract on the dot unit
-                // (bf16_pairs_sub) + v_cvt_pk_bf16_f32; the halves go to the upper 16 bits of the table dwords (the lower
-                // halves were zeroed once), i.e. the entry read back is the fp32 value of the bf16 weight
+                // (bf16_pairs_sub) + v_cvt_pk_bf16_f32; the entry is the fp32 value of the bf16 weight (bf16 << 16)
                 const float s = bf16_bits_to_f32(sb), nz = -bf16_bits_to_f32(zb);
                 const uint32_t sel0 = sel_lo_hi<0>(), sel1 = sel_lo_hi<1>();
-                uint16_t* t16 = reinterpret_cast<uint16_t*>(mytab) + 1;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const uint32_t A0 = pack_bf16x2((float)(4 * j) * s, (float)(4 * j + 1) * s);
@@ -155,10 +156,11 @@ __global__ __launch_bounds__(NW * 64) void mpq_gemv_lut_kernel(const LutArgs a) 
                     float d[4];
                     bf16_pairs_sub(A0, A1, sel0, sel1, nz, d);
                     const uint32_t T0 = pack_bf16x2(d[0], d[1]), T1 = pack_bf16x2(d[2], d[3]);
-                    t16[(4 * j + 0) * 128] = (uint16_t)(T0 & 0xffffu);
-                    t16[(4 * j + 1) * 128] = (uint16_t)(T0 >> 16);
-                    t16[(4 * j + 2) * 128] = (uint16_t)(T1 & 0xffffu);
-                    t16[(4 * j + 3) * 128] = (uint16_t)(T1 >> 16);
+                    // two entries per LDS instruction (ds_write2st64_b32: the rows of the table are 64 dwords apart)
+                    mytab[(4 * j + 0) * 64] = T0 << 16;
+                    mytab[(4 * j + 1) * 64] = T0 & 0xffff0000u;
+                    mytab[(4 * j + 2) * 64] = T1 << 16;
+                    mytab[(4 * j + 3) * 64] = T1 & 0xffff0000u;
                 }
             } else {
                 float s, z = 0.0f;
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(NW * 64) void mpq_gemv_lut_kernel(const LutArgs a) 
             for (int i = 0; i < RPG * 4; i += 8)
                 asm volatile("" ::"s"(xs[m][i]), "s"(xs[m][i + 1]), "s"(xs[m][i + 2]), "s"(xs[m][i + 3]), "s"(xs[m][i + 4]), "s"(xs[m][i + 5]),
                              "s"(xs[m][i + 6]), "s"(xs[m][i + 7]));
-        if constexpr (LAB != 0) {  // tuning aid: stream only
+        if constexpr (LAB == 2 || LAB == 4) {  // tuning aid: stream only
 #pragma unroll
             for (int u = 0; u < RPG; u++) acc[0][0] += __uint_as_float(w[u] & 0x3f7fffffu) + __uint_as_float(sb << 16) + __uint_as_float(xs[0][u]);
             return;
@@ -189,14 +191,14 @@ __global__ __launch_bounds__(NW * 64) void mpq_gemv_lut_kernel(const LutArgs a) 
             uint32_t we, wo;  // bytes (wave, q) of the even / odd nibbles: (w & 0x0f0f0f0f) | wavepat in ONE v_and_or_b32
             asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(we) : "v"(w[u]), "v"(m0f), "s"(wavepat));
             asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(wo) : "v"(w[u] >> 4), "v"(m0f), "s"(wavepat));
-            lut_addr<0>(a0, we); t[0] = lds_f32(a0);
-            lut_addr<0>(a1, wo); t[1] = lds_f32(a1);
-            lut_addr<1>(a2, we); t[2] = lds_f32(a2);
-            lut_addr<1>(a3, wo); t[3] = lds_f32(a3);
-            lut_addr<2>(a0, we); t[4] = lds_f32(a0);
-            lut_addr<2>(a1, wo); t[5] = lds_f32(a1);
-            lut_addr<3>(a2, we); t[6] = lds_f32(a2);
-            lut_addr<3>(a3, wo); t[7] = lds_f32(a3);
+            t[0] = lds_f32(lut_addr<0>(lane_addr, we));
+            t[1] = lds_f32(lut_addr<0>(lane_addr, wo));
+            t[2] = lds_f32(lut_addr<1>(lane_addr, we));
+            t[3] = lds_f32(lut_addr<1>(lane_addr, wo));
+            t[4] = lds_f32(lut_addr<2>(lane_addr, we));
+            t[5] = lds_f32(lut_addr<2>(lane_addr, wo));
+            t[6] = lds_f32(lut_addr<3>(lane_addr, we));
+            t[7] = lds_f32(lut_addr<3>(lane_addr, wo));
         };
         auto fmas = [&](const float (&t)[8], int u) {
 #pragma unroll
@@ -217,21 +219,51 @@ __global__ __launch_bounds__(NW * 64) void mpq_gemv_lut_kernel(const LutArgs a) 
 #pragma unroll
             for (int m = 0; m < MT; m++) asm volatile("" : "+v"(acc[m][0]), "+v"(acc[m][1]));
         };
-        float ta[8], tb[8];
-        lookup(ta, 0);
+        // direct rows: dequantise the word in registers (both reference roundings, mpq_dequant.cuh) and feed v_dot2
+        ColParams<DT, ZM> cp;
+        if constexpr (RD > 0) cp = make_col_params<DT, 4, ZM>(sb, zb);
+        auto direct = [&](int u) {
+            uint32_t wp[4];
+            dequant_word<DT, 4, ZM>(w[u], cp, wp);
 #pragma unroll
-        for (int u = 0; u < RPG; u += 2) {
-            if (u + 1 < RPG) lookup(tb, u + 1);
+            for (int m = 0; m < MT; m++) {
+                uint32_t xp[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {  // pair order of dequant_word: slot p holds k = pair_src_k(p)
+                    const int ka = pair_src_k<DT, 4>(2 * i), kb = pair_src_k<DT, 4>(2 * i + 1);
+                    const uint32_t da = xs[m][u * 4 + (ka >> 1)], db = xs[m][u * 4 + (kb >> 1)];
+                    const uint32_t lo = (ka & 1) ? (da >> 16) : (da & 0xffffu);
+                    const uint32_t hi = (kb & 1) ? (db & 0xffff0000u) : (db << 16);
+                    xp[i] = lo | hi;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc[m][i & 1] = dot2_acc<DT>(wp[i], xp[i], acc[m][i & 1]);
+            }
+        };
+        // table rows 0 .. RL-1, direct rows RL .. RPG-1; a direct row is issued behind the LDS reads of a table row, so its
+        // VALU work covers their latency
+        constexpr int RL = RPG - RD;
+        float ta[8], tb[8];
+        if constexpr (RL > 0) lookup(ta, 0);
+#pragma unroll
+        for (int u = 0; u < RL; u += 2) {
+            if (u + 1 < RL) lookup(tb, u + 1);
+            if (RL + u < RPG) direct(RL + u);
             fmas(ta, u);
             pin();
-            if (u + 1 < RPG) {
-                if (u + 2 < RPG) lookup(ta, u + 2);
+            if (u + 1 < RL) {
+                if (u + 2 < RL) lookup(ta, u + 2);
+                if (RL + u + 1 < RPG) direct(RL + u + 1);
                 fmas(tb, u + 1);
                 pin();
             }
         }
+#pragma unroll
+        for (int u = 2 * RL; u < RPG; u++) direct(u);  // more direct rows than table rows
     };
 
+    unsigned long long st0 = 0, st1 = 0, st2 = 0;
+    if constexpr (LAB == 5) st0 = wall_clock64();
     uint32_t wa[RPG], wb[RPG];
     uint32_t sa = 0, za = 0, sb2 = 0, zb2 = 0;
     if (g0 < g1) {
@@ -239,9 +271,9 @@ __global__ __launch_bounds__(NW * 64) void mpq_gemv_lut_kernel(const LutArgs a) 
         load_params(g0, sa, za);
         if (g0 + 1 < g1) { load_group(wb, g0 + 1); load_params(g0 + 1, sb2, zb2); }
     }
-    if constexpr (LAB == 0 && DT == BIE_BF16 && ZM == ZM_SYM) {  // lower halves of the table dwords: zero, once
-#pragma unroll
-        for (int q = 0; q < 16; q++) mytab[q * 64] = 0u;
+    if constexpr (LAB == 5) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st1 = wall_clock64();
     }
     for (int g = g0; g < g1; g += 2) {
         process_group(wa, g, sa, za);
@@ -252,6 +284,20 @@ __global__ __launch_bounds__(NW * 64) void mpq_gemv_lut_kernel(const LutArgs a) 
         }
     }
 
+    if constexpr (LAB == 5) {
+        asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]));
+        st2 = wall_clock64();
+        const long wid = (long)blockIdx.x * NW + wave;
+        if (lane == 0 && wid < 65536) {
+            g_lut_stamps[wid * 5 + 0] = st0;
+            g_lut_stamps[wid * 5 + 1] = st1;
+            g_lut_stamps[wid * 5 + 2] = st2;
+            unsigned xcc, hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            g_lut_stamps[wid * 5 + 4] = ((unsigned long long)xcc << 32) | hwid;
+        }
+    }
     // ---- workgroup reduction through LDS (the tables are dead), wave order --------------------------------------
     float tot[MT];
     if constexpr (NW > 1) {
@@ -277,7 +323,7 @@ __global__ __launch_bounds__(NW * 64) void mpq_gemv_lut_kernel(const LutArgs a) 
     const bool owner = n < N;
     const long ncat = (long)a.tiles_total * 64;
     const long col = (long)tile * 64 + lane;
-    if (a.S > 1 && LAB == 0) {
+    if (a.S > 1 && (LAB == 0 || LAB == 4 || LAB == 5)) {
         if (slice != a.S - 1) {  // publisher: one 8-byte write-through store per column, no drain, no atomic
 #pragma unroll
             for (int m = 0; m < MT; m++) {
@@ -322,6 +368,15 @@ __global__ __launch_bounds__(NW * 64) void mpq_gemv_lut_kernel(const LutArgs a) 
             dt_traits<DT>::store(ls.y, (long)m * N + n, o);
         }
     }
+    if constexpr (LAB == 5) {
+        const long wid = (long)blockIdx.x * NW;
+        if (lane == 0 && wid < 65536) g_lut_stamps[wid * 5 + 3] = wall_clock64();
+    }
+}
+
+// tuning aid: copy the stamps of the last BIE_GEMV_LAB=5 launch to the host (synchronises the device)
+extern "C" int bie_debug_lut_stamps(unsigned long long* out, int n_waves) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lut_stamps), (size_t)n_waves * 5 * sizeof(unsigned long long));
 }
 
 // ---- host side --------------------------------------------------------------------------------------------
@@ -353,7 +408,7 @@ static LutPlan lut_plan(int K, int group_size, int tiles_total) {
     const int gs = group_size > K ? K : group_size;
     p.rpg = gs / 8;
     p.G = K / gs;
-    p.nw = nw_env == 4 ? 4 : (nw_env == 16 ? 16 : 8);
+    p.nw = nw_env == 4 ? 4 : (nw_env == 2 ? 2 : 8);
     int gpw = cdiv(min_rows, p.rpg);
     const int by_grid = (int)cdivl((long)tiles_total * p.G, (long)max_wg * p.nw);
     if (by_grid > gpw) gpw = by_grid;
@@ -372,12 +427,23 @@ size_t mpq_gemv_lut_part_floats(int M, int K, int group_size, int tiles_total) {
 template <int DT, int ZM, int MT, int NW>
 static void lut_launch_rpg(const LutArgs& a, int rpg, int grid, hipStream_t st) {
     static const int lab = lut_env("BIE_GEMV_LAB", 0);
+    static const int rd = lut_env("BIE_LUT_RD", 0);
 #define BIE_LUT(RPGV)                                                                                                       \
     do {                                                                                                                    \
-        if (lab == 0 || RPGV != 16 || MT != 1 || ZM != ZM_SYM)                                                              \
+        if (lab == 0 && rd > 0 && RPGV == 16 && MT == 1 && ZM == ZM_SYM) {                                                  \
+            if (rd == 4) hipLaunchKernelGGL((mpq_gemv_lut_kernel<DT, ZM_SYM, 1, 16, NW, 0, 4>), dim3(grid), dim3(NW * 64), 0, st, a); \
+            else if (rd == 6) hipLaunchKernelGGL((mpq_gemv_lut_kernel<DT, ZM_SYM, 1, 16, NW, 0, 6>), dim3(grid), dim3(NW * 64), 0, st, a); \
+            else hipLaunchKernelGGL((mpq_gemv_lut_kernel<DT, ZM_SYM, 1, 16, NW, 0, 8>), dim3(grid), dim3(NW * 64), 0, st, a); \
+        } else if (lab == 0 || RPGV != 16 || MT != 1 || ZM != ZM_SYM)                                                       \
             hipLaunchKernelGGL((mpq_gemv_lut_kernel<DT, ZM, MT, RPGV, NW, 0>), dim3(grid), dim3(NW * 64), 0, st, a);        \
-        else                                                                                                                \
+        else if (lab == 2)                                                                                                  \
             hipLaunchKernelGGL((mpq_gemv_lut_kernel<DT, ZM_SYM, 1, 16, NW, 2>), dim3(grid), dim3(NW * 64), 0, st, a);       \
+        else if (lab == 3)                                                                                                  \
+            hipLaunchKernelGGL((mpq_gemv_lut_kernel<DT, ZM_SYM, 1, 16, NW, 3>), dim3(grid), dim3(NW * 64), 0, st, a);       \
+        else if (lab == 5)                                                                                                  \
+            hipLaunchKernelGGL((mpq_gemv_lut_kernel<DT, ZM_SYM, 1, 16, NW, 5>), dim3(grid), dim3(NW * 64), 0, st, a);       \
+        else                                                                                                                \
+            hipLaunchKernelGGL((mpq_gemv_lut_kernel<DT, ZM_SYM, 1, 16, NW, 4>), dim3(grid), dim3(NW * 64), 0, st, a);       \
     } while (0)
     switch (rpg) {
         case 4: BIE_LUT(4); break;
@@ -431,7 +497,7 @@ int mpq_gemv_lut_launch(int nsets, const int32_t* const* qw, const void* const* 
     a.groups_per_wave = p.gpw;
     const int grid = tiles * p.S;
     if (p.nw == 4) lut_launch_nw<4>(a, p.rpg, grid, M, zm, st);
-    else if (p.nw == 16) lut_launch_nw<16>(a, p.rpg, grid, M, zm, st);
+    else if (p.nw == 2) lut_launch_nw<2>(a, p.rpg, grid, M, zm, st);
     else lut_launch_nw<8>(a, p.rpg, grid, M, zm, st);
     return check_launch("mpq_gemv_lut_kernel");
 }
