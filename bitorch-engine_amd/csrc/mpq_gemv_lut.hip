@@ -77,6 +77,61 @@ __device__ __forceinline__ float lut_entry(uint32_t q, float s, float z, int zq1
     else return dequant_scalar_sym<DT>(q, s, z);
 }
 
+// Cross-workgroup reduction of a column tile (called by wave 0 of every workgroup) + the store of y; see the file header.
+template <int DT, int MT, bool REDUCE>
+__device__ __forceinline__ void lut_cross_wg_reduce(const LutArgs& a, const LutSet& ls, float (&tot)[MT], int tile, int slice, int lane,
+                                                    int n, int N, unsigned tag) {
+    // ---- cross-workgroup reduction (wave 0 only) -----------------------------------------------------------------
+    const bool owner = n < N;
+    const long ncat = (long)a.tiles_total * 64;
+    const long col = (long)tile * 64 + lane;
+    if (a.S > 1 && REDUCE) {
+        if (slice != a.S - 1) {  // publisher: one 8-byte write-through store per column, no drain, no atomic
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                const unsigned long long gval = ((unsigned long long)tag << 32) | __float_as_uint(tot[m]);
+                __hip_atomic_store(a.gran + ((long)slice * MT + m) * ncat + col, gval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+        // reducer: poll until every granule of this column carries this launch's tag, then add in slice order
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            float v = 0.0f;
+            for (int s0 = 0; s0 < a.S - 1; s0 += 8) {
+                unsigned long long gv[8];
+                bool ready;
+                int spins = 0;
+                do {
+#pragma unroll
+                    for (int jj = 0; jj < 8; jj++) {
+                        const int sidx = (s0 + jj < a.S - 1) ? s0 + jj : a.S - 2;
+                        gv[jj] = __hip_atomic_load(a.gran + ((long)sidx * MT + m) * ncat + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    ready = true;
+#pragma unroll
+                    for (int jj = 0; jj < 8; jj++) ready = ready && ((unsigned)(gv[jj] >> 32) == tag);
+                    ready = __builtin_amdgcn_ballot_w64(!ready) == 0;  // wave-uniform: every lane's granules are in
+                    if (!ready) __builtin_amdgcn_s_sleep(2);
+                } while (!ready && ++spins < (1 << 24));  // bounded: publishers have lower block ids and never wait
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++)
+                    if (s0 + jj < a.S - 1) v += __uint_as_float((unsigned)gv[jj]);
+            }
+            tot[m] = v + tot[m];
+        }
+        if (lane == 0) a.gen[tile] = tag;  // next launch's tag differs; visible at the kernel boundary
+    }
+    if (owner) {
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            float o = dt_traits<DT>::round(tot[m]);
+            if (ls.bias) o = o + dt_traits<DT>::load(ls.bias, n);
+            dt_traits<DT>::store(ls.y, (long)m * N + n, o);
+        }
+    }
+}
+
 // MT == M (1 or 2); RPG = packed rows per quantisation group (group_size / 8); NW = waves per workgroup;
 // LAB (tuning aids): 2 = stream only, 3 = no cross-workgroup reduction, 4 = stream + reduction (no tables / lookups)
 // RD = rows of every group dequantised directly on the VALU (mpq_dequant.cuh) instead of through the table: the table path is
@@ -105,10 +160,18 @@ __global__ __launch_bounds__(NW * 64) void mpq_gemv_lut_kernel(const LutArgs a) 
     unsigned tag = 0;
     if (a.S > 1) tag = a.gen[tile] + 1u;  // uniform; the generation only changes when this launch's reducer is done
 
-    const uint32_t* wcol = ls.qw + nl;
+    // weights through a buffer descriptor: per-lane column offset in voffset, the row offset is scalar (soffset) -- no 64-bit
+    // per-load address arithmetic on the VALU (it was 10 % of the kernel's vector instructions)
+    const uint64_t qbase = (uint64_t)(uintptr_t)ls.qw;
+    const uint32_t qlo = __builtin_amdgcn_readfirstlane((uint32_t)qbase), qhi = __builtin_amdgcn_readfirstlane((uint32_t)(qbase >> 32));
+    const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((uint64_t)qhi << 32) | qlo), 0,
+                                                         __builtin_amdgcn_readfirstlane((uint32_t)((long)(a.K / NB) * N * 4)), 0x00020000);
+    const uint32_t wvoff = (uint32_t)nl * 4u;
+    const uint32_t row_bytes = __builtin_amdgcn_readfirstlane((uint32_t)N * 4u);
     auto load_group = [&](uint32_t (&dst)[RPG], int g) {
 #pragma unroll
-        for (int u = 0; u < RPG; u++) dst[u] = __builtin_nontemporal_load(wcol + (long)(g * RPG + u) * N);
+        for (int u = 0; u < RPG; u++)
+            dst[u] = __builtin_amdgcn_raw_buffer_load_b32(wrsrc, wvoff, (uint32_t)(g * RPG + u) * row_bytes, /*nt*/ 2);
     };
     const int zero_width = N / NB;
     auto load_params = [&](int g, uint32_t& sb, uint32_t& zb) {
@@ -319,55 +382,184 @@ __global__ __launch_bounds__(NW * 64) void mpq_gemv_lut_kernel(const LutArgs a) 
         for (int m = 0; m < MT; m++) tot[m] = acc[m][0] + acc[m][1];
     }
 
-    // ---- cross-workgroup reduction (wave 0 only) -----------------------------------------------------------------
-    const bool owner = n < N;
-    const long ncat = (long)a.tiles_total * 64;
-    const long col = (long)tile * 64 + lane;
-    if (a.S > 1 && (LAB == 0 || LAB == 4 || LAB == 5)) {
-        if (slice != a.S - 1) {  // publisher: one 8-byte write-through store per column, no drain, no atomic
+    lut_cross_wg_reduce<DT, MT, (LAB == 0 || LAB == 4 || LAB == 5)>(a, ls, tot, tile, slice, lane, n, N, tag);
+    if constexpr (LAB == 5) {
+        const long wid = (long)blockIdx.x * NW;
+        if (lane == 0 && wid < 65536) g_lut_stamps[wid * 5 + 3] = wall_clock64();
+    }
+}
+
+// =====================================================================================================================
+// Cooperative form: the FOUR waves of a workgroup work on the SAME quantisation group at a time.  Each wave builds 4 of the 16
+// table entries and looks up RPG/4 of the group's rows, so the time from "the group's rows have landed" to "the group is
+// summed" is a quarter of the one-wave-per-group form's (whose ~2-3 us per group sat exposed behind the weight stream), and
+// a workgroup walks its 128/RPG ... groups in arrival order.  Two tables (double buffer, one s_barrier per group; the buffer
+// bit travels in the (q) byte of the prepared word, so the lookup is still one v_perm_b32 + one ds_read_b32).  All weight
+// rows of the workgroup's groups are requested up front (32 dwords per lane in flight).
+// =====================================================================================================================
+template <int DT, int ZM, int MT, int RPG, int LAB>
+__global__ __launch_bounds__(256) void mpq_gemv_lutc_kernel(const LutArgs a) {
+    constexpr int NB = 8, NW = 4;
+    constexpr int RPW = RPG / NW;   // rows of a group per wave
+    constexpr int GW = 32 / RPW;    // groups per workgroup: 32 row loads per lane in flight
+    __shared__ __attribute__((aligned(4096))) uint32_t tab[2 * 16 * 64];  // the only LDS object: starts at LDS address 0
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = blockIdx.x % a.tiles_total;
+    const int slice = blockIdx.x / a.tiles_total;
+    int si = 0;
 #pragma unroll
-            for (int m = 0; m < MT; m++) {
-                const unsigned long long gval = ((unsigned long long)tag << 32) | __float_as_uint(tot[m]);
-                __hip_atomic_store(a.gran + ((long)slice * MT + m) * ncat + col, gval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            return;
+    for (int i = 1; i < LUT_MAX_SETS; i++)
+        if (i < a.nsets && tile >= a.set[i].tile_begin) si = i;
+    const LutSet& ls = a.set[si];
+    const int N = ls.N;
+    const int n = (tile - ls.tile_begin) * 64 + lane;
+    const int nl = n < N ? n : N - 1;  // clamp: out-of-range lanes load valid memory and are never stored
+    const int gb = slice * GW;
+    unsigned tag = 0;
+    if (a.S > 1) tag = a.gen[tile] + 1u;
+
+    unsigned long long st0 = 0, st1 = 0, st2 = 0;
+    if constexpr (LAB == 5) st0 = wall_clock64();
+    // ---- every row of this wave, every group constant: requested now
+    const uint32_t* wcol = ls.qw + nl;
+    uint32_t w[GW][RPW];
+    uint32_t sb[GW], zb[GW];
+    const int zero_width = N / NB;
+#pragma unroll
+    for (int j = 0; j < GW; j++) {
+        const int g = (gb + j < a.G) ? gb + j : a.G - 1;  // clamped: valid memory, never used
+#pragma unroll
+        for (int u = 0; u < RPW; u++) w[j][u] = __builtin_nontemporal_load(wcol + (long)(g * RPG + wave * RPW + u) * N);
+        sb[j] = ls.scales[(long)g * N + nl];
+        if constexpr (ZM == ZM_ASYM) {
+            const uint32_t zw = reinterpret_cast<const uint32_t*>(ls.zeros)[(long)g * zero_width + nl / NB];
+            zb[j] = ((zw >> ((nl % NB) * 4)) & 15u) + 1u;
+        } else {
+            zb[j] = reinterpret_cast<const uint16_t*>(ls.zeros)[(long)g * N + nl];
         }
-        // reducer: poll until every granule of this column carries this launch's tag, then add in slice order
+        // issue order = group order: the loads return in order, so group j must not wait behind a later group's request
+        asm volatile("" ::: "memory");
+    }
+    if constexpr (LAB == 5) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st1 = wall_clock64();
+    }
+
+    float acc[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; m++) acc[m][0] = acc[m][1] = 0.0f;
+    const uint32_t lane_addr = lane * 4;
+    uint32_t m0f;
+    asm("v_mov_b32 %0, 0x0f0f0f0f" : "=v"(m0f));
+    const float qbase = (float)(4 * wave);
+
+#pragma unroll
+    for (int j = 0; j < GW; j++) {
+        const int g = gb + j;
+        if (g >= a.G) break;  // workgroup-uniform
+        const int buf = j & 1;
+        uint32_t* mytab = tab + buf * (16 * 64) + (4 * wave) * 64 + lane;  // this wave's 4 entries
+        // activations of this wave's rows: wave-uniform scalar loads
+        uint32_t xs[MT][RPW * 4];
 #pragma unroll
         for (int m = 0; m < MT; m++) {
-            float v = 0.0f;
-            for (int s0 = 0; s0 < a.S - 1; s0 += 8) {
-                unsigned long long gv[8];
-                bool ready;
-                int spins = 0;
-                do {
+            const_u32* xd = (const_u32*)(uintptr_t)(a.x + (long)m * a.K + (long)(g * RPG + wave * RPW) * NB);
 #pragma unroll
-                    for (int jj = 0; jj < 8; jj++) {
-                        const int sidx = (s0 + jj < a.S - 1) ? s0 + jj : a.S - 2;
-                        gv[jj] = __hip_atomic_load(a.gran + ((long)sidx * MT + m) * ncat + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    ready = true;
+            for (int i = 0; i < RPW * 4; i++) xs[m][i] = xd[i];
+        }
+        // ---- entries q = 4*wave .. 4*wave+3 of the group's table
+        if constexpr (LAB == 0 || LAB == 3 || LAB == 5) {
+            if constexpr (DT == BIE_BF16 && ZM == ZM_SYM) {
+                const float s = bf16_bits_to_f32(sb[j]), nz = -bf16_bits_to_f32(zb[j]);
+                const uint32_t sel0 = sel_lo_hi<0>(), sel1 = sel_lo_hi<1>();
+                const uint32_t A0 = pack_bf16x2(qbase * s, (qbase + 1.0f) * s);
+                const uint32_t A1 = pack_bf16x2((qbase + 2.0f) * s, (qbase + 3.0f) * s);
+                float d[4];
+                bf16_pairs_sub(A0, A1, sel0, sel1, nz, d);
+                const uint32_t T0 = pack_bf16x2(d[0], d[1]), T1 = pack_bf16x2(d[2], d[3]);
+                mytab[0 * 64] = T0 << 16;
+                mytab[1 * 64] = T0 & 0xffff0000u;
+                mytab[2 * 64] = T1 << 16;
+                mytab[3 * 64] = T1 & 0xffff0000u;
+            } else {
+                float s, z = 0.0f;
+                int zq1 = 0;
+                if constexpr (DT == BIE_BF16) s = bf16_bits_to_f32(sb[j]); else s = f16_bits_to_f32(sb[j]);
+                if constexpr (ZM == ZM_ASYM) zq1 = (int)zb[j];
+                else if constexpr (DT == BIE_BF16) z = bf16_bits_to_f32(zb[j]); else z = f16_bits_to_f32(zb[j]);
 #pragma unroll
-                    for (int jj = 0; jj < 8; jj++) ready = ready && ((unsigned)(gv[jj] >> 32) == tag);
-                    ready = __builtin_amdgcn_ballot_w64(!ready) == 0;  // wave-uniform: every lane's granules are in
-                    if (!ready) __builtin_amdgcn_s_sleep(2);
-                } while (!ready && ++spins < (1 << 24));  // bounded: publishers have lower block ids and never wait
-#pragma unroll
-                for (int jj = 0; jj < 8; jj++)
-                    if (s0 + jj < a.S - 1) v += __uint_as_float((unsigned)gv[jj]);
+                for (int e = 0; e < 4; e++) mytab[e * 64] = __float_as_uint(lut_entry<DT, ZM>((uint32_t)(4 * wave + e), s, z, zq1));
             }
-            tot[m] = v + tot[m];
         }
-        if (lane == 0) a.gen[tile] = tag;  // next launch's tag differs; visible at the kernel boundary
-    }
-    if (owner) {
 #pragma unroll
-        for (int m = 0; m < MT; m++) {
-            float o = dt_traits<DT>::round(tot[m]);
-            if (ls.bias) o = o + dt_traits<DT>::load(ls.bias, n);
-            dt_traits<DT>::store(ls.y, (long)m * N + n, o);
+        for (int m = 0; m < MT; m++)
+#pragma unroll
+            for (int i = 0; i < RPW * 4; i += 4)
+                asm volatile("" ::"s"(xs[m][i]), "s"(xs[m][i + 1]), "s"(xs[m][i + 2]), "s"(xs[m][i + 3]));
+        // table complete (and every wave is done with the buffer two groups back): LDS-only wait, the weight loads stay in flight
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if constexpr (LAB == 2 || LAB == 4) {
+#pragma unroll
+            for (int u = 0; u < RPW; u++) acc[0][0] += __uint_as_float(w[j][u] & 0x3f7fffffu) + __uint_as_float(sb[j] << 16) + __uint_as_float(xs[0][u]);
+            continue;
+        }
+        const uint32_t bufpat = buf ? 0x10101010u : 0u;  // the buffer bit rides in the high nibble of every (q) byte
+#pragma unroll
+        for (int u = 0; u < RPW; u++) {
+            uint32_t we, wo;
+            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(we) : "v"(w[j][u]), "v"(m0f), "s"(bufpat));
+            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(wo) : "v"(w[j][u] >> 4), "v"(m0f), "s"(bufpat));
+            float t[8];
+            t[0] = lds_f32(lut_addr<0>(lane_addr, we));
+            t[1] = lds_f32(lut_addr<0>(lane_addr, wo));
+            t[2] = lds_f32(lut_addr<1>(lane_addr, we));
+            t[3] = lds_f32(lut_addr<1>(lane_addr, wo));
+            t[4] = lds_f32(lut_addr<2>(lane_addr, we));
+            t[5] = lds_f32(lut_addr<2>(lane_addr, wo));
+            t[6] = lds_f32(lut_addr<3>(lane_addr, we));
+            t[7] = lds_f32(lut_addr<3>(lane_addr, wo));
+#pragma unroll
+            for (int m = 0; m < MT; m++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t p = xs[m][u * 4 + i];
+                    float xlo, xhi;
+                    if constexpr (DT == BIE_BF16) { xlo = __uint_as_float(p << 16); xhi = __uint_as_float(p & 0xffff0000u); }
+                    else { xlo = f16_bits_to_f32(p & 0xffffu); xhi = f16_bits_to_f32(p >> 16); }
+                    acc[m][0] = __builtin_fmaf(xlo, t[2 * i], acc[m][0]);
+                    acc[m][1] = __builtin_fmaf(xhi, t[2 * i + 1], acc[m][1]);
+                }
         }
     }
+    if constexpr (LAB == 5) {
+        asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]));
+        st2 = wall_clock64();
+        const long wid = (long)blockIdx.x * NW + wave;
+        if (lane == 0 && wid < 65536) {
+            g_lut_stamps[wid * 5 + 0] = st0;
+            g_lut_stamps[wid * 5 + 1] = st1;
+            g_lut_stamps[wid * 5 + 2] = st2;
+        }
+    }
+
+    // ---- workgroup reduction through LDS (the tables are dead), wave order ------------------------------------------
+    float tot[MT];
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(tab);
+#pragma unroll
+    for (int m = 0; m < MT; m++) red[(wave * MT + m) * 64 + lane] = acc[m][0] + acc[m][1];
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+        float v = 0.0f;
+#pragma unroll
+        for (int ww = 0; ww < NW; ww++) v += red[(ww * MT + m) * 64 + lane];
+        tot[m] = v;
+    }
+    lut_cross_wg_reduce<DT, MT, (LAB == 0 || LAB == 4 || LAB == 5)>(a, ls, tot, tile, slice, lane, n, N, tag);
     if constexpr (LAB == 5) {
         const long wid = (long)blockIdx.x * NW;
         if (lane == 0 && wid < 65536) g_lut_stamps[wid * 5 + 3] = wall_clock64();
@@ -395,7 +587,7 @@ bool mpq_gemv_lut_ok(int M, int K, int w_bit, int group_size, int dtype, bool ha
 }
 
 struct LutPlan {
-    int rpg, G, gpw, nw, S;
+    int rpg, G, gpw, nw, S, coop;
 };
 
 // A wave takes at least BIE_LUT_ROWS (16) packed rows, i.e. one group of 128; NW (8) waves per workgroup; the grid is
@@ -404,10 +596,18 @@ static LutPlan lut_plan(int K, int group_size, int tiles_total) {
     static const int min_rows = lut_env("BIE_LUT_ROWS", 16);
     static const int nw_env = lut_env("BIE_LUT_NW", 8);
     static const int max_wg = lut_env("BIE_LUT_MAX_WG", 2048);
+    static const int coop = lut_env("BIE_LUT_COOP", 0);  // measured slower (12.1 vs 10.1 us at 4096x11008): kept as a tuning variant
     LutPlan p;
     const int gs = group_size > K ? K : group_size;
     p.rpg = gs / 8;
     p.G = K / gs;
+    p.coop = coop;
+    if (coop) {  // four waves per group, 128 / rpg groups per workgroup (mpq_gemv_lutc_kernel)
+        p.nw = 4;
+        p.gpw = 128 / p.rpg;
+        p.S = cdiv(p.G, p.gpw);
+        return p;
+    }
     p.nw = nw_env == 4 ? 4 : (nw_env == 2 ? 2 : 8);
     int gpw = cdiv(min_rows, p.rpg);
     const int by_grid = (int)cdivl((long)tiles_total * p.G, (long)max_wg * p.nw);
@@ -467,6 +667,38 @@ static void lut_launch_nw(const LutArgs& a, int rpg, int grid, int M, int zm, hi
     }
 }
 
+template <int ZM, int MT>
+static void lutc_launch_rpg(const LutArgs& a, int rpg, int grid, hipStream_t st) {
+    static const int lab = lut_env("BIE_GEMV_LAB", 0);
+#define BIE_LUTC(RPGV, LABV) hipLaunchKernelGGL((mpq_gemv_lutc_kernel<BIE_BF16, ZM, MT, RPGV, LABV>), dim3(grid), dim3(256), 0, st, a)
+    if (lab != 0 && rpg == 16 && MT == 1 && ZM == ZM_SYM) {
+        if (lab == 2) hipLaunchKernelGGL((mpq_gemv_lutc_kernel<BIE_BF16, ZM_SYM, 1, 16, 2>), dim3(grid), dim3(256), 0, st, a);
+        else if (lab == 3) hipLaunchKernelGGL((mpq_gemv_lutc_kernel<BIE_BF16, ZM_SYM, 1, 16, 3>), dim3(grid), dim3(256), 0, st, a);
+        else if (lab == 4) hipLaunchKernelGGL((mpq_gemv_lutc_kernel<BIE_BF16, ZM_SYM, 1, 16, 4>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((mpq_gemv_lutc_kernel<BIE_BF16, ZM_SYM, 1, 16, 5>), dim3(grid), dim3(256), 0, st, a);
+        return;
+    }
+    switch (rpg) {
+        case 4: BIE_LUTC(4, 0); break;
+        case 8: BIE_LUTC(8, 0); break;
+        case 16: BIE_LUTC(16, 0); break;
+        default: BIE_LUTC(32, 0); break;
+    }
+#undef BIE_LUTC
+}
+
+static void lutc_launch(const LutArgs& a, int rpg, int grid, int M, int zm, hipStream_t st) {
+    if (M == 1) {
+        if (zm == ZM_ASYM) lutc_launch_rpg<ZM_ASYM, 1>(a, rpg, grid, st);
+        else if (zm == ZM_FUSED) lutc_launch_rpg<ZM_FUSED, 1>(a, rpg, grid, st);
+        else lutc_launch_rpg<ZM_SYM, 1>(a, rpg, grid, st);
+    } else {
+        if (zm == ZM_ASYM) lutc_launch_rpg<ZM_ASYM, 2>(a, rpg, grid, st);
+        else if (zm == ZM_FUSED) lutc_launch_rpg<ZM_FUSED, 2>(a, rpg, grid, st);
+        else lutc_launch_rpg<ZM_SYM, 2>(a, rpg, grid, st);
+    }
+}
+
 // sets: n weight sets sharing x (one for a plain forward).  `gen` = the workspace's head, `gran` = granule area.
 int mpq_gemv_lut_launch(int nsets, const int32_t* const* qw, const void* const* scales, const void* const* zeros,
                         const void* const* bias, void* const* y, const int* N, const void* x, unsigned* gen, float* gran,
@@ -496,7 +728,8 @@ int mpq_gemv_lut_launch(int nsets, const int32_t* const* qw, const void* const* 
     a.S = p.S;
     a.groups_per_wave = p.gpw;
     const int grid = tiles * p.S;
-    if (p.nw == 4) lut_launch_nw<4>(a, p.rpg, grid, M, zm, st);
+    if (p.coop) lutc_launch(a, p.rpg, grid, M, zm, st);
+    else if (p.nw == 4) lut_launch_nw<4>(a, p.rpg, grid, M, zm, st);
     else if (p.nw == 2) lut_launch_nw<2>(a, p.rpg, grid, M, zm, st);
     else lut_launch_nw<8>(a, p.rpg, grid, M, zm, st);
     return check_launch("mpq_gemv_lut_kernel");

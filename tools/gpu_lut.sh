@@ -1,7 +1,4 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
 run() { echo "== $*"; env "$@" timeout 300 python tools/gemv_lut_check.py $NOPAR 2>&1 | grep -v amdgpu.ids | head -${HEADN:-3}; }
-NOPAR=""; HEADN=30; run BIE_LUT_RD=0; NOPAR="--no-parity"; HEADN=3
-run BIE_LUT_RD=4
-run BIE_LUT_NW=4
-echo "== stamps RD=0"; timeout 120 python tools/lut_stamps.py 4096 11008 2>&1 | grep -v amdgpu.ids | grep -v "workgroup end\|distinct"
+NOPAR=""; HEADN=30; run BIE_LUT_COOP=0

@@ -28,7 +28,7 @@ torch.cuda.synchronize()
 NWv = int(os.environ.get("BIE_LUT_NW", "8"))
 G = K // 128
 tiles = (N + 63) // 64
-S = (G + NWv - 1) // NWv
+S = (G + NWv - 1) // NWv if os.environ.get("BIE_LUT_COOP", "0") == "0" else (G + 7) // 8
 nw = tiles * S * NWv
 buf = np.zeros(nw * 5, dtype=np.uint64)
 raw.bie_debug_lut_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
