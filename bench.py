@@ -1,23 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X low-bit Q-Linear engine (driver contract in the task brief).
 
-Workload (BASELINE.json configs[1]): W4A16 qlinear, K=4096 -> N=11008, group 128, bf16 activations,
-symmetric GBA-style fp zeros, implicit groups.  One STEP = one decode pass (M=1) over L=64 DISTINCT
-layers of that shape (64 x 22.5 MB packed weights = 1.44 GB >> the 256 MiB Infinity Cache, so every
-weight byte comes from HBM), captured once in a HIP graph and replayed -- exactly what a token of
-batch-1 decoding does to the linear layers.  `value` = algorithmic bytes of the step / time (GB/s).
-The compute-bound half (M=4096 prefill GEMM on the same layer) is measured right after the timed
-region and reported in the extra "gemm" / "roofline_gemm" objects.
+Headline workload = the configuration BASELINE.json's `metric` is worded on: W4A16 qlinear, K = N = 4096, group 128,
+bf16 activations, symmetric (GBA-style fp zeros), implicit groups, M = 1.  One STEP = one decode pass over L = 96
+DISTINCT layers of that shape (96 x 8.4 MB of packed weights = 0.8 GB >> the 256 MiB Infinity Cache, so every weight
+byte comes from HBM), captured once in a HIP graph and replayed.  `value` = algorithmic bytes of the step / time (GB/s);
+`roofline` = the same quantity per launch from HIP events recorded on the launch stream around the timed region.
 
-Multi-GPU (--gpus N, one process per GPU, launched by torch.distributed.run): output-column sharding --
-rank r owns the 11008-column block r of every layer of a [4096 -> 11008*N] stack (weak scaling: fixed
-per-GPU work), x is replicated, and the per-step outputs of all layers are exchanged with ONE
-bucketed RCCL all-gather over xGMI (the path's only exchange step).
+Also measured live, each in its own event-bracketed region (rank 0, N = 1): the M = 4096 prefill GEMM of the metric's layer
+(`roofline_gemm`), the 4096x11008 / 11008x4096 layers of configs[1] (M = 1 and M = 4096), the grouped (shared-x) decode
+launches q/k/v and gate/up, configs[2] (exl2 3/2-bit decode), configs[3] (binary linear / conv) and configs[4]'s layer
+(8192x28672, M = 4096) -- every object carries its own roofline fraction.  `cpu_baseline`: the oracle's fused dequant+GEMV on
+the host cores (all cores, and one thread) on a bounded sample.
+
+Multi-GPU (--gpus N, one process per GPU, launched by torch.distributed.run): the headline decode pass with the output
+columns of a [4096 -> 4096*N] stack sharded over the ranks (weak scaling, x replicated, ONE bucketed RCCL all-gather per
+step), plus configs[4] itself in `c5`: 8192x28672 W4 g128, M = 4096, N/world column shards, the all-gather timed
+separately and overlapped with the GEMM by M-tiles (bitorch_engine.distributed).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
-import ctypes
+import hashlib
 import json
 import os
 import sys
@@ -29,105 +33,257 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-K, N, GROUP, WBIT, LAYERS = 4096, 11008, 128, 4, 64
+GROUP, WBIT = 128, 4
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA
+XOR_POPC_PEAK_TOPS = 1260.0  # v_xor_b32 + v_bcnt_u32_b32 accumulate: 2 VALU per 32 binary MACs per lane
+BF16 = torch.bfloat16
 
 
-def alg_bytes(M, k=K, n=N, w=WBIT, g=GROUP):
+def alg_bytes(M, k, n, w=WBIT, g=GROUP):
     """packed weights + scales + fp zeros + x + y (implicit g_idx: 0 bytes)."""
     G = k // g
     return k * n * w // 8 + 2 * G * n + 2 * G * n + 2 * M * k + 2 * M * n
 
 
-def make_layer(dev, gen):
-    qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (K * WBIT // 32, N), dtype=torch.int64, generator=gen, device="cpu").to(torch.int32).to(dev)
-    scales = (torch.rand((K // GROUP, N), generator=gen) * 0.01 + 0.005).to(torch.bfloat16)
-    zeros = (scales.float() * torch.rand((K // GROUP, N), generator=gen) * 15).to(torch.bfloat16)
-    return qw, scales.to(dev), zeros.to(dev)
+def make_layer(dev, gen, k, n):
+    qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (k * WBIT // 32, n), dtype=torch.int32, generator=gen, device=dev)
+    scales = (torch.rand((k // GROUP, n), generator=gen, device=dev) * 0.01 + 0.005).to(BF16)
+    zeros = (scales.float() * torch.rand((k // GROUP, n), generator=gen, device=dev) * 15).to(BF16)
+    return qw, scales, zeros
 
 
-def cpu_baseline(budget_s=12.0):
-    """The oracle's fused dequant+GEMV (OpenMP over all host cores) on a bounded sample of the same workload."""
-    import numpy as np
-    from oracle import oracle as orc
-    rng = np.random.default_rng(0)
-    qw = rng.integers(-2 ** 31, 2 ** 31 - 1, (K * WBIT // 32, N), dtype=np.int64).astype(np.int32)
-    gen = torch.Generator().manual_seed(0)
-    sc = (torch.rand((K // GROUP, N), generator=gen) * 0.01 + 0.005).to(torch.bfloat16)
-    ze = (sc.float() * torch.rand((K // GROUP, N), generator=gen) * 15).to(torch.bfloat16)
-    x = torch.randn((1, K), generator=gen).to(torch.bfloat16)
-    sc_n, ze_n, x_n = orc.torch_to_np(sc), orc.torch_to_np(ze), orc.torch_to_np(x)
-    orc.mpq_forward(x_n, qw, sc_n, ze_n, None, WBIT, GROUP, 0, orc.BF16)  # warm-up
-    t0 = time.perf_counter()
-    n = 0
-    while True:
-        orc.mpq_forward(x_n, qw, sc_n, ze_n, None, WBIT, GROUP, 0, orc.BF16)
-        n += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or n >= LAYERS:
-            break
-    cores = os.cpu_count() or 1
-    return {"value": round(alg_bytes(1) * n / el / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": "port",
-            "sample": f"{n} of {LAYERS} layer GEMVs (M=1, 4096x11008 w4 g128 bf16), oracle/bie_oracle.c orc_mpq_forward_f32acc, OpenMP"}
+def capture(run):
+    """Warm `run(stream_ptr)` on a side stream, then capture it in a HIP graph."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        run(side.cuda_stream)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+        run(torch.cuda.current_stream().cuda_stream)
+    g.replay()
+    torch.cuda.synchronize()
+    return g
 
 
-def pmc_traffic():
-    """HBM bytes per GEMV launch from the committed PMC passes (profiles/r01_pmc_gemv.json, produced by tools/gpu_final.sh:
-    separate FETCH_SIZE and WRITE_SIZE passes, corrected as DESIGN.md section 6 describes); None when the file is absent."""
-    p = os.path.join(ROOT, "profiles", "r01_pmc_gemv.json")
+def time_graph(g, reps):
+    """Microseconds per replay from HIP events on the current stream."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+def kernel_source_sha():
+    """Hash of the GEMV kernel sources: profiles/r02_pmc_gemv.json is only trusted for the sources it was collected on."""
+    h = hashlib.sha256()
+    for f in ("mpq_gemv_lut.hip", "mpq_gemv.hip", "mpq_dequant.cuh"):
+        h.update(open(os.path.join(ROOT, "bitorch-engine_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(shape):
+    """HBM bytes per GEMV launch from this round's PMC passes (tools/gpu_pmc_traffic.sh -> profiles/r02_pmc_gemv.json:
+    separate FETCH_SIZE and WRITE_SIZE passes, corrected as DESIGN.md section 5 describes).  None when the file is absent,
+    was collected on other kernel sources (stale), or has no row for `shape`."""
     try:
-        return json.load(open(p))["gemv_hbm_bytes_per_launch"]
+        d = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_gemv.json")))
+        if d.get("kernel_source_sha") != kernel_source_sha():
+            return None
+        return d["shapes"][shape]["hbm_bytes_per_launch"]
     except Exception:
         return None
 
 
-def bench_square(L, _hip, dev, k=4096, n=4096, nlayers=48):
-    """M=1 decode GEMV (HIP-graph replay over `nlayers` distinct layers, 400 MB of packed weights) and M=4096 GEMM on the
-    4096x4096 g128 W4 bf16 layer; outside the timed region of the headline metric."""
-    gen = torch.Generator().manual_seed(99)
-    layers = []
-    for _ in range(nlayers):
-        qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (k * WBIT // 32, n), dtype=torch.int64, generator=gen).to(torch.int32).to(dev)
-        sc = (torch.rand((k // GROUP, n), generator=gen) * 0.01 + 0.005).to(torch.bfloat16)
-        ze = (sc.float() * torch.rand((k // GROUP, n), generator=gen) * 15).to(torch.bfloat16)
-        layers.append((qw, sc.to(dev), ze.to(dev)))
-    res = {}
-    for M, reps in ((1, 20), (4096, 2)):
-        x = torch.randn((M, k), generator=gen).to(torch.bfloat16).to(dev)
-        y = torch.empty((M, n), dtype=torch.bfloat16, device=dev)
-        ws = torch.zeros(max(L.bie_mpq_workspace_bytes(M, k, n, WBIT), 16), dtype=torch.uint8, device=dev)
+class Bench:
+    def __init__(self, dev):
+        from bitorch_engine import _hip
+        self._hip = _hip
+        self.L = _hip.lib()
+        self.dev = dev
 
-        def run(stream_ptr):
-            for (qw, sc, ze) in layers:
-                rc = L.bie_mpq_forward(x.data_ptr(), qw.data_ptr(), sc.data_ptr(), ze.data_ptr(), None, None, y.data_ptr(), ws.data_ptr(),
-                                       ws.numel(), M, k, n, WBIT, GROUP, 0, _hip.BF16, stream_ptr)
+    def forward(self, x, layer, y, ws, M, k, n, st):
+        qw, sc, ze = layer
+        rc = self.L.bie_mpq_forward(x.data_ptr(), qw.data_ptr(), sc.data_ptr(), ze.data_ptr(), None, None, y.data_ptr(), ws.data_ptr(),
+                                    ws.numel(), M, k, n, WBIT, GROUP, 0, self._hip.BF16, st)
+        if rc:
+            raise RuntimeError(self.L.bie_last_error().decode())
+
+    def workspace(self, M, k, n):
+        return torch.zeros(max(self.L.bie_mpq_workspace_bytes(M, k, n, WBIT), 16), dtype=torch.uint8, device=self.dev)
+
+    # ---- M = 1 decode over `nl` distinct layers -> per-launch microseconds
+    def gemv(self, k, n, nl, reps, seed, M=1):
+        gen = torch.Generator(device=self.dev).manual_seed(seed)
+        layers = [make_layer(self.dev, gen, k, n) for _ in range(nl)]
+        x = torch.randn((M, k), generator=gen, device=self.dev).to(BF16)
+        y = torch.empty((M, n), dtype=BF16, device=self.dev)
+        ws = self.workspace(M, k, n)
+        g = capture(lambda st: [self.forward(x, l, y, ws, M, k, n, st) for l in layers])
+        us = time_graph(g, reps) / nl
+        b = alg_bytes(M, k, n)
+        return {"M": M, "K": k, "N": n, "layers": nl, "us_per_launch": round(us, 3), "alg_bytes_per_launch": b,
+                "roofline": {"bound": "hbm", "achieved": round(b / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(b / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(f"{k}x{n}") if M == 1 else None}}
+
+    # ---- grouped decode: `ns` column counts sharing x, `nl` distinct groups of layers
+    def grouped(self, k, ns, nl, reps, seed, what):
+        import ctypes
+        gen = torch.Generator(device=self.dev).manual_seed(seed)
+        groups = [[make_layer(self.dev, gen, k, n) for n in ns] for _ in range(nl)]
+        x = torch.randn((1, k), generator=gen, device=self.dev).to(BF16)
+        ys = [torch.empty((1, n), dtype=BF16, device=self.dev) for n in ns]
+        cnt = len(ns)
+        Narr = (ctypes.c_int * cnt)(*ns)
+        ws = torch.zeros(max(self.L.bie_mpq_grouped_workspace_bytes(cnt, Narr, 1, k, WBIT), 16), dtype=torch.uint8, device=self.dev)
+        arr = lambda ts: (ctypes.c_void_p * cnt)(*[t.data_ptr() for t in ts])
+        args = [(arr([l[0] for l in gset]), arr([l[1] for l in gset]), arr([l[2] for l in gset])) for gset in groups]
+        yarr = arr(ys)
+
+        def run(st):
+            for (q, s, z) in args:
+                rc = self.L.bie_mpq_forward_grouped(x.data_ptr(), cnt, q, s, z, None, yarr, Narr, ws.data_ptr(), ws.numel(), 1, k, WBIT, GROUP,
+                                                    0, self._hip.BF16, st)
+                if rc:
+                    raise RuntimeError(self.L.bie_last_error().decode())
+        g = capture(run)
+        us = time_graph(g, reps) / nl
+        b = sum(alg_bytes(1, k, n) for n in ns) - 2 * k * (cnt - 1)  # x is read once
+        return {"what": what, "K": k, "N": list(ns), "us_per_launch": round(us, 3), "alg_bytes_per_launch": b,
+                "roofline": {"bound": "hbm", "achieved": round(b / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(b / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None}}
+
+    # ---- M = 4096 prefill GEMM over `nl` distinct layers
+    def gemm(self, M, k, n, nl, reps, seed):
+        gen = torch.Generator(device=self.dev).manual_seed(seed)
+        layers = [make_layer(self.dev, gen, k, n) for _ in range(nl)]
+        x = torch.randn((M, k), generator=gen, device=self.dev).to(BF16)
+        y = torch.empty((M, n), dtype=BF16, device=self.dev)
+        ws = self.workspace(M, k, n)
+        g = capture(lambda st: [self.forward(x, l, y, ws, M, k, n, st) for l in layers])
+        us = time_graph(g, reps) / nl
+        tf = 2.0 * M * k * n / us / 1e6
+        return {"M": M, "K": k, "N": n, "layers": nl, "us_per_launch": round(us, 2), "GB/s_algorithmic": round(alg_bytes(M, k, n) / us / 1e3, 1),
+                "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "traffic": None}}
+
+
+def bench_exl2(dev):
+    """configs[2]: exl2 mixed 3/2-bit decode (g32 rows, random q_perm), Llama-7B shapes, fp16 (the reference kernel is fp16 only)."""
+    from bitorch_engine.extensions import q_linear_cuda
+    from bitorch_engine.layers.qlinear.nbit.cuda.utils import make_group_map
+    gen = torch.Generator().manual_seed(5)
+    out = []
+    for (K, N) in ((4096, 4096), (4096, 11008), (11008, 4096)):
+        qg, row = [], 0
+        for b in (3, 2):
+            for _ in range(K // 2 // 32):
+                qg += [b, row]
+                row += b
+        groups = len(qg) // 2
+        q_groups = torch.tensor(qg, dtype=torch.short)
+        gmap = make_group_map(q_groups, row).to(dev)
+        perm = torch.randperm(K, generator=gen).to(torch.short).to(dev)
+        nset = max(2, min(32, int(500e6 // (row * N * 4))))
+        sets = []
+        for _ in range(nset):
+            qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (row, N), dtype=torch.int32, device=dev)
+            sc = (torch.rand((groups, N), device=dev) * 0.02 + 0.001).half()
+            ze = (torch.randn((groups, N), device=dev) * 0.05).half()
+            sets.append((qw, sc, ze))
+        _, rows = q_linear_cuda.mbwq_trans_qweight(sets[0][0], q_groups, True, K, groups, 4)
+        x = torch.randn((1, K), device=dev).half()
+        g = capture(lambda st: [q_linear_cuda.mbwq_exl2_forward(x, s_[0], s_[1], s_[2], perm, gmap, rows, False) for s_ in sets])
+        us = time_graph(g, 10) / nset
+        byts = row * N * 4 + 4 * groups * N + 6 * K + 2 * K + 2 * N
+        out.append({"op": "exl2 w3/w2 g32 decode", "M": 1, "K": K, "N": N, "us_per_launch": round(us, 2),
+                    "roofline": {"bound": "hbm", "achieved": round(byts / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(byts / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None}})
+    return out
+
+
+def bench_binary(dev, L):
+    """configs[3]: binary XNOR linear 4096x4096 (row-packed) and the ResNet-18 3x3x512 conv on 7x7 maps."""
+    from bitorch_engine.extensions import binary_conv_cpp
+    out = []
+    K = N = 4096
+    wsets = [torch.randint(0, 256, (N, K // 8), dtype=torch.int32, device=dev).to(torch.uint8) for _ in range(16)]
+    for M in (1, 64, 4096):
+        xp = torch.randint(0, 256, (M, K // 8), dtype=torch.int32, device=dev).to(torch.uint8)
+        y = torch.empty((M, N), dtype=torch.float32, device=dev)
+
+        def run(st):
+            for w in wsets:
+                rc = L.bie_binary_linear_forward(xp.data_ptr(), w.data_ptr(), y.data_ptr(), M, N, K, 0, 1.0, st)
                 if rc:
                     raise RuntimeError(L.bie_last_error().decode())
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            run(side.cuda_stream)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
-            run(torch.cuda.current_stream().cuda_stream)
-        g.replay()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            g.replay()
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / (reps * nlayers)
-        if M == 1:
-            res["gemv_M1"] = {"us_per_launch": round(us, 2), "GB/s": round(alg_bytes(1, k, n) / us / 1e3, 1),
-                              "frac_of_hbm_peak": round(alg_bytes(1, k, n) / us / 1e3 / HBM_PEAK_GBS, 4)}
-        else:
-            tf = 2.0 * M * k * n / us / 1e6
-            res["gemm_M4096"] = {"us_per_launch": round(us, 2), "TFLOP/s": round(tf, 1), "frac_of_mfma_peak": round(tf / MFMA_PEAK_TFLOPS, 4)}
+        us = time_graph(capture(run), 10 if M < 4096 else 3) / len(wsets)
+        byts = K * N // 8 + M * K // 8 + 4 * M * N
+        tops = 2.0 * M * K * N / us / 1e6
+        rf = ({"bound": "hbm", "achieved": round(byts / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(byts / us / 1e3 / HBM_PEAK_GBS, 4)}
+              if M <= 64 else {"bound": "valu xor+bcnt", "achieved": round(tops, 1), "peak": XOR_POPC_PEAK_TOPS, "unit": "TOP/s", "frac": round(tops / XOR_POPC_PEAK_TOPS, 4)})
+        out.append({"op": "binary linear 4096x4096", "M": M, "us_per_launch": round(us, 2), "TOP/s": round(tops, 1), "roofline": dict(rf, traffic=None)})
+    for B in (1, 32):
+        x = torch.randn((B, 512, 7, 7), device=dev)
+        w = torch.randn((512, 512, 3, 3), device=dev)
+        wp = binary_conv_cpp.w_pack(w) if hasattr(binary_conv_cpp, "w_pack") else None
+        fn = lambda st: binary_conv_cpp.forward(x, wp if wp is not None else w, 512, 512 * 9, B * 49, 3, 1, 1, 1, 7)
+        try:
+            us = time_graph(capture(fn), 20)
+            tops = 2.0 * B * 49 * 512 * 4608 / us / 1e6
+            out.append({"op": "binary conv 512->512 3x3 on 7x7", "B": B, "us_per_call": round(us, 2), "TOP/s": round(tops, 2),
+                        "roofline": {"bound": "valu xor+bcnt", "achieved": round(tops, 2), "peak": XOR_POPC_PEAK_TOPS, "unit": "TOP/s",
+                                     "frac": round(tops / XOR_POPC_PEAK_TOPS, 5), "traffic": None}})
+        except Exception as e:  # reporting only
+            out.append({"op": "binary conv 512->512 3x3 on 7x7", "B": B, "error": str(e)[:200]})
+    return out
+
+
+def cpu_baselines(budget_s=6.0):
+    """The oracle's fused dequant+GEMV (oracle/bie_oracle.c orc_mpq_forward_f32acc) on the host cores: per layer shape, all cores
+    (OpenMP) and one thread, each on a bounded sample of the decode pass (a few layer GEMVs)."""
+    import ctypes
+    import numpy as np
+    from oracle import oracle as orc
+    try:
+        omp = ctypes.CDLL("libgomp.so.1")
+    except OSError:
+        omp = None
+    cores = os.cpu_count() or 1
+    res = []
+    for (k, n) in ((4096, 4096), (4096, 11008)):
+        rng = np.random.default_rng(0)
+        qw = rng.integers(-2 ** 31, 2 ** 31 - 1, (k * WBIT // 32, n), dtype=np.int64).astype(np.int32)
+        gen = torch.Generator().manual_seed(0)
+        sc = (torch.rand((k // GROUP, n), generator=gen) * 0.01 + 0.005).to(BF16)
+        ze = (sc.float() * torch.rand((k // GROUP, n), generator=gen) * 15).to(BF16)
+        x = torch.randn((1, k), generator=gen).to(BF16)
+        sc_n, ze_n, x_n = orc.torch_to_np(sc), orc.torch_to_np(ze), orc.torch_to_np(x)
+        for threads in (cores, 1):
+            if omp is not None:
+                omp.omp_set_num_threads(threads)
+            elif threads == 1:
+                continue
+            orc.mpq_forward(x_n, qw, sc_n, ze_n, None, WBIT, GROUP, 0, orc.BF16)  # warm-up
+            t0 = time.perf_counter()
+            cnt = 0
+            while True:
+                orc.mpq_forward(x_n, qw, sc_n, ze_n, None, WBIT, GROUP, 0, orc.BF16)
+                cnt += 1
+                el = time.perf_counter() - t0
+                if el > budget_s / 2 or cnt >= 64:
+                    break
+            res.append({"value": round(alg_bytes(1, k, n) * cnt / el / 1e9, 3), "unit": "GB/s", "cores": threads, "kind": "port",
+                        "sample": f"{cnt} layer GEMVs (M=1, {k}x{n} w4 g128 bf16), oracle/bie_oracle.c orc_mpq_forward_f32acc, "
+                                  f"{'OpenMP all cores' if threads > 1 else 'one thread'}"})
+    if omp is not None:
+        omp.omp_set_num_threads(cores)
     return res
 
 
@@ -137,7 +293,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-gemm", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline only (used under rocprofv3)")
+    ap.add_argument("--only", default="", help="profiling aid: run only this shape's M=1 decode pass, e.g. 4096x11008")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -153,34 +310,18 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)
 
-    from bitorch_engine import _hip
-    L = _hip.lib()
-
-    gen = torch.Generator().manual_seed(1234 + rank)
-    layers = [make_layer(dev, gen) for _ in range(LAYERS)]
-    x = torch.randn((1, K), generator=gen).to(torch.bfloat16).to(dev)
-    y_all = torch.empty((LAYERS, N), dtype=torch.bfloat16, device=dev)  # row l = output of layer l
-    gathered = torch.empty((world * LAYERS, N), dtype=torch.bfloat16, device=dev) if distributed else None  # rank-major
-    ws_bytes = L.bie_mpq_workspace_bytes(1, K, N, WBIT)
-    ws = torch.zeros(max(ws_bytes, 16), dtype=torch.uint8, device=dev)  # 4 KiB head of split-K counters starts at zero
-
-    def run_layers(stream_ptr):
-        for l, (qw, sc, ze) in enumerate(layers):
-            rc = L.bie_mpq_forward(x.data_ptr(), qw.data_ptr(), sc.data_ptr(), ze.data_ptr(), None, None,
-                                   y_all[l].data_ptr(), ws.data_ptr(), ws.numel(), 1, K, N, WBIT, GROUP, 0, _hip.BF16, stream_ptr)
-            if rc:
-                raise RuntimeError(L.bie_last_error().decode())
-
-    # capture one decode pass in a HIP graph (launch-bound otherwise: 128 launches of a few microseconds)
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        run_layers(side.cuda_stream)
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
-        run_layers(torch.cuda.current_stream().cuda_stream)
+    B = Bench(dev)
+    K, N, LAYERS = 4096, 4096, 96
+    if args.only:
+        K, N = [int(v) for v in args.only.split("x")]
+        LAYERS = max(8, min(96, int(800e6 // (K * N // 2))))
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    layers = [make_layer(dev, gen, K, N) for _ in range(LAYERS)]
+    x = torch.randn((1, K), generator=gen, device=dev).to(BF16)
+    y_all = torch.empty((LAYERS, N), dtype=BF16, device=dev)  # row l = output of layer l
+    gathered = torch.empty((world * LAYERS, N), dtype=BF16, device=dev) if distributed else None  # rank-major
+    ws = B.workspace(1, K, N)
+    graph = capture(lambda st: [B.forward(x, l, y_all[i], ws, 1, K, N, st) for i, l in enumerate(layers)])
 
     def step():
         graph.replay()
@@ -210,87 +351,68 @@ def main():
         elapsed = float(t.item())
 
     ms_per_step = elapsed / args.steps * 1e3
-    step_bytes = alg_bytes(1) * LAYERS
+    step_bytes = alg_bytes(1, K, N) * LAYERS
     value = step_bytes * world / (elapsed / args.steps) / 1e9
 
     out = None
     if rank == 0:
-        # dominant kernel = the M=1 GEMV; one launch per layer.  Duration from HIP events recorded on the launch
-        # stream around the timed region / launches (graph replay only when N=1 -> includes the ~1 us kernel
-        # boundaries and the split-K finalize kernel: conservative).
         launches = args.steps * LAYERS
         avg_us = gpu_ms * 1e3 / launches
-        achieved = alg_bytes(1) / (avg_us * 1e-6) / 1e9
+        achieved = alg_bytes(1, K, N) / (avg_us * 1e-6) / 1e9
         out = {
-            "metric": "W4A16 decode GEMV weight-streaming throughput (M=1, 4096x11008 g128, bf16)",
+            "metric": f"W4A16 decode GEMV weight-streaming throughput (M=1, {K}x{N} g128, bf16)",
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic (seeded random packed weights / scales / zeros, N(0,1) activations)",
-            "config": {"workload": "BASELINE.json configs[1]: W4A16 qlinear 4096x11008 g128 bf16, M=1 decode pass over 64 distinct layers (1.44 GB of packed weights, HIP-graph replay)",
+            "config": {"workload": f"BASELINE.json metric config (configs[0] shape): W4A16 qlinear {K}x{N} g128 bf16, M=1 decode pass over {LAYERS} "
+                                   f"distinct layers ({LAYERS * K * N // 2 / 1e9:.2f} GB of packed weights, HIP-graph replay)",
                        "layers_per_step": LAYERS, "parallelism": "output-column sharding x%d + 1 all-gather/step" % world if distributed else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(),
-                         "kernel": "bie::mpq_gemv3_kernel<bf16,w4,M=1> (in-kernel split-K, no finalize launch)", "avg_launch_us": round(avg_us, 3),
-                         "alg_bytes_per_launch": alg_bytes(1)},
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(f"{K}x{N}"),
+                         "kernel": "bie::mpq_gemv_lut_kernel<bf16,sym,M=1,rpg=16,NW=8> (table-lookup dequant, in-kernel split-K by tagged granules)",
+                         "avg_launch_us": round(avg_us, 3), "alg_bytes_per_launch": alg_bytes(1, K, N)},
         }
 
-    # ---- compute-bound half: M=4096 prefill GEMM on the same layer shape (rank 0 only, outside the timed region)
-    # (N = 1 only: with a process group alive, its watchdog thread may touch the runtime while rank 0 captures)
-    if rank == 0 and world == 1 and not args.no_gemm:
-        M = 4096
-        xg = torch.randn((M, K), generator=torch.Generator().manual_seed(7)).to(torch.bfloat16).to(dev)
-        yg = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
-        wsg_b = L.bie_mpq_workspace_bytes(M, K, N, WBIT)
-        wsg = torch.zeros(max(wsg_b, 16), dtype=torch.uint8, device=dev)
-        st = torch.cuda.current_stream().cuda_stream
+    extras = rank == 0 and world == 1 and not args.no_extras and not args.only
+    if extras:
+        def guarded(key, fn):
+            try:
+                out[key] = fn()
+            except Exception as e:  # reporting only: never fail the headline for an extra
+                out[key] = {"error": str(e)[:300]}
+        # ---- compute-bound half on the metric's layer (first-class: its own event-timed region)
+        guarded("gemm", lambda: B.gemm(4096, 4096, 4096, 24, 3, 7))
+        if "roofline" in out.get("gemm", {}):
+            out["roofline_gemm"] = dict(out["gemm"]["roofline"], kernel="bie::mpq_gemm_kernel<bf16,w4,256x256x64 tile>", us_per_launch=out["gemm"]["us_per_launch"])
+        # ---- configs[1]: 4096x11008 and 11008x4096, M = 1 and M = 4096
+        guarded("c2_gemv_4096x11008", lambda: B.gemv(4096, 11008, 40, 10, 11))
+        guarded("c2_gemv_11008x4096", lambda: B.gemv(11008, 4096, 40, 10, 12))
+        guarded("c2_gemv_M2_4096x11008", lambda: B.gemv(4096, 11008, 40, 10, 13, M=2))
+        guarded("c2_gemm_4096x11008", lambda: B.gemm(4096, 4096, 11008, 16, 3, 14))
+        guarded("c2_gemm_11008x4096", lambda: B.gemm(4096, 11008, 4096, 16, 3, 15))
+        # ---- grouped decode launches (one x, several weight sets)
+        guarded("grouped_qkv_3x4096x4096", lambda: B.grouped(4096, (4096, 4096, 4096), 32, 10, 21, "q/k/v projections in one launch"))
+        guarded("grouped_gate_up_2x4096x11008", lambda: B.grouped(4096, (11008, 11008), 20, 10, 22, "gate/up projections in one launch"))
+        # ---- configs[2], configs[3]
+        guarded("c3_exl2", lambda: bench_exl2(dev))
+        guarded("c4_binary", lambda: bench_binary(dev, B.L))
+        # ---- configs[4]'s layer on one GPU (the sharded run is `c5` under --gpus N)
+        guarded("c5_single_gpu_8192x28672", lambda: B.gemm(4096, 8192, 28672, 2, 3, 31))
+    if rank == 0:
+        out["kernel_source_sha"] = kernel_source_sha()
 
-        def gemm(l):
-            qw, sc, ze = layers[l % LAYERS]
-            rc = L.bie_mpq_forward(xg.data_ptr(), qw.data_ptr(), sc.data_ptr(), ze.data_ptr(), None, None, yg.data_ptr(),
-                                   wsg.data_ptr(), wsg.numel(), M, K, N, WBIT, GROUP, 0, _hip.BF16, st)
-            if rc:
-                raise RuntimeError(L.bie_last_error().decode())
-        # 16 launches over 16 distinct layers captured in a HIP graph and replayed (same method as the decode pass: no host
-        # launch gaps between kernels)
-        nl = 16
-        gside = torch.cuda.Stream()
-        gside.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(gside):
-            st = gside.cuda_stream
-            for i in range(nl):
-                gemm(i)
-        torch.cuda.current_stream().wait_stream(gside)
-        torch.cuda.synchronize()
-        ggraph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ggraph, stream=gside, capture_error_mode="thread_local"):
-            st = torch.cuda.current_stream().cuda_stream
-            for i in range(nl):
-                gemm(i)
-        ggraph.replay()
-        torch.cuda.synchronize()
-        reps = 4
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            ggraph.replay()
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / (reps * nl)
-        tf = 2.0 * M * K * N / (us * 1e-6) / 1e12
-        out["gemm"] = {"M": M, "us_per_call": round(us, 2), "TFLOP/s": round(tf, 1), "GB/s_algorithmic": round(alg_bytes(M) / (us * 1e-6) / 1e9, 1)}
-        out["roofline_gemm"] = {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "traffic": None, "kernel": "bie::mpq_gemm_kernel<bf16,w4,256x256x64 tile>"}
+    # ---- configs[4] sharded: 8192 x 28672, M = 4096, N / world column shards + all-gather (separate and overlapped)
+    if distributed and not args.only:
+        from bitorch_engine.distributed import bench_column_sharded
+        c5 = bench_column_sharded(B, world, rank, dev, M=4096, K=8192, N=28672, reps=5)
+        if rank == 0:
+            out["c5"] = c5
 
-    # ---- BASELINE.json's metric is worded on the 4096x4096 layer (configs[0], the reference's CPU-runnable case): report it too
-    if rank == 0 and world == 1 and not args.no_gemm:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.only:
         try:
-            out["shape_4096x4096"] = bench_square(L, _hip, dev)
-        except Exception as e:  # reporting only
-            out["shape_4096x4096"] = {"error": str(e)}
-
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        try:
-            out["cpu_baseline"] = cpu_baseline()
+            bl = cpu_baselines()
+            out["cpu_baseline"] = bl[0]          # all cores, the headline shape
+            out["cpu_baselines"] = bl            # all cores + one thread, 4096x4096 and 4096x11008
         except Exception as e:  # the baseline is reporting only; never fail the bench for it
             out["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
     elif rank == 0:

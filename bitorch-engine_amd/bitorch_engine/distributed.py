@@ -78,3 +78,117 @@ class ColumnShardedMPQLinear(torch.nn.Module):
             dist.all_gather(parts, y_local.contiguous(), group=self.group)
             y = torch.cat(parts, dim=1)
         return y.view(lead + [self.N])
+
+    # ------------------------------------------------------------------------------------------------------------------
+    # M-tiled schedule: the all-gather of tile t runs on a side stream while the GEMM of tile t+1 computes
+    # ------------------------------------------------------------------------------------------------------------------
+    def forward_overlapped(self, x: torch.Tensor, m_tile: int = 1024, interleave: bool = True) -> torch.Tensor:
+        """Same result as forward().  x is cut into row tiles of `m_tile`; tile t's local GEMM is followed by its all-gather
+        on a communication stream, so the exchange of tile t (N/W columns x m_tile rows to every peer over xGMI) hides
+        behind the GEMM of tile t+1 -- SURVEY.md section 8e budgets 192 us of exchange against ~192 us of compute for
+        configs[4], i.e. un-overlapped the step is twice as long.  Every rank issues the collectives in the same (tile)
+        order.  On the CPU (gloo tests) the schedule is identical, just without streams.
+        interleave=False returns the collective's natural rank-major layout [W, M, N/W] (what a following row-parallel
+        layer consumes directly) and skips the [M, N] interleave copy."""
+        lead = list(x.shape[:-1])
+        x2 = x.reshape(-1, x.shape[-1])
+        M = x2.shape[0]
+        widths = [hi - lo for lo, hi in self.ranges]
+        if len(set(widths)) != 1 or M <= m_tile:
+            return self.forward(x)
+        wdt = widths[0]
+        on_gpu = x2.is_cuda
+        tiles = [(m0, min(m0 + m_tile, M)) for m0 in range(0, M, m_tile)]
+        out_dtype = x2.dtype
+        gathered = torch.empty((self.world, M, wdt), dtype=out_dtype, device=x2.device)  # rank-major
+        comm = compute = None
+        if on_gpu:
+            compute = torch.cuda.current_stream(x2.device)
+            comm = _comm_stream(x2.device)
+            comm.wait_stream(compute)  # `gathered` exists before the first collective writes it
+        stage = []
+        for (m0, m1) in tiles:
+            y_t = self.local_forward(x2[m0:m1]).contiguous()  # [mt, N/W] on the compute stream
+            recv = torch.empty((self.world, m1 - m0, wdt), dtype=out_dtype, device=x2.device)
+            if on_gpu:
+                ev = torch.cuda.Event()
+                ev.record(compute)
+                with torch.cuda.stream(comm):
+                    comm.wait_event(ev)
+                    dist.all_gather_into_tensor(recv.view(self.world * (m1 - m0), wdt), y_t, group=self.group)
+                    gathered[:, m0:m1].copy_(recv)
+                y_t.record_stream(comm)
+                recv.record_stream(comm)
+            else:
+                dist.all_gather_into_tensor(recv.view(self.world * (m1 - m0), wdt), y_t, group=self.group)
+                gathered[:, m0:m1].copy_(recv)
+            stage.append((y_t, recv))
+        if on_gpu:
+            compute.wait_stream(comm)
+        if not interleave:
+            return gathered
+        y = gathered.permute(1, 0, 2).reshape(M, self.N)
+        return y.view(lead + [self.N])
+
+
+_COMM_STREAMS = {}
+
+
+def _comm_stream(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    s = _COMM_STREAMS.get(key)
+    if s is None:
+        s = torch.cuda.Stream(device=device)
+        _COMM_STREAMS[key] = s
+    return s
+
+
+def bench_column_sharded(B, world: int, rank: int, dev, M: int = 4096, K: int = 8192, N: int = 28672, reps: int = 5, m_tile: int = 1024):
+    """bench.py's configs[4] leg: W4A16 K x N g128 bf16, M rows, the N output columns sharded over `world` ranks (strong scaling).
+    Times, with a barrier + synchronize on both sides and the MAX over ranks: the local GEMM alone, the all-gather alone,
+    GEMM + all-gather back to back, and the M-tiled overlapped schedule.  Aggregate TFLOP/s = 2*M*K*N / time."""
+    import time
+    lo, hi = column_range(N, rank, world)
+    gen = torch.Generator(device=dev).manual_seed(4242 + rank)
+    n_loc = hi - lo
+    qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // 8, n_loc), dtype=torch.int32, generator=gen, device=dev)
+    sc = (torch.rand((K // 128, n_loc), generator=gen, device=dev) * 0.01 + 0.005).to(torch.bfloat16)
+    ze = (sc.float() * torch.rand((K // 128, n_loc), generator=gen, device=dev) * 15).to(torch.bfloat16)
+    layer = ColumnShardedMPQLinear.__new__(ColumnShardedMPQLinear)
+    torch.nn.Module.__init__(layer)
+    layer.N, layer.rank, layer.world, layer.group = N, rank, world, None
+    layer.w_bit, layer.group_size, layer.asym = 4, 128, False
+    layer.ranges = [column_range(N, r, world) for r in range(world)]
+    layer.lo, layer.hi = lo, hi
+    for name, t in (("qweight", qw), ("scales", sc), ("zeros", ze), ("g_idx", None), ("bias", None)):
+        layer.register_buffer(name, t)
+    layer._impl = None
+    x = torch.randn((M, K), generator=torch.Generator(device=dev).manual_seed(7), device=dev).to(torch.bfloat16)
+    y_loc = layer.local_forward(x)
+    gathered = torch.empty((world * M, n_loc), dtype=torch.bfloat16, device=dev)
+
+    def timed(fn):
+        fn()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()) * 1e6
+
+    us_gemm = timed(lambda: layer.local_forward(x))
+    us_gather = timed(lambda: dist.all_gather_into_tensor(gathered, y_loc))
+    us_seq = timed(lambda: layer.forward(x))
+    us_ovl = timed(lambda: layer.forward_overlapped(x, m_tile))
+    us_ovl_rm = timed(lambda: layer.forward_overlapped(x, m_tile, interleave=False))
+    flops = 2.0 * M * K * N
+    return {"workload": f"BASELINE.json configs[4]: W4A16 {K}x{N} g128 bf16, M={M}, {world} column shards of {n_loc}",
+            "scaling": "strong", "us_local_gemm": round(us_gemm, 1), "us_all_gather": round(us_gather, 1),
+            "us_gemm_then_gather": round(us_seq, 1), "us_overlapped_m_tiles": round(us_ovl, 1),
+            "us_overlapped_rank_major_output": round(us_ovl_rm, 1), "m_tile": m_tile,
+            "TFLOP/s_aggregate_overlapped": round(flops / us_ovl / 1e6, 1), "TFLOP/s_aggregate_local_gemm_only": round(flops / us_gemm / 1e6, 1),
+            "gather_bytes_per_rank": M * n_loc * 2 * (world - 1)}

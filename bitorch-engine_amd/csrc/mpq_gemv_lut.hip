@@ -48,7 +48,8 @@ struct LutArgs {
     const uint16_t* x;
     unsigned long long* gran;  // [S-1][M][tiles_total * 64] {fp32 partial, tag}
     unsigned* gen;             // generation word per column tile (workspace head)
-    int nsets, M, K, G, tiles_total, S, groups_per_wave;
+    int nsets, M, K, G, tiles_total, S, groups_per_wave;  // G / groups_per_wave count UNITS of RPG rows: H units per group
+    int hshift;  // log2(H)
 };
 
 // tuning aid (BIE_GEMV_LAB=5): per-wave timestamps {start, weights landed, compute done, end, xcc/cu id} of the last launch
@@ -160,21 +161,14 @@ __global__ __launch_bounds__(NW * 64) void mpq_gemv_lut_kernel(const LutArgs a) 
     unsigned tag = 0;
     if (a.S > 1) tag = a.gen[tile] + 1u;  // uniform; the generation only changes when this launch's reducer is done
 
-    // weights through a buffer descriptor: per-lane column offset in voffset, the row offset is scalar (soffset) -- no 64-bit
-    // per-load address arithmetic on the VALU (it was 10 % of the kernel's vector instructions)
-    const uint64_t qbase = (uint64_t)(uintptr_t)ls.qw;
-    const uint32_t qlo = __builtin_amdgcn_readfirstlane((uint32_t)qbase), qhi = __builtin_amdgcn_readfirstlane((uint32_t)(qbase >> 32));
-    const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((uint64_t)qhi << 32) | qlo), 0,
-                                                         __builtin_amdgcn_readfirstlane((uint32_t)((long)(a.K / NB) * N * 4)), 0x00020000);
-    const uint32_t wvoff = (uint32_t)nl * 4u;
-    const uint32_t row_bytes = __builtin_amdgcn_readfirstlane((uint32_t)N * 4u);
+    const uint32_t* wcol = ls.qw + nl;
     auto load_group = [&](uint32_t (&dst)[RPG], int g) {
 #pragma unroll
-        for (int u = 0; u < RPG; u++)
-            dst[u] = __builtin_amdgcn_raw_buffer_load_b32(wrsrc, wvoff, (uint32_t)(g * RPG + u) * row_bytes, /*nt*/ 2);
+        for (int u = 0; u < RPG; u++) dst[u] = __builtin_nontemporal_load(wcol + (long)(g * RPG + u) * N);
     };
     const int zero_width = N / NB;
-    auto load_params = [&](int g, uint32_t& sb, uint32_t& zb) {
+    auto load_params = [&](int unit, uint32_t& sb, uint32_t& zb) {
+        const int g = unit >> a.hshift;  // a group may be split into H units of RPG rows, each with its own wave (and table)
         sb = ls.scales[(long)g * N + nl];
         if constexpr (ZM == ZM_ASYM) {
             const uint32_t zw = reinterpret_cast<const uint32_t*>(ls.zeros)[(long)g * zero_width + nl / NB];
@@ -330,9 +324,13 @@ __global__ __launch_bounds__(NW * 64) void mpq_gemv_lut_kernel(const LutArgs a) 
     uint32_t wa[RPG], wb[RPG];
     uint32_t sa = 0, za = 0, sb2 = 0, zb2 = 0;
     if (g0 < g1) {
-        load_group(wa, g0);
+        // the group constants are requested BEFORE the weight rows (loads return in order): the table is built while the
+        // rows are still in flight instead of after the last of them has landed
         load_params(g0, sa, za);
-        if (g0 + 1 < g1) { load_group(wb, g0 + 1); load_params(g0 + 1, sb2, zb2); }
+        if (g0 + 1 < g1) load_params(g0 + 1, sb2, zb2);
+        asm volatile("" ::: "memory");
+        load_group(wa, g0);
+        if (g0 + 1 < g1) load_group(wb, g0 + 1);
     }
     if constexpr (LAB == 5) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -340,10 +338,10 @@ __global__ __launch_bounds__(NW * 64) void mpq_gemv_lut_kernel(const LutArgs a) 
     }
     for (int g = g0; g < g1; g += 2) {
         process_group(wa, g, sa, za);
-        if (g + 2 < g1) { load_group(wa, g + 2); load_params(g + 2, sa, za); }
+        if (g + 2 < g1) { load_params(g + 2, sa, za); load_group(wa, g + 2); }
         if (g + 1 < g1) {
             process_group(wb, g + 1, sb2, zb2);
-            if (g + 3 < g1) { load_group(wb, g + 3); load_params(g + 3, sb2, zb2); }
+            if (g + 3 < g1) { load_params(g + 3, sb2, zb2); load_group(wb, g + 3); }
         }
     }
 
@@ -587,21 +585,26 @@ bool mpq_gemv_lut_ok(int M, int K, int w_bit, int group_size, int dtype, bool ha
 }
 
 struct LutPlan {
-    int rpg, G, gpw, nw, S, coop;
+    int rpg, G, gpw, nw, S, coop, H;  // rpg / G in UNITS (a group = H units) once H > 1
 };
 
-// A wave takes at least BIE_LUT_ROWS (16) packed rows, i.e. one group of 128; NW (8) waves per workgroup; the grid is
-// bounded to ~BIE_LUT_MAX_WG workgroups by giving a wave more groups (bounds the granule traffic of big layers).
+// A wave takes one unit = one group of 128 (16 packed rows); NW (8) waves per workgroup.  Small layers that would leave the
+// chip short of waves split every group into H = 2 or 4 units (each wave then builds the group's table for 8 or 4 rows: the
+// per-wave critical path, which is what a 4096x4096 launch spends its time on, shrinks accordingly); big grids give a wave
+// several units (bounds the granule traffic).
 static LutPlan lut_plan(int K, int group_size, int tiles_total) {
     static const int min_rows = lut_env("BIE_LUT_ROWS", 16);
     static const int nw_env = lut_env("BIE_LUT_NW", 8);
     static const int max_wg = lut_env("BIE_LUT_MAX_WG", 2048);
     static const int coop = lut_env("BIE_LUT_COOP", 0);  // measured slower (12.1 vs 10.1 us at 4096x11008): kept as a tuning variant
+    static const int force_h = lut_env("BIE_LUT_H", 0);
+    static const int want_waves = lut_env("BIE_LUT_WANT_WAVES", 4096);
     LutPlan p;
     const int gs = group_size > K ? K : group_size;
     p.rpg = gs / 8;
     p.G = K / gs;
     p.coop = coop;
+    p.H = 1;
     if (coop) {  // four waves per group, 128 / rpg groups per workgroup (mpq_gemv_lutc_kernel)
         p.nw = 4;
         p.gpw = 128 / p.rpg;
@@ -609,7 +612,15 @@ static LutPlan lut_plan(int K, int group_size, int tiles_total) {
         return p;
     }
     p.nw = nw_env == 4 ? 4 : (nw_env == 2 ? 2 : 8);
-    int gpw = cdiv(min_rows, p.rpg);
+    int H = 1;
+    if (force_h > 0) H = force_h;
+    else
+        while (H < 4 && p.rpg / (2 * H) >= 4 && (long)tiles_total * p.G * H < want_waves) H *= 2;
+    while (H > 1 && (p.rpg % H || p.rpg / H < 4)) H /= 2;
+    p.H = H;
+    p.rpg /= H;
+    p.G *= H;
+    int gpw = H > 1 ? 1 : cdiv(min_rows, p.rpg);
     const int by_grid = (int)cdivl((long)tiles_total * p.G, (long)max_wg * p.nw);
     if (by_grid > gpw) gpw = by_grid;
     if (gpw > p.G) gpw = p.G;
@@ -727,6 +738,7 @@ int mpq_gemv_lut_launch(int nsets, const int32_t* const* qw, const void* const* 
     a.tiles_total = tiles;
     a.S = p.S;
     a.groups_per_wave = p.gpw;
+    a.hshift = p.H == 4 ? 2 : (p.H == 2 ? 1 : 0);
     const int grid = tiles * p.S;
     if (p.coop) lutc_launch(a, p.rpg, grid, M, zm, st);
     else if (p.nw == 4) lut_launch_nw<4>(a, p.rpg, grid, M, zm, st);

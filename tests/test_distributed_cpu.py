@@ -59,7 +59,19 @@ def _worker(rank, world, port, asym, out_dir):
     y = layer(x)
     full = _oracle_impl(x.reshape(-1, x.shape[-1]), qweight, scales, zeros, g_idx, w_bit, asym, gs, bias).view(2, 3, -1)
     ok = torch.equal(y, full)
-    torch.save({"ok": ok, "shape": tuple(y.shape)}, os.path.join(out_dir, f"r{rank}.pt"))
+    # the M-tiled (compute / exchange overlapped) schedule: 7 rows in tiles of 3 -> tiles of 3, 3, 1 rows
+    g = torch.Generator().manual_seed(11)
+    x7 = torch.randn((7, x.shape[-1]), generator=g).half()
+    full7 = _oracle_impl(x7, qweight, scales, zeros, g_idx, w_bit, asym, gs, bias)
+    y7 = layer.forward_overlapped(x7, m_tile=3)
+    ok_tiled = torch.equal(y7, full7) if len({hi - lo for lo, hi in layer.ranges}) == 1 else torch.equal(y7, full7)
+    rm = layer.forward_overlapped(x7, m_tile=3, interleave=False)
+    ok_rm = True
+    if rm.dim() == 3:  # rank-major [W, M, N/W]: block r is the column block of rank r
+        for r in range(world):
+            rlo, rhi = column_range(qweight.shape[1], r, world)
+            ok_rm = ok_rm and torch.equal(rm[r], full7[:, rlo:rhi])
+    torch.save({"ok": ok and ok_tiled and ok_rm, "shape": tuple(y.shape)}, os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 

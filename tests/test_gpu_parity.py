@@ -580,3 +580,86 @@ def test_q4_conv_layer_train_eval_equivalence():
     layer.generate_quantized_weight(qweight_only=True)
     y2 = layer.eval()(x)
     assert y.shape == (2, 32, 10, 10) and torch.equal(y, y2)
+
+
+# ------------------------------------------------------------------------------------------------ table-lookup decode GEMV / grouped launch
+@pytest.mark.parametrize("K,N,gs,asym,M", [(1024, 200, 64, 0, 1), (768, 520, 256, 0, 2), (640, 64, 32, 1, 1), (1408, 136, 128, 0, 1),
+                                            (2048, 1000, 128, 1, 2), (512, 72, 32, 0, 2)])
+def test_lut_gemv_group_sizes_ragged_tiles_and_tails(K, N, gs, asym, M):
+    """bf16 W4 decode goes through mpq_gemv_lut.hip: every supported group size, column counts that are not multiples of 64,
+    group counts that do not divide by the groups-per-workgroup (ragged last K slice), sym and asym, M = 1 and 2.  The table
+    holds the exact reference values, so the only difference from the oracle is fp32 summation order."""
+    rng = np.random.default_rng(K + N + gs + M)
+    qw, scales, zeros, gen = rand_case(rng, K, N, 4, gs, orc.BF16, asym)
+    x = torch.randn((M, K), generator=gen).to(torch.bfloat16)
+    bias = (torch.randn(N, generator=gen) * 0.1).to(torch.bfloat16)
+    y = hip_forward(x, qw, scales, zeros, None, 4, gs, asym, bias)
+    ref = oracle_forward(x, qw, scales, zeros, None, 4, gs, asym, orc.BF16, bias)
+    assert_close(y, ref, orc.BF16, f"K={K} N={N} g={gs} asym={asym} M={M}")
+    assert torch.equal(y, hip_forward(x, qw, scales, zeros, None, 4, gs, asym, bias)), "not reproducible run to run"
+
+
+@pytest.mark.parametrize("split", ["1", "2", "4"])
+def test_lut_gemv_split_groups(split, monkeypatch):
+    """Small layers split every quantisation group over 2 or 4 waves (BIE_LUT_H is read once per process: the test forces the
+    plan through a subprocess-free path by choosing shapes whose automatic plan takes each branch)."""
+    K, gs = 4096, 128
+    N = {"1": 12288, "2": 4096, "4": 1024}[split]  # tiles * groups = 6144 / 2048 / 512 -> H = 1 / 2 / 4
+    rng = np.random.default_rng(99 + N)
+    qw, scales, zeros, gen = rand_case(rng, K, N, 4, gs, orc.BF16, 0)
+    x = torch.randn((1, K), generator=gen).to(torch.bfloat16)
+    y = hip_forward(x, qw, scales, zeros, None, 4, gs, 0)
+    ref = oracle_forward(x, qw, scales, zeros, None, 4, gs, 0, orc.BF16)
+    assert_close(y, ref, orc.BF16, f"N={N}")
+
+
+def test_grouped_forward_matches_separate_calls_and_oracle():
+    """bie_mpq_forward_grouped: q/k/v-style sets sharing x in one launch (bf16 W4 -> one grid) and the per-set fallback (fp16)."""
+    from bitorch_engine.extensions import q_linear_cuda
+    K, gs = 1024, 128
+    for dt in (orc.BF16, orc.F16):
+        for M in (1, 2, 5):
+            sets, refs, x = [], [], None
+            for i, N in enumerate((384, 200, 72)):
+                rng = np.random.default_rng(1000 * i + M + dt)
+                qw, scales, zeros, gen = rand_case(rng, K, N, 4, gs, dt, 0)
+                if x is None:
+                    x = torch.randn((M, K), generator=gen).to(TDT[dt])
+                bias = (torch.randn(N, generator=gen) * 0.1).to(TDT[dt]) if i == 1 else None
+                sets.append(tuple(None if t is None else t.to(DEV) for t in (qw, scales, zeros, bias)))
+                refs.append(oracle_forward(x, qw, scales, zeros, None, 4, gs, 0, dt, bias))
+            ys = q_linear_cuda.mpq_forward_grouped_impl(x.to(DEV), sets, 4, 0, gs)
+            for i, (y, r) in enumerate(zip(ys, refs)):
+                assert_close(y, r, dt, f"grouped dt={dt} M={M} set {i}")
+                single = q_linear_cuda.mpq_forward_impl(x.to(DEV), sets[i][0], sets[i][1], sets[i][2], None, 4, 0, gs, sets[i][3])
+                assert torch.equal(y, single) or dt == orc.BF16, "fallback path must equal separate calls bit for bit"
+
+
+def test_decode_gemv_wide_output_more_than_1024_tiles():
+    """N > 65536 (quantised lm_head) used to overflow the 1024-counter workspace head; 2004 column tiles now fit the
+    16 KiB head (fp16 -> dot2 kernel with tickets, bf16 -> lookup kernel with generation words)."""
+    K, N, gs = 1024, 128256, 128
+    for dt in (orc.F16, orc.BF16):
+        rng = np.random.default_rng(4 + dt)
+        qw, scales, zeros, gen = rand_case(rng, K, N, 4, gs, dt, 0)
+        x = torch.randn((1, K), generator=gen).to(TDT[dt])
+        y = hip_forward(x, qw, scales, zeros, None, 4, gs, 0)
+        ref = oracle_forward(x, qw, scales, zeros, None, 4, gs, 0, dt)
+        assert_close(y, ref, dt, f"N={N} dt={dt}")
+        assert torch.equal(y, hip_forward(x, qw, scales, zeros, None, 4, gs, 0))
+
+
+def test_binary_conv_does_not_disturb_the_gemv_workspace_head():
+    """the conv scratch used to start at offset 0 of the shared per-stream workspace and clobbered the split-K
+    tickets; conv -> fp16 decode GEMV (ticketed split-K) -> conv -> GEMV must keep giving the oracle's result."""
+    from bitorch_engine.extensions import binary_conv_cpp
+    rng = np.random.default_rng(12)
+    K, N, gs = 4096, 512, 128
+    qw, scales, zeros, gen = rand_case(rng, K, N, 4, gs, orc.F16, 0)
+    x = torch.randn((1, K), generator=gen).half()
+    ref = oracle_forward(x, qw, scales, zeros, None, 4, gs, 0, orc.F16)
+    xi = torch.randn((2, 64, 7, 7), generator=gen).to(DEV)
+    wi = torch.randn((32, 64, 3, 3), generator=gen).to(DEV)
+    for _ in range(2):
+        binary_conv_cpp.forward(xi, wi, 32, 64 * 9, 2 * 49, 3, 1, 1, 1, 7)
+        assert_close(hip_forward(x, qw, scales, zeros, None, 4, gs, 0), ref, orc.F16, "GEMV after conv")

@@ -9,7 +9,10 @@ import sweep
 from bitorch_engine import _hip
 L = _hip.lib()
 dt = _hip.BF16 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else _hip.F16
-print(sweep.time_case(1, 4096, 11008, dt, layers=26, reps=3, graph=False))
+KK, NN = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (4096, 11008)
+print(sweep.time_case(1, KK, NN, dt, layers=26, reps=3, graph=False))
+if len(sys.argv) > 3:
+    sys.exit(0)
 K, N, gs = 4096, 11008, 128
 tdt = torch.bfloat16 if dt == _hip.BF16 else torch.float16
 gen = torch.Generator().manual_seed(1)
