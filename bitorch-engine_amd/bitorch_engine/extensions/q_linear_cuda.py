@@ -52,6 +52,13 @@ def mpq_forward_impl(x, qweight, scales, zeros, g_idx, w_bit, asym, group_size, 
     if trivial_gidx is None:
         trivial_gidx = gidx_is_trivial(g_idx, group_size)
     gptr = None if trivial_gidx else g_idx.to(torch.int32).contiguous()
+    if gptr is not None and M > 32:
+        # act-order checkpoints (explicit g_idx): the fused kernels need whole groups per packed row; for prefill the dense
+        # weight is materialised once by the HIP dequant kernel and the plain GEMM goes to the vendor library -- the split the
+        # reference makes for every M > 32 (layers/qlinear/nbit/cuda/mpq_layer.py:59-62)
+        W = mpq_dequant(qweight, scales, zeros, gptr, w_bit, asym, group_size)
+        y = torch.matmul(x, W.to(x.dtype))
+        return y if bias is None else y + bias
     y = torch.empty((M, N), dtype=x.dtype, device=x.device)
     if M == 0:
         return y

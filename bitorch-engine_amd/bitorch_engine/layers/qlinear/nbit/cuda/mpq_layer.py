@@ -93,11 +93,9 @@ class MPQLinearCuda(MPQLinearBase):
             out = MPQLinearCudaFunction.apply(x, self.qweight, self.a_bit, self.w_bit, self.scales, self.zeros,
                                               self.g_idx, self.asym, self.training, self.privileged_grad)
             return out if self.disable_bias else out + self.bias
-        # inference fast path: bias fused into the kernel epilogue, g_idx triviality checked once
-        if self._gidx_trivial is None:
-            self._gidx_trivial = q_linear_cuda.gidx_is_trivial(self.g_idx, self.group_size)
+        # inference fast path: bias fused into the kernel epilogue; whether g_idx is the trivial k // group_size is
+        # remembered on the g_idx tensor itself (keyed by its version), so load_state_dict / in-place edits invalidate it
         x2, lead = flatten_x(x)
         out = q_linear_cuda.mpq_forward_impl(x2, self.qweight.data, self.scales, self.zeros, self.g_idx, self.w_bit,
-                                             self.asym, self.group_size, None if self.disable_bias else self.bias,
-                                             self._gidx_trivial)
+                                             self.asym, self.group_size, None if self.disable_bias else self.bias)
         return unflatten_x(out, lead)

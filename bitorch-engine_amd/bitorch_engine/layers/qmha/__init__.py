@@ -1,0 +1,1 @@
+from .binary import *  # noqa: F401,F403

@@ -1,8 +1,35 @@
-"""Quantisation helpers mirroring reference utils/quant_operators.py: get_binary_row / get_binary_col
+"""Quantisation helpers mirroring reference utils/quant_operators.py: nv_tensor_quant (:7-90), get_binary_row / get_binary_col
 (python reference bit packers :118-231), gptq_style_zeros_packing (:348-368), q4_quantization (:272-307)."""
 import math
 
 import torch
+
+
+def nv_tensor_quant(inputs, amax=None, num_bits=8, unsigned=False, narrow_range=True):
+    """Max-scaled integer quantisation, (quantised tensor, scale) -- reference utils/quant_operators.py:7-90 (itself after
+    NVIDIA pytorch-quantization's tensor_quant).  amax defaults to torch.amax(inputs) -- the SIGNED maximum, as the reference
+    has it; fp16/bf16 inputs are processed in fp32 and returned in their dtype; amax <= 2^-24 quantises to 0 with scale 1."""
+    if isinstance(amax, torch.Tensor) and inputs.dim() != amax.dim():
+        raise ValueError(f"amax {tuple(amax.size())} has different shape than inputs {tuple(inputs.size())}. "
+                         "Make sure broadcast works as expected!")
+    if amax is None:
+        amax = torch.amax(inputs, keepdim=True)
+    if unsigned and inputs.min() < 0.0:
+        raise TypeError("Negative values encountered in unsigned quantization.")
+    in_dtype = inputs.dtype
+    half_in = in_dtype in (torch.float16, torch.bfloat16)
+    x = inputs.float() if half_in else inputs
+    amax = amax.float() if amax.dtype in (torch.float16, torch.bfloat16) else amax
+    smallest = amax.min()
+    if smallest < 0:
+        raise ValueError("Negative values in amax")
+    hi = torch.tensor(2.0 ** (num_bits - 1 + int(unsigned)) - 1.0, device=x.device)
+    lo = 0 if unsigned else (-hi if narrow_range else -hi - 1)
+    scale = hi / amax
+    q = torch.clamp((x * scale).round_(), lo, hi)
+    if smallest <= 2.0 ** -24:
+        scale[amax <= 2.0 ** -24] = 1.0
+    return (q.to(in_dtype) if half_in else q), scale
 
 
 def get_binary_row(nd_row, binary_row, nd_size, bits_per_binary_word):

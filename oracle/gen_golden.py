@@ -279,6 +279,44 @@ def main():
     qq["tie"] = tonp((r - r.floor()) == 0.5)
     np.savez_compressed(os.path.join(OUT, "q4_q8_quantization.npz"), **qq)
 
+    # ------------------------------------------------------------------ 6. helpers either side of the path (python reference)
+    # utils/quant_operators.py:7-90 (nv_tensor_quant), utils/model_helper.py:54-155,286-327, utils/convert.py:94-119,
+    # layers/qembedding/binary/layer.py:343-556 (BinaryEmbeddingBag: pure torch, CPU-runnable).  A separate generator keeps the
+    # earlier sections' random streams untouched.
+    from bitorch_engine.utils.quant_operators import nv_tensor_quant
+    from bitorch_engine.utils import model_helper as mh
+    from bitorch_engine.utils.convert import get_mpq_config
+    g6 = torch.Generator().manual_seed(606)
+    hp = {}
+    xq = torch.randn((6, 16), generator=g6) * 2.5
+    for tag, kw in (("default", {}), ("bits4", {"num_bits": 4}), ("wide", {"narrow_range": False}),
+                    ("amax_rows", {"amax": xq.abs().amax(dim=1, keepdim=True)})):
+        q, sc = nv_tensor_quant(xq.clone(), **kw)
+        hp[f"nvq_{tag}_q"], hp[f"nvq_{tag}_scale"] = tonp(q), tonp(sc)
+    qh, sh = nv_tensor_quant(xq.to(torch.bfloat16))
+    hp["nvq_x"], hp["nvq_bf16_q"], hp["nvq_bf16_scale"] = tonp(xq), u16(qh), tonp(sh)
+    qu, su = nv_tensor_quant(xq.abs(), unsigned=True)
+    hp["nvq_unsigned_q"], hp["nvq_unsigned_scale"] = tonp(qu), tonp(su)
+    wi = torch.randn((8, 16), generator=g6)
+    wq, ws = mh.init_weight(wi.clone(), cls=lambda t_: torch.nn.Parameter(t_, requires_grad=False))  # stock torch: no grad on int8
+    hp["iw_w"], hp["iw_q"], hp["iw_scale"] = tonp(wi), tonp(wq.data), tonp(ws)
+    t = torch.randn((2, 5, 130), generator=g6)
+    tp, added = mh.pad_last_2_dims_to_multiple_of_128(t)
+    hp["pad_in"], hp["pad_out"], hp["pad_added"] = tonp(t), tonp(tp), np.array([added])
+    pop = torch.randint(0, 64, (6, 8, 12), generator=g6)
+    hp["post_in"] = tonp(pop)
+    hp["post_out"] = tonp(mh.binary_matmul_forward_post_processing(pop.clone(), [2, 3], 3, 4, 64))
+    we = torch.randn((5, 13), generator=g6)
+    hp["emb_in"], hp["emb_padded"] = tonp(we), tonp(mh.pad_embedding_dim(we))
+    from bitorch_engine.layers.qembedding.binary.layer import BinaryEmbeddingBagForward
+    table = torch.rand((20, 24), generator=g6) > 0.5
+    idx = torch.randint(0, 20, (4, 5), generator=g6)
+    hp["bag_table"], hp["bag_idx"] = tonp(table), tonp(idx)
+    hp["bag_out"] = tonp(BinaryEmbeddingBagForward.apply(idx, table, False))
+    np.savez_compressed(os.path.join(OUT, "helpers.npz"), **hp)
+    manifest["mpq_configs"] = {k: get_mpq_config(k) for k in (None, "2-8-32", "2-32-32", "2-128-32", "4-128-256", "8-128-256")}
+    manifest["mpq_configs"] = {str(k): v for k, v in manifest["mpq_configs"].items()}
+
     with open(os.path.join(OUT, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))

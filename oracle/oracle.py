@@ -112,6 +112,14 @@ def gemm(x, W, dt, bias=None):
     return y
 
 
+def mpq_grad_input(gy, qweight, scales, zeros, g_idx, w_bit, group_size, asym, dt):
+    """grad_x[M, K] = grad_y[M, N] . W^T with W the dequantised weight -- the spec line of the reference's backward
+    (layers/qlinear/nbit/cuda/mpq_layer.py:107-111: "grad_input = output_gradient.mm(weight)"; the CUDA kernel itself,
+    back_quant_mm_kernel mpq_linear_cuda_kernel.cu:635-1049, is not runnable here).  fp32 accumulation, one rounding."""
+    W = mpq_dequant(qweight, scales, zeros, g_idx, w_bit, group_size, asym, dt)
+    return gemm(gy, np.ascontiguousarray(W.T), dt)
+
+
 def mpq_forward(x, qweight, scales, zeros, g_idx, w_bit, group_size, asym, dt):
     """Fused dequant+GEMM with float accumulation (the timed CPU baseline)."""
     x, qweight = _c(x), _c(qweight, np.int32)

@@ -387,9 +387,19 @@ def test_binary_layers_api():
         layer.set_weight_data(w.clone())
         layer.eval().to(DEV)
         y = layer(x.to(DEV)).cpu()
+        # exact expectation: the integers come from the oracle's XNOR-popcount on the layer's own int8 sign carriers, the
+        # scaling is the layer's fp32 expression evaluated in the same order
+        ints = orc.binary_linear_rowpacked(orc.binary_pack_rows(x.numpy()), orc.binary_pack_rows(layer.weight.data.float().cpu().numpy()), K)
+        ints = torch.from_numpy(ints.astype(np.float32))
+        sa, sw = layer.scale_a.detach().cpu(), layer.scale_w.detach().cpu()
+        assert torch.equal(sa, (2 * x.abs().mean()).to(sa.dtype))
+        if cls is BinaryLinearCuda:
+            expect = ints * sa * sw
+        else:
+            expect = ints * torch.tensor(sa.item() * sw.item(), dtype=torch.float32)
+        assert torch.equal(y, expect), f"{cls.__name__}: layer output differs from oracle integers x scales"
         wc = w - w.mean()
-        expect = (sign(x) @ sign(wc).t()) * (2 * x.abs().mean()) * w.abs().mean()
-        assert torch.allclose(y, expect, rtol=1e-5, atol=1e-4)
+        assert torch.equal(layer.weight.data.cpu() >= 0, wc >= 0)
 
 
 def test_binary_conv_vs_reference_cpp_golden_and_resnet_shape():
@@ -663,3 +673,205 @@ def test_binary_conv_does_not_disturb_the_gemv_workspace_head():
     for _ in range(2):
         binary_conv_cpp.forward(xi, wi, 32, 64 * 9, 2 * 49, 3, 1, 1, 1, 7)
         assert_close(hip_forward(x, qw, scales, zeros, None, 4, gs, 0), ref, orc.F16, "GEMV after conv")
+
+
+# ------------------------------------------------------------------------------------------------ backward (A8) / act-order
+@pytest.mark.parametrize("dt", [orc.F16, orc.BF16])
+@pytest.mark.parametrize("w_bit,asym,actorder", [(4, 0, False), (4, 1, False), (2, 0, True), (8, 0, False), (4, 0, True)])
+def test_mpq_grad_input_vs_oracle(dt, w_bit, asym, actorder):
+    """A8: grad_x = grad_y . W^T (bie_mpq_grad_input) against the oracle (dequantised weight, fp32 accumulate)."""
+    from bitorch_engine.extensions import q_linear_cuda
+    rng = np.random.default_rng(31 * w_bit + asym + 5 * dt + actorder)
+    M, K, N, gs = 9, 256, 320, 64
+    qw, scales, zeros, gen = rand_case(rng, K, N, w_bit, gs, dt, asym)
+    g_idx = torch.arange(K, dtype=torch.int32) // gs
+    if actorder:
+        g_idx = g_idx[torch.randperm(K, generator=gen)]
+    gy = torch.randn((M, N), generator=gen).to(TDT[dt])
+    gx = q_linear_cuda.mpq_grad_input(qw.to(DEV), scales.to(DEV), zeros.to(DEV), g_idx.to(DEV), gy.to(DEV), 16, w_bit, bool(asym))
+    ref = orc.mpq_grad_input(orc.torch_to_np(gy), qw.numpy(), orc.torch_to_np(scales), orc.torch_to_np(zeros) if not asym else zeros.numpy(),
+                             g_idx.numpy(), w_bit, gs, asym, dt)
+    assert_close(gx, t16(ref, dt), dt, f"grad_input w{w_bit} asym={asym} actorder={actorder}")
+
+
+def test_mpq_layer_backward_through_autograd():
+    """MPQLinearCudaFunction.backward: grad wrt the input equals grad_y . W^T, privileged_grad = x^T . grad_y
+    (reference layers/qlinear/nbit/cuda/mpq_layer.py:98-117)."""
+    from bitorch_engine.layers.qlinear.nbit.cuda import MPQLinearCuda
+    K, N, gs = 256, 128, 64
+    layer = MPQLinearCuda(K, N, w_bit=4, dtype=torch.half, group_size=gs, dq_group_size=32, use_gba_quant=True, asym=False)
+    g = torch.Generator().manual_seed(3)
+    layer.qweight.data = torch.randint(-2 ** 31, 2 ** 31 - 1, layer.qweight.shape, generator=g, dtype=torch.int64).to(torch.int32)
+    layer.prepare_params()
+    layer.scales = (torch.rand(layer.scales.shape, generator=g) * 0.01 + 0.005).half()
+    layer.zeros = (layer.scales.float() * torch.rand(layer.scales.shape, generator=g) * 15).half()
+    layer.to(DEV).train()
+    x = torch.randn((2, 3, K), generator=g).half().to(DEV).requires_grad_(True)
+    y = layer(x)
+    gy = torch.randn(y.shape, generator=g).half().to(DEV)
+    y.backward(gy)
+    W = orc.mpq_dequant(layer.qweight.data.cpu().numpy(), orc.torch_to_np(layer.scales), orc.torch_to_np(layer.zeros), None, 4, gs, 0, orc.F16)
+    ref = orc.gemm(orc.torch_to_np(gy.reshape(-1, N)), np.ascontiguousarray(W.T), orc.F16)
+    assert_close(x.grad.reshape(-1, K), t16(ref, orc.F16), orc.F16, "autograd grad_input")
+    pg = layer.qweight.privileged_grad
+    if pg is not None:
+        assert tuple(pg.shape) == (K, N)
+
+
+@pytest.mark.parametrize("dt", [orc.F16, orc.BF16])
+@pytest.mark.parametrize("M", [1, 7, 40, 300])
+def test_act_order_gidx_forward(dt, M):
+    """Explicit (randomly permuted) g_idx: M <= 32 through the generic kernel, M > 32 through HIP dequant + library GEMM."""
+    rng = np.random.default_rng(17 + M + dt)
+    K, N, gs = 512, 384, 64
+    qw, scales, zeros, gen = rand_case(rng, K, N, 4, gs, dt, 0)
+    g_idx = (torch.arange(K, dtype=torch.int32) // gs)[torch.randperm(K, generator=gen)]
+    x = torch.randn((M, K), generator=gen).to(TDT[dt])
+    y = hip_forward(x, qw, scales, zeros, g_idx, 4, gs, 0)
+    ref = oracle_forward(x, qw, scales, zeros, g_idx, 4, gs, 0, dt)
+    assert_close(y, ref, dt, f"act-order M={M} dt={dt}")
+
+
+# ------------------------------------------------------------------------------------------------ full-size cases of BASELINE configs
+def _sampled_rows_check(K, N, M, w_bit, gs, dt, seed, what):
+    rng = np.random.default_rng(seed)
+    qw, scales, zeros, gen = rand_case(rng, K, N, w_bit, gs, dt, 0)
+    x = torch.randn((M, K), generator=gen).to(TDT[dt])
+    y = hip_forward(x, qw, scales, zeros, None, w_bit, gs, 0)
+    rows = torch.tensor(sorted({0, 1, 31, 32, 255, M // 2, M - 2, M - 1}))
+    ref = t16(orc.mpq_forward(orc.torch_to_np(x[rows]), qw.numpy(), orc.torch_to_np(scales), orc.torch_to_np(zeros), None, w_bit, gs, 0, dt), dt)
+    assert_close(y[rows.to(DEV)], ref, dt, what + " sampled rows vs oracle")
+    lo = M // 4
+    y2 = hip_forward(x[lo:lo + 128], qw, scales, zeros, None, w_bit, gs, 0)  # another M tiling / split-K plan
+    assert_close(y2, y[lo:lo + 128], dt, what + " row independence")
+    y1 = hip_forward(x[5:6], qw, scales, zeros, None, w_bit, gs, 0)          # the decode kernel on one of the rows
+    assert_close(y1, y[5:6], dt, what + " decode kernel vs prefill kernel")
+    assert torch.isfinite(y.float()).all()
+
+
+def test_full_size_metric_layer_4096x4096_prefill():
+    """BASELINE.json's metric layer at M = 4096 (bf16)."""
+    _sampled_rows_check(4096, 4096, 4096, 4, 128, orc.BF16, 501, "4096x4096 M=4096")
+
+
+def test_full_size_c5_shard_8192x3584_prefill():
+    """configs[4]: the per-GPU column shard of the 8192x28672 layer (N / 8 = 3584 columns), M = 4096, bf16."""
+    _sampled_rows_check(8192, 3584, 4096, 4, 128, orc.BF16, 502, "C5 shard 8192x3584 M=4096")
+
+
+@pytest.mark.parametrize("K,N", [(4096, 11008), (11008, 4096)])
+def test_full_size_uniform_w2a16_llama_shapes(K, N):
+    """configs[2]: uniform W2A16 at the Llama-7B shapes, decode (M = 1, 2) and a prefill sample (fp16)."""
+    dt = orc.F16
+    rng = np.random.default_rng(K + 7 * N)
+    qw, scales, zeros, gen = rand_case(rng, K, N, 2, 128, dt, 0)
+    for M in (1, 2):
+        x = torch.randn((M, K), generator=gen).to(TDT[dt])
+        y = hip_forward(x, qw, scales, zeros, None, 2, 128, 0)
+        ref = t16(orc.mpq_forward(orc.torch_to_np(x), qw.numpy(), orc.torch_to_np(scales), orc.torch_to_np(zeros), None, 2, 128, 0, dt), dt)
+        assert_close(y, ref, dt, f"W2A16 {K}x{N} M={M}")
+    x = torch.randn((512, K), generator=gen).to(TDT[dt])
+    y = hip_forward(x, qw, scales, zeros, None, 2, 128, 0)
+    rows = torch.tensor([0, 1, 100, 511])
+    ref = t16(orc.mpq_forward(orc.torch_to_np(x[rows]), qw.numpy(), orc.torch_to_np(scales), orc.torch_to_np(zeros), None, 2, 128, 0, dt), dt)
+    assert_close(y[rows.to(DEV)], ref, dt, f"W2A16 {K}x{N} M=512 sampled rows")
+
+
+@pytest.mark.parametrize("K,N", [(4096, 11008), (11008, 4096)])
+def test_full_size_exl2_w3w2_random_perm(K, N):
+    """configs[2]: exl2 mixed 3/2-bit at the Llama-7B shapes with a RANDOM q_perm: dequant bit-exact vs the oracle on a column
+    slice, decode (M = 1, 2) and a small prefill against oracle GEMMs."""
+    from bitorch_engine.extensions import q_linear_cuda
+    from bitorch_engine.layers.qlinear.nbit.cuda.utils import make_group_map
+    qg, row = [], 0
+    for b in (3, 2):
+        for _ in range(K // 2 // 32):
+            qg += [b, row]
+            row += b
+    groups = len(qg) // 2
+    q_groups = torch.tensor(qg, dtype=torch.short)
+    gen = torch.Generator().manual_seed(K + N)
+    rng = np.random.default_rng(K + N)
+    qw = torch.from_numpy(rng.integers(-2 ** 31, 2 ** 31 - 1, (row, N), dtype=np.int64).astype(np.int32))
+    scales = (torch.rand((groups, N), generator=gen) * 0.02 + 0.001).half()
+    zeros = (torch.randn((groups, N), generator=gen) * 0.05).half()
+    q_perm = torch.randperm(K, generator=gen).to(torch.short)
+    gmap = make_group_map(q_groups, row)
+    _, rows = q_linear_cuda.mbwq_trans_qweight(qw, q_groups, True, K, groups, 4)
+    d = lambda t: t.to(DEV)
+    Wd = q_linear_cuda.mbwq_exl2fp_weight(d(qw), d(scales), d(zeros), d(q_perm), d(gmap), rows)
+    Wo = orc.exl2_dequant(qw.numpy(), orc.torch_to_np(scales), orc.torch_to_np(zeros), q_perm.numpy(), q_groups.numpy(), K)
+    assert np.array_equal(orc.torch_to_np(Wd), Wo), "exl2 dequant at full size not bit-exact"
+    for M in (1, 2, 48):
+        x = torch.randn((M, K), generator=gen).half()
+        y = q_linear_cuda.mbwq_exl2_forward(d(x), d(qw), d(scales), d(zeros), d(q_perm), d(gmap), rows, False)
+        ref = t16(orc.gemm(orc.torch_to_np(x), Wo, orc.F16), orc.F16)
+        assert_close(y, ref, orc.F16, f"exl2 w3/w2 {K}x{N} M={M}")
+
+
+# ------------------------------------------------------------------------------------------------ section 8f: embedding, BMHA, checkpoints
+def test_binary_embedding_forward_and_backward():
+    """BinaryEmbeddingCuda: pack (HIP sign-pack kernel) + gather + HIP unpack-and-scale == sign(centred row) * mean|row|, exactly."""
+    from bitorch_engine.layers.qembedding.binary import BinaryEmbeddingCuda
+    torch.manual_seed(5)
+    V, D = 50, 37  # D is not a multiple of 8: padded with -1 columns, truncated again on the way out
+    emb = BinaryEmbeddingCuda(num_embeddings=V, embedding_dim=D, padding_idx=3)
+    w = emb.weight.data.clone()
+    emb.to(DEV)
+    emb.eval()
+    emb.prepare_params()
+    assert not hasattr(emb, "weight") and emb.qweight.dtype == torch.uint8 and tuple(emb.qweight.shape) == (V, 5)
+    centred = w - w.mean()
+    centred[3] = 0
+    padded = torch.cat([centred, -torch.ones(V, 3)], dim=1)
+    assert np.array_equal(emb.qweight.data.cpu().numpy(), orc.binary_pack_rows(padded.numpy()))
+    scale = padded.norm(1, 1, keepdim=True) / 40
+    assert torch.allclose(emb.scale_w.cpu(), scale, rtol=1e-6, atol=0)
+    idx = torch.tensor([[0, 3, 7, 49], [5, 5, 1, 2]])
+    out = emb(idx.to(DEV)).cpu()
+    sign = torch.where(padded >= 0, 1.0, -1.0)[:, :D]
+    assert out.shape == (2, 4, D) and torch.equal(out, sign[idx] * emb.scale_w.cpu()[idx])
+
+
+def test_bmha_runs_on_the_xnor_kernels():
+    from bitorch_engine.layers.qmha.binary import BMHA
+    torch.manual_seed(2)
+    m = BMHA(128, 128, 4)
+    for lin in (m.q_linear, m.k_linear, m.v_linear, m.out):
+        lin.set_weight_data(torch.randn(lin.weight.shape))
+    m.eval().to(DEV)
+    x = torch.randn(2, 9, 128, device=DEV)
+    out, scores = m(x)
+    assert out.shape == (2, 9, 128) and scores.shape == (2, 4, 9, 9)
+    assert torch.isfinite(out).all() and torch.allclose(scores.sum(-1), torch.ones_like(scores.sum(-1)), atol=1e-5)
+    q = m.q_linear(x)  # one projection against the closed form: (sign(x) . sign(wc)^T) * scale_a * scale_w
+    ints = orc.binary_linear_rowpacked(orc.binary_pack_rows(x.reshape(-1, 128).cpu().numpy()),
+                                       orc.binary_pack_rows(m.q_linear.weight.data.float().cpu().numpy()), 128)
+    scale = m.q_linear.scale_a.item() * m.q_linear.scale_w.item()
+    assert torch.equal(q.reshape(-1, 128).cpu(), torch.from_numpy(ints.astype(np.float32)) * torch.tensor(scale, dtype=torch.float32))
+
+
+def test_save_and_load_checkpoint_roundtrip(tmp_path):
+    """pack_bie_layers / save_checkpoint / load_checkpoint (reference utils/model_helper.py:199-283): a model with a binary
+    linear layer is packed + saved, a fresh model loads the packed weights and reproduces the outputs."""
+    from bitorch_engine.layers.qlinear.binary.cuda import BinaryLinearCuda
+    from bitorch_engine.utils.model_helper import save_checkpoint, load_checkpoint
+
+    def build():
+        net = torch.nn.Sequential()
+        net.add_module("fc", BinaryLinearCuda(256, 64))
+        return net
+    torch.manual_seed(0)
+    net = build()
+    net.fc.set_weight_data(torch.randn(64, 256))
+    net.eval().to(DEV)
+    x = torch.randn(5, 256, device=DEV)
+    y0 = net(x)
+    path = str(tmp_path / "ckpt.pth")
+    save_checkpoint(net, path, qweight_only=True)
+    sd = torch.load(path)["state_dict"]
+    assert "fc.qweight" in sd and sd["fc.qweight"].dtype == torch.uint8 and sd["fc.qweight"].numel() == 64 * 256 // 8
+    net2 = build().eval().to(DEV)
+    load_checkpoint(net2, path, qweight_only=True)
+    net2.to(DEV)
+    assert torch.equal(net2(x), y0)

@@ -87,7 +87,82 @@ def test_helpers():
     w = torch.randn(8, 16)
     q, s = init_weight(w)
     assert q.dtype == torch.int8 and torch.equal(q >= 0, (w - w.mean()) >= 0) and torch.isclose(s, w.abs().mean())
-    assert pad_last_2_dims_to_multiple_of_128(torch.ones(2, 5, 130)).shape == (2, 128, 256)
+    padded, added = pad_last_2_dims_to_multiple_of_128(torch.ones(2, 5, 130))
+    assert padded.shape == (2, 128, 256) and added == 123
+
+
+def test_helpers_match_the_reference_vectors(golden_dir):
+    """tests/golden/helpers.npz = outputs of the imported Python reference (oracle/gen_golden.py section 6): nv_tensor_quant,
+    init_weight (signed amax!), the two padding helpers, the BMHA post-processing, the embedding-bag majority vote and the
+    named MPQ configurations."""
+    import json
+    import numpy as np
+    from bitorch_engine.utils.quant_operators import nv_tensor_quant
+    from bitorch_engine.utils import model_helper as mh
+    from bitorch_engine.utils.convert import get_mpq_config
+    from bitorch_engine.layers.qembedding.binary.layer import BinaryEmbeddingBagForward
+    from oracle import oracle as orc
+    d = np.load(os.path.join(golden_dir, "helpers.npz"))
+    x = torch.from_numpy(d["nvq_x"])
+    for tag, kw in (("default", {}), ("bits4", {"num_bits": 4}), ("wide", {"narrow_range": False}),
+                    ("amax_rows", {"amax": x.abs().amax(dim=1, keepdim=True)})):
+        q, sc = nv_tensor_quant(x.clone(), **kw)
+        assert np.array_equal(q.numpy(), d[f"nvq_{tag}_q"]) and np.array_equal(sc.numpy(), d[f"nvq_{tag}_scale"]), tag
+    qh, sh = nv_tensor_quant(x.to(torch.bfloat16))
+    assert qh.dtype == torch.bfloat16 and np.array_equal(orc.torch_to_np(qh), d["nvq_bf16_q"]) and np.array_equal(sh.numpy(), d["nvq_bf16_scale"])
+    qu, su = nv_tensor_quant(x.abs(), unsigned=True)
+    assert np.array_equal(qu.numpy(), d["nvq_unsigned_q"]) and np.array_equal(su.numpy(), d["nvq_unsigned_scale"])
+    with pytest.raises(TypeError):
+        nv_tensor_quant(x, unsigned=True)
+    wq, ws = mh.init_weight(torch.from_numpy(d["iw_w"]))
+    assert wq.dtype == torch.int8 and np.array_equal(wq.data.numpy(), d["iw_q"]) and np.array_equal(ws.numpy(), d["iw_scale"])
+    tp, added = mh.pad_last_2_dims_to_multiple_of_128(torch.from_numpy(d["pad_in"]))
+    assert np.array_equal(tp.numpy(), d["pad_out"]) and added == int(d["pad_added"][0])
+    post = mh.binary_matmul_forward_post_processing(torch.from_numpy(d["post_in"]), [2, 3], 3, 4, 64)
+    assert np.array_equal(post.numpy(), d["post_out"])
+    assert np.array_equal(mh.pad_embedding_dim(torch.from_numpy(d["emb_in"])).numpy(), d["emb_padded"])
+    bag = BinaryEmbeddingBagForward.apply(torch.from_numpy(d["bag_idx"]), torch.from_numpy(d["bag_table"]), False)
+    assert np.array_equal(bag.numpy(), d["bag_out"])
+    ref_cfg = json.load(open(os.path.join(golden_dir, "MANIFEST.json")))["mpq_configs"]
+    for key, cfg in ref_cfg.items():
+        assert get_mpq_config(None if key == "None" else key) == cfg
+    with pytest.raises(AssertionError):
+        get_mpq_config("3-3-3")
+
+
+def test_convert_collect_and_replace_layers():
+    from bitorch_engine.utils.convert import collect_layers, replace_layers, quantize_linear_with_mpq_linear_cuda
+    from bitorch_engine.layers.qlinear.nbit.cuda import MPQLinearCuda
+    net = torch.nn.Sequential()
+    net.add_module("a", torch.nn.Linear(64, 32))
+    blk = torch.nn.Module()
+    blk.fc = torch.nn.Linear(32, 64)
+    blk.act = torch.nn.ReLU()
+    net.add_module("blk", blk)
+    found = collect_layers(net)
+    assert sorted(found) == ["a", "blk.fc"]
+    new = quantize_linear_with_mpq_linear_cuda(net, ["blk.fc"], "4-128-256", dtype=torch.half)
+    assert len(new) == 1 and isinstance(net.blk.fc, MPQLinearCuda) and isinstance(net.a, torch.nn.Linear)
+    assert (net.blk.fc.in_channels, net.blk.fc.out_channels, net.blk.fc.w_bit, net.blk.fc.group_size) == (32, 64, 4, 128)
+    with pytest.raises(AssertionError):
+        replace_layers(net, ["a"], MPQLinearCuda, lambda old: torch.nn.Identity())
+
+
+def test_embedding_and_bmha_module_contract():
+    from bitorch_engine.layers.qembedding.binary import BinaryEmbeddingCuda, BinaryEmbeddingBag, BinaryEmbeddingParameter
+    from bitorch_engine.layers.qmha.binary import BMHA
+    from bitorch_engine.layers.qlinear.binary.cutlass import BinaryLinearCutlass
+    e = BinaryEmbeddingCuda(num_embeddings=10, embedding_dim=13, padding_idx=-1)
+    assert e.padding_idx == 9 and tuple(e.qweight.shape) == (10, 2) and e.qweight.dtype == torch.uint8 and tuple(e.scale_w.shape) == (10, 1)
+    assert isinstance(e.qweight, BinaryEmbeddingParameter) and sorted(e.state_dict()) == ["qweight", "scale_w", "weight"]
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        e.prepare_params()
+    b = BinaryEmbeddingBag(num_embeddings=10, embedding_dim=16, padding_idx=0)
+    assert not bool(b.weight[0].any()) and b(torch.tensor([[1, 2, 3], [4, 5, 6]])).shape == (2, 16)
+    m = BMHA(64, 64, 4)
+    assert all(isinstance(l, BinaryLinearCutlass) for l in (m.q_linear, m.k_linear, m.v_linear, m.out)) and m.head_dim == 16
+    with pytest.raises(ValueError):
+        BMHA(64, 30, 4)
 
 
 def test_no_cpu_fallback():
