@@ -74,10 +74,13 @@ template <> struct dt_traits<BIE_F32> {
     static constexpr int bytes = 4;
 };
 
-// Every workspace starts with a head of split-K arrival counters (one 32-bit ticket per 64-column output tile; zero on first
-// use, returned to zero by the last arriver); every scratch user starts behind it.
+// Every workspace starts with a 16 KiB head (zero on first use); every scratch user starts behind it.  Two protocols live in it
+// and must not share words: the first half holds split-K ARRIVAL TICKETS (one per 64-column output tile, returned to zero
+// by the last arriver: mpq_gemv.hip), the second half the tiles' GENERATION words of the tagged-granule reduction
+// (monotonic, never reset: mpq_gemv_lut.hip).
 constexpr size_t BIE_WS_HEAD_BYTES = 16384;
-constexpr int BIE_WS_COUNTERS = (int)(BIE_WS_HEAD_BYTES / 4);  // 4096 tiles = 262144 output columns per launch
+constexpr int BIE_WS_COUNTERS = (int)(BIE_WS_HEAD_BYTES / 8);  // 2048 tiles = 131072 output columns per launch, each protocol
+constexpr int BIE_WS_GEN_OFFSET = BIE_WS_COUNTERS;             // in 32-bit words from the start of the workspace
 
 // shared split-K epilogue (splitk.hip): y[m][n] = dt( sum_s part[s][m][n] ) (+ bias[n])
 int launch_splitk_finalize(const float* part, const void* bias, void* y, int S, int M, int N, int dtype,

@@ -182,7 +182,7 @@ int bie_mpq_forward_grouped(const void* x, int n_sets, const int32_t* const* qwe
     const int tiles = grouped_tiles(n_sets, N);
     if (tiles <= BIE_WS_COUNTERS && mpq_gemv_lut_ok(M, K, w_bit, group_size, dtype, false)) {
         float* head = reinterpret_cast<float*>(workspace);
-        return mpq_gemv_lut_launch(n_sets, qweight, scales, zeros, bias, y, N, x, reinterpret_cast<unsigned*>(head),
+        return mpq_gemv_lut_launch(n_sets, qweight, scales, zeros, bias, y, N, x, reinterpret_cast<unsigned*>(head) + BIE_WS_GEN_OFFSET,
                                    head + WS_HEAD / sizeof(float), M, K, group_size, asym ? 1 : 0, as_stream(stream));
     }
     for (int i = 0; i < n_sets; i++) {  // every other case: one launch per set (same results)

@@ -432,7 +432,7 @@ int mbwq_q4_forward_launch(const void* x, const int32_t* qw, const void* scales,
     if (M <= 8 && (M <= 2 || !gemm_ok) && mpq_gemv_fast_ok(M, K, N, bits, group_size, BIE_F16, false))
         return mpq_gemv_launch(x, qw, scales, zeros, nullptr, y, part, M, K, N, bits, group_size, 2, BIE_F16, p, st);
     if (gemm_ok)
-        return mpq_gemm_launch(x, qw, scales, zeros, nullptr, y, part + BIE_WS_COUNTERS, M, K, N, bits, group_size, 2, BIE_F16, p, st);
+        return mpq_gemm_launch(x, qw, scales, zeros, nullptr, y, part + BIE_WS_HEAD_BYTES / sizeof(float), M, K, N, bits, group_size, 2, BIE_F16, p, st);
     set_error("bie_mbwq_q4_forward: unsupported shape M=%d K=%d N=%d bits=%d group_size=%d (need K %% 64 == 0, N %% 4 == 0)", M,
               K, N, bits, group_size);
     return BIE_ERR_UNSUPPORTED;

@@ -35,7 +35,8 @@ static int env_int(const char* name, int dflt) {
 
 constexpr int GEMV_THREADS = 256;
 constexpr int GEMV_COLS = 256;  // columns per block: 64 lanes x 4
-constexpr int GEMV_COUNTER_FLOATS = BIE_WS_COUNTERS;  // head of the workspace: one arrival counter per column tile
+constexpr int GEMV_COUNTER_FLOATS = BIE_WS_COUNTERS;  // tickets: one arrival counter per column tile (first half of the head)
+constexpr int GEMV_HEAD_FLOATS = (int)(BIE_WS_HEAD_BYTES / sizeof(float));  // the partial slabs start behind the WHOLE head
 
 template <int DT, int WBIT, int MT, int ZM, int U>
 __global__ __launch_bounds__(GEMV_THREADS) void mpq_gemv_kernel(
@@ -446,7 +447,7 @@ static int launch_gemv3(const Gemv3Plan& pl, const void* x, const int32_t* qw, c
     constexpr int NB = 32 / WBIT;
     const int R = K / NB;
     dim3 grid(cdiv(N, 64), pl.S);
-    float* part = ws + GEMV_COUNTER_FLOATS;
+    float* part = ws + GEMV_HEAD_FLOATS;
     unsigned* counters = reinterpret_cast<unsigned*>(ws);
     static const int lab = env_int("BIE_GEMV_LAB", 0);
 #define BIE_G3(NWV)                                                                                                    \
@@ -564,7 +565,7 @@ static int launch_gemv_u(const GemvPlan& pl, const void* x, const int32_t* qw, c
 #define BIE_GEMV_LAUNCH(UU)                                                                                      \
     hipLaunchKernelGGL((mpq_gemv_kernel<DT, WBIT, MT, ZM, UU>), grid, dim3(GEMV_THREADS), lds, st,              \
                        (const uint16_t*)x, (const uint32_t*)qw, (const uint16_t*)scales, zeros, (const uint16_t*)bias, perm, \
-                       part + GEMV_COUNTER_FLOATS, reinterpret_cast<unsigned*>(part), (uint16_t*)y, M, K, N, group_size, pl.rows_per_slab, R, pl.S, lab)
+                       part + GEMV_HEAD_FLOATS, reinterpret_cast<unsigned*>(part), (uint16_t*)y, M, K, N, group_size, pl.rows_per_slab, R, pl.S, lab)
     switch (pl.U) {
         case 8: BIE_GEMV_LAUNCH(8); break;
         case 4: BIE_GEMV_LAUNCH(4); break;
@@ -628,12 +629,12 @@ size_t mpq_gemv_workspace_bytes(int M, int K, int N, int w_bit) {
                 const size_t f = mpq_gemv_lut_part_floats(M, K, gs, cdiv(N, 64));
                 if (f > lut) lut = f;
             }
-    lut = lut ? lut * sizeof(float) + GEMV_COUNTER_FLOATS * sizeof(float) : 0;
+    lut = lut ? lut * sizeof(float) + BIE_WS_HEAD_BYTES : 0;
     const int MT = M <= 1 ? 1 : (M <= 2 ? 2 : (M <= 4 ? 4 : 8));
     const GemvPlan pl = plan_gemv(K, N, w_bit, K, MT);
-    size_t fast = pl.S > 1 ? (size_t)pl.S * M * N * sizeof(float) + GEMV_COUNTER_FLOATS * sizeof(float) : 0;
+    size_t fast = pl.S > 1 ? (size_t)pl.S * M * N * sizeof(float) + BIE_WS_HEAD_BYTES : 0;
     const Gemv3Plan p3 = plan_gemv3(K, N, w_bit);
-    const size_t fast3 = p3.S > 1 ? (size_t)p3.S * M * N * sizeof(float) + GEMV_COUNTER_FLOATS * sizeof(float) : 0;
+    const size_t fast3 = p3.S > 1 ? (size_t)p3.S * M * N * sizeof(float) + BIE_WS_HEAD_BYTES : 0;
     if (fast3 > fast) fast = fast3;
     if (lut > fast) fast = lut;
     const size_t generic = (size_t)cdiv(K, 512) * M * N * sizeof(float);
@@ -643,13 +644,13 @@ size_t mpq_gemv_workspace_bytes(int M, int K, int N, int w_bit) {
 int mpq_gemv_launch(const void* x, const int32_t* qw, const void* scales, const void* zeros, const void* bias, void* y,
                     float* part, int M, int K, int N, int w_bit, int group_size, int zm, int dtype, const uint16_t* perm,
                     hipStream_t st) {
-    if (perm == nullptr && mpq_gemv_lut_ok(M, K, w_bit, group_size, dtype, false)) {  // bf16 W4: table-lookup kernel
+    if (perm == nullptr && cdiv(N, 64) <= BIE_WS_COUNTERS && mpq_gemv_lut_ok(M, K, w_bit, group_size, dtype, false)) {  // bf16 W4: table-lookup kernel
         const void* sc1[1] = {scales};
         const void* ze1[1] = {zeros};
         const void* bi1[1] = {bias};
         void* y1[1] = {y};
-        return mpq_gemv_lut_launch(1, &qw, sc1, ze1, bias ? bi1 : nullptr, y1, &N, x, reinterpret_cast<unsigned*>(part),
-                                   part + GEMV_COUNTER_FLOATS, M, K, group_size, zm, st);
+        return mpq_gemv_lut_launch(1, &qw, sc1, ze1, bias ? bi1 : nullptr, y1, &N, x, reinterpret_cast<unsigned*>(part) + BIE_WS_GEN_OFFSET,
+                                   part + BIE_WS_HEAD_BYTES / sizeof(float), M, K, group_size, zm, st);
     }
     const int MT = M <= 1 ? 1 : (M <= 2 ? 2 : (M <= 4 ? 4 : 8));
     static const int use_v3 = env_int("BIE_GEMV_V3", 1);

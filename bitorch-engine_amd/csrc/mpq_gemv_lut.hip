@@ -20,12 +20,14 @@
 // ids).  Cross-workgroup reduction WITHOUT atomics or drains: slices 0..S-2 publish their column sums as 8-byte
 // {value, tag} granules with one write-through (sc1) store and retire; the workgroup of the LAST slice (highest block
 // ids: dispatched after every publisher, so the wait cannot starve them) polls the granules with bypassing loads until
-// every tag equals this launch's tag, adds them in slice order (deterministic) and writes y.  The tag is the tile's
-// generation word in the workspace head + 1; the reducer advances the generation when it is done, so nothing ever has to
-// be reset and a captured graph replays correctly.  `bie_mpq_forward_grouped` passes several weight sets that share x
+// every tag equals this launch's tag, adds them in slice order (deterministic) and writes y.  A tag = {24 bits: number of
+// the launch CALL (a host counter baked into the arguments: granule addresses of differently shaped launches alias, their
+// tags cannot), 8 bits: the tile's generation word in the workspace head + 1 (advanced by the reducer when it is done: a
+// REPLAY of a captured launch carries the same call number but the next generation)}; nothing ever has to be reset.  `bie_mpq_forward_grouped` passes several weight sets that share x
 // (q/k/v, gate/up): their column tiles are concatenated into one grid.
 #include "mpq_dequant.cuh"
 #include <stdlib.h>
+#include <atomic>
 
 #pragma clang fp contract(off)
 
@@ -50,6 +52,7 @@ struct LutArgs {
     unsigned* gen;             // generation word per column tile (workspace head)
     int nsets, M, K, G, tiles_total, S, groups_per_wave;  // G / groups_per_wave count UNITS of RPG rows: H units per group
     int hshift;  // log2(H)
+    unsigned epoch;  // (launch-call number mod 2^24) << 8: the upper 24 bits of every granule tag of this launch
 };
 
 // tuning aid (BIE_GEMV_LAB=5): per-wave timestamps {start, weights landed, compute done, end, xcc/cu id} of the last launch
@@ -81,7 +84,7 @@ __device__ __forceinline__ float lut_entry(uint32_t q, float s, float z, int zq1
 // Cross-workgroup reduction of a column tile (called by wave 0 of every workgroup) + the store of y; see the file header.
 template <int DT, int MT, bool REDUCE>
 __device__ __forceinline__ void lut_cross_wg_reduce(const LutArgs& a, const LutSet& ls, float (&tot)[MT], int tile, int slice, int lane,
-                                                    int n, int N, unsigned tag) {
+                                                    int n, int N, unsigned tag, unsigned gen_next) {
     // ---- cross-workgroup reduction (wave 0 only) -----------------------------------------------------------------
     const bool owner = n < N;
     const long ncat = (long)a.tiles_total * 64;
@@ -121,7 +124,7 @@ __device__ __forceinline__ void lut_cross_wg_reduce(const LutArgs& a, const LutS
             }
             tot[m] = v + tot[m];
         }
-        if (lane == 0) a.gen[tile] = tag;  // next launch's tag differs; visible at the kernel boundary
+        if (lane == 0) a.gen[tile] = gen_next;  // a replay of this launch gets a different tag; visible at the kernel boundary
     }
     if (owner) {
 #pragma unroll
@@ -159,7 +162,11 @@ __global__ __launch_bounds__(NW * 64) void mpq_gemv_lut_kernel(const LutArgs a) 
     int g1 = g0 + a.groups_per_wave;
     if (g1 > a.G) g1 = a.G;
     unsigned tag = 0;
-    if (a.S > 1) tag = a.gen[tile] + 1u;  // uniform; the generation only changes when this launch's reducer is done
+    unsigned gen_next = 0;
+    if (a.S > 1) {  // uniform; the generation only changes when this launch's reducer is done
+        gen_next = a.gen[tile] + 1u;
+        tag = a.epoch | (gen_next & 0xffu);
+    }
 
     const uint32_t* wcol = ls.qw + nl;
     auto load_group = [&](uint32_t (&dst)[RPG], int g) {
@@ -380,7 +387,7 @@ __global__ __launch_bounds__(NW * 64) void mpq_gemv_lut_kernel(const LutArgs a) 
         for (int m = 0; m < MT; m++) tot[m] = acc[m][0] + acc[m][1];
     }
 
-    lut_cross_wg_reduce<DT, MT, (LAB == 0 || LAB == 4 || LAB == 5)>(a, ls, tot, tile, slice, lane, n, N, tag);
+    lut_cross_wg_reduce<DT, MT, (LAB == 0 || LAB == 4 || LAB == 5)>(a, ls, tot, tile, slice, lane, n, N, tag, gen_next);
     if constexpr (LAB == 5) {
         const long wid = (long)blockIdx.x * NW;
         if (lane == 0 && wid < 65536) g_lut_stamps[wid * 5 + 3] = wall_clock64();
@@ -416,7 +423,11 @@ __global__ __launch_bounds__(256) void mpq_gemv_lutc_kernel(const LutArgs a) {
     const int nl = n < N ? n : N - 1;  // clamp: out-of-range lanes load valid memory and are never stored
     const int gb = slice * GW;
     unsigned tag = 0;
-    if (a.S > 1) tag = a.gen[tile] + 1u;
+    unsigned gen_next = 0;
+    if (a.S > 1) {
+        gen_next = a.gen[tile] + 1u;
+        tag = a.epoch | (gen_next & 0xffu);
+    }
 
     unsigned long long st0 = 0, st1 = 0, st2 = 0;
     if constexpr (LAB == 5) st0 = wall_clock64();
@@ -557,7 +568,7 @@ __global__ __launch_bounds__(256) void mpq_gemv_lutc_kernel(const LutArgs a) {
         for (int ww = 0; ww < NW; ww++) v += red[(ww * MT + m) * 64 + lane];
         tot[m] = v;
     }
-    lut_cross_wg_reduce<DT, MT, (LAB == 0 || LAB == 4 || LAB == 5)>(a, ls, tot, tile, slice, lane, n, N, tag);
+    lut_cross_wg_reduce<DT, MT, (LAB == 0 || LAB == 4 || LAB == 5)>(a, ls, tot, tile, slice, lane, n, N, tag, gen_next);
     if constexpr (LAB == 5) {
         const long wid = (long)blockIdx.x * NW;
         if (lane == 0 && wid < 65536) g_lut_stamps[wid * 5 + 3] = wall_clock64();
@@ -739,6 +750,10 @@ int mpq_gemv_lut_launch(int nsets, const int32_t* const* qw, const void* const* 
     a.S = p.S;
     a.groups_per_wave = p.gpw;
     a.hshift = p.H == 4 ? 2 : (p.H == 2 ? 1 : 0);
+    static std::atomic<unsigned> calls{0};
+    unsigned e = (calls.fetch_add(1, std::memory_order_relaxed) + 1u) & 0xffffffu;
+    if (e == 0) e = (calls.fetch_add(1, std::memory_order_relaxed) + 1u) & 0xffffffu;  // tag 0 = never written
+    a.epoch = e << 8;
     const int grid = tiles * p.S;
     if (p.coop) lutc_launch(a, p.rpg, grid, M, zm, st);
     else if (p.nw == 4) lut_launch_nw<4>(a, p.rpg, grid, M, zm, st);
