@@ -39,6 +39,10 @@ SIGNATURES = {
     "bie_mbwq_exl2_forward": (_i, [_vp] * 9 + [_sz] + [_i] * 4 + [_vp]),
     "bie_binary_pack_rows_u8": (_i, [_vp, _vp, _l, _l, _i, _vp]),
     "bie_binary_pack_cols_u8": (_i, [_vp, _vp, _l, _l, _i, _vp]),
+    "bie_binary_pack_btc32": (_i, [_vp, _vp, _l, _l, _i, _vp]),
+    "bie_binary_pack_bstc32": (_i, [_vp, _vp, _l, _l, _i, _vp]),
+    "bie_binary_unpack_btc32": (_i, [_vp, _vp, _l, _l, _vp]),
+    "bie_binary_unpack_bstc32": (_i, [_vp, _vp, _l, _l, _vp]),
     "bie_binary_linear_forward": (_i, [_vp, _vp, _vp, _l, _l, _l, _i, _f, _vp]),
     "bie_binary_conv2d_workspace_bytes": (_sz, [_i] * 9),
     "bie_binary_conv2d_forward": (_i, [_vp, _vp, _vp, _vp, _sz] + [_i] * 9 + [_f, _i, _vp]),
@@ -50,6 +54,7 @@ SIGNATURES = {
     "bie_q4_quantize_pack": (_i, [_vp, _vp, _l, _f, _i, _vp]),
     "bie_q4_gemm": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _i, _l, _l, _l, _vp]),
     "bie_q8_gemm": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _vp]),
+    "bie_int_gemm_i32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _l, _l, _l, _vp]),
     "bie_q4_conv2d_workspace_bytes": (_sz, [_i] * 9),
     "bie_q4_conv2d_forward": (_i, [_vp, _vp, _vp, _vp, _sz] + [_i] * 9 + [_f, _f, _i, _vp]),
 }

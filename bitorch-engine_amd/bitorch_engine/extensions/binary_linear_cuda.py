@@ -1,20 +1,67 @@
 """Drop-in for `binary_linear_cuda` (layers/qlinear/binary/cuda/binary_linear_cuda.cpp:119-122):
 forward(input, weights, bmm_type, transpose), w_pack(weights, bmm_type, transpose), mm(x, y, bmm_type).
-All bmm_type values run the same wave64 XNOR-popcount kernels; packed weights are row-packed uint8
-[N, K/8] LSB-first (the reference's per-kernel tile-swizzled BTC/BSTC images are CUDA-WMMA specific
-and are not reproduced -- re-pack from the int8 sign carriers)."""
+
+Packed weights are the REFERENCE's images, bit for bit (bmm_type 1 = BSTC32, 2 = BTC32, 3 = adaptive: BTC32 when
+K % 128 == 0 and N % 8 == 0, else BSTC32 -- binary_linear_cuda_kernel.cu:847-870), so a BinaryLinearCuda checkpoint packed on
+CUDA loads here.  The XNOR-popcount kernels themselves read row-packed words: an image is converted once per tensor version
+(bie_binary_unpack_*, a byte permutation with bit reversal) and the result is remembered on the tensor.  Shapes neither image
+can hold (K or N not a multiple of 32) fall back to plain row-packed bytes, which only this build produces and consumes."""
 import torch
 
-from ._binary_common import pack_rows, xnor_linear
+from bitorch_engine import _hip
+from ._binary_common import pack_rows, sign_dt, xnor_linear
+from .q_linear_cuda import _cached
+
+BSTC32, BTC32, ADAPTIVE = 1, 2, 3
+
+
+def image_kind(bmm_type: int, n: int, k: int):
+    """'btc' / 'bstc' / None (no reference image exists for this shape)."""
+    if (bmm_type == BTC32 or bmm_type == ADAPTIVE) and k % 128 == 0 and n % 8 == 0:
+        return "btc"
+    if bmm_type == BTC32:
+        raise RuntimeError(f"bmm_type BTC32 needs k % 128 == 0 and n % 8 == 0 (n={n}, k={k})")
+    if k % 32 == 0 and n % 32 == 0:
+        return "bstc"
+    return None
 
 
 def w_pack(weights: torch.Tensor, bmm_type: int, transpose: bool) -> torch.Tensor:
-    return pack_rows(weights)
+    """weights [N, K] (float / int8 sign carriers) -> flat uint8 image of N*K/8 bytes."""
+    _hip.need_gpu(weights)
+    weights = weights.contiguous()
+    n, k = weights.shape
+    kind = image_kind(bmm_type, n, k)
+    if kind is None:
+        return pack_rows(weights).reshape(-1)
+    out = torch.empty(n * k // 8, dtype=torch.uint8, device=weights.device)
+    fn = _hip.lib().bie_binary_pack_btc32 if kind == "btc" else _hip.lib().bie_binary_pack_bstc32
+    _hip.check(fn(_hip.ptr(weights), _hip.ptr(out), n, k, sign_dt(weights), _hip.stream()), "bie_binary_pack_" + kind + "32")
+    return out
+
+
+def image_to_rows(image: torch.Tensor, n: int, k: int, bmm_type: int) -> torch.Tensor:
+    """image -> row-packed [N, K/8] (remembered on the image tensor until it changes)."""
+    kind = image_kind(bmm_type, n, k)
+    if kind is None:
+        return image.reshape(n, k // 8)
+
+    def convert():
+        _hip.need_gpu(image)
+        out = torch.empty((n, k // 8), dtype=torch.uint8, device=image.device)
+        fn = _hip.lib().bie_binary_unpack_btc32 if kind == "btc" else _hip.lib().bie_binary_unpack_bstc32
+        _hip.check(fn(_hip.ptr(image.contiguous()), _hip.ptr(out), n, k, _hip.stream()), "bie_binary_unpack_" + kind + "32")
+        return out
+    return _cached(image, ("rows", kind, n, k), convert)
 
 
 def forward(input: torch.Tensor, weights: torch.Tensor, bmm_type: int, transpose: bool) -> torch.Tensor:
     m, k = input.shape
-    wp = weights if weights.dtype == torch.uint8 else pack_rows(weights)
+    if weights.dtype == torch.uint8:
+        n = weights.numel() * 8 // k
+        wp = image_to_rows(weights, n, k, bmm_type)
+    else:
+        wp = pack_rows(weights)
     return xnor_linear(pack_rows(input), wp.contiguous(), m, wp.shape[0], k, 0, 1.0)
 
 

@@ -254,6 +254,39 @@ __global__ __launch_bounds__(256) void q4_unpack_scale_kernel(const int8_t* __re
     out[2 * i + 1] = (float)lo * scale;
 }
 
+// ---- the reference CUDA layer's packed-weight IMAGES (checkpoint compatibility) ----------------------------------
+// binary_linear_cuda.w_pack (reference binary_linear_cuda_kernel.cu:830-882) stores, for the transposed weight A[k][n], 32-bit
+// words holding 32 consecutive k of one column n MSB-first (__brev(__ballot) / Bval << 1), serialised big-endian
+// (uint32_to_uint8 :33-41): byte (k % 32) / 8 of the word, bit 7 - k % 8.  Only the ORDER OF THE WORDS differs:
+//   BTC32  (BMMA_toBit32Col_new :59-152, grid (K/128, N/8), block (32, 4, 8)): word ((n/8 * K/128 + k/128) * 8 + n%8) * 4 + (k%128)/32
+//   BSTC32 (ToBit32RowUd :186-300, grid (K/32, N/32)):                          word (k/32) * N + n
+// Against our row-packed LSB-first bytes [N][K/8] an image byte is therefore one source byte with its bits reversed.
+__device__ __forceinline__ long image_byte_index(int layout, long n, long kb, long N, long K) {
+    const long k = kb * 8;
+    long word;
+    if (layout == 0) word = ((n / 8 * (K / 128) + k / 128) * 8 + n % 8) * 4 + (k % 128) / 32;
+    else word = (k / 32) * N + n;
+    return word * 4 + (k % 32) / 8;
+}
+
+// TO_IMAGE: src = values [N][K] (DT) -> dst = image bytes;  otherwise src = image bytes -> dst = row-packed [N][K/8]
+template <int DT, bool TO_IMAGE>
+__global__ __launch_bounds__(256) void binary_image_kernel(const void* __restrict__ src, uint8_t* __restrict__ dst, long N, long K, int layout) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long KB = K / 8;
+    if (idx >= N * KB) return;
+    const long n = idx / KB, kb = idx - n * KB;
+    const long img = image_byte_index(layout, n, kb, N, K);
+    if constexpr (TO_IMAGE) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int t = 0; t < 8; t++) v |= (uint32_t)(sign_bit<DT>(src, n * K + kb * 8 + t)) << (7 - t);
+        dst[img] = (uint8_t)v;
+    } else {
+        dst[idx] = (uint8_t)(__brev((uint32_t)reinterpret_cast<const uint8_t*>(src)[img]) >> 24);
+    }
+}
+
 // ---- launchers -------------------------------------------------------------------------------------------------
 #define BIE_DT_SWITCH(dtype, CALL)                 \
     switch (dtype) {                               \
@@ -267,6 +300,18 @@ int pack_rows_launch(const void* a, uint8_t* out, long n_bytes, int dtype, hipSt
     dim3 grid((unsigned)cdivl(n_bytes, 256));
     BIE_DT_SWITCH(dtype, hipLaunchKernelGGL(pack_rows_kernel<DT>, grid, dim3(256), 0, st, a, out, n_bytes));
     return check_launch("pack_rows_kernel");
+}
+
+int binary_image_pack_launch(const void* w, uint8_t* image, long N, long K, int layout, int dtype, hipStream_t st) {
+    dim3 grid((unsigned)cdivl(N * (K / 8), 256));
+    BIE_DT_SWITCH(dtype, hipLaunchKernelGGL((binary_image_kernel<DT, true>), grid, dim3(256), 0, st, w, image, N, K, layout));
+    return check_launch("binary_image_kernel<pack>");
+}
+
+int binary_image_unpack_launch(const uint8_t* image, uint8_t* rowpacked, long N, long K, int layout, hipStream_t st) {
+    dim3 grid((unsigned)cdivl(N * (K / 8), 256));
+    hipLaunchKernelGGL((binary_image_kernel<3, false>), grid, dim3(256), 0, st, image, rowpacked, N, K, layout);
+    return check_launch("binary_image_kernel<unpack>");
 }
 
 int pack_cols_launch(const void* w, uint8_t* out, long N, long K, int dtype, hipStream_t st) {

@@ -47,6 +47,8 @@ int mbwq_exl2_forward_launch(const void* x, const int32_t* qw, const void* scale
 // binary.hip
 int pack_rows_launch(const void* a, uint8_t* out, long n_bytes, int dtype, hipStream_t st);
 int pack_cols_launch(const void* w, uint8_t* out, long N, long K, int dtype, hipStream_t st);
+int binary_image_pack_launch(const void* w, uint8_t* image, long N, long K, int layout, int dtype, hipStream_t st);
+int binary_image_unpack_launch(const uint8_t* image, uint8_t* rowpacked, long N, long K, int layout, hipStream_t st);
 int binary_linear_launch(const uint8_t* xp, const uint8_t* wp, float* y, long M, long N, long K, int w_layout, float scale,
                          hipStream_t st);
 size_t binary_conv_workspace_bytes(int B, int C, int H, int W, int OC, int ks, int stride, int pad, int dil);
@@ -316,6 +318,38 @@ int bie_binary_pack_cols_u8(const void* w, uint8_t* out, long N, long K, int dty
     return pack_cols_launch(w, out, N, K, dtype, as_stream(stream));
 }
 
+static int check_image_shape(const char* fn, long N, long K, int btc) {
+    BIE_REQUIRE(N > 0 && K > 0, BIE_ERR_INVALID_ARG, "%s: N=%ld K=%ld must be positive", fn, N, K);
+    if (btc) BIE_REQUIRE(K % 128 == 0 && N % 8 == 0, BIE_ERR_UNSUPPORTED, "%s: the BTC32 image needs K %% 128 == 0 and N %% 8 == 0 (K=%ld N=%ld)", fn, K, N);
+    else BIE_REQUIRE(K % 32 == 0 && N % 32 == 0, BIE_ERR_UNSUPPORTED, "%s: the BSTC32 image needs K %% 32 == 0 and N %% 32 == 0 (K=%ld N=%ld)", fn, K, N);
+    return BIE_OK;
+}
+
+int bie_binary_pack_btc32(const void* w, uint8_t* image, long N, long K, int dtype, void* stream) {
+    int rc = check_image_shape("bie_binary_pack_btc32", N, K, 1);
+    if (rc) return rc;
+    BIE_REQUIRE(w && image && dtype >= 0 && dtype <= 3, BIE_ERR_INVALID_ARG, "bie_binary_pack_btc32: bad argument");
+    return binary_image_pack_launch(w, image, N, K, 0, dtype, as_stream(stream));
+}
+int bie_binary_pack_bstc32(const void* w, uint8_t* image, long N, long K, int dtype, void* stream) {
+    int rc = check_image_shape("bie_binary_pack_bstc32", N, K, 0);
+    if (rc) return rc;
+    BIE_REQUIRE(w && image && dtype >= 0 && dtype <= 3, BIE_ERR_INVALID_ARG, "bie_binary_pack_bstc32: bad argument");
+    return binary_image_pack_launch(w, image, N, K, 1, dtype, as_stream(stream));
+}
+int bie_binary_unpack_btc32(const uint8_t* image, uint8_t* rowpacked, long N, long K, void* stream) {
+    int rc = check_image_shape("bie_binary_unpack_btc32", N, K, 1);
+    if (rc) return rc;
+    BIE_REQUIRE(image && rowpacked, BIE_ERR_INVALID_ARG, "bie_binary_unpack_btc32: NULL pointer");
+    return binary_image_unpack_launch(image, rowpacked, N, K, 0, as_stream(stream));
+}
+int bie_binary_unpack_bstc32(const uint8_t* image, uint8_t* rowpacked, long N, long K, void* stream) {
+    int rc = check_image_shape("bie_binary_unpack_bstc32", N, K, 0);
+    if (rc) return rc;
+    BIE_REQUIRE(image && rowpacked, BIE_ERR_INVALID_ARG, "bie_binary_unpack_bstc32: NULL pointer");
+    return binary_image_unpack_launch(image, rowpacked, N, K, 1, as_stream(stream));
+}
+
 int bie_binary_linear_forward(const uint8_t* xpacked, const uint8_t* wpacked, float* y, long M, long N, long K, int w_layout,
                               float scale, void* stream) {
     BIE_REQUIRE(xpacked && wpacked && y && M > 0 && N > 0 && K > 0 && K % 8 == 0, BIE_ERR_INVALID_ARG, "bie_binary_linear_forward: M=%ld N=%ld K=%ld (K %% 8 == 0 required)", M, N, K);
@@ -384,6 +418,14 @@ int bie_q8_gemm(const int8_t* a, const int8_t* w, float* y, int M, int N, int K,
     BIE_REQUIRE(a && w && y && M > 0 && N > 0 && K > 0, BIE_ERR_INVALID_ARG, "bie_q8_gemm: bad argument");
     BIE_REQUIRE(K % 64 == 0 && N % 4 == 0, BIE_ERR_UNSUPPORTED, "bie_q8_gemm: K=%d must be a multiple of 64 and N=%d of 4", K, N);
     return int_gemm_launch(1, a, w, y, M, N, K, scale_a, scale_w, BIE_F32, 1, 0, 0, 0, as_stream(stream));
+}
+
+int bie_int_gemm_i32(const int8_t* a, const int8_t* w, int32_t* y, int M, int N, int K, int bits, int batch, long stride_a, long stride_w,
+                     long stride_y, void* stream) {
+    BIE_REQUIRE(a && w && y && M > 0 && N > 0 && K > 0 && batch > 0, BIE_ERR_INVALID_ARG, "bie_int_gemm_i32: bad argument");
+    BIE_REQUIRE(bits == 4 || bits == 8, BIE_ERR_UNSUPPORTED, "bie_int_gemm_i32: bits=%d (4 or 8)", bits);
+    BIE_REQUIRE(K % 64 == 0 && N % 4 == 0, BIE_ERR_UNSUPPORTED, "bie_int_gemm_i32: K=%d must be a multiple of 64 and N=%d of 4", K, N);
+    return int_gemm_launch(bits == 4 ? 2 : 3, a, w, y, M, N, K, 1.0f, 1.0f, BIE_F32, batch, stride_a, stride_w, stride_y, as_stream(stream));
 }
 
 size_t bie_q4_conv2d_workspace_bytes(int B, int H, int W, int C, int OC, int ksize, int stride, int pad, int dilation) {

@@ -29,13 +29,17 @@ __device__ __forceinline__ int4_t expand_q4(uint2_t p) {
     return r;
 }
 
+typedef int int4v_t __attribute__((ext_vector_type(4)));
+
 // MODE 0: W4A4, out dtype DT: o = fl(fl((float)acc) * fl(scale))            (q4_linear_cutlass_forward :640-680)
 // MODE 1: W8A8, out fp32     : o = ((float)acc * scale_a) * scale_w         (q8_linear_cutlass_forward :215-230)
+// MODE 2 / 3: W4A4 / W8A8 with the raw int32 accumulators as output (q4_gemm :526-555 / q8_gemm: what the reference's
+//             backward entry points return or scale on the torch side)
 template <int MODE, int DT>
 __global__ __launch_bounds__(256) void int_gemm_kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ W,
                                                        void* __restrict__ y, int M, int N, int K, float scale_a, float scale_w,
                                                        long strideA, long strideW, long strideY) {
-    constexpr bool Q4 = (MODE == 0);
+    constexpr bool Q4 = (MODE == 0 || MODE == 2);
     constexpr int ROWB = Q4 ? 32 : 64;  // bytes per tile row
     __shared__ __attribute__((aligned(16))) unsigned char As[IG_BM * ROWB];
     __shared__ __attribute__((aligned(16))) unsigned char Ws[IG_BN * ROWB];
@@ -101,7 +105,7 @@ __global__ __launch_bounds__(256) void int_gemm_kernel(const uint8_t* __restrict
         __syncthreads();
     }
 
-    char* yb = reinterpret_cast<char*>(y) + (long)blockIdx.z * strideY * (MODE == 1 ? 4 : dt_traits<DT>::bytes);
+    char* yb = reinterpret_cast<char*>(y) + (long)blockIdx.z * strideY * (MODE >= 1 ? 4 : dt_traits<DT>::bytes);
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -111,6 +115,13 @@ __global__ __launch_bounds__(256) void int_gemm_kernel(const uint8_t* __restrict
             for (int q = 0; q < 4; q++) {
                 const int nq = n0 + wn * 64 + a * 32 + 8 * q + 4 * h;
                 if (row < M && nq < N) {
+                    if constexpr (MODE >= 2) {
+                        int4v_t iv;
+#pragma unroll
+                        for (int c = 0; c < 4; c++) iv[c] = Q4 ? (acc[a][b][4 * q + c] >> 8) : acc[a][b][4 * q + c];
+                        *reinterpret_cast<int4v_t*>(reinterpret_cast<int*>(yb) + (long)row * N + nq) = iv;
+                        continue;
+                    }
                     float o[4];
 #pragma unroll
                     for (int c = 0; c < 4; c++) {
@@ -184,6 +195,8 @@ int int_gemm_launch(int mode, const void* A, const void* W, void* y, int M, int 
     dim3 grid(cdiv(N, IG_BN), cdiv(M, IG_BM), batch);
 #define L(MODE, DT) hipLaunchKernelGGL((int_gemm_kernel<MODE, DT>), grid, dim3(256), 0, st, (const uint8_t*)A, (const uint8_t*)W, y, M, N, K, sa, sw, strideA, strideW, strideY)
     if (mode == 1) L(1, BIE_F32);
+    else if (mode == 2) L(2, BIE_F32);
+    else if (mode == 3) L(3, BIE_F32);
     else if (dtype == BIE_F16) L(0, BIE_F16);
     else if (dtype == BIE_BF16) L(0, BIE_BF16);
     else L(0, BIE_F32);

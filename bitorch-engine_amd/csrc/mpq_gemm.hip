@@ -235,6 +235,9 @@ struct WTile {  // one K tile (64) worth of this lane's weights + dequant consta
 // loop's address arithmetic stays on the scalar unit (global_load ... v[base], s[offset]).
 template <int WBIT>
 struct WPtrs {
+    __amdgpu_buffer_rsrc_t wrsrc;  // qweight as a raw buffer: the loop's row offsets are scalar (soffset), the lane part is voffset
+    uint32_t wvoff[GEMM_NF];       // byte offset of (lane row part, column)
+    uint32_t row_bytes;            // N * 4
     const uint32_t* w[GEMM_NF];    // qweight + lane row part + column
     const uint16_t* s[GEMM_NF];    // scales + column
     const uint16_t* z[GEMM_NF];    // fp zeros + column            (sym)
@@ -252,11 +255,12 @@ __device__ __forceinline__ void load_wtile(WTile<DT, WBIT, ZM, GPT>& t, const WP
         for (int kk = 0; kk < 4; kk++) {
             const int c8u = (k0 >> 3) + kk * 2;  // uniform part of the chunk index (the lane adds h)
             if constexpr (WBIT == 8) {
-                const long row = (long)(2 * c8u) * N;
-                t.raw[f][kk] = uint2_t{p.w[f][row], p.w[f][row + N]};
+                const uint32_t row = (uint32_t)(2 * c8u) * p.row_bytes;
+                t.raw[f][kk] = uint2_t{__builtin_amdgcn_raw_buffer_load_b32(p.wrsrc, p.wvoff[f], row, 0),
+                                       __builtin_amdgcn_raw_buffer_load_b32(p.wrsrc, p.wvoff[f], row + p.row_bytes, 0)};
             } else {
                 constexpr int CPW = 4 / WBIT;  // chunks per word: w4 1, w2 2, w1 4
-                t.raw[f][kk] = p.w[f][(long)(c8u / CPW) * N];
+                t.raw[f][kk] = __builtin_amdgcn_raw_buffer_load_b32(p.wrsrc, p.wvoff[f], (uint32_t)(c8u / CPW) * p.row_bytes, 0);
             }
         }
 #pragma unroll
@@ -317,9 +321,18 @@ __global__ __launch_bounds__(256, (BM <= 128 ? 2 : 1)) void mpq_gemm_kernel(cons
         constexpr uint32_t dummy = 0;
         (void)dummy;
         const int hrow = (WBIT == 4) ? h : (WBIT == 8 ? 2 * h : 0);  // lane-dependent packed-row offset of chunk c8u + h
+        {   // descriptor inputs through readfirstlane: the compiler must KNOW they are wave-uniform, or it wraps every buffer
+            // load in a waterfall loop (cdna_hip_programming.md T20)
+            const uint64_t qb = (uint64_t)(uintptr_t)qw;
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)qb), hi = __builtin_amdgcn_readfirstlane((uint32_t)(qb >> 32));
+            wp.wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((uint64_t)hi << 32) | lo), 0,
+                                                         __builtin_amdgcn_readfirstlane((uint32_t)((long)(K / NB) * N * 4)), 0x00020000);
+        }
+        wp.row_bytes = __builtin_amdgcn_readfirstlane((uint32_t)N * 4u);
 #pragma unroll
         for (int f = 0; f < NF; f++) {
             const int n = ncol_ld[f];
+            wp.wvoff[f] = (uint32_t)(hrow * N + n) * 4u;
             wp.w[f] = qw + (long)hrow * N + n;
             wp.s[f] = scales + n;
             wp.z[f] = reinterpret_cast<const uint16_t*>(zeros) + n;

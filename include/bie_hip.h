@@ -158,6 +158,17 @@ int bie_binary_pack_rows_u8(const void* a, uint8_t* out, long rows, long K, int 
  * Replaces binary_linear_cpp.w_pack (binary_linear.cpp:454-465). */
 int bie_binary_pack_cols_u8(const void* w, uint8_t* out, long N, long K, int dtype, void* stream);
 
+/* The reference CUDA layer's packed-weight images, bit for bit, so that BinaryLinearCuda checkpoints packed on CUDA load here:
+ * w [N, K] values (dtype 0=f16 1=bf16 2=f32 3=int8 sign carriers) -> image of N*K/8 bytes; 32 consecutive k of one column per
+ * 32-bit word, MSB first, words serialised big-endian.  BTC32 (bmm_type 2, or 3 with K % 128 == 0 and N % 8 == 0):
+ * BMMA_toBit32Col_new tiles, binary_linear_cuda_kernel.cu:59-152; BSTC32 (otherwise): ToBit32RowUd, :186-300; dispatch and
+ * byte order: _get_binary_weight_cuda :830-882, uint32_to_uint8 :33-41.  The unpack entry points turn an image into the
+ * row-packed LSB-first [N, K/8] operand bie_binary_linear_forward(w_layout = 0) consumes. */
+int bie_binary_pack_btc32(const void* w, uint8_t* image, long N, long K, int dtype, void* stream);
+int bie_binary_pack_bstc32(const void* w, uint8_t* image, long N, long K, int dtype, void* stream);
+int bie_binary_unpack_btc32(const uint8_t* image, uint8_t* rowpacked, long N, long K, void* stream);
+int bie_binary_unpack_bstc32(const uint8_t* image, uint8_t* rowpacked, long N, long K, void* stream);
+
 /* y[M, N] fp32 = (K - 2*popcount(xbits ^ wbits)) * scale.
  * w_layout 0: wpacked is row-packed [N, K/8] (binary_linear_cutlass / our native layout)
  * w_layout 1: wpacked is column bit-planes [K/8, N] (binary_linear_cpp.w_pack layout).
@@ -215,6 +226,14 @@ int bie_q4_gemm(const int8_t* a_packed, const int8_t* w_packed, void* y, int M, 
  * Replaces q_linear_cutlass.q8_forward (q8_linear_cutlass_kernel.cu:186-230). */
 int bie_q8_gemm(const int8_t* a, const int8_t* w, float* y, int M, int N, int K, float scale_a, float scale_w,
                 void* stream);
+
+/* y[batch][M][N] (int32) = A[batch][M][K] . W[batch][N][K]^T on packed 4-bit (bits = 4: K/2 bytes per row, first value in the high
+ * nibble) or int8 (bits = 8) operands: the raw accumulators, which is what the reference's q4_gemm / q8_gemm return
+ * (layers/qlinear/nbit/cutlass/q4_linear_cutlass_kernel.cu:526-555) and its backward entry points q4_backward :719-743,
+ * q4_matmul_backward :901-941, q8_backward q8_linear_cutlass_kernel.cu:283-308 are built from.  Strides in bytes of A / W per batch
+ * element and in int32 elements for y.  K % 64 == 0, N % 4 == 0. */
+int bie_int_gemm_i32(const int8_t* a, const int8_t* w, int32_t* y, int M, int N, int K, int bits, int batch, long stride_a,
+                     long stride_w, long stride_y, void* stream);
 
 /* W4A4 convolution on nibble-packed NHWC operands: a [B, H, W, C/2], w [OC, KS, KS, C/2] (C % 8 == 0, OC % 4 == 0), zero padding,
  * y [B, OH, OW, OC] (dtype) with the bie_q4_gemm epilogue; OH = (H + 2*pad - dil*(KS-1) - 1)/stride + 1.  The workspace holds the

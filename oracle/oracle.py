@@ -170,6 +170,33 @@ def binary_pack_rows(a):
     return out
 
 
+def _msb_words(bits_kn):
+    """bits [K, N] (k-major, the transposed weight the reference packs) -> uint32 [K/32, N]: bit 31 = first k of the block
+    (__brev(__ballot) in BMMA_toBit32Col_new, Bval << 1 in ToBit32RowUd)."""
+    K, N = bits_kn.shape
+    b = bits_kn.reshape(K // 32, 32, N).astype(np.uint64)
+    sh = np.arange(31, -1, -1, dtype=np.uint64).reshape(1, 32, 1)
+    return (b << sh).sum(axis=1).astype(np.uint32)
+
+
+def binary_pack_bstc32(w):
+    """Reference BSTC32 image of w [N, K]: ToBit32RowUd<<<(K/32, N/32), 32>>> writes word [k/32][n]
+    (binary_linear_cuda_kernel.cu:186-203, B[bx*gridDim.y*32 + by*32 + laneid]); bytes big-endian (uint32_to_uint8 :33-41)."""
+    bits = (np.asarray(w, np.float32).T >= 0)
+    return _msb_words(bits).astype(">u4").tobytes()
+
+
+def binary_pack_btc32(w):
+    """Reference BTC32 image of w [N, K]: BMMA_toBit32Col_new<<<(K/128, N/8), (32, 4, 8)>>> writes the word of 32 k
+    (k = bx*128 + wx*32 ..) and column n = by*8 + wy at (by*gridDim.x + bx)*32 + wy*4 + wx (binary_linear_cuda_kernel.cu:59-152)."""
+    bits = (np.asarray(w, np.float32).T >= 0)
+    K, N = bits.shape
+    words = _msb_words(bits)  # [K/32, N]
+    tiles = words.reshape(K // 128, 4, N // 8, 8)      # [bx, wx, by, wy]
+    out = np.ascontiguousarray(tiles.transpose(2, 0, 3, 1))  # [by, bx, wy, wx]
+    return out.astype(">u4").tobytes()
+
+
 def binary_pack_cols(w):
     w = _c(w, np.float32)
     N, K = w.shape

@@ -891,3 +891,95 @@ def test_lookup_and_ticket_kernels_share_one_workspace():
         for dt in (orc.BF16, orc.F16, orc.F16, orc.BF16):
             x, qw, scales, zeros, ref = cases[dt]
             assert_close(hip_forward(x, qw, scales, zeros, None, 4, gs, 0), ref, dt, f"interleaved dt={dt}")
+
+
+# ------------------------------------------------------------------------------------------------ A13: CUDA-layer packed images
+@pytest.mark.parametrize("N,K,bmm,kind", [(64, 256, 3, "btc"), (64, 256, 2, "btc"), (64, 256, 1, "bstc"), (96, 160, 3, "bstc"), (8, 128, 3, "btc")])
+def test_binary_cuda_weight_images_bit_exact(N, K, bmm, kind):
+    """binary_linear_cuda.w_pack returns the reference's BTC32 / BSTC32 image byte for byte (oracle = restatement of
+    binary_linear_cuda_kernel.cu:59-152,186-300,830-882), the inverse kernel restores our row-packed operand, and a forward
+    on the image equals sign(x) . sign(w)^T."""
+    from bitorch_engine.extensions import binary_linear_cuda
+    rng = np.random.default_rng(N + K + bmm)
+    w = rng.standard_normal((N, K)).astype(np.float32)
+    for tw in (torch.from_numpy(w), torch.from_numpy(np.where(w >= 0, 3, -5).astype(np.int8)), torch.from_numpy(w).half()):
+        img = binary_linear_cuda.w_pack(tw.to(DEV), bmm, True)
+        want = orc.binary_pack_btc32(w) if kind == "btc" else orc.binary_pack_bstc32(w)
+        assert img.dtype == torch.uint8 and img.numel() == N * K // 8 and img.cpu().numpy().tobytes() == want
+    rows = binary_linear_cuda.image_to_rows(img, N, K, bmm)
+    assert np.array_equal(rows.cpu().numpy(), orc.binary_pack_rows(w))
+    x = rng.standard_normal((5, K)).astype(np.float32)
+    y = binary_linear_cuda.forward(torch.from_numpy(x).to(DEV), img, bmm, True).cpu().numpy()
+    assert np.array_equal(y, np.where(x >= 0, 1.0, -1.0) @ np.where(w >= 0, 1.0, -1.0).T)
+
+
+def test_binary_cuda_layer_checkpoint_is_the_reference_image():
+    from bitorch_engine.layers.qlinear.binary.cuda import BinaryLinearCuda
+    torch.manual_seed(8)
+    layer = BinaryLinearCuda(256, 64)
+    layer.set_weight_data(torch.randn(64, 256))
+    layer.eval().to(DEV)
+    layer.generate_quantized_weight(qweight_only=False)
+    carriers = layer.weight.data.float().cpu().numpy()
+    assert layer.qweight.data.cpu().numpy().tobytes() == orc.binary_pack_btc32(carriers)  # adaptive: K % 128 == 0, N % 8 == 0
+
+
+# ------------------------------------------------------------------------------------------------ section 8f-2: W4A4 / W8A8 backward entry points
+def _nibbles(p):
+    """packed int8 [rows, c/2] -> signed 4-bit values [rows, c], first value in the high nibble."""
+    u = p.astype(np.uint8)
+    hi, lo = (u >> 4).astype(np.int32), (u & 15).astype(np.int32)
+    v = np.stack([hi, lo], axis=-1).reshape(p.shape[:-1] + (p.shape[-1] * 2,))
+    return np.where(v >= 8, v - 16, v)
+
+
+def test_q4_backward_reference_arithmetic():
+    """q4_backward: gradient quantised with scale_grad, two 4-bit GEMMs on the saved packed operands AS THEY LIE IN MEMORY
+    (reference q4_linear_cutlass_kernel.cu:719-743), int32 results times scale_a / scale_w.  Exact integer arithmetic."""
+    from bitorch_engine.extensions import q_linear_cutlass as qc
+    g = torch.Generator().manual_seed(21)
+    m, k, n = 64, 128, 192
+    x = torch.randn((m, k), generator=g).half()
+    w = (torch.randn((n, k), generator=g) * 0.05).half()
+    gy = torch.randn((m, n), generator=g).half()
+    sa, sw, sg = 0.31, 0.02, 0.4
+    qa, qw = qc.q4_w_pack(x.to(DEV), sa), qc.q4_w_pack(w.to(DEV), sw)
+    ga, gw = qc.q4_backward(gy.to(DEV), qa, qw, sa, sw, sg)
+    pg = orc.q4_quantize_pack(orc.torch_to_np(gy), sg, orc.F16)                  # [m, n/2]
+    G = _nibbles(pg)                                                             # [m, n]
+    Wv = _nibbles(qw.cpu().numpy().reshape(k, n // 2))                           # buffer re-read as [k, n]
+    want_a = (G @ Wv.T).astype(np.int32)
+    Gt = _nibbles(np.ascontiguousarray(pg.T).reshape(n, m // 2))                 # transposed BYTES re-read as [n, m]
+    Av = _nibbles(qa.cpu().numpy().reshape(k, m // 2))
+    want_w = (Gt @ Av.T).astype(np.int32)
+    assert ga.shape == (m, k) and gw.shape == (n, k)
+    assert torch.equal(ga.cpu(), torch.from_numpy(want_a) * sa) and torch.equal(gw.cpu(), torch.from_numpy(want_w) * sw)
+
+
+def test_q4_matmul_backward_and_q8_backward():
+    from bitorch_engine.extensions import q_linear_cutlass as qc
+    g = torch.Generator().manual_seed(22)
+    B, m, n, k = 3, 64, 128, 64
+    x = torch.randn((B, m, k), generator=g).half()
+    y = torch.randn((B, n, k), generator=g).half()
+    gy = torch.randn((B, m, n), generator=g).half()
+    out, qx, qy = qc.q4_matmul(x.to(DEV), y.to(DEV), torch.tensor(0.3), torch.tensor(0.4))
+    gx, gyy = qc.q4_matmul_backward(gy.to(DEV), qx, qy, 0.3, 0.4, 0.5)
+    assert gx.shape == (B, m, k) and gyy.shape == (B, n, k)
+    for b in range(B):
+        pg = orc.q4_quantize_pack(orc.torch_to_np(gy[b]), 0.5, orc.F16)
+        want_x = _nibbles(pg) @ _nibbles(qy[b].cpu().numpy().reshape(k, n // 2)).T
+        want_y = _nibbles(np.ascontiguousarray(pg.T).reshape(n, m // 2)) @ _nibbles(qx[b].cpu().numpy().reshape(k, m // 2)).T
+        assert torch.equal(gx[b].cpu(), torch.from_numpy(want_x.astype(np.int32)) * 0.3)
+        assert torch.equal(gyy[b].cpu(), torch.from_numpy(want_y.astype(np.int32)) * 0.4)
+    rng = np.random.default_rng(5)
+    m, k, n = 64, 192, 128
+    a = rng.integers(-128, 128, (m, k)).astype(np.int8)
+    w = rng.integers(-128, 128, (n, k)).astype(np.int8)
+    gq = rng.integers(-128, 128, (m, n)).astype(np.int8)
+    ga, gw = qc.q8_backward(torch.from_numpy(gq).to(DEV), torch.from_numpy(a).to(DEV), torch.from_numpy(w).to(DEV))
+    assert ga.dtype == torch.int32 and gw.dtype == torch.int32
+    assert np.array_equal(ga.cpu().numpy(), gq.astype(np.int32) @ w.reshape(k, n).astype(np.int32).T)
+    assert np.array_equal(gw.cpu().numpy(), np.ascontiguousarray(gq.T).astype(np.int32) @ a.reshape(k, m).astype(np.int32).T)
+    with pytest.raises(RuntimeError):
+        qc.q8_backward(torch.from_numpy(gq).to(DEV), torch.from_numpy(a).float().to(DEV), torch.from_numpy(w).to(DEV))

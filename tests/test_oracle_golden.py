@@ -204,3 +204,46 @@ def test_q4_conv2d_oracle_equals_torch_conv_on_the_integers():
         ref = torch.nn.functional.conv2d(torch.from_numpy(a).permute(0, 3, 1, 2).double(), torch.from_numpy(w).permute(0, 3, 1, 2).double(),
                                          stride=st, padding=pad, dilation=dil).permute(0, 2, 3, 1).numpy()
         assert np.array_equal(y, (ref * 0.25).astype(np.float32))
+
+
+def test_btc_bstc_image_oracle_against_a_thread_by_thread_emulation():
+    """The vectorised oracle of the CUDA layer's packed-weight images (oracle.binary_pack_btc32 / _bstc32) against a literal
+    emulation of the launch geometry the reference uses (binary_linear_cuda_kernel.cu:59-152 BMMA_toBit32Col_new
+    <<<(K/128, N/8), (32, 4, 8)>>>, :186-203 ToBit32RowUd<<<(K/32, N/32), 32>>>, :33-41 uint32_to_uint8).  The CUDA kernels
+    cannot run here; this pins the restatement to the index arithmetic of the source, thread by thread."""
+    rng = np.random.default_rng(3)
+    N, K = 64, 256
+    w = rng.standard_normal((N, K)).astype(np.float32)
+    A = w.T  # the layer packs weight.t(): A[k][n], A_height = K, A_width = N
+
+    def brev_ballot(vals):  # lane i -> bit 31 - i
+        v = 0
+        for i, f in enumerate(vals):
+            v |= int(f >= 0) << (31 - i)
+        return v
+
+    def to_bytes(words):  # uint32_to_uint8: out[4j + b] = (in[j] >> ((3 - b) * 8)) & 0xff
+        out = bytearray()
+        for x in words:
+            out += bytes([(x >> 24) & 255, (x >> 16) & 255, (x >> 8) & 255, x & 255])
+        return bytes(out)
+
+    btc = [0] * (N * K // 32)
+    gx = K // 128
+    for bx in range(K // 128):
+        for by in range(N // 8):
+            for wx in range(4):
+                for wy in range(8):
+                    btc[(by * gx + bx) * 32 + wy * 4 + wx] = brev_ballot([A[bx * 128 + wx * 32 + lane][by * 8 + wy] for lane in range(32)])
+    assert to_bytes(btc) == orc.binary_pack_btc32(w)
+
+    bstc = [0] * (N * K // 32)
+    gy = N // 32
+    for bx in range(K // 32):
+        for by in range(N // 32):
+            for lane in range(32):
+                val = 0
+                for i in range(32):
+                    val = ((val << 1) + int(A[bx * 32 + i][by * 32 + lane] >= 0)) & 0xffffffff
+                bstc[bx * gy * 32 + by * 32 + lane] = val
+    assert to_bytes(bstc) == orc.binary_pack_bstc32(w)
