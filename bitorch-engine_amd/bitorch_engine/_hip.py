@@ -161,6 +161,22 @@ def workspace(nbytes: int, device) -> torch.Tensor:
     return buf
 
 
+_SCRATCH = {}
+
+
+def scratch(nbytes: int, device) -> torch.Tensor:
+    """Per-(device, stream) scratch WITHOUT the ticket / generation head (im2col buffers and the like): grown on demand,
+    superseded buffers retired like workspace()'s."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            _WS_RETIRED.append(buf)
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _SCRATCH[key] = buf
+    return buf
+
+
 def presize_workspace(nbytes: int, device=None):
     """Allocate the current stream's scratch buffer up front (e.g. for the largest prefill) so that it never regrows
     after a decode graph has been captured."""

@@ -25,7 +25,7 @@ def forward(input, weight, scale_a, scale_w, is_train, kernel_size, stride, padd
     out = torch.empty((B, oh, ow, OC), dtype=input.dtype, device=input.device)
     L = _hip.lib()
     need = L.bie_q4_conv2d_workspace_bytes(B, H, W, C, OC, kernel_size, stride, padding, dilation)
-    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=input.device)
+    ws = _hip.scratch(max(need, 16), input.device)  # per-(device, stream) buffer, reused across calls (no per-call allocation)
     rc = L.bie_q4_conv2d_forward(_hip.ptr(packed_a), _hip.ptr(packed_w.contiguous()), _hip.ptr(out), _hip.ptr(ws), ws.numel(), B, H, W, C,
                                  OC, kernel_size, stride, padding, dilation, sa, sw, _hip.dt(input), _hip.stream())
     _hip.check(rc, "bie_q4_conv2d_forward")

@@ -611,7 +611,11 @@ static int env_int(const char* name, int dflt) {
 // re-read plus the finalize launch.  The plan depends on (M, K, N) only: bie_mpq_workspace_bytes has to reproduce it
 // without knowing dtype or bit width.
 static GemmPlan plan_gemm(int M, int K, int N) {
-    const int force_bm = env_int("BIE_GEMM_BM", 0), force_s = env_int("BIE_GEMM_S", 0);  // tuning knobs (read per call: in-process sweeps)
+    // tuning knobs: read ONCE per process -- unless BIE_TUNING is set (tests / sweep tools change them between calls), in which
+    // case they are re-read on every launch.  No getenv on the product's launch path.
+    static const bool tuning = getenv("BIE_TUNING") != nullptr;
+    static const int bm_once = env_int("BIE_GEMM_BM", 0), s_once = env_int("BIE_GEMM_S", 0);
+    const int force_bm = tuning ? env_int("BIE_GEMM_BM", 0) : bm_once, force_s = tuning ? env_int("BIE_GEMM_S", 0) : s_once;
     const int T = K / GEMM_BK;
     const int bms[4] = {32, 64, 128, 256};
     const double c0[4] = {0.93, 1.00, 1.19, 1.53};

@@ -10,6 +10,7 @@ for p in (ROOT, PKG):
         sys.path.insert(0, p)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+os.environ.setdefault("BIE_TUNING", "1")  # the kernels' tuning knobs (BIE_GEMM_BM / BIE_GEMM_S) are re-read per launch: tests force every plan
 
 
 def pytest_configure(config):

@@ -1,5 +1,6 @@
 """In-process sweep of the GEMM plan knobs (BIE_GEMM_BM / BIE_GEMM_S are read per call)."""
-import os, sys, json
+import os
+os.environ.setdefault("BIE_TUNING", "1"), sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import sweep
