@@ -233,7 +233,7 @@ def bench_binary(dev, L):
         x = torch.randn((B, 512, 7, 7), device=dev)
         w = torch.randn((512, 512, 3, 3), device=dev)
         wp = binary_conv_cpp.w_pack(w) if hasattr(binary_conv_cpp, "w_pack") else None
-        fn = lambda st: binary_conv_cpp.forward(x, wp if wp is not None else w, 512, 512 * 9, B * 49, 3, 1, 1, 1, 7)
+        fn = lambda st: binary_conv_cpp.forward(x, wp if wp is not None else w, 512, B * 49, 512 * 9, 3, 1, 1, 1, 7)
         try:
             us = time_graph(capture(fn), 20)
             tops = 2.0 * B * 49 * 512 * 4608 / us / 1e6
@@ -255,7 +255,7 @@ def cpu_baselines(budget_s=6.0):
         omp = ctypes.CDLL("libgomp.so.1")
     except OSError:
         omp = None
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)  # cores this process may run on
     res = []
     for (k, n) in ((4096, 4096), (4096, 11008)):
         rng = np.random.default_rng(0)
