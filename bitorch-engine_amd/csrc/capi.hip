@@ -19,7 +19,7 @@ bool mpq_gemv_lut_ok(int M, int K, int w_bit, int group_size, int dtype, bool ha
 size_t mpq_gemv_lut_part_floats(int M, int K, int group_size, int tiles_total);
 int mpq_gemv_lut_launch(int nsets, const int32_t* const* qw, const void* const* scales, const void* const* zeros,
                         const void* const* bias, void* const* y, const int* N, const void* x, unsigned* counters, float* part,
-                        int M, int K, int group_size, int zm, hipStream_t st);
+                        int M, int K, int group_size, int zm, int dtype, hipStream_t st);
 // mpq_gemm.hip
 bool mpq_gemm_ok(int M, int K, int N, int w_bit, int group_size, int dtype, bool has_gidx);
 size_t mpq_gemm_workspace_bytes(int M, int K, int N);
@@ -91,7 +91,7 @@ const char* bie_last_error(void) { return bie::get_error(); }
 
 size_t bie_mpq_workspace_bytes(int M, int K, int N, int w_bit) {
     if (M <= 0 || K <= 0 || N <= 0 || !(w_bit == 1 || w_bit == 2 || w_bit == 4 || w_bit == 8)) return 0;
-    size_t a = M <= 8 ? mpq_gemv_workspace_bytes(M, K, N, w_bit) : 0;
+    size_t a = M <= 16 ? mpq_gemv_workspace_bytes(M, K, N, w_bit) : 0;
     size_t b = mpq_gemm_workspace_bytes(M, K, N);
     const int mc = M < GENERIC_M_CHUNK ? M : GENERIC_M_CHUNK;
     size_t c = (size_t)cdiv(K, 512) * mc * N * sizeof(float);
@@ -119,6 +119,10 @@ int bie_mpq_forward(const void* x, const int32_t* qweight, const void* scales, c
     // The GEMV also serves M <= 8 for shapes the MFMA tiling cannot take.
     const bool gemm_ok = mpq_gemm_ok(M, K, N, w_bit, group_size, dtype, has_gidx);
     static const int gemv_max_m = []() { const char* e = getenv("BIE_GEMV_MAX_M"); return e ? atoi(e) : 2; }();  // tuning knob
+    // W4 decode and small batches: the table-lookup kernels (mpq_gemv_lut_ok says which M each form takes)
+    static const int lut_max_m = []() { const char* e = getenv("BIE_LUT_MAX_M"); return e ? atoi(e) : 16; }();
+    if (M <= lut_max_m && cdiv(N, 64) <= BIE_WS_COUNTERS && (N & 3) == 0 && mpq_gemv_lut_ok(M, K, w_bit, group_size, dtype, has_gidx))
+        return mpq_gemv_launch(x, qweight, scales, zeros, bias, y, head, M, K, N, w_bit, group_size, asym ? 1 : 0, dtype, nullptr, st);
     if (M <= 8 && (M <= gemv_max_m || !gemm_ok) && mpq_gemv_fast_ok(M, K, N, w_bit, group_size, dtype, has_gidx))
         return mpq_gemv_launch(x, qweight, scales, zeros, bias, y, head, M, K, N, w_bit, group_size, asym ? 1 : 0, dtype, nullptr, st);
     if (gemm_ok)
@@ -154,7 +158,7 @@ size_t bie_mpq_grouped_workspace_bytes(int n_sets, const int* N, int M, int K, i
         const size_t b = bie_mpq_workspace_bytes(M, K, N[i], w_bit);
         if (b > need) need = b;
     }
-    if (w_bit == 4 && M <= 2) {
+    if (w_bit == 4 && M <= 16) {
         const int tiles = grouped_tiles(n_sets, N);
         for (int gs = 32; gs <= 256; gs *= 2)
             if (K % gs == 0) {
@@ -185,7 +189,7 @@ int bie_mpq_forward_grouped(const void* x, int n_sets, const int32_t* const* qwe
     if (tiles <= BIE_WS_COUNTERS && mpq_gemv_lut_ok(M, K, w_bit, group_size, dtype, false)) {
         float* head = reinterpret_cast<float*>(workspace);
         return mpq_gemv_lut_launch(n_sets, qweight, scales, zeros, bias, y, N, x, reinterpret_cast<unsigned*>(head) + BIE_WS_GEN_OFFSET,
-                                   head + WS_HEAD / sizeof(float), M, K, group_size, asym ? 1 : 0, as_stream(stream));
+                                   head + WS_HEAD / sizeof(float), M, K, group_size, asym ? 1 : 0, dtype, as_stream(stream));
     }
     for (int i = 0; i < n_sets; i++) {  // every other case: one launch per set (same results)
         int rc = bie_mpq_forward(x, qweight[i], scales[i], zeros[i], nullptr, bias ? bias[i] : nullptr, y[i], workspace,

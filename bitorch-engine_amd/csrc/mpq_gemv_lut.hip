@@ -63,7 +63,7 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef const __attribute__((address_space(4))) uint32_t const_u32;
 
 // LDS byte address {byte 0 = lane * 4, byte 1 = byte BYTE of w (= wave * 16 + q), bytes 2-3 = 0} in ONE v_perm_b32
-// (selector 0x0c = the constant 0x00; the SDWA form with dst_unused:UNUSED_PRESERVE measured ~3x slower on gfx950)
+// (selector 0x0c = the constant 0x00; an SDWA move with dst_unused:UNUSED_PRESERVE does the same and measured no faster)
 template <int BYTE>
 __device__ __forceinline__ uint32_t lut_addr(uint32_t lane_addr, uint32_t w) {
     return __builtin_amdgcn_perm(w, lane_addr, 0x0c0c0400u + ((uint32_t)BYTE << 8));
@@ -575,6 +575,238 @@ __global__ __launch_bounds__(256) void mpq_gemv_lutc_kernel(const LutArgs a) {
     }
 }
 
+// =====================================================================================================================
+// Matrix-pipe form (M <= 16): the products go to the otherwise idle MFMA unit.  v_mfma_f32_32x32x16 wants, per lane, the 8
+// consecutive-k weights of ONE column -- exactly one packed W4 word -- so a wave takes a 64-column tile as two 32-column
+// fragments, lane (h, j) = (lane >> 5, lane & 31) owning packed row 2*rp + h of columns j and 32 + j.  A word's eight table
+// values are read as 16-bit halves (ds_read_u16) and paired with one v_lshl_or_b32 each into the four operand registers,
+// the activations enter as the second operand: lane (h, m) supplies x[m][16*rp + 8*h .. +8] (one 16-byte buffer load; lanes
+// m >= M read out of bounds = 0), so D[n][m] accumulates all M rows at the price of one.  Per word: 3 + 8 VALU, 8 LDS reads,
+// 1/… MFMA; no FMAs, no scalar unpacking of x.  The two lane halves of a wave build 8 table entries each for the same 64
+// columns (tab[wave][q][column]: bank = column mod 32 within each half -> conflict-free).
+// =====================================================================================================================
+typedef float lutm_acc_t __attribute__((ext_vector_type(16)));
+
+template <int DT>
+__device__ __forceinline__ lutm_acc_t lutm_mfma(const uint32_t (&w)[4], uint4_t xf, lutm_acc_t c) {
+    const uint4_t wv = {w[0], w[1], w[2], w[3]};
+    if constexpr (DT == BIE_F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, wv), __builtin_bit_cast(half8_t, xf), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wv), __builtin_bit_cast(bf16x8_t, xf), c, 0, 0, 0);
+}
+
+template <int DT, int ZM, int RPG, int NW>
+__global__ __launch_bounds__(NW * 64) void mpq_gemv_lutm_kernel(const LutArgs a) {
+    constexpr int NB = 8;
+    constexpr int RP = RPG / 2;  // row pairs per unit
+    __shared__ __attribute__((aligned(4096))) uint32_t tab[NW * 16 * 64];  // the only LDS object: starts at LDS address 0
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int tile = blockIdx.x % a.tiles_total;
+    const int slice = blockIdx.x / a.tiles_total;
+    int si = 0;
+#pragma unroll
+    for (int i = 1; i < LUT_MAX_SETS; i++)
+        if (i < a.nsets && tile >= a.set[i].tile_begin) si = i;
+    const LutSet& ls = a.set[si];
+    const int N = ls.N;
+    const int M = a.M;
+    const int nt0 = (tile - ls.tile_begin) * 64;
+    int ncl[2];
+#pragma unroll
+    for (int f = 0; f < 2; f++) {
+        const int n = nt0 + f * 32 + j;
+        ncl[f] = n < N ? n : N - 1;  // clamp: out-of-range columns load valid memory and are never stored
+    }
+    const int g0 = (slice * NW + wave) * a.groups_per_wave;
+    int g1 = g0 + a.groups_per_wave;
+    if (g1 > a.G) g1 = a.G;
+    unsigned tag = 0, gen_next = 0;
+    if (a.S > 1) {
+        gen_next = a.gen[tile] + 1u;
+        tag = a.epoch | (gen_next & 0xffu);
+    }
+
+    // x as a raw buffer: rows >= M are out of bounds and read as 0 (the unused columns of the MFMA's second operand)
+    const uint64_t xb = (uint64_t)(uintptr_t)a.x;
+    const uint32_t xlo = __builtin_amdgcn_readfirstlane((uint32_t)xb), xhi = __builtin_amdgcn_readfirstlane((uint32_t)(xb >> 32));  // unsigned: no sign extension
+    const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((uint64_t)xhi << 32) | xlo), 0,
+                                                         __builtin_amdgcn_readfirstlane((uint32_t)((long)M * a.K * 2)), 0x00020000);
+    const uint32_t xvoff = j < M ? (uint32_t)(j * a.K * 2 + h * 16) : 0x80000000u;
+
+    const int zero_width = N / NB;
+    const uint32_t* wcol[2] = {ls.qw + ncl[0], ls.qw + ncl[1]};
+    auto load_params = [&](int unit, uint32_t (&sb)[2], uint32_t (&zb)[2]) {
+        const int g = unit >> a.hshift;
+#pragma unroll
+        for (int f = 0; f < 2; f++) {
+            sb[f] = ls.scales[(long)g * N + ncl[f]];
+            if constexpr (ZM == ZM_ASYM) {
+                const uint32_t zw = reinterpret_cast<const uint32_t*>(ls.zeros)[(long)g * zero_width + ncl[f] / NB];
+                zb[f] = ((zw >> ((ncl[f] % NB) * 4)) & 15u) + 1u;
+            } else {
+                zb[f] = reinterpret_cast<const uint16_t*>(ls.zeros)[(long)g * N + ncl[f]];
+            }
+        }
+    };
+    auto load_unit = [&](uint32_t (&w)[2][RP], uint4_t (&xf)[RP], int unit) {
+#pragma unroll
+        for (int rp = 0; rp < RP; rp++) {
+            const long row = (long)unit * RPG + 2 * rp + h;
+#pragma unroll
+            for (int f = 0; f < 2; f++) w[f][rp] = __builtin_nontemporal_load(wcol[f] + row * N);
+            xf[rp] = __builtin_bit_cast(uint4_t, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xvoff, (uint32_t)((unit * RPG + 2 * rp) * 16), 0));
+        }
+    };
+
+    lutm_acc_t acc[2];
+#pragma unroll
+    for (int f = 0; f < 2; f++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[f][e] = 0.0f;
+
+    // LDS byte address of tab[wave][q][c] = ((wave * 16 + q) << 8) | (c << 2)
+    const uint32_t col_addr[2] = {(uint32_t)j * 4u, (uint32_t)(32 + j) * 4u};
+    const uint32_t wavepat = (uint32_t)wave * 0x10101010u;
+    uint32_t* mytab = tab + wave * (16 * 64);
+    uint32_t m0f;
+    asm("v_mov_b32 %0, 0x0f0f0f0f" : "=v"(m0f));
+
+    auto process_unit = [&](const uint32_t (&w)[2][RP], const uint4_t (&xf)[RP], const uint32_t (&sb)[2], const uint32_t (&zb)[2]) {
+        // ---- this half-wave's 8 entries (q = 8h .. 8h+7) of the two columns' tables; 16-bit value in the low half of a dword
+#pragma unroll
+        for (int f = 0; f < 2; f++) {
+            float s, z = 0.0f;
+            int zq1 = 0;
+            if constexpr (DT == BIE_BF16) s = bf16_bits_to_f32(sb[f]); else s = f16_bits_to_f32(sb[f]);
+            if constexpr (ZM == ZM_ASYM) zq1 = (int)zb[f];
+            else if constexpr (DT == BIE_BF16) z = bf16_bits_to_f32(zb[f]); else z = f16_bits_to_f32(zb[f]);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const uint32_t q = (uint32_t)(8 * h + e);
+                const float t = lut_entry<DT, ZM>(q, s, z, zq1);
+                uint32_t bits;
+                if constexpr (DT == BIE_BF16) bits = __float_as_uint(t) >> 16; else bits = f32_to_f16_bits(t);
+                mytab[q * 64 + f * 32 + j] = bits;
+            }
+        }
+        // ---- fragment steps s = 2*rp + f: the eight 16-bit lookups of step s+1 are in flight while step s feeds the MFMA
+        // (plain ds_read_u16 + one v_lshl_or_b32 per pair: with SRAM-ECC register files a d16 load does not preserve the other
+        // half of its destination, so the d16 / d16_hi pair cannot share a register)
+        uint32_t la[8], lb[8];
+        auto issue = [&](uint32_t (&l)[8], int rp, int f) {
+            uint32_t we, wo;
+            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(we) : "v"(w[f][rp]), "v"(m0f), "s"(wavepat));
+            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(wo) : "v"(w[f][rp] >> 4), "v"(m0f), "s"(wavepat));
+            const uint32_t ca = col_addr[f];
+            asm volatile("ds_read_u16 %0, %1" : "=v"(l[0]) : "v"(lut_addr<0>(ca, we)) : "memory");
+            asm volatile("ds_read_u16 %0, %1" : "=v"(l[1]) : "v"(lut_addr<0>(ca, wo)) : "memory");
+            asm volatile("ds_read_u16 %0, %1" : "=v"(l[2]) : "v"(lut_addr<1>(ca, we)) : "memory");
+            asm volatile("ds_read_u16 %0, %1" : "=v"(l[3]) : "v"(lut_addr<1>(ca, wo)) : "memory");
+            asm volatile("ds_read_u16 %0, %1" : "=v"(l[4]) : "v"(lut_addr<2>(ca, we)) : "memory");
+            asm volatile("ds_read_u16 %0, %1" : "=v"(l[5]) : "v"(lut_addr<2>(ca, wo)) : "memory");
+            asm volatile("ds_read_u16 %0, %1" : "=v"(l[6]) : "v"(lut_addr<3>(ca, we)) : "memory");
+            asm volatile("ds_read_u16 %0, %1" : "=v"(l[7]) : "v"(lut_addr<3>(ca, wo)) : "memory");
+        };
+        auto wait_pack = [&](uint32_t (&l)[8], bool more, uint32_t (&b)[4]) {
+            if (more) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3]), "+v"(l[4]), "+v"(l[5]), "+v"(l[6]), "+v"(l[7])::"memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3]), "+v"(l[4]), "+v"(l[5]), "+v"(l[6]), "+v"(l[7])::"memory");
+#pragma unroll
+            for (int i = 0; i < 4; i++) b[i] = (l[2 * i + 1] << 16) | l[2 * i];
+        };
+        issue(la, 0, 0);
+#pragma unroll
+        for (int st = 0; st < 2 * RP; st++) {
+            const int rp = st >> 1, f = st & 1;
+            const bool more = st + 1 < 2 * RP;
+            uint32_t b[4];
+            if (st & 1) {
+                if (more) issue(la, (st + 1) >> 1, (st + 1) & 1);
+                wait_pack(lb, more, b);
+            } else {
+                if (more) issue(lb, (st + 1) >> 1, (st + 1) & 1);
+                wait_pack(la, more, b);
+            }
+            acc[f] = lutm_mfma<DT>(b, xf[rp], acc[f]);
+        }
+    };
+
+    // one unit per wave is the normal plan (its rows, activations and constants are requested up front, constants first so that
+    // the table is built under the row latency); further units of a wave (very wide layers) are taken one after the other
+    uint32_t wa[2][RP];
+    uint4_t xa[RP];
+    uint32_t sa[2] = {0, 0}, za[2] = {0, 0};
+    for (int g = g0; g < g1; g++) {
+        load_params(g, sa, za);
+        asm volatile("" ::: "memory");
+        load_unit(wa, xa, g);
+        process_unit(wa, xa, sa, za);
+    }
+
+    // ---- workgroup reduction through LDS (the tables are dead).  D layout of the 32x32 MFMA: lane (h', m) holds, for e = 0..15,
+    // the output of column n = (e & 3) + 8 * (e >> 2) + 4 * h' (+ 32 * f) of x row m.  red[wave][m][64]
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(tab);
+    if (j < M) {
+#pragma unroll
+        for (int f = 0; f < 2; f++)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; q4++) {
+                const float4_t v = {acc[f][4 * q4], acc[f][4 * q4 + 1], acc[f][4 * q4 + 2], acc[f][4 * q4 + 3]};
+                *reinterpret_cast<float4_t*>(red + ((wave * M + j) * 64 + f * 32 + 8 * q4 + 4 * h)) = v;
+            }
+    }
+    __syncthreads();
+    // wave w finishes x rows m = w, w + NW, ...: lane = column of the tile
+    const int n = nt0 + lane;
+    const bool owner = n < N;
+    const long ncat = (long)a.tiles_total * 64;
+    const long col = (long)tile * 64 + lane;
+    for (int m = wave; m < M; m += NW) {
+        float tot = 0.0f;
+#pragma unroll
+        for (int ww = 0; ww < NW; ww++) tot += red[(ww * M + m) * 64 + lane];
+        if (a.S > 1) {
+            if (slice != a.S - 1) {
+                const unsigned long long gval = ((unsigned long long)tag << 32) | __float_as_uint(tot);
+                __hip_atomic_store(a.gran + ((long)slice * M + m) * ncat + col, gval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                continue;
+            }
+            float v = 0.0f;
+            for (int s0 = 0; s0 < a.S - 1; s0 += 8) {
+                unsigned long long gv[8];
+                bool ready;
+                int spins = 0;
+                do {
+#pragma unroll
+                    for (int jj = 0; jj < 8; jj++) {
+                        const int sidx = (s0 + jj < a.S - 1) ? s0 + jj : a.S - 2;
+                        gv[jj] = __hip_atomic_load(a.gran + ((long)sidx * M + m) * ncat + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    ready = true;
+#pragma unroll
+                    for (int jj = 0; jj < 8; jj++) ready = ready && ((unsigned)(gv[jj] >> 32) == tag);
+                    ready = __builtin_amdgcn_ballot_w64(!ready) == 0;
+                    if (!ready) __builtin_amdgcn_s_sleep(2);
+                } while (!ready && ++spins < (1 << 24));
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++)
+                    if (s0 + jj < a.S - 1) v += __uint_as_float((unsigned)gv[jj]);
+            }
+            tot = v + tot;
+        }
+        if (owner) {
+            float o = dt_traits<DT>::round(tot);
+            if (ls.bias) o = o + dt_traits<DT>::load(ls.bias, n);
+            dt_traits<DT>::store(ls.y, (long)m * N + n, o);
+        }
+    }
+    if (a.S > 1 && slice == a.S - 1 && threadIdx.x == 0) a.gen[tile] = gen_next;  // read only by the next launch
+}
+
 // tuning aid: copy the stamps of the last BIE_GEMV_LAB=5 launch to the host (synchronises the device)
 extern "C" int bie_debug_lut_stamps(unsigned long long* out, int n_waves) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lut_stamps), (size_t)n_waves * 5 * sizeof(unsigned long long));
@@ -586,10 +818,22 @@ static int lut_env(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
-// bf16, W4, implicit groups of 32 / 64 / 128 / 256 that tile K exactly, M <= 2
+// W4, implicit groups of 32 / 64 / 128 / 256 that tile K exactly.  FMA form: bf16, M <= 2.  Matrix-pipe form: fp16 / bf16,
+// M <= 16 by construction, used for 3 <= M <= 8 where it measures faster than both neighbours (4096x11008 bf16: 15.6-17.5 us
+// against 18.7-19.0 us of the MFMA GEMM; at M <= 2 the FMA form wins, 10.3 / 15.3 us against 15.2 / 15.4 us; from M = 12 the
+// x fragments every wave re-reads from L2 cost as much as the weights and the GEMM's LDS-shared x tile is level or better).
+static bool lut_use_mfma(int M) {
+    static const int v = lut_env("BIE_LUT_MFMA", 1);
+    static const int lo = lut_env("BIE_LUT_MFMA_MIN_M", 3);
+    static const int hi = lut_env("BIE_LUT_MFMA_MAX_M", 8);
+    return v != 0 && M >= lo && M <= hi && M <= 16;
+}
 bool mpq_gemv_lut_ok(int M, int K, int w_bit, int group_size, int dtype, bool has_gidx) {
     static const int enabled = lut_env("BIE_GEMV_LUT", 1);
-    if (!enabled || has_gidx || dtype != BIE_BF16 || w_bit != 4 || M < 1 || M > 2) return false;
+    if (!enabled || has_gidx || w_bit != 4 || M < 1) return false;
+    if (lut_use_mfma(M)) {
+        if (dtype != BIE_BF16 && dtype != BIE_F16) return false;
+    } else if (dtype != BIE_BF16 || M > 2) return false;
     const int gs = group_size > K ? K : group_size;
     if (gs != 32 && gs != 64 && gs != 128 && gs != 256) return false;
     return K % gs == 0;
@@ -603,7 +847,7 @@ struct LutPlan {
 // chip short of waves split every group into H = 2 or 4 units (each wave then builds the group's table for 8 or 4 rows: the
 // per-wave critical path, which is what a 4096x4096 launch spends its time on, shrinks accordingly); big grids give a wave
 // several units (bounds the granule traffic).
-static LutPlan lut_plan(int K, int group_size, int tiles_total) {
+static LutPlan lut_plan(int M, int K, int group_size, int tiles_total) {
     static const int min_rows = lut_env("BIE_LUT_ROWS", 16);
     static const int nw_env = lut_env("BIE_LUT_NW", 8);
     static const int max_wg = lut_env("BIE_LUT_MAX_WG", 2048);
@@ -614,15 +858,15 @@ static LutPlan lut_plan(int K, int group_size, int tiles_total) {
     const int gs = group_size > K ? K : group_size;
     p.rpg = gs / 8;
     p.G = K / gs;
-    p.coop = coop;
+    p.coop = coop && !lut_use_mfma(M);
     p.H = 1;
-    if (coop) {  // four waves per group, 128 / rpg groups per workgroup (mpq_gemv_lutc_kernel)
+    if (p.coop) {  // four waves per group, 128 / rpg groups per workgroup (mpq_gemv_lutc_kernel)
         p.nw = 4;
         p.gpw = 128 / p.rpg;
         p.S = cdiv(p.G, p.gpw);
         return p;
     }
-    p.nw = nw_env == 4 ? 4 : (nw_env == 2 ? 2 : 8);
+    p.nw = lut_use_mfma(M) ? 8 : (nw_env == 4 ? 4 : (nw_env == 2 ? 2 : 8));
     int H = 1;
     if (force_h > 0) H = force_h;
     else
@@ -642,7 +886,7 @@ static LutPlan lut_plan(int K, int group_size, int tiles_total) {
 
 // granule area behind the workspace head, counted in floats (a granule = 8 bytes)
 size_t mpq_gemv_lut_part_floats(int M, int K, int group_size, int tiles_total) {
-    const LutPlan p = lut_plan(K, group_size, tiles_total);
+    const LutPlan p = lut_plan(M, K, group_size, tiles_total);
     return p.S > 1 ? (size_t)(p.S - 1) * M * tiles_total * 64 * 2 : 0;
 }
 
@@ -721,10 +965,25 @@ static void lutc_launch(const LutArgs& a, int rpg, int grid, int M, int zm, hipS
     }
 }
 
+template <int DT>
+static void lutm_launch(const LutArgs& a, int rpg, int grid, int zm, hipStream_t st) {
+#define BIE_LUTM(ZMV)                                                                                                          \
+    switch (rpg) {                                                                                                             \
+        case 4: hipLaunchKernelGGL((mpq_gemv_lutm_kernel<DT, ZMV, 4, 8>), dim3(grid), dim3(512), 0, st, a); break;             \
+        case 8: hipLaunchKernelGGL((mpq_gemv_lutm_kernel<DT, ZMV, 8, 8>), dim3(grid), dim3(512), 0, st, a); break;             \
+        case 16: hipLaunchKernelGGL((mpq_gemv_lutm_kernel<DT, ZMV, 16, 8>), dim3(grid), dim3(512), 0, st, a); break;           \
+        default: hipLaunchKernelGGL((mpq_gemv_lutm_kernel<DT, ZMV, 32, 8>), dim3(grid), dim3(512), 0, st, a); break;           \
+    }
+    if (zm == ZM_ASYM) { BIE_LUTM(ZM_ASYM) }
+    else if (zm == ZM_FUSED) { BIE_LUTM(ZM_FUSED) }
+    else { BIE_LUTM(ZM_SYM) }
+#undef BIE_LUTM
+}
+
 // sets: n weight sets sharing x (one for a plain forward).  `gen` = the workspace's head, `gran` = granule area.
 int mpq_gemv_lut_launch(int nsets, const int32_t* const* qw, const void* const* scales, const void* const* zeros,
                         const void* const* bias, void* const* y, const int* N, const void* x, unsigned* gen, float* gran,
-                        int M, int K, int group_size, int zm, hipStream_t st) {
+                        int M, int K, int group_size, int zm, int dtype, hipStream_t st) {
     LutArgs a;
     int tiles = 0;
     for (int i = 0; i < LUT_MAX_SETS; i++) {
@@ -738,7 +997,7 @@ int mpq_gemv_lut_launch(int nsets, const int32_t* const* qw, const void* const* 
         a.set[i].tile_begin = tiles;
         if (i < nsets) tiles += cdiv(N[j], 64);
     }
-    const LutPlan p = lut_plan(K, group_size, tiles);
+    const LutPlan p = lut_plan(M, K, group_size, tiles);
     a.x = reinterpret_cast<const uint16_t*>(x);
     a.gran = reinterpret_cast<unsigned long long*>(gran);
     a.gen = gen;
@@ -755,6 +1014,11 @@ int mpq_gemv_lut_launch(int nsets, const int32_t* const* qw, const void* const* 
     if (e == 0) e = (calls.fetch_add(1, std::memory_order_relaxed) + 1u) & 0xffffffu;  // tag 0 = never written
     a.epoch = e << 8;
     const int grid = tiles * p.S;
+    if (lut_use_mfma(M) && !p.coop) {
+        if (dtype == BIE_F16) lutm_launch<BIE_F16>(a, p.rpg, grid, zm, st);
+        else lutm_launch<BIE_BF16>(a, p.rpg, grid, zm, st);
+        return check_launch("mpq_gemv_lutm_kernel");
+    }
     if (p.coop) lutc_launch(a, p.rpg, grid, M, zm, st);
     else if (p.nw == 4) lut_launch_nw<4>(a, p.rpg, grid, M, zm, st);
     else if (p.nw == 2) lut_launch_nw<2>(a, p.rpg, grid, M, zm, st);
