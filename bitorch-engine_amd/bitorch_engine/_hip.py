@@ -31,6 +31,8 @@ SIGNATURES = {
     "bie_mpq_dequant": (_i, [_vp] * 5 + [_i] * 6 + [_vp]),
     "bie_mpq_pack": (_i, [_vp] * 5 + [_i] * 6 + [_vp]),
     "bie_mpq_grad_input": (_i, [_vp] * 6 + [_i] * 7 + [_vp]),
+    "bie_mpq_sort_rows": (_i, [_vp] * 3 + [_i] * 3 + [_vp]),
+    "bie_gather_cols": (_i, [_vp] * 3 + [_i] * 3 + [_vp]),
     "bie_mbwq_rows": (_i, [_vp, _i, _i, _vp]),
     "bie_mbwq_q4_dequant": (_i, [_vp] * 5 + [_i] * 4 + [_vp]),
     "bie_mbwq_exl2_dequant": (_i, [_vp] * 7 + [_i] * 3 + [_vp]),

@@ -9,17 +9,21 @@ def _group_size(K, scales):
     return (K + G - 1) // G
 
 
-def _cached(t, key, compute):
+def _cached(t, key, compute, also=()):
     """Memoise a property of tensor `t` ON the tensor object, invalidated by in-place modification (`_version`)
-    or re-pointing (`data_ptr`).  (A process-wide dict keyed by address would alias recycled allocations.)"""
-    tag = (key, t._version, t.data_ptr())
-    hit = getattr(t, "_bie_memo", None)
-    if hit is None or hit[0] != tag:
-        hit = (tag, compute())
+    or re-pointing (`data_ptr`) of `t` or of the tensors in `also`.  (A process-wide dict keyed by address would alias
+    recycled allocations.)"""
+    tag = (t._version, t.data_ptr()) + tuple(v for o in also for v in (o._version, o.data_ptr()))
+    memo = getattr(t, "_bie_memo", None)
+    if memo is None:
+        memo = {}
         try:
-            t._bie_memo = hit
+            t._bie_memo = memo
         except Exception:
             pass
+    hit = memo.get(key)
+    if hit is None or hit[0] != tag:
+        hit = memo[key] = (tag, compute())
     return hit[1]
 
 
@@ -33,6 +37,40 @@ def gidx_is_trivial(g_idx, group_size):
         ref = torch.arange(g_idx.numel(), device=g_idx.device, dtype=torch.int32) // group_size
         return bool(torch.equal(g_idx.to(torch.int32), ref))
     return _cached(g_idx, ("trivial", group_size), compute)
+
+
+def act_order_sorted(qweight, g_idx, w_bit, group_size):
+    """Act-order checkpoints whose g_idx is a permutation of k // group_size (what GPTQ's desc_act writes): the packed matrix
+    re-ordered once so that every group's k are consecutive (bie_mpq_sort_rows) + the column order to apply to x.  Returns
+    (perm int32[K], qweight_sorted) or None (g_idx not of that form, or BIE_ACT_ORDER_SORTED=0).  The sorted copy costs
+    K*N*w/8 bytes beside the checkpoint tensor and is remembered per (g_idx, qweight) version."""
+    import os
+    if os.environ.get("BIE_ACT_ORDER_SORTED", "1") == "0":
+        return None
+
+    def compute():
+        K = g_idx.numel()
+        g = g_idx.to(torch.int64)
+        perm = torch.argsort(g, stable=True)
+        ref = torch.arange(K, device=g.device, dtype=torch.int64) // group_size
+        if not bool(torch.equal(g[perm], ref)):
+            return None
+        perm = perm.to(torch.int32).contiguous()
+        qw = qweight.contiguous()
+        out = torch.empty_like(qw)
+        rc = _hip.lib().bie_mpq_sort_rows(_hip.ptr(qw), _hip.ptr(perm), _hip.ptr(out), K, qw.shape[1], w_bit, _hip.stream())
+        _hip.check(rc, "bie_mpq_sort_rows")
+        return perm, out
+    return _cached(g_idx, ("sorted", w_bit, group_size), compute, also=(qweight,))
+
+
+def gather_cols(x, perm):
+    """x[:, perm] (bie_gather_cols)."""
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    rc = _hip.lib().bie_gather_cols(_hip.ptr(x), _hip.ptr(perm), _hip.ptr(out), x.shape[0], x.shape[1], _hip.dt(x), _hip.stream())
+    _hip.check(rc, "bie_gather_cols")
+    return out
 
 
 def perm_or_none(q_perm):
@@ -51,11 +89,16 @@ def mpq_forward_impl(x, qweight, scales, zeros, g_idx, w_bit, asym, group_size, 
     N = qweight.shape[1]
     if trivial_gidx is None:
         trivial_gidx = gidx_is_trivial(g_idx, group_size)
+    if not trivial_gidx and M > 0:
+        # act-order checkpoints (explicit g_idx): re-ordered once into an implicit-group matrix, then the fast kernels on x[:, perm]
+        so = act_order_sorted(qweight, g_idx, w_bit, group_size)
+        if so is not None:
+            x, qweight, trivial_gidx = gather_cols(x, so[0]), so[1], True
     gptr = None if trivial_gidx else g_idx.to(torch.int32).contiguous()
     if gptr is not None and M > 32:
-        # act-order checkpoints (explicit g_idx): the fused kernels need whole groups per packed row; for prefill the dense
-        # weight is materialised once by the HIP dequant kernel and the plain GEMM goes to the vendor library -- the split the
-        # reference makes for every M > 32 (layers/qlinear/nbit/cuda/mpq_layer.py:59-62)
+        # g_idx that is NOT a permutation of k // group_size (unequal groups): the fused kernels need whole groups per packed
+        # row; for prefill the dense weight is materialised once by the HIP dequant kernel and the plain GEMM goes to the vendor
+        # library -- the split the reference makes for every M > 32 (layers/qlinear/nbit/cuda/mpq_layer.py:59-62)
         W = mpq_dequant(qweight, scales, zeros, gptr, w_bit, asym, group_size)
         y = torch.matmul(x, W.to(x.dtype))
         return y if bias is None else y + bias

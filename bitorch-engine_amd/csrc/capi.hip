@@ -31,6 +31,8 @@ int mpq_dequant_launch(const int32_t* qw, const void* scales, const void* zeros,
                        int N, int w_bit, int group_size, int asym, int dtype, hipStream_t st);
 int mpq_pack_launch(const void* weight, const void* scales, const void* zeros, const int32_t* g_idx, int32_t* out, int K,
                     int N, int w_bit, int group_size, int asym, int dtype, hipStream_t st);
+int mpq_sort_rows_launch(const int32_t* qw, const int32_t* perm, int32_t* out, int K, int N, int w_bit, hipStream_t st);
+int gather_cols_launch(const void* x, const int32_t* perm, void* out, int M, int K, int elem_bytes, hipStream_t st);
 int mpq_grad_input_launch(const void* gy, const int32_t* qw, const void* scales, const void* zeros, const int32_t* g_idx,
                           void* gx, int M, int K, int N, int w_bit, int group_size, int asym, int dtype, hipStream_t st);
 // mbwq.hip
@@ -222,6 +224,21 @@ int bie_mpq_grad_input(const void* grad_y, const int32_t* qweight, const void* s
     if (rc) return rc;
     BIE_REQUIRE(grad_y && qweight && scales && zeros && grad_x && M > 0, BIE_ERR_INVALID_ARG, "bie_mpq_grad_input: bad argument");
     return mpq_grad_input_launch(grad_y, qweight, scales, zeros, g_idx, grad_x, M, K, N, w_bit, group_size, asym, dtype, as_stream(stream));
+}
+
+int bie_mpq_sort_rows(const int32_t* qweight, const int32_t* perm, int32_t* out, int K, int N, int w_bit, void* stream) {
+    BIE_REQUIRE(w_bit == 1 || w_bit == 2 || w_bit == 4 || w_bit == 8, BIE_ERR_UNSUPPORTED, "bie_mpq_sort_rows: w_bit %d not supported", w_bit);
+    BIE_REQUIRE(K > 0 && N > 0 && K % (32 / w_bit) == 0, BIE_ERR_INVALID_ARG, "bie_mpq_sort_rows: K=%d must be a positive multiple of %d, N=%d positive", K, 32 / w_bit, N);
+    BIE_REQUIRE(qweight && perm && out && qweight != out, BIE_ERR_INVALID_ARG, "bie_mpq_sort_rows: NULL or aliased tensor pointer");
+    return mpq_sort_rows_launch(qweight, perm, out, K, N, w_bit, as_stream(stream));
+}
+
+int bie_gather_cols(const void* x, const int32_t* perm, void* out, int M, int K, int dtype, void* stream) {
+    BIE_REQUIRE(dtype == BIE_F16 || dtype == BIE_BF16 || dtype == BIE_F32, BIE_ERR_UNSUPPORTED, "bie_gather_cols: dtype %d not supported", dtype);
+    BIE_REQUIRE(M >= 0 && K > 0, BIE_ERR_INVALID_ARG, "bie_gather_cols: bad shape M=%d K=%d", M, K);
+    if (M == 0) return BIE_OK;
+    BIE_REQUIRE(x && perm && out && x != out, BIE_ERR_INVALID_ARG, "bie_gather_cols: NULL or aliased tensor pointer");
+    return gather_cols_launch(x, perm, out, M, K, dtype == BIE_F32 ? 4 : 2, as_stream(stream));
 }
 
 

@@ -3,6 +3,8 @@
 //                        (reference layers/qlinear/nbit/cuda/utils.py:30-51)
 //   mpq_pack_kernel    : dense [K, N] -> packed int32, bit-exact twin of pack_fp_weight (utils.py:72-147)
 //   mpq_grad_input     : grad_x = grad_y . W^T (back_quant_mm_kernel, mpq_linear_cuda_kernel.cu:635-1049)
+//   mpq_sort_rows      : act-order preparation: packed rows re-ordered so that every group's k are consecutive
+//   gather_cols        : x[:, perm] (the activation side of the same re-ordering)
 #include "mpq_dequant.cuh"
 
 #pragma clang fp contract(off)
@@ -135,6 +137,61 @@ __global__ __launch_bounds__(256) void mpq_grad_input_kernel(const void* __restr
         const int k = r * NB + j;
         if (lane == 0 && k < K) dt_traits<DT>::store(gx, (long)m * K + k, v);
     }
+}
+
+// Act-order (explicit g_idx) layers: the reference looks the group of every k up per weight (mpq_linear_cuda_kernel.cu:300-317).
+// W·x is invariant under a common permutation of k, so the packed matrix is re-ordered ONCE (perm = stable argsort of g_idx: group
+// g's members become rows g·gs … g·gs+gs-1, i.e. an implicit-group matrix) and the decode / prefill kernels run unchanged on
+// x[:, perm].  Pure bit movement: out field k' = in field perm[k'].  One thread per output word; lanes along N (coalesced).
+template <int NB>
+__global__ __launch_bounds__(256) void mpq_sort_rows_kernel(const uint32_t* __restrict__ qw, const int32_t* __restrict__ perm,
+                                                            uint32_t* __restrict__ out, int K, int N) {
+    constexpr int W = 32 / NB;
+    constexpr uint32_t MASK = W == 32 ? 0xffffffffu : ((1u << W) - 1u);
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y;
+    if (n >= N) return;
+    uint32_t word = 0;
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+        const int kp = r * NB + i;
+        if (kp < K) {
+            const int k = perm[kp];  // wave-uniform
+            const uint32_t src = qw[(long)(k / NB) * N + n];
+            word |= ((src >> ((k % NB) * W)) & MASK) << (i * W);
+        }
+    }
+    out[(long)r * N + n] = word;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gather_cols_kernel(const T* __restrict__ x, const int32_t* __restrict__ perm,
+                                                          T* __restrict__ out, int M, int K) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    const int src = perm[k];
+    for (int m = blockIdx.y; m < M; m += gridDim.y) out[(long)m * K + k] = x[(long)m * K + src];
+}
+
+int mpq_sort_rows_launch(const int32_t* qw, const int32_t* perm, int32_t* out, int K, int N, int w_bit, hipStream_t st) {
+    const int nb = 32 / w_bit;
+    dim3 grid(cdiv(N, 256), cdiv(K, nb));
+#define L(NBV) hipLaunchKernelGGL(mpq_sort_rows_kernel<NBV>, grid, dim3(256), 0, st, (const uint32_t*)qw, perm, (uint32_t*)out, K, N)
+    switch (w_bit) {
+        case 1: L(32); break;
+        case 2: L(16); break;
+        case 4: L(8); break;
+        default: L(4); break;
+    }
+#undef L
+    return check_launch("mpq_sort_rows_kernel");
+}
+
+int gather_cols_launch(const void* x, const int32_t* perm, void* out, int M, int K, int elem_bytes, hipStream_t st) {
+    dim3 grid(cdiv(K, 256), M < 2048 ? M : 2048);
+    if (elem_bytes == 2) hipLaunchKernelGGL(gather_cols_kernel<uint16_t>, grid, dim3(256), 0, st, (const uint16_t*)x, perm, (uint16_t*)out, M, K);
+    else hipLaunchKernelGGL(gather_cols_kernel<uint32_t>, grid, dim3(256), 0, st, (const uint32_t*)x, perm, (uint32_t*)out, M, K);
+    return check_launch("gather_cols_kernel");
 }
 
 int mpq_dequant_launch(const int32_t* qw, const void* scales, const void* zeros, const int32_t* g_idx, void* out, int K,

@@ -108,6 +108,17 @@ int bie_mpq_grad_input(const void* grad_y, const int32_t* qweight, const void* s
                        const void* zeros, const int32_t* g_idx, void* grad_x, int M, int K, int N,
                        int w_bit, int group_size, int asym, int dtype, void* stream);
 
+/* Act-order (explicit g_idx) preparation.  The reference resolves g_idx[k] per weight inside quant_mm_kernel
+ * (mpq_linear_cuda_kernel.cu:300-317).  Here a layer whose g_idx is a permutation of k / group_size is re-ordered once:
+ * out[K*w/32, N] holds field k' = field perm[k'] of qweight (perm = stable argsort of g_idx, int32[K]); bit-exact.
+ * bie_mpq_forward on (out, g_idx = NULL) and bie_gather_cols(x, perm) then equals the g_idx forward of the original. */
+int bie_mpq_sort_rows(const int32_t* qweight, const int32_t* perm, int32_t* out, int K, int N,
+                      int w_bit, void* stream);
+
+/* out[M, K] = x[:, perm]  (fp16 / bf16 / fp32 by dtype). */
+int bie_gather_cols(const void* x, const int32_t* perm, void* out, int M, int K, int dtype,
+                    void* stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* MBWQ: uniform 4/2-bit (GPTQ-like) and mixed 8/6/5/4/3/2-bit (exl2 layout) linear, fp16 only   */
 /* ------------------------------------------------------------------------------------------ */

@@ -45,6 +45,10 @@ def test_argument_validation_happens_before_any_device_work():
     assert L.bie_mpq_forward_grouped(None, 9, None, None, None, None, None, None, None, 0, 1, 64, 4, 32, 0, 1, None) == -1
     assert L.bie_mpq_forward_grouped(None, 2, None, None, None, None, None, None, None, 0, 1, 64, 4, 32, 0, 1, None) == -1
     assert L.bie_workspace_init(None, 0, None) == -3
+    assert L.bie_mpq_sort_rows(None, None, None, 64, 32, 3, None) == -2
+    assert L.bie_mpq_sort_rows(None, None, None, 60, 32, 4, None) == -1
+    assert L.bie_gather_cols(None, None, None, 0, 64, 1, None) == 0  # empty batch
+    assert L.bie_gather_cols(None, None, None, 2, 64, 1, None) == -1
     n2 = (ctypes.c_int * 2)(4096, 11008)
     assert L.bie_mpq_grouped_workspace_bytes(2, n2, 1, 4096, 4) >= L.bie_mpq_workspace_bytes(1, 4096, 11008, 4)
     assert L.bie_binary_conv2d_workspace_bytes(32, 512, 7, 7, 512, 3, 1, 1, 1) == 16384 + (32 * 49 * 144 + 512 * 144) * 4  # behind the counter head

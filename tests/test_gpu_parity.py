@@ -737,16 +737,77 @@ def test_mpq_layer_backward_through_autograd():
 
 @pytest.mark.parametrize("dt", [orc.F16, orc.BF16])
 @pytest.mark.parametrize("M", [1, 7, 40, 300])
-def test_act_order_gidx_forward(dt, M):
-    """Explicit (randomly permuted) g_idx: M <= 32 through the generic kernel, M > 32 through HIP dequant + library GEMM."""
-    rng = np.random.default_rng(17 + M + dt)
+@pytest.mark.parametrize("w_bit", [4, 2])
+def test_act_order_gidx_forward(dt, M, w_bit):
+    """Explicit (randomly permuted) g_idx, the act-order form GPTQ writes: the packed rows are re-ordered once
+    (bie_mpq_sort_rows) and the implicit-group kernels run on x[:, perm] -- same W values per (k, n) as the reference's
+    per-weight g_idx lookup (mpq_linear_cuda_kernel.cu:300-317), only the fp32 summation order differs."""
+    rng = np.random.default_rng(17 + M + dt + w_bit)
     K, N, gs = 512, 384, 64
-    qw, scales, zeros, gen = rand_case(rng, K, N, 4, gs, dt, 0)
+    qw, scales, zeros, gen = rand_case(rng, K, N, w_bit, gs, dt, 0)
     g_idx = (torch.arange(K, dtype=torch.int32) // gs)[torch.randperm(K, generator=gen)]
     x = torch.randn((M, K), generator=gen).to(TDT[dt])
+    y = hip_forward(x, qw, scales, zeros, g_idx, w_bit, gs, 0)
+    ref = oracle_forward(x, qw, scales, zeros, g_idx, w_bit, gs, 0, dt)
+    assert_close(y, ref, dt, f"act-order M={M} dt={dt} w{w_bit}")
+
+
+@pytest.mark.parametrize("M", [1, 40])
+def test_gidx_with_unequal_groups_takes_the_generic_path(M):
+    """A g_idx that is not a permutation of k // group_size (groups of unequal size) cannot be re-ordered into an
+    implicit-group matrix: generic kernel (M <= 32) / HIP dequant + library GEMM (M > 32), as in round 1."""
+    from bitorch_engine.extensions import q_linear_cuda
+    rng = np.random.default_rng(171 + M)
+    K, N, gs = 512, 384, 64
+    qw, scales, zeros, gen = rand_case(rng, K, N, 4, gs, orc.F16, 0)
+    g_idx = torch.randint(0, K // gs, (K,), generator=gen, dtype=torch.int32)
+    assert q_linear_cuda.act_order_sorted(qw.to(DEV), g_idx.to(DEV), 4, gs) is None
+    x = torch.randn((M, K), generator=gen).half()
     y = hip_forward(x, qw, scales, zeros, g_idx, 4, gs, 0)
-    ref = oracle_forward(x, qw, scales, zeros, g_idx, 4, gs, 0, dt)
-    assert_close(y, ref, dt, f"act-order M={M} dt={dt}")
+    ref = oracle_forward(x, qw, scales, zeros, g_idx, 4, gs, 0, orc.F16)
+    assert_close(y, ref, orc.F16, f"unequal groups M={M}")
+
+
+@pytest.mark.parametrize("w_bit", [1, 2, 4, 8])
+def test_sort_rows_and_gather_cols_are_exact(w_bit):
+    """bie_mpq_sort_rows moves whole w-bit fields (field k' of the output = field perm[k'] of the input), bie_gather_cols moves
+    whole elements: both bit-exact against numpy, and dequant(sorted)[k'] == dequant(original, g_idx)[perm[k']]."""
+    from bitorch_engine.extensions import q_linear_cuda
+    from bitorch_engine import _hip
+    rng = np.random.default_rng(5 + w_bit)
+    K, N, gs = 256, 200, 32
+    nb = 32 // w_bit
+    qw = torch.from_numpy(rng.integers(-2 ** 31, 2 ** 31 - 1, (K // nb, N), dtype=np.int64).astype(np.int32))
+    gen = torch.Generator().manual_seed(w_bit)
+    g_idx = (torch.arange(K, dtype=torch.int32) // gs)[torch.randperm(K, generator=gen)]
+    perm, qs = q_linear_cuda.act_order_sorted(qw.to(DEV), g_idx.to(DEV), w_bit, gs)
+    perm_np = np.argsort(g_idx.numpy(), kind="stable")
+    assert np.array_equal(perm.cpu().numpy(), perm_np)
+    fields = (qw.numpy().view(np.uint32)[:, None, :] >> (np.arange(nb, dtype=np.uint32) * w_bit)[None, :, None]) & np.uint32((1 << w_bit) - 1)
+    fields = fields.reshape(K, N)[perm_np].reshape(K // nb, nb, N)
+    want = np.zeros((K // nb, N), np.uint32)
+    for i in range(nb):
+        want |= fields[:, i, :].astype(np.uint32) << np.uint32(i * w_bit)
+    assert np.array_equal(qs.cpu().numpy().view(np.uint32), want)
+    for tdt in (torch.float16, torch.float32):
+        x = torch.randn((5, K), generator=gen).to(tdt)
+        assert torch.equal(q_linear_cuda.gather_cols(x.to(DEV), perm).cpu(), x[:, torch.from_numpy(perm_np)])
+    assert q_linear_cuda.act_order_sorted(qw.to(DEV), g_idx.to(DEV), w_bit, gs) is not None
+
+
+def test_full_size_act_order_4096x11008():
+    """random-permuted g_idx at 4096x11008, M = 1 (lookup GEMV on the re-ordered matrix) and M = 4096 (MFMA GEMM)."""
+    K, N, gs, dt = 4096, 11008, 128, orc.BF16
+    rng = np.random.default_rng(77)
+    qw, scales, zeros, gen = rand_case(rng, K, N, 4, gs, dt, 0)
+    g_idx = (torch.arange(K, dtype=torch.int32) // gs)[torch.randperm(K, generator=gen)]
+    x = torch.randn((4096, K), generator=gen).to(TDT[dt])
+    y = hip_forward(x, qw, scales, zeros, g_idx, 4, gs, 0)
+    rows = torch.tensor([0, 1, 2047, 4095])
+    ref = oracle_forward(x[rows], qw, scales, zeros, g_idx, 4, gs, 0, dt)
+    assert_close(y[rows.to(DEV)], ref, dt, "act-order 4096x11008 M=4096 sampled rows")
+    y1 = hip_forward(x[:1], qw, scales, zeros, g_idx, 4, gs, 0)
+    assert_close(y1, ref[:1], dt, "act-order 4096x11008 M=1")
 
 
 # ------------------------------------------------------------------------------------------------ full-size cases of BASELINE configs
