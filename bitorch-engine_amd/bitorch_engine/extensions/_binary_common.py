@@ -49,6 +49,30 @@ def xnor_linear(xp: torch.Tensor, wp: torch.Tensor, M: int, N: int, K: int, w_la
     return y
 
 
+def fused_ok(M: int, N: int, K: int) -> bool:
+    return bool(_hip.lib().bie_binary_linear_fused_ok(M, N, K))
+
+
+def xnor_linear_fused(x, wrows, bias_a=None, scale_a=None, scale_w=None, raw_counts=False):
+    """One launch: sign-pack of (x + bias_a), XNOR-popcount against row-packed weights, `.to(dtype) * scale_a * scale_w`
+    epilogue (bie_binary_linear_fused).  raw_counts: fp32 K - 2*popc instead (no scales)."""
+    _hip.need_gpu(x, wrows)
+    x = x.contiguous()
+    M, K = x.shape
+    N = wrows.shape[0]
+    same = lambda t: None if t is None else t.to(device=x.device, dtype=x.dtype).contiguous()
+    bias_a, scale_a, scale_w = same(bias_a), same(scale_a), same(scale_w)
+    if x.data_ptr() % 16:
+        x = x.clone()
+    if bias_a is not None and bias_a.data_ptr() % 16:
+        bias_a = bias_a.clone()
+    y = torch.empty((M, N), dtype=torch.float32 if raw_counts else x.dtype, device=x.device)
+    rc = _hip.lib().bie_binary_linear_fused(_hip.ptr(x), _hip.ptr(bias_a), _hip.ptr(wrows), _hip.ptr(scale_a), _hip.ptr(scale_w),
+                                            _hip.ptr(y), M, N, K, _hip.dt(x), int(raw_counts), _hip.stream())
+    _hip.check(rc, "bie_binary_linear_fused")
+    return y
+
+
 def conv2d(x, wpacked, OC, ksize, stride, pad, dil, scale):
     _hip.need_gpu(x, wpacked)
     x = x.contiguous()

@@ -32,9 +32,15 @@ class BinaryLinearCuda(BinaryLinearBase):
     def w_pack(weights: torch.Tensor, bmm_type: BMM) -> torch.Tensor:
         return binary_linear_cuda.w_pack(weights, bmm_type.value, True)
 
-    def set_activation(self, x: torch.Tensor) -> torch.Tensor:
-        if not self.scale_a.is_nonzero():
+    def _init_scale_a(self, x: torch.Tensor) -> None:
+        # lazily initialised activation scale (reference layer.py set_activation); the reference asks `is_nonzero()` -- a
+        # device sync -- on every forward, here the answer is remembered per version of the parameter
+        from bitorch_engine.extensions.q_linear_cuda import _cached
+        if not _cached(self.scale_a.data, "nonzero", lambda: bool(self.scale_a.is_nonzero())):
             self.scale_a.data = ((2 if self.symmetric else 4) * x.abs().mean()).to(self.dtype)
+
+    def set_activation(self, x: torch.Tensor) -> torch.Tensor:
+        self._init_scale_a(x)
         return x + self.bias_a.expand_as(x)
 
     def set_weight_data(self, x: torch.Tensor) -> None:
@@ -44,6 +50,14 @@ class BinaryLinearCuda(BinaryLinearBase):
     def forward(self, x: torch.Tensor, bmm_type: BMM = BMM.ADAPTIVE) -> torch.Tensor:
         self._check_forward(x)
         self.bmm_type = bmm_type
+        if not (torch.is_grad_enabled() and (x.requires_grad or self.scale_a.requires_grad and self.training)):
+            # inference, M <= 64: the whole layer (activation bias + sign-pack, XNOR-popcount, cast, both scales) in ONE launch
+            self._init_scale_a(x)
+            x2, lead = flatten_x(x)
+            out = binary_linear_cuda.layer_forward(x2, self.bias_a.data, self.opt_weight.data, self.bmm_type.value,
+                                                   self.scale_a.data, self.scale_w) if x2.dtype == self.bias_a.dtype else None
+            if out is not None:
+                return unflatten_x(out, lead)
         x = self.set_activation(x)
         x2, lead = flatten_x(x)
         out = binary_linear_cuda.forward(x2, self.opt_weight.data, self.bmm_type.value, True).to(x.dtype)

@@ -118,6 +118,137 @@ __global__ __launch_bounds__(256) void xnor_gemv_kernel(const uint32_t* __restri
     }
 }
 
+// ---- one launch per layer forward (M <= 64) ---------------------------------------------------------------------
+// y[m][n] = dt( dt( dt(K - 2*popc) * scale_a ) * scale_w ),  bits of x taken from (x + bias_a) >= 0:
+// BinaryLinearCuda.forward = set_activation (x + bias_a) -> binary_linear_cuda.forward(...).to(dtype) -> * scale_a * scale_w
+// (reference layers/qlinear/binary/cuda/layer.py:58-63, 283-284), i.e. what the reference spends an add, a pack, a GEMM, a cast
+// and two multiplies on.  grid = (column blocks, row blocks); a workgroup sign-packs ITS x rows itself -- a thread loads 8
+// consecutive values (16 bytes) and stores one byte of bits to LDS, no cross-lane traffic -- and then sweeps its columns:
+//   ROWS == 4 (M <= 4, one row block): a wave takes 4 output columns at a time, lanes stride the K words (coalesced), shuffle
+//     reduction;
+//   ROWS == 8 (row blocks of 8): lane = (row, column sub-index): 8 columns per wave step, every lane walks the K words of its
+//     column (the 8 lanes of a column share the address) against its own packed x row in LDS (row stride KW + 1 words:
+//     conflict-free), no reduction at all.
+// Every workgroup of a row block repeats that block's packing (L2 reads), so the column blocks are kept wide: the packing is
+// 32 / columns-per-workgroup of the XNOR work.
+// The sign of fl(x + b) in the layer dtype equals the sign of the fp32 sum: a floating-point sum of two finite numbers never
+// underflows to zero, so only exact cancellation gives 0 (>= 0 either way).
+template <int DT>
+__device__ __forceinline__ void load8(const void* p, long i, float (&v)[8]) {
+    if constexpr (DT == BIE_F32) {
+        const float4_t a = *reinterpret_cast<const float4_t*>((const float*)p + i);
+        const float4_t b = *reinterpret_cast<const float4_t*>((const float*)p + i + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+        const uint4_t a = *reinterpret_cast<const uint4_t*>((const uint16_t*)p + i);
+        const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if constexpr (DT == BIE_BF16) {
+                v[2 * q] = __uint_as_float(w[q] << 16);
+                v[2 * q + 1] = __uint_as_float(w[q] & 0xffff0000u);
+            } else {
+                v[2 * q] = f16_bits_to_f32(w[q] & 0xffffu);
+                v[2 * q + 1] = f16_bits_to_f32(w[q] >> 16);
+            }
+        }
+    }
+}
+
+template <int DT, int ROWS>
+__global__ __launch_bounds__(256) void xnor_fused_kernel(const void* __restrict__ x, const void* __restrict__ bias_a,
+                                                         const uint32_t* __restrict__ Wt, const void* __restrict__ scale_a,
+                                                         const void* __restrict__ scale_w, void* __restrict__ y, int M, int N,
+                                                         int K, int cols_per_wg, int y_f32) {
+    extern __shared__ uint32_t xb[];  // [ROWS][KW + 1]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int KW = K >> 5, XS = KW + 1, KB = K >> 3;
+    const int m0 = blockIdx.y * ROWS;
+    uint8_t* xbytes = reinterpret_cast<uint8_t*>(xb);
+#pragma unroll 4
+    for (int t = threadIdx.x; t < ROWS * KB; t += 256) {
+        const int r = t / KB, kb = t - r * KB;
+        uint32_t bits = 0;
+        if (m0 + r < M) {
+            float v[8];
+            load8<DT>(x, (long)(m0 + r) * K + kb * 8, v);
+            if (bias_a) {
+                float b[8];
+                load8<DT>(bias_a, kb * 8, b);
+#pragma unroll
+                for (int q = 0; q < 8; q++) v[q] += b[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) bits |= (uint32_t)(v[q] >= 0.0f) << q;
+        }
+        xbytes[r * XS * 4 + kb] = (uint8_t)bits;
+    }
+    __syncthreads();
+    const float sa = scale_a ? dt_traits<DT>::load(scale_a, 0) : 1.0f;
+    const float sw = scale_w ? dt_traits<DT>::load(scale_w, 0) : 1.0f;
+    auto put = [&](int m, int n, int pc) {
+        float v = (float)(K - 2 * pc);
+        if (y_f32) {  // the extension-level forward: raw fp32 counts (binary_linear_cuda.forward returns float)
+            ((float*)y)[(long)m * N + n] = v;
+            return;
+        }
+        v = dt_traits<DT>::round(v);
+        if (scale_a) v = dt_traits<DT>::round(v * sa);
+        if (scale_w) v = dt_traits<DT>::round(v * sw);
+        dt_traits<DT>::store(y, (long)m * N + n, v);
+    };
+    const int col0 = blockIdx.x * cols_per_wg;
+    const int col1 = min(N, col0 + cols_per_wg);
+    if constexpr (ROWS == 4) {
+        for (int nb = col0 + wave * 4; nb < col1; nb += 16) {  // 4 columns at a time: their loads are in flight together
+            int acc[4][4] = {};
+            const uint32_t* wr[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) wr[c] = Wt + (long)min(nb + c, N - 1) * KW;
+            for (int k = lane; k < KW; k += 64) {
+                uint32_t w[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) w[c] = wr[c][k];
+#pragma unroll
+                for (int m = 0; m < 4; m++) {  // rows >= M hold zeros: harmless
+                    const uint32_t xv = xb[m * XS + k];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) acc[c][m] += __builtin_popcount(w[c] ^ xv);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    if (m >= M) break;
+                    int v = acc[c][m];
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+                    if (lane == 0 && nb + c < col1) put(m, nb + c, v);
+                }
+        }
+    } else {
+        const int r = lane & 7, cs = lane >> 3;
+        const uint32_t* xr = xb + r * XS;
+        for (int nb = col0 + wave * 8; nb < col1; nb += 32) {
+            const int n = nb + cs;
+            const bool live = n < col1 && m0 + r < M;
+            const uint32_t* wr = Wt + (long)(n < N ? n : N - 1) * KW;
+            int pc = 0;
+            int k = 0;
+            if ((KW & 3) == 0)
+                for (; k < KW; k += 4) {
+                    const uint4_t w = *reinterpret_cast<const uint4_t*>(wr + k);
+                    pc += __builtin_popcount(w.x ^ xr[k]) + __builtin_popcount(w.y ^ xr[k + 1]) +
+                          __builtin_popcount(w.z ^ xr[k + 2]) + __builtin_popcount(w.w ^ xr[k + 3]);
+                }
+            for (; k < KW; k++) pc += __builtin_popcount(wr[k] ^ xr[k]);
+            if (live) put(m0 + r, n, pc);
+        }
+    }
+}
+
 // byte-granular compatibility kernel: any K % 8 == 0, either weight layout.  One thread per output.
 __global__ __launch_bounds__(256) void xnor_bytes_kernel(const uint8_t* __restrict__ X, const uint8_t* __restrict__ W,
                                                          float* __restrict__ y, long M, long N, long KB, int w_layout,
@@ -351,6 +482,33 @@ int binary_linear_launch(const uint8_t* xp, const uint8_t* wp, float* y, long M,
                            (int)K, scale, 0L, 0L, 0L);
     }
     return check_launch("xnor_gemm_kernel");
+}
+
+// 1 <= M <= 64 (beyond that packing x once and running the tiled XNOR GEMM is the better split), K % 32 == 0
+bool binary_linear_fused_ok(long M, long N, long K) {
+    return M >= 1 && M <= 64 && N >= 1 && K >= 32 && K % 32 == 0 && K <= 262144 && N < (1L << 31);
+}
+
+template <int DT>
+static void fused_launch_dt(const void* x, const void* bias_a, const uint8_t* wp, const void* sa, const void* sw, void* y, int M, int N, int K, int y_f32, hipStream_t st) {
+    const int rows = M <= 4 ? 4 : 8;
+    const size_t lds = (size_t)rows * (K / 32 + 1) * 4;
+    const int row_blocks = M <= 4 ? 1 : (int)cdivl(M, 8);
+    const int step = M <= 4 ? 16 : 32;                                  // columns one workgroup covers per sweep
+    const int want = M <= 4 ? 256 : (row_blocks >= 4 ? 64 : 128);       // column blocks: wide enough that the repeated packing stays small
+    int cols = (int)cdivl(cdivl(N, want), step) * step;
+    if (cols < step) cols = step;
+    dim3 grid((unsigned)cdivl(N, cols), (unsigned)row_blocks);
+    if (M <= 4) hipLaunchKernelGGL((xnor_fused_kernel<DT, 4>), grid, dim3(256), lds, st, x, bias_a, (const uint32_t*)wp, sa, sw, y, M, N, K, cols, y_f32);
+    else hipLaunchKernelGGL((xnor_fused_kernel<DT, 8>), grid, dim3(256), lds, st, x, bias_a, (const uint32_t*)wp, sa, sw, y, M, N, K, cols, y_f32);
+}
+
+int binary_linear_fused_launch(const void* x, const void* bias_a, const uint8_t* wp, const void* sa, const void* sw, void* y, long M,
+                               long N, long K, int dtype, int y_f32, hipStream_t st) {
+    if (dtype == BIE_F16) fused_launch_dt<BIE_F16>(x, bias_a, wp, sa, sw, y, (int)M, (int)N, (int)K, y_f32, st);
+    else if (dtype == BIE_BF16) fused_launch_dt<BIE_BF16>(x, bias_a, wp, sa, sw, y, (int)M, (int)N, (int)K, y_f32, st);
+    else fused_launch_dt<BIE_F32>(x, bias_a, wp, sa, sw, y, (int)M, (int)N, (int)K, y_f32, st);
+    return check_launch("xnor_fused_kernel");
 }
 
 size_t binary_conv_workspace_bytes(int B, int C, int H, int W, int OC, int ks, int stride, int pad, int dil) {

@@ -51,6 +51,9 @@ int pack_rows_launch(const void* a, uint8_t* out, long n_bytes, int dtype, hipSt
 int pack_cols_launch(const void* w, uint8_t* out, long N, long K, int dtype, hipStream_t st);
 int binary_image_pack_launch(const void* w, uint8_t* image, long N, long K, int layout, int dtype, hipStream_t st);
 int binary_image_unpack_launch(const uint8_t* image, uint8_t* rowpacked, long N, long K, int layout, hipStream_t st);
+bool binary_linear_fused_ok(long M, long N, long K);
+int binary_linear_fused_launch(const void* x, const void* bias_a, const uint8_t* wp, const void* sa, const void* sw, void* y, long M,
+                               long N, long K, int dtype, int y_f32, hipStream_t st);
 int binary_linear_launch(const uint8_t* xp, const uint8_t* wp, float* y, long M, long N, long K, int w_layout, float scale,
                          hipStream_t st);
 size_t binary_conv_workspace_bytes(int B, int C, int H, int W, int OC, int ks, int stride, int pad, int dil);
@@ -376,6 +379,20 @@ int bie_binary_linear_forward(const uint8_t* xpacked, const uint8_t* wpacked, fl
     BIE_REQUIRE(xpacked && wpacked && y && M > 0 && N > 0 && K > 0 && K % 8 == 0, BIE_ERR_INVALID_ARG, "bie_binary_linear_forward: M=%ld N=%ld K=%ld (K %% 8 == 0 required)", M, N, K);
     BIE_REQUIRE(w_layout == 0 || w_layout == 1, BIE_ERR_INVALID_ARG, "bie_binary_linear_forward: w_layout %d", w_layout);
     return binary_linear_launch(xpacked, wpacked, y, M, N, K, w_layout, scale, as_stream(stream));
+}
+
+int bie_binary_linear_fused_ok(long M, long N, long K) { return binary_linear_fused_ok(M, N, K) ? 1 : 0; }
+
+int bie_binary_linear_fused(const void* x, const void* bias_a, const uint8_t* wpacked, const void* scale_a, const void* scale_w,
+                            void* y, long M, long N, long K, int dtype, int y_f32, void* stream) {
+    BIE_REQUIRE(dtype >= 0 && dtype <= 2, BIE_ERR_UNSUPPORTED, "bie_binary_linear_fused: dtype %d", dtype);
+    BIE_REQUIRE(!y_f32 || (!scale_a && !scale_w), BIE_ERR_INVALID_ARG, "bie_binary_linear_fused: y_f32 (raw counts) takes no scales");
+    BIE_REQUIRE(binary_linear_fused_ok(M, N, K), BIE_ERR_UNSUPPORTED,
+                "bie_binary_linear_fused: M=%ld N=%ld K=%ld outside the one-launch range (1 <= M <= 64, K %% 32 == 0)", M, N, K);
+    BIE_REQUIRE(x && wpacked && y, BIE_ERR_INVALID_ARG, "bie_binary_linear_fused: NULL tensor pointer");
+    BIE_REQUIRE(((reinterpret_cast<uintptr_t>(wpacked) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(bias_a)) & 15) == 0, BIE_ERR_INVALID_ARG,
+                "bie_binary_linear_fused: x, bias_a and the packed weights must be 16-byte aligned");
+    return binary_linear_fused_launch(x, bias_a, wpacked, scale_a, scale_w, y, M, N, K, dtype, y_f32 ? 1 : 0, as_stream(stream));
 }
 
 size_t bie_binary_conv2d_workspace_bytes(int B, int C, int H, int W, int OC, int ksize, int stride, int pad, int dilation) {

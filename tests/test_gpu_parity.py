@@ -991,6 +991,62 @@ def test_binary_cuda_weight_images_bit_exact(N, K, bmm, kind):
     assert np.array_equal(y, np.where(x >= 0, 1.0, -1.0) @ np.where(w >= 0, 1.0, -1.0).T)
 
 
+@pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,N,K", [(1, 64, 256), (2, 100, 96), (4, 4096, 4096), (5, 72, 160), (8, 64, 11008), (9, 40, 2048), (16, 33, 96),
+                                   (17, 260, 512), (33, 64, 128), (64, 96, 4096)])
+def test_binary_layer_forward_in_one_launch(M, N, K, tdt):
+    """bie_binary_linear_fused (M <= 64): sign bits of (x + bias_a), XNOR-popcount, `.to(dtype) * scale_a * scale_w`, all in one
+    kernel.  Exact against the oracle's integers pushed through the layer's own expression (reference
+    layers/qlinear/binary/cuda/layer.py:58-63, 283), every lane mapping (M <= 4 / 8 / 16 / 32 / 64), K not a multiple of 64 or
+    128, ragged N; the raw-count form equals the two-launch extension forward."""
+    from bitorch_engine.extensions import binary_linear_cuda
+    from bitorch_engine.extensions._binary_common import pack_rows, xnor_linear, xnor_linear_fused, fused_ok
+    gen = torch.Generator().manual_seed(M * 7 + N + K)
+    x = torch.randn((M, K), generator=gen).to(tdt)
+    b = (torch.randn(K, generator=gen) * 0.5).to(tdt)
+    w = torch.randn((N, K), generator=gen)
+    sa = torch.tensor(0.7312, dtype=tdt)
+    sw = torch.tensor(0.0131, dtype=tdt)
+    assert fused_ok(M, N, K)
+    wrows = pack_rows(w.to(DEV))
+    y = xnor_linear_fused(x.to(DEV), wrows, b.to(DEV), sa.to(DEV), sw.to(DEV)).cpu()
+    xb = (x + b)                                                       # the layer dtype's addition, as set_activation does it
+    ints = orc.binary_linear_rowpacked(orc.binary_pack_rows(xb.float().numpy()), orc.binary_pack_rows(w.numpy()), K)
+    expect = torch.from_numpy(ints.astype(np.float32)).to(tdt) * sa * sw
+    assert y.dtype == tdt and torch.equal(y, expect)
+    raw = xnor_linear_fused(x.to(DEV), wrows, raw_counts=True)
+    assert raw.dtype == torch.float32
+    assert torch.equal(raw, xnor_linear(pack_rows(x.to(DEV)), wrows, M, N, K, 0, 1.0))
+    assert torch.equal(raw, binary_linear_cuda.forward(x.to(DEV), w.to(DEV), 3, True))
+
+
+def test_binary_cuda_layer_uses_the_fused_forward_and_matches_the_composed_one():
+    from bitorch_engine.layers.qlinear.binary.cuda import BinaryLinearCuda
+    from bitorch_engine.extensions import binary_linear_cuda
+    torch.manual_seed(9)
+    K, N = 512, 192
+    layer = BinaryLinearCuda(K, N, dtype=torch.half)
+    layer.set_weight_data(torch.randn(N, K).half())
+    layer.bias_a.data = (torch.randn(K) * 0.3).half()
+    layer.eval().to(DEV)
+    layer.generate_quantized_weight(qweight_only=True)
+    calls = []
+    orig = binary_linear_cuda.layer_forward
+    binary_linear_cuda.layer_forward = lambda *a: calls.append(1) or orig(*a)
+    try:
+        for lead in ((1,), (3, 5), (80,)):                              # 80 rows: outside the fused range -> composed path
+            x = torch.randn(lead + (K,)).half().to(DEV)
+            with torch.no_grad():
+                y = layer(x)
+            xa = layer.set_activation(x).reshape(-1, K)
+            comp = binary_linear_cuda.forward(xa, layer.qweight.data, layer.bmm_type.value, True)
+            comp = comp.to(torch.half).view(lead + (N,)) * layer.scale_a * layer.scale_w
+            assert torch.equal(y, comp)
+    finally:
+        binary_linear_cuda.layer_forward = orig
+    assert len(calls) == 3
+
+
 def test_binary_cuda_layer_checkpoint_is_the_reference_image():
     from bitorch_engine.layers.qlinear.binary.cuda import BinaryLinearCuda
     torch.manual_seed(8)

@@ -1,4 +1,12 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
-echo "== pytest"; timeout 900 python -m pytest tests -m gpu -q --maxfail=10 -p no:cacheprovider > gpurun_out/pytest_ao.log 2>&1; tail -2 gpurun_out/pytest_ao.log; grep -E "^(FAILED|ERROR)" gpurun_out/pytest_ao.log | head -8; grep -E "^E  " gpurun_out/pytest_ao.log | head -8
-echo "== act-order timing"; timeout 300 python tools/act_order_time.py 2>&1 | tail -3
+echo "== pytest"; timeout 900 python -m pytest tests -m gpu -q --maxfail=10 -p no:cacheprovider > gpurun_out/pytest_bin.log 2>&1; tail -2 gpurun_out/pytest_bin.log; grep -E "^(FAILED|ERROR)" gpurun_out/pytest_bin.log | head -8; grep -E "^E  " gpurun_out/pytest_bin.log | head -8
+echo "== binary bench"; timeout 300 python - <<'PY'
+import sys, json
+sys.path.insert(0, "bitorch-engine_amd")
+import torch, bench
+from bitorch_engine import _hip
+dev = torch.device("cuda:0")
+for r in bench.bench_binary(dev, _hip.lib()):
+    print(json.dumps(r), flush=True)
+PY
