@@ -82,6 +82,8 @@ constexpr size_t BIE_WS_HEAD_BYTES = 16384;
 constexpr int BIE_WS_COUNTERS = (int)(BIE_WS_HEAD_BYTES / 8);  // 2048 tiles = 131072 output columns per launch, each protocol
 constexpr int BIE_WS_GEN_OFFSET = BIE_WS_COUNTERS;             // in 32-bit words from the start of the workspace
 
+unsigned next_launch_epoch();  // splitk.hip
+
 // shared split-K epilogue (splitk.hip): y[m][n] = dt( sum_s part[s][m][n] ) (+ bias[n])
 int launch_splitk_finalize(const float* part, const void* bias, void* y, int S, int M, int N, int dtype,
                            hipStream_t stream);

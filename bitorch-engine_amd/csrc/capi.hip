@@ -44,7 +44,7 @@ int mbwq_exl2_dequant_launch(const int32_t* qw, const void* scales, const void* 
 int mbwq_q4_forward_launch(const void* x, const int32_t* qw, const void* scales, const void* zeros, const int16_t* perm,
                            void* y, float* part, int M, int K, int N, int bits, int group_size, hipStream_t st);
 int mbwq_exl2_forward_launch(const void* x, const int32_t* qw, const void* scales, const void* zeros, const int16_t* perm,
-                             const int16_t* gmap, const int* rows7, void* y, float* part, int M, int K, int N,
+                             const int16_t* gmap, const int* rows7, void* y, float* head, float* part, int M, int K, int N,
                              hipStream_t st);
 // binary.hip
 int pack_rows_launch(const void* a, uint8_t* out, long n_bytes, int dtype, hipStream_t st);
@@ -326,7 +326,7 @@ int bie_mbwq_exl2_forward(const void* x, const int32_t* qweight, const void* sca
     if (rc) return rc;
     const size_t need = WS_HEAD + mbwq_workspace_bytes(M, K, N);
     BIE_REQUIRE(workspace && workspace_bytes >= need, BIE_ERR_WORKSPACE, "bie_mbwq_exl2_forward: workspace of %zu bytes required, got %zu", need, workspace_bytes);
-    return mbwq_exl2_forward_launch(x, qweight, scales, zeros, q_perm, q_group_map, rows7_host, y, (float*)workspace + WS_HEAD / sizeof(float), M, K, N, as_stream(stream));
+    return mbwq_exl2_forward_launch(x, qweight, scales, zeros, q_perm, q_group_map, rows7_host, y, (float*)workspace, (float*)workspace + WS_HEAD / sizeof(float), M, K, N, as_stream(stream));
 }
 
 // ---------------------------------------------------------------------------------------------- binary

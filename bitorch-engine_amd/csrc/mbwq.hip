@@ -230,13 +230,15 @@ __global__ __launch_bounds__(256) void exl2_gemv_kernel(const uint16_t* __restri
 // reference's single-rounding __hfma2(q, s, -z) exactly, v_dot2_f32_f16 accumulates in fp32 against x pairs broadcast from
 // LDS (x is gathered through q_perm once per block, as fp16).  ~3.5 VALU per weight instead of ~6.5 in the scalar-fp32
 // kernel below, and no finalize launch when one slab covers K.
-constexpr int EX2_NW = 16;
-template <int MT>
-__global__ __launch_bounds__(EX2_NW * 64) void exl2_gemv2_kernel(const uint16_t* __restrict__ x, const uint32_t* __restrict__ qw,
-                                                                 const uint16_t* __restrict__ scales, const uint16_t* __restrict__ zeros,
-                                                                 const uint16_t* __restrict__ perm, const uint16_t* __restrict__ gmap,
-                                                                 float* __restrict__ part, uint16_t* __restrict__ y, Exl2Rows rows, int M,
-                                                                 int K, int N, int chunks_per_slab, int S) {
+// EX2_NW waves per workgroup: 16 (one workgroup per CU) when the column blocks alone fill most of the chip (measured 17.8 us
+// against 19.4 us at 4096x11008), 8 (two per CU) + K slabs for narrower layers (4096x4096: 7.9 us against 9.1 us)
+template <int MT, int EX2_NW>
+__global__ __launch_bounds__(EX2_NW * 64, (EX2_NW == 8 ? 2 : 1)) void exl2_gemv2_kernel(const uint16_t* __restrict__ x, const uint32_t* __restrict__ qw,
+                                                                    const uint16_t* __restrict__ scales, const uint16_t* __restrict__ zeros,
+                                                                    const uint16_t* __restrict__ perm, const uint16_t* __restrict__ gmap,
+                                                                    unsigned long long* __restrict__ gran, unsigned* __restrict__ gen,
+                                                                    uint16_t* __restrict__ y, Exl2Rows rows, int M, int K, int N,
+                                                                    int chunks_per_slab, int S, unsigned epoch) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem2[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -375,11 +377,63 @@ __global__ __launch_bounds__(EX2_NW * 64) void exl2_gemv2_kernel(const uint16_t*
         float tot = 0.f;
 #pragma unroll
         for (int wv = 0; wv < EX2_NW; wv++) tot += red[(wv * MT + om) * 64 + ol];
-        if (om < M && on < N) {
-            if (S == 1) y[(long)om * N + on] = f32_to_f16_bits(tot);
-            else part[((long)blockIdx.y * M + om) * N + on] = tot;
+        if (S > 1) {
+            // K slabs: the tagged-granule reduction of the lookup GEMV (mpq_gemv_lut.hip) -- slabs 0..S-2 publish {fp32, tag} with
+            // one write-through store per column and retire; the last slab's workgroup (highest block ids: dispatched after every
+            // publisher, which never waits) polls them and adds in slab order.  No finalize launch, no atomics, deterministic.
+            const unsigned gen_next = gen[blockIdx.x] + 1u;
+            const unsigned tag = epoch | (gen_next & 0xffu);
+            const long ncat = (long)gridDim.x * 64, col = (long)blockIdx.x * 64 + ol;
+            const int slab = blockIdx.y;
+            if (slab != S - 1) {
+                const unsigned long long gval = ((unsigned long long)tag << 32) | __float_as_uint(tot);
+                __hip_atomic_store(gran + ((long)slab * MT + om) * ncat + col, gval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            float v = 0.0f;
+            for (int s0 = 0; s0 < S - 1; s0 += 4) {
+                unsigned long long gv[4];
+                bool ready;
+                int spins = 0;
+                do {
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++) {
+                        const int sidx = (s0 + jj < S - 1) ? s0 + jj : S - 2;
+                        gv[jj] = __hip_atomic_load(gran + ((long)sidx * MT + om) * ncat + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    ready = true;
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++) ready = ready && ((unsigned)(gv[jj] >> 32) == tag);
+                    ready = __builtin_amdgcn_ballot_w64(!ready) == 0;
+                    if (!ready) __builtin_amdgcn_s_sleep(2);
+                } while (!ready && ++spins < (1 << 24));
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++)
+                    if (s0 + jj < S - 1) v += __uint_as_float((unsigned)gv[jj]);
+            }
+            tot = v + tot;
+            if (tid == 0) gen[blockIdx.x] = gen_next;  // the next launch (or a replay of this one) tags differently
         }
+        if (om < M && on < N) y[(long)om * N + on] = f32_to_f16_bits(tot);
     }
+}
+
+// decode (M <= 2): column blocks x K slabs ~ 512 workgroups of 8 waves (two per CU -> one round), slabs in whole multiples of
+// 8 chunks so that the 8 waves of a workgroup get equal shares; at most BIE_WS_COUNTERS column blocks use the slab reduction
+static void exl2_decode_plan(int K, int N, int& cps, int& S, int& nw) {
+    const int C = K / 32, colblocks = cdiv(N, 64);
+    if (colblocks >= 160) {  // wide layers: 16-wave workgroups, one K slab
+        nw = 16;
+        cps = C;
+        S = 1;
+        return;
+    }
+    nw = 8;
+    int want = (512 + colblocks / 2) / colblocks;
+    if (want < 1) want = 1;
+    cps = cdiv(cdiv(C, want), nw) * nw;
+    if (cps > C) cps = C;
+    S = cdiv(C, cps);
 }
 
 static int exl2_slabs(int K, int N) {
@@ -403,6 +457,10 @@ size_t mbwq_workspace_bytes(int M, int K, int N) {
     const int S = cdiv(K / 32, cps);
     const int mc = M < 8 ? M : 8;
     size_t c = (size_t)S * mc * N * sizeof(float);
+    int cps2, S2, nw2;
+    exl2_decode_plan(K, N, cps2, S2, nw2);
+    const size_t d = M <= 2 && S2 > 1 ? (size_t)(S2 - 1) * M * cdiv(N, 64) * 64 * 8 : 0;  // decode granules
+    if (d > c) c = d;
     size_t r = a > b ? a : b;
     return r > c ? r : c;
 }
@@ -439,31 +497,33 @@ int mbwq_q4_forward_launch(const void* x, const int32_t* qw, const void* scales,
 }
 
 int mbwq_exl2_forward_launch(const void* x, const int32_t* qw, const void* scales, const void* zeros, const int16_t* perm,
-                             const int16_t* gmap, const int* rows7, void* y, float* part, int M, int K, int N,
+                             const int16_t* gmap, const int* rows7, void* y, float* head, float* part, int M, int K, int N,
                              hipStream_t st) {
     Exl2Rows rows;
     for (int i = 0; i < 6; i++) rows.r[i] = rows7[i];
     if (M <= 2) {  // decode path
-        const int C = K / 32, colblocks = cdiv(N, 64);
-        int S = colblocks >= 160 ? 1 : cdiv(256, colblocks);
-        if (S > C / 4) S = C / 4 > 0 ? C / 4 : 1;  // keep a few chunks per slab
-        int cps2 = cdiv(C, S);
-        S = cdiv(C, cps2);
+        const int colblocks = cdiv(N, 64);
+        int cps2, S, nw;
+        exl2_decode_plan(K, N, cps2, S, nw);
         const int MT = M;
-        size_t lds2 = (size_t)EX2_NW * 4 * MT * 32 * sizeof(uint16_t);  // wave-private x chunk buffers
-        const size_t red = (size_t)EX2_NW * MT * 64 * sizeof(float);
+        size_t lds2 = (size_t)nw * 4 * MT * 32 * sizeof(uint16_t);  // wave-private x chunk buffers
+        const size_t red = (size_t)nw * MT * 64 * sizeof(float);
         if (lds2 < red) lds2 = red;
         dim3 grid2(colblocks, S);
-#define L2(MTV)                                                                                                            \
-    hipLaunchKernelGGL(exl2_gemv2_kernel<MTV>, grid2, dim3(EX2_NW * 64), lds2, st, (const uint16_t*)x, (const uint32_t*)qw,    \
-                       (const uint16_t*)scales, (const uint16_t*)zeros, (const uint16_t*)perm, (const uint16_t*)gmap, part,      \
-                       (uint16_t*)y, rows, M, K, N, cps2, S)
-        if (MT == 1) L2(1); else L2(2);
+        const unsigned epoch = next_launch_epoch();
+        unsigned* gen = reinterpret_cast<unsigned*>(head) + BIE_WS_GEN_OFFSET;
+        unsigned long long* gran = reinterpret_cast<unsigned long long*>(part);
+#define L2(MTV, NWV)                                                                                                       \
+    hipLaunchKernelGGL((exl2_gemv2_kernel<MTV, NWV>), grid2, dim3(NWV * 64), lds2, st, (const uint16_t*)x, (const uint32_t*)qw, \
+                       (const uint16_t*)scales, (const uint16_t*)zeros, (const uint16_t*)perm, (const uint16_t*)gmap, gran, gen, \
+                       (uint16_t*)y, rows, M, K, N, cps2, S, epoch)
+        if (nw == 16) {
+            if (MT == 1) L2(1, 16); else L2(2, 16);
+        } else {
+            if (MT == 1) L2(1, 8); else L2(2, 8);
+        }
 #undef L2
-        int rc = check_launch("exl2_gemv2_kernel");
-        if (rc) return rc;
-        if (S > 1) return launch_splitk_finalize(part, nullptr, (uint16_t*)y, S, M, N, BIE_F16, st);
-        return BIE_OK;
+        return check_launch("exl2_gemv2_kernel");
     }
     const int cps = exl2_slabs(K, N);
     const int S = cdiv(K / 32, cps);

@@ -1009,10 +1009,7 @@ int mpq_gemv_lut_launch(int nsets, const int32_t* const* qw, const void* const* 
     a.S = p.S;
     a.groups_per_wave = p.gpw;
     a.hshift = p.H == 4 ? 2 : (p.H == 2 ? 1 : 0);
-    static std::atomic<unsigned> calls{0};
-    unsigned e = (calls.fetch_add(1, std::memory_order_relaxed) + 1u) & 0xffffffu;
-    if (e == 0) e = (calls.fetch_add(1, std::memory_order_relaxed) + 1u) & 0xffffffu;  // tag 0 = never written
-    a.epoch = e << 8;
+    a.epoch = next_launch_epoch();
     const int grid = tiles * p.S;
     if (lut_use_mfma(M) && !p.coop) {
         if (dtype == BIE_F16) lutm_launch<BIE_F16>(a, p.rpg, grid, zm, st);

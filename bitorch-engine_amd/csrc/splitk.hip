@@ -2,6 +2,7 @@
 //   y[m][n] = fl16( sum_{s=0..S-1} part[s][m][n] ) (+ bias[n], rounded again like `out + bias` in torch)
 // plus the thread-local error string of the C ABI.
 #include "bie_common.h"
+#include <atomic>
 #include <string.h>
 
 namespace bie {
@@ -43,6 +44,15 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __res
     float o = dt_traits<DT>::round(v);
     if (bias) o = o + dt_traits<DT>::load(bias, i % N);
     dt_traits<DT>::store(y, i, o);
+}
+
+// Upper 24 bits of the granule tags of one launch of a tagged-granule reduction (mpq_gemv_lut.hip, mbwq.hip): a process-wide call
+// number, never 0 (tag 0 = granule never written), shared by every kernel that uses the generation words of a workspace head.
+unsigned next_launch_epoch() {
+    static std::atomic<unsigned> calls{0};
+    unsigned e = (calls.fetch_add(1, std::memory_order_relaxed) + 1u) & 0xffffffu;
+    if (e == 0) e = (calls.fetch_add(1, std::memory_order_relaxed) + 1u) & 0xffffffu;
+    return e << 8;
 }
 
 int launch_splitk_finalize(const float* part, const void* bias, void* y, int S, int M, int N, int dtype, hipStream_t st) {
