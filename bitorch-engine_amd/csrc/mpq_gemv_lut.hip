@@ -576,35 +576,52 @@ __global__ __launch_bounds__(256) void mpq_gemv_lutc_kernel(const LutArgs a) {
 }
 
 // =====================================================================================================================
-// Matrix-pipe form (M <= 16): the products go to the otherwise idle MFMA unit.  v_mfma_f32_32x32x16 wants, per lane, the 8
-// consecutive-k weights of ONE column -- exactly one packed W4 word -- so a wave takes a 64-column tile as two 32-column
-// fragments, lane (h, j) = (lane >> 5, lane & 31) owning packed row 2*rp + h of columns j and 32 + j.  A word's eight table
-// values are read as 16-bit halves (ds_read_u16) and paired with one v_lshl_or_b32 each into the four operand registers,
-// the activations enter as the second operand: lane (h, m) supplies x[m][16*rp + 8*h .. +8] (one 16-byte buffer load; lanes
-// m >= M read out of bounds = 0), so D[n][m] accumulates all M rows at the price of one.  Per word: 3 + 8 VALU, 8 LDS reads,
-// 1/… MFMA; no FMAs, no scalar unpacking of x.  The two lane halves of a wave build 8 table entries each for the same 64
-// columns (tab[wave][q][column]: bank = column mod 32 within each half -> conflict-free).
+// Matrix-pipe form (M <= 16): the products go to the otherwise idle MFMA unit.  v_mfma_f32_16x16x32 wants, per lane, the 8
+// consecutive-k weights of ONE column -- exactly one packed W4 word.  Lane (kb, c) = (lane >> 4, lane & 15) loads FOUR adjacent
+// columns 4c .. 4c+3 of packed row 4*rq + kb with one 16-byte load (a wave instruction = 4 full 256-byte row segments), the
+// four words are the A fragments of four MFMAs: fragment f's row c is column 4c + f of the tile.  A word's eight table values
+// are read as 16-bit halves (ds_read_u16) and paired with one v_lshl_or_b32 each into the four operand registers.  The
+// activations enter as the B operand: lane (kb, m) supplies x[m][32*rq + 8*kb .. +8] (one 16-byte buffer load; lanes m >= M
+// read out of bounds = 0), so D accumulates all M rows at the price of one: lane (kb', m) ends with acc[f][r] = column
+// 16*kb' + 4*r + f.  Per word: 2 + 8 + 4 VALU, 8 LDS reads, one MFMA; no FMAs, no scalar unpacking of x.
+// Table layout (per wave 8 KiB): byte ((f >> 1) << 12) | (q << 8) | ((f & 1) << 7) | (rep << 6) | (c << 2) -- the f part is an
+// instruction offset, q is the byte v_perm_b32 drops into the address, and rep = kb & 1 holds a second copy so that the 32
+// lanes the LDS serves per clock (two kb values x 16 c) fall on 32 different banks.  Lane (kb, c) builds the entries
+// q = 4*kb .. 4*kb+3 of its four columns.
 // =====================================================================================================================
-typedef float lutm_acc_t __attribute__((ext_vector_type(16)));
+typedef float lutm_acc_t __attribute__((ext_vector_type(4)));
 
 template <int DT>
 __device__ __forceinline__ lutm_acc_t lutm_mfma(const uint32_t (&w)[4], uint4_t xf, lutm_acc_t c) {
     const uint4_t wv = {w[0], w[1], w[2], w[3]};
     if constexpr (DT == BIE_F16)
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, wv), __builtin_bit_cast(half8_t, xf), c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, wv), __builtin_bit_cast(half8_t, xf), c, 0, 0, 0);
     else
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wv), __builtin_bit_cast(bf16x8_t, xf), c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv), __builtin_bit_cast(bf16x8_t, xf), c, 0, 0, 0);
+}
+
+template <int OFF>
+__device__ __forceinline__ void lutm_issue8(uint32_t (&l)[8], uint32_t ca, uint32_t we, uint32_t wo) {
+    asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(l[0]) : "v"(lut_addr<0>(ca, we)), "n"(OFF) : "memory");
+    asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(l[1]) : "v"(lut_addr<0>(ca, wo)), "n"(OFF) : "memory");
+    asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(l[2]) : "v"(lut_addr<1>(ca, we)), "n"(OFF) : "memory");
+    asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(l[3]) : "v"(lut_addr<1>(ca, wo)), "n"(OFF) : "memory");
+    asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(l[4]) : "v"(lut_addr<2>(ca, we)), "n"(OFF) : "memory");
+    asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(l[5]) : "v"(lut_addr<2>(ca, wo)), "n"(OFF) : "memory");
+    asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(l[6]) : "v"(lut_addr<3>(ca, we)), "n"(OFF) : "memory");
+    asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(l[7]) : "v"(lut_addr<3>(ca, wo)), "n"(OFF) : "memory");
 }
 
 template <int DT, int ZM, int RPG, int NW>
-__global__ __launch_bounds__(NW * 64) void mpq_gemv_lutm_kernel(const LutArgs a) {
+__global__ __launch_bounds__(NW * 64, 2) void mpq_gemv_lutm_kernel(const LutArgs a) {
     constexpr int NB = 8;
-    constexpr int RP = RPG / 2;  // row pairs per unit
-    __shared__ __attribute__((aligned(4096))) uint32_t tab[NW * 16 * 64];  // the only LDS object: starts at LDS address 0
+    constexpr int RQ = RPG / 4;  // row quads (32 k) per unit
+    static_assert(NW <= 8 && RPG % 4 == 0, "wave bits of the table address / whole row quads");
+    __shared__ __attribute__((aligned(8192))) uint32_t tab[NW * 2048];  // the only LDS object: starts at LDS address 0
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int j = lane & 31, h = lane >> 5;
+    const int c = lane & 15, kb = lane >> 4;
     const int tile = blockIdx.x % a.tiles_total;
     const int slice = blockIdx.x / a.tiles_total;
     int si = 0;
@@ -612,15 +629,10 @@ __global__ __launch_bounds__(NW * 64) void mpq_gemv_lutm_kernel(const LutArgs a)
     for (int i = 1; i < LUT_MAX_SETS; i++)
         if (i < a.nsets && tile >= a.set[i].tile_begin) si = i;
     const LutSet& ls = a.set[si];
-    const int N = ls.N;
+    const int N = ls.N;  // N % 4 == 0 on this path: a lane's four columns are all in range or all out
     const int M = a.M;
     const int nt0 = (tile - ls.tile_begin) * 64;
-    int ncl[2];
-#pragma unroll
-    for (int f = 0; f < 2; f++) {
-        const int n = nt0 + f * 32 + j;
-        ncl[f] = n < N ? n : N - 1;  // clamp: out-of-range columns load valid memory and are never stored
-    }
+    const int n4 = nt0 + 4 * c < N ? nt0 + 4 * c : N - 4;  // clamp: out-of-range columns load valid memory and are never stored
     const int g0 = (slice * NW + wave) * a.groups_per_wave;
     int g1 = g0 + a.groups_per_wave;
     if (g1 > a.G) g1 = a.G;
@@ -635,81 +647,75 @@ __global__ __launch_bounds__(NW * 64) void mpq_gemv_lutm_kernel(const LutArgs a)
     const uint32_t xlo = __builtin_amdgcn_readfirstlane((uint32_t)xb), xhi = __builtin_amdgcn_readfirstlane((uint32_t)(xb >> 32));  // unsigned: no sign extension
     const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((uint64_t)xhi << 32) | xlo), 0,
                                                          __builtin_amdgcn_readfirstlane((uint32_t)((long)M * a.K * 2)), 0x00020000);
-    const uint32_t xvoff = j < M ? (uint32_t)(j * a.K * 2 + h * 16) : 0x80000000u;
+    const uint32_t xvoff = c < M ? (uint32_t)(c * a.K * 2 + kb * 16) : 0x80000000u;
 
-    const int zero_width = N / NB;
-    const uint32_t* wcol[2] = {ls.qw + ncl[0], ls.qw + ncl[1]};
-    auto load_params = [&](int unit, uint32_t (&sb)[2], uint32_t (&zb)[2]) {
+    const uint32_t* wcol = ls.qw + n4;
+    auto load_params = [&](int unit, uint32_t (&sb)[4], uint32_t (&zb)[4]) {
         const int g = unit >> a.hshift;
+        const uint2_t s2 = *reinterpret_cast<const uint2_t*>(ls.scales + (long)g * N + n4);
+        sb[0] = s2.x & 0xffffu; sb[1] = s2.x >> 16; sb[2] = s2.y & 0xffffu; sb[3] = s2.y >> 16;
+        if constexpr (ZM == ZM_ASYM) {
+            const uint32_t zw = reinterpret_cast<const uint32_t*>(ls.zeros)[(long)g * (N / NB) + n4 / NB];
 #pragma unroll
-        for (int f = 0; f < 2; f++) {
-            sb[f] = ls.scales[(long)g * N + ncl[f]];
-            if constexpr (ZM == ZM_ASYM) {
-                const uint32_t zw = reinterpret_cast<const uint32_t*>(ls.zeros)[(long)g * zero_width + ncl[f] / NB];
-                zb[f] = ((zw >> ((ncl[f] % NB) * 4)) & 15u) + 1u;
-            } else {
-                zb[f] = reinterpret_cast<const uint16_t*>(ls.zeros)[(long)g * N + ncl[f]];
-            }
+            for (int f = 0; f < 4; f++) zb[f] = ((zw >> (((n4 % NB) + f) * 4)) & 15u) + 1u;
+        } else {
+            const uint2_t z2 = *reinterpret_cast<const uint2_t*>(reinterpret_cast<const uint16_t*>(ls.zeros) + (long)g * N + n4);
+            zb[0] = z2.x & 0xffffu; zb[1] = z2.x >> 16; zb[2] = z2.y & 0xffffu; zb[3] = z2.y >> 16;
         }
     };
-    auto load_unit = [&](uint32_t (&w)[2][RP], uint4_t (&xf)[RP], int unit) {
+    auto load_unit = [&](uint4_t (&w)[RQ], uint4_t (&xf)[RQ], int unit) {
 #pragma unroll
-        for (int rp = 0; rp < RP; rp++) {
-            const long row = (long)unit * RPG + 2 * rp + h;
-#pragma unroll
-            for (int f = 0; f < 2; f++) w[f][rp] = __builtin_nontemporal_load(wcol[f] + row * N);
-            xf[rp] = __builtin_bit_cast(uint4_t, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xvoff, (uint32_t)((unit * RPG + 2 * rp) * 16), 0));
+        for (int rq = 0; rq < RQ; rq++) {
+            const long row = (long)unit * RPG + 4 * rq + kb;
+            w[rq] = __builtin_nontemporal_load(reinterpret_cast<const uint4_t*>(wcol + row * N));
+            xf[rq] = __builtin_bit_cast(uint4_t, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xvoff, (uint32_t)((unit * RPG + 4 * rq) * 16), 0));
         }
     };
 
-    lutm_acc_t acc[2];
+    lutm_acc_t acc[4];
 #pragma unroll
-    for (int f = 0; f < 2; f++)
-#pragma unroll
-        for (int e = 0; e < 16; e++) acc[f][e] = 0.0f;
+    for (int f = 0; f < 4; f++) acc[f] = lutm_acc_t{0.0f, 0.0f, 0.0f, 0.0f};
 
-    // LDS byte address of tab[wave][q][c] = ((wave * 16 + q) << 8) | (c << 2)
-    const uint32_t col_addr[2] = {(uint32_t)j * 4u, (uint32_t)(32 + j) * 4u};
-    const uint32_t wavepat = (uint32_t)wave * 0x10101010u;
-    uint32_t* mytab = tab + wave * (16 * 64);
+    const uint32_t lane_addr = (uint32_t)((kb & 1) * 64 + c * 4);
+    const uint32_t wavepat = (uint32_t)wave * 0x20202020u;  // byte = (wave << 5) | q
+    uint32_t* mytab = tab + wave * 2048;
     uint32_t m0f;
     asm("v_mov_b32 %0, 0x0f0f0f0f" : "=v"(m0f));
 
-    auto process_unit = [&](const uint32_t (&w)[2][RP], const uint4_t (&xf)[RP], const uint32_t (&sb)[2], const uint32_t (&zb)[2]) {
-        // ---- this half-wave's 8 entries (q = 8h .. 8h+7) of the two columns' tables; 16-bit value in the low half of a dword
+    auto process_unit = [&](const uint4_t (&w)[RQ], const uint4_t (&xf)[RQ], const uint32_t (&sb)[4], const uint32_t (&zb)[4]) {
+        // ---- this lane's 16 entries (q = 4*kb .. 4*kb+3 of its four columns), each stored for both bank replicas;
+        // 16-bit value in the low half of a dword
 #pragma unroll
-        for (int f = 0; f < 2; f++) {
+        for (int f = 0; f < 4; f++) {
             float s, z = 0.0f;
             int zq1 = 0;
             if constexpr (DT == BIE_BF16) s = bf16_bits_to_f32(sb[f]); else s = f16_bits_to_f32(sb[f]);
             if constexpr (ZM == ZM_ASYM) zq1 = (int)zb[f];
             else if constexpr (DT == BIE_BF16) z = bf16_bits_to_f32(zb[f]); else z = f16_bits_to_f32(zb[f]);
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const uint32_t q = (uint32_t)(8 * h + e);
+            for (int e = 0; e < 4; e++) {
+                const uint32_t q = (uint32_t)(4 * kb + e);
                 const float t = lut_entry<DT, ZM>(q, s, z, zq1);
                 uint32_t bits;
                 if constexpr (DT == BIE_BF16) bits = __float_as_uint(t) >> 16; else bits = f32_to_f16_bits(t);
-                mytab[q * 64 + f * 32 + j] = bits;
+                uint32_t* p = mytab + (f >> 1) * 1024 + q * 64 + (f & 1) * 32 + c;
+                p[0] = bits;
+                p[16] = bits;
             }
         }
-        // ---- fragment steps s = 2*rp + f: the eight 16-bit lookups of step s+1 are in flight while step s feeds the MFMA
+        // ---- fragment steps st = 4*rq + f: the eight 16-bit lookups of step st+1 are in flight while step st feeds the MFMA
         // (plain ds_read_u16 + one v_lshl_or_b32 per pair: with SRAM-ECC register files a d16 load does not preserve the other
-        // half of its destination, so the d16 / d16_hi pair cannot share a register)
+        // half of its destination, so a d16 / d16_hi pair cannot share a register)
         uint32_t la[8], lb[8];
-        auto issue = [&](uint32_t (&l)[8], int rp, int f) {
+        auto issue = [&](uint32_t (&l)[8], int rq, int f) {
+            const uint32_t word = f == 0 ? w[rq].x : (f == 1 ? w[rq].y : (f == 2 ? w[rq].z : w[rq].w));
             uint32_t we, wo;
-            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(we) : "v"(w[f][rp]), "v"(m0f), "s"(wavepat));
-            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(wo) : "v"(w[f][rp] >> 4), "v"(m0f), "s"(wavepat));
-            const uint32_t ca = col_addr[f];
-            asm volatile("ds_read_u16 %0, %1" : "=v"(l[0]) : "v"(lut_addr<0>(ca, we)) : "memory");
-            asm volatile("ds_read_u16 %0, %1" : "=v"(l[1]) : "v"(lut_addr<0>(ca, wo)) : "memory");
-            asm volatile("ds_read_u16 %0, %1" : "=v"(l[2]) : "v"(lut_addr<1>(ca, we)) : "memory");
-            asm volatile("ds_read_u16 %0, %1" : "=v"(l[3]) : "v"(lut_addr<1>(ca, wo)) : "memory");
-            asm volatile("ds_read_u16 %0, %1" : "=v"(l[4]) : "v"(lut_addr<2>(ca, we)) : "memory");
-            asm volatile("ds_read_u16 %0, %1" : "=v"(l[5]) : "v"(lut_addr<2>(ca, wo)) : "memory");
-            asm volatile("ds_read_u16 %0, %1" : "=v"(l[6]) : "v"(lut_addr<3>(ca, we)) : "memory");
-            asm volatile("ds_read_u16 %0, %1" : "=v"(l[7]) : "v"(lut_addr<3>(ca, wo)) : "memory");
+            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(we) : "v"(word), "v"(m0f), "s"(wavepat));
+            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(wo) : "v"(word >> 4), "v"(m0f), "s"(wavepat));
+            if (f == 0) lutm_issue8<0>(l, lane_addr, we, wo);
+            else if (f == 1) lutm_issue8<128>(l, lane_addr, we, wo);
+            else if (f == 2) lutm_issue8<4096>(l, lane_addr, we, wo);
+            else lutm_issue8<4096 + 128>(l, lane_addr, we, wo);
         };
         auto wait_pack = [&](uint32_t (&l)[8], bool more, uint32_t (&b)[4]) {
             if (more) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3]), "+v"(l[4]), "+v"(l[5]), "+v"(l[6]), "+v"(l[7])::"memory");
@@ -719,26 +725,26 @@ __global__ __launch_bounds__(NW * 64) void mpq_gemv_lutm_kernel(const LutArgs a)
         };
         issue(la, 0, 0);
 #pragma unroll
-        for (int st = 0; st < 2 * RP; st++) {
-            const int rp = st >> 1, f = st & 1;
-            const bool more = st + 1 < 2 * RP;
+        for (int st = 0; st < 4 * RQ; st++) {
+            const int rq = st >> 2, f = st & 3;
+            const bool more = st + 1 < 4 * RQ;
             uint32_t b[4];
             if (st & 1) {
-                if (more) issue(la, (st + 1) >> 1, (st + 1) & 1);
+                if (more) issue(la, (st + 1) >> 2, (st + 1) & 3);
                 wait_pack(lb, more, b);
             } else {
-                if (more) issue(lb, (st + 1) >> 1, (st + 1) & 1);
+                if (more) issue(lb, (st + 1) >> 2, (st + 1) & 3);
                 wait_pack(la, more, b);
             }
-            acc[f] = lutm_mfma<DT>(b, xf[rp], acc[f]);
+            acc[f] = lutm_mfma<DT>(b, xf[rq], acc[f]);
         }
     };
 
     // one unit per wave is the normal plan (its rows, activations and constants are requested up front, constants first so that
     // the table is built under the row latency); further units of a wave (very wide layers) are taken one after the other
-    uint32_t wa[2][RP];
-    uint4_t xa[RP];
-    uint32_t sa[2] = {0, 0}, za[2] = {0, 0};
+    uint4_t wa[RQ];
+    uint4_t xa[RQ];
+    uint32_t sa[4] = {0, 0, 0, 0}, za[4] = {0, 0, 0, 0};
     for (int g = g0; g < g1; g++) {
         load_params(g, sa, za);
         asm volatile("" ::: "memory");
@@ -746,18 +752,16 @@ __global__ __launch_bounds__(NW * 64) void mpq_gemv_lutm_kernel(const LutArgs a)
         process_unit(wa, xa, sa, za);
     }
 
-    // ---- workgroup reduction through LDS (the tables are dead).  D layout of the 32x32 MFMA: lane (h', m) holds, for e = 0..15,
-    // the output of column n = (e & 3) + 8 * (e >> 2) + 4 * h' (+ 32 * f) of x row m.  red[wave][m][64]
+    // ---- workgroup reduction through LDS (the tables are dead).  D layout of the 16x16 MFMA: lane (kb', m) holds in acc[f][r] the
+    // output of tile column 16 * kb' + 4 * r + f for x row m.  red[wave][m][64]
     __syncthreads();
     float* red = reinterpret_cast<float*>(tab);
-    if (j < M) {
+    if (c < M) {
 #pragma unroll
-        for (int f = 0; f < 2; f++)
-#pragma unroll
-            for (int q4 = 0; q4 < 4; q4++) {
-                const float4_t v = {acc[f][4 * q4], acc[f][4 * q4 + 1], acc[f][4 * q4 + 2], acc[f][4 * q4 + 3]};
-                *reinterpret_cast<float4_t*>(red + ((wave * M + j) * 64 + f * 32 + 8 * q4 + 4 * h)) = v;
-            }
+        for (int r = 0; r < 4; r++) {
+            const float4_t v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+            *reinterpret_cast<float4_t*>(red + ((wave * M + c) * 64 + 16 * kb + 4 * r)) = v;
+        }
     }
     __syncthreads();
     // wave w finishes x rows m = w, w + NW, ...: lane = column of the tile
@@ -818,22 +822,22 @@ static int lut_env(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
-// W4, implicit groups of 32 / 64 / 128 / 256 that tile K exactly.  FMA form: bf16, M <= 2.  Matrix-pipe form: fp16 / bf16,
-// M <= 16 by construction, used for 3 <= M <= 8 where it measures faster than both neighbours (4096x11008 bf16: 15.6-17.5 us
-// against 18.7-19.0 us of the MFMA GEMM; at M <= 2 the FMA form wins, 10.3 / 15.3 us against 15.2 / 15.4 us; from M = 12 the
-// x fragments every wave re-reads from L2 cost as much as the weights and the GEMM's LDS-shared x tile is level or better).
-static bool lut_use_mfma(int M) {
+// W4, implicit groups of 32 / 64 / 128 / 256 that tile K exactly.  FMA form: bf16, M <= 2.  Matrix-pipe form: fp16 / bf16, M <= 16.
+// Measured (4096x11008 / 4096x4096, us per launch): bf16 M = 1: FMA form 10.05 / 5.92, matrix-pipe 11.66 / 6.84 -> FMA form;
+// M = 2: 15.1 / 7.3 against 11.8 / 6.8; M = 4, 8, 16: 12.2 / 7.3, 13.0 / 7.9, 15.7 / 10.0 against the MFMA GEMM's 18.7-20.2 /
+// 10.5-12.2 -> matrix-pipe form for 2 <= M <= 16.  fp16 has no FMA form: matrix-pipe from M = 1 (11.5 us against the dot2
+// kernel's 11.9).
+static bool lut_use_mfma(int M, int dtype) {
     static const int v = lut_env("BIE_LUT_MFMA", 1);
-    static const int lo = lut_env("BIE_LUT_MFMA_MIN_M", 3);
-    static const int hi = lut_env("BIE_LUT_MFMA_MAX_M", 8);
-    return v != 0 && M >= lo && M <= hi && M <= 16;
+    static const int lo = lut_env("BIE_LUT_MFMA_MIN_M", 2);
+    static const int hi = lut_env("BIE_LUT_MFMA_MAX_M", 16);
+    return v != 0 && M >= (dtype == BIE_F16 ? 1 : lo) && M <= hi && M <= 16;
 }
 bool mpq_gemv_lut_ok(int M, int K, int w_bit, int group_size, int dtype, bool has_gidx) {
     static const int enabled = lut_env("BIE_GEMV_LUT", 1);
     if (!enabled || has_gidx || w_bit != 4 || M < 1) return false;
-    if (lut_use_mfma(M)) {
-        if (dtype != BIE_BF16 && dtype != BIE_F16) return false;
-    } else if (dtype != BIE_BF16 || M > 2) return false;
+    if (dtype != BIE_BF16 && dtype != BIE_F16) return false;
+    if (!lut_use_mfma(M, dtype) && (dtype != BIE_BF16 || M > 2)) return false;
     const int gs = group_size > K ? K : group_size;
     if (gs != 32 && gs != 64 && gs != 128 && gs != 256) return false;
     return K % gs == 0;
@@ -847,7 +851,7 @@ struct LutPlan {
 // chip short of waves split every group into H = 2 or 4 units (each wave then builds the group's table for 8 or 4 rows: the
 // per-wave critical path, which is what a 4096x4096 launch spends its time on, shrinks accordingly); big grids give a wave
 // several units (bounds the granule traffic).
-static LutPlan lut_plan(int M, int K, int group_size, int tiles_total) {
+static LutPlan lut_plan(int M, int dtype, int K, int group_size, int tiles_total) {
     static const int min_rows = lut_env("BIE_LUT_ROWS", 16);
     static const int nw_env = lut_env("BIE_LUT_NW", 8);
     static const int max_wg = lut_env("BIE_LUT_MAX_WG", 2048);
@@ -858,7 +862,7 @@ static LutPlan lut_plan(int M, int K, int group_size, int tiles_total) {
     const int gs = group_size > K ? K : group_size;
     p.rpg = gs / 8;
     p.G = K / gs;
-    p.coop = coop && !lut_use_mfma(M);
+    p.coop = coop && !lut_use_mfma(M, dtype);
     p.H = 1;
     if (p.coop) {  // four waves per group, 128 / rpg groups per workgroup (mpq_gemv_lutc_kernel)
         p.nw = 4;
@@ -866,7 +870,7 @@ static LutPlan lut_plan(int M, int K, int group_size, int tiles_total) {
         p.S = cdiv(p.G, p.gpw);
         return p;
     }
-    p.nw = lut_use_mfma(M) ? 8 : (nw_env == 4 ? 4 : (nw_env == 2 ? 2 : 8));
+    p.nw = lut_use_mfma(M, dtype) ? 8 : (nw_env == 4 ? 4 : (nw_env == 2 ? 2 : 8));
     int H = 1;
     if (force_h > 0) H = force_h;
     else
@@ -886,8 +890,13 @@ static LutPlan lut_plan(int M, int K, int group_size, int tiles_total) {
 
 // granule area behind the workspace head, counted in floats (a granule = 8 bytes)
 size_t mpq_gemv_lut_part_floats(int M, int K, int group_size, int tiles_total) {
-    const LutPlan p = lut_plan(M, K, group_size, tiles_total);
-    return p.S > 1 ? (size_t)(p.S - 1) * M * tiles_total * 64 * 2 : 0;
+    size_t need = 0;  // the dtype is not known where workspaces are sized: the larger of the two plans
+    for (int dtype : {BIE_F16, BIE_BF16}) {
+        const LutPlan p = lut_plan(M, dtype, K, group_size, tiles_total);
+        const size_t f = p.S > 1 ? (size_t)(p.S - 1) * M * tiles_total * 64 * 2 : 0;
+        if (f > need) need = f;
+    }
+    return need;
 }
 
 template <int DT, int ZM, int MT, int NW>
@@ -997,7 +1006,7 @@ int mpq_gemv_lut_launch(int nsets, const int32_t* const* qw, const void* const* 
         a.set[i].tile_begin = tiles;
         if (i < nsets) tiles += cdiv(N[j], 64);
     }
-    const LutPlan p = lut_plan(M, K, group_size, tiles);
+    const LutPlan p = lut_plan(M, dtype, K, group_size, tiles);
     a.x = reinterpret_cast<const uint16_t*>(x);
     a.gran = reinterpret_cast<unsigned long long*>(gran);
     a.gen = gen;
@@ -1011,7 +1020,7 @@ int mpq_gemv_lut_launch(int nsets, const int32_t* const* qw, const void* const* 
     a.hshift = p.H == 4 ? 2 : (p.H == 2 ? 1 : 0);
     a.epoch = next_launch_epoch();
     const int grid = tiles * p.S;
-    if (lut_use_mfma(M) && !p.coop) {
+    if (lut_use_mfma(M, dtype) && !p.coop) {
         if (dtype == BIE_F16) lutm_launch<BIE_F16>(a, p.rpg, grid, zm, st);
         else lutm_launch<BIE_BF16>(a, p.rpg, grid, zm, st);
         return check_launch("mpq_gemv_lutm_kernel");

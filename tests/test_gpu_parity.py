@@ -611,11 +611,14 @@ def test_lut_gemv_group_sizes_ragged_tiles_and_tails(K, N, gs, asym, M):
 
 @pytest.mark.parametrize("dt", [orc.BF16, orc.F16])
 @pytest.mark.parametrize("K,N,gs,asym,M", [(1024, 200, 64, 0, 3), (768, 520, 256, 0, 8), (640, 64, 32, 1, 5), (1408, 136, 128, 0, 4),
-                                            (2048, 1000, 128, 1, 7), (4096, 4096, 128, 0, 6), (4096, 12288, 128, 0, 3)])
+                                            (2048, 1000, 128, 1, 7), (4096, 4096, 128, 0, 6), (4096, 12288, 128, 0, 3),
+                                            (1024, 200, 128, 0, 1), (1024, 4096, 128, 1, 2), (2048, 328, 64, 0, 12), (4096, 1024, 128, 1, 16),
+                                            (512, 68, 32, 0, 9)])
 def test_lut_gemv_matrix_pipe_form_small_batches(K, N, gs, asym, M, dt):
-    """3 <= M <= 8, W4, fp16 and bf16: mpq_gemv_lutm_kernel (table lookup feeding 32x32x16 MFMAs; rows >= M of the x fragment
-    come back as zeros from the buffer descriptor's bounds check).  Same exact table values, so again only the fp32 summation
-    order differs from the oracle; every group size, ragged column tiles, split groups (4096x4096) and one-unit-per-wave plans."""
+    """2 <= M <= 16 (fp16: from M = 1), W4: mpq_gemv_lutm_kernel (table lookup feeding 16x16x32 MFMAs; rows >= M of the x
+    fragment come back as zeros from the buffer descriptor's bounds check).  Same exact table values, so again only the fp32
+    summation order differs from the oracle; every group size, ragged column tiles (N % 64 = 4, 8, 40), split groups and
+    one-unit-per-wave plans, sym and asym."""
     rng = np.random.default_rng(K + N + gs + M + dt)
     qw, scales, zeros, gen = rand_case(rng, K, N, 4, gs, dt, asym)
     x = torch.randn((M, K), generator=gen).to(TDT[dt])
