@@ -208,6 +208,29 @@ def bench_exl2(dev):
     return out
 
 
+def bench_act_order(dev):
+    """Random-permuted g_idx (GPTQ act-order) at 4096x11008 against the trivial g_idx, M = 1 and M = 4096: the Python-level call
+    (memoised sorted copy + bie_gather_cols + the fast kernel) under graph replay."""
+    from bitorch_engine.extensions import q_linear_cuda as q
+    K, N = 4096, 11008
+    gen = torch.Generator(device=dev).manual_seed(41)
+    out = {"K": K, "N": N}
+    for M in (1, 4096):
+        nl = 8 if M == 1 else 2
+        layers = [make_layer(dev, gen, K, N) for _ in range(nl)]
+        gidx = [(torch.arange(K, dtype=torch.int32, device=dev) // GROUP)[torch.randperm(K, generator=gen, device=dev)] for _ in range(nl)]
+        x = torch.randn((M, K), generator=gen, device=dev).to(BF16)
+        for label in ("trivial", "act_order"):
+            def run(_st):
+                for l, gi in zip(layers, gidx):
+                    q.mpq_forward_impl(x, l[0], l[1], l[2], gi if label == "act_order" else None, WBIT, 0, GROUP)
+            run(None)
+            torch.cuda.synchronize()
+            out[f"M{M}_{label}_us"] = round(time_graph(capture(run), 20 if M == 1 else 5) / nl, 2)
+        out[f"M{M}_ratio"] = round(out[f"M{M}_act_order_us"] / out[f"M{M}_trivial_us"], 3)
+    return out
+
+
 def bench_binary(dev, L):
     """configs[3]: binary XNOR linear 4096x4096 (row-packed) and the ResNet-18 3x3x512 conv on 7x7 maps."""
     from bitorch_engine.extensions import binary_conv_cpp
@@ -251,8 +274,9 @@ def bench_binary(dev, L):
     for B in (1, 32):
         x = torch.randn((B, 512, 7, 7), device=dev)
         w = torch.randn((512, 512, 3, 3), device=dev)
-        wp = binary_conv_cpp.w_pack(w) if hasattr(binary_conv_cpp, "w_pack") else None
-        fn = lambda st: binary_conv_cpp.forward(x, wp if wp is not None else w, 512, B * 49, 512 * 9, 3, 1, 1, 1, 7)
+        from bitorch_engine.extensions._binary_common import pack_rows
+        wp = pack_rows(w.reshape(512, -1)).contiguous()  # what BinaryConv2dCPP.generate_quantized_weight stores (eval mode)
+        fn = lambda st: binary_conv_cpp.forward(x, wp, 512, B * 49, 512 * 9, 3, 1, 1, 1, 7)
         try:
             us = time_graph(capture(fn), 20)
             tops = 2.0 * B * 49 * 512 * 4608 / us / 1e6
@@ -407,6 +431,10 @@ def main():
         guarded("c2_gemv_4096x11008", lambda: B.gemv(4096, 11008, 40, 10, 11))
         guarded("c2_gemv_11008x4096", lambda: B.gemv(11008, 4096, 40, 10, 12))
         guarded("c2_gemv_M2_4096x11008", lambda: B.gemv(4096, 11008, 40, 10, 13, M=2))
+        # small decode batches through the matrix-pipe lookup kernel (M <= 16 costs about what M = 2 costs)
+        guarded("c2_gemv_M8_4096x11008", lambda: B.gemv(4096, 11008, 40, 10, 16, M=8))
+        guarded("c2_gemv_M16_4096x11008", lambda: B.gemv(4096, 11008, 40, 10, 17, M=16))
+        guarded("c2_act_order_4096x11008", lambda: bench_act_order(dev))
         guarded("c2_gemm_4096x11008", lambda: B.gemm(4096, 4096, 11008, 16, 3, 14))
         guarded("c2_gemm_11008x4096", lambda: B.gemm(4096, 11008, 4096, 16, 3, 15))
         # ---- grouped decode launches (one x, several weight sets)

@@ -73,6 +73,19 @@ def xnor_linear_fused(x, wrows, bias_a=None, scale_a=None, scale_w=None, raw_cou
     return y
 
 
+def conv_weight_taps(wpacked, OC, C, ksize):
+    """Packed conv weights [OC, C*k*k/8] -> tap-major words [OC, k*k, ceil(C/32)] (bie_binary_conv_weight_taps), remembered on
+    the packed tensor until it changes."""
+    from .q_linear_cuda import _cached
+
+    def convert():
+        out = torch.empty((OC, ksize * ksize, (C + 31) // 32), dtype=torch.int32, device=wpacked.device)
+        rc = _hip.lib().bie_binary_conv_weight_taps(_hip.ptr(wpacked), _hip.ptr(out), OC, C, ksize, _hip.stream())
+        _hip.check(rc, "bie_binary_conv_weight_taps")
+        return out
+    return _cached(wpacked, ("taps", OC, C, ksize), convert)
+
+
 def conv2d(x, wpacked, OC, ksize, stride, pad, dil, scale):
     _hip.need_gpu(x, wpacked)
     x = x.contiguous()
@@ -83,6 +96,13 @@ def conv2d(x, wpacked, OC, ksize, stride, pad, dil, scale):
     L = _hip.lib()
     need = L.bie_binary_conv2d_workspace_bytes(B, C, H, W, OC, ksize, stride, pad, dil)
     ws = _hip.workspace(need, x.device)
+    if L.bie_binary_conv2d_taps_ok(C, W, ksize) and (C * ksize * ksize) % 8 == 0:
+        # no im2col image: tap-major weights (converted once per tensor version) against channel-minor activation bits
+        wt = conv_weight_taps(wpacked, OC, C, ksize)
+        rc = L.bie_binary_conv2d_forward_taps(_hip.ptr(x), _hip.ptr(wt), _hip.ptr(y), _hip.ptr(ws), ws.numel(), B, C, H, W, OC,
+                                              ksize, stride, pad, dil, float(scale), _hip.dt(x), _hip.stream())
+        _hip.check(rc, "bie_binary_conv2d_forward_taps")
+        return y
     rc = L.bie_binary_conv2d_forward(_hip.ptr(x), _hip.ptr(wpacked), _hip.ptr(y), _hip.ptr(ws), ws.numel(), B, C, H, W, OC,
                                      ksize, stride, pad, dil, float(scale), _hip.dt(x), _hip.stream())
     _hip.check(rc, "bie_binary_conv2d_forward")

@@ -25,6 +25,6 @@ class BinaryConv2dCPP(BinaryConv2dBase):
         k = x.size(1) * self.kernel_size * self.kernel_size
         output_edge = int((x.size(2) - self.kernel_size + 2 * self.padding) / self.stride + 1)
         w = self.opt_weight
-        w = w.data.reshape(m, -1) if w.dtype == torch.uint8 else w.data.reshape(m, k)
+        w = w if w.dtype == torch.uint8 else w.data.reshape(m, k)  # packed: the Parameter itself (the tap re-layout is memoised on it)
         return binary_conv_cpp.forward(x, w, m, output_edge * output_edge, k, self.kernel_size, self.stride, self.padding,
                                        self.dilation, output_edge)

@@ -42,6 +42,6 @@ class BinaryConv2dCutlass(BinaryConv2dBase):
         self._check_forward(x)
         x = self.set_activation(x)
         scale = self.scale_a.item() * self.scale_w.item()
-        out = binary_conv2d_cutlass.forward(x, self.opt_weight.data, scale, self.training, self.kernel_size, self.stride,
+        out = binary_conv2d_cutlass.forward(x, self.opt_weight, scale, self.training, self.kernel_size, self.stride,
                                             self.padding, self.dilation)
         return out.to(x.dtype)

@@ -36,7 +36,7 @@ class BinaryLinearCuda(BinaryLinearBase):
         # lazily initialised activation scale (reference layer.py set_activation); the reference asks `is_nonzero()` -- a
         # device sync -- on every forward, here the answer is remembered per version of the parameter
         from bitorch_engine.extensions.q_linear_cuda import _cached
-        if not _cached(self.scale_a.data, "nonzero", lambda: bool(self.scale_a.is_nonzero())):
+        if not _cached(self.scale_a, "nonzero", lambda: bool(self.scale_a.is_nonzero())):
             self.scale_a.data = ((2 if self.symmetric else 4) * x.abs().mean()).to(self.dtype)
 
     def set_activation(self, x: torch.Tensor) -> torch.Tensor:
@@ -54,11 +54,11 @@ class BinaryLinearCuda(BinaryLinearBase):
             # inference, M <= 64: the whole layer (activation bias + sign-pack, XNOR-popcount, cast, both scales) in ONE launch
             self._init_scale_a(x)
             x2, lead = flatten_x(x)
-            out = binary_linear_cuda.layer_forward(x2, self.bias_a.data, self.opt_weight.data, self.bmm_type.value,
+            out = binary_linear_cuda.layer_forward(x2, self.bias_a.data, self.opt_weight, self.bmm_type.value,
                                                    self.scale_a.data, self.scale_w) if x2.dtype == self.bias_a.dtype else None
             if out is not None:
                 return unflatten_x(out, lead)
         x = self.set_activation(x)
         x2, lead = flatten_x(x)
-        out = binary_linear_cuda.forward(x2, self.opt_weight.data, self.bmm_type.value, True).to(x.dtype)
+        out = binary_linear_cuda.forward(x2, self.opt_weight, self.bmm_type.value, True).to(x.dtype)  # the Parameter itself: conversions are memoised on it
         return unflatten_x(out, lead) * self.scale_a * self.scale_w

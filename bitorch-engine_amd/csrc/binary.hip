@@ -511,6 +511,183 @@ int binary_linear_fused_launch(const void* x, const void* bias_a, const uint8_t*
     return check_launch("xnor_fused_kernel");
 }
 
+// ---- conv2d without the im2col image -------------------------------------------------------------------------------------------
+// The flattened (c, i, j) bit order of the reference's packed weights interleaves the taps inside a word; with the weights
+// re-laid ONCE as wtaps[oc][tap][C/32 words] (channel bits of one tap contiguous) and the activations sign-packed channel-minor,
+// xbits[b][h][w][C/32 words], a tap of an output pixel is a plain XNOR-popcount over C/32 words and zero padding is a zero x word
+// (bit 0 = -1, as the reference counts it; the channel padding bits are 0 on both sides and cancel).
+//   conv_weight_taps_kernel : one-time re-layout of the packed weights (cached by the caller)
+//   pack_nhwc_bits_kernel   : x [B, C, H, W] -> xbits (1/16 .. 1/32 of x's bytes; replaces the 9x larger bit-im2col image)
+//   xnor_conv_taps_kernel   : a wave = (image, output row, 64 output channels): it copies the ks input rows it needs into a private
+//                             LDS slab (+ one zero pixel for out-of-range columns), lane = output channel streams that channel's
+//                             tap words with 16-byte loads, the x words are wave-uniform LDS reads (broadcast), 8 output pixels
+//                             are accumulated at a time.  No workgroup barrier, no reduction.
+__global__ __launch_bounds__(256) void conv_weight_taps_kernel(const uint8_t* __restrict__ wpacked, uint32_t* __restrict__ wtaps,
+                                                               int OC, int C, int T, int CW) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)OC * T * CW) return;
+    const int cw = (int)(idx % CW);
+    const int t = (int)((idx / CW) % T);
+    const long oc = idx / ((long)CW * T);
+    const uint8_t* row = wpacked + oc * ((long)C * T / 8);
+    uint32_t v = 0;
+    for (int cc = 0; cc < 32; cc++) {
+        const int c = cw * 32 + cc;
+        if (c >= C) break;
+        const int k = c * T + t;
+        v |= (uint32_t)((row[k >> 3] >> (k & 7)) & 1u) << cc;
+    }
+    wtaps[idx] = v;
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void pack_nhwc_bits_kernel(const void* __restrict__ x, uint32_t* __restrict__ xbits, int B, int C,
+                                                             int HW, int CW) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // (b, cw, hw) with hw fastest: the 32 channel loads are coalesced along hw
+    if (idx >= (long)B * CW * HW) return;
+    const int hw = (int)(idx % HW);
+    const int cw = (int)((idx / HW) % CW);
+    const long b = idx / ((long)HW * CW);
+    uint32_t v = 0;
+    if (cw * 32 + 32 <= C) {  // whole word: the 32 channel loads are independent and all in flight
+#pragma unroll
+        for (int cc = 0; cc < 32; cc++) v |= (uint32_t)sign_bit<DT>(x, (b * C + cw * 32 + cc) * HW + hw) << cc;
+    } else {
+        for (int cc = 0; cw * 32 + cc < C; cc++) v |= (uint32_t)sign_bit<DT>(x, (b * C + cw * 32 + cc) * HW + hw) << cc;
+    }
+    xbits[(b * HW + hw) * CW + cw] = v;
+}
+
+constexpr int CONV_PX = 8;  // output pixels accumulated per pass
+// CW4 > 0: C / 128 at compile time (16-byte weight / x words, no bounds branches); 0: any C, word by word.
+// The tap loop is a RUNTIME loop on purpose: unrolled (compile-time kernel size), hipcc hoists the 36 weight loads out of the pixel
+// loop and all 288 LDS reads above the first popcount -- 700-1500 spilled registers in every variant tried (register-resident
+// weights, laundered pointers, volatile reads, a 128-register launch bound), 22 us per output row.  Inside one tap the 8 x CW4 LDS
+// reads are independent and batch up; the next tap's weight words are requested before the current tap's popcounts.
+template <int CW4>
+__global__ __launch_bounds__(256) void xnor_conv_taps_kernel(const uint32_t* __restrict__ xbits, const uint32_t* __restrict__ wtaps,
+                                                             float* __restrict__ y, int B, int C, int H, int W, int OC, int OH,
+                                                             int OW, int ks, int stride, int pad, int dil, int cw_rt, float scale,
+                                                             long items, int slab_words) {
+    const int CW = CW4 > 0 ? 4 * CW4 : cw_rt;
+    constexpr int NQ = CW4 > 0 ? CW4 : 1;
+    extern __shared__ __attribute__((aligned(16))) uint32_t conv_lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long item = (long)blockIdx.x * 4 + wave;  // (b, oh, oc block): oc block fastest, so neighbours share the same input rows in L2
+    if (item >= items) return;
+    const int ocbs = (OC + 63) >> 6;
+    const int ocb = (int)(item % ocbs);
+    const int oh = (int)((item / ocbs) % OH);
+    const long b = item / ((long)ocbs * OH);
+    const int T = ks * ks;
+    const int oc = ocb * 64 + lane;
+    const uint32_t* wl = wtaps + (long)(oc < OC ? oc : OC - 1) * T * CW;
+    auto load_tap = [&](int t, uint4_t (&w)[NQ]) {
+#pragma unroll
+        for (int q = 0; q < NQ; q++) w[q] = *reinterpret_cast<const uint4_t*>(wl + t * CW + 4 * q);
+    };
+    uint4_t wc[NQ], wn[NQ];
+    if constexpr (CW4 > 0) load_tap(0, wc);
+    uint32_t* slab = conv_lds + wave * slab_words;  // [ks][W + 1][CW]; pixel W of every row is the zero pixel
+    const int rowstride = (W + 1) * CW;
+    for (int i = 0; i < ks; i++) {
+        const int ih = oh * stride - pad + i * dil;
+        const bool valid = ih >= 0 && ih < H;
+        const uint32_t* src = xbits + ((b * H + (valid ? ih : 0)) * W) * CW;
+#pragma unroll 2
+        for (int t = lane; t < rowstride; t += 64) slab[i * rowstride + t] = (valid && t < W * CW) ? src[t] : 0u;
+    }
+    __builtin_amdgcn_wave_barrier();  // wave-private slab: a wave's LDS operations complete in order
+    const int Kc = C * T;
+    for (int ow0 = 0; ow0 < OW; ow0 += CONV_PX) {
+        int acc[CONV_PX];
+#pragma unroll
+        for (int px = 0; px < CONV_PX; px++) acc[px] = 0;
+        int i = 0, j = 0;
+#pragma unroll 1
+        for (int t = 0; t < T; t++) {
+            int pix[CONV_PX];  // wave-uniform slab offsets of the 8 pixels' x words for this tap
+#pragma unroll
+            for (int px = 0; px < CONV_PX; px++) {
+                const int iw = (ow0 + px) * stride - pad + j * dil;
+                pix[px] = i * rowstride + ((iw >= 0 && iw < W && ow0 + px < OW) ? iw : W) * CW;
+            }
+            if constexpr (CW4 > 0) {
+                load_tap(t + 1 < T ? t + 1 : 0, wn);  // the last one is tap 0 of the next pixel group
+#pragma unroll
+                for (int px = 0; px < CONV_PX; px++)
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) {
+                        const uint4_t x4 = *reinterpret_cast<const uint4_t*>(slab + pix[px] + 4 * q);
+                        acc[px] += __builtin_popcount(wc[q].x ^ x4.x) + __builtin_popcount(wc[q].y ^ x4.y) +
+                                   __builtin_popcount(wc[q].z ^ x4.z) + __builtin_popcount(wc[q].w ^ x4.w);
+                    }
+#pragma unroll
+                for (int q = 0; q < NQ; q++) wc[q] = wn[q];
+            } else {
+                const uint32_t* wr = wl + t * CW;
+                for (int cw = 0; cw < CW; cw++) {
+                    const uint32_t w1 = wr[cw];
+#pragma unroll
+                    for (int px = 0; px < CONV_PX; px++) acc[px] += __builtin_popcount(w1 ^ slab[pix[px] + cw]);
+                }
+            }
+            if (++j == ks) {
+                j = 0;
+                i++;
+            }
+        }
+        if (oc < OC) {
+            float* yr = y + ((b * OC + oc) * OH + oh) * OW + ow0;
+#pragma unroll
+            for (int px = 0; px < CONV_PX; px++)
+                if (ow0 + px < OW) yr[px] = (float)(Kc - 2 * acc[px]) * scale;
+        }
+    }
+}
+
+// LDS of one workgroup (4 waves) of the implicit conv; 0 = geometry outside its range (rows too long for a 16 KiB slab)
+size_t binary_conv_taps_lds_bytes(int C, int W, int ks) {
+    const size_t slab = (size_t)ks * (W + 1) * cdiv(C, 32);
+    const size_t words = (slab + 3) / 4 * 4;
+    return words * 4 <= 16384 ? words * 4 * 4 : 0;
+}
+
+size_t binary_conv_taps_workspace_bytes(int B, int C, int H, int W) { return (size_t)B * H * W * cdiv(C, 32) * 4; }
+
+int binary_conv_weight_taps_launch(const uint8_t* wpacked, uint32_t* wtaps, int OC, int C, int ks, hipStream_t st) {
+    const int T = ks * ks, CW = cdiv(C, 32);
+    const long total = (long)OC * T * CW;
+    hipLaunchKernelGGL(conv_weight_taps_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, st, wpacked, wtaps, OC, C, T, CW);
+    return check_launch("conv_weight_taps_kernel");
+}
+
+int binary_conv_taps_launch(const void* x, const uint32_t* wtaps, float* y, void* ws, int B, int C, int H, int W, int OC, int ks,
+                            int stride, int pad, int dil, float scale, int dtype, hipStream_t st) {
+    const int OH = (H + 2 * pad - dil * (ks - 1) - 1) / stride + 1;
+    const int OW = (W + 2 * pad - dil * (ks - 1) - 1) / stride + 1;
+    const int CW = cdiv(C, 32);
+    uint32_t* xbits = reinterpret_cast<uint32_t*>(ws);
+    {
+        const long total = (long)B * CW * H * W;
+        dim3 grid((unsigned)cdivl(total, 256));
+        BIE_DT_SWITCH(dtype, hipLaunchKernelGGL(pack_nhwc_bits_kernel<DT>, grid, dim3(256), 0, st, x, xbits, B, C, H * W, CW));
+        int rc = check_launch("pack_nhwc_bits_kernel");
+        if (rc) return rc;
+    }
+    const size_t lds = binary_conv_taps_lds_bytes(C, W, ks);
+    const long items = (long)B * OH * cdiv(OC, 64);
+#define LC(C4V) hipLaunchKernelGGL(xnor_conv_taps_kernel<C4V>, dim3((unsigned)cdivl(items, 4)), dim3(256), lds, st, xbits, wtaps, y, B, C, H, W, OC, OH, OW, \
+                                   ks, stride, pad, dil, CW, scale, items, (int)(lds / 16))
+    if (CW == 16) LC(4);  // 512 / 256 / 128 channels: the deep layers of a binary ResNet
+    else if (CW == 8) LC(2);
+    else if (CW == 4) LC(1);
+    else LC(0);
+#undef LC
+    return check_launch("xnor_conv_taps_kernel");
+}
+
 size_t binary_conv_workspace_bytes(int B, int C, int H, int W, int OC, int ks, int stride, int pad, int dil) {
     const int OH = (H + 2 * pad - dil * (ks - 1) - 1) / stride + 1;
     const int OW = (W + 2 * pad - dil * (ks - 1) - 1) / stride + 1;

@@ -54,6 +54,11 @@ int binary_image_unpack_launch(const uint8_t* image, uint8_t* rowpacked, long N,
 bool binary_linear_fused_ok(long M, long N, long K);
 int binary_linear_fused_launch(const void* x, const void* bias_a, const uint8_t* wp, const void* sa, const void* sw, void* y, long M,
                                long N, long K, int dtype, int y_f32, hipStream_t st);
+size_t binary_conv_taps_lds_bytes(int C, int W, int ks);
+size_t binary_conv_taps_workspace_bytes(int B, int C, int H, int W);
+int binary_conv_weight_taps_launch(const uint8_t* wpacked, uint32_t* wtaps, int OC, int C, int ks, hipStream_t st);
+int binary_conv_taps_launch(const void* x, const uint32_t* wtaps, float* y, void* ws, int B, int C, int H, int W, int OC, int ks,
+                            int stride, int pad, int dil, float scale, int dtype, hipStream_t st);
 int binary_linear_launch(const uint8_t* xp, const uint8_t* wp, float* y, long M, long N, long K, int w_layout, float scale,
                          hipStream_t st);
 size_t binary_conv_workspace_bytes(int B, int C, int H, int W, int OC, int ks, int stride, int pad, int dil);
@@ -397,7 +402,30 @@ int bie_binary_linear_fused(const void* x, const void* bias_a, const uint8_t* wp
 
 size_t bie_binary_conv2d_workspace_bytes(int B, int C, int H, int W, int OC, int ksize, int stride, int pad, int dilation) {
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || OC <= 0 || ksize <= 0 || stride <= 0 || dilation <= 0 || pad < 0) return 0;
-    return WS_HEAD + binary_conv_workspace_bytes(B, C, H, W, OC, ksize, stride, pad, dilation);  // scratch starts behind the counter head
+    const size_t a = binary_conv_workspace_bytes(B, C, H, W, OC, ksize, stride, pad, dilation), b = binary_conv_taps_workspace_bytes(B, C, H, W);
+    return WS_HEAD + (a > b ? a : b);  // scratch starts behind the counter head; covers the im2col form and the tap form
+}
+
+int bie_binary_conv2d_taps_ok(int C, int W, int ksize) { return C > 0 && W > 0 && ksize > 0 && binary_conv_taps_lds_bytes(C, W, ksize) > 0 ? 1 : 0; }
+
+int bie_binary_conv_weight_taps(const uint8_t* wpacked, uint32_t* wtaps, int OC, int C, int ksize, void* stream) {
+    BIE_REQUIRE(wpacked && wtaps && OC > 0 && C > 0 && ksize > 0, BIE_ERR_INVALID_ARG, "bie_binary_conv_weight_taps: bad argument");
+    BIE_REQUIRE((C * ksize * ksize) % 8 == 0, BIE_ERR_UNSUPPORTED, "bie_binary_conv_weight_taps: C*k*k=%d must be a multiple of 8", C * ksize * ksize);
+    return binary_conv_weight_taps_launch(wpacked, wtaps, OC, C, ksize, as_stream(stream));
+}
+
+int bie_binary_conv2d_forward_taps(const void* x, const uint32_t* wtaps, float* y, void* workspace, size_t workspace_bytes, int B, int C,
+                                   int H, int W, int OC, int ksize, int stride, int pad, int dilation, float scale, int dtype,
+                                   void* stream) {
+    BIE_REQUIRE(x && wtaps && y && workspace, BIE_ERR_INVALID_ARG, "bie_binary_conv2d_forward_taps: NULL tensor pointer");
+    BIE_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && OC > 0 && ksize > 0 && stride > 0 && dilation > 0 && pad >= 0, BIE_ERR_INVALID_ARG, "bie_binary_conv2d_forward_taps: bad geometry");
+    BIE_REQUIRE(dtype >= 0 && dtype <= 2, BIE_ERR_UNSUPPORTED, "bie_binary_conv2d_forward_taps: dtype %d", dtype);
+    BIE_REQUIRE(binary_conv_taps_lds_bytes(C, W, ksize) > 0, BIE_ERR_UNSUPPORTED, "bie_binary_conv2d_forward_taps: k=%d rows of W=%d x C=%d do not fit the 16 KiB slab (use bie_binary_conv2d_forward)", ksize, W, C);
+    BIE_REQUIRE((H + 2 * pad - dilation * (ksize - 1) - 1) / stride + 1 > 0 && (W + 2 * pad - dilation * (ksize - 1) - 1) / stride + 1 > 0, BIE_ERR_INVALID_ARG, "bie_binary_conv2d_forward_taps: empty output");
+    BIE_REQUIRE((reinterpret_cast<uintptr_t>(wtaps) & 15) == 0, BIE_ERR_INVALID_ARG, "bie_binary_conv2d_forward_taps: wtaps must be 16-byte aligned");
+    const size_t need = WS_HEAD + binary_conv_taps_workspace_bytes(B, C, H, W);
+    BIE_REQUIRE(workspace_bytes >= need, BIE_ERR_WORKSPACE, "bie_binary_conv2d_forward_taps: workspace of %zu bytes required, got %zu", need, workspace_bytes);
+    return binary_conv_taps_launch(x, wtaps, y, static_cast<char*>(workspace) + WS_HEAD, B, C, H, W, OC, ksize, stride, pad, dilation, scale, dtype, as_stream(stream));
 }
 
 int bie_binary_conv2d_forward(const void* x, const uint8_t* wpacked, float* y, void* workspace, size_t workspace_bytes, int B,

@@ -212,6 +212,19 @@ int bie_binary_conv2d_forward(const void* x, const uint8_t* wpacked, float* y, v
                               size_t workspace_bytes, int B, int C, int H, int W, int OC, int ksize,
                               int stride, int pad, int dilation, float scale, int dtype, void* stream);
 
+/* The same convolution without the bit-im2col image: the packed weights re-laid once per tensor as
+ * wtaps[OC][k*k][ceil(C/32)] uint32 (channel bits of one tap contiguous; bie_binary_conv_weight_taps, 16-byte aligned output),
+ * activations sign-packed channel-minor into the workspace (bie_binary_conv2d_workspace_bytes covers both forms), one
+ * XNOR-popcount pass.  bie_binary_conv2d_taps_ok: 1 when k input rows of W pixels x C channels fit a wave's 16 KiB LDS slab
+ * (otherwise use bie_binary_conv2d_forward).  Same result bit for bit (binary_conv.cpp:464-530). */
+int bie_binary_conv2d_taps_ok(int C, int W, int ksize);
+int bie_binary_conv_weight_taps(const uint8_t* wpacked, uint32_t* wtaps, int OC, int C, int ksize,
+                                void* stream);
+int bie_binary_conv2d_forward_taps(const void* x, const uint32_t* wtaps, float* y, void* workspace,
+                                   size_t workspace_bytes, int B, int C, int H, int W, int OC,
+                                   int ksize, int stride, int pad, int dilation, float scale,
+                                   int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* functions/cuda pack / unpack helpers (functions/cuda/functions_cuda_kernel.cu)                */
 /* ------------------------------------------------------------------------------------------ */

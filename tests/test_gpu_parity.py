@@ -426,6 +426,36 @@ def test_binary_conv_vs_reference_cpp_golden_and_resnet_shape():
     assert np.array_equal(y, orc.binary_conv2d(x.numpy(), w.numpy(), 1, 1, 1))
 
 
+@pytest.mark.parametrize("B,C,H,W,OC,ks,st,pad,dil", [(2, 64, 14, 14, 64, 3, 1, 1, 1), (1, 24, 9, 11, 36, 3, 2, 1, 1), (3, 8, 7, 7, 4, 1, 1, 0, 1),
+                                                     (2, 40, 12, 10, 70, 3, 1, 2, 2), (1, 128, 5, 17, 130, 5, 1, 2, 1), (2, 32, 8, 8, 64, 2, 2, 0, 1),
+                                                     (1, 64, 6, 300, 8, 7, 2, 3, 1)])
+def test_binary_conv_tap_form_equals_the_im2col_form_and_the_oracle(B, C, H, W, OC, ks, st, pad, dil):
+    """The implicit conv (tap-major weights x channel-minor activation bits, no im2col image) against the round-1 bit-im2col path
+    through the C ABI and against the oracle: strides, dilation, channel counts that are not multiples of 32, output widths that
+    are not multiples of 8, output channel counts that are not multiples of 64; the last geometry (7 rows of 300 pixels) does not
+    fit the LDS slab and must take the im2col form."""
+    from bitorch_engine import _hip
+    from bitorch_engine.extensions._binary_common import pack_rows, conv2d
+    gen = torch.Generator().manual_seed(B + C + H + W + OC)
+    x = torch.randn((B, C, H, W), generator=gen)
+    w = torch.randn((OC, C, ks, ks), generator=gen)
+    wp = pack_rows(w.reshape(OC, -1).to(DEV)).contiguous()
+    y = conv2d(x.to(DEV), wp, OC, ks, st, pad, dil, 1.0)
+    L = _hip.lib()
+    assert bool(L.bie_binary_conv2d_taps_ok(C, W, ks)) == (W != 300)
+    OH, OW = y.shape[2], y.shape[3]
+    y2 = torch.empty_like(y)
+    xd = x.to(DEV)
+    ws = torch.zeros(L.bie_binary_conv2d_workspace_bytes(B, C, H, W, OC, ks, st, pad, dil), dtype=torch.uint8, device=DEV)
+    rc = L.bie_binary_conv2d_forward(xd.data_ptr(), wp.data_ptr(), y2.data_ptr(), ws.data_ptr(), ws.numel(), B, C, H, W, OC, ks, st, pad, dil,
+                                     1.0, _hip.F32, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    assert torch.equal(y, y2)
+    assert np.array_equal(y.cpu().numpy(), orc.binary_conv2d(x.numpy(), w.numpy(), st, pad, dil))
+    for tdt in (torch.float16, torch.bfloat16):  # the sign of a value does not depend on the carrier dtype
+        assert torch.equal(conv2d(x.to(tdt).to(DEV), wp, OC, ks, st, pad, dil, 0.5), y * 0.5)
+
+
 # ------------------------------------------------------------------------------------------------ functions
 def test_functions_cuda_helpers():
     from bitorch_engine.functions.cuda import (tensor_to_packed_uint8, unpack_uint8_tensor, q4_pack_tensor,
