@@ -412,7 +412,7 @@ def main():
                        "layers_per_step": LAYERS, "parallelism": "output-column sharding x%d + 1 all-gather/step" % world if distributed else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(f"{K}x{N}"),
-                         "kernel": "bie::mpq_gemv_lut_kernel<bf16,sym,M=1,rpg=16,NW=8> (table-lookup dequant, in-kernel split-K by tagged granules)",
+                         "kernel": "bie::mpq_gemv_lut_kernel<bf16,sym,M=1,rpg=8,NW=8> (table-lookup dequant, a group split over two waves, in-kernel split-K by tagged granules)",
                          "avg_launch_us": round(avg_us, 3), "alg_bytes_per_launch": alg_bytes(1, K, N)},
         }
 

@@ -18,4 +18,13 @@ for shape in 4096x4096 4096x11008 11008x4096; do
   cp /tmp/prof_$shape.json gpurun_out/${TAG}_prof_bench_$shape.json 2>/dev/null
 done
 echo "== pmc traffic"; timeout 400 bash tools/gpu_pmc_traffic.sh > gpurun_out/${TAG}_pmc_traffic.log 2>&1; tail -5 gpurun_out/${TAG}_pmc_traffic.log
-echo "== per-wave timeline"; for s in "4096 11008" "4096 4096"; do timeout 120 python tools/lut_stamps.py $s 2>&1 | grep -v "amdgpu.ids\|distinct\|workgroup end"; done | tee gpurun_out/${TAG}_lut_timeline.txt
+echo "== per-wave timeline (4096x11008: one group per wave; the instrumented variant exists for that plan only)"; timeout 120 python tools/lut_stamps.py 4096 11008 2>&1 | grep -v "amdgpu.ids\|distinct\|workgroup end" | tee gpurun_out/${TAG}_lut_timeline.txt
+echo "== small-batch sweep"; timeout 300 python - <<'PY' 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${TAG}_m_sweep.txt
+import sys
+sys.path.insert(0, "tools"); sys.path.insert(0, "bitorch-engine_amd")
+from sweep import time_case
+from bitorch_engine import _hip
+for (K, N) in ((4096, 11008), (4096, 4096)):
+    print("bf16", K, N, " ".join(f"M{M}:{time_case(M, K, N, _hip.BF16)['us']}" for M in (1, 2, 3, 4, 8, 12, 16, 17, 32)), flush=True)
+print("f16 4096 11008", " ".join(f"M{M}:{time_case(M, 4096, 11008, _hip.F16)['us']}" for M in (1, 2, 4, 8, 16, 17)), flush=True)
+PY
