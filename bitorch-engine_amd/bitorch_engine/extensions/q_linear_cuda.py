@@ -262,7 +262,8 @@ def mbwq_q4_forward(x, qweight, scales, zeros, group_size, q_perm, bits):
     return y
 
 
-EXL2_GEMV_MAX_M = 32  # rows of x served by the streaming exl2 kernel (4 passes over the packed weight)
+EXL2_GEMV_MAX_M = 8   # rows of x served by the streaming exl2 kernels (one pass over the packed weight).  Measured at 4096x11008,
+                      # 3/2-bit g32: M = 8 39.9 us, M = 16 77.7, M = 32 149.8 (8-row passes) against 52 us for reconstruct + library GEMM
 
 
 def mbwq_exl2_forward(x, qweight, scales, zeros, q_perm, q_group_map, rows, use_cublas=False):

@@ -275,7 +275,7 @@ def test_mbwq_q4_dequant_and_forward(bits, M, perm):
 
 
 @pytest.mark.parametrize("cfg", ["q_proj", "k_proj", "w3w2", "all6"])
-@pytest.mark.parametrize("M", [1, 2, 11, 70])  # 70 > EXL2_GEMV_MAX_M: reconstruct + library GEMM branch
+@pytest.mark.parametrize("M", [1, 2, 7, 11, 70])  # > EXL2_GEMV_MAX_M (8): reconstruct + library GEMM branch
 def test_mbwq_exl2_dequant_and_forward(cfg, M):
     from bitorch_engine.extensions import q_linear_cuda
     from bitorch_engine.layers.qlinear.nbit.cuda.utils import make_group_map
@@ -693,6 +693,34 @@ def test_grouped_forward_matches_separate_calls_and_oracle():
                 assert_close(y, r, dt, f"grouped dt={dt} M={M} set {i}")
                 single = q_linear_cuda.mpq_forward_impl(x.to(DEV), sets[i][0], sets[i][1], sets[i][2], None, 4, 0, gs, sets[i][3])
                 assert torch.equal(y, single) or dt == orc.BF16, "fallback path must equal separate calls bit for bit"
+
+
+def test_layer_level_grouped_forward_equals_the_separate_layers():
+    """MPQLinearCuda.forward_grouped: q/k/v-style layers sharing x through one grouped launch against each layer's own forward (same
+    table values; the K-split plan of the larger grid may differ, hence the summation-order tolerance), and the fallback for a set
+    that cannot be grouped (bit-equal: it IS the layers' forward)."""
+    from bitorch_engine.layers.qlinear.nbit.cuda import MPQLinearCuda
+    K, gs = 1024, 128
+    g = torch.Generator().manual_seed(11)
+    layers = []
+    for N in (256, 384, 128):
+        layer = MPQLinearCuda(K, N, w_bit=4, dtype=torch.bfloat16, group_size=gs, dq_group_size=32, use_gba_quant=True, asym=False)
+        layer.qweight.data = torch.randint(-2 ** 31, 2 ** 31 - 1, layer.qweight.shape, generator=g, dtype=torch.int64).to(torch.int32)
+        layer.prepare_params()
+        layer.scales = (torch.rand(layer.scales.shape, generator=g) * 0.01 + 0.005).bfloat16()
+        layer.zeros = (layer.scales.float() * torch.rand(layer.scales.shape, generator=g) * 15).bfloat16()
+        layers.append(layer.to(DEV).eval())
+    for lead in ((1,), (2, 3), (40,)):  # 40 rows: not groupable -> per-layer forward
+        x = torch.randn(lead + (K,), generator=g).bfloat16().to(DEV)
+        with torch.no_grad():
+            ys = MPQLinearCuda.forward_grouped(layers, x)
+            for y, l in zip(ys, layers):
+                ref = l(x)
+                assert y.shape == lead + (l.out_channels,)
+                if lead == (40,):
+                    assert torch.equal(y, ref)
+                else:
+                    assert_close(y.reshape(-1, l.out_channels), ref.reshape(-1, l.out_channels), orc.BF16, f"grouped layers {lead}")
 
 
 def test_decode_gemv_wide_output_more_than_1024_tiles():
