@@ -420,7 +420,7 @@ __global__ __launch_bounds__(EX2_NW * 64, (EX2_NW == 8 ? 2 : 1)) void exl2_gemv2
 
 // decode (M <= 2): column blocks x K slabs ~ 512 workgroups of 8 waves (two per CU -> one round), slabs in whole multiples of
 // 8 chunks so that the 8 waves of a workgroup get equal shares; at most BIE_WS_COUNTERS column blocks use the slab reduction
-static void exl2_decode_plan(int K, int N, int& cps, int& S, int& nw) {
+static void exl2_decode_plan(int M, int K, int N, int& cps, int& S, int& nw) {
     const int C = K / 32, colblocks = cdiv(N, 64);
     if (colblocks >= 160) {  // wide layers: 16-wave workgroups, one K slab
         nw = 16;
@@ -458,7 +458,7 @@ size_t mbwq_workspace_bytes(int M, int K, int N) {
     const int mc = M < 8 ? M : 8;
     size_t c = (size_t)S * mc * N * sizeof(float);
     int cps2, S2, nw2;
-    exl2_decode_plan(K, N, cps2, S2, nw2);
+    exl2_decode_plan(M, K, N, cps2, S2, nw2);
     const size_t d = M <= 2 && S2 > 1 ? (size_t)(S2 - 1) * M * cdiv(N, 64) * 64 * 8 : 0;  // decode granules
     if (d > c) c = d;
     size_t r = a > b ? a : b;
@@ -501,10 +501,11 @@ int mbwq_exl2_forward_launch(const void* x, const int32_t* qw, const void* scale
                              hipStream_t st) {
     Exl2Rows rows;
     for (int i = 0; i < 6; i++) rows.r[i] = rows7[i];
-    if (M <= 2) {  // decode path
+    if (M <= 2) {  // decode path.  (The packed-fp16 kernel instantiated for 4 / 8 rows measured SLOWER than the fp32 kernel below:
+                   //  33.3 / 46.2 us against 28.0 / 39.9 us at 4096x11008 M = 3 / 8 -- 178-256 registers, one wave per SIMD.)
         const int colblocks = cdiv(N, 64);
         int cps2, S, nw;
-        exl2_decode_plan(K, N, cps2, S, nw);
+        exl2_decode_plan(M, K, N, cps2, S, nw);
         const int MT = M;
         size_t lds2 = (size_t)nw * 4 * MT * 32 * sizeof(uint16_t);  // wave-private x chunk buffers
         const size_t red = (size_t)nw * MT * 64 * sizeof(float);
