@@ -445,6 +445,9 @@ def main():
         guarded("c4_binary", lambda: bench_binary(dev, B.L))
         # ---- configs[4]'s layer on one GPU (the sharded run is `c5` under --gpus N)
         guarded("c5_single_gpu_8192x28672", lambda: B.gemm(4096, 8192, 28672, 2, 3, 31))
+        # the same layer at M = 1 and its gate/up pair in one launch: what the decode kernel reaches once a launch is large (125 / 250 MB)
+        guarded("c5_gemv_8192x28672", lambda: B.gemv(8192, 28672, 6, 10, 32))
+        guarded("c5_grouped_gate_up_2x8192x28672", lambda: B.grouped(8192, (28672, 28672), 3, 10, 33, "70B-class gate/up projections in one launch"))
     if rank == 0:
         out["kernel_source_sha"] = kernel_source_sha()
 
