@@ -92,6 +92,85 @@ __global__ __launch_bounds__(256) void xnor_gemm_kernel(const uint32_t* __restri
         }
 }
 
+// Large-M variant: 128 x 128 block tile, 8 x 8 outputs per thread, K in chunks of 16 words.  Per 4 k-words a thread reads 8 + 8
+// 16-byte LDS vectors for 256 xor + popcount pairs (v_bcnt_u32_b32 accumulates by itself: exactly 2 VALU per 32 binary MACs), i.e.
+// 1 LDS instruction per 32 VALU where the 64 x 64 kernel above needs 1 per 4.  Row stride 20 words: the 16 rows a wave's B read
+// touches fall on 16 disjoint 4-bank groups, 16-byte aligned.  The next chunk's global loads are in flight during the popcounts.
+constexpr int XB = 128, XBK = 16, XBS = 20;
+__global__ __launch_bounds__(256) void xnor_gemm128_kernel(const uint32_t* __restrict__ A, const uint32_t* __restrict__ B,
+                                                           float* __restrict__ y, int M, int N, int KW, int Kbits, float scale) {
+    __shared__ __attribute__((aligned(16))) uint32_t As[XB * XBS];
+    __shared__ __attribute__((aligned(16))) uint32_t Bs[XB * XBS];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int m0 = blockIdx.y * XB, n0 = blockIdx.x * XB;
+    // staging: thread t moves 16-byte pieces (row = t / 4 + 64 * h, words 4 * (t % 4) ..) of both operands
+    const int sr = threadIdx.x >> 2, sc = (threadIdx.x & 3) * 4;
+    const uint32_t* ap[2];
+    const uint32_t* bp[2];
+    bool av[2], bv[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int ra = m0 + sr + 64 * h, rb = n0 + sr + 64 * h;
+        av[h] = ra < M;
+        bv[h] = rb < N;
+        ap[h] = A + (long)(av[h] ? ra : 0) * KW + sc;
+        bp[h] = B + (long)(bv[h] ? rb : 0) * KW + sc;
+    }
+    uint4_t ra4[2], rb4[2];
+    auto gload = [&](int k0) {  // KW % 4 == 0 on this path: a 16-byte piece is all in range or all out
+        const bool kin = k0 + sc < KW;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            ra4[h] = (av[h] && kin) ? *reinterpret_cast<const uint4_t*>(ap[h] + k0) : uint4_t{0u, 0u, 0u, 0u};
+            rb4[h] = (bv[h] && kin) ? *reinterpret_cast<const uint4_t*>(bp[h] + k0) : uint4_t{0u, 0u, 0u, 0u};
+        }
+    };
+    int acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[i][j] = 0;
+    gload(0);
+    for (int k0 = 0; k0 < KW; k0 += XBK) {
+        __syncthreads();  // the previous chunk's readers are done
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            *reinterpret_cast<uint4_t*>(As + (sr + 64 * h) * XBS + sc) = ra4[h];
+            *reinterpret_cast<uint4_t*>(Bs + (sr + 64 * h) * XBS + sc) = rb4[h];
+        }
+        __syncthreads();
+        if (k0 + XBK < KW) gload(k0 + XBK);
+#pragma unroll
+        for (int c = 0; c < XBK; c += 4) {
+            uint4_t a[8], b[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) a[i] = *reinterpret_cast<const uint4_t*>(As + (ty + 16 * i) * XBS + c);
+#pragma unroll
+            for (int j = 0; j < 8; j++) b[j] = *reinterpret_cast<const uint4_t*>(Bs + (tx + 16 * j) * XBS + c);
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                {   // v_bcnt_u32_b32 D = popcount(S0) + S1: written out, or the compiler sums the four popcounts first (+25 % v_add)
+                    asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc[i][j]) : "v"(a[i].x ^ b[j].x));
+                    asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc[i][j]) : "v"(a[i].y ^ b[j].y));
+                    asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc[i][j]) : "v"(a[i].z ^ b[j].z));
+                    asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc[i][j]) : "v"(a[i].w ^ b[j].w));
+                }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int m = m0 + ty + 16 * i;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int n = n0 + tx + 16 * j;
+            if (n < N) y[(long)m * N + n] = (float)(Kbits - 2 * acc[i][j]) * scale;
+        }
+    }
+}
+
 // Skinny-M variant (decode): one wave per output column n, lanes stride over the K words (coalesced),
 // x rows cached in registers, wave reduction.  M <= 4 per launch.
 template <int MT>
@@ -471,6 +550,11 @@ int binary_linear_launch(const uint8_t* xp, const uint8_t* wp, float* y, long M,
         else if (M == 2) hipLaunchKernelGGL(xnor_gemv_kernel<2>, grid, dim3(256), 0, st, (const uint32_t*)xp, (const uint32_t*)wp, y, (int)M, (int)N, KW, (int)K, scale);
         else hipLaunchKernelGGL(xnor_gemv_kernel<4>, grid, dim3(256), 0, st, (const uint32_t*)xp, (const uint32_t*)wp, y, (int)M, (int)N, KW, (int)K, scale);
         return check_launch("xnor_gemv_kernel");
+    }
+    if ((KW & 3) == 0 && cdivl(N, XB) * cdivl(M, XB) >= 256) {  // large M: 128 x 128 tiles, 8 x 8 outputs per thread
+        dim3 grid((unsigned)cdivl(N, XB), (unsigned)cdivl(M, XB));
+        hipLaunchKernelGGL(xnor_gemm128_kernel, grid, dim3(256), 0, st, (const uint32_t*)xp, (const uint32_t*)wp, y, (int)M, (int)N, KW, (int)K, scale);
+        return check_launch("xnor_gemm128_kernel");
     }
     if (cdivl(N, XT) * cdivl(M, XT) < 192) {  // skinny M: 16-row tiles, 4x the blocks
         dim3 grid((unsigned)cdivl(N, XT), (unsigned)cdivl(M, 16), 1);

@@ -369,6 +369,23 @@ def test_binary_linear_4096_vs_oracle(M):
     assert np.array_equal(y.astype(np.int64).sum(axis=1), sx @ colsum)
 
 
+def test_binary_linear_large_ragged_shapes_take_the_128_tile_kernel():
+    """xnor_gemm128_kernel (>= 256 tiles of 128 x 128, K % 128 == 0): M, N not multiples of 128, K of 3 chunks -- exact against the
+    oracle on sampled rows and through the integer checksum over the whole output."""
+    from bitorch_engine.extensions import binary_linear_cuda
+    gen = torch.Generator().manual_seed(77)
+    M, N, K = 2100, 2000, 384
+    x = torch.randn((M, K), generator=gen)
+    w = torch.randn((N, K), generator=gen)
+    y = binary_linear_cuda.forward(x.to(DEV), w.to(DEV), 3, True).cpu().numpy()
+    rows = np.array([0, 1, 127, 128, 1000, 2047, 2048, 2099])
+    ref = orc.binary_linear_rowpacked(orc.binary_pack_rows(x.numpy()[rows]), orc.binary_pack_rows(w.numpy()), K)
+    assert np.array_equal(y[rows], ref)
+    sx = np.where(x.numpy() >= 0, 1, -1).astype(np.int64)
+    colsum = np.where(w.numpy() >= 0, 1, -1).astype(np.int64).sum(axis=0)
+    assert np.array_equal(y.astype(np.int64).sum(axis=1), sx @ colsum)
+
+
 def test_binary_layers_api():
     from bitorch_engine.layers.qlinear.binary.cpp import BinaryLinearCPP
     from bitorch_engine.layers.qlinear.binary.cuda import BinaryLinearCuda

@@ -1,4 +1,12 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
-echo "== pytest"; timeout 900 python -m pytest tests -m gpu -q --maxfail=10 -p no:cacheprovider > gpurun_out/pytest_x.log 2>&1; tail -2 gpurun_out/pytest_x.log; grep -E "^(FAILED|ERROR)" gpurun_out/pytest_x.log | head -8; grep -E "^E  " gpurun_out/pytest_x.log | head -8
-timeout 300 python tools/exl2_m_sweep.py 2>&1 | grep -v amdgpu.ids | tail -1
+echo "== pytest"; timeout 900 python -m pytest tests -m gpu -q --maxfail=10 -p no:cacheprovider -k "binary or conv" > gpurun_out/pytest_x.log 2>&1; tail -2 gpurun_out/pytest_x.log; grep -E "^(FAILED|ERROR)" gpurun_out/pytest_x.log | head -8; grep -E "^E  " gpurun_out/pytest_x.log | head -8
+echo "== binary bench"; timeout 300 python - <<'PY'
+import sys, json
+sys.path.insert(0, "bitorch-engine_amd")
+import torch, bench
+from bitorch_engine import _hip
+dev = torch.device("cuda:0")
+for r in bench.bench_binary(dev, _hip.lib()):
+    if "linear" in r["op"]: print(json.dumps(r), flush=True)
+PY
