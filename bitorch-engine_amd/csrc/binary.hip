@@ -731,6 +731,86 @@ __global__ __launch_bounds__(256) void xnor_conv_taps_kernel(const uint32_t* __r
     }
 }
 
+// The same pass with the lane's tap words staged in LDS by DMA: the 1-tap-ahead prefetch above still pays one global-load latency per
+// tap (a lane's tap rows are private 16-byte pieces, 9 x ~1.5 us per output row on a 7x7 map).  Here a one-wave workgroup issues ALL
+// T * CW4 loads as global_load_lds_dwordx4 up front (no registers; piece p lands at p * 1024 + lane * 16, conflict-free to read
+// back), waits once, and runs the tap loop out of LDS.  T * CW4 * 1 KiB + the row slab per workgroup (37.5 KiB for 3x3x512).
+template <int CW4, int PXC>  // PXC output pixels per workgroup: 2 when the problem is small (more, shorter waves), else 8
+__global__ __launch_bounds__(64) void xnor_conv_taps_dma_kernel(const uint32_t* __restrict__ xbits, const uint32_t* __restrict__ wtaps,
+                                                                float* __restrict__ y, int B, int C, int H, int W, int OC, int OH, int OW,
+                                                                int ks, int stride, int pad, int dil, float scale) {
+    constexpr int CW = 4 * CW4;
+    extern __shared__ __attribute__((aligned(16))) uint32_t conv_lds[];
+    const int lane = threadIdx.x;
+    const int pchunks = (OW + PXC - 1) / PXC;
+    const long item = blockIdx.x / pchunks;  // (b, oh, oc block), oc block fastest; pixel chunk innermost
+    const int ow0 = (int)(blockIdx.x % pchunks) * PXC;
+    const int ocbs = (OC + 63) >> 6;
+    const int ocb = (int)(item % ocbs);
+    const int oh = (int)((item / ocbs) % OH);
+    const long b = item / ((long)ocbs * OH);
+    const int T = ks * ks;
+    const int oc = ocb * 64 + lane;
+    const uint32_t* wl = wtaps + (long)(oc < OC ? oc : OC - 1) * T * CW;
+    uint32_t* wlds = conv_lds;                       // [T * CW4][64 lanes][4 words]
+    uint32_t* slab = conv_lds + T * CW4 * 256;       // [ks][W + 1][CW]
+#if defined(__HIP_DEVICE_COMPILE__)
+    {
+        auto* dst = (__attribute__((address_space(3))) unsigned char*)wlds;
+        for (int p = 0; p < T * CW4; p++) __builtin_amdgcn_global_load_lds(wl + 4 * p, dst + p * 1024, 16, 0, 0);
+    }
+#endif
+    const int rowstride = (W + 1) * CW;
+    for (int i = 0; i < ks; i++) {
+        const int ih = oh * stride - pad + i * dil;
+        const bool valid = ih >= 0 && ih < H;
+        const uint32_t* src = xbits + ((b * H + (valid ? ih : 0)) * W) * CW;
+#pragma unroll 2
+        for (int t = lane; t < rowstride; t += 64) slab[i * rowstride + t] = (valid && t < W * CW) ? src[t] : 0u;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA pieces have landed
+    __builtin_amdgcn_wave_barrier();
+    const int Kc = C * T;
+    {
+        int acc[PXC];
+#pragma unroll
+        for (int px = 0; px < PXC; px++) acc[px] = 0;
+        int i = 0, j = 0;
+#pragma unroll 1
+        for (int t = 0; t < T; t++) {
+            int pix[PXC];
+#pragma unroll
+            for (int px = 0; px < PXC; px++) {
+                const int iw = (ow0 + px) * stride - pad + j * dil;
+                pix[px] = i * rowstride + ((iw >= 0 && iw < W && ow0 + px < OW) ? iw : W) * CW;
+            }
+            uint4_t wq[CW4];
+#pragma unroll
+            for (int q = 0; q < CW4; q++) wq[q] = *reinterpret_cast<const uint4_t*>(wlds + (t * CW4 + q) * 256 + lane * 4);
+#pragma unroll
+            for (int px = 0; px < PXC; px++)
+#pragma unroll
+                for (int q = 0; q < CW4; q++) {
+                    const uint4_t x4 = *reinterpret_cast<const uint4_t*>(slab + pix[px] + 4 * q);
+                    asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc[px]) : "v"(wq[q].x ^ x4.x));
+                    asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc[px]) : "v"(wq[q].y ^ x4.y));
+                    asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc[px]) : "v"(wq[q].z ^ x4.z));
+                    asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc[px]) : "v"(wq[q].w ^ x4.w));
+                }
+            if (++j == ks) {
+                j = 0;
+                i++;
+            }
+        }
+        if (oc < OC) {
+            float* yr = y + ((b * OC + oc) * OH + oh) * OW + ow0;
+#pragma unroll
+            for (int px = 0; px < PXC; px++)
+                if (ow0 + px < OW) yr[px] = (float)(Kc - 2 * acc[px]) * scale;
+        }
+    }
+}
+
 // LDS of one workgroup (4 waves) of the implicit conv; 0 = geometry outside its range (rows too long for a 16 KiB slab)
 size_t binary_conv_taps_lds_bytes(int C, int W, int ks) {
     const size_t slab = (size_t)ks * (W + 1) * cdiv(C, 32);
@@ -762,6 +842,21 @@ int binary_conv_taps_launch(const void* x, const uint32_t* wtaps, float* y, void
     }
     const size_t lds = binary_conv_taps_lds_bytes(C, W, ks);
     const long items = (long)B * OH * cdiv(OC, 64);
+    {   // one-wave workgroups with the tap words DMA-staged in LDS, when they fit next to the row slab in 64 KiB
+        const size_t wbytes = (size_t)ks * ks * CW * 256, sbytes = (size_t)ks * (W + 1) * CW * 4;
+        static const bool dma_on = [] { const char* e = getenv("BIE_CONV_DMA"); return !e || atoi(e) != 0; }();
+        if (dma_on && (CW == 16 || CW == 8 || CW == 4) && wbytes + sbytes <= 65536 && items < 1024) {
+            // small problems only (measured 7x7x512 3x3: B = 1 15.3 -> see profiles; at B = 32 the 4-wave kernel below is faster, 24.9 against 33 us)
+            const size_t l2 = wbytes + ((sbytes + 15) & ~(size_t)15);
+            const long grid = items * cdiv(OW, 2);
+#define LD(C4V) hipLaunchKernelGGL((xnor_conv_taps_dma_kernel<C4V, 2>), dim3((unsigned)grid), dim3(64), l2, st, xbits, wtaps, y, B, C, H, W, OC, OH, OW, ks, stride, pad, dil, scale)
+            if (CW == 16) LD(4);
+            else if (CW == 8) LD(2);
+            else LD(1);
+#undef LD
+            return check_launch("xnor_conv_taps_dma_kernel");
+        }
+    }
 #define LC(C4V) hipLaunchKernelGGL(xnor_conv_taps_kernel<C4V>, dim3((unsigned)cdivl(items, 4)), dim3(256), lds, st, xbits, wtaps, y, B, C, H, W, OC, OH, OW, \
                                    ks, stride, pad, dil, CW, scale, items, (int)(lds / 16))
     if (CW == 16) LC(4);  // 512 / 256 / 128 channels: the deep layers of a binary ResNet
