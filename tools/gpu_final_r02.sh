@@ -14,7 +14,7 @@ for shape in 4096x4096 4096x11008 11008x4096; do
   echo "== rocprof kernel stats $shape"
   (cd /tmp && rm -rf /tmp/prof_$shape && timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$shape -o s -- python $R/bench.py --only $shape --no-cpu-baseline > /tmp/prof_$shape.json 2> /tmp/prof_$shape.err)
   f=$(find /tmp/prof_$shape -name "*kernel_stats*.csv" | head -1)
-  if [ -n "$f" ]; then cp $f gpurun_out/${TAG}_kernel_stats_$shape.csv; head -4 $f; fi
+  if [ -n "$f" ]; then cp $f gpurun_out/${TAG}_kernel_stats_$shape.csv; head -2 $f | cut -c1-200; fi
   cp /tmp/prof_$shape.json gpurun_out/${TAG}_prof_bench_$shape.json 2>/dev/null
 done
 echo "== pmc traffic"; timeout 400 bash tools/gpu_pmc_traffic.sh > gpurun_out/${TAG}_pmc_traffic.log 2>&1; tail -5 gpurun_out/${TAG}_pmc_traffic.log
