@@ -46,8 +46,8 @@ def alg_bytes(M, k, n, w=WBIT, g=GROUP):
     return k * n * w // 8 + 2 * G * n + 2 * G * n + 2 * M * k + 2 * M * n
 
 
-def make_layer(dev, gen, k, n):
-    qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (k * WBIT // 32, n), dtype=torch.int32, generator=gen, device=dev)
+def make_layer(dev, gen, k, n, w_bit=WBIT):
+    qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (k * w_bit // 32, n), dtype=torch.int32, generator=gen, device=dev)
     scales = (torch.rand((k // GROUP, n), generator=gen, device=dev) * 0.01 + 0.005).to(BF16)
     zeros = (scales.float() * torch.rand((k // GROUP, n), generator=gen, device=dev) * 15).to(BF16)
     return qw, scales, zeros
@@ -108,29 +108,29 @@ class Bench:
         self.L = _hip.lib()
         self.dev = dev
 
-    def forward(self, x, layer, y, ws, M, k, n, st):
+    def forward(self, x, layer, y, ws, M, k, n, st, w_bit=WBIT):
         qw, sc, ze = layer
         rc = self.L.bie_mpq_forward(x.data_ptr(), qw.data_ptr(), sc.data_ptr(), ze.data_ptr(), None, None, y.data_ptr(), ws.data_ptr(),
-                                    ws.numel(), M, k, n, WBIT, GROUP, 0, self._hip.BF16, st)
+                                    ws.numel(), M, k, n, w_bit, GROUP, 0, self._hip.BF16, st)
         if rc:
             raise RuntimeError(self.L.bie_last_error().decode())
 
-    def workspace(self, M, k, n):
-        return torch.zeros(max(self.L.bie_mpq_workspace_bytes(M, k, n, WBIT), 16), dtype=torch.uint8, device=self.dev)
+    def workspace(self, M, k, n, w_bit=WBIT):
+        return torch.zeros(max(self.L.bie_mpq_workspace_bytes(M, k, n, w_bit), 16), dtype=torch.uint8, device=self.dev)
 
     # ---- M = 1 decode over `nl` distinct layers -> per-launch microseconds
-    def gemv(self, k, n, nl, reps, seed, M=1):
+    def gemv(self, k, n, nl, reps, seed, M=1, w_bit=WBIT):
         gen = torch.Generator(device=self.dev).manual_seed(seed)
-        layers = [make_layer(self.dev, gen, k, n) for _ in range(nl)]
+        layers = [make_layer(self.dev, gen, k, n, w_bit) for _ in range(nl)]
         x = torch.randn((M, k), generator=gen, device=self.dev).to(BF16)
         y = torch.empty((M, n), dtype=BF16, device=self.dev)
-        ws = self.workspace(M, k, n)
-        g = capture(lambda st: [self.forward(x, l, y, ws, M, k, n, st) for l in layers])
+        ws = self.workspace(M, k, n, w_bit)
+        g = capture(lambda st: [self.forward(x, l, y, ws, M, k, n, st, w_bit) for l in layers])
         us = time_graph(g, reps) / nl
-        b = alg_bytes(M, k, n)
-        return {"M": M, "K": k, "N": n, "layers": nl, "us_per_launch": round(us, 3), "alg_bytes_per_launch": b,
+        b = alg_bytes(M, k, n, w_bit)
+        return {"M": M, "K": k, "N": n, "w_bit": w_bit, "layers": nl, "us_per_launch": round(us, 3), "alg_bytes_per_launch": b,
                 "roofline": {"bound": "hbm", "achieved": round(b / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(b / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(f"{k}x{n}") if M == 1 else None}}
+                             "frac": round(b / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(f"{k}x{n}") if (M == 1 and w_bit == 4) else None}}
 
     # ---- grouped decode: `ns` column counts sharing x, `nl` distinct groups of layers
     def grouped(self, k, ns, nl, reps, seed, what):
@@ -442,6 +442,9 @@ def main():
         guarded("grouped_gate_up_2x4096x11008", lambda: B.grouped(4096, (11008, 11008), 20, 10, 22, "gate/up projections in one launch"))
         # ---- configs[2], configs[3]
         guarded("c3_exl2", lambda: bench_exl2(dev))
+        guarded("c3_w2a16_4096x4096", lambda: B.gemv(4096, 4096, 64, 10, 41, w_bit=2))      # uniform W2A16 (MPQ): pair-lookup + dot2 kernel
+        guarded("c3_w2a16_4096x11008", lambda: B.gemv(4096, 11008, 40, 10, 42, w_bit=2))
+        guarded("c3_w2a16_11008x4096", lambda: B.gemv(11008, 4096, 40, 10, 43, w_bit=2))
         guarded("c4_binary", lambda: bench_binary(dev, B.L))
         # ---- configs[4]'s layer on one GPU (the sharded run is `c5` under --gpus N)
         guarded("c5_single_gpu_8192x28672", lambda: B.gemm(4096, 8192, 28672, 2, 3, 31))

@@ -16,10 +16,10 @@ int mpq_gemv_generic_launch(const void* x, const int32_t* qw, const void* scales
                             int asym, int dtype, hipStream_t st);
 // mpq_gemv_lut.hip
 bool mpq_gemv_lut_ok(int M, int K, int w_bit, int group_size, int dtype, bool has_gidx);
-size_t mpq_gemv_lut_part_floats(int M, int K, int group_size, int tiles_total);
+size_t mpq_gemv_lut_part_floats(int M, int K, int group_size, int tiles_total, int w_bit);
 int mpq_gemv_lut_launch(int nsets, const int32_t* const* qw, const void* const* scales, const void* const* zeros,
                         const void* const* bias, void* const* y, const int* N, const void* x, unsigned* counters, float* part,
-                        int M, int K, int group_size, int zm, int dtype, hipStream_t st);
+                        int M, int K, int group_size, int zm, int dtype, hipStream_t st, int w_bit);
 // mpq_gemm.hip
 bool mpq_gemm_ok(int M, int K, int N, int w_bit, int group_size, int dtype, bool has_gidx);
 size_t mpq_gemm_workspace_bytes(int M, int K, int N);
@@ -168,11 +168,11 @@ size_t bie_mpq_grouped_workspace_bytes(int n_sets, const int* N, int M, int K, i
         const size_t b = bie_mpq_workspace_bytes(M, K, N[i], w_bit);
         if (b > need) need = b;
     }
-    if (w_bit == 4 && M <= 16) {
+    if ((w_bit == 4 && M <= 16) || (w_bit == 2 && M <= 2)) {
         const int tiles = grouped_tiles(n_sets, N);
         for (int gs = 32; gs <= 256; gs *= 2)
             if (K % gs == 0) {
-                const size_t b = WS_HEAD + mpq_gemv_lut_part_floats(M, K, gs, tiles) * sizeof(float);
+                const size_t b = WS_HEAD + mpq_gemv_lut_part_floats(M, K, gs, tiles, w_bit) * sizeof(float);
                 if (b > need) need = b;
             }
     }
@@ -199,7 +199,7 @@ int bie_mpq_forward_grouped(const void* x, int n_sets, const int32_t* const* qwe
     if (tiles <= BIE_WS_COUNTERS && mpq_gemv_lut_ok(M, K, w_bit, group_size, dtype, false)) {
         float* head = reinterpret_cast<float*>(workspace);
         return mpq_gemv_lut_launch(n_sets, qweight, scales, zeros, bias, y, N, x, reinterpret_cast<unsigned*>(head) + BIE_WS_GEN_OFFSET,
-                                   head + WS_HEAD / sizeof(float), M, K, group_size, asym ? 1 : 0, dtype, as_stream(stream));
+                                   head + WS_HEAD / sizeof(float), M, K, group_size, asym ? 1 : 0, dtype, as_stream(stream), w_bit);
     }
     for (int i = 0; i < n_sets; i++) {  // every other case: one launch per set (same results)
         int rc = bie_mpq_forward(x, qweight[i], scales[i], zeros[i], nullptr, bias ? bias[i] : nullptr, y[i], workspace,

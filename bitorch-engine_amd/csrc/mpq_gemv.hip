@@ -23,10 +23,10 @@ namespace bie {
 
 // mpq_gemv_lut.hip
 bool mpq_gemv_lut_ok(int M, int K, int w_bit, int group_size, int dtype, bool has_gidx);
-size_t mpq_gemv_lut_part_floats(int M, int K, int group_size, int tiles_total);
+size_t mpq_gemv_lut_part_floats(int M, int K, int group_size, int tiles_total, int w_bit);
 int mpq_gemv_lut_launch(int nsets, const int32_t* const* qw, const void* const* scales, const void* const* zeros,
                         const void* const* bias, void* const* y, const int* N, const void* x, unsigned* counters, float* part,
-                        int M, int K, int group_size, int zm, int dtype, hipStream_t st);
+                        int M, int K, int group_size, int zm, int dtype, hipStream_t st, int w_bit);
 
 static int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
@@ -623,10 +623,10 @@ bool mpq_gemv_fast_ok(int M, int K, int N, int w_bit, int group_size, int dtype,
 
 size_t mpq_gemv_workspace_bytes(int M, int K, int N, int w_bit) {
     size_t lut = 0;  // the group size is not known here: take the largest slab count any supported group size gives
-    if (w_bit == 4 && M <= 16)
+    if ((w_bit == 4 && M <= 16) || (w_bit == 2 && M <= 2))
         for (int gs = 32; gs <= 256; gs *= 2)
             if (K % gs == 0) {
-                const size_t f = mpq_gemv_lut_part_floats(M, K, gs, cdiv(N, 64));
+                const size_t f = mpq_gemv_lut_part_floats(M, K, gs, cdiv(N, 64), w_bit);
                 if (f > lut) lut = f;
             }
     lut = lut ? lut * sizeof(float) + BIE_WS_HEAD_BYTES : 0;
@@ -650,7 +650,7 @@ int mpq_gemv_launch(const void* x, const int32_t* qw, const void* scales, const 
         const void* bi1[1] = {bias};
         void* y1[1] = {y};
         return mpq_gemv_lut_launch(1, &qw, sc1, ze1, bias ? bi1 : nullptr, y1, &N, x, reinterpret_cast<unsigned*>(part) + BIE_WS_GEN_OFFSET,
-                                   part + BIE_WS_HEAD_BYTES / sizeof(float), M, K, group_size, zm, dtype, st);
+                                   part + BIE_WS_HEAD_BYTES / sizeof(float), M, K, group_size, zm, dtype, st, w_bit);
     }
     const int MT = M <= 1 ? 1 : (M <= 2 ? 2 : (M <= 4 ? 4 : 8));
     static const int use_v3 = env_int("BIE_GEMV_V3", 1);

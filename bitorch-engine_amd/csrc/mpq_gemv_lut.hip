@@ -141,9 +141,15 @@ __device__ __forceinline__ void lut_cross_wg_reduce(const LutArgs& a, const LutS
 // RD = rows of every group dequantised directly on the VALU (mpq_dequant.cuh) instead of through the table: the table path is
 // LDS-throughput bound (one ds_read_b32 per weight, 32 lookups per clock per CU), the direct path VALU bound; splitting the
 // rows between them balances the two pipes
-template <int DT, int ZM, int MT, int RPG, int NW, int LAB, int RD = 0>
+// WB = 2 (W2A16): a packed word holds 16 two-bit weights = 8 nibbles, and a nibble is a PAIR index (q[2i] | q[2i+1] << 2): the
+// table holds the 16 possible pairs of dequantised weights as packed 16-bit halves and one v_dot2(c)_f32_{bf16,f16} against the
+// packed x pair -- which is how x arrives from the scalar loads anyway -- consumes two weights: per word the same 2 + 8 + 8
+// instructions as W4 for twice the weights, fp16 and bf16 alike (RPG = group_size / 16).
+template <int DT, int ZM, int MT, int RPG, int NW, int LAB, int RD = 0, int WB = 4>
 __global__ __launch_bounds__(NW * 64) void mpq_gemv_lut_kernel(const LutArgs a) {
-    constexpr int NB = 8;  // W4: 8 weights per packed word
+    constexpr int NB = 32 / WB;      // weights per packed word
+    constexpr int XD = NB / 2;       // x dwords (16-bit pairs) per packed word
+    static_assert(WB == 4 || (WB == 2 && LAB == 0 && RD == 0), "the tuning variants exist for W4 only");
     __shared__ __attribute__((aligned(4096))) uint32_t tab[NW * 16 * 64];  // the only LDS object: starts at LDS address 0
 
     const int lane = threadIdx.x & 63;
@@ -179,7 +185,7 @@ __global__ __launch_bounds__(NW * 64) void mpq_gemv_lut_kernel(const LutArgs a) 
         sb = ls.scales[(long)g * N + nl];
         if constexpr (ZM == ZM_ASYM) {
             const uint32_t zw = reinterpret_cast<const uint32_t*>(ls.zeros)[(long)g * zero_width + nl / NB];
-            zb = ((zw >> ((nl % NB) * 4)) & 15u) + 1u;
+            zb = ((zw >> ((nl % NB) * WB)) & ((1u << WB) - 1u)) + 1u;
         } else {
             zb = reinterpret_cast<const uint16_t*>(ls.zeros)[(long)g * N + nl];
         }
@@ -199,15 +205,29 @@ __global__ __launch_bounds__(NW * 64) void mpq_gemv_lut_kernel(const LutArgs a) 
     auto process_group = [&](const uint32_t (&w)[RPG], int g, uint32_t sb, uint32_t zb) {
         // the activations of the group are wave-uniform: scalar loads, issued before the table is built so that nothing
         // but LDS traffic is pending in the lookup phase
-        uint32_t xs[MT][RPG * 4];
+        uint32_t xs[MT][RPG * XD];
 #pragma unroll
         for (int m = 0; m < MT; m++) {
             const_u32* xd = (const_u32*)(uintptr_t)(a.x + (long)m * a.K + (long)g * (RPG * NB));
 #pragma unroll
-            for (int i = 0; i < RPG * 4; i++) xs[m][i] = xd[i];
+            for (int i = 0; i < RPG * XD; i++) xs[m][i] = xd[i];
         }
         // ---- the 16-entry table of this (group, column)
-        if constexpr (LAB == 0 || LAB == 3 || LAB == 5) {
+        if constexpr (WB == 2) {
+            float s, z = 0.0f;
+            int zq1 = 0;
+            if constexpr (DT == BIE_BF16) s = bf16_bits_to_f32(sb); else s = f16_bits_to_f32(sb);
+            if constexpr (ZM == ZM_ASYM) zq1 = (int)zb;
+            else if constexpr (DT == BIE_BF16) z = bf16_bits_to_f32(zb); else z = f16_bits_to_f32(zb);
+            uint32_t v[4];  // the four dequantised values as 16-bit patterns
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float t = lut_entry<DT, ZM>((uint32_t)q, s, z, zq1);
+                if constexpr (DT == BIE_BF16) v[q] = __float_as_uint(t) >> 16; else v[q] = f32_to_f16_bits(t);
+            }
+#pragma unroll
+            for (int p2 = 0; p2 < 16; p2++) mytab[p2 * 64] = v[p2 & 3] | (v[p2 >> 2] << 16);
+        } else if constexpr (LAB == 0 || LAB == 3 || LAB == 5) {
             if constexpr (DT == BIE_BF16 && ZM == ZM_SYM) {
                 // a_q = fl(q*s): v_mul_f32 (exact) + v_cvt_pk_bf16_f32; T_q = fl(a_q - z): unpack-and-subtract on the dot unit
                 // (bf16_pairs_sub) + v_cvt_pk_bf16_f32; the entry is the fp32 value of the bf16 weight (bf16 << 16)
@@ -241,7 +261,7 @@ __global__ __launch_bounds__(NW * 64) void mpq_gemv_lut_kernel(const LutArgs a) 
 #pragma unroll
         for (int m = 0; m < MT; m++)
 #pragma unroll
-            for (int i = 0; i < RPG * 4; i += 8)
+            for (int i = 0; i < RPG * XD; i += 8)
                 asm volatile("" ::"s"(xs[m][i]), "s"(xs[m][i + 1]), "s"(xs[m][i + 2]), "s"(xs[m][i + 3]), "s"(xs[m][i + 4]), "s"(xs[m][i + 5]),
                              "s"(xs[m][i + 6]), "s"(xs[m][i + 7]));
         if constexpr (LAB == 2 || LAB == 4) {  // tuning aid: stream only
@@ -265,6 +285,14 @@ __global__ __launch_bounds__(NW * 64) void mpq_gemv_lut_kernel(const LutArgs a) 
             t[7] = lds_f32(lut_addr<3>(lane_addr, wo));
         };
         auto fmas = [&](const float (&t)[8], int u) {
+            if constexpr (WB == 2) {  // t[i] = the packed pair (w[2i], w[2i+1]) of nibble i; x dword i of the word = (x[2i], x[2i+1])
+#pragma unroll
+                for (int m = 0; m < MT; m++)
+#pragma unroll
+                    for (int i = 0; i < 8; i++)
+                        acc[m][i & 1] = dot2_acc<DT>(__float_as_uint(t[i]), xs[m][u * 8 + i], acc[m][i & 1]);
+                return;
+            }
 #pragma unroll
             for (int m = 0; m < MT; m++)
 #pragma unroll
@@ -835,10 +863,17 @@ static bool lut_use_mfma(int M, int dtype) {
 }
 bool mpq_gemv_lut_ok(int M, int K, int w_bit, int group_size, int dtype, bool has_gidx) {
     static const int enabled = lut_env("BIE_GEMV_LUT", 1);
-    if (!enabled || has_gidx || w_bit != 4 || M < 1) return false;
+    static const int w2 = lut_env("BIE_GEMV_LUT_W2", 1);
+    if (!enabled || has_gidx || M < 1) return false;
     if (dtype != BIE_BF16 && dtype != BIE_F16) return false;
-    if (!lut_use_mfma(M, dtype) && (dtype != BIE_BF16 || M > 2)) return false;
     const int gs = group_size > K ? K : group_size;
+    if (w_bit == 2) {  // pair lookup + dot2: fp16 and bf16, M <= 2, groups of 64 / 128 / 256 (RPG = gs / 16 >= 4)
+        if (!w2 || M > 2) return false;
+        if (gs != 64 && gs != 128 && gs != 256) return false;
+        return K % gs == 0;
+    }
+    if (w_bit != 4) return false;
+    if (!lut_use_mfma(M, dtype) && (dtype != BIE_BF16 || M > 2)) return false;
     if (gs != 32 && gs != 64 && gs != 128 && gs != 256) return false;
     return K % gs == 0;
 }
@@ -851,7 +886,7 @@ struct LutPlan {
 // chip short of waves split every group into H = 2 or 4 units (each wave then builds the group's table for 8 or 4 rows: the
 // per-wave critical path, which is what a 4096x4096 launch spends its time on, shrinks accordingly); big grids give a wave
 // several units (bounds the granule traffic).
-static LutPlan lut_plan(int M, int dtype, int K, int group_size, int tiles_total) {
+static LutPlan lut_plan(int M, int dtype, int K, int group_size, int tiles_total, int w_bit = 4) {
     static const int min_rows = lut_env("BIE_LUT_ROWS", 16);
     static const int nw_env = lut_env("BIE_LUT_NW", 8);
     static const int max_wg = lut_env("BIE_LUT_MAX_WG", 2048);
@@ -860,9 +895,10 @@ static LutPlan lut_plan(int M, int dtype, int K, int group_size, int tiles_total
     static const int want_waves = lut_env("BIE_LUT_WANT_WAVES", 4096);
     LutPlan p;
     const int gs = group_size > K ? K : group_size;
-    p.rpg = gs / 8;
+    p.rpg = gs / (32 / w_bit);
     p.G = K / gs;
-    p.coop = coop && !lut_use_mfma(M, dtype);
+    const bool mfma = w_bit == 4 && lut_use_mfma(M, dtype);
+    p.coop = coop && !mfma && w_bit == 4;
     p.H = 1;
     if (p.coop) {  // four waves per group, 128 / rpg groups per workgroup (mpq_gemv_lutc_kernel)
         p.nw = 4;
@@ -870,7 +906,7 @@ static LutPlan lut_plan(int M, int dtype, int K, int group_size, int tiles_total
         p.S = cdiv(p.G, p.gpw);
         return p;
     }
-    p.nw = lut_use_mfma(M, dtype) ? 8 : (nw_env == 4 ? 4 : (nw_env == 2 ? 2 : 8));
+    p.nw = (mfma || w_bit != 4) ? 8 : (nw_env == 4 ? 4 : (nw_env == 2 ? 2 : 8));
     int H = 1;
     if (force_h > 0) H = force_h;
     else
@@ -889,14 +925,36 @@ static LutPlan lut_plan(int M, int dtype, int K, int group_size, int tiles_total
 }
 
 // granule area behind the workspace head, counted in floats (a granule = 8 bytes)
-size_t mpq_gemv_lut_part_floats(int M, int K, int group_size, int tiles_total) {
+size_t mpq_gemv_lut_part_floats(int M, int K, int group_size, int tiles_total, int w_bit) {
     size_t need = 0;  // the dtype is not known where workspaces are sized: the larger of the two plans
     for (int dtype : {BIE_F16, BIE_BF16}) {
-        const LutPlan p = lut_plan(M, dtype, K, group_size, tiles_total);
+        const LutPlan p = lut_plan(M, dtype, K, group_size, tiles_total, w_bit);
         const size_t f = p.S > 1 ? (size_t)(p.S - 1) * M * tiles_total * 64 * 2 : 0;
         if (f > need) need = f;
     }
     return need;
+}
+
+// W2A16: pair-lookup instances (8-wave workgroups, no tuning variants)
+template <int DT, int ZM, int MT>
+static void lut2_launch_rpg(const LutArgs& a, int rpg, int grid, hipStream_t st) {
+    switch (rpg) {
+        case 4: hipLaunchKernelGGL((mpq_gemv_lut_kernel<DT, ZM, MT, 4, 8, 0, 0, 2>), dim3(grid), dim3(512), 0, st, a); break;
+        case 8: hipLaunchKernelGGL((mpq_gemv_lut_kernel<DT, ZM, MT, 8, 8, 0, 0, 2>), dim3(grid), dim3(512), 0, st, a); break;
+        default: hipLaunchKernelGGL((mpq_gemv_lut_kernel<DT, ZM, MT, 16, 8, 0, 0, 2>), dim3(grid), dim3(512), 0, st, a); break;
+    }
+}
+template <int DT>
+static void lut2_launch(const LutArgs& a, int rpg, int grid, int M, int zm, hipStream_t st) {
+    if (M == 1) {
+        if (zm == ZM_ASYM) lut2_launch_rpg<DT, ZM_ASYM, 1>(a, rpg, grid, st);
+        else if (zm == ZM_FUSED) lut2_launch_rpg<DT, ZM_FUSED, 1>(a, rpg, grid, st);
+        else lut2_launch_rpg<DT, ZM_SYM, 1>(a, rpg, grid, st);
+    } else {
+        if (zm == ZM_ASYM) lut2_launch_rpg<DT, ZM_ASYM, 2>(a, rpg, grid, st);
+        else if (zm == ZM_FUSED) lut2_launch_rpg<DT, ZM_FUSED, 2>(a, rpg, grid, st);
+        else lut2_launch_rpg<DT, ZM_SYM, 2>(a, rpg, grid, st);
+    }
 }
 
 template <int DT, int ZM, int MT, int NW>
@@ -992,7 +1050,7 @@ static void lutm_launch(const LutArgs& a, int rpg, int grid, int zm, hipStream_t
 // sets: n weight sets sharing x (one for a plain forward).  `gen` = the workspace's head, `gran` = granule area.
 int mpq_gemv_lut_launch(int nsets, const int32_t* const* qw, const void* const* scales, const void* const* zeros,
                         const void* const* bias, void* const* y, const int* N, const void* x, unsigned* gen, float* gran,
-                        int M, int K, int group_size, int zm, int dtype, hipStream_t st) {
+                        int M, int K, int group_size, int zm, int dtype, hipStream_t st, int w_bit) {
     LutArgs a;
     int tiles = 0;
     for (int i = 0; i < LUT_MAX_SETS; i++) {
@@ -1006,7 +1064,7 @@ int mpq_gemv_lut_launch(int nsets, const int32_t* const* qw, const void* const* 
         a.set[i].tile_begin = tiles;
         if (i < nsets) tiles += cdiv(N[j], 64);
     }
-    const LutPlan p = lut_plan(M, dtype, K, group_size, tiles);
+    const LutPlan p = lut_plan(M, dtype, K, group_size, tiles, w_bit);
     a.x = reinterpret_cast<const uint16_t*>(x);
     a.gran = reinterpret_cast<unsigned long long*>(gran);
     a.gen = gen;
@@ -1020,6 +1078,11 @@ int mpq_gemv_lut_launch(int nsets, const int32_t* const* qw, const void* const* 
     a.hshift = p.H == 4 ? 2 : (p.H == 2 ? 1 : 0);
     a.epoch = next_launch_epoch();
     const int grid = tiles * p.S;
+    if (w_bit == 2) {
+        if (dtype == BIE_F16) lut2_launch<BIE_F16>(a, p.rpg, grid, M, zm, st);
+        else lut2_launch<BIE_BF16>(a, p.rpg, grid, M, zm, st);
+        return check_launch("mpq_gemv_lut_kernel<W2>");
+    }
     if (lut_use_mfma(M, dtype) && !p.coop) {
         if (dtype == BIE_F16) lutm_launch<BIE_F16>(a, p.rpg, grid, zm, st);
         else lutm_launch<BIE_BF16>(a, p.rpg, grid, zm, st);

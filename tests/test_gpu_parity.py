@@ -676,6 +676,23 @@ def test_lut_gemv_matrix_pipe_form_small_batches(K, N, gs, asym, M, dt):
     assert torch.equal(y, hip_forward(x, qw, scales, zeros, None, 4, gs, asym, bias)), "not reproducible run to run"
 
 
+@pytest.mark.parametrize("dt", [orc.BF16, orc.F16])
+@pytest.mark.parametrize("K,N,gs,asym,M", [(1024, 208, 64, 0, 1), (768, 528, 256, 0, 2), (1408, 144, 128, 1, 1), (2048, 1008, 128, 1, 2),
+                                            (4096, 4096, 128, 0, 1), (512, 80, 64, 0, 2)])
+def test_lut_gemv_w2_pair_lookup(K, N, gs, asym, M, dt):
+    """W2A16 decode (M <= 2): the lookup kernel's pair form -- a nibble of the packed word indexes a 16-entry table of weight PAIRS,
+    one v_dot2 per pair against the packed x pair.  Table values are the reference's doubly rounded weights, so only the fp32
+    summation order differs from the oracle; group sizes 64 / 128 / 256, sym and asym, ragged column tiles, fp16 and bf16."""
+    rng = np.random.default_rng(K + N + gs + M + dt)
+    qw, scales, zeros, gen = rand_case(rng, K, N, 2, gs, dt, asym)
+    x = torch.randn((M, K), generator=gen).to(TDT[dt])
+    bias = (torch.randn(N, generator=gen) * 0.1).to(TDT[dt])
+    y = hip_forward(x, qw, scales, zeros, None, 2, gs, asym, bias)
+    ref = oracle_forward(x, qw, scales, zeros, None, 2, gs, asym, dt, bias)
+    assert_close(y, ref, dt, f"w2 K={K} N={N} g={gs} asym={asym} M={M}")
+    assert torch.equal(y, hip_forward(x, qw, scales, zeros, None, 2, gs, asym, bias)), "not reproducible run to run"
+
+
 @pytest.mark.parametrize("split", ["1", "2", "4"])
 def test_lut_gemv_split_groups(split, monkeypatch):
     """Small layers split every quantisation group over 2 or 4 waves (BIE_LUT_H is read once per process: the test forces the
