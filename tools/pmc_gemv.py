@@ -10,7 +10,9 @@ from bitorch_engine import _hip
 L = _hip.lib()
 dt = _hip.BF16 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else _hip.F16
 KK, NN = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (4096, 11008)
-print(sweep.time_case(1, KK, NN, dt, layers=26, reps=3, graph=False))
+MM = int(sys.argv[4]) if len(sys.argv) > 4 else 1   # optional: rows of x
+WB = int(sys.argv[5]) if len(sys.argv) > 5 else 4   # optional: weight bits
+print(sweep.time_case(MM, KK, NN, dt, layers=26, reps=3, graph=False, w_bit=WB))
 if len(sys.argv) > 3:
     sys.exit(0)
 K, N, gs = 4096, 11008, 128
