@@ -662,7 +662,7 @@ def test_lut_gemv_group_sizes_ragged_tiles_and_tails(K, N, gs, asym, M):
                                             (1024, 200, 128, 0, 1), (1024, 4096, 128, 1, 2), (2048, 328, 64, 0, 12), (4096, 1024, 128, 1, 16),
                                             (512, 68, 32, 0, 9)])
 def test_lut_gemv_matrix_pipe_form_small_batches(K, N, gs, asym, M, dt):
-    """2 <= M <= 16 (fp16: from M = 1), W4: mpq_gemv_lutm_kernel (table lookup feeding 16x16x32 MFMAs; rows >= M of the x
+    """2 <= M <= 16, W4 (M = 1: the FMA form, bf16 FMAs / fp16 v_fma_mix_f32): mpq_gemv_lutm_kernel (table lookup feeding 16x16x32 MFMAs; rows >= M of the x
     fragment come back as zeros from the buffer descriptor's bounds check).  Same exact table values, so again only the fp32
     summation order differs from the oracle; every group size, ragged column tiles (N % 64 = 4, 8, 40), split groups and
     one-unit-per-wave plans, sym and asym."""

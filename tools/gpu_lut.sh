@@ -1,19 +1,18 @@
 #!/bin/bash
-# SQ instruction counters of the small-batch (matrix-pipe) and W2 (pair) forms of the lookup GEMV at 4096x11008
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
-R=$PWD; cd /tmp
-for cfg in "bf16 4096 11008 8 4" "bf16 4096 11008 1 2" "f16 4096 11008 1 4"; do
-  tag=${cfg// /_}; rm -rf /tmp/pq_$tag
-  timeout 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAVES --output-format csv -d /tmp/pq_$tag -o p -- python $R/tools/pmc_gemv.py $cfg > /tmp/pq_$tag.log 2>&1
-  f=$(find /tmp/pq_$tag -name "*counter_collection.csv" | head -1)
-  echo "== $cfg"; python - "$f" <<'PY'
-import csv, sys, collections
-agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for r in csv.DictReader(open(sys.argv[1])):
-    k = r.get("Kernel_Name", "")
-    if "bie::mpq_gemv" not in k: continue
-    agg[k[:64]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-for k, d in agg.items():
-    print(k, {c: round(sum(v) / len(v)) for c, v in d.items()}, "n=", len(next(iter(d.values()))))
+echo "== pytest"; timeout 900 python -m pytest tests -m gpu -q --maxfail=10 -p no:cacheprovider > gpurun_out/pytest_x.log 2>&1; tail -2 gpurun_out/pytest_x.log; grep -E "^(FAILED|ERROR)" gpurun_out/pytest_x.log | head -8; grep -E "^E  " gpurun_out/pytest_x.log | head -8
+for lo in 2 1; do echo "fp16 MFMA from M=$lo: $(BIE_LUT_MFMA_MIN_M_F16=$lo timeout 200 python - <<'PY' 2>&1 | grep -v amdgpu.ids | tail -1
+import sys
+sys.path.insert(0, "tools"); sys.path.insert(0, "bitorch-engine_amd")
+from sweep import time_case
+from bitorch_engine import _hip
+print(" ".join(f"{K}x{N}:M1 {time_case(1, K, N, _hip.F16)['us']} M2 {time_case(2, K, N, _hip.F16)['us']}" for (K, N) in ((4096, 4096), (4096, 11008), (11008, 4096))))
 PY
-done
+)"; done
+timeout 200 python - <<'PY' 2>&1 | grep -v amdgpu.ids | tail -1
+import sys
+sys.path.insert(0, "tools"); sys.path.insert(0, "bitorch-engine_amd")
+from sweep import time_case
+from bitorch_engine import _hip
+print("w2 bf16", " ".join(f"{K}x{N}:M1 {time_case(1, K, N, _hip.BF16, w_bit=2)['us']} M2 {time_case(2, K, N, _hip.BF16, w_bit=2)['us']}" for (K, N) in ((4096, 4096), (4096, 11008), (11008, 4096))))
+PY
