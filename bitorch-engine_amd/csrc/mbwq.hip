@@ -251,119 +251,140 @@ __global__ __launch_bounds__(EX2_NW * 64, (EX2_NW == 8 ? 2 : 1)) void exl2_gemv2
     const int c_begin = blockIdx.y * chunks_per_slab;
     int c_end = c_begin + chunks_per_slab;
     if (c_end > C) c_end = C;
+    // The slab's permutation indices and group-map entries are staged in LDS once per workgroup: a chunk's group constants and
+    // gathered activations can then be requested TOGETHER with its packed words.  (Fetched per chunk they were two dependent
+    // global loads behind the words -- PMC: 58 % of the wave time waiting, profiles/r02_pmc_exl2.txt.)
+    uint16_t* perm_s = reinterpret_cast<uint16_t*>(smem2) + EX2_NW * (4 * MT * 32);  // [chunks_per_slab * 32]
+    uint16_t* gmap_s = perm_s + chunks_per_slab * 32;                               // [chunks_per_slab * 2]
+    {
+        const int nk = (c_end - c_begin) * 32;
+        for (int i = tid; i < nk; i += EX2_NW * 64) perm_s[i] = perm ? perm[c_begin * 32 + i] : (uint16_t)(c_begin * 32 + i);
+        for (int i = tid; i < (c_end - c_begin) * 2; i += EX2_NW * 64) gmap_s[i] = gmap[2 * ((c_begin + (i >> 1)) * 32 + 16 * (i & 1))];
+    }
     float acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; m++) acc[m] = 0.f;
     const half2_t k1024 = half2_t{(half_t)1024.0f, (half_t)1024.0f};
-    // A chunk's loads (packed words, group constants) are issued one chunk ahead of its arithmetic; the two register sets
-    // alternate (no copies: a copied load result would have to be waited for at the loop's back edge).
-    struct Chunk {
-        uint32_t w[8];
-        uint32_t s[2], z[2];
-        int g[2];
-        int bits;
-        int pidx;           // q_perm[k0 + lane % 32]
-        uint32_t xraw[MT];  // x[m][pidx]
-    };
-    // issue_w: the packed words and the two group-map entries (scalar loads) of a chunk; issue_sz: the group constants, which
-    // need the map entries -- called one compute() later, so the scalar-load latency is never waited for (PMC of the first
-    // version: VALU busy 11 %, 56 % of the wave time in s_waitcnt, most of it on these dependent scalar loads).
-    auto issue_w = [&](int c, Chunk& ch) {
-        const int k0 = c * 32;
-        int bits, prow;
-        exl2_locate(rows, k0, bits, prow);
-        ch.bits = bits;
+    // The wave's chunks are taken BAND BY BAND: inside a band the bit width -- hence the number of loads per chunk -- is a compile-time
+    // constant, every issue is unconditional (the look-ahead index is clamped to the band's last chunk: a harmless re-load), so the
+    // compiler can wait with an exact vmcnt for the OLDEST chunk only.  (With the width switched at run time and `if (c < c_end)`
+    // around the issues every wait came out as vmcnt(0..3): the 4-deep prefetch was really 1-deep and each of a wave's 8 chunks paid
+    // a full memory latency -- PMC: 58 % of the wave time waiting.)
+    __syncthreads();  // the metadata slab is in LDS
+    auto band = [&](auto bits_tag, int cb0, int cb1, int prow0) {  // chunks [cb0, cb1) of this slab lie in one band starting at row prow0
+        constexpr int BITS = decltype(bits_tag)::value;
+        struct Chunk {
+            uint32_t w[BITS];
+            uint32_t s[2], z[2];
+            uint32_t xraw[MT];
+        };
+        auto issue = [&](int c, Chunk& ch) {
+            const int cl = c - c_begin;
+            const int prow = prow0 + (c - cb0) * BITS;
 #pragma unroll
-        for (int i = 0; i < 8; i++)
-            if (i < bits) ch.w[i] = __builtin_nontemporal_load(qw + (long)(prow + i) * N + nl);
-        ch.g[0] = gmap[2 * k0];
-        ch.g[1] = gmap[2 * (k0 + 16)];
-        ch.pidx = perm ? (int)perm[k0 + (lane & 31)] : k0 + (lane & 31);
-    };
-    auto issue_sz = [&](Chunk& ch) {
-        ch.s[0] = scales[(long)ch.g[0] * N + nl];
-        ch.z[0] = zeros[(long)ch.g[0] * N + nl];
-        if (ch.g[1] != ch.g[0]) {  // wave-uniform; groups of >= 32 k share the constants between the two halves of a chunk
-            ch.s[1] = scales[(long)ch.g[1] * N + nl];
-            ch.z[1] = zeros[(long)ch.g[1] * N + nl];
-        } else {
-            ch.s[1] = ch.s[0];
-            ch.z[1] = ch.z[0];
-        }
+            for (int i = 0; i < BITS; i++) ch.w[i] = __builtin_nontemporal_load(qw + (long)(prow + i) * N + nl);
+            const int g0 = __builtin_amdgcn_readfirstlane((int)gmap_s[2 * cl]), g1 = __builtin_amdgcn_readfirstlane((int)gmap_s[2 * cl + 1]);
+            const int pidx = (int)perm_s[cl * 32 + (lane & 31)];
+            ch.s[0] = scales[(long)g0 * N + nl];
+            ch.z[0] = zeros[(long)g0 * N + nl];
+            ch.s[1] = scales[(long)g1 * N + nl];  // unconditional (same line as [0] when the halves share a group): static load count
+            ch.z[1] = zeros[(long)g1 * N + nl];
 #pragma unroll
-        for (int m = 0; m < MT; m++) ch.xraw[m] = (m < M) ? x[(long)m * K + ch.pidx] : 0;
-    };
-    auto compute = [&](int set, const Chunk& ch) {
-        uint16_t* xw = xs + set * (MT * 32);
-        if (lane < 32) {
+            for (int m = 0; m < MT; m++) ch.xraw[m] = x[(long)(m < M ? m : 0) * K + pidx];
+        };
+        auto compute = [&](int set, const Chunk& ch) {
+            uint16_t* xw = xs + set * (MT * 32);
+            if (lane < 32) {
 #pragma unroll
-            for (int m = 0; m < MT; m++) xw[m * 32 + lane] = (uint16_t)ch.xraw[m];
-        }
-        // same wave writes then reads: the LDS pipe keeps a wave's operations in order, the compiler must too (the 2-byte
-        // stores and the 16-byte loads below have different types)
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        uint32_t P[16];
-        switch (ch.bits) {
-            case 8: exl2_pairs16<8>(ch.w, P); break;
-            case 6: exl2_pairs16<6>(ch.w, P); break;
-            case 5: exl2_pairs16<5>(ch.w, P); break;
-            case 4: exl2_pairs16<4>(ch.w, P); break;
-            case 3: exl2_pairs16<3>(ch.w, P); break;
-            default: exl2_pairs16<2>(ch.w, P); break;
-        }
-#pragma unroll
-        for (int half = 0; half < 2; half++) {
-            const half_t sh = __builtin_bit_cast(half_t, (uint16_t)ch.s[half]);
-            const half_t zh = __builtin_bit_cast(half_t, (uint16_t)ch.z[half]);
-            const half2_t s2 = half2_t{sh, sh}, nz2 = half2_t{(half_t)-zh, (half_t)-zh};
-            uint4_t xv[MT][2];
-#pragma unroll
-            for (int m = 0; m < MT; m++) {
-                const uint4_t* xp = reinterpret_cast<const uint4_t*>(xw + m * 32 + 16 * half);
-                xv[m][0] = xp[0];
-                xv[m][1] = xp[1];
+                for (int m = 0; m < MT; m++) xw[m * 32 + lane] = (uint16_t)ch.xraw[m];
             }
+            // same wave writes then reads: the LDS pipe keeps a wave's operations in order, the compiler must too (the 2-byte
+            // stores and the 16-byte loads below have different types)
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            uint32_t w8[8];
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const half2_t qh = __builtin_bit_cast(half2_t, P[8 * half + i]) - k1024;  // exact
-                const half2_t r = __builtin_elementwise_fma(qh, s2, nz2);           // one rounding == __hfma2(q, s, -z)
+            for (int i = 0; i < 8; i++) w8[i] = i < BITS ? ch.w[i] : 0u;
+            uint32_t P[16];
+            exl2_pairs16<BITS>(w8, P);
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const half_t sh = __builtin_bit_cast(half_t, (uint16_t)ch.s[half]);
+                const half_t zh = __builtin_bit_cast(half_t, (uint16_t)ch.z[half]);
+                const half2_t s2 = half2_t{sh, sh}, nz2 = half2_t{(half_t)-zh, (half_t)-zh};
+                uint4_t xv[MT][2];
 #pragma unroll
                 for (int m = 0; m < MT; m++) {
-                    const uint4_t xq = xv[m][i >> 2];
-                    const uint32_t xpair = (i & 3) == 0 ? xq.x : ((i & 3) == 1 ? xq.y : ((i & 3) == 2 ? xq.z : xq.w));
-                    acc[m] = __builtin_amdgcn_fdot2(r, __builtin_bit_cast(half2_t, xpair), acc[m], false);
+                    const uint4_t* xp = reinterpret_cast<const uint4_t*>(xw + m * 32 + 16 * half);
+                    xv[m][0] = xp[0];
+                    xv[m][1] = xp[1];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const half2_t qh = __builtin_bit_cast(half2_t, P[8 * half + i]) - k1024;  // exact
+                    const half2_t r = __builtin_elementwise_fma(qh, s2, nz2);           // one rounding == __hfma2(q, s, -z)
+#pragma unroll
+                    for (int m = 0; m < MT; m++) {
+                        if (m >= M) continue;
+                        const uint4_t xq = xv[m][i >> 2];
+                        const uint32_t xpair = (i & 3) == 0 ? xq.x : ((i & 3) == 1 ? xq.y : ((i & 3) == 2 ? xq.z : xq.w));
+                        acc[m] = __builtin_amdgcn_fdot2(r, __builtin_bit_cast(half2_t, xpair), acc[m], false);
+                    }
                 }
             }
+        };
+        // this wave's chunks in the band: c = first, first + NW, ... < cb1
+        int first = c_begin + wave;
+        if (first < cb0) first += ((cb0 - first + EX2_NW - 1) / EX2_NW) * EX2_NW;
+        if (first >= cb1) return;
+        const int cnt = (cb1 - first + EX2_NW - 1) / EX2_NW;
+        const int last = first + (cnt - 1) * EX2_NW;
+        auto at = [&](int jj) { const int c = first + jj * EX2_NW; return c < last ? c : last; };  // clamped look-ahead
+        Chunk c0, c1, c2, c3;
+        issue(at(0), c0);
+        issue(at(1), c1);
+        issue(at(2), c2);
+        issue(at(3), c3);
+        int jj = 0;
+        for (; jj + 4 < cnt; jj += 4) {  // a further group follows: four full steps, each re-filling the set it has just consumed
+            compute(0, c0);
+            issue(at(jj + 4), c0);
+            compute(1, c1);
+            issue(at(jj + 5), c1);
+            compute(2, c2);
+            issue(at(jj + 6), c2);
+            compute(3, c3);
+            issue(at(jj + 7), c3);
         }
+        compute(0, c0);  // last group: nothing left to request
+        if (jj + 1 < cnt) compute(1, c1);
+        if (jj + 2 < cnt) compute(2, c2);
+        if (jj + 3 < cnt) compute(3, c3);
     };
     {
-        Chunk ca, cb, cc, cd;
-        int c = c_begin + wave;
-        constexpr int W1 = EX2_NW;
-        // four chunks per wave in flight
-        if (c < c_end) issue_w(c, ca);
-        if (c + W1 < c_end) issue_w(c + W1, cb);
-        if (c + 2 * W1 < c_end) issue_w(c + 2 * W1, cc);
-        if (c + 3 * W1 < c_end) issue_w(c + 3 * W1, cd);
-        if (c < c_end) issue_sz(ca);
-        if (c + W1 < c_end) issue_sz(cb);
-        if (c + 2 * W1 < c_end) issue_sz(cc);
-        // step i: compute chunk i, then the group constants of chunk i+3 (its map entries were requested a step ago), then
-        // the words + map entries of chunk i+4 into the set just consumed
-        for (; c < c_end; c += 4 * W1) {
-            compute(0, ca);
-            if (c + 3 * W1 < c_end) issue_sz(cd);
-            if (c + 4 * W1 < c_end) issue_w(c + 4 * W1, ca);
-            if (c + W1 < c_end) compute(1, cb);
-            if (c + 4 * W1 < c_end) issue_sz(ca);
-            if (c + 5 * W1 < c_end) issue_w(c + 5 * W1, cb);
-            if (c + 2 * W1 < c_end) compute(2, cc);
-            if (c + 5 * W1 < c_end) issue_sz(cb);
-            if (c + 6 * W1 < c_end) issue_w(c + 6 * W1, cc);
-            if (c + 3 * W1 < c_end) compute(3, cd);
-            if (c + 6 * W1 < c_end) issue_sz(cc);
-            if (c + 7 * W1 < c_end) issue_w(c + 7 * W1, cd);
+        int kprev = 0, prow = 0;
+#pragma unroll
+        for (int b = 0; b < 6; b++) {
+            const int khi = rows.r[b];
+            const int bits = exl2_bits_of_band(b);
+            int cb0 = kprev >> 5, cb1 = khi >> 5;  // the band's chunk range
+            const int prow_band = prow;
+            prow += (cb1 - cb0) * bits;
+            kprev = khi;
+            const int skip = cb0 < c_begin ? c_begin - cb0 : 0;  // clip to the slab
+            cb0 += skip;
+            if (cb1 > c_end) cb1 = c_end;
+            if (cb0 < cb1) {
+                const int p0 = prow_band + skip * bits;
+                switch (b) {
+                    case 0: band(std::integral_constant<int, 8>{}, cb0, cb1, p0); break;
+                    case 1: band(std::integral_constant<int, 6>{}, cb0, cb1, p0); break;
+                    case 2: band(std::integral_constant<int, 5>{}, cb0, cb1, p0); break;
+                    case 3: band(std::integral_constant<int, 4>{}, cb0, cb1, p0); break;
+                    case 4: band(std::integral_constant<int, 3>{}, cb0, cb1, p0); break;
+                    default: band(std::integral_constant<int, 2>{}, cb0, cb1, p0); break;
+                }
+            }
         }
     }
     // block reduction over the waves in wave order (deterministic)
@@ -432,6 +453,7 @@ static void exl2_decode_plan(int M, int K, int N, int& cps, int& S, int& nw) {
     int want = (512 + colblocks / 2) / colblocks;
     if (want < 1) want = 1;
     cps = cdiv(cdiv(C, want), nw) * nw;
+    if (cps < 4 * nw) cps = 4 * nw;  // at least four chunks per wave: the depth of the kernel's prefetch
     if (cps > C) cps = C;
     S = cdiv(C, cps);
 }
@@ -507,7 +529,8 @@ int mbwq_exl2_forward_launch(const void* x, const int32_t* qw, const void* scale
         int cps2, S, nw;
         exl2_decode_plan(M, K, N, cps2, S, nw);
         const int MT = M;
-        size_t lds2 = (size_t)nw * 4 * MT * 32 * sizeof(uint16_t);  // wave-private x chunk buffers
+        size_t lds2 = (size_t)nw * 4 * MT * 32 * sizeof(uint16_t)   // wave-private x chunk buffers
+                      + (size_t)cps2 * 34 * sizeof(uint16_t);      // + the slab's q_perm indices and group-map entries
         const size_t red = (size_t)nw * MT * 64 * sizeof(float);
         if (lds2 < red) lds2 = red;
         dim3 grid2(colblocks, S);
