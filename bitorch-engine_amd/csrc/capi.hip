@@ -196,7 +196,9 @@ int bie_mpq_forward_grouped(const void* x, int n_sets, const int32_t* const* qwe
     BIE_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), BIE_ERR_WORKSPACE,
                 "bie_mpq_forward_grouped: workspace of %zu bytes required, got %zu", need, workspace_bytes);
     const int tiles = grouped_tiles(n_sets, N);
-    if (tiles <= BIE_WS_COUNTERS && mpq_gemv_lut_ok(M, K, w_bit, group_size, dtype, false)) {
+    bool n4 = true;  // the matrix-pipe form loads four adjacent columns with one 16-byte load
+    for (int i = 0; i < n_sets; i++) n4 = n4 && (N[i] & 3) == 0;
+    if (n4 && tiles <= BIE_WS_COUNTERS && mpq_gemv_lut_ok(M, K, w_bit, group_size, dtype, false)) {
         float* head = reinterpret_cast<float*>(workspace);
         return mpq_gemv_lut_launch(n_sets, qweight, scales, zeros, bias, y, N, x, reinterpret_cast<unsigned*>(head) + BIE_WS_GEN_OFFSET,
                                    head + WS_HEAD / sizeof(float), M, K, group_size, asym ? 1 : 0, dtype, as_stream(stream), w_bit);

@@ -757,6 +757,24 @@ def test_layer_level_grouped_forward_equals_the_separate_layers():
                     assert_close(y.reshape(-1, l.out_channels), ref.reshape(-1, l.out_channels), orc.BF16, f"grouped layers {lead}")
 
 
+def test_grouped_forward_with_a_column_count_that_is_not_a_multiple_of_4():
+    """N % 4 != 0 in one set: the grouped entry point must leave the 16-byte-load kernels and fall back to one launch per set."""
+    from bitorch_engine.extensions import q_linear_cuda
+    K, gs, dt = 512, 128, orc.BF16
+    for M in (1, 3):
+        sets, refs, x = [], [], None
+        for i, N in enumerate((128, 66)):
+            rng = np.random.default_rng(50 * i + M)
+            qw, scales, zeros, gen = rand_case(rng, K, N, 4, gs, dt, 0)
+            if x is None:
+                x = torch.randn((M, K), generator=gen).to(TDT[dt])
+            sets.append(tuple(None if t is None else t.to(DEV) for t in (qw, scales, zeros, None)))
+            refs.append(oracle_forward(x, qw, scales, zeros, None, 4, gs, 0, dt))
+        ys = q_linear_cuda.mpq_forward_grouped_impl(x.to(DEV), sets, 4, 0, gs)
+        for y, r in zip(ys, refs):
+            assert_close(y, r, dt, f"grouped N%4 M={M}")
+
+
 def test_decode_gemv_wide_output_more_than_1024_tiles():
     """N > 65536 (quantised lm_head) used to overflow the 1024-counter workspace head; 2004 column tiles now fit the
     16 KiB head (fp16 -> dot2 kernel with tickets, bf16 -> lookup kernel with generation words)."""
