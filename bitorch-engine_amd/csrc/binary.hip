@@ -570,7 +570,8 @@ int binary_linear_launch(const uint8_t* xp, const uint8_t* wp, float* y, long M,
 
 // 1 <= M <= 64 (beyond that packing x once and running the tiled XNOR GEMM is the better split), K % 32 == 0
 bool binary_linear_fused_ok(long M, long N, long K) {
-    return M >= 1 && M <= 64 && N >= 1 && K >= 32 && K % 32 == 0 && K <= 262144 && N < (1L << 31);
+    // the packed x rows of one workgroup (4 or 8 rows of K/32 + 1 words) live in LDS: 64 KiB
+    return M >= 1 && M <= 64 && N >= 1 && K >= 32 && K % 32 == 0 && (size_t)(M <= 4 ? 4 : 8) * (K / 32 + 1) * 4 <= 65536 && N < (1L << 31);
 }
 
 template <int DT>
