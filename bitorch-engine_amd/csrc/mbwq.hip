@@ -443,10 +443,13 @@ __global__ __launch_bounds__(EX2_NW * 64, (EX2_NW == 8 ? 2 : 1)) void exl2_gemv2
 // 8 chunks so that the 8 waves of a workgroup get equal shares; at most BIE_WS_COUNTERS column blocks use the slab reduction
 static void exl2_decode_plan(int M, int K, int N, int& cps, int& S, int& nw) {
     const int C = K / 32, colblocks = cdiv(N, 64);
-    if (colblocks >= 160) {  // wide layers: 16-wave workgroups, one K slab
+    constexpr int CPS_MAX = 768;  // the slab's q_perm / group-map copy in LDS: 68 bytes per chunk (52 KiB) beside the x buffers
+    if (colblocks >= 160) {  // wide layers: 16-wave workgroups, one K slab (more only when K is too long for the LDS copy)
         nw = 16;
-        cps = C;
-        S = 1;
+        S = cdiv(C, CPS_MAX);
+        cps = cdiv(cdiv(C, S), nw) * nw;
+        if (cps > C) cps = C;
+        S = cdiv(C, cps);
         return;
     }
     nw = 8;
@@ -454,6 +457,7 @@ static void exl2_decode_plan(int M, int K, int N, int& cps, int& S, int& nw) {
     if (want < 1) want = 1;
     cps = cdiv(cdiv(C, want), nw) * nw;
     if (cps < 4 * nw) cps = 4 * nw;  // at least four chunks per wave: the depth of the kernel's prefetch
+    if (cps > CPS_MAX) cps = CPS_MAX;
     if (cps > C) cps = C;
     S = cdiv(C, cps);
 }
@@ -481,7 +485,7 @@ size_t mbwq_workspace_bytes(int M, int K, int N) {
     size_t c = (size_t)S * mc * N * sizeof(float);
     int cps2, S2, nw2;
     exl2_decode_plan(M, K, N, cps2, S2, nw2);
-    const size_t d = M <= 2 && S2 > 1 ? (size_t)(S2 - 1) * M * cdiv(N, 64) * 64 * 8 : 0;  // decode granules
+    const size_t d = M <= 2 && S2 > 1 ? (size_t)(S2 - 1) * M * cdiv(N, 64) * 64 * 8 : 0;  // decode granules (unused when the fp32 kernel takes over)
     if (d > c) c = d;
     size_t r = a > b ? a : b;
     return r > c ? r : c;
@@ -523,7 +527,8 @@ int mbwq_exl2_forward_launch(const void* x, const int32_t* qw, const void* scale
                              hipStream_t st) {
     Exl2Rows rows;
     for (int i = 0; i < 6; i++) rows.r[i] = rows7[i];
-    if (M <= 2) {  // decode path.  (The packed-fp16 kernel instantiated for 4 / 8 rows measured SLOWER than the fp32 kernel below:
+    const bool slab_ok = !(cdiv(N, 64) > BIE_WS_COUNTERS && K / 32 > 768);  // K slabs need one generation word per column block
+    if (M <= 2 && slab_ok) {  // decode path.  (The packed-fp16 kernel instantiated for 4 / 8 rows measured SLOWER than the fp32 kernel below:
                    //  33.3 / 46.2 us against 28.0 / 39.9 us at 4096x11008 M = 3 / 8 -- 178-256 registers, one wave per SIMD.)
         const int colblocks = cdiv(N, 64);
         int cps2, S, nw;

@@ -639,6 +639,35 @@ def test_q4_conv_layer_train_eval_equivalence():
     assert y.shape == (2, 32, 10, 10) and torch.equal(y, y2)
 
 
+def test_exl2_decode_long_k_uses_several_slabs():
+    """K = 28672 (a 70B-class down projection): 896 chunks do not fit one LDS metadata slab, so even a wide layer (>= 160 column
+    blocks) is cut into K slabs reduced by granules; single band (4-bit rows), random q_perm."""
+    from bitorch_engine.extensions import q_linear_cuda
+    from bitorch_engine.layers.qlinear.nbit.cuda.utils import make_group_map
+    K, N, gs = 28672, 10240, 128
+    qg, row = [], 0
+    for _ in range(K // gs):
+        qg += [4, row]
+        row += 4 * (gs // 32)
+    groups = len(qg) // 2
+    q_groups = torch.tensor(qg, dtype=torch.short)
+    gmap = make_group_map(q_groups, row)
+    rng = np.random.default_rng(3)
+    gen = torch.Generator().manual_seed(3)
+    qw = torch.from_numpy(rng.integers(-2 ** 31, 2 ** 31 - 1, (row, N), dtype=np.int64).astype(np.int32))
+    scales = (torch.rand((groups, N), generator=gen) * 0.02 + 0.001).half()
+    zeros = (torch.randn((groups, N), generator=gen) * 0.1).half()
+    q_perm = torch.randperm(K, generator=gen).to(torch.short)
+    _, rows = q_linear_cuda.mbwq_trans_qweight(qw, q_groups, True, K, groups, 4)
+    x = torch.randn((1, K), generator=gen).half()
+    y = q_linear_cuda.mbwq_exl2_forward(x.to(DEV), qw.to(DEV), scales.to(DEV), zeros.to(DEV), q_perm.to(DEV), gmap.to(DEV), rows, False)
+    cols = np.arange(0, N, 257)
+    Wo = orc.exl2_dequant(np.ascontiguousarray(qw.numpy()[:, cols]), orc.torch_to_np(scales[:, cols].contiguous()),
+                          orc.torch_to_np(zeros[:, cols].contiguous()), q_perm.numpy(), q_groups.numpy(), K)
+    ref = t16(orc.gemm(orc.torch_to_np(x), Wo, orc.F16), orc.F16)
+    assert_close(y[:, torch.from_numpy(cols).to(DEV)], ref, orc.F16, "exl2 K=28672")
+
+
 # ------------------------------------------------------------------------------------------------ table-lookup decode GEMV / grouped launch
 @pytest.mark.parametrize("K,N,gs,asym,M", [(1024, 200, 64, 0, 1), (768, 520, 256, 0, 2), (640, 64, 32, 1, 1), (1408, 136, 128, 0, 1),
                                             (2048, 1000, 128, 1, 2), (512, 72, 32, 0, 2)])
