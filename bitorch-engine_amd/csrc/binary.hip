@@ -16,6 +16,18 @@ __device__ __forceinline__ bool sign_bit(const void* p, long i) {
     else return dt_traits<DT>::load(p, i) >= 0.0f;
 }
 
+// Wave-wide integer sum on the DPP network (no LDS traffic): quad swaps, half-row and row mirrors, then the two row broadcasts;
+// the total lands in lane 63 and is read back as a scalar.
+__device__ __forceinline__ int wave_sum_dpp(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);  // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);  // row_mirror: every lane of a row holds the row's sum
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 // ---- packing ---------------------------------------------------------------------------------------------
 // rows x K values -> rows x K/8 bytes, LSB first.  One thread per output byte.
 template <int DT>
@@ -190,9 +202,7 @@ __global__ __launch_bounds__(256) void xnor_gemv_kernel(const uint32_t* __restri
     }
 #pragma unroll
     for (int m = 0; m < MT; m++) {
-        int v = acc[m];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        const int v = wave_sum_dpp(acc[m]);
         if (lane == 0 && m < M) y[(long)m * N + n] = (float)(Kbits - 2 * v) * scale;
     }
 }
@@ -203,7 +213,7 @@ __global__ __launch_bounds__(256) void xnor_gemv_kernel(const uint32_t* __restri
 // (reference layers/qlinear/binary/cuda/layer.py:58-63, 283-284), i.e. what the reference spends an add, a pack, a GEMM, a cast
 // and two multiplies on.  grid = (column blocks, row blocks); a workgroup sign-packs ITS x rows itself -- a thread loads 8
 // consecutive values (16 bytes) and stores one byte of bits to LDS, no cross-lane traffic -- and then sweeps its columns:
-//   ROWS == 4 (M <= 4, one row block): a wave takes 4 output columns at a time, lanes stride the K words (coalesced), shuffle
+//   ROWS == 4 (M <= 4, one row block): a wave takes 4 output columns at a time, lanes stride the K words (coalesced), DPP wave
 //     reduction;
 //   ROWS == 8 (row blocks of 8): lane = (row, column sub-index): 8 columns per wave step, every lane walks the K words of its
 //     column (the 8 lanes of a column share the address) against its own packed x row in LDS (row stride KW + 1 words:
@@ -301,9 +311,7 @@ __global__ __launch_bounds__(256) void xnor_fused_kernel(const void* __restrict_
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
                     if (m >= M) break;
-                    int v = acc[c][m];
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+                    const int v = wave_sum_dpp(acc[c][m]);
                     if (lane == 0 && nb + c < col1) put(m, nb + c, v);
                 }
         }

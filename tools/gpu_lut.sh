@@ -1,8 +1,12 @@
 #!/bin/bash
-# rocprofv3 kernel stats of the whole default bench pass (every extra row): per-kernel averages for the GEMM / exl2 / binary / conv kernels
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
-R=$PWD
-(cd /tmp && rm -rf /tmp/prof_full && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_full -o s -- python $R/bench.py --no-cpu-baseline > /tmp/prof_full.json 2> /tmp/prof_full.err)
-f=$(find /tmp/prof_full -name "*kernel_stats*.csv" | head -1)
-(head -1 $f; grep '"void bie::\|"bie::' $f) | cut -c1-260 > gpurun_out/r02_kernel_stats_full_bench.csv
-wc -l gpurun_out/r02_kernel_stats_full_bench.csv; head -30 gpurun_out/r02_kernel_stats_full_bench.csv | cut -c1-170
+echo "== pytest"; timeout 900 python -m pytest tests -m gpu -q --maxfail=10 -p no:cacheprovider -k "binary or conv or embedding or bmha or BMHA" > gpurun_out/pytest_x.log 2>&1; tail -2 gpurun_out/pytest_x.log; grep -E "^(FAILED|ERROR)" gpurun_out/pytest_x.log | head -8; grep -E "^E  " gpurun_out/pytest_x.log | head -8
+timeout 300 python - <<'PY' 2>&1 | grep -v amdgpu.ids | tail -9
+import sys, json
+sys.path.insert(0, "bitorch-engine_amd")
+import torch, bench
+from bitorch_engine import _hip
+dev = torch.device("cuda:0")
+for r in bench.bench_binary(dev, _hip.lib()):
+    print(r["op"][:40], r.get("M", r.get("B")), r.get("us_per_launch", r.get("us_per_call")), flush=True)
+PY
