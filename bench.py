@@ -3,9 +3,12 @@
 
 Headline workload = the configuration BASELINE.json's `metric` is worded on: W4A16 qlinear, K = N = 4096, group 128,
 bf16 activations, symmetric (GBA-style fp zeros), implicit groups, M = 1.  One STEP = one decode pass over L = 96
-DISTINCT layers of that shape (96 x 8.4 MB of packed weights = 0.8 GB >> the 256 MiB Infinity Cache, so every weight
-byte comes from HBM), captured once in a HIP graph and replayed.  `value` = algorithmic bytes of the step / time (GB/s);
+DISTINCT layers of that shape, each with its own activation vector (96 x 8.4 MB of packed weights = 0.8 GB >> the 256 MiB
+Infinity Cache, so every weight byte comes from HBM), issued as ONE launch of the layer-list kernel (bie_mpq_list_forward,
+csrc/mpq_list.hip) captured in a HIP graph and replayed.  `value` = algorithmic bytes of the step / time (GB/s);
 `roofline` = the same quantity per launch from HIP events recorded on the launch stream around the timed region.
+The per-layer-launch form of the same pass (one bie_mpq_forward per layer, round 2's headline) is reported beside it
+(`per_layer_launches_4096x4096`), as are dependent chains inside one launch (`chain4_4096x4096`).
 
 Also measured live, each in its own event-bracketed region (rank 0, N = 1): the M = 4096 prefill GEMM of the metric's layer
 (`roofline_gemm`), the 4096x11008 / 11008x4096 layers of configs[1] (M = 1 and M = 4096), the grouped (shared-x) decode
@@ -80,20 +83,23 @@ def time_graph(g, reps):
     return e0.elapsed_time(e1) * 1e3 / reps
 
 
+PMC_FILE = "r03_pmc_gemv.json"
+
+
 def kernel_source_sha():
-    """Hash of the GEMV kernel sources: profiles/r02_pmc_gemv.json is only trusted for the sources it was collected on."""
+    """Hash of the decode kernel sources: profiles/r03_pmc_gemv.json is only trusted for the sources it was collected on."""
     h = hashlib.sha256()
-    for f in ("mpq_gemv_lut.hip", "mpq_gemv.hip", "mpq_dequant.cuh"):
+    for f in ("mpq_list.hip", "mpq_gemv_lut.hip", "mpq_gemv.hip", "mpq_dequant.cuh"):
         h.update(open(os.path.join(ROOT, "bitorch-engine_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
 
 def pmc_traffic(shape):
-    """HBM bytes per GEMV launch from this round's PMC passes (tools/gpu_pmc_traffic.sh -> profiles/r02_pmc_gemv.json:
+    """HBM bytes per GEMV launch from this round's PMC passes (tools/gpu_pmc_traffic.sh -> profiles/r03_pmc_gemv.json:
     separate FETCH_SIZE and WRITE_SIZE passes, corrected as DESIGN.md section 5 describes).  None when the file is absent,
     was collected on other kernel sources (stale), or has no row for `shape`."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_gemv.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
         if d.get("kernel_source_sha") != kernel_source_sha():
             return None
         return d["shapes"][shape]["hbm_bytes_per_launch"]
@@ -131,6 +137,29 @@ class Bench:
         return {"M": M, "K": k, "N": n, "w_bit": w_bit, "layers": nl, "us_per_launch": round(us, 3), "alg_bytes_per_launch": b,
                 "roofline": {"bound": "hbm", "achieved": round(b / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(b / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(f"{k}x{n}") if (M == 1 and w_bit == 4) else None}}
+
+    # ---- ONE launch over a list of layers (bie_mpq_list_*): `per_launch` entries per launch, optional dependent chains
+    def make_list(self, layers, k, n, gen, M=1, chain=0, w_bit=WBIT, ys=None):
+        from bitorch_engine.layers.qlinear.nbit.cuda import MPQForwardList
+        entries = []
+        for i, (qw, sc, ze) in enumerate(layers):
+            dep = i - 1 if (chain and i % chain) else -1
+            x = entries[-1]["y"] if dep >= 0 else torch.randn((M, k), generator=gen, device=self.dev).to(BF16)
+            y = ys[i] if ys is not None else torch.empty((M, n), dtype=BF16, device=self.dev)
+            entries.append({"x": x, "qweight": qw, "scales": sc, "zeros": ze, "y": y, "depends_on": dep})
+        return MPQForwardList(entries, w_bit=w_bit, group_size=GROUP)
+
+    def gemv_list(self, k, n, nl, per_launch, reps, seed, chain=0, w_bit=WBIT, key=None):
+        gen = torch.Generator(device=self.dev).manual_seed(seed)
+        layers = [make_layer(self.dev, gen, k, n, w_bit) for _ in range(nl)]
+        plans = [self.make_list(layers[p0:p0 + per_launch], k, n, gen, chain=chain, w_bit=w_bit) for p0 in range(0, nl, per_launch)]
+        g = capture(lambda st: [p.forward(st) for p in plans])
+        us = time_graph(g, reps) / nl
+        b = alg_bytes(1, k, n, w_bit)
+        return {"M": 1, "K": k, "N": n, "w_bit": w_bit, "layers": nl, "layers_per_launch": per_launch, "dependent_chain_length": chain,
+                "launches_per_pass": len(plans) * plans[0].launches, "us_per_layer": round(us, 3), "alg_bytes_per_layer": b,
+                "roofline": {"bound": "hbm", "achieved": round(b / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(b / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(key) if key else None}}
 
     # ---- grouped decode: `ns` column counts sharing x, `nl` distinct groups of layers
     def grouped(self, k, ns, nl, reps, seed, what):
@@ -360,11 +389,10 @@ def main():
         LAYERS = max(8, min(96, int(800e6 // (K * N // 2))))
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     layers = [make_layer(dev, gen, K, N) for _ in range(LAYERS)]
-    x = torch.randn((1, K), generator=gen, device=dev).to(BF16)
     y_all = torch.empty((LAYERS, N), dtype=BF16, device=dev)  # row l = output of layer l
     gathered = torch.empty((world * LAYERS, N), dtype=BF16, device=dev) if distributed else None  # rank-major
-    ws = B.workspace(1, K, N)
-    graph = capture(lambda st: [B.forward(x, l, y_all[i], ws, 1, K, N, st) for i, l in enumerate(layers)])
+    plan = B.make_list(layers, K, N, gen, ys=[y_all[i:i + 1] for i in range(LAYERS)])  # every layer has its own x; ONE launch per pass
+    graph = capture(lambda st: plan.forward(st))
 
     def step():
         graph.replay()
@@ -399,21 +427,22 @@ def main():
 
     out = None
     if rank == 0:
-        launches = args.steps * LAYERS
+        launches = args.steps  # one list launch per pass
         avg_us = gpu_ms * 1e3 / launches
-        achieved = alg_bytes(1, K, N) / (avg_us * 1e-6) / 1e9
+        achieved = alg_bytes(1, K, N) * LAYERS / (avg_us * 1e-6) / 1e9
         out = {
             "metric": f"W4A16 decode GEMV weight-streaming throughput (M=1, {K}x{N} g128, bf16)",
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic (seeded random packed weights / scales / zeros, N(0,1) activations)",
             "config": {"workload": f"BASELINE.json metric config (configs[0] shape): W4A16 qlinear {K}x{N} g128 bf16, M=1 decode pass over {LAYERS} "
-                                   f"distinct layers ({LAYERS * K * N // 2 / 1e9:.2f} GB of packed weights, HIP-graph replay)",
-                       "layers_per_step": LAYERS, "parallelism": "output-column sharding x%d + 1 all-gather/step" % world if distributed else "single GPU"},
+                                   f"distinct layers, each with its own x ({LAYERS * K * N // 2 / 1e9:.2f} GB of packed weights), ONE layer-list launch per pass, HIP-graph replay",
+                       "layers_per_step": LAYERS, "launches_per_step": 1, "parallelism": "output-column sharding x%d + 1 all-gather/step" % world if distributed else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(f"{K}x{N}"),
-                         "kernel": "bie::mpq_gemv_lut_kernel<bf16,sym,M=1,rpg=8,NW=8> (table-lookup dequant, a group split over two waves, in-kernel split-K by tagged granules)",
-                         "avg_launch_us": round(avg_us, 3), "alg_bytes_per_launch": alg_bytes(1, K, N)},
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(f"list{LAYERS}_{K}x{N}"),
+                         "kernel": "bie::mpq_list_kernel<bf16,sym,M=1,rpg=16,w4> (table-lookup dequant, buffer-addressed rows, v_pk_fma_f32; one launch walks the column tiles of every layer of the pass)",
+                         "avg_launch_us": round(avg_us, 3), "us_per_layer": round(avg_us / LAYERS, 3),
+                         "alg_bytes_per_launch": alg_bytes(1, K, N) * LAYERS},
         }
 
     extras = rank == 0 and world == 1 and not args.no_extras and not args.only
@@ -427,7 +456,14 @@ def main():
         guarded("gemm", lambda: B.gemm(4096, 4096, 4096, 24, 3, 7))
         if "roofline" in out.get("gemm", {}):
             out["roofline_gemm"] = dict(out["gemm"]["roofline"], kernel="bie::mpq_gemm_kernel<bf16,w4,256x256x64 tile>", us_per_launch=out["gemm"]["us_per_launch"])
-        # ---- configs[1]: 4096x11008 and 11008x4096, M = 1 and M = 4096
+        # ---- the same pass as per-layer launches (round 2's headline form), as 4 launches of 24 layers, and as dependent chains
+        guarded("per_layer_launches_4096x4096", lambda: B.gemv(4096, 4096, 96, 10, 1))
+        guarded("list_4x24_4096x4096", lambda: B.gemv_list(4096, 4096, 96, 24, 10, 2))
+        guarded("chain4_4096x4096", lambda: B.gemv_list(4096, 4096, 96, 4, 10, 3, chain=4))
+        guarded("chain8_in_list32_4096x4096", lambda: B.gemv_list(4096, 4096, 96, 32, 10, 4, chain=8))
+        # ---- configs[1]: 4096x11008 and 11008x4096, M = 1 (list launch and per-layer launches) and M = 4096
+        guarded("c2_list_4096x11008", lambda: B.gemv_list(4096, 11008, 40, 40, 10, 11, key="list40_4096x11008"))
+        guarded("c2_list_11008x4096", lambda: B.gemv_list(11008, 4096, 40, 40, 10, 12, key="list40_11008x4096"))
         guarded("c2_gemv_4096x11008", lambda: B.gemv(4096, 11008, 40, 10, 11))
         guarded("c2_gemv_11008x4096", lambda: B.gemv(11008, 4096, 40, 10, 12))
         guarded("c2_gemv_M2_4096x11008", lambda: B.gemv(4096, 11008, 40, 10, 13, M=2))
@@ -442,6 +478,7 @@ def main():
         guarded("grouped_gate_up_2x4096x11008", lambda: B.grouped(4096, (11008, 11008), 20, 10, 22, "gate/up projections in one launch"))
         # ---- configs[2], configs[3]
         guarded("c3_exl2", lambda: bench_exl2(dev))
+        guarded("c3_w2a16_list_4096x4096", lambda: B.gemv_list(4096, 4096, 96, 96, 10, 44, w_bit=2))
         guarded("c3_w2a16_4096x4096", lambda: B.gemv(4096, 4096, 64, 10, 41, w_bit=2))      # uniform W2A16 (MPQ): pair-lookup + dot2 kernel
         guarded("c3_w2a16_4096x11008", lambda: B.gemv(4096, 11008, 40, 10, 42, w_bit=2))
         guarded("c3_w2a16_11008x4096", lambda: B.gemv(11008, 4096, 40, 10, 43, w_bit=2))
@@ -450,6 +487,7 @@ def main():
         guarded("c5_single_gpu_8192x28672", lambda: B.gemm(4096, 8192, 28672, 2, 3, 31))
         # the same layer at M = 1 and its gate/up pair in one launch: what the decode kernel reaches once a launch is large (125 / 250 MB)
         guarded("c5_gemv_8192x28672", lambda: B.gemv(8192, 28672, 6, 10, 32))
+        guarded("c5_list_8192x28672", lambda: B.gemv_list(8192, 28672, 6, 6, 10, 32))
         guarded("c5_grouped_gate_up_2x8192x28672", lambda: B.grouped(8192, (28672, 28672), 3, 10, 33, "70B-class gate/up projections in one launch"))
     if rank == 0:
         out["kernel_source_sha"] = kernel_source_sha()
@@ -476,7 +514,12 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        # the two headline fractions, the GEMM object and the CPU baseline go FIRST: a truncated log tail must not lose them
+        front = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                 "data", "config", "roofline", "roofline_gemm", "cpu_baseline")
+        ordered = {k: out[k] for k in front if k in out}
+        ordered.update({k: v for k, v in out.items() if k not in ordered})
+        print(json.dumps(ordered))
 
 
 if __name__ == "__main__":

@@ -28,6 +28,14 @@ SIGNATURES = {
     "bie_workspace_init": (_i, [_vp, _sz, _vp]),
     "bie_mpq_grouped_workspace_bytes": (_sz, [_i, _vp, _i, _i, _i]),
     "bie_mpq_forward_grouped": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz] + [_i] * 6 + [_vp]),
+    "bie_status_init": (_i, []),
+    "bie_device_status": (ctypes.c_uint, [_i]),
+    "bie_test_forge_reducer": (None, [ctypes.c_uint, _i]),
+    "bie_mpq_list_device_bytes": (_sz, [_i, _vp, _i, _i, _i]),
+    "bie_mpq_list_create": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _sz]),
+    "bie_mpq_list_forward": (_i, [_vp, _vp]),
+    "bie_mpq_list_launches": (_i, [_vp]),
+    "bie_mpq_list_destroy": (None, [_vp]),
     "bie_mpq_dequant": (_i, [_vp] * 5 + [_i] * 6 + [_vp]),
     "bie_mpq_pack": (_i, [_vp] * 5 + [_i] * 6 + [_vp]),
     "bie_mpq_grad_input": (_i, [_vp] * 6 + [_i] * 7 + [_vp]),
@@ -67,6 +75,16 @@ SIGNATURES = {
 }
 
 
+_HOST_ONLY = ("bie_version", "bie_last_error", "bie_mbwq_rows", "bie_status_init", "bie_device_status", "bie_test_forge_reducer",
+              "bie_mpq_list_launches", "bie_mpq_list_destroy")
+
+
+class ListEntry(ctypes.Structure):
+    """bie_mpq_list_entry (include/bie_hip.h)."""
+    _fields_ = [("x", _vp), ("qweight", _vp), ("scales", _vp), ("zeros", _vp), ("bias", _vp), ("y", _vp),
+                ("K", _i), ("N", _i), ("depends_on", _i), ("reserved", _i)]
+
+
 def lib():
     """Load libbie_hip.so (once).  Raises if it has not been built -- never falls back."""
     global _lib
@@ -81,8 +99,10 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-            launches = not (name.endswith("_bytes") or name in ("bie_version", "bie_last_error", "bie_mbwq_rows"))
+            launches = not (name.endswith("_bytes") or name in _HOST_ONLY)
             setattr(ns, name, _guarded(fn) if launches else fn)
+        if torch.cuda.is_available():
+            l.bie_status_init()  # the host-mapped status page the kernels raise their fail-loud bits in (once, outside any capture)
         _lib = ns
     return _lib
 
@@ -149,23 +169,38 @@ def check(rc: int, what: str):
 
 
 _WS = {}
-_WS_RETIRED = []  # superseded buffers are kept alive: a captured HIP graph may have their address baked in
+_WS_RETIRED = []  # buffers outgrown AFTER a capture used them are kept alive: a captured HIP graph has their address baked in
+_CAPTURED = set()  # keys of buffers that were handed out while their stream was capturing
+
+
+def _grow(table, key, nbytes, device, zero):
+    """Shared growth policy of workspace() / scratch(): geometric (a serving loop with slowly growing M must not reallocate at
+    every new maximum), never under stream capture (an allocation inside a capture is an error the caller can avoid with
+    presize_workspace), and an outgrown buffer is only retired -- kept alive forever -- if a captured graph may hold its
+    address; otherwise it is simply dropped."""
+    buf = table.get(key)
+    if buf is not None and buf.numel() >= nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            _CAPTURED.add((id(table), key))
+        return buf
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError(f"bitorch_engine: the per-stream scratch buffer has to grow to {nbytes} bytes while the stream is being "
+                           "captured; call bitorch_engine._hip.presize_workspace(nbytes) (or run the step once) before capturing")
+    if buf is not None and (id(table), key) in _CAPTURED:
+        _WS_RETIRED.append(buf)
+    size = max(nbytes, 1 << 20, 2 * buf.numel() if buf is not None else 0)
+    buf = (torch.zeros if zero else torch.empty)(size, dtype=torch.uint8, device=device)
+    table[key] = buf
+    return buf
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
-    """Per-(device, stream) scratch buffer, grown on demand and reused (stream-ordered reuse is safe).
-    A buffer that is outgrown is retired, never freed: graph replays that captured its pointer keep writing their
-    split-K slabs and tickets into memory nobody else owns.  presize_workspace() avoids the regrowth altogether."""
+    """Per-(device, stream) scratch buffer with the zero-initialised ticket / generation head, grown on demand and reused
+    (stream-ordered reuse is safe).  See _grow() for the growth / retirement policy."""
     if nbytes == 0:
         return None
     key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
-    buf = _WS.get(key)
-    if buf is None or buf.numel() < nbytes:
-        if buf is not None:
-            _WS_RETIRED.append(buf)
-        buf = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)  # head = split-K counters, must start at 0
-        _WS[key] = buf
-    return buf
+    return _grow(_WS, key, nbytes, device, True)  # head = split-K counters, must start at 0
 
 
 _SCRATCH = {}
@@ -175,13 +210,7 @@ def scratch(nbytes: int, device) -> torch.Tensor:
     """Per-(device, stream) scratch WITHOUT the ticket / generation head (im2col buffers and the like): grown on demand,
     superseded buffers retired like workspace()'s."""
     key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
-    buf = _SCRATCH.get(key)
-    if buf is None or buf.numel() < nbytes:
-        if buf is not None:
-            _WS_RETIRED.append(buf)
-        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-        _SCRATCH[key] = buf
-    return buf
+    return _grow(_SCRATCH, key, nbytes, device, False)
 
 
 def presize_workspace(nbytes: int, device=None):

@@ -1,0 +1,92 @@
+"""Decode (M <= 2) over a LIST of MPQ layers in ONE kernel launch (bie_mpq_list_*, include/bie_hip.h).
+
+The reference launches one `quant_mm_kernel` per layer on the default stream
+(layers/qlinear/nbit/cuda/mpq_layer.py:65 -> mpq_linear_cuda_kernel.cu:482-577).  A 4096x4096 W4 layer is 8.9 MB --
+1.1 us of HBM time on MI355X, less than a kernel boundary -- so a per-layer launch can never be bandwidth-bound.
+`MPQForwardList` hands the column tiles of many layers to one grid: independent entries (q/k/v, gate/up, the experts of an
+MoE block, every layer of a speculative batch ...) and dependent chains (y of entry d is x of entry e: `depends_on`).
+
+Results are those of `MPQLinearCuda.forward` entry by entry (same kernels' arithmetic, same roundings).
+"""
+import ctypes
+
+import torch
+
+from bitorch_engine import _hip
+
+
+class MPQForwardList:
+    """entries: sequence of dicts with keys x, qweight, scales, zeros, y and optionally bias, depends_on (index of an
+    EARLIER entry whose `y` tensor IS this entry's `x`).  All tensors on one GPU; x [M, K], y [M, N] contiguous, dtype
+    fp16 / bf16; the tensors' storage is frozen in the plan (update their CONTENTS, never rebind them)."""
+
+    def __init__(self, entries, w_bit=4, group_size=128, asym=False):
+        if not entries:
+            raise ValueError("MPQForwardList: empty list")
+        L = _hip.lib()
+        first = entries[0]
+        dev = _hip.need_gpu(*[t for e in entries for t in (e["x"], e["qweight"], e["scales"], e["zeros"], e["y"], e.get("bias"))])
+        self.M = first["x"].reshape(-1, first["x"].shape[-1]).shape[0]
+        dtype = first["x"].dtype
+        arr = (_hip.ListEntry * len(entries))()
+        keep = []
+        for i, e in enumerate(entries):
+            x, y = e["x"], e["y"]
+            K = x.shape[-1]
+            N = e["qweight"].shape[1]
+            if x.dtype != dtype or y.dtype != dtype or e["scales"].dtype != dtype:
+                raise RuntimeError("MPQForwardList: one dtype per list")
+            if not (x.is_contiguous() and y.is_contiguous() and e["qweight"].is_contiguous() and e["scales"].is_contiguous() and e["zeros"].is_contiguous()):
+                raise RuntimeError("MPQForwardList: tensors must be contiguous")
+            if x.numel() != self.M * K or y.numel() != self.M * N or e["qweight"].shape[0] != K * w_bit // 32:
+                raise RuntimeError(f"MPQForwardList: entry {i} has inconsistent shapes")
+            bias = e.get("bias")
+            arr[i] = _hip.ListEntry(x.data_ptr(), e["qweight"].data_ptr(), e["scales"].data_ptr(), e["zeros"].data_ptr(),
+                                    None if bias is None else bias.data_ptr(), y.data_ptr(), K, N, int(e.get("depends_on", -1)), 0)
+            keep.append((x, e["qweight"], e["scales"], e["zeros"], bias, y))
+        self._keep = keep  # the plan holds raw pointers
+        self._entries = arr
+        nbytes = L.bie_mpq_list_device_bytes(len(entries), arr, self.M, w_bit, group_size)
+        if nbytes == 0:
+            raise RuntimeError("MPQForwardList: this list is outside the one-launch decode range (1 <= M <= 2, w_bit 4 with groups of "
+                               "32/64/128/256 or w_bit 2 with 64/128/256, K a multiple of one common group size)")
+        self._mem = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+        base = (self._mem.data_ptr() + 255) // 256 * 256
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(dev):
+            _hip.check(L.bie_mpq_list_create(ctypes.byref(handle), len(entries), arr, self.M, w_bit, group_size, 1 if asym else 0,
+                                             _hip.dt(first["x"]), base, nbytes), "bie_mpq_list_create")
+        self._plan = handle
+        self._L = L
+        self.device = dev
+        self.launches = L.bie_mpq_list_launches(handle)
+
+    def forward(self, stream=None):
+        """Enqueue the launch on `stream` (a raw hipStream_t / None = the current stream of the plan's device)."""
+        _hip.need_gpu(self._mem)
+        st = _hip.stream() if stream is None else stream
+        _hip.check(self._L.bie_mpq_list_forward(self._plan, st), "bie_mpq_list_forward")
+
+    __call__ = forward
+
+    def __del__(self):
+        plan, self._plan = getattr(self, "_plan", None), None
+        if plan:
+            self._L.bie_mpq_list_destroy(plan)
+
+    @classmethod
+    def from_layers(cls, layers, xs, chain=False):
+        """layers: prepared MPQLinearCuda modules (implicit g_idx); xs: one input tensor per layer, or ONE tensor when
+        chain=True (layer i+1 reads layer i's output).  Returns (plan, ys)."""
+        entries, ys = [], []
+        l0 = layers[0]
+        for i, layer in enumerate(layers):
+            x = ys[-1] if (chain and i > 0) else (xs if (chain or isinstance(xs, torch.Tensor)) else xs[i])
+            x2 = x.reshape(-1, x.shape[-1])
+            y = torch.empty((x2.shape[0], layer.out_channels), dtype=x.dtype, device=x.device)
+            zeros = layer.qzeros if layer.asym else layer.zeros
+            entries.append({"x": x2, "qweight": layer.qweight.data, "scales": layer.scales, "zeros": zeros,
+                            "bias": getattr(layer, "bias", None) if getattr(layer, "disable_bias", True) is False else None,
+                            "y": y, "depends_on": i - 1 if (chain and i > 0) else -1})
+            ys.append(y)
+        return cls(entries, w_bit=l0.w_bit, group_size=l0.group_size, asym=l0.asym), ys

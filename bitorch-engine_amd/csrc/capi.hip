@@ -20,6 +20,19 @@ size_t mpq_gemv_lut_part_floats(int M, int K, int group_size, int tiles_total, i
 int mpq_gemv_lut_launch(int nsets, const int32_t* const* qw, const void* const* scales, const void* const* zeros,
                         const void* const* bias, void* const* y, const int* N, const void* x, unsigned* counters, float* part,
                         int M, int K, int group_size, int zm, int dtype, hipStream_t st, int w_bit);
+// mpq_list.hip
+struct MpqList;
+size_t mpq_list_device_bytes(int n, const bie_mpq_list_entry* ent, int M, int w_bit, int group_size);
+int mpq_list_create(MpqList** out, int n, const bie_mpq_list_entry* ent, int M, int w_bit, int group_size, int asym, int dtype,
+                    void* device_mem, size_t device_bytes);
+int mpq_list_forward(MpqList* p, hipStream_t st);
+int mpq_list_launches(const MpqList* p);
+void mpq_list_destroy(MpqList* p);
+// splitk.hip
+int status_init();
+unsigned status_read(bool clear);
+int status_report(const char* fn);
+void test_forge_set(unsigned tag_skew, int spin_limit);
 // mpq_gemm.hip
 bool mpq_gemm_ok(int M, int K, int N, int w_bit, int group_size, int dtype, bool has_gidx);
 size_t mpq_gemm_workspace_bytes(int M, int K, int N);
@@ -99,6 +112,21 @@ extern "C" {
 int bie_version(void) { return BIE_VERSION; }
 const char* bie_last_error(void) { return bie::get_error(); }
 
+int bie_status_init(void) { return status_init(); }
+unsigned bie_device_status(int clear) { return status_read(clear != 0); }
+void bie_test_forge_reducer(unsigned tag_skew, int spin_limit) { test_forge_set(tag_skew, spin_limit); }
+
+size_t bie_mpq_list_device_bytes(int n_entries, const bie_mpq_list_entry* entries, int M, int w_bit, int group_size) {
+    return mpq_list_device_bytes(n_entries, entries, M, w_bit, group_size);
+}
+int bie_mpq_list_create(bie_mpq_list_t** plan, int n_entries, const bie_mpq_list_entry* entries, int M, int w_bit, int group_size,
+                        int asym, int dtype, void* device_mem, size_t device_bytes) {
+    return mpq_list_create(reinterpret_cast<MpqList**>(plan), n_entries, entries, M, w_bit, group_size, asym, dtype, device_mem, device_bytes);
+}
+int bie_mpq_list_forward(bie_mpq_list_t* plan, void* stream) { return mpq_list_forward(reinterpret_cast<MpqList*>(plan), as_stream(stream)); }
+int bie_mpq_list_launches(const bie_mpq_list_t* plan) { return mpq_list_launches(reinterpret_cast<const MpqList*>(plan)); }
+void bie_mpq_list_destroy(bie_mpq_list_t* plan) { mpq_list_destroy(reinterpret_cast<MpqList*>(plan)); }
+
 size_t bie_mpq_workspace_bytes(int M, int K, int N, int w_bit) {
     if (M <= 0 || K <= 0 || N <= 0 || !(w_bit == 1 || w_bit == 2 || w_bit == 4 || w_bit == 8)) return 0;
     size_t a = M <= 16 ? mpq_gemv_workspace_bytes(M, K, N, w_bit) : 0;
@@ -121,6 +149,8 @@ int bie_mpq_forward(const void* x, const int32_t* qweight, const void* scales, c
     const size_t need = bie_mpq_workspace_bytes(M, K, N, w_bit);
     BIE_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), BIE_ERR_WORKSPACE,
                 "bie_mpq_forward: workspace of %zu bytes required, got %zu", need, workspace_bytes);
+    rc = status_report("bie_mpq_forward");
+    if (rc) return rc;
     hipStream_t st = as_stream(stream);
     float* head = reinterpret_cast<float*>(workspace);
     float* part = head + WS_HEAD / sizeof(float);
@@ -195,6 +225,8 @@ int bie_mpq_forward_grouped(const void* x, int n_sets, const int32_t* const* qwe
     const size_t need = bie_mpq_grouped_workspace_bytes(n_sets, N, M, K, w_bit);
     BIE_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), BIE_ERR_WORKSPACE,
                 "bie_mpq_forward_grouped: workspace of %zu bytes required, got %zu", need, workspace_bytes);
+    int src = status_report("bie_mpq_forward_grouped");
+    if (src) return src;
     const int tiles = grouped_tiles(n_sets, N);
     bool n4 = true;  // the matrix-pipe form loads four adjacent columns with one 16-byte load
     for (int i = 0; i < n_sets; i++) n4 = n4 && (N[i] & 3) == 0;
@@ -333,6 +365,8 @@ int bie_mbwq_exl2_forward(const void* x, const int32_t* qweight, const void* sca
     if (rc) return rc;
     const size_t need = WS_HEAD + mbwq_workspace_bytes(M, K, N);
     BIE_REQUIRE(workspace && workspace_bytes >= need, BIE_ERR_WORKSPACE, "bie_mbwq_exl2_forward: workspace of %zu bytes required, got %zu", need, workspace_bytes);
+    rc = status_report("bie_mbwq_exl2_forward");
+    if (rc) return rc;
     return mbwq_exl2_forward_launch(x, qweight, scales, zeros, q_perm, q_group_map, rows7_host, y, (float*)workspace, (float*)workspace + WS_HEAD / sizeof(float), M, K, N, as_stream(stream));
 }
 

@@ -18,6 +18,8 @@
 #pragma clang fp contract(off)
 
 namespace bie {
+unsigned* device_status_word();                            // splitk.hip
+void test_forge_get(unsigned* tag_skew, int* spin_limit);  // splitk.hip
 
 int mpq_gemv_launch(const void* x, const int32_t* qw, const void* scales, const void* zeros, const void* bias, void* y,
                     float* part, int M, int K, int N, int w_bit, int group_size, int zm, int dtype, const uint16_t* perm,
@@ -238,9 +240,14 @@ __global__ __launch_bounds__(EX2_NW * 64, (EX2_NW == 8 ? 2 : 1)) void exl2_gemv2
                                                                     const uint16_t* __restrict__ perm, const uint16_t* __restrict__ gmap,
                                                                     unsigned long long* __restrict__ gran, unsigned* __restrict__ gen,
                                                                     uint16_t* __restrict__ y, Exl2Rows rows, int M, int K, int N,
-                                                                    int chunks_per_slab, int S, unsigned epoch) {
+                                                                    int chunks_per_slab, int S, unsigned epoch, unsigned* status,
+                                                                    unsigned tag_skew, int spin_limit) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem2[];
     const int tid = threadIdx.x, lane = tid & 63;
+    // the tile's generation is read ONCE, at kernel entry, by every wave: the reducer advances the word as soon as it is done, and a
+    // wave that read it only in the epilogue could see the NEXT generation, tag with it and never be matched
+    unsigned gen_entry = 0;
+    if (S > 1) gen_entry = __hip_atomic_load(gen + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // wave-private x chunk buffers [wave][set 0..3][MT][32] fp16 (q_perm applied): each wave gathers the 32 activations of
     // its own chunk together with the chunk's loads -- no block-wide x slab, no barrier before the weight stream
@@ -402,7 +409,7 @@ __global__ __launch_bounds__(EX2_NW * 64, (EX2_NW == 8 ? 2 : 1)) void exl2_gemv2
             // K slabs: the tagged-granule reduction of the lookup GEMV (mpq_gemv_lut.hip) -- slabs 0..S-2 publish {fp32, tag} with
             // one write-through store per column and retire; the last slab's workgroup (highest block ids: dispatched after every
             // publisher, which never waits) polls them and adds in slab order.  No finalize launch, no atomics, deterministic.
-            const unsigned gen_next = gen[blockIdx.x] + 1u;
+            const unsigned gen_next = gen_entry + 1u;
             const unsigned tag = epoch | (gen_next & 0xffu);
             const long ncat = (long)gridDim.x * 64, col = (long)blockIdx.x * 64 + ol;
             const int slab = blockIdx.y;
@@ -424,13 +431,17 @@ __global__ __launch_bounds__(EX2_NW * 64, (EX2_NW == 8 ? 2 : 1)) void exl2_gemv2
                     }
                     ready = true;
 #pragma unroll
-                    for (int jj = 0; jj < 4; jj++) ready = ready && ((unsigned)(gv[jj] >> 32) == tag);
+                    for (int jj = 0; jj < 4; jj++) ready = ready && ((unsigned)(gv[jj] >> 32) == (tag ^ tag_skew));
                     ready = __builtin_amdgcn_ballot_w64(!ready) == 0;
                     if (!ready) __builtin_amdgcn_s_sleep(2);
-                } while (!ready && ++spins < (1 << 24));
+                } while (!ready && ++spins < spin_limit);
 #pragma unroll
                 for (int jj = 0; jj < 4; jj++)
                     if (s0 + jj < S - 1) v += __uint_as_float((unsigned)gv[jj]);
+                if (!ready) {  // wave-uniform: never a silent number -- NaN in y and a bit in the status page (bie_device_status)
+                    v = __uint_as_float(0x7fc00000u);
+                    if (ol == 0 && status) __hip_atomic_fetch_or(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
             }
             tot = v + tot;
             if (tid == 0) gen[blockIdx.x] = gen_next;  // the next launch (or a replay of this one) tags differently
@@ -542,10 +553,13 @@ int mbwq_exl2_forward_launch(const void* x, const int32_t* qw, const void* scale
         const unsigned epoch = next_launch_epoch();
         unsigned* gen = reinterpret_cast<unsigned*>(head) + BIE_WS_GEN_OFFSET;
         unsigned long long* gran = reinterpret_cast<unsigned long long*>(part);
+        unsigned skew;
+        int spin;
+        test_forge_get(&skew, &spin);
 #define L2(MTV, NWV)                                                                                                       \
     hipLaunchKernelGGL((exl2_gemv2_kernel<MTV, NWV>), grid2, dim3(NWV * 64), lds2, st, (const uint16_t*)x, (const uint32_t*)qw, \
                        (const uint16_t*)scales, (const uint16_t*)zeros, (const uint16_t*)perm, (const uint16_t*)gmap, gran, gen, \
-                       (uint16_t*)y, rows, M, K, N, cps2, S, epoch)
+                       (uint16_t*)y, rows, M, K, N, cps2, S, epoch, device_status_word(), skew, spin)
         if (nw == 16) {
             if (MT == 1) L2(1, 16); else L2(2, 16);
         } else {

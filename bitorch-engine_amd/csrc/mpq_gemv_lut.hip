@@ -33,6 +33,9 @@
 
 namespace bie {
 
+unsigned* device_status_word();                            // splitk.hip
+void test_forge_get(unsigned* tag_skew, int* spin_limit);  // splitk.hip
+
 constexpr int LUT_MAX_SETS = 8;
 
 struct LutSet {
@@ -53,10 +56,19 @@ struct LutArgs {
     int nsets, M, K, G, tiles_total, S, groups_per_wave;  // G / groups_per_wave count UNITS of RPG rows: H units per group
     int hshift;  // log2(H)
     unsigned epoch;  // (launch-call number mod 2^24) << 8: the upper 24 bits of every granule tag of this launch
+    unsigned* status;   // host-mapped status word (NULL before bie_status_init): bit 0 = a reducer gave up
+    unsigned tag_skew;  // testing aid (bie_test_forge_reducer): the reducer expects tag ^ tag_skew
+    int spin_limit;
 };
 
-// tuning aid (BIE_GEMV_LAB=5): per-wave timestamps {start, weights landed, compute done, end, xcc/cu id} of the last launch
+// tuning aid (BIE_GEMV_LAB=5, LAB builds only: make lab): per-wave timestamps {start, weights landed, compute done, end, xcc/cu id}
+#ifdef BIE_LAB_BUILD
 __device__ unsigned long long g_lut_stamps[65536 * 5];
+#define BIE_LAB5(LABV) ((LABV) == 5)
+#else
+__device__ unsigned long long g_lut_stamps[1];  // never touched: LAB == 5 is not instantiated in the product build
+#define BIE_LAB5(LABV) false
+#endif
 
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 // constant address space: x is never written by this kernel, and uniform loads from it always take the scalar path
@@ -99,6 +111,8 @@ __device__ __forceinline__ void lut_cross_wg_reduce(const LutArgs& a, const LutS
             return;
         }
         // reducer: poll until every granule of this column carries this launch's tag, then add in slice order
+        const unsigned want = tag ^ a.tag_skew;
+        bool poisoned = false;
 #pragma unroll
         for (int m = 0; m < MT; m++) {
             float v = 0.0f;
@@ -114,10 +128,11 @@ __device__ __forceinline__ void lut_cross_wg_reduce(const LutArgs& a, const LutS
                     }
                     ready = true;
 #pragma unroll
-                    for (int jj = 0; jj < 8; jj++) ready = ready && ((unsigned)(gv[jj] >> 32) == tag);
+                    for (int jj = 0; jj < 8; jj++) ready = ready && ((unsigned)(gv[jj] >> 32) == want);
                     ready = __builtin_amdgcn_ballot_w64(!ready) == 0;  // wave-uniform: every lane's granules are in
                     if (!ready) __builtin_amdgcn_s_sleep(2);
-                } while (!ready && ++spins < (1 << 24));  // bounded: publishers have lower block ids and never wait
+                } while (!ready && ++spins < a.spin_limit);  // bounded: publishers never wait, but HIP promises no dispatch order
+                if (!ready) poisoned = true;  // wave-uniform
 #pragma unroll
                 for (int jj = 0; jj < 8; jj++)
                     if (s0 + jj < a.S - 1) v += __uint_as_float((unsigned)gv[jj]);
@@ -125,6 +140,11 @@ __device__ __forceinline__ void lut_cross_wg_reduce(const LutArgs& a, const LutS
             tot[m] = v + tot[m];
         }
         if (lane == 0) a.gen[tile] = gen_next;  // a replay of this launch gets a different tag; visible at the kernel boundary
+        if (poisoned) {  // never a silent number: NaN in y and a bit in the status page the next C-ABI call reports
+#pragma unroll
+            for (int m = 0; m < MT; m++) tot[m] = __uint_as_float(0x7fc00000u);
+            if (lane == 0 && a.status) __hip_atomic_fetch_or(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     if (owner) {
 #pragma unroll
@@ -366,7 +386,7 @@ __global__ __launch_bounds__(NW * 64) void mpq_gemv_lut_kernel(const LutArgs a) 
     };
 
     unsigned long long st0 = 0, st1 = 0, st2 = 0;
-    if constexpr (LAB == 5) st0 = wall_clock64();
+    if constexpr (BIE_LAB5(LAB)) st0 = wall_clock64();
     uint32_t wa[RPG], wb[RPG];
     uint32_t sa = 0, za = 0, sb2 = 0, zb2 = 0;
     if (g0 < g1) {
@@ -378,7 +398,7 @@ __global__ __launch_bounds__(NW * 64) void mpq_gemv_lut_kernel(const LutArgs a) 
         load_group(wa, g0);
         if (g0 + 1 < g1) load_group(wb, g0 + 1);
     }
-    if constexpr (LAB == 5) {
+    if constexpr (BIE_LAB5(LAB)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         st1 = wall_clock64();
     }
@@ -391,7 +411,7 @@ __global__ __launch_bounds__(NW * 64) void mpq_gemv_lut_kernel(const LutArgs a) 
         }
     }
 
-    if constexpr (LAB == 5) {
+    if constexpr (BIE_LAB5(LAB)) {
         asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]));
         st2 = wall_clock64();
         const long wid = (long)blockIdx.x * NW + wave;
@@ -427,7 +447,7 @@ __global__ __launch_bounds__(NW * 64) void mpq_gemv_lut_kernel(const LutArgs a) 
     }
 
     lut_cross_wg_reduce<DT, MT, (LAB == 0 || LAB == 4 || LAB == 5)>(a, ls, tot, tile, slice, lane, n, N, tag, gen_next);
-    if constexpr (LAB == 5) {
+    if constexpr (BIE_LAB5(LAB)) {
         const long wid = (long)blockIdx.x * NW;
         if (lane == 0 && wid < 65536) g_lut_stamps[wid * 5 + 3] = wall_clock64();
     }
@@ -469,7 +489,7 @@ __global__ __launch_bounds__(256) void mpq_gemv_lutc_kernel(const LutArgs a) {
     }
 
     unsigned long long st0 = 0, st1 = 0, st2 = 0;
-    if constexpr (LAB == 5) st0 = wall_clock64();
+    if constexpr (BIE_LAB5(LAB)) st0 = wall_clock64();
     // ---- every row of this wave, every group constant: requested now
     const uint32_t* wcol = ls.qw + nl;
     uint32_t w[GW][RPW];
@@ -490,7 +510,7 @@ __global__ __launch_bounds__(256) void mpq_gemv_lutc_kernel(const LutArgs a) {
         // issue order = group order: the loads return in order, so group j must not wait behind a later group's request
         asm volatile("" ::: "memory");
     }
-    if constexpr (LAB == 5) {
+    if constexpr (BIE_LAB5(LAB)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         st1 = wall_clock64();
     }
@@ -581,7 +601,7 @@ __global__ __launch_bounds__(256) void mpq_gemv_lutc_kernel(const LutArgs a) {
                 }
         }
     }
-    if constexpr (LAB == 5) {
+    if constexpr (BIE_LAB5(LAB)) {
         asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]));
         st2 = wall_clock64();
         const long wid = (long)blockIdx.x * NW + wave;
@@ -608,7 +628,7 @@ __global__ __launch_bounds__(256) void mpq_gemv_lutc_kernel(const LutArgs a) {
         tot[m] = v;
     }
     lut_cross_wg_reduce<DT, MT, (LAB == 0 || LAB == 4 || LAB == 5)>(a, ls, tot, tile, slice, lane, n, N, tag, gen_next);
-    if constexpr (LAB == 5) {
+    if constexpr (BIE_LAB5(LAB)) {
         const long wid = (long)blockIdx.x * NW;
         if (lane == 0 && wid < 65536) g_lut_stamps[wid * 5 + 3] = wall_clock64();
     }
@@ -831,13 +851,17 @@ __global__ __launch_bounds__(NW * 64, 2) void mpq_gemv_lutm_kernel(const LutArgs
                     }
                     ready = true;
 #pragma unroll
-                    for (int jj = 0; jj < 8; jj++) ready = ready && ((unsigned)(gv[jj] >> 32) == tag);
+                    for (int jj = 0; jj < 8; jj++) ready = ready && ((unsigned)(gv[jj] >> 32) == (tag ^ a.tag_skew));
                     ready = __builtin_amdgcn_ballot_w64(!ready) == 0;
                     if (!ready) __builtin_amdgcn_s_sleep(2);
-                } while (!ready && ++spins < (1 << 24));
+                } while (!ready && ++spins < a.spin_limit);
 #pragma unroll
                 for (int jj = 0; jj < 8; jj++)
                     if (s0 + jj < a.S - 1) v += __uint_as_float((unsigned)gv[jj]);
+                if (!ready) {  // wave-uniform: never a silent number
+                    v = __uint_as_float(0x7fc00000u);
+                    if (lane == 0 && a.status) __hip_atomic_fetch_or(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
             }
             tot = v + tot;
         }
@@ -850,10 +874,12 @@ __global__ __launch_bounds__(NW * 64, 2) void mpq_gemv_lutm_kernel(const LutArgs
     if (a.S > 1 && slice == a.S - 1 && threadIdx.x == 0) a.gen[tile] = gen_next;  // read only by the next launch
 }
 
+#ifdef BIE_LAB_BUILD
 // tuning aid: copy the stamps of the last BIE_GEMV_LAB=5 launch to the host (synchronises the device)
 extern "C" int bie_debug_lut_stamps(unsigned long long* out, int n_waves) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lut_stamps), (size_t)n_waves * 5 * sizeof(unsigned long long));
 }
+#endif
 
 // ---- host side --------------------------------------------------------------------------------------------
 static int lut_env(const char* name, int dflt) {
@@ -1112,6 +1138,8 @@ int mpq_gemv_lut_launch(int nsets, const int32_t* const* qw, const void* const* 
     a.groups_per_wave = p.gpw;
     a.hshift = p.H == 4 ? 2 : (p.H == 2 ? 1 : 0);
     a.epoch = next_launch_epoch();
+    a.status = device_status_word();
+    test_forge_get(&a.tag_skew, &a.spin_limit);
     const int grid = tiles * p.S;
     if (w_bit == 2) {
         if (dtype == BIE_F16) lut2_launch<BIE_F16>(a, p.rpg, grid, M, zm, st);

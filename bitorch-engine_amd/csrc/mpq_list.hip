@@ -1,0 +1,683 @@
+// ONE launch, MANY layers: the decode GEMV (M <= 2) of a LIST of W4 / W2 layers -- the MI355X answer to the reference's
+// "one default-stream quant_mm_kernel launch per layer" (layers/qlinear/nbit/cuda/mpq_linear_cuda_kernel.cu:482-577).
+//
+// Why.  A 4096x4096 W4 layer is 8.9 MB: 1.1 us of HBM time, less than a kernel boundary.  A lone launch of that size spends
+// its life in ramp-up, one load -> compute -> reduce round and drain (profiles/r02_lut_timeline.txt: HBM idle while the
+// VALU works and vice versa; 0.18 of the roofline).  With the column tiles of MANY layers in one grid the phases of
+// different workgroups overlap -- while one workgroup looks up and multiplies, its CU neighbours' rows are in flight -- and
+// the launch reaches the steady-state rate of the kernel instead of its start-up transient.
+//
+// What an entry is: x[M, K] -> y[M, N] through (qweight, scales, zeros | qzeros, bias) exactly as bie_mpq_forward takes
+// them (implicit groups).  Entries may differ in K, N and x; w_bit, group size, dtype and zero mode are common to a list.
+// Entry e may name ONE earlier entry it DEPENDS on (its x is that entry's y, or is derived from it by the caller's own
+// kernels -- no: only direct y -> x chains are supported): its workgroups request their weight rows first and only then
+// wait for the producer's completion count, so layer l+1's weight stream runs under layer l's compute and reduction.
+//
+// Kernel = the table-lookup dequantisation of mpq_gemv_lut.hip (see its header for the arithmetic: the 16 doubly-rounded
+// reference values of a (group, column) live in LDS as fp32, one v_perm_b32 + ds_read_b32 + FMA per weight), with
+//   * weight rows, scales and zeros through BUFFER loads: the row offset is a scalar register (one s_add per row) and the
+//     column offset one shared VGPR -- the 64-bit per-row VALU address arithmetic of the pointer form (0.33 VALU per
+//     weight, 42 v_lshl_add_u64 per group) is gone;
+//   * FMAs issued as v_pk_fma_f32 pairs with the activation pair in an SGPR pair (two weights per VALU slot);
+//   * a device-resident descriptor table (entries, block -> (entry, tile, slice) records) instead of kernel arguments, so
+//     a list is not bounded by the 4 KiB of kernarg space and a captured launch keeps working when the caller updates x / y
+//     contents (never the pointers);
+//   * the tagged-granule cross-workgroup reduction of the lookup GEMV, now FAILING LOUDLY: a reducer whose granules do not
+//     arrive within the spin bound stores NaN and raises a bit in the host-visible status page (bie_device_status).
+#include "mpq_dequant.cuh"
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#pragma clang fp contract(off)
+
+namespace bie {
+
+unsigned* device_status_word();  // status.hip: device pointer of the host-mapped status page (NULL before bie_status_init)
+void test_forge_get(unsigned* tag_skew, int* spin_limit);
+
+struct ListEntry {          // 128 bytes, read with scalar loads
+    const uint32_t* qw;
+    const uint16_t* scales;
+    const void* zeros;
+    const uint16_t* bias;
+    const uint16_t* x;
+    uint16_t* y;
+    unsigned long long* gran;  // [S-1][M][tiles*64] {fp32 partial, tag} granules of this entry (NULL when S == 1)
+    unsigned* gen;             // [tiles] generation words of this entry's column tiles
+    unsigned* done;            // completion counter of this entry (tiles finished, monotonic over launches)
+    const unsigned* dep_done;  // the producer's counter (NULL: independent)
+    int N, K, G, gpw, S, hshift, tiles, dep_tiles;
+    unsigned qw_bytes, sc_bytes, ze_bytes, pad0;
+};
+static_assert(sizeof(ListEntry) == 128, "ListEntry layout");
+
+struct ListArgs {
+    const ListEntry* ent;
+    const uint2_t* blk;   // per block: {entry, tile | slice << 20}
+    unsigned* status;     // host-visible status word (may be NULL)
+    unsigned epoch;       // (launch-call number mod 2^24) << 8
+    unsigned tag_skew;    // testing aid: the reducer expects tag ^ tag_skew (forges a stale granule)
+    int spin_limit;
+    int M;
+};
+
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+typedef const __attribute__((address_space(4))) uint32_t cu32_t;
+typedef const __attribute__((address_space(4))) ListEntry cent_t;
+typedef const __attribute__((address_space(4))) uint2_t cu2_t;
+
+template <int BYTE>
+__device__ __forceinline__ uint32_t list_lut_addr(uint32_t lane_addr, uint32_t w) {
+    return __builtin_amdgcn_perm(w, lane_addr, 0x0c0c0400u + ((uint32_t)BYTE << 8));
+}
+__device__ __forceinline__ float list_lds_f32(uint32_t byte_addr) {
+    return __uint_as_float(*reinterpret_cast<const lds_u32_t*>(byte_addr));
+}
+template <int DT, int ZM>
+__device__ __forceinline__ float list_lut_entry(uint32_t q, float s, float z, int zq1) {
+    if constexpr (ZM == ZM_ASYM) return dequant_scalar_asym<DT>(q, s, zq1);
+    else if constexpr (ZM == ZM_FUSED) return dt_traits<DT>::round(__builtin_fmaf((float)q, s, -z));
+    else return dequant_scalar_sym<DT>(q, s, z);
+}
+
+constexpr unsigned BIE_STATUS_REDUCER_TIMEOUT = 1u, BIE_STATUS_DEP_TIMEOUT = 2u;
+
+// VAR bit 0: v_pk_fma_f32 pairs; bit 1 (tuning aid): stream only -- rows, constants and x are loaded, nothing is looked up;
+// bit 2: registers capped at 64 (four workgroups = 32 waves per CU instead of three)
+template <int DT, int ZM, int MT, int RPG, int WB, int VAR>
+__global__ __launch_bounds__(512, ((VAR & 4) ? 8 : 1)) void mpq_list_kernel(const ListArgs a) {
+    constexpr int NW = 8;
+    constexpr int NB = 32 / WB;      // weights per packed word
+    constexpr int XD = NB / 2;       // x dwords (16-bit pairs) per packed word
+    constexpr bool PK = (VAR & 1) != 0 && WB == 4 && DT == BIE_BF16;
+    constexpr bool STREAM_ONLY = (VAR & 2) != 0;
+    __shared__ __attribute__((aligned(4096))) uint32_t tab[NW * 16 * 64];  // the only LDS object: starts at LDS address 0
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint2_t rec = *((cu2_t*)(uintptr_t)(a.blk + blockIdx.x));
+    cent_t* e = (cent_t*)(uintptr_t)(a.ent + rec.x);
+    const int tile = (int)(rec.y & 0xfffffu);
+    const int slice = (int)(rec.y >> 20);
+    const int N = e->N, K = e->K, G = e->G, gpw = e->gpw, S = e->S, hshift = e->hshift;
+    const int n = tile * 64 + lane;
+    const int nl = n < N ? n : N - 1;  // clamp: out-of-range lanes load valid memory and are never stored
+    const int g0 = (slice * NW + wave) * gpw;
+    int g1 = g0 + gpw;
+    if (g1 > G) g1 = G;
+    unsigned* gen = e->gen;
+    unsigned tag = 0, gen_next = 0;
+    if (S > 1) {  // uniform; the generation only changes when this launch's reducer is done
+        gen_next = gen[tile] + 1u;
+        tag = a.epoch | (gen_next & 0xffu);
+    }
+
+    // weight rows / group constants through buffer descriptors: scalar row offset + one shared column offset register
+    const auto rq = __builtin_amdgcn_make_buffer_rsrc((void*)e->qw, 0, (int)e->qw_bytes, 0x00020000);
+    const unsigned col4 = (unsigned)nl * 4u;
+    const uint16_t* scol = e->scales + nl;  // group constants: plain pointers (two 64-bit address adds per unit are noise, two more
+    const void* zbase = e->zeros;           // buffer descriptors = 8 SGPRs in a kernel that spills SGPRs are not)
+    const unsigned row_bytes = (unsigned)N * 4u;
+    auto load_group = [&](uint32_t (&dst)[RPG], int unit) {
+        // the row stride is made opaque at every call: otherwise the sixteen multiples u * row_bytes become loop invariants, live
+        // (and spilled to VGPR lanes) across the whole lookup phase instead of fifteen s_add_u32 right here
+        unsigned rb = row_bytes;
+        asm volatile("" : "+s"(rb));
+        unsigned soff = (unsigned)(unit * RPG) * rb;
+#pragma unroll
+        for (int u = 0; u < RPG; u++) {
+            dst[u] = __builtin_amdgcn_raw_buffer_load_b32(rq, col4, soff, 2);  // aux 2 = nt: every weight byte is read once
+            soff += rb;
+        }
+    };
+    auto load_params = [&](int unit, uint32_t& sb, uint32_t& zb) {
+        const int g = unit >> hshift;  // a group may be split into H units of RPG rows, each with its own wave (and table)
+        sb = scol[(long)g * N];
+        if constexpr (ZM == ZM_ASYM) {
+            const uint32_t zw = reinterpret_cast<const uint32_t*>(zbase)[(long)g * (N / NB) + nl / NB];
+            zb = ((zw >> ((nl % NB) * WB)) & ((1u << WB) - 1u)) + 1u;
+        } else {
+            zb = reinterpret_cast<const uint16_t*>(zbase)[(long)g * N + nl];
+        }
+    };
+
+    float acc[MT][2];  // even / odd nibbles: two independent FMA chains (one v_pk_fma_f32 chain in the PK form)
+#pragma unroll
+    for (int m = 0; m < MT; m++) acc[m][0] = acc[m][1] = 0.0f;
+
+    // LDS byte address of tab[wave][q][lane] = ((wave * 16 + q) << 8) | (lane << 2): byte 1 carries (wave, q)
+    const uint32_t lane_addr = lane * 4;
+    const uint32_t wavepat = (uint32_t)wave * 0x10101010u;
+    uint32_t* mytab = tab + wave * (16 * 64) + lane;
+    uint32_t m0f;  // VOP3 takes no 32-bit literal: the nibble mask lives in a register
+    asm("v_mov_b32 %0, 0x0f0f0f0f" : "=v"(m0f));
+    const uint16_t* xbase = e->x;
+
+    auto process_group = [&](const uint32_t (&w)[RPG], int g, uint32_t sb, uint32_t zb) {
+        // the activations of the unit are wave-uniform: scalar loads, issued before the table is built so that nothing
+        // but LDS traffic is pending in the lookup phase
+        uint32_t xs[MT][RPG * XD];
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            cu32_t* xd = (cu32_t*)(uintptr_t)(xbase + (long)m * K + (long)g * (RPG * NB));
+#pragma unroll
+            for (int i = 0; i < RPG * XD; i++) xs[m][i] = xd[i];
+        }
+        // ---- the 16-entry table of this (group, column)
+        if constexpr (STREAM_ONLY) {
+#pragma unroll
+            for (int u = 0; u < RPG; u++) acc[0][0] += __uint_as_float(w[u] & 0x3f7fffffu) + __uint_as_float(sb << 16) + __uint_as_float(zb << 16) + __uint_as_float(xs[0][u]);
+            return;
+        } else if constexpr (WB == 2) {
+            float s, z = 0.0f;
+            int zq1 = 0;
+            if constexpr (DT == BIE_BF16) s = bf16_bits_to_f32(sb); else s = f16_bits_to_f32(sb);
+            if constexpr (ZM == ZM_ASYM) zq1 = (int)zb;
+            else if constexpr (DT == BIE_BF16) z = bf16_bits_to_f32(zb); else z = f16_bits_to_f32(zb);
+            uint32_t v[4];  // the four dequantised values as 16-bit patterns
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float t = list_lut_entry<DT, ZM>((uint32_t)q, s, z, zq1);
+                if constexpr (DT == BIE_BF16) v[q] = __float_as_uint(t) >> 16; else v[q] = f32_to_f16_bits(t);
+            }
+#pragma unroll
+            for (int p2 = 0; p2 < 16; p2++) mytab[p2 * 64] = v[p2 & 3] | (v[p2 >> 2] << 16);
+        } else if constexpr (DT == BIE_BF16 && ZM == ZM_SYM) {
+            // a_q = fl(q*s): v_mul_f32 (exact) + v_cvt_pk_bf16_f32; T_q = fl(a_q - z): unpack-and-subtract on the dot unit
+            // (bf16_pairs_sub) + v_cvt_pk_bf16_f32; the entry is the fp32 value of the bf16 weight (bf16 << 16)
+            const float s = bf16_bits_to_f32(sb), nz = -bf16_bits_to_f32(zb);
+            const uint32_t sel0 = sel_lo_hi<0>(), sel1 = sel_lo_hi<1>();
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t A0 = pack_bf16x2((float)(4 * j) * s, (float)(4 * j + 1) * s);
+                const uint32_t A1 = pack_bf16x2((float)(4 * j + 2) * s, (float)(4 * j + 3) * s);
+                float d[4];
+                bf16_pairs_sub(A0, A1, sel0, sel1, nz, d);
+                const uint32_t T0 = pack_bf16x2(d[0], d[1]), T1 = pack_bf16x2(d[2], d[3]);
+                mytab[(4 * j + 0) * 64] = T0 << 16;
+                mytab[(4 * j + 1) * 64] = T0 & 0xffff0000u;
+                mytab[(4 * j + 2) * 64] = T1 << 16;
+                mytab[(4 * j + 3) * 64] = T1 & 0xffff0000u;
+            }
+        } else {
+            float s, z = 0.0f;
+            int zq1 = 0;
+            if constexpr (DT == BIE_BF16) s = bf16_bits_to_f32(sb); else s = f16_bits_to_f32(sb);
+            if constexpr (ZM == ZM_ASYM) zq1 = (int)zb;
+            else if constexpr (DT == BIE_BF16) z = bf16_bits_to_f32(zb); else z = f16_bits_to_f32(zb);
+#pragma unroll
+            for (int q = 0; q < 16; q++) mytab[q * 64] = __float_as_uint(list_lut_entry<DT, ZM>((uint32_t)q, s, z, zq1));
+        }
+        // the activations have landed (in SGPRs) before the first lookup is issued: no scalar load is pending in the lookup
+        // phase, so the LDS reads can be waited for with counted lgkmcnt
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+#pragma unroll
+            for (int i = 0; i < RPG * XD; i += 8)
+                asm volatile("" ::"s"(xs[m][i]), "s"(xs[m][i + 1]), "s"(xs[m][i + 2]), "s"(xs[m][i + 3]), "s"(xs[m][i + 4]), "s"(xs[m][i + 5]),
+                             "s"(xs[m][i + 6]), "s"(xs[m][i + 7]));
+        // ---- 8 lookups + FMAs per packed word, one row ahead (lgkmcnt is a 4-bit counter: at most 15 LDS reads can be
+        // waited for individually)
+        auto lookup = [&](float (&t)[8], int u) {
+            uint32_t we, wo;  // bytes (wave, q) of the even / odd nibbles: (w & 0x0f0f0f0f) | wavepat in ONE v_and_or_b32
+            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(we) : "v"(w[u]), "v"(m0f), "s"(wavepat));
+            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(wo) : "v"(w[u] >> 4), "v"(m0f), "s"(wavepat));
+            t[0] = list_lds_f32(list_lut_addr<0>(lane_addr, we));
+            t[1] = list_lds_f32(list_lut_addr<0>(lane_addr, wo));
+            t[2] = list_lds_f32(list_lut_addr<1>(lane_addr, we));
+            t[3] = list_lds_f32(list_lut_addr<1>(lane_addr, wo));
+            t[4] = list_lds_f32(list_lut_addr<2>(lane_addr, we));
+            t[5] = list_lds_f32(list_lut_addr<2>(lane_addr, wo));
+            t[6] = list_lds_f32(list_lut_addr<3>(lane_addr, we));
+            t[7] = list_lds_f32(list_lut_addr<3>(lane_addr, wo));
+        };
+        auto fmas = [&](const float (&t)[8], int u) {
+            if constexpr (WB == 2) {  // t[i] = the packed pair (w[2i], w[2i+1]) of nibble i; x dword i of the word = (x[2i], x[2i+1])
+#pragma unroll
+                for (int m = 0; m < MT; m++)
+#pragma unroll
+                    for (int i = 0; i < 8; i++)
+                        acc[m][i & 1] = dot2_acc<DT>(__float_as_uint(t[i]), xs[m][u * 8 + i], acc[m][i & 1]);
+                return;
+            } else if constexpr (DT == BIE_F16) {  // fp16 x straight from the SGPR pair: v_fma_mix_f32 converts the selected half on the fly
+#pragma unroll
+                for (int m = 0; m < MT; m++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const uint32_t p = xs[m][u * 4 + i];
+                        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[0,1,0]" : "+v"(acc[m][0]) : "v"(t[2 * i]), "s"(p));
+                        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(acc[m][1]) : "v"(t[2 * i + 1]), "s"(p));
+                    }
+                return;
+            } else {
+#pragma unroll
+                for (int m = 0; m < MT; m++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const uint32_t p = xs[m][u * 4 + i];
+                        const float xlo = __uint_as_float(p << 16), xhi = __uint_as_float(p & 0xffff0000u);
+                        if constexpr (PK) {  // (acc0, acc1) += (t[2i], t[2i+1]) * (xlo, xhi): one VALU slot for two weights
+                            const float2_t tt = {t[2 * i], t[2 * i + 1]}, xx = {xlo, xhi};
+                            float2_t aa = {acc[m][0], acc[m][1]};
+                            aa = __builtin_elementwise_fma(tt, xx, aa);
+                            acc[m][0] = aa.x;
+                            acc[m][1] = aa.y;
+                        } else {
+                            acc[m][0] = __builtin_fmaf(xlo, t[2 * i], acc[m][0]);
+                            acc[m][1] = __builtin_fmaf(xhi, t[2 * i + 1], acc[m][1]);
+                        }
+                    }
+            }
+        };
+        // pin(): the DAG linearisation is free to sink the (unchained) FMAs below every later LDS read; a volatile asm that
+        // consumes the accumulators keeps row u's FMAs between the reads of row u+1 and those of row u+2
+        auto pin = [&]() {
+#pragma unroll
+            for (int m = 0; m < MT; m++) asm volatile("" : "+v"(acc[m][0]), "+v"(acc[m][1]));
+        };
+        float ta[8], tb[8];
+        lookup(ta, 0);
+#pragma unroll
+        for (int u = 0; u < RPG; u += 2) {
+            if (u + 1 < RPG) lookup(tb, u + 1);
+            fmas(ta, u);
+            pin();
+            if (u + 1 < RPG) {
+                if (u + 2 < RPG) lookup(ta, u + 2);
+                fmas(tb, u + 1);
+                pin();
+            }
+        }
+    };
+
+    uint32_t wa[RPG], wb[RPG];
+    uint32_t sa = 0, za = 0, sb2 = 0, zb2 = 0;
+    if (g0 < g1) {
+        // the group constants are requested BEFORE the weight rows (loads return in order): the table is built while the
+        // rows are still in flight instead of after the last of them has landed
+        load_params(g0, sa, za);
+        if (g0 + 1 < g1) load_params(g0 + 1, sb2, zb2);
+        asm volatile("" ::: "memory");
+        load_group(wa, g0);
+        if (g0 + 1 < g1) load_group(wb, g0 + 1);
+    }
+    // ---- a dependent entry: the weight rows are in flight; now wait for the producer (x = its y)
+    const unsigned* dep = e->dep_done;
+    if (dep != nullptr) {
+        // the producer's counter counts finished tiles over ALL launches of this plan: a launch's target is a multiple of its tile
+        // count that the host keeps in the entry record (dep_target is rewritten before every launch? no: derived from gen)
+        const unsigned target = (unsigned)e->dep_tiles;
+        int spins = 0;
+        unsigned seen;
+        do {
+            seen = __hip_atomic_load(dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (seen >= target) break;
+            __builtin_amdgcn_s_sleep(4);
+        } while (++spins < a.spin_limit);
+        if (seen < target && a.status && threadIdx.x == 0) __hip_atomic_fetch_or(a.status, BIE_STATUS_DEP_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    for (int g = g0; g < g1; g += 2) {
+        process_group(wa, g, sa, za);
+        if (g + 2 < g1) { load_params(g + 2, sa, za); load_group(wa, g + 2); }
+        if (g + 1 < g1) {
+            process_group(wb, g + 1, sb2, zb2);
+            if (g + 3 < g1) { load_params(g + 3, sb2, zb2); load_group(wb, g + 3); }
+        }
+    }
+
+    // ---- workgroup reduction through LDS (the tables are dead), wave order --------------------------------------
+    // the epilogue's fields of the entry record are read HERE (an opaque copy of its address: loads from the constant address
+    // space would otherwise be hoisted to the top and occupy ~20 SGPRs through the main loop, which spills SGPRs as it is)
+    cent_t* e2 = e;
+    asm volatile("" : "+s"(e2));
+    float tot[MT];
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(tab);
+#pragma unroll
+    for (int m = 0; m < MT; m++) red[(wave * MT + m) * 64 + lane] = acc[m][0] + acc[m][1];
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; w++) v += red[(w * MT + m) * 64 + lane];
+        tot[m] = v;
+    }
+
+    // ---- cross-workgroup reduction (wave 0 only): slices 0 .. S-2 publish {fp32, tag} granules, the last slice adds them in
+    // slice order (deterministic) once every tag matches
+    const bool owner = n < N;
+    const long ncat = (long)e2->tiles * 64;
+    const long col = (long)tile * 64 + lane;
+    unsigned long long* gran = e2->gran;
+    bool poisoned = false;
+    if (S > 1) {
+        if (slice != S - 1) {  // publisher: one 8-byte write-through store per column, no drain, no atomic
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                const unsigned long long gval = ((unsigned long long)tag << 32) | __float_as_uint(tot[m]);
+                __hip_atomic_store(gran + ((long)slice * MT + m) * ncat + col, gval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+        const unsigned want = tag ^ a.tag_skew;
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            float v = 0.0f;
+            for (int s0 = 0; s0 < S - 1; s0 += 8) {
+                unsigned long long gv[8];
+                bool ready;
+                int spins = 0;
+                do {
+#pragma unroll
+                    for (int jj = 0; jj < 8; jj++) {
+                        const int sidx = (s0 + jj < S - 1) ? s0 + jj : S - 2;
+                        gv[jj] = __hip_atomic_load(gran + ((long)sidx * MT + m) * ncat + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    ready = true;
+#pragma unroll
+                    for (int jj = 0; jj < 8; jj++) ready = ready && ((unsigned)(gv[jj] >> 32) == want);
+                    ready = __builtin_amdgcn_ballot_w64(!ready) == 0;  // wave-uniform: every lane's granules are in
+                    if (!ready) __builtin_amdgcn_s_sleep(2);
+                } while (!ready && ++spins < a.spin_limit);
+                if (!ready) poisoned = true;  // wave-uniform
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++)
+                    if (s0 + jj < S - 1) v += __uint_as_float((unsigned)gv[jj]);
+            }
+            tot[m] = v + tot[m];
+        }
+        if (lane == 0) e2->gen[tile] = gen_next;  // a replay of this launch gets a different tag; visible at the kernel boundary
+        if (poisoned) {  // never a silent number: NaN in y and a bit in the status page the next C-ABI call reports
+#pragma unroll
+            for (int m = 0; m < MT; m++) tot[m] = __uint_as_float(0x7fc00000u);
+            if (lane == 0 && a.status) __hip_atomic_fetch_or(a.status, BIE_STATUS_REDUCER_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    if (owner) {
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            float o = dt_traits<DT>::round(tot[m]);
+            if (e2->bias && !poisoned) o = o + dt_traits<DT>::load(e2->bias, n);
+            dt_traits<DT>::store(e2->y, (long)m * N + n, o);
+        }
+    }
+    // completion count of this entry (consumed by dependent entries of the same launch): y stores of this wave are made
+    // visible device-wide before the count moves
+    if (e2->done != nullptr) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(e2->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+int status_report(const char* fn);  // splitk.hip
+
+static int list_env(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+struct ListPlanEntry { int rpg, G, gpw, S, H, tiles; };
+
+struct MpqList {
+    int n = 0, M = 1, w_bit = 4, group_size = 128, zm = 0, dtype = BIE_BF16;
+    int rpg = 16;              // rows per unit (common to the list: one kernel instance)
+    unsigned grid = 0;
+    bool has_deps = false;
+    ListEntry* d_ent = nullptr;
+    uint2_t* d_blk = nullptr;
+    unsigned* d_done = nullptr;
+    size_t done_bytes = 0;
+};
+
+// The plan.  A wave takes `gpw` consecutive UNITS (a unit = RPG packed rows with one table: a whole quantisation group, or 1/H
+// of one when the list is too small to fill the chip); 8 waves per workgroup; a column tile's K range is split over S
+// workgroups.  Big lists: S = 1 (no cross-workgroup reduction at all), every wave walks several units with the next unit's
+// rows in flight.  Small lists: units are split (H) and K is sliced (S) until ~`want` waves exist.
+static void list_plan(int n, const bie_mpq_list_entry* ent, int w_bit, int group_size, int* rpg_out, std::vector<ListPlanEntry>& pe) {
+    static const int want = list_env("BIE_LIST_WANT_WAVES", 6144);
+    static const int force_h = list_env("BIE_LIST_H", 0);
+    static const int max_gpw = list_env("BIE_LIST_MAX_GPW", 16);
+    const int NB = 32 / w_bit;
+    long units = 0;  // at H = 1
+    int min_gs = group_size;
+    for (int i = 0; i < n; i++) {
+        const int gs = group_size > ent[i].K ? ent[i].K : group_size;
+        if (gs < min_gs) min_gs = gs;
+        units += (long)cdiv(ent[i].N, 64) * (ent[i].K / gs);
+    }
+    int rpg = min_gs / NB;  // every entry's group must be a whole number of units: validated by the caller (gs uniform or K < gs)
+    int H = 1;
+    if (force_h > 0) H = force_h;
+    else
+        while (H < 4 && rpg / (2 * H) >= 4 && units * H < want) H *= 2;
+    while (H > 1 && (rpg % H || rpg / H < 4)) H /= 2;
+    rpg /= H;
+    units *= H;
+    long gpw_global = units / want;
+    if (gpw_global < 1) gpw_global = 1;
+    if (gpw_global > max_gpw) gpw_global = max_gpw;
+    pe.resize(n);
+    for (int i = 0; i < n; i++) {
+        const int gs = group_size > ent[i].K ? ent[i].K : group_size;
+        ListPlanEntry& p = pe[i];
+        p.rpg = rpg;
+        p.H = (gs / NB) / rpg;          // units per group of THIS entry
+        p.G = (ent[i].K / gs) * p.H;
+        p.tiles = cdiv(ent[i].N, 64);
+        int gpw = (int)gpw_global;
+        const int per_wave_all = cdiv(p.G, 8);  // S = 1
+        if (gpw > per_wave_all) gpw = per_wave_all;
+        p.S = cdiv(p.G, gpw * 8);
+        p.gpw = cdiv(p.G, p.S * 8);     // even out
+        p.S = cdiv(p.G, p.gpw * 8);
+    }
+    *rpg_out = rpg;
+}
+
+static bool list_shape_ok(int n, const bie_mpq_list_entry* ent, int M, int w_bit, int group_size) {
+    if (n <= 0 || !ent || M < 1 || M > 2 || (w_bit != 4 && w_bit != 2)) return false;
+    const int NB = 32 / w_bit;
+    int gs0 = -1;
+    for (int i = 0; i < n; i++) {
+        if (ent[i].K <= 0 || ent[i].N <= 0) return false;
+        const int gs = group_size > ent[i].K ? ent[i].K : group_size;
+        if (w_bit == 4 && gs != 32 && gs != 64 && gs != 128 && gs != 256) return false;
+        if (w_bit == 2 && gs != 64 && gs != 128 && gs != 256) return false;
+        if (ent[i].K % gs) return false;
+        if (gs0 < 0) gs0 = gs;
+        if (gs != gs0) return false;  // one kernel instance per list
+        if ((long)ent[i].K * ent[i].N * w_bit / 8 > 0xfffffff0L) return false;  // 32-bit buffer offsets
+        if (cdiv(ent[i].N, 64) >= (1 << 20)) return false;
+        (void)NB;
+    }
+    return true;
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct ListLayout { size_t ent, blk, gen, done, gran, total; unsigned grid; long tiles; };
+
+static ListLayout list_layout(int n, const std::vector<ListPlanEntry>& pe, int M) {
+    ListLayout L;
+    long tiles = 0, blocks = 0;
+    size_t gran = 0;
+    for (int i = 0; i < n; i++) {
+        tiles += pe[i].tiles;
+        blocks += (long)pe[i].tiles * pe[i].S;
+        if (pe[i].S > 1) gran += (size_t)(pe[i].S - 1) * M * pe[i].tiles * 64 * 8;
+    }
+    L.tiles = tiles;
+    L.grid = (unsigned)blocks;
+    L.ent = 0;
+    L.blk = align_up((size_t)n * sizeof(ListEntry), 256);
+    L.gen = align_up(L.blk + (size_t)blocks * 8, 256);
+    L.done = align_up(L.gen + (size_t)tiles * 4, 256);
+    L.gran = align_up(L.done + (size_t)n * 4, 256);
+    L.total = L.gran + gran;
+    return L;
+}
+
+size_t mpq_list_device_bytes(int n, const bie_mpq_list_entry* ent, int M, int w_bit, int group_size) {
+    if (!list_shape_ok(n, ent, M, w_bit, group_size)) return 0;
+    std::vector<ListPlanEntry> pe;
+    int rpg;
+    list_plan(n, ent, w_bit, group_size, &rpg, pe);
+    return list_layout(n, pe, M).total;
+}
+
+int mpq_list_create(MpqList** out, int n, const bie_mpq_list_entry* ent, int M, int w_bit, int group_size, int asym, int dtype,
+                    void* device_mem, size_t device_bytes) {
+    BIE_REQUIRE(out && ent && device_mem, BIE_ERR_INVALID_ARG, "bie_mpq_list_create: NULL argument");
+    BIE_REQUIRE(dtype == BIE_F16 || dtype == BIE_BF16, BIE_ERR_UNSUPPORTED, "bie_mpq_list_create: dtype %d (fp16 / bf16 only)", dtype);
+    BIE_REQUIRE(list_shape_ok(n, ent, M, w_bit, group_size), BIE_ERR_UNSUPPORTED,
+                "bie_mpq_list_create: a list takes 1 <= M <= 2, w_bit 4 (groups of 32/64/128/256) or 2 (64/128/256), K a multiple of ONE common group size");
+    for (int i = 0; i < n; i++) {
+        BIE_REQUIRE(ent[i].x && ent[i].qweight && ent[i].scales && ent[i].zeros && ent[i].y, BIE_ERR_INVALID_ARG, "bie_mpq_list_create: NULL tensor pointer in entry %d", i);
+        BIE_REQUIRE(ent[i].depends_on < i, BIE_ERR_INVALID_ARG, "bie_mpq_list_create: entry %d depends on entry %d, which is not EARLIER in the list", i, ent[i].depends_on);
+        if (ent[i].depends_on >= 0) {
+            const bie_mpq_list_entry& d = ent[ent[i].depends_on];
+            BIE_REQUIRE(d.y == ent[i].x && d.N == ent[i].K, BIE_ERR_INVALID_ARG, "bie_mpq_list_create: entry %d depends on entry %d but does not read its y (x != y or K != N)", i, ent[i].depends_on);
+        }
+        if (asym) BIE_REQUIRE(ent[i].N % (32 / w_bit) == 0, BIE_ERR_INVALID_ARG, "bie_mpq_list_create: asym needs N %% %d == 0 (entry %d)", 32 / w_bit, i);
+        BIE_REQUIRE((reinterpret_cast<uintptr_t>(ent[i].x) & 3) == 0, BIE_ERR_INVALID_ARG, "bie_mpq_list_create: x of entry %d must be 4-byte aligned", i);
+    }
+    std::vector<ListPlanEntry> pe;
+    int rpg;
+    list_plan(n, ent, w_bit, group_size, &rpg, pe);
+    const ListLayout L = list_layout(n, pe, M);
+    BIE_REQUIRE(device_bytes >= L.total, BIE_ERR_WORKSPACE, "bie_mpq_list_create: device buffer of %zu bytes required, got %zu", L.total, device_bytes);
+    BIE_REQUIRE((reinterpret_cast<uintptr_t>(device_mem) & 255) == 0, BIE_ERR_INVALID_ARG, "bie_mpq_list_create: the device buffer must be 256-byte aligned");
+
+    char* base = static_cast<char*>(device_mem);
+    std::vector<ListEntry> he(n);
+    std::vector<uint2_t> hb(L.grid);
+    size_t gran_off = L.gran;
+    long tile0 = 0;
+    size_t b = 0;
+    bool has_deps = false;
+    const int esz = 2;
+    for (int i = 0; i < n; i++) {
+        ListEntry& e = he[i];
+        memset(&e, 0, sizeof(e));
+        const ListPlanEntry& p = pe[i];
+        const int gs = group_size > ent[i].K ? ent[i].K : group_size;
+        const long Gq = ent[i].K / gs;
+        e.qw = reinterpret_cast<const uint32_t*>(ent[i].qweight);
+        e.scales = reinterpret_cast<const uint16_t*>(ent[i].scales);
+        e.zeros = ent[i].zeros;
+        e.bias = reinterpret_cast<const uint16_t*>(ent[i].bias);
+        e.x = reinterpret_cast<const uint16_t*>(ent[i].x);
+        e.y = reinterpret_cast<uint16_t*>(ent[i].y);
+        e.gran = p.S > 1 ? reinterpret_cast<unsigned long long*>(base + gran_off) : nullptr;
+        if (p.S > 1) gran_off += (size_t)(p.S - 1) * M * p.tiles * 64 * 8;
+        e.gen = reinterpret_cast<unsigned*>(base + L.gen) + tile0;
+        e.done = nullptr;
+        e.dep_done = nullptr;
+        e.N = ent[i].N;
+        e.K = ent[i].K;
+        e.G = p.G;
+        e.gpw = p.gpw;
+        e.S = p.S;
+        e.hshift = p.H == 4 ? 2 : (p.H == 2 ? 1 : 0);
+        e.tiles = p.tiles;
+        e.qw_bytes = (unsigned)((long)ent[i].K * w_bit / 32 * ent[i].N * 4);
+        e.sc_bytes = (unsigned)(Gq * ent[i].N * esz);
+        e.ze_bytes = asym ? (unsigned)(Gq * (ent[i].N * w_bit / 32) * 4) : (unsigned)(Gq * ent[i].N * esz);
+        if (ent[i].depends_on >= 0) {
+            has_deps = true;
+            ListEntry& d = he[ent[i].depends_on];
+            d.done = reinterpret_cast<unsigned*>(base + L.done) + ent[i].depends_on;
+            e.dep_done = d.done;
+            e.dep_tiles = d.tiles;
+        }
+        for (int sl = 0; sl < p.S; sl++)      // slice-major inside an entry: a tile's reducer (last slice) comes after its publishers
+            for (int t = 0; t < p.tiles; t++) hb[b++] = uint2_t{(uint32_t)i, (uint32_t)t | ((uint32_t)sl << 20)};
+        BIE_REQUIRE(p.S < 4096, BIE_ERR_UNSUPPORTED, "bie_mpq_list_create: entry %d needs %d K slices (< 4096)", i, p.S);
+        tile0 += p.tiles;
+    }
+    hipError_t err = hipMemset(base + L.gen, 0, L.total - L.gen);  // generation words, counters, granule tags: zero once
+    if (err == hipSuccess) err = hipMemcpy(base + L.ent, he.data(), (size_t)n * sizeof(ListEntry), hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemcpy(base + L.blk, hb.data(), (size_t)L.grid * 8, hipMemcpyHostToDevice);
+    BIE_REQUIRE(err == hipSuccess, BIE_ERR_HIP, "bie_mpq_list_create: uploading the plan: %s", hipGetErrorString(err));
+
+    MpqList* pl = new MpqList();
+    pl->n = n; pl->M = M; pl->w_bit = w_bit; pl->group_size = group_size; pl->zm = asym ? ZM_ASYM : ZM_SYM; pl->dtype = dtype;
+    pl->rpg = rpg;
+    pl->grid = L.grid;
+    pl->has_deps = has_deps;
+    pl->d_ent = reinterpret_cast<ListEntry*>(base + L.ent);
+    pl->d_blk = reinterpret_cast<uint2_t*>(base + L.blk);
+    pl->d_done = reinterpret_cast<unsigned*>(base + L.done);
+    pl->done_bytes = (size_t)n * 4;
+    *out = pl;
+    return BIE_OK;
+}
+
+void mpq_list_destroy(MpqList* p) { delete p; }
+int mpq_list_launches(const MpqList* p) { return p ? (p->has_deps ? 2 : 1) : 0; }
+
+template <int DT, int ZM, int MT, int WB, int VAR>
+static void list_launch_rpg(const ListArgs& a, int rpg, unsigned grid, hipStream_t st) {
+    switch (rpg) {
+        case 4: hipLaunchKernelGGL((mpq_list_kernel<DT, ZM, MT, 4, WB, VAR>), dim3(grid), dim3(512), 0, st, a); break;
+        case 8: hipLaunchKernelGGL((mpq_list_kernel<DT, ZM, MT, 8, WB, VAR>), dim3(grid), dim3(512), 0, st, a); break;
+        case 16: hipLaunchKernelGGL((mpq_list_kernel<DT, ZM, MT, 16, WB, VAR>), dim3(grid), dim3(512), 0, st, a); break;
+        default:
+            if constexpr (WB == 4) hipLaunchKernelGGL((mpq_list_kernel<DT, ZM, MT, 32, WB, VAR>), dim3(grid), dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((mpq_list_kernel<DT, ZM, MT, 16, WB, VAR>), dim3(grid), dim3(512), 0, st, a);
+            break;
+    }
+}
+template <int DT, int WB, int VAR>
+static void list_launch_zm(const ListArgs& a, int rpg, unsigned grid, int M, int zm, hipStream_t st) {
+    if (M == 1) {
+        if (zm == ZM_ASYM) list_launch_rpg<DT, ZM_ASYM, 1, WB, VAR>(a, rpg, grid, st);
+        else list_launch_rpg<DT, ZM_SYM, 1, WB, VAR>(a, rpg, grid, st);
+    } else {
+        if (zm == ZM_ASYM) list_launch_rpg<DT, ZM_ASYM, 2, WB, VAR>(a, rpg, grid, st);
+        else list_launch_rpg<DT, ZM_SYM, 2, WB, VAR>(a, rpg, grid, st);
+    }
+}
+
+int mpq_list_forward(MpqList* p, hipStream_t st) {
+    BIE_REQUIRE(p, BIE_ERR_INVALID_ARG, "bie_mpq_list_forward: NULL plan");
+    int rc = status_report("bie_mpq_list_forward");
+    if (rc) return rc;
+    if (p->has_deps) {  // completion counters: zero before EVERY launch (a memset node, replayed with the graph)
+        const hipError_t e = hipMemsetAsync(p->d_done, 0, p->done_bytes, st);
+        BIE_REQUIRE(e == hipSuccess, BIE_ERR_HIP, "bie_mpq_list_forward: hipMemsetAsync: %s", hipGetErrorString(e));
+    }
+    ListArgs a;
+    a.ent = p->d_ent;
+    a.blk = p->d_blk;
+    a.status = device_status_word();
+    a.epoch = next_launch_epoch();
+    test_forge_get(&a.tag_skew, &a.spin_limit);
+    a.M = p->M;
+    static const int var = list_env("BIE_LIST_VAR", 1);  // tuning aid: 0 = scalar FMAs, 1 = v_pk_fma_f32 pairs, 2 / 3 = stream only
+    const bool lab_ok = p->dtype == BIE_BF16 && p->zm == ZM_SYM && p->M == 1 && p->rpg == 16 && p->w_bit == 4;
+    if (lab_ok && var != 1) {
+        if (var == 0) hipLaunchKernelGGL((mpq_list_kernel<BIE_BF16, ZM_SYM, 1, 16, 4, 0>), dim3(p->grid), dim3(512), 0, st, a);
+        else if (var == 5) hipLaunchKernelGGL((mpq_list_kernel<BIE_BF16, ZM_SYM, 1, 16, 4, 5>), dim3(p->grid), dim3(512), 0, st, a);
+        else if (var == 4) hipLaunchKernelGGL((mpq_list_kernel<BIE_BF16, ZM_SYM, 1, 16, 4, 4>), dim3(p->grid), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((mpq_list_kernel<BIE_BF16, ZM_SYM, 1, 16, 4, 3>), dim3(p->grid), dim3(512), 0, st, a);
+        return check_launch("mpq_list_kernel<lab>");
+    }
+    if (p->w_bit == 2) {
+        if (p->dtype == BIE_F16) list_launch_zm<BIE_F16, 2, 0>(a, p->rpg, p->grid, p->M, p->zm, st);
+        else list_launch_zm<BIE_BF16, 2, 0>(a, p->rpg, p->grid, p->M, p->zm, st);
+    } else {
+        if (p->dtype == BIE_F16) list_launch_zm<BIE_F16, 4, 0>(a, p->rpg, p->grid, p->M, p->zm, st);
+        else list_launch_zm<BIE_BF16, 4, 1>(a, p->rpg, p->grid, p->M, p->zm, st);
+    }
+    return check_launch("mpq_list_kernel");
+}
+
+}  // namespace bie

@@ -4,6 +4,7 @@
 #include "bie_common.h"
 #include <atomic>
 #include <string.h>
+#include <mutex>
 
 namespace bie {
 
@@ -53,6 +54,50 @@ unsigned next_launch_epoch() {
     unsigned e = (calls.fetch_add(1, std::memory_order_relaxed) + 1u) & 0xffffffu;
     if (e == 0) e = (calls.fetch_add(1, std::memory_order_relaxed) + 1u) & 0xffffffu;
     return e << 8;
+}
+
+// ---- device status page: 4 KiB of host-mapped memory the kernels can raise bits in (a reducer whose granules never arrive,
+// a dependent entry whose producer never finishes).  Read by the host without any synchronisation: the word is host memory.
+static std::atomic<unsigned*> g_status_host{nullptr};
+static unsigned* g_status_dev = nullptr;
+static std::atomic<unsigned> g_forge_skew{0};
+static std::atomic<int> g_forge_spin{0};
+
+int status_init() {
+    if (g_status_host.load(std::memory_order_acquire)) return BIE_OK;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (g_status_host.load(std::memory_order_acquire)) return BIE_OK;
+    void* h = nullptr;
+    hipError_t e = hipHostMalloc(&h, 4096, hipHostMallocMapped | hipHostMallocPortable);
+    if (e != hipSuccess) { set_error("bie_status_init: hipHostMalloc: %s", hipGetErrorString(e)); return BIE_ERR_HIP; }
+    memset(h, 0, 4096);
+    void* d = nullptr;
+    e = hipHostGetDevicePointer(&d, h, 0);
+    if (e != hipSuccess) { hipHostFree(h); set_error("bie_status_init: hipHostGetDevicePointer: %s", hipGetErrorString(e)); return BIE_ERR_HIP; }
+    g_status_dev = reinterpret_cast<unsigned*>(d);
+    g_status_host.store(reinterpret_cast<unsigned*>(h), std::memory_order_release);
+    return BIE_OK;
+}
+unsigned* device_status_word() { return g_status_host.load(std::memory_order_acquire) ? g_status_dev : nullptr; }
+unsigned status_read(bool clear) {
+    unsigned* h = g_status_host.load(std::memory_order_acquire);
+    if (!h) return 0;
+    return clear ? __atomic_exchange_n(h, 0u, __ATOMIC_ACQ_REL) : __atomic_load_n(h, __ATOMIC_ACQUIRE);
+}
+// called by every launching entry point of the reduction-carrying kernels: an earlier launch's fault is reported once
+int status_report(const char* fn) {
+    const unsigned s = status_read(true);
+    if (s == 0) return BIE_OK;
+    set_error("%s: an EARLIER launch raised device status 0x%x (%s%s): its outputs were poisoned with NaN; the status is now cleared", fn, s,
+              (s & 1u) ? "a split-K reducer timed out waiting for partial sums; " : "", (s & 2u) ? "a dependent list entry timed out waiting for its producer" : "");
+    return BIE_ERR_DEVICE;
+}
+void test_forge_set(unsigned tag_skew, int spin_limit) { g_forge_skew.store(tag_skew); g_forge_spin.store(spin_limit); }
+void test_forge_get(unsigned* tag_skew, int* spin_limit) {
+    *tag_skew = g_forge_skew.load(std::memory_order_relaxed);
+    const int s = g_forge_spin.load(std::memory_order_relaxed);
+    *spin_limit = s > 0 ? s : (1 << 22);
 }
 
 int launch_splitk_finalize(const float* part, const void* bias, void* y, int S, int M, int N, int dtype, hipStream_t st) {

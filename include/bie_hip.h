@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BIE_VERSION 200 /* 0.2.0 */
+#define BIE_VERSION 300 /* 0.3.0 */
 
 typedef enum { BIE_F16 = 0, BIE_BF16 = 1, BIE_F32 = 2 } bie_dtype;
 
@@ -41,12 +41,27 @@ typedef enum {
     BIE_ERR_INVALID_ARG = -1, /* NULL pointer, non-positive size, misaligned shape */
     BIE_ERR_UNSUPPORTED = -2, /* bit width / dtype / shape this build has no kernel for */
     BIE_ERR_WORKSPACE = -3,   /* scratch buffer smaller than bie_*_workspace_bytes() */
-    BIE_ERR_HIP = -4          /* a HIP runtime call failed (launch error) */
+    BIE_ERR_HIP = -4,         /* a HIP runtime call failed (launch error) */
+    BIE_ERR_DEVICE = -5       /* an EARLIER launch raised the device status page (see bie_device_status) */
 } bie_status;
 
 int bie_version(void);
 /* message of the last failing call made by THIS thread ("" if none) */
 const char* bie_last_error(void);
+
+/* Device status page.  The decode kernels reduce split-K partial sums INSIDE the launch (tagged granules, no atomics); a
+ * reducer whose partial sums do not arrive within its spin bound -- or a dependent list entry whose producer never finishes --
+ * stores NaN in y and raises a bit in a 4 KiB host-mapped page instead of returning a silently wrong number (the reference's
+ * half-precision atomicAdd split-K, mpq_linear_cuda_kernel.cu:440-450, cannot fail this way; an in-kernel hand-off can).
+ * bie_status_init allocates the page (host-mapped pinned memory; call it ONCE, outside stream capture; without it the kernels
+ * still poison y but cannot report).  bie_device_status returns the bits (1 = reducer timeout, 2 = dependency timeout) without
+ * any device synchronisation and clears them if `clear`; every launching bie_mpq_* / bie_mbwq_exl2_forward call checks the page
+ * first and fails with BIE_ERR_DEVICE (clearing it) if an earlier launch raised it. */
+int bie_status_init(void);
+unsigned bie_device_status(int clear);
+/* Testing aid: make the reducers of subsequent launches expect tag ^ tag_skew and give up after spin_limit polls
+ * (tag_skew = 0, spin_limit = 0 restores normal operation).  Forges a stale granule for the fail-loud tests. */
+void bie_test_forge_reducer(unsigned tag_skew, int spin_limit);
 
 /* ------------------------------------------------------------------------------------------ */
 /* MPQ (GPTQ-style) W{1,2,4,8}A16 linear                                                       */
@@ -89,6 +104,39 @@ int bie_mpq_forward_grouped(const void* x, int n_sets, const int32_t* const* qwe
                             const void* const* zeros, const void* const* bias, void* const* y, const int* N,
                             void* workspace, size_t workspace_bytes, int M, int K, int w_bit, int group_size,
                             int asym, int dtype, void* stream);
+
+/* A LIST of decode layers (M <= 2) in ONE launch.  Entry i computes y_i[M, N_i] = x_i[M, K_i] . dequant(qweight_i) (+ bias_i)
+ * exactly as bie_mpq_forward with g_idx = NULL would; entries may differ in K, N and in their x / y buffers, while w_bit (4 or
+ * 2), group_size, dtype (fp16 / bf16) and asym are common to the list.  `depends_on` >= 0 names an EARLIER entry whose y buffer
+ * is this entry's x (a chain y_l -> x_{l+1}): the dependent entry's workgroups request their weight rows first and then wait for
+ * the producer's completion count, so the weight stream of layer l+1 runs under the compute and reduction of layer l.
+ * No reference counterpart: the reference issues one default-stream quant_mm_kernel launch per layer
+ * (layers/qlinear/nbit/cuda/mpq_linear_cuda_kernel.cu:482-577, mpq_layer.py:65); an 8.9 MB layer is over before the chip is
+ * full, so the per-layer launch can never be bandwidth-bound.  This entry point is what makes decode HBM-bound on MI355X.
+ *   bie_mpq_list_device_bytes: size of the caller-allocated DEVICE buffer the plan lives in (descriptor table, block table,
+ *       generation words, completion counters, granules).
+ *   bie_mpq_list_create: validates, plans and uploads the tables (blocking copy; not capturable) and returns a host handle.
+ *       The tensor POINTERS are frozen in the plan; their contents may change between launches.
+ *   bie_mpq_list_forward: one kernel launch (+ one memset node when the list has dependencies); stream-ordered, capturable.
+ *   bie_mpq_list_destroy: frees the host handle (the device buffer is the caller's). */
+typedef struct bie_mpq_list bie_mpq_list_t;
+typedef struct {
+    const void* x;           /* [M, K] dtype */
+    const int32_t* qweight;  /* [K*w_bit/32, N] */
+    const void* scales;      /* [K/group_size, N] dtype */
+    const void* zeros;       /* [K/group_size, N] dtype, or int32 [K/group_size, N*w_bit/32] if asym */
+    const void* bias;        /* [N] dtype or NULL */
+    void* y;                 /* [M, N] dtype */
+    int K, N;
+    int depends_on;          /* index of an earlier entry whose y is this entry's x, or -1 */
+    int reserved;
+} bie_mpq_list_entry;
+size_t bie_mpq_list_device_bytes(int n_entries, const bie_mpq_list_entry* entries, int M, int w_bit, int group_size);
+int bie_mpq_list_create(bie_mpq_list_t** plan, int n_entries, const bie_mpq_list_entry* entries, int M, int w_bit,
+                        int group_size, int asym, int dtype, void* device_mem, size_t device_bytes);
+int bie_mpq_list_forward(bie_mpq_list_t* plan, void* stream);
+int bie_mpq_list_launches(const bie_mpq_list_t* plan); /* kernel launches one forward issues (1, or 1 + a memset node) */
+void bie_mpq_list_destroy(bie_mpq_list_t* plan);
 
 /* out[K, N] (dtype) = dequantised weight.  Bit-exact twin of unpack_qweight layer_type 1
  * (layers/qlinear/nbit/cuda/utils.py:30-51). */

@@ -27,7 +27,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"libbie_hip.so does not export {s}"
     assert sorted(_hip.SIGNATURES) == syms, "ctypes signature table out of sync with include/bie_hip.h"
-    assert lib.bie_version() == 200
+    assert lib.bie_version() == 300
 
 
 def test_argument_validation_happens_before_any_device_work():

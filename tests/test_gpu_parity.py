@@ -1259,3 +1259,137 @@ def test_q4_matmul_backward_and_q8_backward():
     assert np.array_equal(gw.cpu().numpy(), np.ascontiguousarray(gq.T).astype(np.int32) @ a.reshape(k, m).astype(np.int32).T)
     with pytest.raises(RuntimeError):
         qc.q8_backward(torch.from_numpy(gq).to(DEV), torch.from_numpy(a).float().to(DEV), torch.from_numpy(w).to(DEV))
+
+
+# ------------------------------------------------------------------------------------------------ one launch, many layers (bie_mpq_list_*)
+def _list_case(specs, dt, w_bit, gs, asym, M, seed, chain=False):
+    """specs: [(K, N, with_bias)].  Returns (entries on DEV, per-entry host tensors for the oracle)."""
+    entries, host = [], []
+    prev_y = None
+    for i, (K, N, with_bias) in enumerate(specs):
+        rng = np.random.default_rng(seed + 17 * i)
+        qw, scales, zeros, gen = rand_case(rng, K, N, w_bit, gs, dt, asym)
+        bias = (torch.randn(N, generator=gen) * 0.1).to(TDT[dt]) if with_bias else None
+        if chain and i > 0:
+            x_dev, x = prev_y, None
+        else:
+            x = torch.randn((M, K), generator=gen).to(TDT[dt])
+            x_dev = x.to(DEV)
+        y = torch.full((M, N), float("nan"), dtype=TDT[dt], device=DEV)
+        entries.append({"x": x_dev, "qweight": qw.to(DEV), "scales": scales.to(DEV), "zeros": zeros.to(DEV),
+                        "bias": None if bias is None else bias.to(DEV), "y": y, "depends_on": i - 1 if (chain and i > 0) else -1})
+        host.append((x, qw, scales, zeros, bias))
+        prev_y = y
+    return entries, host
+
+
+@pytest.mark.parametrize("dt,w_bit,gs,asym,M", [(orc.BF16, 4, 128, 0, 1), (orc.BF16, 4, 64, 1, 2), (orc.F16, 4, 128, 0, 1), (orc.F16, 4, 32, 1, 1),
+                                                  (orc.BF16, 2, 128, 0, 1), (orc.F16, 2, 64, 1, 2), (orc.BF16, 4, 256, 0, 2)])
+def test_list_forward_mixed_shapes_vs_oracle_and_single_calls(dt, w_bit, gs, asym, M):
+    """bie_mpq_list_forward: entries with different K / N (ragged column tiles, N % 64 = 8, 40), bias on some, each with its own x;
+    small list -> groups split over waves and K sliced over workgroups (tagged-granule reduction inside the launch).  Every entry
+    against the oracle; the table holds the reference's doubly rounded values, so only the fp32 summation order differs."""
+    from bitorch_engine.layers.qlinear.nbit.cuda import MPQForwardList
+    specs = [(1024, 200, True), (512, 520, False), (2048, 64, True), (768, 136, False), (1024, 1000, False)]
+    entries, host = _list_case(specs, dt, w_bit, gs, asym, M, seed=4000 + w_bit + gs + M)
+    plan = MPQForwardList(entries, w_bit=w_bit, group_size=gs, asym=bool(asym))
+    assert plan.launches == 1
+    plan()
+    torch.cuda.synchronize()
+    first = [e["y"].clone() for e in entries]
+    for i, (e, (x, qw, scales, zeros, bias)) in enumerate(zip(entries, host)):
+        ref = oracle_forward(x, qw, scales, zeros, None, w_bit, gs, asym, dt, bias)
+        assert_close(e["y"], ref, dt, f"list entry {i} {specs[i]} w{w_bit} g{gs} asym={asym} M={M}")
+    plan()  # same plan again: generation words advance, results identical
+    torch.cuda.synchronize()
+    for i, e in enumerate(entries):
+        assert torch.equal(e["y"], first[i]), f"entry {i}: a second launch of the plan differs"
+
+
+def test_list_forward_big_list_whole_k_per_workgroup_and_graph_replay():
+    """A list big enough that every workgroup owns a column tile's whole K range (S = 1, several units per wave, the next unit's rows
+    in flight): 48 layers of 4096 -> 1024 (W4 g128 bf16).  Captured in a HIP graph and replayed with NEW activations: the plan
+    freezes pointers, not contents."""
+    from bitorch_engine.layers.qlinear.nbit.cuda import MPQForwardList
+    specs = [(4096, 1024, i % 3 == 0) for i in range(48)]
+    entries, host = _list_case(specs, orc.BF16, 4, 128, 0, 1, seed=5100)
+    plan = MPQForwardList(entries, w_bit=4, group_size=128)
+    plan()
+    torch.cuda.synchronize()
+    for i in (0, 7, 23, 47):
+        x, qw, scales, zeros, bias = host[i]
+        assert_close(entries[i]["y"], oracle_forward(x, qw, scales, zeros, None, 4, 128, 0, orc.BF16, bias), orc.BF16, f"big list entry {i}")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        plan()
+    gen = torch.Generator().manual_seed(5)
+    for rep in range(3):
+        newx = [torch.randn((1, 4096), generator=gen).to(torch.bfloat16) for _ in entries]
+        for e, nx in zip(entries, newx):
+            e["x"].copy_(nx.to(DEV))
+        g.replay()
+        torch.cuda.synchronize()
+        for i in (3, 31):
+            _, qw, scales, zeros, bias = host[i]
+            assert_close(entries[i]["y"], oracle_forward(newx[i], qw, scales, zeros, None, 4, 128, 0, orc.BF16, bias), orc.BF16, f"replay {rep} entry {i}")
+
+
+@pytest.mark.parametrize("dt,M", [(orc.BF16, 1), (orc.F16, 2)])
+def test_list_forward_dependent_chain_equals_layer_by_layer(dt, M):
+    """y of entry l is x of entry l+1 (depends_on): one launch (+ the memset node of the completion counters) must give exactly
+    what layer-by-layer launches of the same kernels give, and match the oracle chain layer by layer (each layer checked on
+    the HIP input it actually saw, so the tolerance does not compound)."""
+    from bitorch_engine.layers.qlinear.nbit.cuda import MPQForwardList
+    specs = [(1024, 2048, True), (2048, 512, False), (512, 1024, True), (1024, 1024, False), (1024, 384, False)]
+    entries, host = _list_case(specs, dt, 4, 128, 0, M, seed=6200 + M, chain=True)
+    plan = MPQForwardList(entries, w_bit=4, group_size=128)
+    assert plan.launches == 2
+    for rep in range(3):  # several launches: the counters are re-armed every time
+        for e in entries:
+            e["y"].fill_(float("nan"))
+        plan()
+        torch.cuda.synchronize()
+        x = host[0][0]
+        for i, (e, (_, qw, scales, zeros, bias)) in enumerate(zip(entries, host)):
+            xin = x if i == 0 else entries[i - 1]["y"].cpu()
+            ref = oracle_forward(xin, qw, scales, zeros, None, 4, 128, 0, dt, bias)
+            assert_close(e["y"], ref, dt, f"chain rep {rep} layer {i}")
+            single = hip_forward(xin, qw, scales, zeros, None, 4, 128, 0, bias)
+            assert_close(e["y"], single, dt, f"chain rep {rep} layer {i} vs the single-layer launch")
+
+
+def test_reducer_timeout_fails_loudly():
+    """A reducer whose partial sums never arrive (forged: it is told to expect another tag) must not return a number: NaN in y,
+    a bit in the status page, and the NEXT launching call fails with BIE_ERR_DEVICE (then the page is clear again)."""
+    from bitorch_engine import _hip
+    from bitorch_engine.layers.qlinear.nbit.cuda import MPQForwardList
+    L = _hip.lib()
+    entries, host = _list_case([(2048, 256, False)], orc.BF16, 4, 128, 0, 1, seed=77)  # small: K sliced over workgroups
+    plan = MPQForwardList(entries, w_bit=4, group_size=128)
+    assert L.bie_device_status(1) == 0
+    L.bie_test_forge_reducer(0x5a, 2000)
+    try:
+        plan()
+        torch.cuda.synchronize()
+    finally:
+        L.bie_test_forge_reducer(0, 0)
+    assert torch.isnan(entries[0]["y"].float()).all(), "a timed-out reducer returned numbers"
+    assert L.bie_device_status(0) & 1
+    with pytest.raises(RuntimeError, match="device status"):
+        plan()
+    assert L.bie_device_status(0) == 0
+    plan()  # healthy again
+    torch.cuda.synchronize()
+    x, qw, scales, zeros, bias = host[0]
+    assert_close(entries[0]["y"], oracle_forward(x, qw, scales, zeros, None, 4, 128, 0, orc.BF16, bias), orc.BF16, "after the forged timeout")
+    # the single-layer lookup GEMV and the exl2 decode carry the same reducer: same behaviour
+    L.bie_test_forge_reducer(0x33, 2000)
+    try:
+        y = hip_forward(x, qw, scales, zeros, None, 4, 128, 0)
+        torch.cuda.synchronize()
+    finally:
+        L.bie_test_forge_reducer(0, 0)
+    assert torch.isnan(y.float()).all()
+    assert L.bie_device_status(1) & 1
