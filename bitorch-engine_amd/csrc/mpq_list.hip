@@ -276,17 +276,24 @@ __global__ __launch_bounds__(512, ((VAR & 4) ? 8 : 1)) void mpq_list_kernel(cons
 #pragma unroll
             for (int m = 0; m < MT; m++) asm volatile("" : "+v"(acc[m][0]), "+v"(acc[m][1]));
         };
+        // software pipeline, one row ahead: the eight reads of row u+1 are in flight while row u's FMAs issue.  hipcc's scheduler
+        // undoes the interleave (it sinks every lookup next to its FMAs: reads, s_waitcnt lgkmcnt(0), FMAs, row after row -- the
+        // LDS latency exposed sixteen times per unit), so the phases are fenced with sched_barrier
         float ta[8], tb[8];
         lookup(ta, 0);
 #pragma unroll
         for (int u = 0; u < RPG; u += 2) {
             if (u + 1 < RPG) lookup(tb, u + 1);
+            __builtin_amdgcn_sched_barrier(0);
             fmas(ta, u);
             pin();
+            __builtin_amdgcn_sched_barrier(0);
             if (u + 1 < RPG) {
                 if (u + 2 < RPG) lookup(ta, u + 2);
+                __builtin_amdgcn_sched_barrier(0);
                 fmas(tb, u + 1);
                 pin();
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
@@ -302,21 +309,26 @@ __global__ __launch_bounds__(512, ((VAR & 4) ? 8 : 1)) void mpq_list_kernel(cons
         load_group(wa, g0);
         if (g0 + 1 < g1) load_group(wb, g0 + 1);
     }
-    // ---- a dependent entry: the weight rows are in flight; now wait for the producer (x = its y)
+    // ---- a dependent entry: the weight rows are in flight; now wait for the producer (x = its y).  ONE lane polls the producer's
+    // tile count (relaxed, device scope, s_sleep between polls: 2048 polling waves would eat the weight stream's bandwidth), the
+    // barrier releases the other waves, and every wave invalidates the SCALAR cache: x is read through it only (never through the
+    // vector L1, so no agent-scope buffer_inv and its ~1.7 us are needed; the XCD L2s are kept coherent for device-local memory
+    // by the fabric's probes), and the buffer may have been cached there by an earlier workgroup of this launch.
     const unsigned* dep = e->dep_done;
     if (dep != nullptr) {
-        // the producer's counter counts finished tiles over ALL launches of this plan: a launch's target is a multiple of its tile
-        // count that the host keeps in the entry record (dep_target is rewritten before every launch? no: derived from gen)
-        const unsigned target = (unsigned)e->dep_tiles;
-        int spins = 0;
-        unsigned seen;
-        do {
-            seen = __hip_atomic_load(dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (seen >= target) break;
-            __builtin_amdgcn_s_sleep(4);
-        } while (++spins < a.spin_limit);
-        if (seen < target && a.status && threadIdx.x == 0) __hip_atomic_fetch_or(a.status, BIE_STATUS_DEP_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (threadIdx.x == 0) {
+            const unsigned target = (unsigned)e->dep_tiles;  // the counters are zeroed by a memset node before every launch
+            int spins = 0;
+            unsigned seen;
+            do {
+                seen = __hip_atomic_load(dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (seen >= target) break;
+                __builtin_amdgcn_s_sleep(8);
+            } while (++spins < a.spin_limit);
+            if (seen < target && a.status) __hip_atomic_fetch_or(a.status, BIE_STATUS_DEP_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __syncthreads();
+        asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     }
     for (int g = g0; g < g1; g += 2) {
         process_group(wa, g, sa, za);
@@ -397,20 +409,28 @@ __global__ __launch_bounds__(512, ((VAR & 4) ? 8 : 1)) void mpq_list_kernel(cons
             if (lane == 0 && a.status) __hip_atomic_fetch_or(a.status, BIE_STATUS_REDUCER_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
+    unsigned* done = e2->done;
     if (owner) {
 #pragma unroll
         for (int m = 0; m < MT; m++) {
             float o = dt_traits<DT>::round(tot[m]);
             if (e2->bias && !poisoned) o = o + dt_traits<DT>::load(e2->bias, n);
-            dt_traits<DT>::store(e2->y, (long)m * N + n, o);
+            const long yi = (long)m * N + n;
+            if (done == nullptr) {
+                dt_traits<DT>::store(e2->y, yi, o);
+            } else {  // a dependent entry of this launch reads y: write-through store (sc0 sc1), visible device-wide without a release fence
+                uint16_t bits;
+                if constexpr (DT == BIE_BF16) bits = (uint16_t)f32_to_bf16_bits(o); else bits = (uint16_t)f32_to_f16_bits(o);
+                uint16_t* yp = e2->y + yi;
+                asm volatile("global_store_short %0, %1, off sc0 sc1" ::"v"(yp), "v"((uint32_t)bits) : "memory");
+            }
         }
     }
-    // completion count of this entry (consumed by dependent entries of the same launch): y stores of this wave are made
-    // visible device-wide before the count moves
-    if (e2->done != nullptr) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    // completion count of this entry (consumed by dependent entries of the same launch): this wave's write-through stores have
+    // left the CU (vmcnt(0)) before the count moves -- no release fence, no L2 write-back sweep
+    if (done != nullptr) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(e2->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

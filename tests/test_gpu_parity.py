@@ -1291,6 +1291,8 @@ def test_list_forward_mixed_shapes_vs_oracle_and_single_calls(dt, w_bit, gs, asy
     against the oracle; the table holds the reference's doubly rounded values, so only the fp32 summation order differs."""
     from bitorch_engine.layers.qlinear.nbit.cuda import MPQForwardList
     specs = [(1024, 200, True), (512, 520, False), (2048, 64, True), (768, 136, False), (1024, 1000, False)]
+    if asym:  # packed qzeros: N must be a multiple of 32 / w_bit
+        specs = [(K, (N + 15) // 16 * 16, b) for (K, N, b) in specs]
     entries, host = _list_case(specs, dt, w_bit, gs, asym, M, seed=4000 + w_bit + gs + M)
     plan = MPQForwardList(entries, w_bit=w_bit, group_size=gs, asym=bool(asym))
     assert plan.launches == 1
@@ -1346,12 +1348,14 @@ def test_list_forward_dependent_chain_equals_layer_by_layer(dt, M):
     entries, host = _list_case(specs, dt, 4, 128, 0, M, seed=6200 + M, chain=True)
     plan = MPQForwardList(entries, w_bit=4, group_size=128)
     assert plan.launches == 2
-    for rep in range(3):  # several launches: the counters are re-armed every time
+    gen = torch.Generator().manual_seed(9)
+    for rep in range(3):  # several launches: the counters are re-armed every time; NEW input every time (stale activations would show)
         for e in entries:
             e["y"].fill_(float("nan"))
+        x = torch.randn(host[0][0].shape, generator=gen).to(TDT[dt])
+        entries[0]["x"].copy_(x.to(DEV))
         plan()
         torch.cuda.synchronize()
-        x = host[0][0]
         for i, (e, (_, qw, scales, zeros, bias)) in enumerate(zip(entries, host)):
             xin = x if i == 0 else entries[i - 1]["y"].cpu()
             ref = oracle_forward(xin, qw, scales, zeros, None, 4, 128, 0, dt, bias)

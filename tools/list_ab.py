@@ -32,6 +32,12 @@ def list_case(k, n, nl, per_launch, chain=0, reps=20, seed=1):
             x = entries[-1]["y"] if dep >= 0 else torch.randn((1, k), generator=gen, device=dev).to(BF16)
             entries.append({"x": x, "qweight": qw, "scales": sc, "zeros": ze, "y": torch.empty((1, n), dtype=BF16, device=dev), "depends_on": dep})
         plans.append(MPQForwardList(entries, w_bit=4, group_size=GROUP))
+    if os.environ.get("LIST_AB_NOGRAPH"):  # PMC passes: every launch a dispatch row of its own
+        for _ in range(3):
+            for p in plans:
+                p.forward()
+        torch.cuda.synchronize()
+        return {"K": k, "N": n, "layers": nl, "per_launch": per_launch, "nograph": True}
     g = capture(lambda st: [p.forward(st) for p in plans])
     us = time_graph(g, reps) / nl
     b = alg_bytes(1, k, n)
