@@ -54,6 +54,7 @@ SIGNATURES = {
     "bie_binary_unpack_btc32": (_i, [_vp, _vp, _l, _l, _vp]),
     "bie_binary_unpack_bstc32": (_i, [_vp, _vp, _l, _l, _vp]),
     "bie_binary_linear_forward": (_i, [_vp, _vp, _vp, _l, _l, _l, _i, _f, _vp]),
+    "bie_binary_matmul_batched": (_i, [_vp, _vp, _vp] + [_l] * 7 + [_f, _vp]),
     "bie_binary_linear_fused_ok": (_i, [_l] * 3),
     "bie_binary_linear_fused": (_i, [_vp] * 6 + [_l] * 3 + [_i, _i, _vp]),
     "bie_binary_conv2d_workspace_bytes": (_sz, [_i] * 9),

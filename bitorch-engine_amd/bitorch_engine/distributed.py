@@ -94,8 +94,16 @@ class ColumnShardedMPQLinear(torch.nn.Module):
         x2 = x.reshape(-1, x.shape[-1])
         M = x2.shape[0]
         widths = [hi - lo for lo, hi in self.ranges]
-        if len(set(widths)) != 1 or M <= m_tile:
+        if len(set(widths)) != 1:
+            if not interleave:
+                raise RuntimeError("forward_overlapped(interleave=False): the rank-major [W, M, N/W] layout needs equal shard widths, got "
+                                   f"{widths}")
             return self.forward(x)
+        if M <= m_tile:  # one tile: nothing to overlap; still honour the requested layout
+            y = self.forward(x)
+            if interleave:
+                return y
+            return y.reshape(M, self.world, widths[0]).permute(1, 0, 2).contiguous()
         wdt = widths[0]
         on_gpu = x2.is_cuda
         tiles = [(m0, min(m0 + m_tile, M)) for m0 in range(0, M, m_tile)]

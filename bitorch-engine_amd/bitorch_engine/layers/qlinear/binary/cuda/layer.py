@@ -50,8 +50,10 @@ class BinaryLinearCuda(BinaryLinearBase):
     def forward(self, x: torch.Tensor, bmm_type: BMM = BMM.ADAPTIVE) -> torch.Tensor:
         self._check_forward(x)
         self.bmm_type = bmm_type
-        if not (torch.is_grad_enabled() and (x.requires_grad or self.scale_a.requires_grad and self.training)):
-            # inference, M <= 64: the whole layer (activation bias + sign-pack, XNOR-popcount, cast, both scales) in ONE launch
+        if not torch.is_grad_enabled() or not (x.requires_grad or self.bias_a.requires_grad or self.scale_a.requires_grad):
+            # no gradient can flow (the fused output is detached from bias_a / scale_a: fine-tuning those under model.eval() must
+            # take the differentiable composition below).  M <= 64: the whole layer (activation bias + sign-pack, XNOR-popcount,
+            # cast, both scales) in ONE launch
             self._init_scale_a(x)
             x2, lead = flatten_x(x)
             out = binary_linear_cuda.layer_forward(x2, self.bias_a.data, self.opt_weight, self.bmm_type.value,

@@ -576,6 +576,30 @@ int binary_linear_launch(const uint8_t* xp, const uint8_t* wp, float* y, long M,
     return check_launch("xnor_gemm_kernel");
 }
 
+// batch of independent XNOR GEMMs (BinaryMatMul: heads x batch): ONE launch, the batch index is blockIdx.z of the tiled kernel
+int binary_matmul_batched_launch(const uint8_t* xp, const uint8_t* wp, float* y, long batch, long M, long N, long K, long stride_x,
+                                 long stride_w, long stride_y, float scale, hipStream_t st) {
+    const bool words_ok = (K % 32 == 0) && (((uintptr_t)xp | (uintptr_t)wp) & 3) == 0 && (stride_x % 4 == 0) && (stride_w % 4 == 0) && batch <= 65535;
+    if (!words_ok || batch == 1) {
+        for (long b = 0; b < batch; b++) {
+            const int rc = binary_linear_launch(xp + b * stride_x, wp + b * stride_w, y + b * stride_y, M, N, K, 0, scale, st);
+            if (rc) return rc;
+        }
+        return BIE_OK;
+    }
+    const int KW = (int)(K / 32);
+    if (cdivl(N, XT) * cdivl(M, XT) * batch < 192) {
+        dim3 grid((unsigned)cdivl(N, XT), (unsigned)cdivl(M, 16), (unsigned)batch);
+        hipLaunchKernelGGL(xnor_gemm_kernel<1>, grid, dim3(256), 0, st, (const uint32_t*)xp, (const uint32_t*)wp, y, (int)M, (int)N, KW, (int)K,
+                           scale, stride_x / 4, stride_w / 4, stride_y);
+    } else {
+        dim3 grid((unsigned)cdivl(N, XT), (unsigned)cdivl(M, XT), (unsigned)batch);
+        hipLaunchKernelGGL(xnor_gemm_kernel<4>, grid, dim3(256), 0, st, (const uint32_t*)xp, (const uint32_t*)wp, y, (int)M, (int)N, KW, (int)K,
+                           scale, stride_x / 4, stride_w / 4, stride_y);
+    }
+    return check_launch("xnor_gemm_kernel<batched>");
+}
+
 // 1 <= M <= 64 (beyond that packing x once and running the tiled XNOR GEMM is the better split), K % 32 == 0
 bool binary_linear_fused_ok(long M, long N, long K) {
     // the packed x rows of one workgroup (4 or 8 rows of K/32 + 1 words) live in LDS: 64 KiB

@@ -74,6 +74,8 @@ int binary_conv_taps_launch(const void* x, const uint32_t* wtaps, float* y, void
                             int stride, int pad, int dil, float scale, int dtype, hipStream_t st);
 int binary_linear_launch(const uint8_t* xp, const uint8_t* wp, float* y, long M, long N, long K, int w_layout, float scale,
                          hipStream_t st);
+int binary_matmul_batched_launch(const uint8_t* xp, const uint8_t* wp, float* y, long batch, long M, long N, long K, long stride_x,
+                                 long stride_w, long stride_y, float scale, hipStream_t st);
 size_t binary_conv_workspace_bytes(int B, int C, int H, int W, int OC, int ks, int stride, int pad, int dil);
 int binary_conv_launch(const void* x, const uint8_t* wpacked, float* y, void* ws, int B, int C, int H, int W, int OC, int ks,
                        int stride, int pad, int dil, float scale, int dtype, hipStream_t st);
@@ -420,6 +422,14 @@ int bie_binary_linear_forward(const uint8_t* xpacked, const uint8_t* wpacked, fl
     BIE_REQUIRE(xpacked && wpacked && y && M > 0 && N > 0 && K > 0 && K % 8 == 0, BIE_ERR_INVALID_ARG, "bie_binary_linear_forward: M=%ld N=%ld K=%ld (K %% 8 == 0 required)", M, N, K);
     BIE_REQUIRE(w_layout == 0 || w_layout == 1, BIE_ERR_INVALID_ARG, "bie_binary_linear_forward: w_layout %d", w_layout);
     return binary_linear_launch(xpacked, wpacked, y, M, N, K, w_layout, scale, as_stream(stream));
+}
+
+int bie_binary_matmul_batched(const uint8_t* xpacked, const uint8_t* wpacked, float* y, long batch, long M, long N, long K, long stride_x,
+                              long stride_w, long stride_y, float scale, void* stream) {
+    BIE_REQUIRE(xpacked && wpacked && y && batch > 0 && M > 0 && N > 0 && K > 0 && K % 8 == 0, BIE_ERR_INVALID_ARG,
+                "bie_binary_matmul_batched: batch=%ld M=%ld N=%ld K=%ld (K %% 8 == 0 required)", batch, M, N, K);
+    BIE_REQUIRE(stride_x >= M * (K / 8) && stride_w >= N * (K / 8) && stride_y >= M * N, BIE_ERR_INVALID_ARG, "bie_binary_matmul_batched: strides smaller than one matrix");
+    return binary_matmul_batched_launch(xpacked, wpacked, y, batch, M, N, K, stride_x, stride_w, stride_y, scale, as_stream(stream));
 }
 
 int bie_binary_linear_fused_ok(long M, long N, long K) { return binary_linear_fused_ok(M, N, K) ? 1 : 0; }

@@ -601,328 +601,6 @@ __global__ __launch_bounds__(256, (BM <= 128 ? 2 : 1)) void mpq_gemm_kernel(cons
 #endif
 }
 
-// =====================================================================================================================
-// W4 with the dequantisation by TABLE LOOKUP (the decode kernels' idea, mpq_gemv_lut.hip, carried into the MFMA GEMM).
-// The arithmetic dequant above costs ~48 VALU per 16 weights of a lane (bf16: no packed bf16 ALU), i.e. 6 VALU per MFMA at
-// BM = 256 -- more than the ~5 issue slots a 32-cycle MFMA shadow offers a lone wave (MI355X_MICROARCH.md), so the matrix pipe
-// sat at 57 % (profiles/r01_j_pmc_gemm.txt).  Inside one (group, column) a 4-bit weight takes 16 values: the lanes (h, j) of a
-// wave park them in a wave-private LDS table [fragment][q][256 B row, slot j] as (T | T << 16) and every weight then costs one
-// v_perm_b32 (address), one conflict-free ds_read_b32 and half a v_perm_b32 (two looked-up halves -> one operand dword):
-// 30 VALU + 16 LDS reads per k16 step instead of 96 VALU, ~2 VALU per MFMA, plus the table build (lane (h, j) computes
-// entries 8h .. 8h+7 of its column once per group: 64 VALU per 128 k).  The table holds the reference's doubly rounded
-// values, so the operands -- and the results -- are bit-identical to the arithmetic path.
-// LDS: [0, 32 KiB) tables (wave w at w * 8 KiB: byte 1 of the lookup address = w << 5 | f << 4 | q), then the x tiles.
-// =====================================================================================================================
-constexpr int GEMM_TAB_BYTES = 32768;
-
-template <int DT, int ZM, int BM>
-__global__ __launch_bounds__(256, (BM <= 128 ? 2 : 1)) void mpq_gemm_lut_kernel(const uint16_t* __restrict__ x, const uint32_t* __restrict__ qw,
-                                                          const uint16_t* __restrict__ scales, const void* __restrict__ zeros,
-                                                          const uint16_t* __restrict__ bias, float* __restrict__ part,
-                                                          uint16_t* __restrict__ y, int M, int K, int N, int gshift, int tiles_per_split,
-                                                          int S, int m_tiles, int n_tiles) {
-    constexpr int WBIT = 4;
-    constexpr int TM = BM / 32;
-    constexpr int NF = GEMM_NF;
-    constexpr int A_BYTES = BM * GEMM_BK * 2;
-    constexpr int A_PIECES = BM / 32;
-    constexpr int VALU_PER_MFMA = (30 + TM * NF - 1) / (TM * NF);
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = lane >> 5, j = lane & 31;
-    int m_tile, n_tile;
-    {
-        const int T = m_tiles * n_tiles;
-        const int b = blockIdx.x;
-        const int xcd = b & 7, i = b >> 3;
-        const int q = T >> 3, r = T & 7;
-        const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-        const int t = start + i;
-        m_tile = t / n_tiles;
-        n_tile = t - m_tile * n_tiles;
-    }
-    const int m0 = m_tile * BM;
-    int ncol[NF], ncol_ld[NF];
-#pragma unroll
-    for (int f = 0; f < NF; f++) {
-        ncol[f] = n_tile * GEMM_BN + wave * (32 * NF) + f * 32 + j;
-        ncol_ld[f] = ncol[f] < N ? ncol[f] : N - 1;
-    }
-    WPtrs<WBIT> wp;
-    {
-        constexpr int NB = 8;
-        const uint64_t qb = (uint64_t)(uintptr_t)qw;
-        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)qb), hi = __builtin_amdgcn_readfirstlane((uint32_t)(qb >> 32));
-        wp.wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((uint64_t)hi << 32) | lo), 0,
-                                                     __builtin_amdgcn_readfirstlane((uint32_t)((long)(K / NB) * N * 4)), 0x00020000);
-        wp.row_bytes = __builtin_amdgcn_readfirstlane((uint32_t)N * 4u);
-#pragma unroll
-        for (int f = 0; f < NF; f++) {
-            const int n = ncol_ld[f];
-            wp.wvoff[f] = (uint32_t)(h * N + n) * 4u;
-            wp.w[f] = qw + (long)h * N + n;
-            wp.s[f] = scales + n;
-            wp.z[f] = reinterpret_cast<const uint16_t*>(zeros) + n;
-            wp.zq[f] = reinterpret_cast<const uint32_t*>(zeros) + n / NB;
-            wp.zshift[f] = (n % NB) * WBIT;
-        }
-    }
-    const int split = blockIdx.y;
-    const int T_total = K / GEMM_BK;
-    const int t_begin = split * tiles_per_split;
-    int t_end = t_begin + tiles_per_split;
-    if (t_end > T_total) t_end = T_total;
-
-    float16_t acc[NF][TM];
-#pragma unroll
-    for (int f = 0; f < NF; f++)
-#pragma unroll
-        for (int t = 0; t < TM; t++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[f][t][e] = 0.0f;
-
-    // x tile: global -> LDS by DMA, XOR swizzle on the source side (as in mpq_gemm_kernel)
-    const uint16_t* asrc[A_PIECES];
-#pragma unroll
-    for (int i = 0; i < A_PIECES; i++) {
-        const int piece = wave * A_PIECES + i;
-        const int rp = piece * 4 + (lane >> 4), slot16 = lane & 15;
-        const int row = 2 * rp + (slot16 >> 3), sl = (slot16 & 7) ^ (rp & 7);
-        int m = m0 + row;
-        if (m > M - 1) m = M - 1;
-        asrc[i] = x + (long)m * K + sl * 8;
-    }
-    auto glds_a = [&](int kt, int buf, int part) {
-        auto* dst = (__attribute__((address_space(3))) unsigned char*)lds + GEMM_TAB_BYTES + buf * A_BYTES + wave * (A_PIECES * 1024);
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-        for (int i = 0; i < A_PIECES; i++)
-            if (part < 0 || (i * 2) / A_PIECES == part) __builtin_amdgcn_global_load_lds(asrc[i] + kt * GEMM_BK, dst + i * 1024, 16, 0, 0);
-#else
-        (void)dst;
-#endif
-    };
-    const uint32_t lds_base = (uint32_t)(uintptr_t)lds + GEMM_TAB_BYTES;
-    uint32_t foff[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; kk++) foff[kk] = lds_base + (uint32_t)a_lds_off(j, kk * 2 + h);
-
-    // ---- the wave's lookup table: byte address ((wave << 5 | f << 4 | q) << 8) | (j << 2)
-    const uint32_t lane_addr = (uint32_t)j * 4u;
-    const uint32_t wavepat = (uint32_t)wave * 0x20202020u;
-    uint32_t m0f;
-    asm("v_mov_b32 %0, 0x0f0f0f0f" : "=v"(m0f));
-    auto build_table = [&](const WTile<DT, WBIT, ZM, true>& w) {
-#pragma unroll
-        for (int f = 0; f < NF; f++) {
-            uint32_t zb = w.zb[f][0];
-            if constexpr (ZM == ZM_ASYM) zb = ((zb >> wp.zshift[f]) & 15u) + 1u;
-            lds_u32_t* row0 = (lds_u32_t*)(uintptr_t)(((uint32_t)(wave * 32 + f * 16 + 8 * h) << 8) + lane_addr);
-            if constexpr (DT == BIE_BF16 && ZM == ZM_SYM) {
-                const float s = bf16_bits_to_f32(w.sb[f][0]), nz = -bf16_bits_to_f32(zb);
-                const uint32_t sel0 = sel_lo_hi<0>(), sel1 = sel_lo_hi<1>();
-                const float qb = (float)(8 * h);
-#pragma unroll
-                for (int i4 = 0; i4 < 2; i4++) {
-                    const uint32_t A0 = pack_bf16x2((qb + (float)(4 * i4)) * s, (qb + (float)(4 * i4 + 1)) * s);
-                    const uint32_t A1 = pack_bf16x2((qb + (float)(4 * i4 + 2)) * s, (qb + (float)(4 * i4 + 3)) * s);
-                    float d[4];
-                    bf16_pairs_sub(A0, A1, sel0, sel1, nz, d);
-                    const uint32_t T0 = pack_bf16x2(d[0], d[1]), T1 = pack_bf16x2(d[2], d[3]);
-                    row0[(4 * i4 + 0) * 64] = __builtin_amdgcn_perm(T0, T0, 0x01000100u);
-                    row0[(4 * i4 + 1) * 64] = __builtin_amdgcn_perm(T0, T0, 0x03020302u);
-                    row0[(4 * i4 + 2) * 64] = __builtin_amdgcn_perm(T1, T1, 0x01000100u);
-                    row0[(4 * i4 + 3) * 64] = __builtin_amdgcn_perm(T1, T1, 0x03020302u);
-                }
-            } else {
-                float s, z = 0.0f;
-                int zq1 = 0;
-                if constexpr (DT == BIE_BF16) s = bf16_bits_to_f32(w.sb[f][0]); else s = f16_bits_to_f32(w.sb[f][0]);
-                if constexpr (ZM == ZM_ASYM) zq1 = (int)zb;
-                else if constexpr (DT == BIE_BF16) z = bf16_bits_to_f32(zb); else z = f16_bits_to_f32(zb);
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const uint32_t q = (uint32_t)(8 * h + i);
-                    float t;
-                    if constexpr (ZM == ZM_ASYM) t = dequant_scalar_asym<DT>(q, s, zq1);
-                    else if constexpr (ZM == ZM_FUSED) t = dt_traits<DT>::round(__builtin_fmaf((float)q, s, -z));
-                    else t = dequant_scalar_sym<DT>(q, s, z);
-                    uint32_t bits;
-                    if constexpr (DT == BIE_BF16) bits = __float_as_uint(t) >> 16; else bits = f32_to_f16_bits(t);
-                    row0[i * 64] = bits | (bits << 16);
-                }
-            }
-        }
-    };
-    // eight lookups of one packed word -> the four operand dwords (k order 0..7: even nibbles sit in `we`, odd ones in `wo`).
-    // A step's sixteen reads are issued under the first twelve MFMAs of the PREVIOUS step's group, its eight pairing v_perm_b32
-    // under the last four -- in a scheduling region of their own (sched_barrier), or hipcc hoists a pack right behind its read and
-    // the in-order wave waits a full LDS round trip beside one queued MFMA
-    auto lookup_issue = [&](const WTile<DT, WBIT, ZM, true>& w, int kk, uint32_t (&v)[NF][8]) {
-#pragma unroll
-        for (int f = 0; f < NF; f++) {
-            const uint32_t raw = w.raw[f][kk];
-            const uint32_t pat = wavepat | (f ? 0x10101010u : 0u);
-            // plain C (not asm): the scheduler must be able to classify these as VALU for the sched_group_barrier pattern
-            const uint32_t we = (raw & m0f) | pat, wo = ((raw >> 4) & m0f) | pat;
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const uint32_t sel = 0x0c0c0400u + ((uint32_t)b << 8);
-                v[f][2 * b] = *(const lds_u32_t*)(uintptr_t)__builtin_amdgcn_perm(we, lane_addr, sel);
-                v[f][2 * b + 1] = *(const lds_u32_t*)(uintptr_t)__builtin_amdgcn_perm(wo, lane_addr, sel);
-            }
-        }
-    };
-    auto lookup_pack = [&](const uint32_t (&v)[NF][8], uint4_t (&bf)[NF]) {
-#pragma unroll
-        for (int f = 0; f < NF; f++) {
-            uint32_t o[4];
-#pragma unroll
-            for (int b = 0; b < 4; b++) o[b] = __builtin_amdgcn_perm(v[f][2 * b + 1], v[f][2 * b], 0x07060100u);
-            bf[f] = uint4_t{o[0], o[1], o[2], o[3]};
-        }
-    };
-    constexpr int NM = TM * NF, NM_HEAD = NM - NM / 4;
-    auto mfma_head = [&](const uint4_t (&af)[TM], const uint4_t (&bf)[NF]) {
-#pragma unroll
-        for (int i = 0; i < NM_HEAD; i++) acc[i % NF][i / NF] = mfma32<DT>(bf[i % NF], af[i / NF], acc[i % NF][i / NF]);
-#pragma unroll
-        for (int i = 0; i < NM_HEAD; i++) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // address VALU of the next step (22 in all)
-            if (i < 8) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // its lookups
-        }
-    };
-    auto mfma_tail = [&](const uint4_t (&af)[TM], const uint4_t (&bf)[NF]) {
-#pragma unroll
-        for (int i = NM_HEAD; i < NM; i++) acc[i % NF][i / NF] = mfma32<DT>(bf[i % NF], af[i / NF], acc[i % NF][i / NF]);
-#pragma unroll
-        for (int i = NM_HEAD; i < NM; i++) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, (8 + NM / 4 - 1) / (NM / 4), 0);  // pairing VALU
-        }
-    };
-    auto new_group = [&](int t) { return ((t * GEMM_BK) & ((1 << gshift) - 1)) == 0; };  // gshift 31: only t = 0
-
-    WTile<DT, WBIT, ZM, true> wcur, wnext;
-    const int t_last = t_end - 1;
-    int cur = 0;
-    uint4_t af0[TM], af1[TM];
-    uint4_t bfrag[NF], bnext[NF];
-    uint32_t lv[NF][8];
-    if (t_begin < t_end) {
-        glds_a(t_begin, 0, -1);
-        // a split may start inside a group: the group's constants are those of its first row
-        load_wtile<DT, WBIT, ZM, true>(wcur, wp, t_begin * GEMM_BK, N, gshift);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        lds_issue_frags<TM>(af0, foff[0]);
-        build_table(wcur);
-        lookup_issue(wcur, 0, lv);
-        lookup_pack(lv, bfrag);
-        lds_wait_frags<TM>(af0);
-    }
-#if BIE_GEMM_LAB == 7
-    unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
-    unsigned stamp_sum[6] = {0, 0, 0, 0, 0, 0};
-#endif
-    for (int kt = t_begin; kt < t_end; kt++) {
-        const int ktn = (kt + 1 < t_end) ? kt + 1 : t_last;
-        const uint32_t abase = (uint32_t)(cur * A_BYTES), abase_n = (uint32_t)((cur ^ 1) * A_BYTES);
-#pragma unroll
-        for (int kk = 0; kk < 3; kk++) {
-            if (kk & 1) lds_issue_frags<TM>(af0, foff[kk + 1] + abase);
-            else lds_issue_frags<TM>(af1, foff[kk + 1] + abase);
-            glds_a(ktn, cur ^ 1, kk);
-            if (kk == 0) load_wtile<DT, WBIT, ZM, true>(wnext, wp, ktn * GEMM_BK, N, gshift);
-            __builtin_amdgcn_sched_barrier(0);
-            lookup_issue(wcur, kk + 1, lv);
-            if (kk & 1) mfma_head(af1, bfrag);
-            else mfma_head(af0, bfrag);
-            __builtin_amdgcn_sched_barrier(0);
-            lookup_pack(lv, bnext);
-            if (kk & 1) mfma_tail(af1, bfrag);
-            else mfma_tail(af0, bfrag);
-            if (kk & 1) lds_wait_frags<TM>(af0);
-            else lds_wait_frags<TM>(af1);
-#pragma unroll
-            for (int f = 0; f < NF; f++) bfrag[f] = bnext[f];
-            BIE_STAMP(kk)
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA pieces (and the next tile's words) have landed
-        BIE_STAMP(3)
-        __syncthreads();
-        BIE_STAMP(4)
-        lds_issue_frags<TM>(af0, foff[0] + abase_n);
-        __builtin_amdgcn_sched_barrier(0);
-        // every lookup of the current table has been issued AND collected (bfrag holds the last step's operands): a new group's
-        // table may overwrite it now.  LDS operations of one wave execute in order, so the lookups below see the new entries.
-        if (kt + 1 < t_end && new_group(ktn)) build_table(wnext);
-        lookup_issue(wnext, 0, lv);
-        mfma_head(af1, bfrag);
-        __builtin_amdgcn_sched_barrier(0);
-        lookup_pack(lv, bnext);
-        mfma_tail(af1, bfrag);
-        lds_wait_frags<TM>(af0);
-#pragma unroll
-        for (int f = 0; f < NF; f++) bfrag[f] = bnext[f];
-        wcur = wnext;
-        cur ^= 1;
-        BIE_STAMP(5)
-    }
-
-    // ---- epilogue (as mpq_gemm_kernel: D = W_frag x x_frag, a lane owns one row m and groups of 4 consecutive columns)
-#if BIE_GEMM_LAB == 7
-    if (acc[0][0][0] == 123.456f)
-#endif
-#pragma unroll
-    for (int f = 0; f < NF; f++) {
-        const int nf0 = n_tile * GEMM_BN + wave * (32 * NF) + f * 32;
-        const bool use_bias = (S == 1) && (bias != nullptr);
-#pragma unroll
-        for (int t = 0; t < TM; t++) {
-            const int row = m0 + t * 32 + j;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int n0 = nf0 + 8 * q + 4 * h;
-                if (row < M && n0 < N) {
-                    if (S == 1) {
-                        float o[4];
-#pragma unroll
-                        for (int c = 0; c < 4; c++) {
-                            o[c] = dt_traits<DT>::round(acc[f][t][4 * q + c]);
-                            if (use_bias) o[c] = o[c] + dt_traits<DT>::load(bias, n0 + c);
-                        }
-                        uint2_t pk;
-                        if constexpr (DT == BIE_F16) {
-                            pk.x = f32_to_f16_bits(o[0]) | (f32_to_f16_bits(o[1]) << 16);
-                            pk.y = f32_to_f16_bits(o[2]) | (f32_to_f16_bits(o[3]) << 16);
-                        } else {
-                            pk.x = pack_bf16x2(o[0], o[1]);
-                            pk.y = pack_bf16x2(o[2], o[3]);
-                        }
-                        *reinterpret_cast<uint2_t*>(y + (long)row * N + n0) = pk;
-                    } else {
-                        float4_t v = {acc[f][t][4 * q], acc[f][t][4 * q + 1], acc[f][t][4 * q + 2], acc[f][t][4 * q + 3]};
-                        *reinterpret_cast<float4_t*>(part + ((long)split * M + row) * N + n0) = v;
-                    }
-                }
-            }
-        }
-    }
-#if BIE_GEMM_LAB == 7
-    __syncthreads();
-    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) {
-        uint32_t* dbg = reinterpret_cast<uint32_t*>(y + (long)(M - 1) * N) + wave * 8;
-        for (int i = 0; i < 6; i++) dbg[i] = stamp_sum[i];
-        dbg[6] = (uint32_t)(t_end - t_begin);
-    }
-#endif
-}
-
 // ---- launch plumbing ---------------------------------------------------------------------------------
 struct GemmPlan {
     int BM, S, tiles_per_split;
@@ -1003,19 +681,6 @@ template <int DT, int WBIT, int ZM, bool PERM, bool GPT>
 static int gemm_launch_bm(const GemmPlan& p, const GemmArgs& a) {
     const int m_tiles = cdiv(a.M, p.BM), n_tiles = cdiv(a.N, GEMM_BN);
     dim3 grid(m_tiles * n_tiles, p.S);
-    if constexpr (WBIT == 4 && GPT && !PERM) {  // table-lookup dequantisation (BM = 256: one wave per SIMD, where the arithmetic form starves the matrix pipe)
-        static const int lut = env_int("BIE_GEMM_LUT", 1);
-        if (lut && p.BM == 256) {
-            const size_t lds_lut = (size_t)GEMM_TAB_BYTES + (size_t)2 * 256 * GEMM_BK * 2;  // 96 KiB: above the 64 KiB default cap
-            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&mpq_gemm_lut_kernel<DT, ZM, 256>),
-                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lut);
-            BIE_REQUIRE(attr == hipSuccess, BIE_ERR_HIP, "mpq_gemm_lut_kernel: hipFuncSetAttribute: %s", hipGetErrorString(attr));
-            hipLaunchKernelGGL((mpq_gemm_lut_kernel<DT, ZM, 256>), grid, dim3(256), lds_lut, a.st, (const uint16_t*)a.x, (const uint32_t*)a.qw,
-                               (const uint16_t*)a.scales, a.zeros, (const uint16_t*)a.bias, a.part, (uint16_t*)a.y, a.M, a.K, a.N, a.gshift,
-                               p.tiles_per_split, p.S, m_tiles, n_tiles);
-            return check_launch("mpq_gemm_lut_kernel");
-        }
-    }
     const size_t lds = (size_t)2 * p.BM * GEMM_BK * 2;
 #define L(BMV)                                                                                                          \
     hipLaunchKernelGGL((mpq_gemm_kernel<DT, WBIT, ZM, BMV, PERM, GPT>), grid, dim3(256), lds, a.st, (const uint16_t*)a.x, \

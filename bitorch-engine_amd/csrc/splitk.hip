@@ -74,7 +74,7 @@ int status_init() {
     memset(h, 0, 4096);
     void* d = nullptr;
     e = hipHostGetDevicePointer(&d, h, 0);
-    if (e != hipSuccess) { hipHostFree(h); set_error("bie_status_init: hipHostGetDevicePointer: %s", hipGetErrorString(e)); return BIE_ERR_HIP; }
+    if (e != hipSuccess) { (void)hipHostFree(h); set_error("bie_status_init: hipHostGetDevicePointer: %s", hipGetErrorString(e)); return BIE_ERR_HIP; }
     g_status_dev = reinterpret_cast<unsigned*>(d);
     g_status_host.store(reinterpret_cast<unsigned*>(h), std::memory_order_release);
     return BIE_OK;

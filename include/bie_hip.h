@@ -237,6 +237,13 @@ int bie_binary_unpack_bstc32(const uint8_t* image, uint8_t* rowpacked, long N, l
 int bie_binary_linear_forward(const uint8_t* xpacked, const uint8_t* wpacked, float* y, long M,
                               long N, long K, int w_layout, float scale, void* stream);
 
+/* `batch` independent XNOR GEMMs in ONE launch: y[b][M, N] = (K - 2*popc(x[b] ^ w[b])) * scale, both operands row-packed
+ * uint8 [rows, K/8]; strides in BYTES (packed operands) / ELEMENTS (y) between consecutive matrices.
+ * Replaces binary_linear_cutlass.matmul -> binary_batched_forward_cutlass
+ * (layers/qlinear/binary/cutlass/binary_linear_cutlass_kernel.cu:336-393, 700-738). */
+int bie_binary_matmul_batched(const uint8_t* xpacked, const uint8_t* wpacked, float* y, long batch, long M, long N, long K,
+                              long stride_x, long stride_w, long stride_y, float scale, void* stream);
+
 /* One launch per BinaryLinearCuda layer forward (M <= 64):
  *   y[M, N] (dtype) = dt( dt( dt(K - 2*popcount(xbits ^ wbits)) * scale_a ) * scale_w ),  xbits = ((x + bias_a) >= 0)
  * x [M, K] raw activations, bias_a [K] or NULL, wpacked row-packed [N, K/8] (all three 16-byte aligned), scale_a / scale_w device

@@ -95,6 +95,33 @@ def tonp(t):
     return t.detach().cpu().contiguous().numpy()
 
 
+def extension_signatures():
+    import glob
+    import re
+    mods = {"q_linear_cuda": "layers/qlinear/nbit/cuda/q_linear_cuda.cpp", "q_linear_cutlass": "layers/qlinear/nbit/cutlass/q_linear_cutlass.cpp",
+            "binary_linear_cpp": "layers/qlinear/binary/cpp/binary_linear.cpp", "binary_linear_cuda": "layers/qlinear/binary/cuda/binary_linear_cuda.cpp",
+            "binary_linear_cutlass": "layers/qlinear/binary/cutlass/binary_linear_cutlass.cpp", "binary_conv_cpp": "layers/qconv/binary/cpp/binary_conv.cpp",
+            "binary_conv2d_cutlass": "layers/qconv/binary/cutlass/binary_conv2d_cutlass.cpp", "q4_conv_cutlass": "layers/qconv/nbit/cutlass/q4_conv_cutlass.cpp",
+            "functions_cuda": "functions/cuda/functions_cuda.cpp"}
+    out = {}
+    for mod, rel in mods.items():
+        text = open(os.path.join(REF, "bitorch_engine", rel)).read()
+        text_nc = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text_nc = re.sub(r"//[^\n]*", "", text_nc)
+        fns = {}
+        for name, fn in re.findall(r'm\.def\(\s*"(\w+)"\s*,\s*&(\w+)', text_nc):
+            m = None
+            for m in re.finditer(r"\b" + fn + r"\s*\(([^)]*)\)\s*\{", text_nc):
+                pass  # the last match with a body is the definition
+            if m is None:  # defined in the .cu: the .cpp holds the declaration
+                m = re.search(r"\b" + fn + r"\s*\(([^)]*)\)\s*;", text_nc)
+            assert m is not None, (mod, fn)
+            params = [re.sub(r"\s*=.*$", "", a).strip().split()[-1].lstrip("&*") for a in m.group(1).split(",") if a.strip()]
+            fns[name] = params
+        out[mod] = fns
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     _stub_bitorch()
@@ -316,6 +343,11 @@ def main():
     np.savez_compressed(os.path.join(OUT, "helpers.npz"), **hp)
     manifest["mpq_configs"] = {k: get_mpq_config(k) for k in (None, "2-8-32", "2-32-32", "2-128-32", "4-128-256", "8-128-256")}
     manifest["mpq_configs"] = {str(k): v for k, v in manifest["mpq_configs"].items()}
+
+    # ---- the extension modules' boundary: name and positional parameter list of every function the reference binds with pybind11
+    # (m.def("name", &fn)), read off the reference's own C++ definitions.  Data only (names), consumed by tests/test_boundary_cpu.py.
+    with open(os.path.join(OUT, "extension_signatures.json"), "w") as f:
+        json.dump(extension_signatures(), f, indent=1, sort_keys=True)
 
     with open(os.path.join(OUT, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1)

@@ -75,3 +75,51 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_hip, "LIB_PATH", "/nonexistent/libbie_hip.so")
     with pytest.raises(RuntimeError, match="not found"):
         _hip.lib()
+
+
+def test_every_extension_function_takes_the_reference_positional_argument_list(golden_dir):
+    """tests/golden/extension_signatures.json = name -> positional parameter list of every function the reference binds with
+    pybind11 (m.def without py::arg: positional only), read off the reference's C++ by oracle/gen_golden.py.  Every one of them
+    must exist in the same-named module here and accept exactly that many positional arguments (extra parameters only with
+    defaults) -- a caller written against the reference's extension modules must not be able to hit a silently different meaning
+    (round 2: binary_linear_cutlass.mm took `transpose` where the reference takes `kernel_id`)."""
+    import importlib
+    import inspect
+    import json
+    sig = json.load(open(os.path.join(golden_dir, "extension_signatures.json")))
+    assert len(sig) == 9 and sum(len(v) for v in sig.values()) == 36
+    for mod_name, fns in sig.items():
+        mod = importlib.import_module("bitorch_engine.extensions." + mod_name)
+        for name, params in fns.items():
+            assert hasattr(mod, name), f"{mod_name}.{name} is missing"
+            ps = list(inspect.signature(getattr(mod, name)).parameters.values())
+            assert all(p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD) for p in ps), f"{mod_name}.{name}: non-positional parameter"
+            required = [p for p in ps if p.default is inspect.Parameter.empty]
+            assert len(required) <= len(params) <= len(ps), f"{mod_name}.{name} takes {[p.name for p in ps]}, the reference {params}"
+    # the parameter whose MEANING was wrong in round 2
+    from bitorch_engine.extensions import binary_linear_cutlass
+    assert list(inspect.signature(binary_linear_cutlass.mm).parameters) == ["x", "y", "kernel_id"]
+
+
+def test_list_plan_validation_without_a_device():
+    """bie_mpq_list_*: sizes and argument errors are decided on the host before any device work."""
+    from bitorch_engine import _hip
+    L = _hip.lib()
+    E = _hip.ListEntry
+    ok = (E * 2)(E(8, 8, 8, 8, None, 8, 4096, 4096, -1, 0), E(8, 8, 8, 8, None, 8, 4096, 11008, -1, 0))
+    n = L.bie_mpq_list_device_bytes(2, ok, 1, 4, 128)
+    assert n >= 2 * 128 + (64 + 172) * 8
+    assert L.bie_mpq_list_device_bytes(2, ok, 3, 4, 128) == 0  # M > 2
+    assert L.bie_mpq_list_device_bytes(2, ok, 1, 8, 128) == 0  # w_bit 8
+    bad = (E * 1)(E(8, 8, 8, 8, None, 8, 4000, 64, -1, 0))
+    assert L.bie_mpq_list_device_bytes(1, bad, 1, 4, 128) == 0  # K not a multiple of the group
+    h = ctypes.c_void_p()
+    dep = (E * 2)(E(8, 8, 8, 8, None, 16, 4096, 4096, 1, 0), E(16, 8, 8, 8, None, 24, 4096, 4096, -1, 0))
+    assert L.bie_mpq_list_create(ctypes.byref(h), 2, dep, 1, 4, 128, 0, 1, 256, 1 << 30) == -1
+    assert b"not EARLIER" in L.bie_last_error()
+    dep2 = (E * 2)(E(8, 8, 8, 8, None, 16, 4096, 4096, -1, 0), E(32, 8, 8, 8, None, 24, 4096, 4096, 0, 0))
+    assert L.bie_mpq_list_create(ctypes.byref(h), 2, dep2, 1, 4, 128, 0, 1, 256, 1 << 30) == -1
+    assert b"does not read its y" in L.bie_last_error()
+    assert L.bie_mpq_list_create(ctypes.byref(h), 2, ok, 1, 4, 128, 0, 1, 256, 16) == -3  # device buffer too small
+    assert L.bie_mpq_list_forward(None, None) == -1
+    assert L.bie_device_status(0) == 0  # no status page without a GPU: reads as clear

@@ -64,13 +64,22 @@ def _worker(rank, world, port, asym, out_dir):
     x7 = torch.randn((7, x.shape[-1]), generator=g).half()
     full7 = _oracle_impl(x7, qweight, scales, zeros, g_idx, w_bit, asym, gs, bias)
     y7 = layer.forward_overlapped(x7, m_tile=3)
-    ok_tiled = torch.equal(y7, full7) if len({hi - lo for lo, hi in layer.ranges}) == 1 else torch.equal(y7, full7)
-    rm = layer.forward_overlapped(x7, m_tile=3, interleave=False)
+    ok_tiled = torch.equal(y7, full7)
+    equal_shards = len({hi - lo for lo, hi in layer.ranges}) == 1
     ok_rm = True
-    if rm.dim() == 3:  # rank-major [W, M, N/W]: block r is the column block of rank r
-        for r in range(world):
-            rlo, rhi = column_range(qweight.shape[1], r, world)
-            ok_rm = ok_rm and torch.equal(rm[r], full7[:, rlo:rhi])
+    for mt in (3, 16):  # tiled schedule, and the single-tile fallback: interleave=False ALWAYS means rank-major [W, M, N/W]
+        if equal_shards:
+            rm = layer.forward_overlapped(x7, m_tile=mt, interleave=False)
+            ok_rm = ok_rm and rm.dim() == 3 and rm.shape[0] == world
+            for r in range(world):  # block r is the column block of rank r
+                rlo, rhi = column_range(qweight.shape[1], r, world)
+                ok_rm = ok_rm and torch.equal(rm[r], full7[:, rlo:rhi])
+        else:  # unequal shard widths cannot be laid out rank-major: an error, not a silently different layout
+            try:
+                layer.forward_overlapped(x7, m_tile=mt, interleave=False)
+                ok_rm = False
+            except RuntimeError:
+                pass
     torch.save({"ok": ok and ok_tiled and ok_rm, "shape": tuple(y.shape)}, os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()

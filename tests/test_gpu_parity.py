@@ -1397,3 +1397,24 @@ def test_reducer_timeout_fails_loudly():
         L.bie_test_forge_reducer(0, 0)
     assert torch.isnan(y.float()).all()
     assert L.bie_device_status(1) & 1
+
+
+def test_binary_linear_cutlass_mm_and_batched_matmul_follow_the_reference_signatures():
+    """binary_linear_cutlass.mm(x, y, kernel_id) -> int32 XOR-popcount accumulator (binary_linear_cutlass_kernel.cu:293-332,650-666);
+    matmul(x, y, scale) batched in ONE launch, float32 exact and bfloat16 with the reference's bf16 arithmetic on the popcount."""
+    from bitorch_engine.extensions import binary_linear_cutlass as blc
+    g = torch.Generator().manual_seed(3)
+    x, y = torch.randn((24, 320), generator=g), torch.randn((40, 320), generator=g)
+    sx, sy = torch.where(x >= 0, 1.0, -1.0), torch.where(y >= 0, 1.0, -1.0)
+    popc = ((320 - sx @ sy.t()) / 2).to(torch.int32)
+    for kid in (1, 3, 9):  # a kernel id never changes the meaning
+        out = blc.mm(x.to(DEV), y.to(DEV), kid)
+        assert out.dtype == torch.int32 and torch.equal(out.cpu(), popc)
+    xb, yb = torch.randn((2, 3, 17, 512), generator=g), torch.randn((2, 3, 33, 512), generator=g)
+    ref = (torch.where(xb >= 0, 1.0, -1.0) @ torch.where(yb >= 0, 1.0, -1.0).transpose(-1, -2)) * 0.5
+    out = blc.matmul(xb.to(DEV), yb.to(DEV), 0.5)
+    assert out.dtype == torch.float32 and torch.equal(out.cpu(), ref)
+    outb = blc.matmul(xb.to(DEV).bfloat16(), yb.to(DEV).bfloat16(), 0.5)
+    pb = ((512 - 2 * ref) / 2).to(torch.bfloat16)  # signs are unchanged by the bf16 cast of x / y (no zeros in randn)
+    refb = (torch.tensor(512.0) - 2 * pb.float()).to(torch.bfloat16) * torch.tensor(0.5, dtype=torch.bfloat16)
+    assert outb.dtype == torch.bfloat16 and torch.equal(outb.cpu(), refb)
