@@ -227,13 +227,28 @@ def bench_exl2(dev):
             ze = (torch.randn((groups, N), device=dev) * 0.05).half()
             sets.append((qw, sc, ze))
         _, rows = q_linear_cuda.mbwq_trans_qweight(sets[0][0], q_groups, True, K, groups, 4)
-        x = torch.randn((1, K), device=dev).half()
-        g = capture(lambda st: [q_linear_cuda.mbwq_exl2_forward(x, s_[0], s_[1], s_[2], perm, gmap, rows, False) for s_ in sets])
-        us = time_graph(g, 10) / nset
         byts = row * N * 4 + 4 * groups * N + 6 * K + 2 * K + 2 * N
-        out.append({"op": "exl2 w3/w2 g32 decode", "M": 1, "K": K, "N": N, "us_per_launch": round(us, 2),
+        for M in (1, 2):
+            x = torch.randn((M, K), device=dev).half()
+            g = capture(lambda st: [q_linear_cuda.mbwq_exl2_forward(x, s_[0], s_[1], s_[2], perm, gmap, rows, False) for s_ in sets])
+            us = time_graph(g, 10) / nset
+            out.append({"op": "exl2 w3/w2 g32 decode, one launch per layer", "M": M, "K": K, "N": N, "us_per_launch": round(us, 2),
+                        "roofline": {"bound": "hbm", "achieved": round(byts / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": round(byts / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None}})
+        # the same layers, each with its own x, as ONE launch (bie_mbwq_exl2_list_*)
+        from bitorch_engine.layers.qlinear.nbit.cuda import MBWQExl2ForwardList
+        ents = [{"x": torch.randn((1, K), device=dev).half(), "qweight": s_[0], "scales": s_[1], "zeros": s_[2], "q_perm": perm, "q_group_map": gmap,
+                 "rows": rows, "y": torch.empty((1, N), dtype=torch.float16, device=dev)} for s_ in sets]
+        plan = MBWQExl2ForwardList(ents)
+        us = time_graph(capture(lambda st: plan.forward(st)), 10) / nset
+        out.append({"op": "exl2 w3/w2 g32 decode, layer list in one launch", "M": 1, "K": K, "N": N, "layers": nset, "us_per_layer": round(us, 2),
                     "roofline": {"bound": "hbm", "achieved": round(byts / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": round(byts / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None}})
+        for M in (16, 64):  # mid-size batches: HIP reconstruct + library GEMM (the reference's split for M > 32, mbwq_linear_cuda_kernel.cu:947-957)
+            x = torch.randn((M, K), device=dev).half()
+            g = capture(lambda st: [q_linear_cuda.mbwq_exl2_forward(x, s_[0], s_[1], s_[2], perm, gmap, rows, False) for s_ in sets[:4]])
+            us = time_graph(g, 5) / 4
+            out.append({"op": "exl2 w3/w2 g32", "M": M, "K": K, "N": N, "us_per_launch": round(us, 2), "TFLOP/s": round(2.0 * M * K * N / us / 1e6, 2)})
     return out
 
 

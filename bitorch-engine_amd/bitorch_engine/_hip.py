@@ -36,6 +36,10 @@ SIGNATURES = {
     "bie_mpq_list_forward": (_i, [_vp, _vp]),
     "bie_mpq_list_launches": (_i, [_vp]),
     "bie_mpq_list_destroy": (None, [_vp]),
+    "bie_mbwq_exl2_list_device_bytes": (_sz, [_i, _vp, _i]),
+    "bie_mbwq_exl2_list_create": (_i, [_vp, _i, _vp, _i, _vp, _sz]),
+    "bie_mbwq_exl2_list_forward": (_i, [_vp, _vp]),
+    "bie_mbwq_exl2_list_destroy": (None, [_vp]),
     "bie_mpq_dequant": (_i, [_vp] * 5 + [_i] * 6 + [_vp]),
     "bie_mpq_pack": (_i, [_vp] * 5 + [_i] * 6 + [_vp]),
     "bie_mpq_grad_input": (_i, [_vp] * 6 + [_i] * 7 + [_vp]),
@@ -77,13 +81,19 @@ SIGNATURES = {
 
 
 _HOST_ONLY = ("bie_version", "bie_last_error", "bie_mbwq_rows", "bie_status_init", "bie_device_status", "bie_test_forge_reducer",
-              "bie_mpq_list_launches", "bie_mpq_list_destroy")
+              "bie_mpq_list_launches", "bie_mpq_list_destroy", "bie_mbwq_exl2_list_destroy")
 
 
 class ListEntry(ctypes.Structure):
     """bie_mpq_list_entry (include/bie_hip.h)."""
     _fields_ = [("x", _vp), ("qweight", _vp), ("scales", _vp), ("zeros", _vp), ("bias", _vp), ("y", _vp),
                 ("K", _i), ("N", _i), ("depends_on", _i), ("reserved", _i)]
+
+
+class Exl2ListEntry(ctypes.Structure):
+    """bie_exl2_list_entry (include/bie_hip.h)."""
+    _fields_ = [("x", _vp), ("qweight", _vp), ("scales", _vp), ("zeros", _vp), ("q_perm", _vp), ("q_group_map", _vp), ("rows7", _vp),
+                ("y", _vp), ("K", _i), ("N", _i), ("reserved0", _i), ("reserved1", _i)]
 
 
 def lib():

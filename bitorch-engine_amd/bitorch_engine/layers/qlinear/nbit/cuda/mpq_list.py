@@ -90,3 +90,52 @@ class MPQForwardList:
                             "y": y, "depends_on": i - 1 if (chain and i > 0) else -1})
             ys.append(y)
         return cls(entries, w_bit=l0.w_bit, group_size=l0.group_size, asym=l0.asym), ys
+
+
+class MBWQExl2ForwardList:
+    """A list of exl2 (mixed 8/6/5/4/3/2-bit) decode layers in ONE launch (bie_mbwq_exl2_list_*): entry i is one
+    `q_linear_cuda.mbwq_exl2_forward(x, qweight, scales, zeros, q_perm, q_group_map, rows)` call of the reference
+    (mbwq_linear_cuda_kernel.cu:926-1007) with its own y.  entries: dicts with x, qweight, scales, zeros, q_perm (or None),
+    q_group_map, rows (the 7-int band table from mbwq_trans_qweight), y.  fp16, M <= 2."""
+
+    def __init__(self, entries):
+        L = _hip.lib()
+        dev = _hip.need_gpu(*[t for e in entries for t in (e["x"], e["qweight"], e["scales"], e["zeros"], e["q_group_map"], e["y"], e.get("q_perm"))])
+        self.M = entries[0]["x"].reshape(-1, entries[0]["x"].shape[-1]).shape[0]
+        arr = (_hip.Exl2ListEntry * len(entries))()
+        keep = []
+        for i, e in enumerate(entries):
+            x, y = e["x"], e["y"]
+            if x.dtype != torch.float16 or y.dtype != torch.float16:
+                raise RuntimeError("MBWQExl2ForwardList: fp16 only (as the reference kernels)")
+            K, N = x.shape[-1], e["qweight"].shape[1]
+            rows = (ctypes.c_int * 7)(*[int(v) for v in e["rows"]])
+            perm = e.get("q_perm")
+            for t in (x, y, e["qweight"], e["scales"], e["zeros"], e["q_group_map"]):
+                if not t.is_contiguous():
+                    raise RuntimeError("MBWQExl2ForwardList: tensors must be contiguous")
+            arr[i] = _hip.Exl2ListEntry(x.data_ptr(), e["qweight"].data_ptr(), e["scales"].data_ptr(), e["zeros"].data_ptr(),
+                                        None if perm is None else perm.data_ptr(), e["q_group_map"].data_ptr(),
+                                        ctypes.cast(rows, ctypes.c_void_p), y.data_ptr(), K, N, 0, 0)
+            keep.append((x, y, e["qweight"], e["scales"], e["zeros"], e["q_group_map"], perm, rows))
+        self._keep = keep
+        nbytes = L.bie_mbwq_exl2_list_device_bytes(len(entries), arr, self.M)
+        if nbytes == 0:
+            raise RuntimeError("MBWQExl2ForwardList: outside the one-launch decode range (1 <= M <= 2, K % 32 == 0)")
+        self._mem = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+        base = (self._mem.data_ptr() + 255) // 256 * 256
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(dev):
+            _hip.check(L.bie_mbwq_exl2_list_create(ctypes.byref(handle), len(entries), arr, self.M, base, nbytes), "bie_mbwq_exl2_list_create")
+        self._plan, self._L = handle, L
+
+    def forward(self, stream=None):
+        _hip.need_gpu(self._mem)
+        _hip.check(self._L.bie_mbwq_exl2_list_forward(self._plan, _hip.stream() if stream is None else stream), "bie_mbwq_exl2_list_forward")
+
+    __call__ = forward
+
+    def __del__(self):
+        plan, self._plan = getattr(self, "_plan", None), None
+        if plan:
+            self._L.bie_mbwq_exl2_list_destroy(plan)

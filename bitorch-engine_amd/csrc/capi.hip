@@ -59,6 +59,11 @@ int mbwq_q4_forward_launch(const void* x, const int32_t* qw, const void* scales,
 int mbwq_exl2_forward_launch(const void* x, const int32_t* qw, const void* scales, const void* zeros, const int16_t* perm,
                              const int16_t* gmap, const int* rows7, void* y, float* head, float* part, int M, int K, int N,
                              hipStream_t st);
+struct Exl2List;
+size_t exl2_list_device_bytes(int n, const bie_exl2_list_entry* e, int M);
+int exl2_list_create(Exl2List** out, int n, const bie_exl2_list_entry* e, int M, void* device_mem, size_t device_bytes);
+int exl2_list_forward(Exl2List* p, hipStream_t st);
+void exl2_list_destroy(Exl2List* p);
 // binary.hip
 int pack_rows_launch(const void* a, uint8_t* out, long n_bytes, int dtype, hipStream_t st);
 int pack_cols_launch(const void* w, uint8_t* out, long N, long K, int dtype, hipStream_t st);
@@ -371,6 +376,13 @@ int bie_mbwq_exl2_forward(const void* x, const int32_t* qweight, const void* sca
     if (rc) return rc;
     return mbwq_exl2_forward_launch(x, qweight, scales, zeros, q_perm, q_group_map, rows7_host, y, (float*)workspace, (float*)workspace + WS_HEAD / sizeof(float), M, K, N, as_stream(stream));
 }
+
+size_t bie_mbwq_exl2_list_device_bytes(int n_entries, const bie_exl2_list_entry* entries, int M) { return exl2_list_device_bytes(n_entries, entries, M); }
+int bie_mbwq_exl2_list_create(bie_exl2_list_t** plan, int n_entries, const bie_exl2_list_entry* entries, int M, void* device_mem, size_t device_bytes) {
+    return exl2_list_create(reinterpret_cast<Exl2List**>(plan), n_entries, entries, M, device_mem, device_bytes);
+}
+int bie_mbwq_exl2_list_forward(bie_exl2_list_t* plan, void* stream) { return exl2_list_forward(reinterpret_cast<Exl2List*>(plan), as_stream(stream)); }
+void bie_mbwq_exl2_list_destroy(bie_exl2_list_t* plan) { exl2_list_destroy(reinterpret_cast<Exl2List*>(plan)); }
 
 // ---------------------------------------------------------------------------------------------- binary
 int bie_binary_pack_rows_u8(const void* a, uint8_t* out, long rows, long K, int dtype, void* stream) {

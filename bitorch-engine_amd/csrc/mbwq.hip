@@ -17,6 +17,8 @@
 
 #pragma clang fp contract(off)
 
+#include <vector>
+
 namespace bie {
 unsigned* device_status_word();                            // splitk.hip
 void test_forge_get(unsigned* tag_skew, int* spin_limit);  // splitk.hip
@@ -234,39 +236,66 @@ __global__ __launch_bounds__(256) void exl2_gemv_kernel(const uint16_t* __restri
 // kernel below, and no finalize launch when one slab covers K.
 // EX2_NW waves per workgroup: 16 (one workgroup per CU) when the column blocks alone fill most of the chip (measured 17.8 us
 // against 19.4 us at 4096x11008), 8 (two per CU) + K slabs for narrower layers (4096x4096: 7.9 us against 9.1 us)
-template <int MT, int EX2_NW>
-__global__ __launch_bounds__(EX2_NW * 64, (EX2_NW == 8 ? 2 : 1)) void exl2_gemv2_kernel(const uint16_t* __restrict__ x, const uint32_t* __restrict__ qw,
-                                                                    const uint16_t* __restrict__ scales, const uint16_t* __restrict__ zeros,
-                                                                    const uint16_t* __restrict__ perm, const uint16_t* __restrict__ gmap,
-                                                                    unsigned long long* __restrict__ gran, unsigned* __restrict__ gen,
-                                                                    uint16_t* __restrict__ y, Exl2Rows rows, int M, int K, int N,
-                                                                    int chunks_per_slab, int S, unsigned epoch, unsigned* status,
-                                                                    unsigned tag_skew, int spin_limit) {
+struct Exl2Call {  // everything one workgroup of the decode kernel needs (kernel arguments, or an entry of a device-resident list)
+    const uint16_t* x; const uint32_t* qw; const uint16_t* scales; const uint16_t* zeros; const uint16_t* perm; const uint16_t* gmap;
+    unsigned long long* gran; unsigned* gen; uint16_t* y;
+    Exl2Rows rows;
+    int M, K, N, chunks_per_slab, S, colblocks;
+};
+
+// STAGED (two x rows): the slab's activations are gathered through q_perm ONCE per workgroup into LDS.  !STAGED (one row): every wave
+// gathers the 32 activations of its own chunk together with the chunk's loads (wave-private LDS buffers) and the weight stream
+// starts one round trip earlier -- measured: one row 8.0 / 16.5 us per layer against 8.9 / 18.3 staged (4096x4096 / 4096x11008),
+// two rows 24.5 against 19.1 (profiles/r03_l_exl2_staged_x.txt).  Both forms are exact.
+template <int MT, int EX2_NW, bool STAGED>
+__device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, const uint32_t* __restrict__ qw,
+                                                const uint16_t* __restrict__ scales, const uint16_t* __restrict__ zeros,
+                                                const uint16_t* __restrict__ perm, const uint16_t* __restrict__ gmap,
+                                                unsigned long long* __restrict__ gran, unsigned* __restrict__ gen,
+                                                uint16_t* __restrict__ y, const Exl2Rows rows, const int M, const int K, const int N,
+                                                const int chunks_per_slab, const int S, const int colblock, const int slab_idx,
+                                                const int colblocks, unsigned epoch, unsigned* status, unsigned tag_skew, int spin_limit) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem2[];
     const int tid = threadIdx.x, lane = tid & 63;
     // the tile's generation is read ONCE, at kernel entry, by every wave: the reducer advances the word as soon as it is done, and a
     // wave that read it only in the epilogue could see the NEXT generation, tag with it and never be matched
     unsigned gen_entry = 0;
-    if (S > 1) gen_entry = __hip_atomic_load(gen + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (S > 1) gen_entry = __hip_atomic_load(gen + colblock, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // wave-private x chunk buffers [wave][set 0..3][MT][32] fp16 (q_perm applied): each wave gathers the 32 activations of
-    // its own chunk together with the chunk's loads -- no block-wide x slab, no barrier before the weight stream
-    uint16_t* xs = reinterpret_cast<uint16_t*>(smem2) + wave * (4 * MT * 32);
-    const int n = blockIdx.x * 64 + lane;
+    const int n = colblock * 64 + lane;
     const int nl = n < N ? n : N - 1;
     const int C = K >> 5;
-    const int c_begin = blockIdx.y * chunks_per_slab;
+    const int c_begin = slab_idx * chunks_per_slab;
     int c_end = c_begin + chunks_per_slab;
     if (c_end > C) c_end = C;
-    // The slab's permutation indices and group-map entries are staged in LDS once per workgroup: a chunk's group constants and
-    // gathered activations can then be requested TOGETHER with its packed words.  (Fetched per chunk they were two dependent
-    // global loads behind the words -- PMC: 58 % of the wave time waiting, profiles/r02_pmc_exl2.txt.)
-    uint16_t* perm_s = reinterpret_cast<uint16_t*>(smem2) + EX2_NW * (4 * MT * 32);  // [chunks_per_slab * 32]
-    uint16_t* gmap_s = perm_s + chunks_per_slab * 32;                               // [chunks_per_slab * 2]
+    // Staged in LDS once per workgroup: the slab's group-map entries and either its activations (STAGED: gathered through q_perm, M
+    // rows) or its permutation indices (a wave then gathers its own chunk's 32 activations with the chunk's loads).  A chunk's
+    // group constants can thus be requested TOGETHER with its packed words.  (Fetched per chunk they were two dependent global loads
+    // behind the words -- PMC: 58 % of the wave time waiting, profiles/r02_pmc_exl2.txt.)
+    const int slab_k = chunks_per_slab * 32;
+    uint16_t* x_s = reinterpret_cast<uint16_t*>(smem2);                       // STAGED: [MT][slab_k] fp16, q_perm applied
+    uint16_t* xs = reinterpret_cast<uint16_t*>(smem2) + wave * (4 * MT * 32);  // !STAGED: wave-private [set 0..3][MT][32]
+    uint16_t* perm_s = reinterpret_cast<uint16_t*>(smem2) + EX2_NW * (4 * MT * 32);  // !STAGED: [slab_k]
+    uint16_t* gmap_s = STAGED ? x_s + MT * slab_k : perm_s + slab_k;           // [chunks_per_slab * 2]
+    int two_groups = 0;  // does any chunk of the slab straddle two groups (group sizes below 32)?
     {
         const int nk = (c_end - c_begin) * 32;
-        for (int i = tid; i < nk; i += EX2_NW * 64) perm_s[i] = perm ? perm[c_begin * 32 + i] : (uint16_t)(c_begin * 32 + i);
-        for (int i = tid; i < (c_end - c_begin) * 2; i += EX2_NW * 64) gmap_s[i] = gmap[2 * ((c_begin + (i >> 1)) * 32 + 16 * (i & 1))];
+        for (int i = tid; i < nk; i += EX2_NW * 64) {
+            const int kx = perm ? (int)perm[c_begin * 32 + i] : c_begin * 32 + i;
+            if constexpr (STAGED) {
+#pragma unroll
+                for (int m = 0; m < MT; m++) x_s[m * slab_k + i] = x[(long)(m < M ? m : 0) * K + kx];
+            } else {
+                perm_s[i] = (uint16_t)kx;
+            }
+        }
+        for (int i = tid; i < (c_end - c_begin); i += EX2_NW * 64) {
+            const uint16_t ga = gmap[2 * ((c_begin + i) * 32)], gb = gmap[2 * ((c_begin + i) * 32 + 16)];
+            gmap_s[2 * i] = ga;
+            gmap_s[2 * i + 1] = gb;
+            two_groups |= (ga != gb);
+        }
+        two_groups = __syncthreads_or(two_groups);  // the slab's metadata is in LDS; workgroup-uniform flag
     }
     float acc[MT];
 #pragma unroll
@@ -277,38 +306,54 @@ __global__ __launch_bounds__(EX2_NW * 64, (EX2_NW == 8 ? 2 : 1)) void exl2_gemv2
     // compiler can wait with an exact vmcnt for the OLDEST chunk only.  (With the width switched at run time and `if (c < c_end)`
     // around the issues every wait came out as vmcnt(0..3): the 4-deep prefetch was really 1-deep and each of a wave's 8 chunks paid
     // a full memory latency -- PMC: 58 % of the wave time waiting.)
-    __syncthreads();  // the metadata slab is in LDS
-    auto band = [&](auto bits_tag, int cb0, int cb1, int prow0) {  // chunks [cb0, cb1) of this slab lie in one band starting at row prow0
+    auto band = [&](auto bits_tag, auto two_tag, int cb0, int cb1, int prow0) {  // chunks [cb0, cb1) of this slab lie in one band starting at row prow0
         constexpr int BITS = decltype(bits_tag)::value;
+        constexpr bool TWO = decltype(two_tag)::value;  // group constants per 16-k half (two loads more per chunk) or per chunk
         struct Chunk {
             uint32_t w[BITS];
             uint32_t s[2], z[2];
-            uint32_t xraw[MT];
+            uint32_t xraw[STAGED ? 1 : MT];  // !STAGED: this lane's gathered activation(s) of the chunk
         };
-        auto issue = [&](int c, Chunk& ch) {
-            const int cl = c - c_begin;
+        auto issue_w = [&](int c, Chunk& ch) {
             const int prow = prow0 + (c - cb0) * BITS;
 #pragma unroll
             for (int i = 0; i < BITS; i++) ch.w[i] = __builtin_nontemporal_load(qw + (long)(prow + i) * N + nl);
-            const int g0 = __builtin_amdgcn_readfirstlane((int)gmap_s[2 * cl]), g1 = __builtin_amdgcn_readfirstlane((int)gmap_s[2 * cl + 1]);
-            const int pidx = (int)perm_s[cl * 32 + (lane & 31)];
+        };
+        auto group_of = [&](int c, int half) -> int { return __builtin_amdgcn_readfirstlane((int)gmap_s[2 * (c - c_begin) + half]); };
+        auto issue_p = [&](int c, Chunk& ch) {
+            const int g0 = group_of(c, 0);
             ch.s[0] = scales[(long)g0 * N + nl];
             ch.z[0] = zeros[(long)g0 * N + nl];
-            ch.s[1] = scales[(long)g1 * N + nl];  // unconditional (same line as [0] when the halves share a group): static load count
-            ch.z[1] = zeros[(long)g1 * N + nl];
-#pragma unroll
-            for (int m = 0; m < MT; m++) ch.xraw[m] = x[(long)(m < M ? m : 0) * K + pidx];
-        };
-        auto compute = [&](int set, const Chunk& ch) {
-            uint16_t* xw = xs + set * (MT * 32);
-            if (lane < 32) {
-#pragma unroll
-                for (int m = 0; m < MT; m++) xw[m * 32 + lane] = (uint16_t)ch.xraw[m];
+            if constexpr (TWO) {  // static load count per chunk either way
+                const int g1 = group_of(c, 1);
+                ch.s[1] = scales[(long)g1 * N + nl];
+                ch.z[1] = zeros[(long)g1 * N + nl];
             }
-            // same wave writes then reads: the LDS pipe keeps a wave's operations in order, the compiler must too (the 2-byte
-            // stores and the 16-byte loads below have different types)
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
+            if constexpr (!STAGED) {
+                const int pidx = (int)perm_s[(c - c_begin) * 32 + (lane & 31)];
+#pragma unroll
+                for (int m = 0; m < MT; m++) ch.xraw[m] = x[(long)(m < M ? m : 0) * K + pidx];
+            }
+        };
+        auto compute = [&](int set, int c, const Chunk& ch) {
+            const uint16_t* xw;
+            int xstride;
+            if constexpr (STAGED) {
+                xw = x_s + (c - c_begin) * 32;
+                xstride = slab_k;
+            } else {
+                uint16_t* xwr = xs + set * (MT * 32);
+                if (lane < 32) {
+#pragma unroll
+                    for (int m = 0; m < MT; m++) xwr[m * 32 + lane] = (uint16_t)ch.xraw[m];
+                }
+                // same wave writes then reads: the LDS pipe keeps a wave's operations in order, the compiler must too (the 2-byte
+                // stores and the 16-byte loads below have different types)
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                xw = xwr;
+                xstride = 32;
+            }
             uint32_t w8[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) w8[i] = i < BITS ? ch.w[i] : 0u;
@@ -316,13 +361,13 @@ __global__ __launch_bounds__(EX2_NW * 64, (EX2_NW == 8 ? 2 : 1)) void exl2_gemv2
             exl2_pairs16<BITS>(w8, P);
 #pragma unroll
             for (int half = 0; half < 2; half++) {
-                const half_t sh = __builtin_bit_cast(half_t, (uint16_t)ch.s[half]);
-                const half_t zh = __builtin_bit_cast(half_t, (uint16_t)ch.z[half]);
+                const half_t sh = __builtin_bit_cast(half_t, (uint16_t)ch.s[TWO ? half : 0]);
+                const half_t zh = __builtin_bit_cast(half_t, (uint16_t)ch.z[TWO ? half : 0]);
                 const half2_t s2 = half2_t{sh, sh}, nz2 = half2_t{(half_t)-zh, (half_t)-zh};
                 uint4_t xv[MT][2];
 #pragma unroll
                 for (int m = 0; m < MT; m++) {
-                    const uint4_t* xp = reinterpret_cast<const uint4_t*>(xw + m * 32 + 16 * half);
+                    const uint4_t* xp = reinterpret_cast<const uint4_t*>(xw + m * xstride + 16 * half);
                     xv[m][0] = xp[0];
                     xv[m][1] = xp[1];
                 }
@@ -347,6 +392,7 @@ __global__ __launch_bounds__(EX2_NW * 64, (EX2_NW == 8 ? 2 : 1)) void exl2_gemv2
         const int cnt = (cb1 - first + EX2_NW - 1) / EX2_NW;
         const int last = first + (cnt - 1) * EX2_NW;
         auto at = [&](int jj) { const int c = first + jj * EX2_NW; return c < last ? c : last; };  // clamped look-ahead
+        auto issue = [&](int c, Chunk& ch) { issue_w(c, ch); issue_p(c, ch); };
         Chunk c0, c1, c2, c3;
         issue(at(0), c0);
         issue(at(1), c1);
@@ -354,19 +400,19 @@ __global__ __launch_bounds__(EX2_NW * 64, (EX2_NW == 8 ? 2 : 1)) void exl2_gemv2
         issue(at(3), c3);
         int jj = 0;
         for (; jj + 4 < cnt; jj += 4) {  // a further group follows: four full steps, each re-filling the set it has just consumed
-            compute(0, c0);
+            compute(0, at(jj), c0);
             issue(at(jj + 4), c0);
-            compute(1, c1);
+            compute(1, at(jj + 1), c1);
             issue(at(jj + 5), c1);
-            compute(2, c2);
+            compute(2, at(jj + 2), c2);
             issue(at(jj + 6), c2);
-            compute(3, c3);
+            compute(3, at(jj + 3), c3);
             issue(at(jj + 7), c3);
         }
-        compute(0, c0);  // last group: nothing left to request
-        if (jj + 1 < cnt) compute(1, c1);
-        if (jj + 2 < cnt) compute(2, c2);
-        if (jj + 3 < cnt) compute(3, c3);
+        compute(0, at(jj), c0);  // last group: nothing left to request
+        if (jj + 1 < cnt) compute(1, at(jj + 1), c1);
+        if (jj + 2 < cnt) compute(2, at(jj + 2), c2);
+        if (jj + 3 < cnt) compute(3, at(jj + 3), c3);
     };
     {
         int kprev = 0, prow = 0;
@@ -383,14 +429,20 @@ __global__ __launch_bounds__(EX2_NW * 64, (EX2_NW == 8 ? 2 : 1)) void exl2_gemv2
             if (cb1 > c_end) cb1 = c_end;
             if (cb0 < cb1) {
                 const int p0 = prow_band + skip * bits;
+#define BIE_BAND(B)                                                                        \
+    do {                                                                                   \
+        if (two_groups) band(std::integral_constant<int, B>{}, std::true_type{}, cb0, cb1, p0); \
+        else band(std::integral_constant<int, B>{}, std::false_type{}, cb0, cb1, p0);      \
+    } while (0)
                 switch (b) {
-                    case 0: band(std::integral_constant<int, 8>{}, cb0, cb1, p0); break;
-                    case 1: band(std::integral_constant<int, 6>{}, cb0, cb1, p0); break;
-                    case 2: band(std::integral_constant<int, 5>{}, cb0, cb1, p0); break;
-                    case 3: band(std::integral_constant<int, 4>{}, cb0, cb1, p0); break;
-                    case 4: band(std::integral_constant<int, 3>{}, cb0, cb1, p0); break;
-                    default: band(std::integral_constant<int, 2>{}, cb0, cb1, p0); break;
+                    case 0: BIE_BAND(8); break;
+                    case 1: BIE_BAND(6); break;
+                    case 2: BIE_BAND(5); break;
+                    case 3: BIE_BAND(4); break;
+                    case 4: BIE_BAND(3); break;
+                    default: BIE_BAND(2); break;
                 }
+#undef BIE_BAND
             }
         }
     }
@@ -401,7 +453,7 @@ __global__ __launch_bounds__(EX2_NW * 64, (EX2_NW == 8 ? 2 : 1)) void exl2_gemv2
     for (int m = 0; m < MT; m++) red[(wave * MT + m) * 64 + lane] = acc[m];
     __syncthreads();
     if (tid < 64 * MT) {
-        const int om = tid >> 6, ol = tid & 63, on = blockIdx.x * 64 + ol;
+        const int om = tid >> 6, ol = tid & 63, on = colblock * 64 + ol;
         float tot = 0.f;
 #pragma unroll
         for (int wv = 0; wv < EX2_NW; wv++) tot += red[(wv * MT + om) * 64 + ol];
@@ -411,8 +463,8 @@ __global__ __launch_bounds__(EX2_NW * 64, (EX2_NW == 8 ? 2 : 1)) void exl2_gemv2
             // publisher, which never waits) polls them and adds in slab order.  No finalize launch, no atomics, deterministic.
             const unsigned gen_next = gen_entry + 1u;
             const unsigned tag = epoch | (gen_next & 0xffu);
-            const long ncat = (long)gridDim.x * 64, col = (long)blockIdx.x * 64 + ol;
-            const int slab = blockIdx.y;
+            const long ncat = (long)colblocks * 64, col = (long)colblock * 64 + ol;
+            const int slab = slab_idx;
             if (slab != S - 1) {
                 const unsigned long long gval = ((unsigned long long)tag << 32) | __float_as_uint(tot);
                 __hip_atomic_store(gran + ((long)slab * MT + om) * ncat + col, gval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -444,18 +496,44 @@ __global__ __launch_bounds__(EX2_NW * 64, (EX2_NW == 8 ? 2 : 1)) void exl2_gemv2
                 }
             }
             tot = v + tot;
-            if (tid == 0) gen[blockIdx.x] = gen_next;  // the next launch (or a replay of this one) tags differently
+            if (tid == 0) gen[colblock] = gen_next;  // the next launch (or a replay of this one) tags differently
         }
         if (om < M && on < N) y[(long)om * N + on] = f32_to_f16_bits(tot);
     }
+}
+
+
+template <int MT, int EX2_NW>
+__global__ __launch_bounds__(EX2_NW * 64, (EX2_NW == 8 ? 2 : 1)) void exl2_gemv2_kernel(const Exl2Call c, unsigned epoch, unsigned* status, unsigned tag_skew,
+                                                                                          int spin_limit) {
+    exl2_gemv2_body<MT, EX2_NW, (MT > 1)>(c.x, c.qw, c.scales, c.zeros, c.perm, c.gmap, c.gran, c.gen, c.y, c.rows, c.M, c.K, c.N,
+                                          c.chunks_per_slab, c.S, (int)blockIdx.x, (int)blockIdx.y, c.colblocks, epoch, status, tag_skew, spin_limit);
+}
+
+// ONE launch over a LIST of exl2 layers (bie_mbwq_exl2_list_*): block b -> {entry, column block | slab << 20} through a device table
+// (the MPQ list's idea, mpq_list.hip): a 4096x4096 3/2-bit layer is 5 MB -- far too little for a launch of its own.
+template <int MT>
+__global__ __launch_bounds__(512, 2) void exl2_list_kernel(const Exl2Call* __restrict__ ent, const uint2_t* __restrict__ blk, unsigned epoch,
+                                                           unsigned* status, unsigned tag_skew, int spin_limit) {
+    typedef const __attribute__((address_space(4))) uint2_t cu2_t;
+    typedef const __attribute__((address_space(4))) Exl2Call ccall_t;
+    const uint2_t rec = *((cu2_t*)(uintptr_t)(blk + blockIdx.x));
+    ccall_t* c = (ccall_t*)(uintptr_t)(ent + rec.x);
+    Exl2Rows rows;
+#pragma unroll
+    for (int i = 0; i < 6; i++) rows.r[i] = c->rows.r[i];
+    exl2_gemv2_body<MT, 8, (MT > 1)>(c->x, c->qw, c->scales, c->zeros, c->perm, c->gmap, c->gran, c->gen, c->y, rows, c->M, c->K, c->N,
+                                     c->chunks_per_slab, c->S, (int)(rec.y & 0xfffffu), (int)(rec.y >> 20), c->colblocks, epoch, status, tag_skew,
+                                     spin_limit);
 }
 
 // decode (M <= 2): column blocks x K slabs ~ 512 workgroups of 8 waves (two per CU -> one round), slabs in whole multiples of
 // 8 chunks so that the 8 waves of a workgroup get equal shares; at most BIE_WS_COUNTERS column blocks use the slab reduction
 static void exl2_decode_plan(int M, int K, int N, int& cps, int& S, int& nw) {
     const int C = K / 32, colblocks = cdiv(N, 64);
-    constexpr int CPS_MAX = 768;  // the slab's q_perm / group-map copy in LDS: 68 bytes per chunk (52 KiB) beside the x buffers
-    if (colblocks >= 160) {  // wide layers: 16-wave workgroups, one K slab (more only when K is too long for the LDS copy)
+    const int CPS_MAX = 768 / M;  // the slab's x (q_perm applied, M rows) / group-map copy in LDS: 64 M + 4 bytes per chunk (<= 52 KiB)
+    if (colblocks >= 160 && M == 1) {  // wide layers: 16-wave workgroups, one K slab (more only when K is too long for the LDS copy).
+        // M = 2 keeps the 8-wave form: 1024-thread workgroups cap a wave at 128 registers and the two-row variant spilled 1096 dwords
         nw = 16;
         S = cdiv(C, CPS_MAX);
         cps = cdiv(cdiv(C, S), nw) * nw;
@@ -545,8 +623,8 @@ int mbwq_exl2_forward_launch(const void* x, const int32_t* qw, const void* scale
         int cps2, S, nw;
         exl2_decode_plan(M, K, N, cps2, S, nw);
         const int MT = M;
-        size_t lds2 = (size_t)nw * 4 * MT * 32 * sizeof(uint16_t)   // wave-private x chunk buffers
-                      + (size_t)cps2 * 34 * sizeof(uint16_t);      // + the slab's q_perm indices and group-map entries
+        size_t lds2 = MT > 1 ? (size_t)cps2 * (32 * MT + 2) * sizeof(uint16_t)   // the slab's gathered activations (M rows) + group map
+                             : (size_t)nw * 4 * MT * 32 * sizeof(uint16_t) + (size_t)cps2 * 34 * sizeof(uint16_t);  // wave x buffers + q_perm + group map
         const size_t red = (size_t)nw * MT * 64 * sizeof(float);
         if (lds2 < red) lds2 = red;
         dim3 grid2(colblocks, S);
@@ -556,10 +634,9 @@ int mbwq_exl2_forward_launch(const void* x, const int32_t* qw, const void* scale
         unsigned skew;
         int spin;
         test_forge_get(&skew, &spin);
-#define L2(MTV, NWV)                                                                                                       \
-    hipLaunchKernelGGL((exl2_gemv2_kernel<MTV, NWV>), grid2, dim3(NWV * 64), lds2, st, (const uint16_t*)x, (const uint32_t*)qw, \
-                       (const uint16_t*)scales, (const uint16_t*)zeros, (const uint16_t*)perm, (const uint16_t*)gmap, gran, gen, \
-                       (uint16_t*)y, rows, M, K, N, cps2, S, epoch, device_status_word(), skew, spin)
+        Exl2Call call{(const uint16_t*)x, (const uint32_t*)qw, (const uint16_t*)scales, (const uint16_t*)zeros, (const uint16_t*)perm,
+                      (const uint16_t*)gmap, gran, gen, (uint16_t*)y, rows, M, K, N, cps2, S, colblocks};
+#define L2(MTV, NWV) hipLaunchKernelGGL((exl2_gemv2_kernel<MTV, NWV>), grid2, dim3(NWV * 64), lds2, st, call, epoch, device_status_word(), skew, spin)
         if (nw == 16) {
             if (MT == 1) L2(1, 16); else L2(2, 16);
         } else {
@@ -593,5 +670,137 @@ int mbwq_exl2_forward_launch(const void* x, const int32_t* qw, const void* scale
     }
     return BIE_OK;
 }
+
+
+// ---- a LIST of exl2 layers in one launch --------------------------------------------------------------------------
+int status_report(const char* fn);  // splitk.hip
+
+struct Exl2List {
+    int n = 0, M = 1, max_k = 0;
+    unsigned grid = 0;
+    size_t lds = 0;
+    Exl2Call* d_ent = nullptr;
+    uint2_t* d_blk = nullptr;
+};
+
+static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+
+// column blocks x K slabs, 8-wave workgroups; ~`want` workgroups in all (two per CU and four rounds), a slab at least 4 chunks
+// per wave (the depth of the kernel's prefetch) and at most CPS_MAX chunks (the LDS copy of the slab's q_perm / group map)
+static void exl2_list_plan(int n, const bie_exl2_list_entry* e, std::vector<int>& cps, std::vector<int>& S, long* blocks, size_t* gran_bytes,
+                           size_t* lds, int M) {
+    const int CPS_MAX = 768 / M;
+    long colblocks_all = 0;
+    for (int i = 0; i < n; i++) colblocks_all += cdiv(e[i].N, 64);
+    cps.resize(n); S.resize(n);
+    *blocks = 0; *gran_bytes = 0; *lds = 0;
+    for (int i = 0; i < n; i++) {
+        const int C = e[i].K / 32, cb = cdiv(e[i].N, 64);
+        int want = (int)((2048 + colblocks_all / 2) / colblocks_all);
+        if (want < 1) want = 1;
+        int c = cdiv(cdiv(C, want), 8) * 8;
+        if (c < 32) c = 32;
+        if (c > CPS_MAX) c = CPS_MAX;
+        if (c > C) c = C;
+        cps[i] = c;
+        S[i] = cdiv(C, c);
+        *blocks += (long)cb * S[i];
+        if (S[i] > 1) *gran_bytes += (size_t)(S[i] - 1) * M * cb * 64 * 8;
+        size_t l = M > 1 ? (size_t)c * (32 * M + 2) * sizeof(uint16_t) : (size_t)8 * 4 * M * 32 * sizeof(uint16_t) + (size_t)c * 34 * sizeof(uint16_t);
+        const size_t red = (size_t)8 * M * 64 * sizeof(float);
+        if (l < red) l = red;
+        if (l > *lds) *lds = l;
+    }
+}
+
+static bool exl2_list_ok(int n, const bie_exl2_list_entry* e, int M) {
+    if (n <= 0 || !e || M < 1 || M > 2) return false;
+    for (int i = 0; i < n; i++) {
+        if (e[i].K <= 0 || e[i].N <= 0 || e[i].K % 32 || !e[i].rows7) return false;
+        if (cdiv(e[i].N, 64) >= (1 << 20)) return false;
+    }
+    return true;
+}
+
+size_t exl2_list_device_bytes(int n, const bie_exl2_list_entry* e, int M) {
+    if (!exl2_list_ok(n, e, M)) return 0;
+    std::vector<int> cps, S;
+    long blocks; size_t gran, lds;
+    exl2_list_plan(n, e, cps, S, &blocks, &gran, &lds, M);
+    long tiles = 0;
+    for (int i = 0; i < n; i++) tiles += cdiv(e[i].N, 64);
+    return align256((size_t)n * sizeof(Exl2Call)) + align256((size_t)blocks * 8) + align256((size_t)tiles * 4) + align256(gran);
+}
+
+int exl2_list_create(Exl2List** out, int n, const bie_exl2_list_entry* e, int M, void* device_mem, size_t device_bytes) {
+    BIE_REQUIRE(out && e && device_mem, BIE_ERR_INVALID_ARG, "bie_mbwq_exl2_list_create: NULL argument");
+    BIE_REQUIRE(exl2_list_ok(n, e, M), BIE_ERR_UNSUPPORTED, "bie_mbwq_exl2_list_create: a list takes 1 <= M <= 2 and K %% 32 == 0 (fp16 only)");
+    for (int i = 0; i < n; i++) {
+        BIE_REQUIRE(e[i].x && e[i].qweight && e[i].scales && e[i].zeros && e[i].q_group_map && e[i].y, BIE_ERR_INVALID_ARG, "bie_mbwq_exl2_list_create: NULL tensor pointer in entry %d", i);
+        int prev = 0;
+        for (int b = 0; b < 6; b++) {
+            BIE_REQUIRE(e[i].rows7[b] >= prev && e[i].rows7[b] % 32 == 0, BIE_ERR_UNSUPPORTED, "bie_mbwq_exl2_list_create: entry %d: band boundary rows[%d]=%d must be a non-decreasing multiple of 32", i, b, e[i].rows7[b]);
+            prev = e[i].rows7[b];
+        }
+        BIE_REQUIRE(e[i].rows7[5] == e[i].K, BIE_ERR_INVALID_ARG, "bie_mbwq_exl2_list_create: entry %d: rows[5]=%d must equal K=%d", i, e[i].rows7[5], e[i].K);
+    }
+    BIE_REQUIRE((reinterpret_cast<uintptr_t>(device_mem) & 255) == 0, BIE_ERR_INVALID_ARG, "bie_mbwq_exl2_list_create: the device buffer must be 256-byte aligned");
+    std::vector<int> cps, S;
+    long blocks; size_t gran, lds;
+    exl2_list_plan(n, e, cps, S, &blocks, &gran, &lds, M);
+    long tiles = 0;
+    for (int i = 0; i < n; i++) tiles += cdiv(e[i].N, 64);
+    const size_t o_blk = align256((size_t)n * sizeof(Exl2Call)), o_gen = o_blk + align256((size_t)blocks * 8), o_gran = o_gen + align256((size_t)tiles * 4);
+    const size_t o_xp = o_gran + align256(gran);
+    BIE_REQUIRE(device_bytes >= o_xp, BIE_ERR_WORKSPACE, "bie_mbwq_exl2_list_create: device buffer of %zu bytes required, got %zu", o_xp, device_bytes);
+    char* base = static_cast<char*>(device_mem);
+    std::vector<Exl2Call> he(n);
+    std::vector<uint2_t> hb((size_t)blocks);
+    size_t b = 0, go = o_gran;
+    long t0 = 0;
+    int max_k = 0;
+    for (int i = 0; i < n; i++) {
+        Exl2Call& c = he[i];
+        const int cb = cdiv(e[i].N, 64);
+        c.x = (const uint16_t*)e[i].x;
+        if (e[i].K > max_k) max_k = e[i].K;
+        c.qw = (const uint32_t*)e[i].qweight; c.scales = (const uint16_t*)e[i].scales; c.zeros = (const uint16_t*)e[i].zeros;
+        c.perm = (const uint16_t*)e[i].q_perm; c.gmap = (const uint16_t*)e[i].q_group_map; c.y = (uint16_t*)e[i].y;
+        c.gran = S[i] > 1 ? reinterpret_cast<unsigned long long*>(base + go) : nullptr;
+        if (S[i] > 1) go += (size_t)(S[i] - 1) * M * cb * 64 * 8;
+        c.gen = reinterpret_cast<unsigned*>(base + o_gen) + t0;
+        for (int k = 0; k < 6; k++) c.rows.r[k] = e[i].rows7[k];
+        c.M = M; c.K = e[i].K; c.N = e[i].N; c.chunks_per_slab = cps[i]; c.S = S[i]; c.colblocks = cb;
+        BIE_REQUIRE(S[i] < 4096, BIE_ERR_UNSUPPORTED, "bie_mbwq_exl2_list_create: entry %d needs %d K slabs (< 4096)", i, S[i]);
+        for (int sl = 0; sl < S[i]; sl++)
+            for (int t = 0; t < cb; t++) hb[b++] = uint2_t{(uint32_t)i, (uint32_t)t | ((uint32_t)sl << 20)};
+        t0 += cb;
+    }
+    hipError_t err = hipMemset(base + o_gen, 0, o_xp - o_gen);
+    if (err == hipSuccess) err = hipMemcpy(base, he.data(), (size_t)n * sizeof(Exl2Call), hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemcpy(base + o_blk, hb.data(), (size_t)blocks * 8, hipMemcpyHostToDevice);
+    BIE_REQUIRE(err == hipSuccess, BIE_ERR_HIP, "bie_mbwq_exl2_list_create: uploading the plan: %s", hipGetErrorString(err));
+    Exl2List* pl = new Exl2List();
+    pl->n = n; pl->M = M; pl->grid = (unsigned)blocks; pl->lds = lds; pl->max_k = max_k;
+    pl->d_ent = reinterpret_cast<Exl2Call*>(base);
+    pl->d_blk = reinterpret_cast<uint2_t*>(base + o_blk);
+    *out = pl;
+    return BIE_OK;
+}
+
+int exl2_list_forward(Exl2List* p, hipStream_t st) {
+    BIE_REQUIRE(p, BIE_ERR_INVALID_ARG, "bie_mbwq_exl2_list_forward: NULL plan");
+    int rc = status_report("bie_mbwq_exl2_list_forward");
+    if (rc) return rc;
+    unsigned skew;
+    int spin;
+    test_forge_get(&skew, &spin);
+    const unsigned epoch = next_launch_epoch();
+    if (p->M == 1) hipLaunchKernelGGL((exl2_list_kernel<1>), dim3(p->grid), dim3(512), p->lds, st, p->d_ent, p->d_blk, epoch, device_status_word(), skew, spin);
+    else hipLaunchKernelGGL((exl2_list_kernel<2>), dim3(p->grid), dim3(512), p->lds, st, p->d_ent, p->d_blk, epoch, device_status_word(), skew, spin);
+    return check_launch("exl2_list_kernel");
+}
+
+void exl2_list_destroy(Exl2List* p) { delete p; }
 
 }  // namespace bie

@@ -205,6 +205,31 @@ int bie_mbwq_exl2_forward(const void* x, const int32_t* qweight, const void* sca
                           const int* rows7_host, void* y, void* workspace, size_t workspace_bytes,
                           int M, int K, int N, int groups, void* stream);
 
+/* A LIST of exl2 decode layers (M <= 2, fp16) in ONE launch: entry i is exactly one bie_mbwq_exl2_forward call (its own x, packed
+ * matrix, band table, q_perm / q_group_map, y).  A 4096x4096 3/2-bit layer is 5 MB -- a lone launch of that size never leaves its
+ * start-up transient (0.13-0.17 of the HBM roofline per layer launch); the list form walks the column blocks of every layer in one
+ * grid.  Same contract as bie_mpq_list_*: caller-allocated device buffer of bie_mbwq_exl2_list_device_bytes, create uploads the
+ * tables (blocking, not capturable), forward is one stream-ordered capturable launch, destroy frees the host handle.
+ * No reference counterpart (one gemm_half_q_half_kernel launch per layer, mbwq_linear_cuda_kernel.cu:926-1007). */
+typedef struct bie_exl2_list bie_exl2_list_t;
+typedef struct {
+    const void* x;              /* [M, K] fp16 */
+    const int32_t* qweight;     /* [rows_packed, N] */
+    const void* scales;         /* [groups, N] fp16 */
+    const void* zeros;          /* [groups, N] fp16 */
+    const int16_t* q_perm;      /* [K] or NULL */
+    const int16_t* q_group_map; /* [2K] device */
+    const int* rows7;           /* HOST band table of bie_mbwq_rows (read during create) */
+    void* y;                    /* [M, N] fp16 */
+    int K, N;
+    int reserved0, reserved1;   /* 0 */
+} bie_exl2_list_entry;
+size_t bie_mbwq_exl2_list_device_bytes(int n_entries, const bie_exl2_list_entry* entries, int M);
+int bie_mbwq_exl2_list_create(bie_exl2_list_t** plan, int n_entries, const bie_exl2_list_entry* entries, int M, void* device_mem,
+                              size_t device_bytes);
+int bie_mbwq_exl2_list_forward(bie_exl2_list_t* plan, void* stream);
+void bie_mbwq_exl2_list_destroy(bie_exl2_list_t* plan);
+
 /* ------------------------------------------------------------------------------------------ */
 /* Binary (1-bit W / 1-bit A) linear + conv2d, XNOR-popcount                                     */
 /* ------------------------------------------------------------------------------------------ */

@@ -1418,3 +1418,45 @@ def test_binary_linear_cutlass_mm_and_batched_matmul_follow_the_reference_signat
     pb = ((512 - 2 * ref) / 2).to(torch.bfloat16)  # signs are unchanged by the bf16 cast of x / y (no zeros in randn)
     refb = (torch.tensor(512.0) - 2 * pb.float()).to(torch.bfloat16) * torch.tensor(0.5, dtype=torch.bfloat16)
     assert outb.dtype == torch.bfloat16 and torch.equal(outb.cpu(), refb)
+
+
+@pytest.mark.parametrize("M", [1, 2])
+def test_exl2_list_forward_equals_the_per_layer_calls(M):
+    """bie_mbwq_exl2_list_*: several mixed-bit layers (different K / N / band tables, with and without q_perm) in ONE launch must
+    give, entry by entry, exactly what bie_mbwq_exl2_forward gives (same kernel body, same slab plan or not: the fp32 sums
+    are added in chunk order inside a wave and in wave / slab order across them, so a different slab plan may differ in the last
+    bit -- hence oracle tolerance for both and exact equality between two launches of the same plan)."""
+    from bitorch_engine.extensions import q_linear_cuda
+    from bitorch_engine.layers.qlinear.nbit.cuda import MBWQExl2ForwardList
+    from bitorch_engine.layers.qlinear.nbit.cuda.utils import make_group_map
+    g = np.load(os.path.join(GOLDEN, "exl2_group_maps.npz"))
+    cfgs = sorted(k[:-5] for k in g.files if k.endswith("_meta"))
+    entries, refs = [], []
+    for i, cfg in enumerate(cfgs + cfgs[:2]):
+        K, groups, rows_packed = [int(v) for v in g[cfg + "_meta"]]
+        q_groups = torch.from_numpy(g[cfg + "_q_groups"])
+        N = (200, 64, 328, 136, 520, 72)[i % 6]
+        rng = np.random.default_rng(K + M + i)
+        gen = torch.Generator().manual_seed(K + M + i)
+        qw = torch.from_numpy(rng.integers(-2 ** 31, 2 ** 31 - 1, (rows_packed, N), dtype=np.int64).astype(np.int32))
+        scales = (torch.rand((groups, N), generator=gen) * 0.02 + 0.001).half()
+        zeros = (torch.randn((groups, N), generator=gen) * 0.1).half()
+        q_perm = torch.randperm(K, generator=gen).to(torch.short) if i % 3 != 2 else None
+        gmap = make_group_map(q_groups, rows_packed)
+        _, rows = q_linear_cuda.mbwq_trans_qweight(qw, q_groups, True, K, groups, 4)
+        x = torch.randn((M, K), generator=gen).half()
+        Wo = orc.exl2_dequant(qw.numpy(), orc.torch_to_np(scales), orc.torch_to_np(zeros), None if q_perm is None else q_perm.numpy(), q_groups.numpy(), K)
+        refs.append(t16(orc.gemm(orc.torch_to_np(x), Wo, orc.F16), orc.F16))
+        entries.append({"x": x.to(DEV), "qweight": qw.to(DEV), "scales": scales.to(DEV), "zeros": zeros.to(DEV),
+                        "q_perm": None if q_perm is None else q_perm.to(DEV), "q_group_map": gmap.to(DEV), "rows": rows,
+                        "y": torch.full((M, N), float("nan"), dtype=torch.float16, device=DEV)})
+    plan = MBWQExl2ForwardList(entries)
+    plan()
+    torch.cuda.synchronize()
+    first = [e["y"].clone() for e in entries]
+    for i, (e, r) in enumerate(zip(entries, refs)):
+        assert_close(e["y"], r, orc.F16, f"exl2 list entry {i} M={M}")
+    plan()
+    torch.cuda.synchronize()
+    for i, e in enumerate(entries):
+        assert torch.equal(e["y"], first[i]), f"exl2 list entry {i}: second launch differs"
