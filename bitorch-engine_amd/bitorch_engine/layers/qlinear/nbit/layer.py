@@ -30,9 +30,12 @@ class MPQWeightParameter(nn.Parameter):
             setattr(self, name, meta.get(name, _QDEFAULTS.get(name)))
 
     @staticmethod
-    def update(qweight, *args, **kwargs):
-        raise NotImplementedError("MPQWeightParameter.update (DiodeMix training step, reference "
-                                  "utils/model_helper.py:363-532) is outside the inference hot path of this build")
+    def update(qweight, exp_avg_s=None, exp_avg_l=None, step=None, lr=1e-4, weight_decay=0.0, beta1=0.99, beta2=0.9999, eps=1e-6,
+               dtype=torch.half, correct_bias=None, projector=None, grad=None) -> None:
+        """The optimizer-side re-pack step (reference nbit/layer.py:86-119 -> utils/model_helper.py:363-532), on the device."""
+        from bitorch_engine.utils.model_helper import qweight_update_fn
+        qweight_update_fn(qweight=qweight, exp_avg_s=exp_avg_s, exp_avg_l=exp_avg_l, step=step, lr=lr, weight_decay=weight_decay,
+                          beta1=beta1, beta2=beta2, eps=eps, dtype=dtype, correct_bias=correct_bias, projector=projector, grad=grad)
 
 
 def _groups(k, g):

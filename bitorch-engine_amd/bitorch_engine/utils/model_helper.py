@@ -1,6 +1,7 @@
 """Helpers either side of the hot path, mirroring reference utils/model_helper.py: flatten_x / unflatten_x (:10-51),
 pad_embedding_dim (:54-82), pad_last_2_dims_to_multiple_of_128 (:85-117), binary_matmul_forward_post_processing (:120-155),
 prepare_bie_layers (:158-196), pack_bie_layers / save_checkpoint / load_checkpoint (:199-283), init_weight (:286-327)."""
+import math
 from typing import Tuple, Type
 
 import torch
@@ -104,3 +105,86 @@ def init_weight(weight: torch.Tensor, cls: Type[torch.nn.Parameter] = torch.nn.P
     carriers = nv_tensor_quant(centred)[0]
     carriers = torch.where(carriers == 0, centred.sign(), carriers)
     return cls(carriers.to(torch.int8), requires_grad=False), scale_w
+
+
+def _unpack_gptq_zeros(qzeros: torch.Tensor, w_bit: int, n_cols: int) -> torch.Tensor:
+    """int32 [G, N*w/32] packed along N -> integer zeros + 1, [G, N] (the zeros half of gptq_style_unpacking,
+    reference utils/quant_operators.py:326-331)."""
+    wf = torch.arange(0, 32, w_bit, dtype=torch.int32, device=qzeros.device)
+    z = torch.bitwise_right_shift(qzeros.unsqueeze(2).expand(-1, -1, 32 // w_bit), wf.view(1, 1, -1))
+    z = torch.bitwise_and(z, (2 ** w_bit) - 1) + 1
+    return z.reshape(-1, n_cols)
+
+
+def _pack_gptq_zeros(zeros: torch.Tensor, w_bit: int, out_features: int) -> torch.Tensor:
+    """gptq_style_zeros_packing (reference utils/quant_operators.py:348-368): truncation to int32, stored value - 1."""
+    z = zeros.reshape(zeros.shape[0], math.ceil(out_features // 32 * w_bit), 32 // w_bit).to(torch.int32)
+    wf = torch.arange(0, 32, w_bit, device=zeros.device, dtype=torch.int32)
+    z = torch.bitwise_and(z - 1, (2 ** w_bit) - 1)
+    return torch.bitwise_left_shift(z, wf.view(1, 1, -1)).sum(dim=-1).to(torch.int32)
+
+
+def _add_scaled_(t: torch.Tensor, other: torch.Tensor, alpha: float) -> torch.Tensor:
+    """`t.add_(other, alpha=alpha)` with the rounding of torch's CPU kernel, which is what the reference's update runs on and what the
+    golden vectors pin: for fp16 / bf16 tensors the scalar `alpha` is first rounded to the TENSOR dtype, then t + alpha * other is
+    evaluated in fp32 (the product of two 16-bit floats is exact there, so fused or not does not matter) and rounded once.  The GPU
+    kernel of the same torch op keeps alpha in fp32 -- a third of the first-moment elements then differ in the last bit."""
+    if t.dtype in (torch.float16, torch.bfloat16):
+        a = float(torch.tensor(alpha, dtype=t.dtype))
+        return t.copy_((t.float() + a * other.float()).to(t.dtype))
+    return t.add_(other, alpha=alpha)
+
+
+def qweight_update_fn(qweight: torch.nn.Parameter, exp_avg_s: torch.Tensor = None, exp_avg_l: torch.Tensor = None, step: torch.Tensor = None,
+                      lr: float = 1e-4, weight_decay: float = 0.0, beta1: float = 0.99, beta2: float = 0.9999, eps: float = 1e-6,
+                      dtype=torch.half, correct_bias=None, projector=None, grad: torch.Tensor = None) -> None:
+    """The DiodeMix re-pack step of a quantised parameter, ON THE DEVICE: unpack -> Adam moments -> update -> (every fifth step)
+    zero-point update -> pack.  Mirror of the reference's qweight_update_fn (utils/model_helper.py:363-532) for
+    MPQWeightParameter in the GPTQ form (asym, explicit g_idx, layer_type 1) -- the case the reference executes: its symmetric
+    g_idx branch returns an unassigned `zeros` (quant_operators.py:341-343) and the no-g_idx branch needs an MBWQ q_perm.
+    The unpack is the HIP dequant kernel (bie_mpq_dequant == gptq_style_unpacking here: s * (q - (zq + 1)), one rounding), the pack
+    the HIP pack kernel (bie_mpq_pack == pack_fp_weight: round(w / s + z), clamp, bit-pack); the moment arithmetic in between is
+    the reference's own sequence of torch elementwise ops in `dtype`, op for op, so every rounding lands where the reference's does
+    (pinned to reference outputs: tests/golden/update_step.npz).  Like the reference, pack_fp_weight sees the zero points from
+    BEFORE this step's update_zeros."""
+    from bitorch_engine.extensions import q_linear_cuda
+    from bitorch_engine.layers.qlinear.nbit.layer import MPQWeightParameter
+    step.add_(1)
+    if not isinstance(qweight, MPQWeightParameter):
+        raise NotImplementedError("qweight_update_fn: only MPQWeightParameter is updated by this build (the binary / n-bit integer parameters need "
+                                  "the reference's custom torch with gradients on integer tensors)")
+    if not (qweight.layer_type == 1 and qweight.asym and qweight.g_idx is not None):
+        raise NotImplementedError("qweight_update_fn: MPQWeightParameter is updated in its GPTQ form (layer_type 1, asym, g_idx), the form the "
+                                  "reference's own update executes")
+    w_bit, gs = qweight.w_bit, qweight.group_size
+    scales, qzeros, g_idx = qweight.scales, qweight.zeros, qweight.g_idx
+    K, N = g_idx.numel(), qweight.shape[1]
+    w = q_linear_cuda.mpq_dequant(qweight.data, scales, qzeros, g_idx, w_bit, True, gs).to(dtype)  # == gptq_style_unpacking(qweight)[0]
+    _add_scaled_(exp_avg_l.mul_(beta1), grad, 1.0 - beta1)
+    # t.addcmul_(g, g, value) as torch's CPU kernel evaluates it: t + (value * g) * g, left to right in fp32 (every product and the
+    # sum rounded to fp32, `value` kept in fp32), then one rounding to dtype.  Separate eager ops: no fused multiply-add can sneak
+    # in.  (The GPU kernel of the op differs for bf16: the reference vectors caught it.)
+    exp_avg_s.mul_(beta2)
+    g32 = grad.float()
+    exp_avg_s.copy_((exp_avg_s.float() + ((1.0 - beta2) * g32) * g32).to(exp_avg_s.dtype))
+    denom = exp_avg_s.sqrt().add_(eps)
+    step_size = lr
+    if correct_bias:
+        bias_correction1 = 1.0 - beta1 ** step.item()
+        bias_correction2 = 1.0 - beta2 ** step.item()
+        step_size = step_size * math.sqrt(bias_correction2) / bias_correction1
+    norm_grad = exp_avg_l / denom
+    if projector is not None:
+        norm_grad = projector.project_back(norm_grad.to(dtype))
+    _add_scaled_(w, norm_grad, -step_size)
+    new_zeros = None
+    if step % 5 == 0:  # update_zeros, layer_type 1 with g_idx (reference model_helper.py:346-356)
+        gl = g_idx.long()
+        zeros_unpack = _unpack_gptq_zeros(qzeros, w_bit, N).to(dtype)[gl]
+        zeros_unpack.add_(step_size * norm_grad)
+        perm = torch.argsort(gl, dim=0)
+        zeros = zeros_unpack[perm, :].view(-1, K // scales.size(0), scales.size(-1)).mean(1)
+        new_zeros = _pack_gptq_zeros(zeros, w_bit, zeros.size(-1))
+    qweight.data = q_linear_cuda.mpq_pack(w, scales, qzeros, g_idx, w_bit, True, gs)  # the zero points from before update_zeros, as the reference
+    if new_zeros is not None:
+        qweight.zeros = new_zeros

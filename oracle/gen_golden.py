@@ -95,6 +95,38 @@ def tonp(t):
     return t.detach().cpu().contiguous().numpy()
 
 
+def update_step_vectors():
+    from bitorch_engine.layers.qlinear.nbit.layer import MPQWeightParameter
+    from bitorch_engine.utils.model_helper import qweight_update_fn
+    out = {}
+    K, N, w_bit, gs = 128, 64, 4, 32
+    for tag, dtype in (("f16", torch.float16), ("bf16", torch.bfloat16)):
+        for order in ("trivial", "actorder"):
+            g = torch.Generator().manual_seed(31 + len(tag) + len(order))
+            qweight = torch.randint(-2 ** 31, 2 ** 31 - 1, (K * w_bit // 32, N), generator=g, dtype=torch.int64).to(torch.int32)
+            scales = (torch.rand((K // gs, N), generator=g) * 0.01 + 0.005).to(dtype)
+            qzeros = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // gs, N * w_bit // 32), generator=g, dtype=torch.int64).to(torch.int32)
+            g_idx = torch.arange(K, dtype=torch.int32) // gs
+            if order == "actorder":
+                g_idx = g_idx[torch.randperm(K, generator=g)]
+            p = MPQWeightParameter(qweight.clone(), requires_grad=False, scales=scales.clone(), zeros=qzeros.clone(), g_idx=g_idx.clone(),
+                                   w_bit=w_bit, asym=True, group_size=gs, layer_type=1)
+            exp_l, exp_s = torch.zeros((K, N), dtype=dtype), torch.zeros((K, N), dtype=dtype)
+            step = torch.tensor(0.0)
+            key = f"{tag}_{order}"
+            out[key + "_qweight0"], out[key + "_scales"], out[key + "_qzeros0"], out[key + "_g_idx"] = tonp(qweight), tonp(scales), tonp(qzeros), tonp(g_idx)
+            for it in range(1, 6):
+                grad = (torch.randn((K, N), generator=g) * 0.02).to(dtype)
+                out[f"{key}_grad{it}"] = tonp(grad)
+                qweight_update_fn(p, exp_avg_s=exp_s, exp_avg_l=exp_l, step=step, lr=2e-3, weight_decay=0.0, beta1=0.9, beta2=0.99, eps=1e-6,
+                                  dtype=dtype, correct_bias=(it % 2 == 0), projector=None, grad=grad)
+                out[f"{key}_qweight{it}"] = tonp(p.data)
+                out[f"{key}_exp_l{it}"], out[f"{key}_exp_s{it}"] = tonp(exp_l).copy(), tonp(exp_s).copy()  # snapshots: the moments are updated in place
+            out[key + "_qzeros5"] = tonp(p.zeros)
+            out[key + "_meta"] = np.array([K, N, w_bit, gs])
+    return out
+
+
 def extension_signatures():
     import glob
     import re
@@ -343,6 +375,10 @@ def main():
     np.savez_compressed(os.path.join(OUT, "helpers.npz"), **hp)
     manifest["mpq_configs"] = {k: get_mpq_config(k) for k in (None, "2-8-32", "2-32-32", "2-128-32", "4-128-256", "8-128-256")}
     manifest["mpq_configs"] = {str(k): v for k, v in manifest["mpq_configs"].items()}
+
+    # ---- the DiodeMix re-pack step, MPQWeightParameter.update -> qweight_update_fn (utils/model_helper.py:363-532) on a
+    # GPTQ-style (asym, g_idx) parameter: five steps each (step 5 also runs update_zeros), trivial and permuted g_idx, fp16 and bf16
+    np.savez_compressed(os.path.join(OUT, "update_step.npz"), **update_step_vectors())
 
     # ---- the extension modules' boundary: name and positional parameter list of every function the reference binds with pybind11
     # (m.def("name", &fn)), read off the reference's own C++ definitions.  Data only (names), consumed by tests/test_boundary_cpu.py.

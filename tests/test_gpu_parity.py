@@ -1509,3 +1509,32 @@ def test_exl2_list_forward_equals_the_per_layer_calls(M):
     torch.cuda.synchronize()
     for i, e in enumerate(entries):
         assert torch.equal(e["y"], first[i]), f"exl2 list entry {i}: second launch differs"
+
+
+@pytest.mark.parametrize("key", ["f16_trivial", "f16_actorder", "bf16_trivial", "bf16_actorder"])
+def test_qweight_update_step_bit_exact_vs_reference(key):
+    """MPQWeightParameter.update -> qweight_update_fn on the device (HIP unpack + Adam moments + HIP re-pack) against
+    vectors produced by the REFERENCE's own qweight_update_fn on the CPU (tests/golden/update_step.npz, oracle/gen_golden.py): five
+    consecutive steps on a GPTQ-style parameter, bias correction on the even steps, the zero-point update on step 5.  Packed
+    weights, both moment tensors and the re-packed qzeros must be identical bit for bit after every step."""
+    from bitorch_engine.layers.qlinear.nbit.layer import MPQWeightParameter
+    g = np.load(os.path.join(GOLDEN, "update_step.npz"))
+    dtype = torch.float16 if key.startswith("f16") else torch.bfloat16
+    K, N, w_bit, gs = [int(v) for v in g[key + "_meta"]]
+    as_dt = lambda a: torch.from_numpy(a.view(np.int16).copy()).view(dtype)
+    p = MPQWeightParameter(torch.from_numpy(g[key + "_qweight0"]).to(DEV), scales=as_dt(g[key + "_scales"]).to(DEV),
+                           zeros=torch.from_numpy(g[key + "_qzeros0"]).to(DEV), g_idx=torch.from_numpy(g[key + "_g_idx"]).to(DEV),
+                           w_bit=w_bit, asym=True, group_size=gs, layer_type=1)
+    exp_l = torch.zeros((K, N), dtype=dtype, device=DEV)
+    exp_s = torch.zeros((K, N), dtype=dtype, device=DEV)
+    step = torch.tensor(0.0)
+    for it in range(1, 6):
+        grad = as_dt(g[f"{key}_grad{it}"]).to(DEV)
+        MPQWeightParameter.update(p, exp_avg_s=exp_s, exp_avg_l=exp_l, step=step, lr=2e-3, weight_decay=0.0, beta1=0.9, beta2=0.99, eps=1e-6,
+                                  dtype=dtype, correct_bias=(it % 2 == 0), projector=None, grad=grad)
+        assert np.array_equal(orc.torch_to_np(exp_l), g[f"{key}_exp_l{it}"]), f"{key}: first moment differs after step {it}"
+        assert np.array_equal(orc.torch_to_np(exp_s), g[f"{key}_exp_s{it}"]), f"{key}: second moment differs after step {it}"
+        got, want = p.data.cpu().numpy(), g[f"{key}_qweight{it}"]
+        assert np.array_equal(got, want), f"{key}: packed weights differ after step {it} ({(got != want).sum()} of {want.size} words)"
+    assert np.array_equal(p.zeros.cpu().numpy(), g[key + "_qzeros5"]), f"{key}: re-packed qzeros differ after the step-5 zero-point update"
+    assert float(step) == 5.0
