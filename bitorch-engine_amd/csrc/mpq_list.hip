@@ -84,10 +84,10 @@ __device__ __forceinline__ float list_lut_entry(uint32_t q, float s, float z, in
 constexpr unsigned BIE_STATUS_REDUCER_TIMEOUT = 1u, BIE_STATUS_DEP_TIMEOUT = 2u;
 
 // VAR bit 0: v_pk_fma_f32 pairs; bit 1 (tuning aid): stream only -- rows, constants and x are loaded, nothing is looked up;
-// bit 2: registers capped at 64 (four workgroups = 32 waves per CU instead of three)
+// bit 2: registers capped at 64 (four workgroups = 32 waves per CU instead of three); bit 3: four waves per workgroup instead of eight
 template <int DT, int ZM, int MT, int RPG, int WB, int VAR>
-__global__ __launch_bounds__(512, ((VAR & 4) ? 8 : 1)) void mpq_list_kernel(const ListArgs a) {
-    constexpr int NW = 8;
+__global__ __launch_bounds__(((VAR & 8) ? 256 : ((VAR & 16) ? 128 : ((VAR & 32) ? 64 : 512))), ((VAR & 4) ? 8 : 1)) void mpq_list_kernel(const ListArgs a) {
+    constexpr int NW = (VAR & 8) ? 4 : ((VAR & 16) ? 2 : ((VAR & 32) ? 1 : 8));  // bits 4 / 5 (tuning aids): two / one wave per workgroup
     constexpr int NB = 32 / WB;      // weights per packed word
     constexpr int XD = NB / 2;       // x dwords (16-bit pairs) per packed word
     constexpr bool PK = (VAR & 1) != 0 && WB == 4 && DT == BIE_BF16;
@@ -448,6 +448,7 @@ struct ListPlanEntry { int rpg, G, gpw, S, H, tiles; };
 struct MpqList {
     int n = 0, M = 1, w_bit = 4, group_size = 128, zm = 0, dtype = BIE_BF16;
     int rpg = 16;              // rows per unit (common to the list: one kernel instance)
+    int nw = 8;                // waves per workgroup
     unsigned grid = 0;
     bool has_deps = false;
     ListEntry* d_ent = nullptr;
@@ -460,7 +461,17 @@ struct MpqList {
 // of one when the list is too small to fill the chip); 8 waves per workgroup; a column tile's K range is split over S
 // workgroups.  Big lists: S = 1 (no cross-workgroup reduction at all), every wave walks several units with the next unit's
 // rows in flight.  Small lists: units are split (H) and K is sliced (S) until ~`want` waves exist.
-static void list_plan(int n, const bie_mpq_list_entry* ent, int w_bit, int group_size, int* rpg_out, std::vector<ListPlanEntry>& pe) {
+// Waves per workgroup.  W4 at M = 1: FOUR (a wave then walks twice as many units: the per-wave prologue -- descriptor loads, first
+// table -- and the workgroup barriers are amortised over more weights; measured 2.02-2.04 us per 4096x4096 layer against 2.09-2.15
+// with eight, 2.2 / 2.1 with two / one: profiles/r03_p_list_nw.txt).  Everything else: eight.  BIE_LIST_NW (tuning aid, lab
+// configuration only) overrides.
+static int list_nw(int M, int w_bit) {
+    static const int nw = list_env("BIE_LIST_NW", 0);
+    if (nw == 8 || nw == 4 || nw == 2 || nw == 1) return nw;
+    return (M == 1 && w_bit == 4) ? 4 : 8;
+}
+
+static void list_plan(int n, const bie_mpq_list_entry* ent, int w_bit, int group_size, int* rpg_out, std::vector<ListPlanEntry>& pe, int nw = 8) {
     static const int want = list_env("BIE_LIST_WANT_WAVES", 6144);
     static const int force_h = list_env("BIE_LIST_H", 0);
     static const int max_gpw = list_env("BIE_LIST_MAX_GPW", 16);
@@ -492,11 +503,11 @@ static void list_plan(int n, const bie_mpq_list_entry* ent, int w_bit, int group
         p.G = (ent[i].K / gs) * p.H;
         p.tiles = cdiv(ent[i].N, 64);
         int gpw = (int)gpw_global;
-        const int per_wave_all = cdiv(p.G, 8);  // S = 1
+        const int per_wave_all = cdiv(p.G, nw);  // S = 1
         if (gpw > per_wave_all) gpw = per_wave_all;
-        p.S = cdiv(p.G, gpw * 8);
-        p.gpw = cdiv(p.G, p.S * 8);     // even out
-        p.S = cdiv(p.G, p.gpw * 8);
+        p.S = cdiv(p.G, gpw * nw);
+        p.gpw = cdiv(p.G, p.S * nw);     // even out
+        p.S = cdiv(p.G, p.gpw * nw);
     }
     *rpg_out = rpg;
 }
@@ -548,8 +559,13 @@ size_t mpq_list_device_bytes(int n, const bie_mpq_list_entry* ent, int M, int w_
     if (!list_shape_ok(n, ent, M, w_bit, group_size)) return 0;
     std::vector<ListPlanEntry> pe;
     int rpg;
-    list_plan(n, ent, w_bit, group_size, &rpg, pe);
-    return list_layout(n, pe, M).total;
+    size_t need = 0;
+    for (int nw : {8, 4, 2, 1}) {  // the dtype / zero mode decide the plan (tuning overrides apply to one configuration only): size for the largest
+        list_plan(n, ent, w_bit, group_size, &rpg, pe, nw);
+        const size_t b = list_layout(n, pe, M).total;
+        if (b > need) need = b;
+    }
+    return need;
 }
 
 int mpq_list_create(MpqList** out, int n, const bie_mpq_list_entry* ent, int M, int w_bit, int group_size, int asym, int dtype,
@@ -571,6 +587,9 @@ int mpq_list_create(MpqList** out, int n, const bie_mpq_list_entry* ent, int M, 
     std::vector<ListPlanEntry> pe;
     int rpg;
     list_plan(n, ent, w_bit, group_size, &rpg, pe);
+    int nw = (M == 1 && w_bit == 4) ? 4 : 8;
+    if (dtype == BIE_BF16 && !asym && M == 1 && rpg == 16 && w_bit == 4) nw = list_nw(M, w_bit);  // the lab configuration takes the override
+    list_plan(n, ent, w_bit, group_size, &rpg, pe, nw);
     const ListLayout L = list_layout(n, pe, M);
     BIE_REQUIRE(device_bytes >= L.total, BIE_ERR_WORKSPACE, "bie_mpq_list_create: device buffer of %zu bytes required, got %zu", L.total, device_bytes);
     BIE_REQUIRE((reinterpret_cast<uintptr_t>(device_mem) & 255) == 0, BIE_ERR_INVALID_ARG, "bie_mpq_list_create: the device buffer must be 256-byte aligned");
@@ -630,6 +649,7 @@ int mpq_list_create(MpqList** out, int n, const bie_mpq_list_entry* ent, int M, 
     MpqList* pl = new MpqList();
     pl->n = n; pl->M = M; pl->w_bit = w_bit; pl->group_size = group_size; pl->zm = asym ? ZM_ASYM : ZM_SYM; pl->dtype = dtype;
     pl->rpg = rpg;
+    pl->nw = nw;
     pl->grid = L.grid;
     pl->has_deps = has_deps;
     pl->d_ent = reinterpret_cast<ListEntry*>(base + L.ent);
@@ -643,15 +663,17 @@ int mpq_list_create(MpqList** out, int n, const bie_mpq_list_entry* ent, int M, 
 void mpq_list_destroy(MpqList* p) { delete p; }
 int mpq_list_launches(const MpqList* p) { return p ? (p->has_deps ? 2 : 1) : 0; }
 
-template <int DT, int ZM, int MT, int WB, int VAR>
+template <int DT, int ZM, int MT, int WB, int VAR0>
 static void list_launch_rpg(const ListArgs& a, int rpg, unsigned grid, hipStream_t st) {
+    constexpr int VAR = VAR0 | ((MT == 1 && WB == 4) ? 8 : 0);  // W4, M = 1: four waves per workgroup (list_nw)
+    constexpr int T = (VAR & 8) ? 256 : 512;
     switch (rpg) {
-        case 4: hipLaunchKernelGGL((mpq_list_kernel<DT, ZM, MT, 4, WB, VAR>), dim3(grid), dim3(512), 0, st, a); break;
-        case 8: hipLaunchKernelGGL((mpq_list_kernel<DT, ZM, MT, 8, WB, VAR>), dim3(grid), dim3(512), 0, st, a); break;
-        case 16: hipLaunchKernelGGL((mpq_list_kernel<DT, ZM, MT, 16, WB, VAR>), dim3(grid), dim3(512), 0, st, a); break;
+        case 4: hipLaunchKernelGGL((mpq_list_kernel<DT, ZM, MT, 4, WB, VAR>), dim3(grid), dim3(T), 0, st, a); break;
+        case 8: hipLaunchKernelGGL((mpq_list_kernel<DT, ZM, MT, 8, WB, VAR>), dim3(grid), dim3(T), 0, st, a); break;
+        case 16: hipLaunchKernelGGL((mpq_list_kernel<DT, ZM, MT, 16, WB, VAR>), dim3(grid), dim3(T), 0, st, a); break;
         default:
-            if constexpr (WB == 4) hipLaunchKernelGGL((mpq_list_kernel<DT, ZM, MT, 32, WB, VAR>), dim3(grid), dim3(512), 0, st, a);
-            else hipLaunchKernelGGL((mpq_list_kernel<DT, ZM, MT, 16, WB, VAR>), dim3(grid), dim3(512), 0, st, a);
+            if constexpr (WB == 4) hipLaunchKernelGGL((mpq_list_kernel<DT, ZM, MT, 32, WB, VAR>), dim3(grid), dim3(T), 0, st, a);
+            else hipLaunchKernelGGL((mpq_list_kernel<DT, ZM, MT, 16, WB, VAR>), dim3(grid), dim3(T), 0, st, a);
             break;
     }
 }
@@ -683,11 +705,15 @@ int mpq_list_forward(MpqList* p, hipStream_t st) {
     a.M = p->M;
     static const int var = list_env("BIE_LIST_VAR", 1);  // tuning aid: 0 = scalar FMAs, 1 = v_pk_fma_f32 pairs, 2 / 3 = stream only
     const bool lab_ok = p->dtype == BIE_BF16 && p->zm == ZM_SYM && p->M == 1 && p->rpg == 16 && p->w_bit == 4;
-    if (lab_ok && var != 1) {
-        if (var == 0) hipLaunchKernelGGL((mpq_list_kernel<BIE_BF16, ZM_SYM, 1, 16, 4, 0>), dim3(p->grid), dim3(512), 0, st, a);
-        else if (var == 5) hipLaunchKernelGGL((mpq_list_kernel<BIE_BF16, ZM_SYM, 1, 16, 4, 5>), dim3(p->grid), dim3(512), 0, st, a);
-        else if (var == 4) hipLaunchKernelGGL((mpq_list_kernel<BIE_BF16, ZM_SYM, 1, 16, 4, 4>), dim3(p->grid), dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((mpq_list_kernel<BIE_BF16, ZM_SYM, 1, 16, 4, 3>), dim3(p->grid), dim3(512), 0, st, a);
+    if (lab_ok && p->nw != 4) {
+        if (p->nw == 8) hipLaunchKernelGGL((mpq_list_kernel<BIE_BF16, ZM_SYM, 1, 16, 4, 1>), dim3(p->grid), dim3(512), 0, st, a);
+        else if (p->nw == 2) hipLaunchKernelGGL((mpq_list_kernel<BIE_BF16, ZM_SYM, 1, 16, 4, 17>), dim3(p->grid), dim3(128), 0, st, a);
+        else hipLaunchKernelGGL((mpq_list_kernel<BIE_BF16, ZM_SYM, 1, 16, 4, 33>), dim3(p->grid), dim3(64), 0, st, a);
+        return check_launch("mpq_list_kernel<nw>");
+    }
+    if (lab_ok && var != 1) {  // tuning variants (four-wave plan): scalar FMAs / stream only
+        if (var == 0) hipLaunchKernelGGL((mpq_list_kernel<BIE_BF16, ZM_SYM, 1, 16, 4, 8>), dim3(p->grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((mpq_list_kernel<BIE_BF16, ZM_SYM, 1, 16, 4, 11>), dim3(p->grid), dim3(256), 0, st, a);
         return check_launch("mpq_list_kernel<lab>");
     }
     if (p->w_bit == 2) {

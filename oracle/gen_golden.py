@@ -19,7 +19,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-OUT = os.path.join(ROOT, "tests", "golden")
+OUT = os.environ.get("BIE_GOLDEN_OUT", os.path.join(ROOT, "tests", "golden"))  # BIE_GOLDEN_OUT: regenerate elsewhere and diff
 REF = os.environ.get("BIE_REFERENCE", "/root/reference")
 
 
