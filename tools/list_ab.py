@@ -45,6 +45,10 @@ def list_case(k, n, nl, per_launch, chain=0, reps=20, seed=1):
 
 
 def main():
+    if len(sys.argv) > 3 and sys.argv[1] == "shape":  # PMC / rocprof passes: one list launch form of one shape, e.g. `shape 4096 11008 40`
+        k, n, nl = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+        print(json.dumps(list_case(k, n, nl, nl, reps=5)))
+        return
     quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
     tag = {k: os.environ.get(k) for k in ("BIE_LIST_VAR", "BIE_LIST_WANT_WAVES", "BIE_LIST_MAX_GPW", "BIE_LIST_H") if os.environ.get(k)}
     out = {"env": tag}
