@@ -83,6 +83,14 @@ __device__ __forceinline__ float list_lut_entry(uint32_t q, float s, float z, in
 
 constexpr unsigned BIE_STATUS_REDUCER_TIMEOUT = 1u, BIE_STATUS_DEP_TIMEOUT = 2u;
 
+#ifdef BIE_LAB_BUILD
+// LAB builds only (make lab; tools/list_timeline.py): per wave {start, first rows landed, lookups done, end, xcc << 32 | hw id, entry << 32 | tile}
+__device__ unsigned long long g_list_stamps[65536 * 6];
+#define BIE_LIST_STAMP(...) __VA_ARGS__
+#else
+#define BIE_LIST_STAMP(...)
+#endif
+
 // VAR bit 0: v_pk_fma_f32 pairs; bit 1 (tuning aid): stream only -- rows, constants and x are loaded, nothing is looked up;
 // bit 2: registers capped at 64 (four workgroups = 32 waves per CU instead of three); bit 3: four waves per workgroup instead of eight
 template <int DT, int ZM, int MT, int RPG, int WB, int VAR>
@@ -298,6 +306,7 @@ __global__ __launch_bounds__(((VAR & 8) ? 256 : ((VAR & 16) ? 128 : ((VAR & 32) 
         }
     };
 
+    BIE_LIST_STAMP(unsigned long long st0 = wall_clock64(); unsigned long long st1 = 0;)
     uint32_t wa[RPG], wb[RPG];
     uint32_t sa = 0, za = 0, sb2 = 0, zb2 = 0;
     if (g0 < g1) {
@@ -330,6 +339,7 @@ __global__ __launch_bounds__(((VAR & 8) ? 256 : ((VAR & 16) ? 128 : ((VAR & 32) 
         __syncthreads();
         asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    BIE_LIST_STAMP(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st1 = wall_clock64();)  // the wave's first two units have landed
     for (int g = g0; g < g1; g += 2) {
         process_group(wa, g, sa, za);
         if (g + 2 < g1) { load_params(g + 2, sa, za); load_group(wa, g + 2); }
@@ -339,6 +349,22 @@ __global__ __launch_bounds__(((VAR & 8) ? 256 : ((VAR & 16) ? 128 : ((VAR & 32) 
         }
     }
 
+    BIE_LIST_STAMP(
+        asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]));
+        {
+            const unsigned long long st2 = wall_clock64();
+            const long wid = (long)blockIdx.x * NW + wave;
+            if (lane == 0 && wid < 65536) {
+                unsigned xcc, hwid;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+                g_list_stamps[wid * 6 + 0] = st0;
+                g_list_stamps[wid * 6 + 1] = st1;
+                g_list_stamps[wid * 6 + 2] = st2;
+                g_list_stamps[wid * 6 + 4] = ((unsigned long long)xcc << 32) | hwid;
+                g_list_stamps[wid * 6 + 5] = ((unsigned long long)rec.x << 32) | (unsigned)tile;
+            }
+        })
     // ---- workgroup reduction through LDS (the tables are dead), wave order --------------------------------------
     // the epilogue's fields of the entry record are read HERE (an opaque copy of its address: loads from the constant address
     // space would otherwise be hoisted to the top and occupy ~20 SGPRs through the main loop, which spills SGPRs as it is)
@@ -432,7 +458,14 @@ __global__ __launch_bounds__(((VAR & 8) ? 256 : ((VAR & 16) ? 128 : ((VAR & 32) 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    BIE_LIST_STAMP(if (lane == 0 && (long)blockIdx.x * NW < 65536) g_list_stamps[(long)blockIdx.x * NW * 6 + 3] = wall_clock64();)
 }
+
+#ifdef BIE_LAB_BUILD
+extern "C" int bie_debug_list_stamps(unsigned long long* out, int n_waves) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_list_stamps), (size_t)n_waves * 6 * sizeof(unsigned long long));
+}
+#endif
 
 
 // ---- host side ---------------------------------------------------------------------------------------------------
