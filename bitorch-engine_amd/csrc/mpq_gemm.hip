@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256, (BM <= 128 ? 2 : 1)) void mpq_gemm_kernel(cons
         dequant_step(wcur, t_begin, 0, bfrag);
         lds_wait_frags<TM>(af0);
     }
-#if BIE_GEMM_LAB == 7
+#ifdef BIE_GEMM_STAMPS
     unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
     unsigned stamp_sum[6] = {0, 0, 0, 0, 0, 0};
 #define BIE_STAMP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stamp_sum[i] += (unsigned)(now_ - stamp_prev); stamp_prev = now_; }
@@ -513,11 +513,18 @@ __global__ __launch_bounds__(256, (BM <= 128 ? 2 : 1)) void mpq_gemm_kernel(cons
             __builtin_amdgcn_sched_barrier(0);  // keep the MFMAs below the issue point of the fragment reads
             // the other x buffer: its last readers finished before the previous barrier.  The DMA pieces and the next tile's loads
             // share the scheduling region of this group's MFMAs (one memory instruction per MFMA shadow)
+#if BIE_GEMM_LAB == 9     // timing experiment: no loads / DMA in the loop at all (stale operands)
+            if (kt < 0) { glds_a(ktn, cur ^ 1, kk); load_wtile<DT, WBIT, ZM, GPT>(wnext, wp, ktn * GEMM_BK, N, gshift); }
+#elif BIE_GEMM_LAB == 8   // timing experiment: everything the first group issues moves to the second and third
+            if constexpr (GLDS) { if (kk >= 1) glds_a(ktn, cur ^ 1, kk - 1); }
+            if (kk == 1) load_wtile<DT, WBIT, ZM, GPT>(wnext, wp, ktn * GEMM_BK, N, gshift);
+#else
             if constexpr (GLDS) glds_a(ktn, cur ^ 1, kk);
             if (kk == 0) {
                 if constexpr (!GLDS) load_a(ktn);
                 load_wtile<DT, WBIT, ZM, GPT>(wnext, wp, ktn * GEMM_BK, N, gshift);
             }
+#endif
             dequant_step(wcur, kt, kk + 1, bnext);
             constexpr int NLD = (WBIT == 8 ? 16 : 8) + 2 * NF * (GPT ? 1 : 4);  // loads of load_wtile
             const int nv = (GLDS && kk < 2 ? A_PIECES / 2 : 0) + (kk == 0 ? NLD : 0);
@@ -552,7 +559,7 @@ __global__ __launch_bounds__(256, (BM <= 128 ? 2 : 1)) void mpq_gemm_kernel(cons
     // 32x32 C/D layout (col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)) a lane holds ONE output row m = t*32 + j
     // and, per group of four registers, FOUR CONSECUTIVE columns n = 8*q + 4*h + (0..3): one 8-byte store per group
     // (4 per tile instead of 16 two-byte stores); the two lane halves complete 16 contiguous bytes per row.
-#if BIE_GEMM_LAB == 1 || BIE_GEMM_LAB == 7
+#ifdef BIE_GEMM_STAMPS
     if (acc[0][0][0] == 123.456f)
 #endif
 #pragma unroll
@@ -590,7 +597,7 @@ __global__ __launch_bounds__(256, (BM <= 128 ? 2 : 1)) void mpq_gemm_kernel(cons
             }
         }
     }
-#if BIE_GEMM_LAB == 7
+#ifdef BIE_GEMM_STAMPS
     // timing build only: the LAST row of y receives, per wave of block 0, the six phase cycle sums (y is garbage there)
     __syncthreads();
     if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) {
