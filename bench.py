@@ -283,7 +283,7 @@ def bench_binary(dev, L):
     out = []
     K = N = 4096
     wsets = [torch.randint(0, 256, (N, K // 8), dtype=torch.int32, device=dev).to(torch.uint8) for _ in range(16)]
-    for M in (1, 64, 4096):
+    for M in (1, 64, 512, 4096):
         xp = torch.randint(0, 256, (M, K // 8), dtype=torch.int32, device=dev).to(torch.uint8)
         y = torch.empty((M, N), dtype=torch.float32, device=dev)
 
@@ -296,12 +296,12 @@ def bench_binary(dev, L):
         byts = K * N // 8 + M * K // 8 + 4 * M * N
         tops = 2.0 * M * K * N / us / 1e6
         rf = ({"bound": "hbm", "achieved": round(byts / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(byts / us / 1e3 / HBM_PEAK_GBS, 4)}
-              if M <= 64 else {"bound": "valu xor+bcnt", "achieved": round(tops, 1), "peak": XOR_POPC_PEAK_TOPS, "unit": "TOP/s", "frac": round(tops / XOR_POPC_PEAK_TOPS, 4)})
+              if M < 16 else {"bound": "valu xor+bcnt", "achieved": round(tops, 1), "peak": XOR_POPC_PEAK_TOPS, "unit": "TOP/s", "frac": round(tops / XOR_POPC_PEAK_TOPS, 4)})
         out.append({"op": "binary linear 4096x4096", "M": M, "us_per_launch": round(us, 2), "TOP/s": round(tops, 1), "roofline": dict(rf, traffic=None)})
     # the whole BinaryLinearCuda layer forward (activation bias + sign-pack of bf16 x, XNOR-popcount, cast, both scales) in one launch
     bias_a = torch.randn(K, device=dev).to(BF16)
     sa, sw = torch.tensor(0.7, device=dev).to(BF16), torch.tensor(0.01, device=dev).to(BF16)
-    for M in (1, 16, 64):
+    for M in (1, 16, 64, 256):
         x = torch.randn((M, K), device=dev).to(BF16)
         yb = torch.empty((M, N), dtype=BF16, device=dev)
 
@@ -315,8 +315,10 @@ def bench_binary(dev, L):
         byts = K * N // 8 + 2 * M * K + 2 * K + 2 * M * N
         out.append({"op": "binary layer forward 4096x4096, one launch (bf16 x -> bf16 y)", "M": M, "us_per_launch": round(us, 2),
                     "TOP/s": round(2.0 * M * K * N / us / 1e6, 1),
-                    "roofline": {"bound": "hbm", "achieved": round(byts / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": round(byts / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None}})
+                    "roofline": ({"bound": "hbm", "achieved": round(byts / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(byts / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None} if M < 16 else
+                                 {"bound": "valu xor+bcnt", "achieved": round(2.0 * M * K * N / us / 1e6, 1), "peak": XOR_POPC_PEAK_TOPS,
+                                  "unit": "TOP/s", "frac": round(2.0 * M * K * N / us / 1e6 / XOR_POPC_PEAK_TOPS, 4), "traffic": None})})
     for B in (1, 32):
         x = torch.randn((B, 512, 7, 7), device=dev)
         w = torch.randn((512, 512, 3, 3), device=dev)

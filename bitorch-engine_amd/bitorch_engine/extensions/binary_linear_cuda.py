@@ -64,12 +64,12 @@ def forward(input: torch.Tensor, weights: torch.Tensor, bmm_type: int, transpose
         wp = pack_rows(weights)
     wp = wp.contiguous()
     if input.dtype in _hip._DT and fused_ok(m, wp.shape[0], k) and wp.data_ptr() % 16 == 0:
-        return xnor_linear_fused(input, wp, raw_counts=True)  # M <= 64: sign-pack of x inside the XNOR kernel (one launch)
+        return xnor_linear_fused(input, wp, raw_counts=True)  # M <= 64 (<= 512 when K % 512 == 0): sign-pack of x inside the XNOR kernel (one launch)
     return xnor_linear(pack_rows(input), wp, m, wp.shape[0], k, 0, 1.0)
 
 
 def layer_forward(input, bias_a, weights, bmm_type, scale_a, scale_w):
-    """BinaryLinearCuda's whole forward for M <= 64 in one launch: `((x + bias_a) >= 0)` bits, XNOR-popcount,
+    """BinaryLinearCuda's whole forward for M <= 64 (M <= 512 when K % 512 == 0) in one launch: `((x + bias_a) >= 0)` bits, XNOR-popcount,
     `.to(dtype) * scale_a * scale_w` (reference layers/qlinear/binary/cuda/layer.py:58-63, 283-284).  None when the shape is
     outside the fused range (the caller then composes the separate steps)."""
     m, k = input.shape

@@ -52,7 +52,7 @@ class BinaryLinearCuda(BinaryLinearBase):
         self.bmm_type = bmm_type
         if not torch.is_grad_enabled() or not (x.requires_grad or self.bias_a.requires_grad or self.scale_a.requires_grad):
             # no gradient can flow (the fused output is detached from bias_a / scale_a: fine-tuning those under model.eval() must
-            # take the differentiable composition below).  M <= 64: the whole layer (activation bias + sign-pack, XNOR-popcount,
+            # take the differentiable composition below).  M <= 64 (<= 512 when K % 512 == 0): the whole layer (activation bias + sign-pack, XNOR-popcount,
             # cast, both scales) in ONE launch
             self._init_scale_a(x)
             x2, lead = flatten_x(x)

@@ -7,6 +7,7 @@
 // binary_linear_cutlass_kernel.cu (:44-113), binary_conv.cpp (im2binary_col :319-365, forward :464-530)
 // and functions_cuda_kernel.cu (:73-207).
 #include "bie_common.h"
+#include <stdlib.h>
 
 namespace bie {
 
@@ -336,6 +337,161 @@ __global__ __launch_bounds__(256) void xnor_fused_kernel(const void* __restrict_
     }
 }
 
+// ---- mid M (5 <= M, K % 512 == 0): RT rows x (4 waves x 16*G columns) per workgroup, full K per wave --------------------------
+// The M <= 64 kernel above re-packs its 8 x rows in every one of its 128 column blocks (2.25x the XNOR work at 4096 x 4096) and the
+// 64 x 64 LDS tile kernel reads one LDS word per 4 popcounts; both sit near 0.1 of the v_xor + v_bcnt rate at M = 64.  Here a lane is
+// (column c = lane >> 2, k quarter kq = lane & 3): a 16-byte load per lane covers 64 contiguous bytes of each of 16 weight rows (the
+// lane-per-column form would touch 64 cache lines per instruction), a chunk = 16 k-words, PD chunks in flight per wave ahead of the
+// one being counted.  x bits (packed by the workgroup itself from the layer-dtype x, or copied when they arrive packed) are read
+// from LDS with 4 distinct addresses per instruction (one per kq): 1 LDS read per 8 * G popcount pairs.  The four kq partial counts
+// are summed on the DPP quad network; lane kq then stores rows kq (and kq + 4).  No reduction across waves or workgroups.
+template <int DT, int RT, int G>  // DT = -1: x is already sign-packed ([M, K/8] bytes)
+__global__ __launch_bounds__(256) void xnor_mid_kernel(const void* __restrict__ x, const void* __restrict__ bias_a,
+                                                       const uint32_t* __restrict__ Wt, const void* __restrict__ scale_a,
+                                                       const void* __restrict__ scale_w, void* __restrict__ y, int M, int N, int K,
+                                                       float scale, int y_f32) {
+    constexpr int PD = G >= 4 ? 4 : 8;  // chunks in flight: 16 (G = 4, 2) or 8 loads per lane
+    extern __shared__ uint32_t xb[];  // [RT][KW]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int KW = K >> 5, KB = K >> 3, T = KW >> 4;
+    const int m0 = blockIdx.y * RT;
+    const int c = lane >> 2, kq = lane & 3;
+    const int nw0 = (blockIdx.x * 4 + wave) * (16 * G);
+    const uint32_t* wrow[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) wrow[g] = Wt + (long)min(nw0 + g * 16 + c, N - 1) * KW + 4 * kq;
+    uint4_t wr[PD][G];
+#pragma unroll
+    for (int p = 0; p < PD; p++)
+#pragma unroll
+        for (int g = 0; g < G; g++) wr[p][g] = __builtin_nontemporal_load(reinterpret_cast<const uint4_t*>(wrow[g] + 16 * min(p, T - 1)));
+    if constexpr (DT >= 0) {
+        uint8_t* xbytes = reinterpret_cast<uint8_t*>(xb);
+        for (int kb = threadIdx.x; kb < KB; kb += 256) {  // a thread packs bytes kb of all RT rows: the bias is loaded once
+            float b[8];
+            if (bias_a) load8<DT>(bias_a, kb * 8, b);
+            float v[RT][8];
+#pragma unroll
+            for (int r = 0; r < RT; r++) load8<DT>(x, (long)min(m0 + r, M - 1) * K + kb * 8, v[r]);
+#pragma unroll
+            for (int r = 0; r < RT; r++) {
+                uint32_t bits = 0;
+#pragma unroll
+                for (int q = 0; q < 8; q++) bits |= (uint32_t)((bias_a ? v[r][q] + b[q] : v[r][q]) >= 0.0f) << q;
+                xbytes[r * KB + kb] = (uint8_t)(m0 + r < M ? bits : 0u);
+            }
+        }
+    } else {
+        const uint32_t* X = reinterpret_cast<const uint32_t*>(x);
+        for (int t = threadIdx.x; t < RT * KW; t += 256) {
+            const int r = t / KW, kw = t - r * KW;
+            xb[t] = (m0 + r < M) ? X[(long)(m0 + r) * KW + kw] : 0u;
+        }
+    }
+    __syncthreads();
+    int acc[G][RT];
+#pragma unroll
+    for (int g = 0; g < G; g++)
+#pragma unroll
+        for (int m = 0; m < RT; m++) acc[g][m] = 0;
+    const uint32_t* xq = xb + 4 * kq;
+    for (int t0 = 0; t0 < T; t0 += PD) {
+#pragma unroll
+        for (int p = 0; p < PD; p++) {
+            const int t = t0 + p;
+            if (t >= T) break;
+            uint4_t xv[RT];
+#pragma unroll
+            for (int m = 0; m < RT; m++) xv[m] = *reinterpret_cast<const uint4_t*>(xq + m * KW + 16 * t);
+            uint4_t w[G];
+#pragma unroll
+            for (int g = 0; g < G; g++) w[g] = wr[p][g];
+#pragma unroll
+            for (int g = 0; g < G; g++) wr[p][g] = __builtin_nontemporal_load(reinterpret_cast<const uint4_t*>(wrow[g] + 16 * min(t + PD, T - 1)));
+#pragma unroll
+            for (int g = 0; g < G; g++)
+#pragma unroll
+                for (int m = 0; m < RT; m++)
+                    acc[g][m] += __builtin_popcount(w[g].x ^ xv[m].x) + __builtin_popcount(w[g].y ^ xv[m].y) +
+                                 __builtin_popcount(w[g].z ^ xv[m].z) + __builtin_popcount(w[g].w ^ xv[m].w);
+        }
+    }
+    float sa = 1.0f, sw = 1.0f;
+    if constexpr (DT >= 0) {
+        if (scale_a) sa = dt_traits<DT>::load(scale_a, 0);
+        if (scale_w) sw = dt_traits<DT>::load(scale_w, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        const int n = nw0 + g * 16 + c;
+        const bool b0 = (kq & 1) != 0, b1 = (kq & 2) != 0;
+#pragma unroll
+        for (int h = 0; h < RT / 4; h++) {
+            // 4 rows x 4 kq lanes: transpose-reduce on the quad network -- lane kq ends with the full count of row 4h + kq
+            const int a0 = acc[g][4 * h], a1 = acc[g][4 * h + 1], a2 = acc[g][4 * h + 2], a3 = acc[g][4 * h + 3];
+            const int r01 = (b0 ? a1 : a0) + __builtin_amdgcn_update_dpp(0, b0 ? a0 : a1, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
+            const int r23 = (b0 ? a3 : a2) + __builtin_amdgcn_update_dpp(0, b0 ? a2 : a3, 0xB1, 0xf, 0xf, false);
+            const int pc = (b1 ? r23 : r01) + __builtin_amdgcn_update_dpp(0, b1 ? r01 : r23, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
+            const int m = m0 + 4 * h + kq;
+            if (m >= M || n >= N) continue;
+            float v = (float)(K - 2 * pc);
+            if constexpr (DT < 0) {
+                ((float*)y)[(long)m * N + n] = v * scale;
+            } else {
+                if (y_f32) {
+                    ((float*)y)[(long)m * N + n] = v;
+                } else {
+                    v = dt_traits<DT>::round(v);
+                    if (scale_a) v = dt_traits<DT>::round(v * sa);
+                    if (scale_w) v = dt_traits<DT>::round(v * sw);
+                    dt_traits<DT>::store(y, (long)m * N + n, v);
+                }
+            }
+        }
+    }
+}
+
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+struct MidPlan { int rt, g; };
+// widest tile whose grid still gives every CU a workgroup; BIE_BINARY_MID=<rt><g> (e.g. 84) pins one for tools/
+static MidPlan mid_plan(long M, long N) {
+    static const int forced = env_int("BIE_BINARY_MID", 0);
+    if (forced == 84 || forced == 44 || forced == 42 || forced == 41) return MidPlan{forced / 10, forced % 10};
+    // (8 rows with 2 or 1 column groups measured slower than 4 x 4 at equal grid size: profiles/r03_u_binary_mid_ab.txt)
+    const int cand[4][2] = {{8, 4}, {4, 4}, {4, 2}, {4, 1}};
+    for (int i = 0; i < 4; i++) {
+        const long wgs = cdivl(N, 64 * cand[i][1]) * cdivl(M, cand[i][0]);
+        if (wgs >= (i == 0 ? 1024 : 256)) return MidPlan{cand[i][0], cand[i][1]};
+    }
+    return MidPlan{4, 1};
+}
+// upper M: beyond it the 128 x 128 register-tile kernel (weights re-read once per 128 rows, not once per RT) wins -- measured crossover
+static long mid_max_rows() {
+    static const int v = env_int("BIE_BINARY_MID_MAX", 512);
+    return v;
+}
+bool binary_mid_ok(long M, long N, long K) {
+    return M >= 5 && M <= mid_max_rows() && K % 512 == 0 && K <= (1L << 18) && N >= 1 && N < (1L << 31);
+}
+
+template <int DT>
+static void mid_launch_dt(const void* x, const void* bias_a, const uint32_t* wp, const void* sa, const void* sw, void* y, int M, int N, int K,
+                          float scale, int y_f32, hipStream_t st) {
+    const MidPlan p = mid_plan(M, N);
+    const size_t lds = (size_t)p.rt * (K / 32) * 4;
+    dim3 grid((unsigned)cdivl(N, 64 * p.g), (unsigned)cdivl(M, p.rt));
+#define BIE_MID(RT_, G_) hipLaunchKernelGGL((xnor_mid_kernel<DT, RT_, G_>), grid, dim3(256), lds, st, x, bias_a, wp, sa, sw, y, M, N, K, scale, y_f32)
+    if (p.rt == 8) BIE_MID(8, 4);
+    else if (p.g == 4) BIE_MID(4, 4);
+    else if (p.g == 2) BIE_MID(4, 2);
+    else BIE_MID(4, 1);
+#undef BIE_MID
+}
+
 // byte-granular compatibility kernel: any K % 8 == 0, either weight layout.  One thread per output.
 __global__ __launch_bounds__(256) void xnor_bytes_kernel(const uint8_t* __restrict__ X, const uint8_t* __restrict__ W,
                                                          float* __restrict__ y, long M, long N, long KB, int w_layout,
@@ -559,6 +715,10 @@ int binary_linear_launch(const uint8_t* xp, const uint8_t* wp, float* y, long M,
         else hipLaunchKernelGGL(xnor_gemv_kernel<4>, grid, dim3(256), 0, st, (const uint32_t*)xp, (const uint32_t*)wp, y, (int)M, (int)N, KW, (int)K, scale);
         return check_launch("xnor_gemv_kernel");
     }
+    if (binary_mid_ok(M, N, K) && ((uintptr_t)wp & 15) == 0) {  // mid M: register tiles of RT rows x 16*G columns per wave, x bits in LDS
+        mid_launch_dt<-1>(xp, nullptr, (const uint32_t*)wp, nullptr, nullptr, y, (int)M, (int)N, (int)K, scale, 1, st);
+        return check_launch("xnor_mid_kernel");
+    }
     if ((KW & 3) == 0 && cdivl(N, XB) * cdivl(M, XB) >= 256) {  // large M: 128 x 128 tiles, 8 x 8 outputs per thread
         dim3 grid((unsigned)cdivl(N, XB), (unsigned)cdivl(M, XB));
         hipLaunchKernelGGL(xnor_gemm128_kernel, grid, dim3(256), 0, st, (const uint32_t*)xp, (const uint32_t*)wp, y, (int)M, (int)N, KW, (int)K, scale);
@@ -603,11 +763,16 @@ int binary_matmul_batched_launch(const uint8_t* xp, const uint8_t* wp, float* y,
 // 1 <= M <= 64 (beyond that packing x once and running the tiled XNOR GEMM is the better split), K % 32 == 0
 bool binary_linear_fused_ok(long M, long N, long K) {
     // the packed x rows of one workgroup (4 or 8 rows of K/32 + 1 words) live in LDS: 64 KiB
+    if (binary_mid_ok(M, N, K)) return true;  // 5 <= M <= 512, K % 512 == 0: xnor_mid_kernel packs its rows itself
     return M >= 1 && M <= 64 && N >= 1 && K >= 32 && K % 32 == 0 && (size_t)(M <= 4 ? 4 : 8) * (K / 32 + 1) * 4 <= 65536 && N < (1L << 31);
 }
 
 template <int DT>
 static void fused_launch_dt(const void* x, const void* bias_a, const uint8_t* wp, const void* sa, const void* sw, void* y, int M, int N, int K, int y_f32, hipStream_t st) {
+    if (binary_mid_ok(M, N, K)) {
+        mid_launch_dt<DT>(x, bias_a, (const uint32_t*)wp, sa, sw, y, M, N, K, 1.0f, y_f32, st);
+        return;
+    }
     const int rows = M <= 4 ? 4 : 8;
     const size_t lds = (size_t)rows * (K / 32 + 1) * 4;
     const int row_blocks = M <= 4 ? 1 : (int)cdivl(M, 8);
@@ -844,6 +1009,109 @@ __global__ __launch_bounds__(64) void xnor_conv_taps_dma_kernel(const uint32_t* 
     }
 }
 
+// The tap pass in the lane mapping of xnor_mid_kernel: lane = (output channel c = lane >> 2 of 16, k quarter kq = lane & 3 of a
+// 16-word chunk of the oc's [T][CW] tap words), G channel groups per wave.  A 16-byte load per lane covers 64 contiguous bytes of 16
+// weight rows and feeds PXN pixels x 4 words; x words are LDS reads with 4 distinct addresses (one per kq): 1 LDS read per 8 * G
+// popcounts where the lane-per-channel kernel above needs 1 per 8.  The PXN pixel counts of the four kq lanes are summed on the DPP
+// quad network, lane kq stores pixels kq and 4 + kq.  CW = 4 * CW4; a chunk holds 4 / CW4 taps (the tap is wave-uniform when
+// CW4 == 4, per lane otherwise); the tail chunk's unused words count zero (w = 0 against the zero pixel).  PXN = 7 for the 7 / 14 / 28
+// wide maps of a ResNet (no eighth idle pixel), else 8.
+template <int CW4, int G, int PXN>
+__global__ __launch_bounds__(256) void xnor_conv_quad_kernel(const uint32_t* __restrict__ xbits, const uint32_t* __restrict__ wtaps,
+                                                             float* __restrict__ y, int B, int C, int H, int W, int OC, int OH,
+                                                             int OW, int ks, int stride, int pad, int dil, float scale,
+                                                             long items, int slab_words) {
+    constexpr int CW = 4 * CW4, TPC = 4 / CW4;  // taps per 16-word chunk
+    extern __shared__ __attribute__((aligned(16))) uint32_t conv_lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long item = (long)blockIdx.x * 4 + wave;  // (b, oh, oc block): oc block fastest
+    if (item >= items) return;
+    const int ocbs = (OC + 16 * G - 1) / (16 * G);
+    const int ocb = (int)(item % ocbs);
+    const int oh = (int)((item / ocbs) % OH);
+    const long b = item / ((long)ocbs * OH);
+    const int T = ks * ks, TW = T * CW, NCH = (TW + 15) >> 4;
+    const int c = lane >> 2, kq = lane & 3;
+    const int tq = kq / CW4, cwq = 4 * (kq % CW4);  // the lane's tap inside a chunk and its first channel word
+    const uint32_t* wl[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) wl[g] = wtaps + (long)min(ocb * 16 * G + g * 16 + c, OC - 1) * TW;
+    (void)wl;
+    auto load_chunk = [&](int ch, uint4_t (&w)[G]) {
+        const int wi = min(16 * ch + 4 * kq, TW - 4);
+#pragma unroll
+        for (int g = 0; g < G; g++) w[g] = *reinterpret_cast<const uint4_t*>(wl[g] + wi);
+    };
+    uint4_t wc[G], wn[G];
+    load_chunk(0, wc);
+    uint32_t* slab = conv_lds + wave * slab_words;  // [ks][W + 1][CW]; pixel W of every row is the zero pixel
+    const int rowstride = (W + 1) * CW;
+    for (int i = 0; i < ks; i++) {
+        const int ih = oh * stride - pad + i * dil;
+        const bool valid = ih >= 0 && ih < H;
+        const uint32_t* src = xbits + ((b * H + (valid ? ih : 0)) * W) * CW;
+#pragma unroll 2
+        for (int t = lane; t < rowstride; t += 64) slab[i * rowstride + t] = (valid && t < W * CW) ? src[t] : 0u;
+    }
+    __builtin_amdgcn_wave_barrier();  // wave-private slab: a wave's LDS operations complete in order
+    const int Kc = C * T;
+    const int zero_px = W * CW + cwq;
+    for (int ow0 = 0; ow0 < OW; ow0 += PXN) {
+        int acc[G][8];
+#pragma unroll
+        for (int g = 0; g < G; g++)
+#pragma unroll
+            for (int px = 0; px < 8; px++) acc[g][px] = 0;
+        int ti = 0, tj = tq;  // (kernel row, kernel column) of the lane's tap; tq < TPC <= 4 may already exceed ks - 1
+        while (tj >= ks) { tj -= ks; ti++; }
+#pragma unroll 1
+        for (int ch = 0; ch < NCH; ch++) {
+            load_chunk(ch + 1 < NCH ? ch + 1 : 0, wn);  // the last one is chunk 0 of the next pixel group
+            const bool live = ch * TPC + tq < T;
+            if (!live) {
+#pragma unroll
+                for (int g = 0; g < G; g++) wc[g] = uint4_t{0u, 0u, 0u, 0u};
+            }
+            const int base = ti * rowstride + cwq, jd = tj * dil - pad + ow0 * stride;
+            uint4_t xv[PXN];
+#pragma unroll
+            for (int px = 0; px < PXN; px++) {
+                const int iw = px * stride + jd;
+                const bool in = (unsigned)iw < (unsigned)W && ow0 + px < OW && live;
+                xv[px] = *reinterpret_cast<const uint4_t*>(slab + (in ? base + iw * CW : zero_px));
+            }
+#pragma unroll
+            for (int g = 0; g < G; g++)
+#pragma unroll
+                for (int px = 0; px < PXN; px++) {
+                    asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc[g][px]) : "v"(wc[g].x ^ xv[px].x));
+                    asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc[g][px]) : "v"(wc[g].y ^ xv[px].y));
+                    asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc[g][px]) : "v"(wc[g].z ^ xv[px].z));
+                    asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc[g][px]) : "v"(wc[g].w ^ xv[px].w));
+                }
+#pragma unroll
+            for (int g = 0; g < G; g++) wc[g] = wn[g];
+            tj += TPC;
+            while (tj >= ks) { tj -= ks; ti++; }
+        }
+        const bool b0 = (kq & 1) != 0, b1 = (kq & 2) != 0;
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const int oc = ocb * 16 * G + g * 16 + c;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int a0 = acc[g][4 * h], a1 = acc[g][4 * h + 1], a2 = acc[g][4 * h + 2], a3 = acc[g][4 * h + 3];
+                const int r01 = (b0 ? a1 : a0) + __builtin_amdgcn_update_dpp(0, b0 ? a0 : a1, 0xB1, 0xf, 0xf, false);
+                const int r23 = (b0 ? a3 : a2) + __builtin_amdgcn_update_dpp(0, b0 ? a2 : a3, 0xB1, 0xf, 0xf, false);
+                const int pc = (b1 ? r23 : r01) + __builtin_amdgcn_update_dpp(0, b1 ? r01 : r23, 0x4E, 0xf, 0xf, false);
+                const int pxi = 4 * h + kq;
+                if (oc < OC && pxi < PXN && ow0 + pxi < OW) y[((b * OC + oc) * OH + oh) * OW + ow0 + pxi] = (float)(Kc - 2 * pc) * scale;
+            }
+        }
+    }
+}
+
 // LDS of one workgroup (4 waves) of the implicit conv; 0 = geometry outside its range (rows too long for a 16 KiB slab)
 size_t binary_conv_taps_lds_bytes(int C, int W, int ks) {
     const size_t slab = (size_t)ks * (W + 1) * cdiv(C, 32);
@@ -889,6 +1157,23 @@ int binary_conv_taps_launch(const void* x, const uint32_t* wtaps, float* y, void
 #undef LD
             return check_launch("xnor_conv_taps_dma_kernel");
         }
+    }
+    static const bool quad_on = [] { const char* e = getenv("BIE_CONV_QUAD"); return !e || atoi(e) != 0; }();
+    if (quad_on && (CW == 16 || CW == 8 || CW == 4) && ks * ks * CW >= 16) {  // lane = (channel, k quarter): 64-byte pieces of 16 weight rows per load
+        const int g = (long)B * OH * cdiv(OC, 64) >= 1024 ? 4 : ((long)B * OH * cdiv(OC, 32) >= 1024 ? 2 : 1);
+        const long qitems = (long)B * OH * cdiv(OC, 16 * g);
+        dim3 grid((unsigned)cdivl(qitems, 4));
+#define LQ3(CV, GV, PV) hipLaunchKernelGGL((xnor_conv_quad_kernel<CV, GV, PV>), grid, dim3(256), lds, st, xbits, wtaps, y, B, C, H, W, OC, OH, OW, ks, \
+                                           stride, pad, dil, scale, qitems, (int)(lds / 16))
+#define LQ2(CV, GV) do { if (OW % 7 == 0) LQ3(CV, GV, 7); else LQ3(CV, GV, 8); } while (0)
+#define LQ(CV) do { if (g == 4) LQ2(CV, 4); else if (g == 2) LQ2(CV, 2); else LQ2(CV, 1); } while (0)
+        if (CW == 16) LQ(4);
+        else if (CW == 8) LQ(2);
+        else LQ(1);
+#undef LQ
+#undef LQ2
+#undef LQ3
+        return check_launch("xnor_conv_quad_kernel");
     }
 #define LC(C4V) hipLaunchKernelGGL(xnor_conv_taps_kernel<C4V>, dim3((unsigned)cdivl(items, 4)), dim3(256), lds, st, xbits, wtaps, y, B, C, H, W, OC, OH, OW, \
                                    ks, stride, pad, dil, CW, scale, items, (int)(lds / 16))

@@ -451,7 +451,7 @@ int bie_binary_linear_fused(const void* x, const void* bias_a, const uint8_t* wp
     BIE_REQUIRE(dtype >= 0 && dtype <= 2, BIE_ERR_UNSUPPORTED, "bie_binary_linear_fused: dtype %d", dtype);
     BIE_REQUIRE(!y_f32 || (!scale_a && !scale_w), BIE_ERR_INVALID_ARG, "bie_binary_linear_fused: y_f32 (raw counts) takes no scales");
     BIE_REQUIRE(binary_linear_fused_ok(M, N, K), BIE_ERR_UNSUPPORTED,
-                "bie_binary_linear_fused: M=%ld N=%ld K=%ld outside the one-launch range (1 <= M <= 64, K %% 32 == 0)", M, N, K);
+                "bie_binary_linear_fused: M=%ld N=%ld K=%ld outside the one-launch range (1 <= M <= 64 with K %% 32 == 0, or 5 <= M <= 512 with K %% 512 == 0)", M, N, K);
     BIE_REQUIRE(x && wpacked && y, BIE_ERR_INVALID_ARG, "bie_binary_linear_fused: NULL tensor pointer");
     BIE_REQUIRE(((reinterpret_cast<uintptr_t>(wpacked) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(bias_a)) & 15) == 0, BIE_ERR_INVALID_ARG,
                 "bie_binary_linear_fused: x, bias_a and the packed weights must be 16-byte aligned");

@@ -269,13 +269,13 @@ int bie_binary_linear_forward(const uint8_t* xpacked, const uint8_t* wpacked, fl
 int bie_binary_matmul_batched(const uint8_t* xpacked, const uint8_t* wpacked, float* y, long batch, long M, long N, long K,
                               long stride_x, long stride_w, long stride_y, float scale, void* stream);
 
-/* One launch per BinaryLinearCuda layer forward (M <= 64):
+/* One launch per BinaryLinearCuda layer forward (M <= 64; M <= 512 when K % 512 == 0):
  *   y[M, N] (dtype) = dt( dt( dt(K - 2*popcount(xbits ^ wbits)) * scale_a ) * scale_w ),  xbits = ((x + bias_a) >= 0)
  * x [M, K] raw activations, bias_a [K] or NULL, wpacked row-packed [N, K/8] (all three 16-byte aligned), scale_a / scale_w device
  * scalars of the same dtype or NULL (= 1).  The roundings are those of BinaryLinearForward.forward
  * (layers/qlinear/binary/cuda/layer.py:58-63: forward(...).to(input.dtype), then out*scale_a*scale_w) after set_activation
  * (:283).  y_f32 != 0: y is float[M, N] = K - 2*popcount, no rounding, scales must be NULL (what binary_linear_cuda.forward
- * itself returns, binary_linear_cuda_kernel.cu:629-660).  bie_binary_linear_fused_ok says whether a shape is in range (1 <= M <= 64, K % 32 == 0). */
+ * itself returns, binary_linear_cuda_kernel.cu:629-660).  bie_binary_linear_fused_ok says whether a shape is in range (1 <= M <= 64 with K % 32 == 0, or 5 <= M <= 512 with K % 512 == 0). */
 int bie_binary_linear_fused_ok(long M, long N, long K);
 int bie_binary_linear_fused(const void* x, const void* bias_a, const uint8_t* wpacked,
                             const void* scale_a, const void* scale_w, void* y, long M, long N,

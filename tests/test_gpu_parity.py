@@ -1184,9 +1184,12 @@ def test_binary_cuda_weight_images_bit_exact(N, K, bmm, kind):
 
 @pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("M,N,K", [(1, 64, 256), (2, 100, 96), (4, 4096, 4096), (5, 72, 160), (8, 64, 11008), (9, 40, 2048), (16, 33, 96),
-                                   (17, 260, 512), (33, 64, 128), (64, 96, 4096)])
+                                   (17, 260, 512), (33, 64, 128), (64, 96, 4096),
+                                   # xnor_mid_kernel (M >= 5, K % 512 == 0): every (rows, column groups) tile form, ragged M and N
+                                   (7, 1000, 1024), (32, 4096, 512), (64, 4096, 512), (64, 1024, 4096), (100, 257, 1536), (512, 4096, 512),
+                                   (509, 300, 1024)])
 def test_binary_layer_forward_in_one_launch(M, N, K, tdt):
-    """bie_binary_linear_fused (M <= 64): sign bits of (x + bias_a), XNOR-popcount, `.to(dtype) * scale_a * scale_w`, all in one
+    """bie_binary_linear_fused (M <= 64, or M <= 512 when K % 512 == 0): sign bits of (x + bias_a), XNOR-popcount, `.to(dtype) * scale_a * scale_w`, all in one
     kernel.  Exact against the oracle's integers pushed through the layer's own expression (reference
     layers/qlinear/binary/cuda/layer.py:58-63, 283), every lane mapping (M <= 4 / 8 / 16 / 32 / 64), K not a multiple of 64 or
     128, ragged N; the raw-count form equals the two-launch extension forward."""
@@ -1225,7 +1228,7 @@ def test_binary_cuda_layer_uses_the_fused_forward_and_matches_the_composed_one()
     orig = binary_linear_cuda.layer_forward
     binary_linear_cuda.layer_forward = lambda *a: calls.append(1) or orig(*a)
     try:
-        for lead in ((1,), (3, 5), (80,)):                              # 80 rows: outside the fused range -> composed path
+        for lead in ((1,), (3, 5), (80,), (600,)):                      # 600 rows: outside the fused range -> composed path
             x = torch.randn(lead + (K,)).half().to(DEV)
             with torch.no_grad():
                 y = layer(x)
@@ -1235,7 +1238,7 @@ def test_binary_cuda_layer_uses_the_fused_forward_and_matches_the_composed_one()
             assert torch.equal(y, comp)
     finally:
         binary_linear_cuda.layer_forward = orig
-    assert len(calls) == 3
+    assert len(calls) == 4
 
 
 def test_binary_cuda_layer_checkpoint_is_the_reference_image():
