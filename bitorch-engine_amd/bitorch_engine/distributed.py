@@ -55,12 +55,14 @@ class ColumnShardedMPQLinear(torch.nn.Module):
         return cls(layer.qweight.data, layer.scales, layer.zeros, layer.g_idx, bias, layer.w_bit, layer.group_size,
                    layer.asym, rank, world, group, forward_impl)
 
-    def local_forward(self, x2: torch.Tensor) -> torch.Tensor:
+    def local_forward(self, x2: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """This rank's columns, [M, hi - lo]; written in place into `out` (contiguous) when given."""
         if self._impl is not None:
-            return self._impl(x2, self.qweight, self.scales, self.zeros, self.g_idx, self.w_bit, self.asym, self.group_size, self.bias)
+            y = self._impl(x2, self.qweight, self.scales, self.zeros, self.g_idx, self.w_bit, self.asym, self.group_size, self.bias)
+            return y if out is None else out.copy_(y)
         from bitorch_engine.extensions import q_linear_cuda
         return q_linear_cuda.mpq_forward_impl(x2, self.qweight, self.scales, self.zeros, self.g_idx, self.w_bit, self.asym,
-                                              self.group_size, self.bias)
+                                              self.group_size, self.bias, out=out)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         lead = list(x.shape[:-1])
@@ -139,6 +141,92 @@ class ColumnShardedMPQLinear(torch.nn.Module):
         return y.view(lead + [self.N])
 
 
+    # ------------------------------------------------------------------------------------------------------------------
+    # Direct exchange: every rank SENDS its tile to each peer and RECEIVES each peer's tile where it finally lives
+    # ------------------------------------------------------------------------------------------------------------------
+    def forward_direct(self, x: torch.Tensor, m_tile: int = 1024, interleave: bool = True) -> torch.Tensor:
+        """Same result as forward() / forward_overlapped(), without the passes those spend on re-arranging:
+
+        * xGMI is point-to-point (7 links per GPU): a grouped send/recv to and from every peer puts one peer's block on each link at
+          the same time, where a ring all-gather moves all W - 1 blocks over one link per step (192 us against
+          1.34 ms for configs[4]).  One batch_isend_irecv per row tile (ncclGroupStart/End under the RCCL backend; plain isend/irecv
+          under gloo), on the communication stream, overlapped with the next tile's GEMM.
+        * interleave=False: the destination is the rank-major [W, M, N/W] buffer itself.  This rank's GEMM writes its tile IN PLACE
+          (`out=`), every receive lands in the peer's slice `gathered[p, m0:m1]` (contiguous): zero copies.
+        * interleave=True: the destination is y [M, N].  A block's rows are strided there (row pitch N), which neither RCCL nor gloo
+          can receive into, so remote blocks land in a per-tile staging buffer and are copied ONCE into their column range (one pass
+          over the data instead of the two of forward_overlapped: stage -> rank-major -> permute/reshape); shard widths may differ.
+          Writing y's strided blocks straight from the GEMM epilogue needs IPC-mapped peer buffers and an output pitch in the C-ABI;
+          not built (no multi-GPU hardware was available to validate it).
+        Every rank posts the same operations in the same order (peers ascending, tile by tile)."""
+        lead = list(x.shape[:-1])
+        x2 = x.reshape(-1, x.shape[-1])
+        M = x2.shape[0]
+        widths = [hi - lo for lo, hi in self.ranges]
+        if not interleave and len(set(widths)) != 1:
+            raise RuntimeError(f"forward_direct(interleave=False): the rank-major [W, M, N/W] layout needs equal shard widths, got {widths}")
+        dev, dt = x2.device, x2.dtype
+        on_gpu = x2.is_cuda
+        peers = [p for p in range(self.world) if p != self.rank]
+        tiles = [(m0, min(m0 + max(1, m_tile), M)) for m0 in range(0, M, max(1, m_tile))] if M else []
+        if interleave:
+            y = torch.empty((M, self.N), dtype=dt, device=dev)
+        else:
+            gathered = torch.empty((self.world, M, widths[0]), dtype=dt, device=dev)
+        comm = compute = None
+        if on_gpu:
+            compute = torch.cuda.current_stream(dev)
+            comm = _comm_stream(dev)
+            comm.wait_stream(compute)  # the destination exists before the first receive writes it
+        keep = []
+        for (m0, m1) in tiles:
+            if interleave:
+                mine = self.local_forward(x2[m0:m1])  # [mt, my width], contiguous
+                stage = {p: torch.empty((m1 - m0, widths[p]), dtype=dt, device=dev) for p in peers}
+                dst = stage
+            else:
+                mine = self.local_forward(x2[m0:m1], out=gathered[self.rank, m0:m1])
+                dst = {p: gathered[p, m0:m1] for p in peers}
+            ops = []
+            for p in peers:
+                ops.append(dist.P2POp(dist.isend, mine, _global_rank(self.group, p), group=self.group))
+                ops.append(dist.P2POp(dist.irecv, dst[p], _global_rank(self.group, p), group=self.group))
+
+            def exchange():
+                if ops:
+                    for req in dist.batch_isend_irecv(ops):
+                        req.wait()
+                if interleave:
+                    y[m0:m1, self.lo:self.hi].copy_(mine)
+                    for p in peers:
+                        y[m0:m1, self.ranges[p][0]:self.ranges[p][1]].copy_(stage[p])
+
+            if on_gpu:
+                ev = torch.cuda.Event()
+                ev.record(compute)
+                with torch.cuda.stream(comm):
+                    comm.wait_event(ev)
+                    exchange()
+                mine.record_stream(comm)
+                for t in dst.values():
+                    t.record_stream(comm)
+            else:
+                exchange()
+            keep.append((mine, dst))
+        if on_gpu:
+            compute.wait_stream(comm)
+        if not interleave:
+            return gathered
+        return y.view(lead + [self.N])
+
+
+def _global_rank(group, group_rank: int) -> int:
+    """P2POp addresses peers by GLOBAL rank; the layer's ranks are ranks of its (sub)group."""
+    if group is None:
+        return group_rank
+    return dist.get_global_rank(group, group_rank)
+
+
 _COMM_STREAMS = {}
 
 
@@ -193,8 +281,13 @@ def bench_column_sharded(B, world: int, rank: int, dev, M: int = 4096, K: int = 
     us_seq = timed(lambda: layer.forward(x))
     us_ovl = timed(lambda: layer.forward_overlapped(x, m_tile))
     us_ovl_rm = timed(lambda: layer.forward_overlapped(x, m_tile, interleave=False))
+    direct = {}
+    import os
+    if os.environ.get("BIE_BENCH_DIRECT", "0") == "1":  # opt-in: the grouped send/recv exchange has only ever run under gloo (CPU tests)
+        direct = {"us_direct_interleaved": round(timed(lambda: layer.forward_direct(x, m_tile)), 1),
+                  "us_direct_rank_major_zero_copy": round(timed(lambda: layer.forward_direct(x, m_tile, interleave=False)), 1)}
     flops = 2.0 * M * K * N
-    return {"workload": f"BASELINE.json configs[4]: W4A16 {K}x{N} g128 bf16, M={M}, {world} column shards of {n_loc}",
+    return {**direct, "workload": f"BASELINE.json configs[4]: W4A16 {K}x{N} g128 bf16, M={M}, {world} column shards of {n_loc}",
             "scaling": "strong", "us_local_gemm": round(us_gemm, 1), "us_all_gather": round(us_gather, 1),
             "us_gemm_then_gather": round(us_seq, 1), "us_overlapped_m_tiles": round(us_ovl, 1),
             "us_overlapped_rank_major_output": round(us_ovl_rm, 1), "m_tile": m_tile,

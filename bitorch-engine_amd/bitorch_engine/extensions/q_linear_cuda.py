@@ -82,7 +82,8 @@ def perm_or_none(q_perm):
     return None if zero else q_perm
 
 
-def mpq_forward_impl(x, qweight, scales, zeros, g_idx, w_bit, asym, group_size, bias=None, trivial_gidx=None):
+def mpq_forward_impl(x, qweight, scales, zeros, g_idx, w_bit, asym, group_size, bias=None, trivial_gidx=None, out=None):
+    """out: optional contiguous [M, N] tensor of x's dtype that receives y (the kernels write it in place: no copy)."""
     _hip.need_gpu(x, qweight, scales, zeros)
     x = x.contiguous()
     M, K = x.shape
@@ -101,8 +102,11 @@ def mpq_forward_impl(x, qweight, scales, zeros, g_idx, w_bit, asym, group_size, 
         # library -- the split the reference makes for every M > 32 (layers/qlinear/nbit/cuda/mpq_layer.py:59-62)
         W = mpq_dequant(qweight, scales, zeros, gptr, w_bit, asym, group_size)
         y = torch.matmul(x, W.to(x.dtype))
-        return y if bias is None else y + bias
-    y = torch.empty((M, N), dtype=x.dtype, device=x.device)
+        y = y if bias is None else y + bias
+        return y if out is None else out.copy_(y)
+    if out is not None and (out.shape != (M, N) or out.dtype != x.dtype or out.device != x.device or not out.is_contiguous()):
+        raise RuntimeError("mpq_forward_impl: out must be a contiguous [M, N] tensor of x's dtype on x's device")
+    y = torch.empty((M, N), dtype=x.dtype, device=x.device) if out is None else out
     if M == 0:
         return y
     L = _hip.lib()

@@ -80,7 +80,25 @@ def _worker(rank, world, port, asym, out_dir):
                 ok_rm = False
             except RuntimeError:
                 pass
-    torch.save({"ok": ok and ok_tiled and ok_rm, "shape": tuple(y.shape)}, os.path.join(out_dir, f"r{rank}.pt"))
+    # direct exchange (grouped send / recv into the final place): interleaved [M, N] for any shard widths, rank-major with zero copies
+    ok_direct = True
+    for mt in (3, 16):
+        yd = layer.forward_direct(x7, m_tile=mt)
+        ok_direct = ok_direct and torch.equal(yd, full7)
+        if equal_shards:
+            rm = layer.forward_direct(x7, m_tile=mt, interleave=False)
+            ok_direct = ok_direct and rm.shape == (world, 7, (qweight.shape[1]) // world)
+            for r in range(world):
+                rlo, rhi = column_range(qweight.shape[1], r, world)
+                ok_direct = ok_direct and torch.equal(rm[r], full7[:, rlo:rhi])
+        else:
+            try:
+                layer.forward_direct(x7, m_tile=mt, interleave=False)
+                ok_direct = False
+            except RuntimeError:
+                pass
+    ok_direct = ok_direct and torch.equal(layer.forward_direct(x), full)  # leading dims, one tile
+    torch.save({"ok": ok and ok_tiled and ok_rm and ok_direct, "shape": tuple(y.shape)}, os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
