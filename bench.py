@@ -108,6 +108,22 @@ def pmc_traffic(shape):
         return None
 
 
+def pmc_gemm():
+    """MFMA-pipe utilisation of the GEMM kernel from this round's counters (tools/gpu_pmc_gemm_r03.sh -> profiles/r03_pmc_gemm.json:
+    SQ_VALU_MFMA_BUSY_CYCLES per SIMD / GRBM_GUI_ACTIVE per XCD, M = 4096, 4096 -> 11008, bf16).  None when absent or collected on
+    another mpq_gemm.hip."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_gemm.json")))
+        sha = hashlib.sha256(open(os.path.join(ROOT, "bitorch-engine_amd", "csrc", "mpq_gemm.hip"), "rb").read()).hexdigest()[:16]
+        if d.get("gemm_source_sha") != sha:
+            return None
+        b = d["bf16"]
+        return {"shape": d["shape"], "mfma_pipe_utilisation": b["mfma_pipe_utilisation"], "valu_per_mfma": b["instructions"]["valu_per_mfma"],
+                "fetch_bytes": b["fetch_bytes_corrected"], "write_bytes": b["write_bytes"], "algorithmic_bytes": b["algorithmic_bytes"]}
+    except Exception:
+        return None
+
+
 class Bench:
     def __init__(self, dev):
         from bitorch_engine import _hip
@@ -541,7 +557,8 @@ def main():
         # ---- compute-bound half on the metric's layer (first-class: its own event-timed region)
         guarded("gemm", lambda: B.gemm(4096, 4096, 4096, 24, 3, 7))
         if "roofline" in out.get("gemm", {}):
-            out["roofline_gemm"] = dict(out["gemm"]["roofline"], kernel="bie::mpq_gemm_kernel<bf16,w4,256x256x64 tile>", us_per_launch=out["gemm"]["us_per_launch"])
+            out["roofline_gemm"] = dict(out["gemm"]["roofline"], kernel="bie::mpq_gemm_kernel<bf16,w4,256x256x64 tile>", us_per_launch=out["gemm"]["us_per_launch"],
+                                        pmc=pmc_gemm())
         # ---- the same pass as per-layer launches (round 2's headline form), as 4 launches of 24 layers, and as dependent chains
         guarded("per_layer_launches_4096x4096", lambda: B.gemv(4096, 4096, 96, 10, 1))
         guarded("list_4x24_4096x4096", lambda: B.gemv_list(4096, 4096, 96, 24, 10, 2))
