@@ -1,5 +1,7 @@
 """Drop-in for the reference's `q_linear_cuda` pybind module
 (layers/qlinear/nbit/cuda/q_linear_cuda.cpp:357-369): same function names and argument order."""
+import os
+
 import torch
 
 from bitorch_engine import _hip
@@ -266,8 +268,12 @@ def mbwq_q4_forward(x, qweight, scales, zeros, group_size, q_perm, bits):
     return y
 
 
-EXL2_GEMV_MAX_M = 8   # rows of x served by the streaming exl2 kernels (one pass over the packed weight).  Measured at 4096x11008,
-                      # 3/2-bit g32: M = 8 39.9 us, M = 16 77.7, M = 32 149.8 (8-row passes) against 52 us for reconstruct + library GEMM
+# rows of x served by the fused exl2 kernels (one pass over the packed weight): M <= 2 the decode kernel, 3 <= M <= 48 the same
+# stream feeding v_mfma_f32_16x16x32_f16 (the reference keeps these in its fused kernel, exl2/q_gemm_kernel.cuh:90-549); beyond:
+# reconstruct + library GEMM.  Measured at 4096x11008, 3/2-bit g32, random q_perm (profiles/r03_x_exl2_mfma.txt): M = 3...16
+# 22.8-23.8 us, 32 39.3, 33 43.4, 64 59.2 against 48.1-51.4 us for reconstruct + library GEMM.  BIE_EXL2_MAX_M pins the switch for
+# tools/ (8 = the round-2 split; the C-ABI itself takes M <= 64).
+EXL2_GEMV_MAX_M = int(os.environ.get("BIE_EXL2_MAX_M", "48"))
 
 
 def mbwq_exl2_forward(x, qweight, scales, zeros, q_perm, q_group_map, rows, use_cublas=False):

@@ -510,6 +510,292 @@ __global__ __launch_bounds__(EX2_NW * 64, (EX2_NW == 8 ? 2 : 1)) void exl2_gemv2
                                           c.chunks_per_slab, c.S, (int)blockIdx.x, (int)blockIdx.y, c.colblocks, epoch, status, tag_skew, spin_limit);
 }
 
+// ---- exl2 for 3 <= M <= 64 on the matrix pipe (the reference keeps these rows in its fused kernel, exl2/q_gemm_kernel.cuh:90-549;
+// round 2 handed M >= 9 to reconstruct + a library GEMM: 35-52 us per layer) ------------------------------------------------------
+// The load / extract / dequant half is the decode kernel's: lane = column, a wave takes 32-k chunks band by band with a 4-deep
+// prefetch, v_pk_fma_f16 reproduces __hfma2(q, s, -z).  A lane then holds the 32 fp16 weights of ITS column; v_mfma_f32_16x16x32_f16
+// wants lane (c, kb) to hold 8 consecutive k of column c, so the chunk goes through a wave-private LDS buffer (64 columns x 80 bytes:
+// four 16-byte writes per lane, four 16-byte reads back, conflict-free -- the pitch is an odd number of 16-byte units; a wave's LDS
+// operations complete in order, no barrier).  x is permuted ONCE per call by exl2_permute_x_kernel (x[:, q_perm] into the workspace;
+// gathering the slab per workgroup as the decode kernel does cost 45 M two-byte loads at 64 x 4096 x 11008: 193 us); its fragments --
+// lane (m, kb): 16 bytes -- are requested with the chunk's words, per chunk 4 * MB MFMAs (D = W_frag x x_frag: rows = columns n,
+// columns = x rows m; rows >= M repeat row M - 1 and are never stored).  Waves are reduced through LDS 16 rows at a time, K slabs by
+// the decode kernel's tagged granules.
+__global__ __launch_bounds__(256) void exl2_permute_x_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ perm,
+                                                             uint16_t* __restrict__ xp, int M, int K) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    const int kx = perm[k];
+    for (int m = blockIdx.y; m < M; m += gridDim.y) xp[(long)m * K + k] = x[(long)m * K + kx];
+}
+
+typedef float exl2_acc_t __attribute__((ext_vector_type(4)));
+constexpr int EXL2_T_PITCH = 40;  // halves per column of the transpose buffer (80 bytes)
+
+// NARROW: no 8 / 6 / 5-bit rows in this tensor (host: rows7[2] == 0) -- the wide bands' prefetch sets (4 x 8 words) cost the 3/2-bit models
+// 40-60 registers they never use; OCC = workgroups per CU the register budget is capped for.
+template <int MB, int EX2_NW, int OCC, bool NARROW>
+__global__ __launch_bounds__(EX2_NW * 64, OCC) void exl2_mfma_kernel(const Exl2Call c0, unsigned epoch, unsigned* status, unsigned tag_skew, int spin_limit) {
+    const uint16_t* __restrict__ x = c0.x;
+    const uint32_t* __restrict__ qw = c0.qw;
+    const uint16_t* __restrict__ scales = c0.scales;
+    const uint16_t* __restrict__ zeros = c0.zeros;
+    const uint16_t* __restrict__ gmap = c0.gmap;
+    const Exl2Rows rows = c0.rows;
+    const int M = c0.M, K = c0.K, N = c0.N, chunks_per_slab = c0.chunks_per_slab, S = c0.S;
+    const int colblock = blockIdx.x, slab_idx = blockIdx.y;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem2[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    unsigned gen_entry = 0;
+    if (S > 1) gen_entry = __hip_atomic_load(c0.gen + colblock, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // once, at entry (see the decode kernel)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = colblock * 64 + lane;
+    const int nl = n < N ? n : N - 1;
+    const int C = K >> 5;
+    const int c_begin = slab_idx * chunks_per_slab;
+    int c_end = c_begin + chunks_per_slab;
+    if (c_end > C) c_end = C;
+    uint16_t* T = reinterpret_cast<uint16_t*>(smem2) + wave * (64 * EXL2_T_PITCH);          // wave-private [64 columns][EXL2_T_PITCH]
+    uint16_t* gmap_s = reinterpret_cast<uint16_t*>(smem2) + EX2_NW * (64 * EXL2_T_PITCH);   // [chunks_per_slab * 2]
+    int two_groups = 0;
+    {
+        for (int i = tid; i < (c_end - c_begin); i += EX2_NW * 64) {
+            const uint16_t ga = gmap[2 * ((c_begin + i) * 32)], gb = gmap[2 * ((c_begin + i) * 32 + 16)];
+            gmap_s[2 * i] = ga;
+            gmap_s[2 * i + 1] = gb;
+            two_groups |= (ga != gb);
+        }
+        two_groups = __syncthreads_or(two_groups);
+    }
+    exl2_acc_t acc[4][MB];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int rb = 0; rb < MB; rb++) acc[j][rb] = exl2_acc_t{0.f, 0.f, 0.f, 0.f};
+    const half2_t k1024 = half2_t{(half_t)1024.0f, (half_t)1024.0f};
+    const int c16 = lane & 15, kb = lane >> 4;
+    const uint16_t* xrow[MB];  // x here is the PERMUTED activation matrix [M][K]
+#pragma unroll
+    for (int rb = 0; rb < MB; rb++) xrow[rb] = x + (long)min(16 * rb + c16, M - 1) * K + 8 * kb;
+    auto band = [&](auto bits_tag, auto two_tag, int cb0, int cb1, int prow0) {
+        constexpr int BITS = decltype(bits_tag)::value;
+        constexpr bool TWO = decltype(two_tag)::value;
+        struct Chunk {
+            uint32_t w[BITS];
+            uint32_t s[2], z[2];
+        };
+        auto group_of = [&](int c, int half) -> int { return __builtin_amdgcn_readfirstlane((int)gmap_s[2 * (c - c_begin) + half]); };
+        auto issue = [&](int c, Chunk& ch) {
+            const int prow = prow0 + (c - cb0) * BITS;
+#pragma unroll
+            for (int i = 0; i < BITS; i++) ch.w[i] = __builtin_nontemporal_load(qw + (long)(prow + i) * N + nl);
+            const int g0 = group_of(c, 0);
+            ch.s[0] = scales[(long)g0 * N + nl];
+            ch.z[0] = zeros[(long)g0 * N + nl];
+            if constexpr (TWO) {
+                const int g1 = group_of(c, 1);
+                ch.s[1] = scales[(long)g1 * N + nl];
+                ch.z[1] = zeros[(long)g1 * N + nl];
+            }
+        };
+        auto compute = [&](int c, const Chunk& ch) {
+            uint4_t xf[MB];  // L2-resident: requested here, used after the ~100 VALU of the extraction below (one set, not one per prefetch slot)
+#pragma unroll
+            for (int rb = 0; rb < MB; rb++) xf[rb] = *reinterpret_cast<const uint4_t*>(xrow[rb] + c * 32);
+            uint32_t w8[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) w8[i] = i < BITS ? ch.w[i] : 0u;
+            uint32_t P[16];
+            exl2_pairs16<BITS>(w8, P);
+            uint32_t r[16];
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const half_t sh = __builtin_bit_cast(half_t, (uint16_t)ch.s[TWO ? half : 0]);
+                const half_t zh = __builtin_bit_cast(half_t, (uint16_t)ch.z[TWO ? half : 0]);
+                const half2_t s2 = half2_t{sh, sh}, nz2 = half2_t{(half_t)-zh, (half_t)-zh};
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const half2_t qh = __builtin_bit_cast(half2_t, P[8 * half + i]) - k1024;  // exact
+                    r[8 * half + i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_fma(qh, s2, nz2));  // == __hfma2(q, s, -z)
+                }
+            }
+            uint4_t* tw = reinterpret_cast<uint4_t*>(T + lane * EXL2_T_PITCH);
+#pragma unroll
+            for (int i = 0; i < 4; i++) tw[i] = uint4_t{r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]};
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            uint4_t wf[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) wf[j] = *reinterpret_cast<const uint4_t*>(T + (16 * j + c16) * EXL2_T_PITCH + 8 * kb);
+#pragma unroll
+            for (int rb = 0; rb < MB; rb++) {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    acc[j][rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, wf[j]), __builtin_bit_cast(half8_t, xf[rb]), acc[j][rb], 0, 0, 0);
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        };
+        int first = c_begin + wave;
+        if (first < cb0) first += ((cb0 - first + EX2_NW - 1) / EX2_NW) * EX2_NW;
+        if (first >= cb1) return;
+        const int cnt = (cb1 - first + EX2_NW - 1) / EX2_NW;
+        const int last = first + (cnt - 1) * EX2_NW;
+        auto at = [&](int jj) { const int c = first + jj * EX2_NW; return c < last ? c : last; };
+        Chunk c0_, c1_, c2_, c3_;
+        issue(at(0), c0_);
+        issue(at(1), c1_);
+        issue(at(2), c2_);
+        issue(at(3), c3_);
+        int jj = 0;
+        for (; jj + 4 < cnt; jj += 4) {
+            compute(at(jj), c0_);
+            issue(at(jj + 4), c0_);
+            compute(at(jj + 1), c1_);
+            issue(at(jj + 5), c1_);
+            compute(at(jj + 2), c2_);
+            issue(at(jj + 6), c2_);
+            compute(at(jj + 3), c3_);
+            issue(at(jj + 7), c3_);
+        }
+        compute(at(jj), c0_);
+        if (jj + 1 < cnt) compute(at(jj + 1), c1_);
+        if (jj + 2 < cnt) compute(at(jj + 2), c2_);
+        if (jj + 3 < cnt) compute(at(jj + 3), c3_);
+    };
+    {
+        int kprev = 0, prow = 0;
+#pragma unroll
+        for (int b = 0; b < 6; b++) {
+            const int khi = rows.r[b];
+            const int bits = exl2_bits_of_band(b);
+            int cb0 = kprev >> 5, cb1 = khi >> 5;
+            const int prow_band = prow;
+            prow += (cb1 - cb0) * bits;
+            kprev = khi;
+            const int skip = cb0 < c_begin ? c_begin - cb0 : 0;
+            cb0 += skip;
+            if (cb1 > c_end) cb1 = c_end;
+            if (cb0 < cb1) {
+                const int p0 = prow_band + skip * bits;
+#define BIE_BAND(B)                                                                        \
+    do {                                                                                   \
+        if (two_groups) band(std::integral_constant<int, B>{}, std::true_type{}, cb0, cb1, p0); \
+        else band(std::integral_constant<int, B>{}, std::false_type{}, cb0, cb1, p0);      \
+    } while (0)
+                if constexpr (NARROW) {
+                    switch (b) {
+                        case 3: BIE_BAND(4); break;
+                        case 4: BIE_BAND(3); break;
+                        case 5: BIE_BAND(2); break;
+                        default: break;  // the host checked: no such rows
+                    }
+                } else {
+                    switch (b) {
+                        case 0: BIE_BAND(8); break;
+                        case 1: BIE_BAND(6); break;
+                        case 2: BIE_BAND(5); break;
+                        case 3: BIE_BAND(4); break;
+                        case 4: BIE_BAND(3); break;
+                        default: BIE_BAND(2); break;
+                    }
+                }
+#undef BIE_BAND
+            }
+        }
+    }
+    // ---- reduction over the waves, 16 x rows at a time.  D layout of the 16x16 MFMA: lane (kb', m) holds in acc[j][rb][r] the output of
+    // column 16 j + 4 kb' + r for x row 16 rb + m.  red[wave][16][64]
+    float* red = reinterpret_cast<float*>(smem2);
+    const unsigned gen_next = gen_entry + 1u;
+    const unsigned tag = epoch | (gen_next & 0xffu);
+    const long ncat = (long)c0.colblocks * 64;
+    __syncthreads();
+#pragma unroll
+    for (int rb = 0; rb < MB; rb++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            *reinterpret_cast<float4_t*>(red + ((wave * 16 + c16) * 64 + 16 * j + 4 * kb)) = float4_t{acc[j][rb][0], acc[j][rb][1], acc[j][rb][2], acc[j][rb][3]};
+        __syncthreads();
+        for (int o = tid; o < 16 * 64; o += EX2_NW * 64) {
+            const int om = o >> 6, ol = o & 63, m = 16 * rb + om, on = colblock * 64 + ol;
+            float tot = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < EX2_NW; wv++) tot += red[(wv * 16 + om) * 64 + ol];
+            if (S > 1 && m < M) {  // m < M is wave-uniform (a wave covers one om)
+                const long col = (long)colblock * 64 + ol;
+                if (slab_idx != S - 1) {
+                    const unsigned long long gval = ((unsigned long long)tag << 32) | __float_as_uint(tot);
+                    __hip_atomic_store(c0.gran + ((long)slab_idx * M + m) * ncat + col, gval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    continue;
+                }
+                float v = 0.0f;
+                for (int s0 = 0; s0 < S - 1; s0 += 4) {
+                    unsigned long long gv[4];
+                    bool ready;
+                    int spins = 0;
+                    do {
+#pragma unroll
+                        for (int jj = 0; jj < 4; jj++) {
+                            const int sidx = (s0 + jj < S - 1) ? s0 + jj : S - 2;
+                            gv[jj] = __hip_atomic_load(c0.gran + ((long)sidx * M + m) * ncat + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        ready = true;
+#pragma unroll
+                        for (int jj = 0; jj < 4; jj++) ready = ready && ((unsigned)(gv[jj] >> 32) == (tag ^ tag_skew));
+                        ready = __builtin_amdgcn_ballot_w64(!ready) == 0;
+                        if (!ready) __builtin_amdgcn_s_sleep(2);
+                    } while (!ready && ++spins < spin_limit);
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++)
+                        if (s0 + jj < S - 1) v += __uint_as_float((unsigned)gv[jj]);
+                    if (!ready) {  // never a silent number
+                        v = __uint_as_float(0x7fc00000u);
+                        if (ol == 0 && status) __hip_atomic_fetch_or(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                }
+                tot = v + tot;
+            }
+            if (m < M && on < N) c0.y[(long)m * N + on] = f32_to_f16_bits(tot);
+        }
+        __syncthreads();
+    }
+    if (S > 1 && slab_idx == S - 1 && tid == 0) c0.gen[colblock] = gen_next;
+}
+
+// K slabs of the matrix-pipe kernel: ~512 workgroups (column blocks x slabs), every wave at least 4 chunks (the prefetch depth)
+static void exl2_mfma_plan(int M, int K, int N, int& cps, int& S, int& mb, int& nw) {
+    mb = cdiv(M, 16);
+    nw = mb >= 2 ? 4 : 8;  // 32-64 accumulator + 8-16 x-fragment registers per prefetch set: one wave per SIMD (512 registers)
+    const int C = K / 32;
+    const int colblocks = cdiv(N, 64);
+    const int want_s = cdiv(nw == 8 ? 512 : 1024, colblocks);
+    cps = cdiv(C, want_s);
+    if (cps < 4 * nw) cps = 4 * nw;
+    cps = cdiv(cps, nw) * nw;
+    if (cps > 2048) cps = 2048;  // the group-map copy in LDS
+    if (cps > C) cps = C;
+    S = cdiv(C, cps);
+}
+static size_t exl2_mfma_lds_bytes(int mb, int nw, int cps) {
+    const size_t a = (size_t)nw * 64 * EXL2_T_PITCH * 2 + (size_t)cps * 4;
+    const size_t red = (size_t)nw * 16 * 64 * 4;
+    return a > red ? a : red;
+}
+bool exl2_mfma_ok(int M, int K, int N) { return M >= 3 && M <= 64 && K % 32 == 0 && cdiv(N, 64) <= BIE_WS_COUNTERS; }
+size_t exl2_mfma_granule_bytes(int M, int K, int N) {
+    if (!exl2_mfma_ok(M, K, N)) return 0;
+    int cps, S, mb, nw;
+    exl2_mfma_plan(M, K, N, cps, S, mb, nw);
+    return (S > 1 ? (size_t)(S - 1) * M * cdiv(N, 64) * 64 * 8 : 0) + 256 + (size_t)M * K * 2;  // granules, then x[:, q_perm]
+}
+static size_t exl2_mfma_xp_offset(int M, int K, int N) {
+    int cps, S, mb, nw;
+    exl2_mfma_plan(M, K, N, cps, S, mb, nw);
+    const size_t g = S > 1 ? (size_t)(S - 1) * M * cdiv(N, 64) * 64 * 8 : 0;
+    return (g + 255) / 256 * 256;
+}
+
 // ONE launch over a LIST of exl2 layers (bie_mbwq_exl2_list_*): block b -> {entry, column block | slab << 20} through a device table
 // (the MPQ list's idea, mpq_list.hip): a 4096x4096 3/2-bit layer is 5 MB -- far too little for a launch of its own.
 template <int MT>
@@ -576,6 +862,8 @@ size_t mbwq_workspace_bytes(int M, int K, int N) {
     exl2_decode_plan(M, K, N, cps2, S2, nw2);
     const size_t d = M <= 2 && S2 > 1 ? (size_t)(S2 - 1) * M * cdiv(N, 64) * 64 * 8 : 0;  // decode granules (unused when the fp32 kernel takes over)
     if (d > c) c = d;
+    const size_t e = exl2_mfma_granule_bytes(M, K, N);  // 3 <= M <= 64: granules of the matrix-pipe kernel's K slabs
+    if (e > c) c = e;
     size_t r = a > b ? a : b;
     return r > c ? r : c;
 }
@@ -644,6 +932,43 @@ int mbwq_exl2_forward_launch(const void* x, const int32_t* qw, const void* scale
         }
 #undef L2
         return check_launch("exl2_gemv2_kernel");
+    }
+    static const bool mfma_on = [] { const char* e = getenv("BIE_EXL2_MFMA"); return !e || atoi(e) != 0; }();
+    if (mfma_on && exl2_mfma_ok(M, K, N)) {  // 3 <= M <= 64: the decode kernel's stream feeding v_mfma_f32_16x16x32_f16
+        int cpsm, Sm, mb, nwm;
+        exl2_mfma_plan(M, K, N, cpsm, Sm, mb, nwm);
+        const size_t ldsm = exl2_mfma_lds_bytes(mb, nwm, cpsm);
+        const int colblocks = cdiv(N, 64);
+        dim3 gridm(colblocks, Sm);
+        const unsigned epoch = next_launch_epoch();
+        unsigned* gen = reinterpret_cast<unsigned*>(head) + BIE_WS_GEN_OFFSET;
+        unsigned skew;
+        int spin;
+        test_forge_get(&skew, &spin);
+        const uint16_t* xin = (const uint16_t*)x;
+        if (perm) {  // x[:, q_perm] once per call, behind the granule area of the workspace
+            uint16_t* xp = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(part) + exl2_mfma_xp_offset(M, K, N));
+            hipLaunchKernelGGL(exl2_permute_x_kernel, dim3(cdiv(K, 256), M < 16 ? M : 16), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)perm, xp, M, K);
+            int rc = check_launch("exl2_permute_x_kernel");
+            if (rc) return rc;
+            xin = xp;
+        }
+        Exl2Call call{xin, (const uint32_t*)qw, (const uint16_t*)scales, (const uint16_t*)zeros, nullptr,
+                      (const uint16_t*)gmap, reinterpret_cast<unsigned long long*>(part), gen, (uint16_t*)y, rows, M, K, N, cpsm, Sm, colblocks};
+        const bool narrow = rows7[2] == 0;  // cumulative end of the 5-bit band: no 8 / 6 / 5-bit rows
+#define LM(MBV, NWV, OCCN, OCCW)                                                                                                                 \
+    do {                                                                                                                                         \
+        if (narrow) hipLaunchKernelGGL((exl2_mfma_kernel<MBV, NWV, OCCN, true>), gridm, dim3(NWV * 64), ldsm, st, call, epoch, device_status_word(), skew, spin); \
+        else hipLaunchKernelGGL((exl2_mfma_kernel<MBV, NWV, OCCW, false>), gridm, dim3(NWV * 64), ldsm, st, call, epoch, device_status_word(), skew, spin);      \
+    } while (0)
+        switch (mb) {
+            case 1: LM(1, 8, 1, 1); break;
+            case 2: LM(2, 4, 2, 2); break;
+            case 3: LM(3, 4, 2, 1); break;
+            default: LM(4, 4, 2, 1); break;
+        }
+#undef LM
+        return check_launch("exl2_mfma_kernel");
     }
     const int cps = exl2_slabs(K, N);
     const int S = cdiv(K / 32, cps);

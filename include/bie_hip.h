@@ -195,7 +195,11 @@ int bie_mbwq_exl2_dequant(const int32_t* qweight, const void* scales, const void
 size_t bie_mbwq_workspace_bytes(int M, int K, int N);
 
 /* y[M, N] fp16 = x[:, q_perm] . dequant.  Replace q_linear_cuda.mbwq_q4_forward
- * (mbwq_linear_cuda_kernel.cu:742-825) and q_linear_cuda.mbwq_exl2_forward (:926-1007). */
+ * (mbwq_linear_cuda_kernel.cu:742-825) and q_linear_cuda.mbwq_exl2_forward (:926-1007).
+ * bie_mbwq_exl2_forward: one pass over the packed weight for M <= 64 (M <= 2 the decode kernel; 3 <= M <= 64 the same stream on the
+ * matrix pipe, after one x[:, q_perm] launch into the workspace; the reference's fused range is M <= 32, exl2/q_gemm_kernel.cuh:90-549);
+ * larger M is served in passes of 8 rows -- callers reconstruct (bie_mbwq_exl2_dequant) and use a dense GEMM there, as the
+ * reference does (:947-957).  q_perm may be NULL (no act-order). */
 int bie_mbwq_q4_forward(const void* x, const int32_t* qweight, const void* scales,
                         const void* zeros, const int16_t* q_perm, void* y, void* workspace,
                         size_t workspace_bytes, int M, int K, int N, int bits, int group_size,

@@ -295,7 +295,7 @@ def test_mbwq_q4_dequant_and_forward(bits, M, perm):
 
 
 @pytest.mark.parametrize("cfg", ["q_proj", "k_proj", "w3w2", "all6"])
-@pytest.mark.parametrize("M", [1, 2, 7, 11, 70])  # > EXL2_GEMV_MAX_M (8): reconstruct + library GEMM branch
+@pytest.mark.parametrize("M", [1, 2, 3, 7, 11, 16, 17, 33, 48, 64, 70])  # 3..48: matrix-pipe kernel (1-3 row blocks); > EXL2_GEMV_MAX_M (48): reconstruct + library GEMM
 def test_mbwq_exl2_dequant_and_forward(cfg, M):
     from bitorch_engine.extensions import q_linear_cuda
     from bitorch_engine.layers.qlinear.nbit.cuda.utils import make_group_map
@@ -320,6 +320,27 @@ def test_mbwq_exl2_dequant_and_forward(cfg, M):
     y = q_linear_cuda.mbwq_exl2_forward(x.to(DEV), qw.to(DEV), scales.to(DEV), zeros.to(DEV), q_perm.to(DEV), gmap.to(DEV), rows, False)
     ref = t16(orc.gemm(orc.torch_to_np(x), Wo, orc.F16), orc.F16)
     assert_close(y, ref, orc.F16, f"exl2 {cfg} M={M}")
+    if M in (16, 64):
+        # the C-ABI takes M <= 64 on the matrix-pipe kernel whatever the Python switch says (M = 64: four row blocks), and a NULL
+        # q_perm (no act-order: x is read in place, no permute launch)
+        from bitorch_engine import _hip
+        saved = q_linear_cuda.EXL2_GEMV_MAX_M
+        q_linear_cuda.EXL2_GEMV_MAX_M = 64
+        try:
+            y64 = q_linear_cuda.mbwq_exl2_forward(x.to(DEV), qw.to(DEV), scales.to(DEV), zeros.to(DEV), q_perm.to(DEV), gmap.to(DEV), rows, False)
+        finally:
+            q_linear_cuda.EXL2_GEMV_MAX_M = saved
+        assert_close(y64, ref, orc.F16, f"exl2 {cfg} M={M} fused")
+        L = _hip.lib()
+        xd, qd, sd, zd, gd = x.to(DEV), qw.to(DEV), scales.to(DEV), zeros.to(DEV), gmap.to(DEV)
+        yn = torch.empty((M, N), dtype=torch.float16, device=DEV)
+        ws = _hip.workspace(L.bie_mbwq_workspace_bytes(M, K, N), DEV)
+        keep, rp = q_linear_cuda._rows_arg(rows)
+        rc = L.bie_mbwq_exl2_forward(_hip.ptr(xd), _hip.ptr(qd), _hip.ptr(sd), _hip.ptr(zd), None, _hip.ptr(gd), rp, _hip.ptr(yn), _hip.ptr(ws),
+                                     ws.numel(), M, K, N, groups, _hip.stream())
+        assert rc == 0
+        Wn = orc.exl2_dequant(qw.numpy(), orc.torch_to_np(scales), orc.torch_to_np(zeros), None, q_groups.numpy(), K)
+        assert_close(yn, t16(orc.gemm(orc.torch_to_np(x), Wn, orc.F16), orc.F16), orc.F16, f"exl2 {cfg} M={M} no q_perm")
 
 
 def test_mbwq_layer_llama_shapes_w3w2_decode():
@@ -1071,7 +1092,7 @@ def test_full_size_exl2_w3w2_random_perm(K, N):
     Wd = q_linear_cuda.mbwq_exl2fp_weight(d(qw), d(scales), d(zeros), d(q_perm), d(gmap), rows)
     Wo = orc.exl2_dequant(qw.numpy(), orc.torch_to_np(scales), orc.torch_to_np(zeros), q_perm.numpy(), q_groups.numpy(), K)
     assert np.array_equal(orc.torch_to_np(Wd), Wo), "exl2 dequant at full size not bit-exact"
-    for M in (1, 2, 48):
+    for M in (1, 2, 5, 16, 48, 64):
         x = torch.randn((M, K), generator=gen).half()
         y = q_linear_cuda.mbwq_exl2_forward(d(x), d(qw), d(scales), d(zeros), d(q_perm), d(gmap), rows, False)
         ref = t16(orc.gemm(orc.torch_to_np(x), Wo, orc.F16), orc.F16)
