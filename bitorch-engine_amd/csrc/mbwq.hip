@@ -247,7 +247,9 @@ struct Exl2Call {  // everything one workgroup of the decode kernel needs (kerne
 // gathers the 32 activations of its own chunk together with the chunk's loads (wave-private LDS buffers) and the weight stream
 // starts one round trip earlier -- measured: one row 8.0 / 16.5 us per layer against 8.9 / 18.3 staged (4096x4096 / 4096x11008),
 // two rows 24.5 against 19.1 (profiles/r03_l_exl2_staged_x.txt).  Both forms are exact.
-template <int MT, int EX2_NW, bool STAGED>
+// NARROW: the tensor has no 8 / 6 / 5-bit rows (host: rows7[2] == 0): those bands' prefetch sets (4 x up to 8 words) are what sets the
+// kernel's register count -- 151 with them (8-wave workgroups: ONE per CU), <= 128 without (two per CU).
+template <int MT, int EX2_NW, bool STAGED, bool NARROW>
 __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, const uint32_t* __restrict__ qw,
                                                 const uint16_t* __restrict__ scales, const uint16_t* __restrict__ zeros,
                                                 const uint16_t* __restrict__ perm, const uint16_t* __restrict__ gmap,
@@ -434,13 +436,22 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
         if (two_groups) band(std::integral_constant<int, B>{}, std::true_type{}, cb0, cb1, p0); \
         else band(std::integral_constant<int, B>{}, std::false_type{}, cb0, cb1, p0);      \
     } while (0)
-                switch (b) {
-                    case 0: BIE_BAND(8); break;
-                    case 1: BIE_BAND(6); break;
-                    case 2: BIE_BAND(5); break;
-                    case 3: BIE_BAND(4); break;
-                    case 4: BIE_BAND(3); break;
-                    default: BIE_BAND(2); break;
+                if constexpr (NARROW) {
+                    switch (b) {
+                        case 3: BIE_BAND(4); break;
+                        case 4: BIE_BAND(3); break;
+                        case 5: BIE_BAND(2); break;
+                        default: break;  // the host checked: no such rows
+                    }
+                } else {
+                    switch (b) {
+                        case 0: BIE_BAND(8); break;
+                        case 1: BIE_BAND(6); break;
+                        case 2: BIE_BAND(5); break;
+                        case 3: BIE_BAND(4); break;
+                        case 4: BIE_BAND(3); break;
+                        default: BIE_BAND(2); break;
+                    }
                 }
 #undef BIE_BAND
             }
@@ -503,10 +514,10 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
 }
 
 
-template <int MT, int EX2_NW>
+template <int MT, int EX2_NW, bool NARROW>
 __global__ __launch_bounds__(EX2_NW * 64, (EX2_NW == 8 ? 2 : 1)) void exl2_gemv2_kernel(const Exl2Call c, unsigned epoch, unsigned* status, unsigned tag_skew,
                                                                                           int spin_limit) {
-    exl2_gemv2_body<MT, EX2_NW, (MT > 1)>(c.x, c.qw, c.scales, c.zeros, c.perm, c.gmap, c.gran, c.gen, c.y, c.rows, c.M, c.K, c.N,
+    exl2_gemv2_body<MT, EX2_NW, (MT > 1), NARROW>(c.x, c.qw, c.scales, c.zeros, c.perm, c.gmap, c.gran, c.gen, c.y, c.rows, c.M, c.K, c.N,
                                           c.chunks_per_slab, c.S, (int)blockIdx.x, (int)blockIdx.y, c.colblocks, epoch, status, tag_skew, spin_limit);
 }
 
@@ -798,9 +809,9 @@ static size_t exl2_mfma_xp_offset(int M, int K, int N) {
 
 // ONE launch over a LIST of exl2 layers (bie_mbwq_exl2_list_*): block b -> {entry, column block | slab << 20} through a device table
 // (the MPQ list's idea, mpq_list.hip): a 4096x4096 3/2-bit layer is 5 MB -- far too little for a launch of its own.
-template <int MT>
-__global__ __launch_bounds__(512, 2) void exl2_list_kernel(const Exl2Call* __restrict__ ent, const uint2_t* __restrict__ blk, unsigned epoch,
-                                                           unsigned* status, unsigned tag_skew, int spin_limit) {
+template <int MT, bool NARROW>
+__device__ __forceinline__ void exl2_list_body(const Exl2Call* __restrict__ ent, const uint2_t* __restrict__ blk, unsigned epoch, unsigned* status,
+                                               unsigned tag_skew, int spin_limit) {
     typedef const __attribute__((address_space(4))) uint2_t cu2_t;
     typedef const __attribute__((address_space(4))) Exl2Call ccall_t;
     const uint2_t rec = *((cu2_t*)(uintptr_t)(blk + blockIdx.x));
@@ -808,11 +819,15 @@ __global__ __launch_bounds__(512, 2) void exl2_list_kernel(const Exl2Call* __res
     Exl2Rows rows;
 #pragma unroll
     for (int i = 0; i < 6; i++) rows.r[i] = c->rows.r[i];
-    exl2_gemv2_body<MT, 8, (MT > 1)>(c->x, c->qw, c->scales, c->zeros, c->perm, c->gmap, c->gran, c->gen, c->y, rows, c->M, c->K, c->N,
-                                     c->chunks_per_slab, c->S, (int)(rec.y & 0xfffffu), (int)(rec.y >> 20), c->colblocks, epoch, status, tag_skew,
-                                     spin_limit);
+    exl2_gemv2_body<MT, 8, (MT > 1), NARROW>(c->x, c->qw, c->scales, c->zeros, c->perm, c->gmap, c->gran, c->gen, c->y, rows, c->M, c->K, c->N,
+                                             c->chunks_per_slab, c->S, (int)(rec.y & 0xfffffu), (int)(rec.y >> 20), c->colblocks, epoch, status,
+                                             tag_skew, spin_limit);
 }
-
+template <int MT, bool NARROW>
+__global__ __launch_bounds__(512, 2) void exl2_list_kernel(const Exl2Call* __restrict__ ent, const uint2_t* __restrict__ blk, unsigned epoch,
+                                                           unsigned* status, unsigned tag_skew, int spin_limit) {
+    exl2_list_body<MT, NARROW>(ent, blk, epoch, status, tag_skew, spin_limit);
+}
 // decode (M <= 2): column blocks x K slabs ~ 512 workgroups of 8 waves (two per CU -> one round), slabs in whole multiples of
 // 8 chunks so that the 8 waves of a workgroup get equal shares; at most BIE_WS_COUNTERS column blocks use the slab reduction
 static void exl2_decode_plan(int M, int K, int N, int& cps, int& S, int& nw) {
@@ -924,7 +939,12 @@ int mbwq_exl2_forward_launch(const void* x, const int32_t* qw, const void* scale
         test_forge_get(&skew, &spin);
         Exl2Call call{(const uint16_t*)x, (const uint32_t*)qw, (const uint16_t*)scales, (const uint16_t*)zeros, (const uint16_t*)perm,
                       (const uint16_t*)gmap, gran, gen, (uint16_t*)y, rows, M, K, N, cps2, S, colblocks};
-#define L2(MTV, NWV) hipLaunchKernelGGL((exl2_gemv2_kernel<MTV, NWV>), grid2, dim3(NWV * 64), lds2, st, call, epoch, device_status_word(), skew, spin)
+        const bool narrow2 = rows7[2] == 0;  // no 8 / 6 / 5-bit rows
+#define L2(MTV, NWV)                                                                                                                        \
+    do {                                                                                                                                    \
+        if (narrow2) hipLaunchKernelGGL((exl2_gemv2_kernel<MTV, NWV, true>), grid2, dim3(NWV * 64), lds2, st, call, epoch, device_status_word(), skew, spin); \
+        else hipLaunchKernelGGL((exl2_gemv2_kernel<MTV, NWV, false>), grid2, dim3(NWV * 64), lds2, st, call, epoch, device_status_word(), skew, spin);      \
+    } while (0)
         if (nw == 16) {
             if (MT == 1) L2(1, 16); else L2(2, 16);
         } else {
@@ -1002,6 +1022,7 @@ int status_report(const char* fn);  // splitk.hip
 
 struct Exl2List {
     int n = 0, M = 1, max_k = 0;
+    bool narrow = true;  // no entry has 8 / 6 / 5-bit rows: the leaner kernel instance
     unsigned grid = 0;
     size_t lds = 0;
     Exl2Call* d_ent = nullptr;
@@ -1107,6 +1128,8 @@ int exl2_list_create(Exl2List** out, int n, const bie_exl2_list_entry* e, int M,
     BIE_REQUIRE(err == hipSuccess, BIE_ERR_HIP, "bie_mbwq_exl2_list_create: uploading the plan: %s", hipGetErrorString(err));
     Exl2List* pl = new Exl2List();
     pl->n = n; pl->M = M; pl->grid = (unsigned)blocks; pl->lds = lds; pl->max_k = max_k;
+    for (int i = 0; i < n; i++)
+        if (e[i].rows7[2] != 0) pl->narrow = false;
     pl->d_ent = reinterpret_cast<Exl2Call*>(base);
     pl->d_blk = reinterpret_cast<uint2_t*>(base + o_blk);
     *out = pl;
@@ -1121,8 +1144,14 @@ int exl2_list_forward(Exl2List* p, hipStream_t st) {
     int spin;
     test_forge_get(&skew, &spin);
     const unsigned epoch = next_launch_epoch();
-    if (p->M == 1) hipLaunchKernelGGL((exl2_list_kernel<1>), dim3(p->grid), dim3(512), p->lds, st, p->d_ent, p->d_blk, epoch, device_status_word(), skew, spin);
-    else hipLaunchKernelGGL((exl2_list_kernel<2>), dim3(p->grid), dim3(512), p->lds, st, p->d_ent, p->d_blk, epoch, device_status_word(), skew, spin);
+#define LL(MTV)                                                                                                                                  \
+    do {                                                                                                                                         \
+        if (p->narrow) hipLaunchKernelGGL((exl2_list_kernel<MTV, true>), dim3(p->grid), dim3(512), p->lds, st, p->d_ent, p->d_blk, epoch, device_status_word(), skew, spin); \
+        else hipLaunchKernelGGL((exl2_list_kernel<MTV, false>), dim3(p->grid), dim3(512), p->lds, st, p->d_ent, p->d_blk, epoch, device_status_word(), skew, spin);      \
+    } while (0)
+    if (p->M == 1) LL(1);
+    else LL(2);
+#undef LL
     return check_launch("exl2_list_kernel");
 }
 
