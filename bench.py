@@ -166,15 +166,15 @@ class Bench:
             entries.append({"x": x, "qweight": qw, "scales": sc, "zeros": ze, "y": y, "depends_on": dep})
         return MPQForwardList(entries, w_bit=w_bit, group_size=GROUP)
 
-    def gemv_list(self, k, n, nl, per_launch, reps, seed, chain=0, w_bit=WBIT, key=None):
+    def gemv_list(self, k, n, nl, per_launch, reps, seed, chain=0, w_bit=WBIT, key=None, M=1):
         gen = torch.Generator(device=self.dev).manual_seed(seed)
         layers = [make_layer(self.dev, gen, k, n, w_bit) for _ in range(nl)]
-        plans = [self.make_list(layers[p0:p0 + per_launch], k, n, gen, chain=chain, w_bit=w_bit) for p0 in range(0, nl, per_launch)]
+        plans = [self.make_list(layers[p0:p0 + per_launch], k, n, gen, M=M, chain=chain, w_bit=w_bit) for p0 in range(0, nl, per_launch)]
         inner = 4 if len(plans) == 1 else 1  # a graph replay costs 10-16 us by itself: several passes per replay when a pass is one launch
         g = capture(lambda st: [p.forward(st) for _ in range(inner) for p in plans])
         us = time_graph(g, reps) / (nl * inner)
-        b = alg_bytes(1, k, n, w_bit)
-        return {"M": 1, "K": k, "N": n, "w_bit": w_bit, "layers": nl, "layers_per_launch": per_launch, "dependent_chain_length": chain,
+        b = alg_bytes(M, k, n, w_bit)
+        return {"M": M, "K": k, "N": n, "w_bit": w_bit, "layers": nl, "layers_per_launch": per_launch, "dependent_chain_length": chain,
                 "launches_per_pass": len(plans) * plans[0].launches, "us_per_layer": round(us, 3), "alg_bytes_per_layer": b,
                 "roofline": {"bound": "hbm", "achieved": round(b / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(b / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(key) if key else None}}
@@ -578,6 +578,9 @@ def main():
         # small decode batches through the matrix-pipe lookup kernel (M <= 16 costs about what M = 2 costs)
         guarded("c2_gemv_M8_4096x11008", lambda: B.gemv(4096, 11008, 40, 10, 16, M=8))
         guarded("c2_gemv_M16_4096x11008", lambda: B.gemv(4096, 11008, 40, 10, 17, M=16))
+        guarded("c2_list_M2_4096x11008", lambda: B.gemv_list(4096, 11008, 40, 40, 10, 18, M=2))   # batched decode: 40 layers, one launch
+        guarded("c2_list_M8_4096x11008", lambda: B.gemv_list(4096, 11008, 40, 40, 10, 19, M=8))
+        guarded("c2_list_M16_4096x11008", lambda: B.gemv_list(4096, 11008, 40, 40, 10, 20, M=16))
         guarded("c2_act_order_4096x11008", lambda: bench_act_order(dev))
         guarded("c2_gemm_4096x11008", lambda: B.gemm(4096, 4096, 11008, 16, 3, 14))
         guarded("c2_gemm_11008x4096", lambda: B.gemm(4096, 11008, 4096, 16, 3, 15))

@@ -1,4 +1,4 @@
-"""Decode (M <= 2) over a LIST of MPQ layers in ONE kernel launch (bie_mpq_list_*, include/bie_hip.h).
+"""Decode (M <= 2; W4: M <= 16) over a LIST of MPQ layers in ONE kernel launch (bie_mpq_list_*, include/bie_hip.h).
 
 The reference launches one `quant_mm_kernel` per layer on the default stream
 (layers/qlinear/nbit/cuda/mpq_layer.py:65 -> mpq_linear_cuda_kernel.cu:482-577).  A 4096x4096 W4 layer is 8.9 MB --
@@ -48,8 +48,8 @@ class MPQForwardList:
         self._entries = arr
         nbytes = L.bie_mpq_list_device_bytes(len(entries), arr, self.M, w_bit, group_size)
         if nbytes == 0:
-            raise RuntimeError("MPQForwardList: this list is outside the one-launch decode range (1 <= M <= 2, w_bit 4 with groups of "
-                               "32/64/128/256 or w_bit 2 with 64/128/256, K a multiple of one common group size)")
+            raise RuntimeError("MPQForwardList: this list is outside the one-launch decode range (w_bit 4: 1 <= M <= 16, groups of 32/64/128/256; "
+                               "w_bit 2: M <= 2, groups of 64/128/256; K a multiple of one common group size)")
         self._mem = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
         base = (self._mem.data_ptr() + 255) // 256 * 256
         handle = ctypes.c_void_p()

@@ -26,6 +26,7 @@
 // REPLAY of a captured launch carries the same call number but the next generation)}; nothing ever has to be reset.  `bie_mpq_forward_grouped` passes several weight sets that share x
 // (q/k/v, gate/up): their column tiles are concatenated into one grid.
 #include "mpq_dequant.cuh"
+#include "mpq_list.h"
 #include <stdlib.h>
 #include <atomic>
 
@@ -671,8 +672,19 @@ __device__ __forceinline__ void lutm_issue8(uint32_t (&l)[8], uint32_t ca, uint3
     asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(l[7]) : "v"(lut_addr<3>(ca, wo)), "n"(OFF) : "memory");
 }
 
-template <int DT, int ZM, int RPG, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void mpq_gemv_lutm_kernel(const LutArgs a) {
+// what one workgroup of the matrix-pipe form needs about its layer: filled from the kernel arguments (one launch per layer / set of
+// layers sharing x) or from a device-resident ListEntry (bie_mpq_list_*, 3 <= M <= 16: many layers in one launch)
+struct LutmView {
+    const uint32_t* qw; const uint16_t* scales; const void* zeros; const uint16_t* bias; uint16_t* y; const uint16_t* x;
+    unsigned long long* gran;  // [S-1][M][ncat] granules of the launch / of the list entry
+    unsigned* gen;             // generation words, indexed by the tile number the granule columns are counted in
+    int N, M, K, G, S, gpw, hshift;
+    long ncat;                 // granule columns: tiles * 64
+};
+
+template <int DT, int ZM, int RPG, int NW, bool PF>  // PF: the next unit's loads in flight under the current one (costs ~40 registers)
+__device__ __forceinline__ void lutm_body(const LutmView& lv, const int tile_local, const int gtile, const int slice, const unsigned epoch,
+                                          unsigned* status, const unsigned tag_skew, const int spin_limit) {
     constexpr int NB = 8;
     constexpr int RQ = RPG / 4;  // row quads (32 k) per unit
     static_assert(NW <= 8 && RPG % 4 == 0, "wave bits of the table address / whole row quads");
@@ -681,44 +693,37 @@ __global__ __launch_bounds__(NW * 64, 2) void mpq_gemv_lutm_kernel(const LutArgs
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 15, kb = lane >> 4;
-    const int tile = blockIdx.x % a.tiles_total;
-    const int slice = blockIdx.x / a.tiles_total;
-    int si = 0;
-#pragma unroll
-    for (int i = 1; i < LUT_MAX_SETS; i++)
-        if (i < a.nsets && tile >= a.set[i].tile_begin) si = i;
-    const LutSet& ls = a.set[si];
-    const int N = ls.N;  // N % 4 == 0 on this path: a lane's four columns are all in range or all out
-    const int M = a.M;
-    const int nt0 = (tile - ls.tile_begin) * 64;
+    const int N = lv.N;  // N % 4 == 0 on this path: a lane's four columns are all in range or all out
+    const int M = lv.M;
+    const int nt0 = tile_local * 64;
     const int n4 = nt0 + 4 * c < N ? nt0 + 4 * c : N - 4;  // clamp: out-of-range columns load valid memory and are never stored
-    const int g0 = (slice * NW + wave) * a.groups_per_wave;
-    int g1 = g0 + a.groups_per_wave;
-    if (g1 > a.G) g1 = a.G;
+    const int g0 = (slice * NW + wave) * lv.gpw;
+    int g1 = g0 + lv.gpw;
+    if (g1 > lv.G) g1 = lv.G;
     unsigned tag = 0, gen_next = 0;
-    if (a.S > 1) {
-        gen_next = a.gen[tile] + 1u;
-        tag = a.epoch | (gen_next & 0xffu);
+    if (lv.S > 1) {
+        gen_next = lv.gen[gtile] + 1u;
+        tag = epoch | (gen_next & 0xffu);
     }
 
     // x as a raw buffer: rows >= M are out of bounds and read as 0 (the unused columns of the MFMA's second operand)
-    const uint64_t xb = (uint64_t)(uintptr_t)a.x;
+    const uint64_t xb = (uint64_t)(uintptr_t)lv.x;
     const uint32_t xlo = __builtin_amdgcn_readfirstlane((uint32_t)xb), xhi = __builtin_amdgcn_readfirstlane((uint32_t)(xb >> 32));  // unsigned: no sign extension
     const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((uint64_t)xhi << 32) | xlo), 0,
-                                                         __builtin_amdgcn_readfirstlane((uint32_t)((long)M * a.K * 2)), 0x00020000);
-    const uint32_t xvoff = c < M ? (uint32_t)(c * a.K * 2 + kb * 16) : 0x80000000u;
+                                                         __builtin_amdgcn_readfirstlane((uint32_t)((long)M * lv.K * 2)), 0x00020000);
+    const uint32_t xvoff = c < M ? (uint32_t)(c * lv.K * 2 + kb * 16) : 0x80000000u;
 
-    const uint32_t* wcol = ls.qw + n4;
+    const uint32_t* wcol = lv.qw + n4;
     auto load_params = [&](int unit, uint32_t (&sb)[4], uint32_t (&zb)[4]) {
-        const int g = unit >> a.hshift;
-        const uint2_t s2 = *reinterpret_cast<const uint2_t*>(ls.scales + (long)g * N + n4);
+        const int g = unit >> lv.hshift;
+        const uint2_t s2 = *reinterpret_cast<const uint2_t*>(lv.scales + (long)g * N + n4);
         sb[0] = s2.x & 0xffffu; sb[1] = s2.x >> 16; sb[2] = s2.y & 0xffffu; sb[3] = s2.y >> 16;
         if constexpr (ZM == ZM_ASYM) {
-            const uint32_t zw = reinterpret_cast<const uint32_t*>(ls.zeros)[(long)g * (N / NB) + n4 / NB];
+            const uint32_t zw = reinterpret_cast<const uint32_t*>(lv.zeros)[(long)g * (N / NB) + n4 / NB];
 #pragma unroll
             for (int f = 0; f < 4; f++) zb[f] = ((zw >> (((n4 % NB) + f) * 4)) & 15u) + 1u;
         } else {
-            const uint2_t z2 = *reinterpret_cast<const uint2_t*>(reinterpret_cast<const uint16_t*>(ls.zeros) + (long)g * N + n4);
+            const uint2_t z2 = *reinterpret_cast<const uint2_t*>(reinterpret_cast<const uint16_t*>(lv.zeros) + (long)g * N + n4);
             zb[0] = z2.x & 0xffffu; zb[1] = z2.x >> 16; zb[2] = z2.y & 0xffffu; zb[3] = z2.y >> 16;
         }
     };
@@ -801,14 +806,30 @@ __global__ __launch_bounds__(NW * 64, 2) void mpq_gemv_lutm_kernel(const LutArgs
 
     // one unit per wave is the normal plan (its rows, activations and constants are requested up front, constants first so that
     // the table is built under the row latency); further units of a wave (very wide layers) are taken one after the other
-    uint4_t wa[RQ];
-    uint4_t xa[RQ];
-    uint32_t sa[4] = {0, 0, 0, 0}, za[4] = {0, 0, 0, 0};
-    for (int g = g0; g < g1; g++) {
-        load_params(g, sa, za);
-        asm volatile("" ::: "memory");
-        load_unit(wa, xa, g);
-        process_unit(wa, xa, sa, za);
+    uint4_t wa[RQ], wn[RQ];
+    uint4_t xa[RQ], xn[RQ];
+    uint32_t sa[4] = {0, 0, 0, 0}, za[4] = {0, 0, 0, 0}, sn[4] = {0, 0, 0, 0}, zn[4] = {0, 0, 0, 0};
+    if (!PF || g1 - g0 <= 1) {  // the per-layer plan: one unit per wave (more only on very wide layers)
+        for (int g = g0; g < g1; g++) {
+            load_params(g, sa, za);
+            asm volatile("" ::: "memory");
+            load_unit(wa, xa, g);
+            process_unit(wa, xa, sa, za);
+        }
+    } else {  // several units per wave (list launches, very wide layers): the next unit's rows and constants are in flight under the current one
+        load_params(g0, sa, za);
+        load_unit(wa, xa, g0);
+        for (int g = g0; g < g1; g += 2) {
+            const int gn = g + 1 < g1 ? g + 1 : g1 - 1;  // clamped: an unconditional issue keeps the waits exact
+            load_params(gn, sn, zn);
+            load_unit(wn, xn, gn);
+            process_unit(wa, xa, sa, za);
+            if (g + 1 >= g1) break;
+            const int gnn = g + 2 < g1 ? g + 2 : g1 - 1;
+            load_params(gnn, sa, za);
+            load_unit(wa, xa, gnn);
+            process_unit(wn, xn, sn, zn);
+        }
     }
 
     // ---- workgroup reduction through LDS (the tables are dead).  D layout of the 16x16 MFMA: lane (kb', m) holds in acc[f][r] the
@@ -826,52 +847,81 @@ __global__ __launch_bounds__(NW * 64, 2) void mpq_gemv_lutm_kernel(const LutArgs
     // wave w finishes x rows m = w, w + NW, ...: lane = column of the tile
     const int n = nt0 + lane;
     const bool owner = n < N;
-    const long ncat = (long)a.tiles_total * 64;
-    const long col = (long)tile * 64 + lane;
+    const long ncat = lv.ncat;
+    const long col = (long)gtile * 64 + lane;
     for (int m = wave; m < M; m += NW) {
         float tot = 0.0f;
 #pragma unroll
         for (int ww = 0; ww < NW; ww++) tot += red[(ww * M + m) * 64 + lane];
-        if (a.S > 1) {
-            if (slice != a.S - 1) {
+        if (lv.S > 1) {
+            if (slice != lv.S - 1) {
                 const unsigned long long gval = ((unsigned long long)tag << 32) | __float_as_uint(tot);
-                __hip_atomic_store(a.gran + ((long)slice * M + m) * ncat + col, gval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(lv.gran + ((long)slice * M + m) * ncat + col, gval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 continue;
             }
             float v = 0.0f;
-            for (int s0 = 0; s0 < a.S - 1; s0 += 8) {
+            for (int s0 = 0; s0 < lv.S - 1; s0 += 8) {
                 unsigned long long gv[8];
                 bool ready;
                 int spins = 0;
                 do {
 #pragma unroll
                     for (int jj = 0; jj < 8; jj++) {
-                        const int sidx = (s0 + jj < a.S - 1) ? s0 + jj : a.S - 2;
-                        gv[jj] = __hip_atomic_load(a.gran + ((long)sidx * M + m) * ncat + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const int sidx = (s0 + jj < lv.S - 1) ? s0 + jj : lv.S - 2;
+                        gv[jj] = __hip_atomic_load(lv.gran + ((long)sidx * M + m) * ncat + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     ready = true;
 #pragma unroll
-                    for (int jj = 0; jj < 8; jj++) ready = ready && ((unsigned)(gv[jj] >> 32) == (tag ^ a.tag_skew));
+                    for (int jj = 0; jj < 8; jj++) ready = ready && ((unsigned)(gv[jj] >> 32) == (tag ^ tag_skew));
                     ready = __builtin_amdgcn_ballot_w64(!ready) == 0;
                     if (!ready) __builtin_amdgcn_s_sleep(2);
-                } while (!ready && ++spins < a.spin_limit);
+                } while (!ready && ++spins < spin_limit);
 #pragma unroll
                 for (int jj = 0; jj < 8; jj++)
-                    if (s0 + jj < a.S - 1) v += __uint_as_float((unsigned)gv[jj]);
+                    if (s0 + jj < lv.S - 1) v += __uint_as_float((unsigned)gv[jj]);
                 if (!ready) {  // wave-uniform: never a silent number
                     v = __uint_as_float(0x7fc00000u);
-                    if (lane == 0 && a.status) __hip_atomic_fetch_or(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (lane == 0 && status) __hip_atomic_fetch_or(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
             }
             tot = v + tot;
         }
         if (owner) {
             float o = dt_traits<DT>::round(tot);
-            if (ls.bias) o = o + dt_traits<DT>::load(ls.bias, n);
-            dt_traits<DT>::store(ls.y, (long)m * N + n, o);
+            if (lv.bias) o = o + dt_traits<DT>::load(lv.bias, n);
+            dt_traits<DT>::store(lv.y, (long)m * N + n, o);
         }
     }
-    if (a.S > 1 && slice == a.S - 1 && threadIdx.x == 0) a.gen[tile] = gen_next;  // read only by the next launch
+    if (lv.S > 1 && slice == lv.S - 1 && threadIdx.x == 0) lv.gen[gtile] = gen_next;  // read only by the next launch
+}
+
+
+template <int DT, int ZM, int RPG, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void mpq_gemv_lutm_kernel(const LutArgs a) {
+    const int tile = blockIdx.x % a.tiles_total;
+    const int slice = blockIdx.x / a.tiles_total;
+    int si = 0;
+#pragma unroll
+    for (int i = 1; i < LUT_MAX_SETS; i++)
+        if (i < a.nsets && tile >= a.set[i].tile_begin) si = i;
+    const LutSet& ls = a.set[si];
+    const LutmView v{ls.qw, ls.scales, ls.zeros, ls.bias, ls.y, a.x, a.gran, a.gen, ls.N, a.M, a.K, a.G, a.S, a.groups_per_wave, a.hshift,
+                     (long)a.tiles_total * 64};
+    lutm_body<DT, ZM, RPG, NW, false>(v, tile - ls.tile_begin, tile, slice, a.epoch, a.status, a.tag_skew, a.spin_limit);
+}
+
+// ONE launch over a LIST of layers, 3 <= M <= 16 (bie_mpq_list_*): block b -> {entry, tile | slice << 20}; the entry's granules and
+// generation words are its own (tile numbers local to the entry).
+template <int DT, int ZM, int RPG, int NW, bool PF>
+__global__ __launch_bounds__(NW * 64, 2) void mpq_lutm_list_kernel(const ListEntry* __restrict__ ent, const uint2_t* __restrict__ blk, const int M,
+                                                                  const unsigned epoch, unsigned* status, const unsigned tag_skew, const int spin_limit) {
+    typedef const __attribute__((address_space(4))) uint2_t cu2_t;
+    typedef const __attribute__((address_space(4))) ListEntry cent_t;
+    const uint2_t rec = *((cu2_t*)(uintptr_t)(blk + blockIdx.x));
+    cent_t* e = (cent_t*)(uintptr_t)(ent + rec.x);
+    const int tile = (int)(rec.y & 0xfffffu), slice = (int)(rec.y >> 20);
+    const LutmView v{e->qw, e->scales, e->zeros, e->bias, e->y, e->x, e->gran, e->gen, e->N, M, e->K, e->G, e->S, e->gpw, e->hshift, (long)e->tiles * 64};
+    lutm_body<DT, ZM, RPG, NW, PF>(v, tile, tile, slice, epoch, status, tag_skew, spin_limit);
 }
 
 #ifdef BIE_LAB_BUILD
@@ -1106,6 +1156,33 @@ static void lutm_launch(const LutArgs& a, int rpg, int grid, int zm, hipStream_t
     else if (zm == ZM_FUSED) { BIE_LUTM(ZM_FUSED) }
     else { BIE_LUTM(ZM_SYM) }
 #undef BIE_LUTM
+}
+
+// the list form of the matrix-pipe kernel (mpq_list.hip builds the entries and the block table)
+template <int DT, bool PF>
+static void lutm_list_launch_dt(const ListEntry* ent, const uint2_t* blk, unsigned grid, int M, int rpg, int zm, unsigned epoch, unsigned* status,
+                                unsigned skew, int spin, hipStream_t st) {
+#define BIE_LUTML(ZMV)                                                                                                                               \
+    switch (rpg) {                                                                                                                                   \
+        case 4: hipLaunchKernelGGL((mpq_lutm_list_kernel<DT, ZMV, 4, 8, PF>), dim3(grid), dim3(512), 0, st, ent, blk, M, epoch, status, skew, spin); break;   \
+        case 8: hipLaunchKernelGGL((mpq_lutm_list_kernel<DT, ZMV, 8, 8, PF>), dim3(grid), dim3(512), 0, st, ent, blk, M, epoch, status, skew, spin); break;   \
+        case 16: hipLaunchKernelGGL((mpq_lutm_list_kernel<DT, ZMV, 16, 8, PF>), dim3(grid), dim3(512), 0, st, ent, blk, M, epoch, status, skew, spin); break; \
+        default: hipLaunchKernelGGL((mpq_lutm_list_kernel<DT, ZMV, 32, 8, PF>), dim3(grid), dim3(512), 0, st, ent, blk, M, epoch, status, skew, spin); break; \
+    }
+    if (zm == ZM_ASYM) { BIE_LUTML(ZM_ASYM) }
+    else { BIE_LUTML(ZM_SYM) }
+#undef BIE_LUTML
+}
+int mpq_lutm_list_launch(const ListEntry* ent, const uint2_t* blk, unsigned grid, int M, int rpg, int zm, int dtype, hipStream_t st) {
+    unsigned skew;
+    int spin;
+    test_forge_get(&skew, &spin);
+    const unsigned epoch = next_launch_epoch();
+    // (the next-unit prefetch variant, PF = true, needs 139 registers: one 8-wave workgroup per CU instead of two -- measured 8.4 against
+    //  6.7 us per 4096x11008 layer at M = 8, profiles/r03_z_lutm_list_ab.txt; not instantiated)
+    if (dtype == BIE_F16) lutm_list_launch_dt<BIE_F16, false>(ent, blk, grid, M, rpg, zm, epoch, device_status_word(), skew, spin, st);
+    else lutm_list_launch_dt<BIE_BF16, false>(ent, blk, grid, M, rpg, zm, epoch, device_status_word(), skew, spin, st);
+    return check_launch("mpq_lutm_list_kernel");
 }
 
 // sets: n weight sets sharing x (one for a plain forward).  `gen` = the workspace's head, `gran` = granule area.

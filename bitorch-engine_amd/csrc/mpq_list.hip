@@ -25,6 +25,7 @@
 //   * the tagged-granule cross-workgroup reduction of the lookup GEMV, now FAILING LOUDLY: a reducer whose granules do not
 //     arrive within the spin bound stores NaN and raises a bit in the host-visible status page (bie_device_status).
 #include "mpq_dequant.cuh"
+#include "mpq_list.h"
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
@@ -35,22 +36,7 @@ namespace bie {
 
 unsigned* device_status_word();  // status.hip: device pointer of the host-mapped status page (NULL before bie_status_init)
 void test_forge_get(unsigned* tag_skew, int* spin_limit);
-
-struct ListEntry {          // 128 bytes, read with scalar loads
-    const uint32_t* qw;
-    const uint16_t* scales;
-    const void* zeros;
-    const uint16_t* bias;
-    const uint16_t* x;
-    uint16_t* y;
-    unsigned long long* gran;  // [S-1][M][tiles*64] {fp32 partial, tag} granules of this entry (NULL when S == 1)
-    unsigned* gen;             // [tiles] generation words of this entry's column tiles
-    unsigned* done;            // completion counter of this entry (tiles finished, monotonic over launches)
-    const unsigned* dep_done;  // the producer's counter (NULL: independent)
-    int N, K, G, gpw, S, hshift, tiles, dep_tiles;
-    unsigned qw_bytes, sc_bytes, ze_bytes, pad0;
-};
-static_assert(sizeof(ListEntry) == 128, "ListEntry layout");
+int mpq_lutm_list_launch(const ListEntry* ent, const uint2_t* blk, unsigned grid, int M, int rpg, int zm, int dtype, hipStream_t st);  // mpq_gemv_lut.hip
 
 struct ListArgs {
     const ListEntry* ent;
@@ -484,6 +470,7 @@ struct MpqList {
     int nw = 8;                // waves per workgroup
     unsigned grid = 0;
     bool has_deps = false;
+    bool lutm = false;         // the lookup / matrix-pipe kernel (mpq_gemv_lut.hip) instead of the lookup / FMA kernel below
     ListEntry* d_ent = nullptr;
     uint2_t* d_blk = nullptr;
     unsigned* d_done = nullptr;
@@ -546,7 +533,8 @@ static void list_plan(int n, const bie_mpq_list_entry* ent, int w_bit, int group
 }
 
 static bool list_shape_ok(int n, const bie_mpq_list_entry* ent, int M, int w_bit, int group_size) {
-    if (n <= 0 || !ent || M < 1 || M > 2 || (w_bit != 4 && w_bit != 2)) return false;
+    if (n <= 0 || !ent || M < 1 || M > 16 || (w_bit != 4 && w_bit != 2)) return false;
+    if (M > 2 && w_bit != 4) return false;  // 3 <= M <= 16: the matrix-pipe list kernel (mpq_gemv_lut.hip), W4 only
     const int NB = 32 / w_bit;
     int gs0 = -1;
     for (int i = 0; i < n; i++) {
@@ -606,7 +594,7 @@ int mpq_list_create(MpqList** out, int n, const bie_mpq_list_entry* ent, int M, 
     BIE_REQUIRE(out && ent && device_mem, BIE_ERR_INVALID_ARG, "bie_mpq_list_create: NULL argument");
     BIE_REQUIRE(dtype == BIE_F16 || dtype == BIE_BF16, BIE_ERR_UNSUPPORTED, "bie_mpq_list_create: dtype %d (fp16 / bf16 only)", dtype);
     BIE_REQUIRE(list_shape_ok(n, ent, M, w_bit, group_size), BIE_ERR_UNSUPPORTED,
-                "bie_mpq_list_create: a list takes 1 <= M <= 2, w_bit 4 (groups of 32/64/128/256) or 2 (64/128/256), K a multiple of ONE common group size");
+                "bie_mpq_list_create: a list takes 1 <= M <= 2 (w_bit 4: up to 16), w_bit 4 (groups of 32/64/128/256) or 2 (64/128/256), K a multiple of ONE common group size");
     for (int i = 0; i < n; i++) {
         BIE_REQUIRE(ent[i].x && ent[i].qweight && ent[i].scales && ent[i].zeros && ent[i].y, BIE_ERR_INVALID_ARG, "bie_mpq_list_create: NULL tensor pointer in entry %d", i);
         BIE_REQUIRE(ent[i].depends_on < i, BIE_ERR_INVALID_ARG, "bie_mpq_list_create: entry %d depends on entry %d, which is not EARLIER in the list", i, ent[i].depends_on);
@@ -615,6 +603,11 @@ int mpq_list_create(MpqList** out, int n, const bie_mpq_list_entry* ent, int M, 
             BIE_REQUIRE(d.y == ent[i].x && d.N == ent[i].K, BIE_ERR_INVALID_ARG, "bie_mpq_list_create: entry %d depends on entry %d but does not read its y (x != y or K != N)", i, ent[i].depends_on);
         }
         if (asym) BIE_REQUIRE(ent[i].N % (32 / w_bit) == 0, BIE_ERR_INVALID_ARG, "bie_mpq_list_create: asym needs N %% %d == 0 (entry %d)", 32 / w_bit, i);
+        if (M > 2) {
+            BIE_REQUIRE(ent[i].depends_on < 0, BIE_ERR_UNSUPPORTED, "bie_mpq_list_create: dependent entries need M <= 2 (entry %d, M = %d)", i, M);
+            BIE_REQUIRE(ent[i].N % 4 == 0, BIE_ERR_UNSUPPORTED, "bie_mpq_list_create: 3 <= M <= 16 needs N %% 4 == 0 (entry %d)", i);
+            BIE_REQUIRE((reinterpret_cast<uintptr_t>(ent[i].x) & 15) == 0 && ent[i].K % 8 == 0, BIE_ERR_INVALID_ARG, "bie_mpq_list_create: 3 <= M <= 16 needs a 16-byte aligned x and K %% 8 == 0 (entry %d)", i);
+        }
         BIE_REQUIRE((reinterpret_cast<uintptr_t>(ent[i].x) & 3) == 0, BIE_ERR_INVALID_ARG, "bie_mpq_list_create: x of entry %d must be 4-byte aligned", i);
     }
     std::vector<ListPlanEntry> pe;
@@ -622,6 +615,16 @@ int mpq_list_create(MpqList** out, int n, const bie_mpq_list_entry* ent, int M, 
     list_plan(n, ent, w_bit, group_size, &rpg, pe);
     int nw = (M == 1 && w_bit == 4) ? 4 : 8;
     if (dtype == BIE_BF16 && !asym && M == 1 && rpg == 16 && w_bit == 4) nw = list_nw(M, w_bit);  // the lab configuration takes the override
+    // Two rows of W4 also go to the matrix-pipe kernel when the entries allow it (independent, N % 4 == 0, 16-byte aligned x): measured
+    // 6.6 against 7.5 us per 4096x11008 layer for the two-row FMA form (profiles/r03_z_lutm_list_ab.txt).  BIE_LIST_M2_MFMA=0: FMA form.
+    static const int m2_mfma = list_env("BIE_LIST_M2_MFMA", 1);
+    bool lutm = M > 2;
+    if (M == 2 && w_bit == 4 && m2_mfma) {
+        lutm = true;
+        for (int i = 0; i < n; i++)
+            if (ent[i].depends_on >= 0 || ent[i].N % 4 || (reinterpret_cast<uintptr_t>(ent[i].x) & 15) || ent[i].K % 8) lutm = false;
+    }
+    if (lutm) nw = 8;  // the matrix-pipe kernel: eight waves, each with its own 8 KiB table
     list_plan(n, ent, w_bit, group_size, &rpg, pe, nw);
     const ListLayout L = list_layout(n, pe, M);
     BIE_REQUIRE(device_bytes >= L.total, BIE_ERR_WORKSPACE, "bie_mpq_list_create: device buffer of %zu bytes required, got %zu", L.total, device_bytes);
@@ -685,6 +688,7 @@ int mpq_list_create(MpqList** out, int n, const bie_mpq_list_entry* ent, int M, 
     pl->nw = nw;
     pl->grid = L.grid;
     pl->has_deps = has_deps;
+    pl->lutm = lutm;
     pl->d_ent = reinterpret_cast<ListEntry*>(base + L.ent);
     pl->d_blk = reinterpret_cast<uint2_t*>(base + L.blk);
     pl->d_done = reinterpret_cast<unsigned*>(base + L.done);
@@ -729,6 +733,8 @@ int mpq_list_forward(MpqList* p, hipStream_t st) {
         const hipError_t e = hipMemsetAsync(p->d_done, 0, p->done_bytes, st);
         BIE_REQUIRE(e == hipSuccess, BIE_ERR_HIP, "bie_mpq_list_forward: hipMemsetAsync: %s", hipGetErrorString(e));
     }
+    if (p->lutm)  // 2 / 3 <= M <= 16: lookups feeding v_mfma_f32_16x16x32 (mpq_gemv_lut.hip), same entries and block table
+        return mpq_lutm_list_launch(p->d_ent, p->d_blk, p->grid, p->M, p->rpg, p->zm, p->dtype, st);
     ListArgs a;
     a.ent = p->d_ent;
     a.blk = p->d_blk;

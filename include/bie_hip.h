@@ -105,11 +105,13 @@ int bie_mpq_forward_grouped(const void* x, int n_sets, const int32_t* const* qwe
                             void* workspace, size_t workspace_bytes, int M, int K, int w_bit, int group_size,
                             int asym, int dtype, void* stream);
 
-/* A LIST of decode layers (M <= 2) in ONE launch.  Entry i computes y_i[M, N_i] = x_i[M, K_i] . dequant(qweight_i) (+ bias_i)
+/* A LIST of decode layers (M <= 2; w_bit 4: M <= 16, batched / speculative decode) in ONE launch.  Entry i computes y_i[M, N_i] = x_i[M, K_i] . dequant(qweight_i) (+ bias_i)
  * exactly as bie_mpq_forward with g_idx = NULL would; entries may differ in K, N and in their x / y buffers, while w_bit (4 or
  * 2), group_size, dtype (fp16 / bf16) and asym are common to the list.  `depends_on` >= 0 names an EARLIER entry whose y buffer
  * is this entry's x (a chain y_l -> x_{l+1}): the dependent entry's workgroups request their weight rows first and then wait for
- * the producer's completion count, so the weight stream of layer l+1 runs under the compute and reduction of layer l.
+ * the producer's completion count, so the weight stream of layer l+1 runs under the compute and reduction of layer l
+ * (M <= 2 only).  Rows 3...16 (and 2 when the entries are independent, N % 4 == 0, x 16-byte aligned) take the lookup /
+ * matrix-pipe kernel (v_mfma_f32_16x16x32); they need N % 4 == 0, K % 8 == 0 and a 16-byte aligned x.
  * No reference counterpart: the reference issues one default-stream quant_mm_kernel launch per layer
  * (layers/qlinear/nbit/cuda/mpq_linear_cuda_kernel.cu:482-577, mpq_layer.py:65); an 8.9 MB layer is over before the chip is
  * full, so the per-layer launch can never be bandwidth-bound.  This entry point is what makes decode HBM-bound on MI355X.

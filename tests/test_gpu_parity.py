@@ -1357,7 +1357,10 @@ def _list_case(specs, dt, w_bit, gs, asym, M, seed, chain=False):
 
 
 @pytest.mark.parametrize("dt,w_bit,gs,asym,M", [(orc.BF16, 4, 128, 0, 1), (orc.BF16, 4, 64, 1, 2), (orc.F16, 4, 128, 0, 1), (orc.F16, 4, 32, 1, 1),
-                                                  (orc.BF16, 2, 128, 0, 1), (orc.F16, 2, 64, 1, 2), (orc.BF16, 4, 256, 0, 2)])
+                                                  (orc.BF16, 2, 128, 0, 1), (orc.F16, 2, 64, 1, 2), (orc.BF16, 4, 256, 0, 2),
+                                                  # 3 <= M <= 16: the lookup / matrix-pipe kernel in list form (mpq_lutm_list_kernel)
+                                                  (orc.BF16, 4, 128, 0, 3), (orc.F16, 4, 64, 1, 8), (orc.BF16, 4, 32, 0, 16), (orc.F16, 4, 256, 0, 5),
+                                                  (orc.BF16, 4, 128, 1, 16)])
 def test_list_forward_mixed_shapes_vs_oracle_and_single_calls(dt, w_bit, gs, asym, M):
     """bie_mpq_list_forward: entries with different K / N (ragged column tiles, N % 64 = 8, 40), bias on some, each with its own x;
     small list -> groups split over waves and K sliced over workgroups (tagged-granule reduction inside the launch).  Every entry
@@ -1381,13 +1384,14 @@ def test_list_forward_mixed_shapes_vs_oracle_and_single_calls(dt, w_bit, gs, asy
         assert torch.equal(e["y"], first[i]), f"entry {i}: a second launch of the plan differs"
 
 
-def test_list_forward_big_list_whole_k_per_workgroup_and_graph_replay():
+@pytest.mark.parametrize("M", [1, 8])
+def test_list_forward_big_list_whole_k_per_workgroup_and_graph_replay(M):
     """A list big enough that every workgroup owns a column tile's whole K range (S = 1, several units per wave, the next unit's rows
-    in flight): 48 layers of 4096 -> 1024 (W4 g128 bf16).  Captured in a HIP graph and replayed with NEW activations: the plan
-    freezes pointers, not contents."""
+    in flight): 48 layers of 4096 -> 1024 (W4 g128 bf16), one row (FMA form) and eight (matrix-pipe form).  Captured in a HIP graph
+    and replayed with NEW activations: the plan freezes pointers, not contents."""
     from bitorch_engine.layers.qlinear.nbit.cuda import MPQForwardList
     specs = [(4096, 1024, i % 3 == 0) for i in range(48)]
-    entries, host = _list_case(specs, orc.BF16, 4, 128, 0, 1, seed=5100)
+    entries, host = _list_case(specs, orc.BF16, 4, 128, 0, M, seed=5100)
     plan = MPQForwardList(entries, w_bit=4, group_size=128)
     plan()
     torch.cuda.synchronize()
@@ -1401,7 +1405,7 @@ def test_list_forward_big_list_whole_k_per_workgroup_and_graph_replay():
         plan()
     gen = torch.Generator().manual_seed(5)
     for rep in range(3):
-        newx = [torch.randn((1, 4096), generator=gen).to(torch.bfloat16) for _ in entries]
+        newx = [torch.randn((M, 4096), generator=gen).to(torch.bfloat16) for _ in entries]
         for e, nx in zip(entries, newx):
             e["x"].copy_(nx.to(DEV))
         g.replay()
