@@ -1,4 +1,6 @@
 """Shared ctypes plumbing of the binary (XNOR-popcount) extension front-ends."""
+import os
+
 import torch
 
 from bitorch_engine import _hip
@@ -39,9 +41,50 @@ def pack_cols(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def xnor_linear(xp: torch.Tensor, wp: torch.Tensor, M: int, N: int, K: int, w_layout: int, scale: float) -> torch.Tensor:
-    """y[M, N] fp32 = (K - 2*popc(x ^ w)) * scale from packed operands."""
+def fp4_min_rows() -> int:
+    """Smallest M served by the matrix-pipe (FP4 image) form of the binary GEMM; below it the XNOR kernels win (two extra small
+    launches and a 4x larger activation operand).  BIE_FP4_MIN_M overrides (0 switches the form off)."""
+    v = os.environ.get("BIE_FP4_MIN_M")
+    return int(v) if v else 192
+
+
+def fp4_image(rowpacked: torch.Tensor, rows: int, K: int, out: torch.Tensor = None) -> torch.Tensor:
+    """Row-packed sign bits [rows, K/8] -> FP4 (E2M1 +-1) image in MFMA fragment order (bie_binary_fp4_image)."""
+    _hip.need_gpu(rowpacked)
+    L = _hip.lib()
+    need = L.bie_binary_fp4_image_bytes(rows, K)
+    if out is None:
+        out = torch.empty(need, dtype=torch.uint8, device=rowpacked.device)
+    _hip.check(L.bie_binary_fp4_image(_hip.ptr(rowpacked), _hip.ptr(out), rows, K, _hip.stream()), "bie_binary_fp4_image")
+    return out
+
+
+def fp4_weight_image(wp: torch.Tensor, N: int, K: int) -> torch.Tensor:
+    """The weights' image, built once per tensor version and remembered on the packed tensor (4 bits per weight beside the
+    1-bit checkpoint tensor)."""
+    from .q_linear_cuda import _cached
+    return _cached(wp, ("fp4", N, K), lambda: fp4_image(wp.contiguous(), N, K))
+
+
+def xnor_linear_fp4(xp: torch.Tensor, wp: torch.Tensor, M: int, N: int, K: int, scale: float) -> torch.Tensor:
+    """The same y as xnor_linear(w_layout = 0) on the matrix pipe: x image into stream scratch, weight image memoised."""
     _hip.need_gpu(xp, wp)
+    L = _hip.lib()
+    wimg = fp4_weight_image(wp, N, K)
+    ximg = fp4_image(xp, M, K, out=_hip.scratch(L.bie_binary_fp4_image_bytes(M, K), xp.device))
+    y = torch.empty((M, N), dtype=torch.float32, device=xp.device)
+    _hip.check(L.bie_binary_linear_forward_fp4(_hip.ptr(ximg), _hip.ptr(wimg), _hip.ptr(y), M, N, K, float(scale), _hip.stream()),
+               "bie_binary_linear_forward_fp4")
+    return y
+
+
+def xnor_linear(xp: torch.Tensor, wp: torch.Tensor, M: int, N: int, K: int, w_layout: int, scale: float) -> torch.Tensor:
+    """y[M, N] fp32 = (K - 2*popc(x ^ w)) * scale from packed operands.  Large M with row-packed weights: the matrix-pipe form
+    (identical integers); everything else: the XNOR-popcount kernels."""
+    _hip.need_gpu(xp, wp)
+    m_min = fp4_min_rows()
+    if w_layout == 0 and m_min and M >= m_min and N >= 64 and K >= 256 and K < (1 << 24):
+        return xnor_linear_fp4(xp.contiguous(), wp, M, N, K, scale)
     y = torch.empty((M, N), dtype=torch.float32, device=xp.device)
     if M and N:
         rc = _hip.lib().bie_binary_linear_forward(_hip.ptr(xp), _hip.ptr(wp), _hip.ptr(y), M, N, K, w_layout, float(scale), _hip.stream())

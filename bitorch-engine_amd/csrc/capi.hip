@@ -2,6 +2,7 @@
 // functions each entry point replaces).  Argument validation + dispatch only; kernels live in the
 // sibling translation units.
 #include "bie_common.h"
+#include <stdlib.h>
 
 namespace bie {
 const char* get_error();
@@ -79,6 +80,10 @@ int binary_conv_taps_launch(const void* x, const uint32_t* wtaps, float* y, void
                             int stride, int pad, int dil, float scale, int dtype, hipStream_t st);
 int binary_linear_launch(const uint8_t* xp, const uint8_t* wp, float* y, long M, long N, long K, int w_layout, float scale,
                          hipStream_t st);
+size_t binary_fp4_image_bytes(long rows, long K);
+int binary_fp4_image_launch(const uint8_t* rowpacked, uint8_t* image, long rows, long K, hipStream_t st);
+int binary_fp4_image_values_launch(const void* v, const void* bias, uint8_t* image, long rows, long K, int dtype, hipStream_t st);
+int binary_fp4_gemm_launch(const uint8_t* ximg, const uint8_t* wimg, float* y, long M, long N, long K, float scale, int tile, hipStream_t st);
 int binary_matmul_batched_launch(const uint8_t* xp, const uint8_t* wp, float* y, long batch, long M, long N, long K, long stride_x,
                                  long stride_w, long stride_y, float scale, hipStream_t st);
 size_t binary_conv_workspace_bytes(int B, int C, int H, int W, int OC, int ks, int stride, int pad, int dil);
@@ -434,6 +439,30 @@ int bie_binary_linear_forward(const uint8_t* xpacked, const uint8_t* wpacked, fl
     BIE_REQUIRE(xpacked && wpacked && y && M > 0 && N > 0 && K > 0 && K % 8 == 0, BIE_ERR_INVALID_ARG, "bie_binary_linear_forward: M=%ld N=%ld K=%ld (K %% 8 == 0 required)", M, N, K);
     BIE_REQUIRE(w_layout == 0 || w_layout == 1, BIE_ERR_INVALID_ARG, "bie_binary_linear_forward: w_layout %d", w_layout);
     return binary_linear_launch(xpacked, wpacked, y, M, N, K, w_layout, scale, as_stream(stream));
+}
+
+size_t bie_binary_fp4_image_bytes(long rows, long K) { return rows > 0 && K > 0 ? binary_fp4_image_bytes(rows, K) : 0; }
+
+int bie_binary_fp4_image(const uint8_t* rowpacked, uint8_t* image, long rows, long K, void* stream) {
+    BIE_REQUIRE(rowpacked && image && rows > 0 && K > 0 && K % 8 == 0, BIE_ERR_INVALID_ARG, "bie_binary_fp4_image: rows=%ld K=%ld (K %% 8 == 0 required)", rows, K);
+    BIE_REQUIRE((reinterpret_cast<uintptr_t>(image) & 15) == 0, BIE_ERR_INVALID_ARG, "bie_binary_fp4_image: image must be 16-byte aligned");
+    return binary_fp4_image_launch(rowpacked, image, rows, K, as_stream(stream));
+}
+
+int bie_binary_fp4_image_from_values(const void* values, const void* bias, uint8_t* image, long rows, long K, int dtype, void* stream) {
+    BIE_REQUIRE(values && image && rows > 0 && K > 0, BIE_ERR_INVALID_ARG, "bie_binary_fp4_image_from_values: rows=%ld K=%ld", rows, K);
+    BIE_REQUIRE(dtype >= 0 && dtype <= 3, BIE_ERR_UNSUPPORTED, "bie_binary_fp4_image_from_values: dtype %d", dtype);
+    BIE_REQUIRE(!(bias && dtype == 3), BIE_ERR_INVALID_ARG, "bie_binary_fp4_image_from_values: int8 sign carriers take no bias");
+    BIE_REQUIRE((reinterpret_cast<uintptr_t>(image) & 15) == 0, BIE_ERR_INVALID_ARG, "bie_binary_fp4_image_from_values: image must be 16-byte aligned");
+    return binary_fp4_image_values_launch(values, bias, image, rows, K, dtype, as_stream(stream));
+}
+
+int bie_binary_linear_forward_fp4(const uint8_t* ximage, const uint8_t* wimage, float* y, long M, long N, long K, float scale, void* stream) {
+    BIE_REQUIRE(ximage && wimage && y && M > 0 && N > 0 && K > 0, BIE_ERR_INVALID_ARG, "bie_binary_linear_forward_fp4: M=%ld N=%ld K=%ld", M, N, K);
+    BIE_REQUIRE(K < (1L << 24) && M < (1L << 31) && N < (1L << 31), BIE_ERR_UNSUPPORTED, "bie_binary_linear_forward_fp4: K=%ld beyond the exact range of the fp32 accumulator (2^24)", K);
+    BIE_REQUIRE(((reinterpret_cast<uintptr_t>(ximage) | reinterpret_cast<uintptr_t>(wimage)) & 15) == 0, BIE_ERR_INVALID_ARG, "bie_binary_linear_forward_fp4: images must be 16-byte aligned");
+    const char* et = getenv("BIE_FP4_TILE");  // tuning / A-B only: 128 or 256
+    return binary_fp4_gemm_launch(ximage, wimage, y, M, N, K, scale, et ? atoi(et) : 0, as_stream(stream));
 }
 
 int bie_binary_matmul_batched(const uint8_t* xpacked, const uint8_t* wpacked, float* y, long batch, long M, long N, long K, long stride_x,

@@ -268,6 +268,21 @@ int bie_binary_unpack_bstc32(const uint8_t* image, uint8_t* rowpacked, long N, l
 int bie_binary_linear_forward(const uint8_t* xpacked, const uint8_t* wpacked, float* y, long M,
                               long N, long K, int w_layout, float scale, void* stream);
 
+/* The same product on the MATRIX pipe (large M): +1 / -1 are exact FP4 (E2M1) values, so v_mfma_scale_f32_32x32x64_f8f6f4 on
+ * FP4 images of the sign matrices accumulates K - 2*popcount(xbits ^ wbits) exactly in fp32 (K < 2^24) -- the same integers as
+ * bie_binary_linear_forward at ~4x the rate of the v_xor + v_bcnt contraction (CDNA4 has no 1-bit MFMA).  Replaces the same
+ * reference functions: binary_linear_cuda_kernel.cu:155-181,308-393,629-660, binary_linear_cutlass_kernel.cu:293-332,604-625.
+ *   bie_binary_fp4_image_bytes(rows, K): size of an image (rows padded to 32, K to 128, 4 bits per element, 1 KiB MFMA fragments).
+ *   bie_binary_fp4_image: row-packed sign bits [rows, K/8] (LSB first, the operand format above) -> image.
+ *   bie_binary_fp4_image_from_values: values [rows, K] (dtype 0=f16 1=bf16 2=f32 3=int8), sign = ((v + bias[k]) >= 0) with the
+ *     sum rounded in the tensor dtype (bias may be NULL) -> image; the bit packing of BinaryLinearCuda's set_activation
+ *     (layers/qlinear/binary/cuda/layer.py:283) and bie_binary_pack_rows_u8 folded into the image pass.
+ *   bie_binary_linear_forward_fp4: y[M, N] fp32 = (K - 2*popcount) * scale from two images (x: M rows, w: N rows). */
+size_t bie_binary_fp4_image_bytes(long rows, long K);
+int bie_binary_fp4_image(const uint8_t* rowpacked, uint8_t* image, long rows, long K, void* stream);
+int bie_binary_fp4_image_from_values(const void* values, const void* bias, uint8_t* image, long rows, long K, int dtype, void* stream);
+int bie_binary_linear_forward_fp4(const uint8_t* ximage, const uint8_t* wimage, float* y, long M, long N, long K, float scale, void* stream);
+
 /* `batch` independent XNOR GEMMs in ONE launch: y[b][M, N] = (K - 2*popc(x[b] ^ w[b])) * scale, both operands row-packed
  * uint8 [rows, K/8]; strides in BYTES (packed operands) / ELEMENTS (y) between consecutive matrices.
  * Replaces binary_linear_cutlass.matmul -> binary_batched_forward_cutlass

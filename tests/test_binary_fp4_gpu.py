@@ -1,0 +1,163 @@
+"""GPU parity of the matrix-pipe form of the binary GEMM (csrc/binary_fp4.hip): +-1 as FP4 (E2M1) operands of
+v_mfma_scale_f32_32x32x64_f8f6f4.  Bar: BIT-EXACT -- the same integers K - 2*popcount(x ^ w) as the oracle
+(oracle/bie_oracle.c orc_binary_linear_rowpacked, pinned to the outputs of the reference's own binary_linear.cpp by
+tests/test_oracle_golden.py) and as the XNOR-popcount kernels; called through the C ABI (ctypes) and through the
+reference's extension-level entry points."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _image_ref(bits: np.ndarray, rows: int, K: int) -> np.ndarray:
+    """include/bie_hip.h's image definition restated in numpy: 1 KiB fragments (row block of 32, k block of 64), lane l owns the 32
+    nibbles of row 32*rb + (l & 31), k 64*kb + 32*(l >> 5) .. +31, element e in bits 4e .. 4e+3; +1 -> 0x2, -1 -> 0xA, padding 0."""
+    RB, KT = (rows + 31) // 32, (K + 127) // 128
+    sign = np.unpackbits(bits.reshape(rows, K // 8), axis=1, bitorder="little")[:, :K]  # 1 = (v >= 0)
+    nib = np.zeros((RB * 32, KT * 128), dtype=np.uint8)
+    nib[:rows, :K] = np.where(sign == 1, 0x2, 0xA)
+    # [rb, r, kb, h, e] -> [rb, kb, h, r, e]: lane = h * 32 + r
+    frag = nib.reshape(RB, 32, KT * 2, 2, 32).transpose(0, 2, 3, 1, 4)
+    byt = (frag[..., 0::2] | (frag[..., 1::2] << 4)).astype(np.uint8)
+    return np.ascontiguousarray(byt).reshape(-1)
+
+
+def _fp4_forward(L, _hip, xp, wp, M, N, K, scale=1.0):
+    ximg = torch.empty(L.bie_binary_fp4_image_bytes(M, K), dtype=torch.uint8, device=DEV)
+    wimg = torch.empty(L.bie_binary_fp4_image_bytes(N, K), dtype=torch.uint8, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    _hip.check(L.bie_binary_fp4_image(xp.data_ptr(), ximg.data_ptr(), M, K, st), "image x")
+    _hip.check(L.bie_binary_fp4_image(wp.data_ptr(), wimg.data_ptr(), N, K, st), "image w")
+    y = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+    _hip.check(L.bie_binary_linear_forward_fp4(ximg.data_ptr(), wimg.data_ptr(), y.data_ptr(), M, N, K, float(scale), st), "fp4 forward")
+    torch.cuda.synchronize()
+    return y
+
+
+@pytest.mark.parametrize("rows,K", [(1, 8), (32, 128), (33, 136), (100, 520), (257, 1000), (64, 4096)])
+def test_fp4_image_is_the_documented_layout(rows, K):
+    from bitorch_engine import _hip
+    L = _hip.lib()
+    rng = np.random.default_rng(rows * 7919 + K)
+    bits = rng.integers(0, 256, size=(rows, K // 8), dtype=np.uint8)
+    ref = _image_ref(bits, rows, K)
+    assert L.bie_binary_fp4_image_bytes(rows, K) == ref.size
+    img = torch.full((ref.size,), 0x55, dtype=torch.uint8, device=DEV)
+    _hip.check(L.bie_binary_fp4_image(torch.from_numpy(bits).to(DEV).data_ptr(), img.data_ptr(), rows, K, torch.cuda.current_stream().cuda_stream), "image")
+    assert np.array_equal(img.cpu().numpy(), ref)
+    # an unaligned source pointer takes the byte path: same image
+    buf = torch.zeros(bits.size + 1, dtype=torch.uint8, device=DEV)
+    buf[1:] = torch.from_numpy(bits.reshape(-1)).to(DEV)
+    img2 = torch.empty_like(img)
+    _hip.check(L.bie_binary_fp4_image(buf.data_ptr() + 1, img2.data_ptr(), rows, K, torch.cuda.current_stream().cuda_stream), "image")
+    assert np.array_equal(img2.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16, torch.float32, torch.int8])
+@pytest.mark.parametrize("rows,K,with_bias", [(70, 200, True), (33, 136, False), (128, 1024, True)])
+def test_fp4_image_from_values_equals_pack_rows_then_image(tdt, rows, K, with_bias):
+    from bitorch_engine import _hip
+    from bitorch_engine.extensions._binary_common import pack_rows, sign_dt
+    L = _hip.lib()
+    g = torch.Generator().manual_seed(rows + K)
+    if tdt == torch.int8:
+        v = torch.randint(-3, 4, (rows, K), generator=g, dtype=torch.int8).to(DEV)
+        bias = None
+    else:
+        v = torch.randn((rows, K), generator=g).to(tdt).to(DEV)
+        v[0, :8] = 0.0  # zeros (and -0.0) count as +1, as torch's >= does
+        v[0, 1] = -0.0
+        bias = (torch.randn((K,), generator=g) * 0.5).to(tdt).to(DEV) if with_bias else None
+    bits = pack_rows(v if bias is None else v + bias)
+    st = torch.cuda.current_stream().cuda_stream
+    ref = torch.empty(L.bie_binary_fp4_image_bytes(rows, K), dtype=torch.uint8, device=DEV)
+    _hip.check(L.bie_binary_fp4_image(bits.data_ptr(), ref.data_ptr(), rows, K, st), "image")
+    img = torch.full_like(ref, 0x55)
+    _hip.check(L.bie_binary_fp4_image_from_values(v.data_ptr(), _hip.ptr(bias), img.data_ptr(), rows, K, sign_dt(v), st), "image from values")
+    assert torch.equal(img, ref)
+
+
+@pytest.mark.parametrize("tile", ["128", "256"])
+@pytest.mark.parametrize("var", ["0", "1"])
+@pytest.mark.parametrize("M,N,K", [(1, 1, 8), (32, 32, 128), (130, 70, 264), (256, 256, 384), (300, 520, 1000), (257, 129, 2048), (512, 384, 4096)])
+def test_fp4_gemm_bit_exact_vs_oracle(M, N, K, tile, var, monkeypatch):
+    from bitorch_engine import _hip
+    L = _hip.lib()
+    monkeypatch.setenv("BIE_FP4_TILE", tile)
+    monkeypatch.setenv("BIE_FP4_VAR", var)
+    rng = np.random.default_rng(M * 31 + N * 17 + K)
+    xb = rng.integers(0, 256, size=(M, K // 8), dtype=np.uint8)
+    wb = rng.integers(0, 256, size=(N, K // 8), dtype=np.uint8)
+    ref = orc.binary_linear_rowpacked(xb, wb, K, 0.5)
+    y = _fp4_forward(L, _hip, torch.from_numpy(xb).to(DEV), torch.from_numpy(wb).to(DEV), M, N, K, 0.5)
+    assert np.array_equal(y.cpu().numpy(), ref)
+
+
+def test_fp4_gemm_rows_and_columns_land_where_they_belong():
+    """Asymmetric operands (the A = I check of the MFMA playbook): x row m agrees with w row n on exactly the first (m + 2n) % K positions."""
+    from bitorch_engine import _hip
+    L = _hip.lib()
+    M, N, K = 96, 160, 512
+    w = np.ones((N, K), dtype=np.float32)
+    x = np.ones((M, K), dtype=np.float32)
+    rng = np.random.default_rng(5)
+    w[:] = np.where(rng.random((N, K)) < 0.5, 1.0, -1.0)
+    x[:] = np.where(rng.random((M, K)) < 0.5, 1.0, -1.0)
+    x[3] = w[7]          # y[3, 7] = K
+    x[64] = -w[130]      # y[64, 130] = -K
+    ref = x @ w.T
+    y = _fp4_forward(L, _hip, torch.from_numpy(orc.binary_pack_rows(x)).to(DEV), torch.from_numpy(orc.binary_pack_rows(w)).to(DEV), M, N, K)
+    assert np.array_equal(y.cpu().numpy(), ref)
+    assert y[3, 7].item() == K and y[64, 130].item() == -K
+
+
+@pytest.mark.parametrize("M", [1024, 4096])
+def test_fp4_gemm_4096_equals_the_xnor_kernels_and_the_oracle(M):
+    from bitorch_engine import _hip
+    L = _hip.lib()
+    N = K = 4096
+    g = torch.Generator().manual_seed(M)
+    xp = torch.randint(0, 256, (M, K // 8), generator=g, dtype=torch.uint8).to(DEV)
+    wp = torch.randint(0, 256, (N, K // 8), generator=g, dtype=torch.uint8).to(DEV)
+    y = _fp4_forward(L, _hip, xp, wp, M, N, K)
+    yx = torch.empty_like(y)
+    _hip.check(L.bie_binary_linear_forward(xp.data_ptr(), wp.data_ptr(), yx.data_ptr(), M, N, K, 0, 1.0, torch.cuda.current_stream().cuda_stream), "xnor")
+    torch.cuda.synchronize()
+    assert torch.equal(y, yx)
+    rows = np.array([0, 1, 31, 32, 255, 256, M // 2 + 3, M - 1])
+    ref = orc.binary_linear_rowpacked(xp.cpu().numpy()[rows], wp.cpu().numpy(), K)
+    assert np.array_equal(y.cpu().numpy()[rows], ref)
+
+
+def test_extension_forward_takes_the_matrix_pipe_for_large_m_and_matches_the_xnor_path(monkeypatch):
+    """binary_linear_cutlass.forward / binary_linear_cuda.forward at M = 512: FP4 form (default threshold) == XNOR form == oracle;
+    the weight image is built once per tensor version."""
+    from bitorch_engine.extensions import binary_linear_cutlass, binary_linear_cuda
+    M, N, K = 512, 768, 1024
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn((M, K), generator=g).to(torch.bfloat16).to(DEV)
+    w = torch.randn((N, K), generator=g).to(torch.bfloat16).to(DEV)
+    ref = orc.binary_linear_rowpacked(orc.binary_pack_rows(x.float().cpu().numpy()), orc.binary_pack_rows(w.float().cpu().numpy()), K, 0.25)
+    wp = binary_linear_cutlass.w_pack(w, False)
+    y1 = binary_linear_cutlass.forward(x, wp, 0.25, False, 0)
+    assert ("fp4", N, K) in wp._bie_memo
+    img = wp._bie_memo[("fp4", N, K)][1]
+    y1b = binary_linear_cutlass.forward(x, wp, 0.25, False, 0)
+    assert wp._bie_memo[("fp4", N, K)][1] is img
+    monkeypatch.setenv("BIE_FP4_MIN_M", "0")
+    y2 = binary_linear_cutlass.forward(x, wp, 0.25, False, 0)
+    monkeypatch.delenv("BIE_FP4_MIN_M")
+    assert np.array_equal(y1.cpu().numpy(), ref) and torch.equal(y1, y2) and torch.equal(y1, y1b)
+    wimg = binary_linear_cuda.w_pack(w, 3, False)
+    y3 = binary_linear_cuda.forward(x, wimg, 3, False)
+    assert np.array_equal(y3.cpu().numpy() * 0.25, ref)
+    wp[0, 0] ^= 0xFF  # in-place edit: the image must follow
+    y4 = binary_linear_cutlass.forward(x, wp, 0.25, False, 0)
+    wb = wp.cpu().numpy()
+    assert np.array_equal(y4.cpu().numpy(), orc.binary_linear_rowpacked(orc.binary_pack_rows(x.float().cpu().numpy()), wb, K, 0.25))
