@@ -129,11 +129,17 @@ __device__ __forceinline__ void wait_frags(v4i_t (&a)[NA], v4i_t (&b)[NB]) {
         asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a[0]), "+v"(b[0]) : "n"(CNT) : "memory");
 }
 
-__device__ __forceinline__ float16_t mfma_fp4(const v4i_t a, const v4i_t b, const float16_t c) {
-    const v8i_t a8 = {a.x, a.y, a.z, a.w, 0, 0, 0, 0}, b8 = {b.x, b.y, b.z, b.w, 0, 0, 0, 0};  // FP4 operands occupy 4 registers; hipcc drops the upper half
-    // cbsz = blgp = 4: both operands FP4 (E2M1); block scales E8M0 0x7f = 2^0
-    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+// The MFMA as inline asm, on purpose.  Issued through the builtin the MFMAs are pure values: hipcc first sank all 96 of a three-stage
+// loop body below the hand-issued reads, and a zero-instruction asm fence on the accumulator ("+a") that pins them makes the hazard
+// recogniser put an s_nop between consecutive MFMAs -- one extra issue state costs a lone in-order wave ~28 cycles per MFMA here
+// (26 ns per MFMA against 13.8 ns for the bare stream, profiles/r03_fp4_b_probe_mfma.txt / r03_fp4_b_ablations.txt).  As asm volatile
+// the whole loop body (reads, waits, barrier, MFMAs) is one ordered stream and nothing is padded.  Hazards that are now ours:
+// operands come from ds_read (covered by the lgkmcnt waits); an accumulator is re-used 16 MFMAs later; the epilogue's reads of the
+// accumulators sit behind mfma_drain().  cbsz = blgp = 4: both operands FP4 (E2M1); block scales E8M0 0x7f = 2^0.
+__device__ __forceinline__ void mfma_fp4(float16_t& c, const v4i_t& a, const v4i_t& b, int scale) {
+    asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0] cbsz:4 blgp:4" : "+a"(c) : "v"(a), "v"(b), "v"(scale));
 }
+__device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }  // >= 18 wait states: XDL write -> VALU read
 
 template <int I> struct ic_t { static constexpr int value = I; };
 template <int I, int N, class F>
@@ -143,11 +149,6 @@ __device__ __forceinline__ void static_for(F&& f) {
         static_for<I + 1, N>(f);
     }
 }
-
-// The MFMA builtins are pure: nothing but a data dependence keeps them on their side of the hand-issued waits / barrier / LDS reads
-// (hipcc sank all 96 MFMAs of three stages to the end of the loop body without it).  A zero-instruction asm that "modifies" the
-// accumulator ties each MFMA into the ordered asm stream and keeps the accumulators in the AGPR half of the register file.
-#define BIE_PIN_ACC(c) asm volatile("" : "+a"(c)::"memory")
 
 // VAR 0: fragment reads and LDS-DMA pieces BETWEEN the MFMAs (one item per MFMA shadow: a lone in-order wave per SIMD overlaps
 //        nothing it does not interleave), branch-free stage body (look-ahead clamped to the last K tile);
@@ -161,6 +162,8 @@ __global__ __launch_bounds__(256) void xnor_fp4_gemm_kernel(const uint8_t* __res
     constexpr int STAGE = NFR * 1024;
     constexpr int NR = WM + WN;              // fragment reads per k64 half
     constexpr int NM = WM * WN;              // MFMAs per k64 half
+    // timing ablations (lab build only, results are wrong): VAR 2: no LDS-DMA in the loop, 3: no fragment reads, 4: neither, 5: and no barrier
+    constexpr bool DMA = VAR < 2 || VAR == 3, READS = VAR < 3, BARRIER = VAR < 5;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[3 * STAGE];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -212,6 +215,8 @@ __global__ __launch_bounds__(256) void xnor_fp4_gemm_kernel(const uint8_t* __res
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
 
     v4i_t XA[WM], XB[WN], YA[WM], YB[WN], ZA[WM], ZB[WN];
+    int e8m0_one = 0x7f7f7f7f;
+    asm volatile("" : "+v"(e8m0_one));  // one VGPR for the whole kernel (not re-materialised per MFMA)
 
     // prologue: K tiles 0..2 requested, tile 0 landed on every wave, its first k64 half on the way to registers
 #pragma unroll
@@ -235,28 +240,24 @@ __global__ __launch_bounds__(256) void xnor_fp4_gemm_kernel(const uint8_t* __res
     // stage's first half.  The buffer a stage leaves is refilled with K tile kt+3 behind the barrier.
     auto stage = [&](int kt, v4i_t (&PA)[WM], v4i_t (&PB)[WN], v4i_t (&QA)[WM], v4i_t (&QB)[WN], v4i_t (&NA)[WM], v4i_t (&NB)[WN]) {
         const uint32_t so = (uint32_t)(kt % 3) * STAGE, sn = (uint32_t)((kt + 1) % 3) * STAGE;
-        if constexpr (VAR == 0) {
+        if constexpr (VAR != 1) {
             wait_frags<0>(PA, PB);
             static_for<0, NM>([&](auto mc) {
                 constexpr int m = decltype(mc)::value, i = m / WN, j = m % WN;
-                BIE_PIN_ACC(acc[i][j]);  // below the items placed after the previous MFMA ...
-                acc[i][j] = mfma_fp4(PA[i], PB[j], acc[i][j]);
-                BIE_PIN_ACC(acc[i][j]);  // ... and above its own
-                static_for<m * NR / NM, (m + 1) * NR / NM>([&](auto rc) { read_item(rc, ic_t<1>{}, so, QA, QB); });
+                mfma_fp4(acc[i][j], PB[j], PA[i], e8m0_one);
+                if constexpr (READS) static_for<m * NR / NM, (m + 1) * NR / NM>([&](auto rc) { read_item(rc, ic_t<1>{}, so, QA, QB); });
             });
             wait_frags<0>(QA, QB);  // every LDS read of this stage has returned: its buffer may be refilled behind the barrier
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");  // K tile kt+1 landed (kt+2 still in flight)
-            __builtin_amdgcn_s_barrier();
+            if constexpr (DMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");  // K tile kt+1 landed (kt+2 still in flight)
+            if constexpr (BARRIER) __builtin_amdgcn_s_barrier();
             constexpr int NI = NR + PW;  // items of the second half: next stage's first reads, then the refill pieces
             static_for<0, NM>([&](auto mc) {
                 constexpr int m = decltype(mc)::value, i = m / WN, j = m % WN;
-                BIE_PIN_ACC(acc[i][j]);
-                acc[i][j] = mfma_fp4(QA[i], QB[j], acc[i][j]);
-                BIE_PIN_ACC(acc[i][j]);
+                mfma_fp4(acc[i][j], QB[j], QA[i], e8m0_one);
                 static_for<m * NI / NM, (m + 1) * NI / NM>([&](auto xc) {
                     constexpr int x = decltype(xc)::value;
-                    if constexpr (x < NR) read_item(xc, ic_t<0>{}, sn, NA, NB);
-                    else issue_piece(kt + 3, x - NR);
+                    if constexpr (x < NR) { if constexpr (READS) read_item(xc, ic_t<0>{}, sn, NA, NB); }
+                    else if constexpr (DMA) issue_piece(kt + 3, x - NR);
                 });
             });
         } else {
@@ -265,8 +266,7 @@ __global__ __launch_bounds__(256) void xnor_fp4_gemm_kernel(const uint8_t* __res
             wait_frags<NR>(PA, PB);
             static_for<0, NM>([&](auto mc) {
                 constexpr int m = decltype(mc)::value, i = m / WN, j = m % WN;
-                acc[i][j] = mfma_fp4(PA[i], PB[j], acc[i][j]);
-                BIE_PIN_ACC(acc[i][j]);
+                mfma_fp4(acc[i][j], PB[j], PA[i], e8m0_one);
             });
             wait_frags<0>(QA, QB);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
@@ -277,8 +277,7 @@ __global__ __launch_bounds__(256) void xnor_fp4_gemm_kernel(const uint8_t* __res
             read_frags<WN, 0>(NB, b_addr + sn);
             static_for<0, NM>([&](auto mc) {
                 constexpr int m = decltype(mc)::value, i = m / WN, j = m % WN;
-                acc[i][j] = mfma_fp4(QA[i], QB[j], acc[i][j]);
-                BIE_PIN_ACC(acc[i][j]);
+                mfma_fp4(acc[i][j], QB[j], QA[i], e8m0_one);
             });
         }
     };
@@ -293,20 +292,32 @@ __global__ __launch_bounds__(256) void xnor_fp4_gemm_kernel(const uint8_t* __res
         if (kt + 1 < KT) stage(kt + 1, ZA, ZB, XA, XB, YA, YB);
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the clamped look-ahead pieces / reads must not outlive the workgroup's LDS
+    mfma_drain();
 
-    // D[i][j]: column = lane & 31 (the B operand's row = output feature n), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    const int n_l = lane & 31, m_l = 4 * (lane >> 5);
+    // The MFMAs were issued as D = w_frag (A operand: D rows = output features n) x x_frag (B operand: D columns = rows m of x), so in the
+    // 32 x 32 C/D layout (column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) a lane holds ONE row m and, per group of
+    // four registers, FOUR CONSECUTIVE n: one 16-byte store per group (64 per lane instead of 256 dword stores -- the dword form was
+    // store-issue bound: 13 us of fixed cost per launch, profiles/r03_fp4_c_k_slope.txt).
+    const int m_l = lane & 31, n_l = 4 * (lane >> 5);
+    const bool vec_ok = (N & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
 #pragma unroll
     for (int i = 0; i < WM; i++) {
-        const int m0 = (tile_m * AF + wy * WM + i) * 32 + m_l;
+        const int m = (tile_m * AF + wy * WM + i) * 32 + m_l;
+        if (m < M) {
+            float* yr = y + (long)m * N;
 #pragma unroll
-        for (int j = 0; j < WN; j++) {
-            const int n = (tile_n * BF + wx * WN + j) * 32 + n_l;
-            if (n < N) {
+            for (int j = 0; j < WN; j++) {
+                const int n0 = (tile_n * BF + wx * WN + j) * 32 + n_l;
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int m = m0 + (r & 3) + 8 * (r >> 2);
-                    if (m < M) y[(long)m * N + n] = acc[i][j][r] * scale;
+                for (int q = 0; q < 4; q++) {
+                    const int n = n0 + 8 * q;
+                    const float4_t v = {acc[i][j][4 * q] * scale, acc[i][j][4 * q + 1] * scale, acc[i][j][4 * q + 2] * scale, acc[i][j][4 * q + 3] * scale};
+                    if (vec_ok && n + 3 < N) *reinterpret_cast<float4_t*>(yr + n) = v;
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            if (n + e < N) yr[n + e] = v[e];
+                    }
                 }
             }
         }
@@ -343,6 +354,12 @@ int binary_fp4_gemm_launch(const uint8_t* ximg, const uint8_t* wimg, float* y, l
     if (big) {
         const int tn = (int)cdivl(N, 256);
         if (var == 1) hipLaunchKernelGGL((xnor_fp4_gemm_kernel<4, 4, 1>), dim3((unsigned)t256), dim3(256), 0, st, ximg, wimg, y, (int)M, (int)N, KT, RBA, RBB, tn, scale);
+#ifdef BIE_FP4_LAB
+        else if (var == 2) hipLaunchKernelGGL((xnor_fp4_gemm_kernel<4, 4, 2>), dim3((unsigned)t256), dim3(256), 0, st, ximg, wimg, y, (int)M, (int)N, KT, RBA, RBB, tn, scale);
+        else if (var == 3) hipLaunchKernelGGL((xnor_fp4_gemm_kernel<4, 4, 3>), dim3((unsigned)t256), dim3(256), 0, st, ximg, wimg, y, (int)M, (int)N, KT, RBA, RBB, tn, scale);
+        else if (var == 4) hipLaunchKernelGGL((xnor_fp4_gemm_kernel<4, 4, 4>), dim3((unsigned)t256), dim3(256), 0, st, ximg, wimg, y, (int)M, (int)N, KT, RBA, RBB, tn, scale);
+        else if (var == 5) hipLaunchKernelGGL((xnor_fp4_gemm_kernel<4, 4, 5>), dim3((unsigned)t256), dim3(256), 0, st, ximg, wimg, y, (int)M, (int)N, KT, RBA, RBB, tn, scale);
+#endif
         else hipLaunchKernelGGL((xnor_fp4_gemm_kernel<4, 4, 0>), dim3((unsigned)t256), dim3(256), 0, st, ximg, wimg, y, (int)M, (int)N, KT, RBA, RBB, tn, scale);
     } else {
         const int tn = (int)cdivl(N, 128);
