@@ -45,7 +45,7 @@ def fp4_min_rows() -> int:
     """Smallest M served by the matrix-pipe (FP4 image) form of the binary GEMM; below it the XNOR kernels win (two extra small
     launches and a 4x larger activation operand).  BIE_FP4_MIN_M overrides (0 switches the form off)."""
     v = os.environ.get("BIE_FP4_MIN_M")
-    return int(v) if v else 192
+    return int(v) if v else 256
 
 
 def fp4_image(rowpacked: torch.Tensor, rows: int, K: int, out: torch.Tensor = None) -> torch.Tensor:
@@ -78,12 +78,57 @@ def xnor_linear_fp4(xp: torch.Tensor, wp: torch.Tensor, M: int, N: int, K: int, 
     return y
 
 
+def fp4_ok(M: int, N: int, K: int) -> bool:
+    """Shapes the matrix-pipe form serves by default (it is correct for any shape; below these sizes the XNOR kernels are faster)."""
+    m_min = fp4_min_rows()
+    return bool(m_min) and M >= m_min and N >= 64 and 256 <= K < (1 << 24)
+
+
+def _x_image_from_values(x: torch.Tensor, bias_a, M: int, K: int) -> torch.Tensor:
+    L = _hip.lib()
+    ximg = _hip.scratch(L.bie_binary_fp4_image_bytes(M, K), x.device)
+    _hip.check(L.bie_binary_fp4_image_from_values(_hip.ptr(x), _hip.ptr(bias_a), _hip.ptr(ximg), M, K, sign_dt(x), _hip.stream()),
+               "bie_binary_fp4_image_from_values")
+    return ximg
+
+
+def xnor_values_fp4(x: torch.Tensor, wp: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    """fp32 (K - 2*popc) * scale of sign(x) against row-packed weights, two launches: values -> FP4 image (the sign-pack folded in),
+    matrix-pipe GEMM."""
+    _hip.need_gpu(x, wp)
+    x = x.contiguous()
+    M, K = x.shape
+    N = wp.shape[0]
+    wimg = fp4_weight_image(wp, N, K)
+    ximg = _x_image_from_values(x, None, M, K)
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    _hip.check(_hip.lib().bie_binary_linear_forward_fp4(_hip.ptr(ximg), _hip.ptr(wimg), _hip.ptr(y), M, N, K, float(scale), _hip.stream()),
+               "bie_binary_linear_forward_fp4")
+    return y
+
+
+def xnor_layer_fp4(x, wrows, bias_a=None, scale_a=None, scale_w=None):
+    """BinaryLinearCuda's forward at large M in two launches: `((x + bias_a) >= 0)` -> FP4 image, then the matrix-pipe GEMM with the
+    `.to(dtype) * scale_a * scale_w` epilogue (bie_binary_linear_layer_fp4) -- same roundings as xnor_linear_fused."""
+    _hip.need_gpu(x, wrows)
+    x = x.contiguous()
+    M, K = x.shape
+    N = wrows.shape[0]
+    same = lambda t: None if t is None else t.to(device=x.device, dtype=x.dtype).contiguous()
+    bias_a, scale_a, scale_w = same(bias_a), same(scale_a), same(scale_w)
+    wimg = fp4_weight_image(wrows, N, K)
+    ximg = _x_image_from_values(x, bias_a, M, K)
+    y = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    _hip.check(_hip.lib().bie_binary_linear_layer_fp4(_hip.ptr(ximg), _hip.ptr(wimg), _hip.ptr(scale_a), _hip.ptr(scale_w), _hip.ptr(y), M, N, K,
+                                                      _hip.dt(x), _hip.stream()), "bie_binary_linear_layer_fp4")
+    return y
+
+
 def xnor_linear(xp: torch.Tensor, wp: torch.Tensor, M: int, N: int, K: int, w_layout: int, scale: float) -> torch.Tensor:
     """y[M, N] fp32 = (K - 2*popc(x ^ w)) * scale from packed operands.  Large M with row-packed weights: the matrix-pipe form
     (identical integers); everything else: the XNOR-popcount kernels."""
     _hip.need_gpu(xp, wp)
-    m_min = fp4_min_rows()
-    if w_layout == 0 and m_min and M >= m_min and N >= 64 and K >= 256 and K < (1 << 24):
+    if w_layout == 0 and fp4_ok(M, N, K):
         return xnor_linear_fp4(xp.contiguous(), wp, M, N, K, scale)
     y = torch.empty((M, N), dtype=torch.float32, device=xp.device)
     if M and N:

@@ -9,7 +9,7 @@ can hold (K or N not a multiple of 32) fall back to plain row-packed bytes, whic
 import torch
 
 from bitorch_engine import _hip
-from ._binary_common import pack_rows, sign_dt, xnor_linear, xnor_linear_fused, fused_ok
+from ._binary_common import pack_rows, sign_dt, xnor_linear, xnor_linear_fused, fused_ok, fp4_ok, xnor_values_fp4, xnor_layer_fp4
 from .q_linear_cuda import _cached
 
 BSTC32, BTC32, ADAPTIVE = 1, 2, 3
@@ -63,19 +63,23 @@ def forward(input: torch.Tensor, weights: torch.Tensor, bmm_type: int, transpose
     else:
         wp = pack_rows(weights)
     wp = wp.contiguous()
+    if fp4_ok(m, wp.shape[0], k) and (input.dtype in _hip._DT or input.dtype == torch.int8):
+        return xnor_values_fp4(input, wp)  # large M: sign-pack folded into the FP4 image pass, GEMM on the matrix pipe (two launches)
     if input.dtype in _hip._DT and fused_ok(m, wp.shape[0], k) and wp.data_ptr() % 16 == 0:
         return xnor_linear_fused(input, wp, raw_counts=True)  # M <= 64 (<= 512 when K % 512 == 0): sign-pack of x inside the XNOR kernel (one launch)
     return xnor_linear(pack_rows(input), wp, m, wp.shape[0], k, 0, 1.0)
 
 
 def layer_forward(input, bias_a, weights, bmm_type, scale_a, scale_w):
-    """BinaryLinearCuda's whole forward for M <= 64 (M <= 512 when K % 512 == 0) in one launch: `((x + bias_a) >= 0)` bits, XNOR-popcount,
+    """BinaryLinearCuda's whole forward: M >= 256 on the matrix pipe in two launches (xnor_layer_fp4); M <= 64 (M <= 512 when K % 512 == 0) in one launch: `((x + bias_a) >= 0)` bits, XNOR-popcount,
     `.to(dtype) * scale_a * scale_w` (reference layers/qlinear/binary/cuda/layer.py:58-63, 283-284).  None when the shape is
     outside the fused range (the caller then composes the separate steps)."""
     m, k = input.shape
     if weights.dtype != torch.uint8 or input.dtype not in _hip._DT:
         return None
     n = weights.numel() * 8 // k
+    if fp4_ok(m, n, k):  # large M: two launches (values -> FP4 image with the bias add, matrix-pipe GEMM with the layer epilogue)
+        return xnor_layer_fp4(input, image_to_rows(weights, n, k, bmm_type).contiguous(), bias_a, scale_a, scale_w)
     if not fused_ok(m, n, k):
         return None
     wp = image_to_rows(weights, n, k, bmm_type).contiguous()

@@ -5,7 +5,7 @@ matmul(x, y, scale), kernel_eval(device_id, m, n, k).  Row-packed uint8 LSB-firs
 import torch
 
 from bitorch_engine import _hip
-from ._binary_common import pack_rows, xnor_linear
+from ._binary_common import pack_rows, xnor_linear, fp4_ok, xnor_values_fp4
 
 
 def w_pack(weight: torch.Tensor, transpose: bool) -> torch.Tensor:
@@ -14,8 +14,10 @@ def w_pack(weight: torch.Tensor, transpose: bool) -> torch.Tensor:
 
 def forward(input: torch.Tensor, weight: torch.Tensor, scale: float, transpose: bool, kernel_id: int) -> torch.Tensor:
     m, k = input.shape
-    wp = weight if weight.dtype == torch.uint8 else w_pack(weight, transpose)
-    return xnor_linear(pack_rows(input), wp.contiguous(), m, wp.shape[0], k, 0, scale)
+    wp = (weight if weight.dtype == torch.uint8 else w_pack(weight, transpose)).contiguous()
+    if fp4_ok(m, wp.shape[0], k):  # large M: sign-pack folded into the FP4 image pass, GEMM on the matrix pipe
+        return xnor_values_fp4(input, wp, scale)
+    return xnor_linear(pack_rows(input), wp, m, wp.shape[0], k, 0, scale)
 
 
 def mm(x: torch.Tensor, y: torch.Tensor, kernel_id: int) -> torch.Tensor:

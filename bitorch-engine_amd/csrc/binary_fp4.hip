@@ -65,40 +65,83 @@ __global__ __launch_bounds__(256) void fp4_image_kernel(const uint8_t* __restric
     img[f * 64 + lane] = uint4_t{o[0], o[1], o[2], o[3]};
 }
 
-// values [rows, K] (dtype; + bias[K] when given) -> the same image, sign taken as (v >= 0): pack_rows + the kernel above in one pass
+// values [rows, K] (dtype; + bias[K] when given) -> the same image, sign taken as (v >= 0): bie_binary_pack_rows_u8 + the kernel above in
+// one pass.  One wave per fragment (32 rows x 64 k): lane (row l >> 3 of 8, chunk l & 7) loads 8 consecutive values (8 lanes = one
+// row's 64 values, contiguous), four passes cover the 32 rows; the nibble words go through a 1 KiB LDS image of the fragment so that
+// the store is the fragment's 1 KiB, contiguous.
 template <int DT>
-__global__ __launch_bounds__(256) void fp4_image_values_kernel(const void* __restrict__ v, const void* __restrict__ bias, uint4_t* __restrict__ img, long rows,
-                                                               long K, long nfrag, int kb_per_row) {
-    const long f = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (f >= nfrag) return;
-    const int lane = threadIdx.x & 63;
-    const long rb = f / kb_per_row;
-    const int kb = (int)(f - rb * kb_per_row);
-    const long row = rb * 32 + (lane & 31);
-    const long k0 = (long)kb * 64 + (lane >> 5) * 32;
-    uint32_t o[4] = {0u, 0u, 0u, 0u};
-    if (row < rows) {
+__device__ __forceinline__ void load8(const void* p, long idx, float (&v)[8]) {
+    if constexpr (DT == BIE_F32) {
+        const float4_t a = *reinterpret_cast<const float4_t*>((const float*)p + idx), b = *reinterpret_cast<const float4_t*>((const float*)p + idx + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else if constexpr (DT == 3) {
+        const uint2_t a = *reinterpret_cast<const uint2_t*>((const int8_t*)p + idx);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            uint32_t d = 0;
+        for (int e = 0; e < 8; e++) v[e] = (float)(int8_t)(((e < 4 ? a.x : a.y) >> (8 * (e & 3))) & 0xff);
+    } else {
+        const uint4_t a = *reinterpret_cast<const uint4_t*>((const uint16_t*)p + idx);
+        const uint32_t w[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const long k = k0 + 8 * i + e;
-                if (k < K) {
-                    bool pos;
-                    if constexpr (DT == 3) pos = ((const int8_t*)v)[row * K + k] >= 0;
-                    else {
-                        float a = dt_traits<DT>::load(v, row * K + k);
-                        if (bias) a = dt_traits<DT>::round(a + dt_traits<DT>::load(bias, k));  // x + bias_a rounded in the tensor dtype, as torch does
-                        pos = a >= 0.0f;
-                    }
-                    d |= (pos ? 0x2u : 0xau) << (4 * e);
-                }
-            }
-            o[i] = d;
+        for (int e = 0; e < 8; e++) {
+            const uint32_t h = (w[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+            v[e] = DT == BIE_F16 ? f16_bits_to_f32(h) : bf16_bits_to_f32(h);
         }
     }
-    img[f * 64 + lane] = uint4_t{o[0], o[1], o[2], o[3]};
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void fp4_image_values_kernel(const void* __restrict__ v, const void* __restrict__ bias, uint4_t* __restrict__ img, long rows,
+                                                               long K, long nfrag, int kb_per_row, int vec) {
+    __shared__ uint32_t tile[4][256];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long f = (long)blockIdx.x * 4 + wave;
+    if (f < nfrag) {
+        const long rb = f / kb_per_row;
+        const int kb = (int)(f - rb * kb_per_row);
+        const int c = lane & 7;
+        const long k0 = (long)kb * 64 + 8 * c;
+        float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+            if (vec && k0 + 8 <= K) load8<DT>(bias, k0, bv);
+            else
+                for (int e = 0; e < 8; e++)
+                    if (k0 + e < K) {
+                        if constexpr (DT != 3) bv[e] = dt_traits<DT>::load(bias, k0 + e);
+                    }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int r = t * 8 + (lane >> 3);
+            const long row = rb * 32 + r;
+            uint32_t d = 0;
+            if (row < rows && k0 < K) {
+                float a[8];
+                int valid = 8;
+                if (vec && k0 + 8 <= K) load8<DT>(v, row * K + k0, a);
+                else {
+                    valid = (int)(K - k0 < 8 ? K - k0 : 8);
+                    for (int e = 0; e < 8; e++) {
+                        a[e] = 0.f;
+                        if (e < valid) {
+                            if constexpr (DT == 3) a[e] = (float)((const int8_t*)v)[row * K + k0 + e];
+                            else a[e] = dt_traits<DT>::load(v, row * K + k0 + e);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    float x = a[e];
+                    if constexpr (DT != 3) {
+                        if (bias) x = dt_traits<DT>::round(x + bv[e]);  // x + bias_a rounded in the tensor dtype, as torch does
+                    }
+                    if (e < valid) d |= (x >= 0.0f ? 0x2u : 0xau) << (4 * e);
+                }
+            }
+            tile[wave][((c >> 2) * 32 + r) * 4 + (c & 3)] = d;  // fragment lane (k half, row), dword c & 3
+        }
+    }
+    __syncthreads();
+    if (f < nfrag) img[f * 64 + lane] = *reinterpret_cast<const uint4_t*>(&tile[wave][lane * 4]);
 }
 
 // ---- LDS fragment reads (hand-issued: the compiler must not order them against the LDS-DMA by its own alias rules) ----
@@ -153,9 +196,13 @@ __device__ __forceinline__ void static_for(F&& f) {
 // VAR 0: fragment reads and LDS-DMA pieces BETWEEN the MFMAs (one item per MFMA shadow: a lone in-order wave per SIMD overlaps
 //        nothing it does not interleave), branch-free stage body (look-ahead clamped to the last K tile);
 // VAR 1: the same pipeline with reads / DMA issued in bursts between the two 16-MFMA clusters of a stage (kept for the A/B).
-template <int WM, int WN, int VAR>
-__global__ __launch_bounds__(256) void xnor_fp4_gemm_kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B, float* __restrict__ y, int M, int N,
-                                                            int KT, int RBA, int RBB, int tiles_n, float scale) {
+// ODT < 0: y fp32 = (K - 2*popc) * scale.  ODT = BIE_F16 / BF16 / F32: the BinaryLinearCuda layer epilogue, y (ODT) =
+// dt(dt(dt(K - 2*popc) * scale_a) * scale_w) with scale_a / scale_w device scalars of that dtype (NULL = 1): the roundings of
+// `forward(...).to(input.dtype) * scale_a * scale_w` (layers/qlinear/binary/cuda/layer.py:58-63), as xnor_fused_kernel.
+template <int WM, int WN, int VAR, int ODT>
+__global__ __launch_bounds__(256) void xnor_fp4_gemm_kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B, void* __restrict__ yv, int M, int N,
+                                                            int KT, int RBA, int RBB, int tiles_n, float scale, const void* __restrict__ scale_a,
+                                                            const void* __restrict__ scale_w) {
     constexpr int AF = 2 * WM, BF = 2 * WN;  // 32-row blocks per workgroup tile
     constexpr int NFR = (AF + BF) * 2;       // 1 KiB fragments per stage (k = 128)
     constexpr int PW = NFR / 4;              // LDS-DMA pieces per wave and stage
@@ -298,25 +345,85 @@ __global__ __launch_bounds__(256) void xnor_fp4_gemm_kernel(const uint8_t* __res
     // 32 x 32 C/D layout (column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) a lane holds ONE row m and, per group of
     // four registers, FOUR CONSECUTIVE n: one 16-byte store per group (64 per lane instead of 256 dword stores -- the dword form was
     // store-issue bound: 13 us of fixed cost per launch, profiles/r03_fp4_c_k_slope.txt).
-    const int m_l = lane & 31, n_l = 4 * (lane >> 5);
-    const bool vec_ok = (N & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+    const int m_l = lane & 31;
+    if constexpr (ODT < 0 || ODT == BIE_F32) {
+        float* y = (float*)yv;
+        float sa = 1.0f, sw = 1.0f;
+        if constexpr (ODT == BIE_F32) {
+            if (scale_a) sa = *(const float*)scale_a;
+            if (scale_w) sw = *(const float*)scale_w;
+        }
+        const int n_l = 4 * (lane >> 5);
+        const bool vec_ok = (N & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
 #pragma unroll
-    for (int i = 0; i < WM; i++) {
-        const int m = (tile_m * AF + wy * WM + i) * 32 + m_l;
-        if (m < M) {
-            float* yr = y + (long)m * N;
+        for (int i = 0; i < WM; i++) {
+            const int m = (tile_m * AF + wy * WM + i) * 32 + m_l;
+            if (m < M) {
+                float* yr = y + (long)m * N;
+#pragma unroll
+                for (int j = 0; j < WN; j++) {
+                    const int n0 = (tile_n * BF + wx * WN + j) * 32 + n_l;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int n = n0 + 8 * q;
+                        float4_t v;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            if constexpr (ODT < 0) v[e] = acc[i][j][4 * q + e] * scale;
+                            else v[e] = (acc[i][j][4 * q + e] * sa) * sw;  // fp32 layer: two rounded multiplies
+                        }
+                        if (vec_ok && n + 3 < N) *reinterpret_cast<float4_t*>(yr + n) = v;
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 4; e++)
+                                if (n + e < N) yr[n + e] = v[e];
+                        }
+                    }
+                }
+            }
+        }
+    } else {
+        // 16-bit outputs: the two half-waves hold the n + 0..3 / n + 4..7 quads of the same row; v_permlane32_swap_b32 trades the packed
+        // quads of register groups q and q + 1 between them, after which a lane owns 8 consecutive n of group 2*(q/2) + (lane >> 5):
+        // one 16-byte store (32 per lane)
+        uint16_t* y = (uint16_t*)yv;
+        const float sa = scale_a ? dt_traits<ODT>::load(scale_a, 0) : 1.0f, sw = scale_w ? dt_traits<ODT>::load(scale_w, 0) : 1.0f;
+        auto fin = [&](float c) {
+            float v = dt_traits<ODT>::round(c);
+            if (scale_a) v = dt_traits<ODT>::round(v * sa);
+            if (scale_w) v = dt_traits<ODT>::round(v * sw);
+            return v;
+        };
+        auto pack2 = [&](float lo, float hi) -> uint32_t {
+            if constexpr (ODT == BIE_BF16) return pack_bf16x2(lo, hi);
+            else return f32_to_f16_bits(lo) | (f32_to_f16_bits(hi) << 16);
+        };
+        const bool vec_ok = (N & 7) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+        const int half = lane >> 5;
+#pragma unroll
+        for (int i = 0; i < WM; i++) {
+            const int m = (tile_m * AF + wy * WM + i) * 32 + m_l;
+            uint16_t* yr = y + (long)(m < M ? m : 0) * N;
 #pragma unroll
             for (int j = 0; j < WN; j++) {
-                const int n0 = (tile_n * BF + wx * WN + j) * 32 + n_l;
+                const int nb = (tile_n * BF + wx * WN + j) * 32;
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int n = n0 + 8 * q;
-                    const float4_t v = {acc[i][j][4 * q] * scale, acc[i][j][4 * q + 1] * scale, acc[i][j][4 * q + 2] * scale, acc[i][j][4 * q + 3] * scale};
-                    if (vec_ok && n + 3 < N) *reinterpret_cast<float4_t*>(yr + n) = v;
-                    else {
+                for (int qp = 0; qp < 2; qp++) {
+                    float v[8];
 #pragma unroll
-                        for (int e = 0; e < 4; e++)
-                            if (n + e < N) yr[n + e] = v[e];
+                    for (int e = 0; e < 8; e++) v[e] = fin(acc[i][j][8 * qp + e]);  // e < 4: group 2qp (n + 4*half + e), e >= 4: group 2qp + 1
+                    if (vec_ok) {
+                        const uint32_t p0 = pack2(v[0], v[1]), p1 = pack2(v[2], v[3]), p2 = pack2(v[4], v[5]), p3 = pack2(v[6], v[7]);
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(p0, p2, false, false);  // first operand's upper half <-> second's lower half
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(p1, p3, false, false);
+                        const int n = nb + 8 * (2 * qp + half);
+                        if (m < M && n < N) *reinterpret_cast<uint4_t*>(yr + n) = uint4_t{s0[0], s1[0], s0[1], s1[1]};
+                    } else if (m < M) {
+#pragma unroll
+                        for (int e = 0; e < 8; e++) {
+                            const int n = nb + 8 * (2 * qp + (e >> 2)) + 4 * half + (e & 3);
+                            if (n < N) dt_traits<ODT>::store(yr, n, v[e]);
+                        }
                     }
                 }
             }
@@ -335,38 +442,58 @@ int binary_fp4_image_launch(const uint8_t* rowpacked, uint8_t* image, long rows,
 int binary_fp4_image_values_launch(const void* v, const void* bias, uint8_t* image, long rows, long K, int dtype, hipStream_t st) {
     const long kb_per_row = 2 * fp4_k_tiles(K), nfrag = fp4_row_blocks(rows) * kb_per_row;
     const dim3 grid((unsigned)cdivl(nfrag, 4));
+    const int vec = (K % 8 == 0) && ((reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0;  // 8-value chunks stay aligned in every row
     switch (dtype) {
-        case BIE_F16: hipLaunchKernelGGL(fp4_image_values_kernel<BIE_F16>, grid, dim3(256), 0, st, v, bias, (uint4_t*)image, rows, K, nfrag, (int)kb_per_row); break;
-        case BIE_BF16: hipLaunchKernelGGL(fp4_image_values_kernel<BIE_BF16>, grid, dim3(256), 0, st, v, bias, (uint4_t*)image, rows, K, nfrag, (int)kb_per_row); break;
-        case BIE_F32: hipLaunchKernelGGL(fp4_image_values_kernel<BIE_F32>, grid, dim3(256), 0, st, v, bias, (uint4_t*)image, rows, K, nfrag, (int)kb_per_row); break;
-        default: hipLaunchKernelGGL(fp4_image_values_kernel<3>, grid, dim3(256), 0, st, v, nullptr, (uint4_t*)image, rows, K, nfrag, (int)kb_per_row); break;
+        case BIE_F16: hipLaunchKernelGGL(fp4_image_values_kernel<BIE_F16>, grid, dim3(256), 0, st, v, bias, (uint4_t*)image, rows, K, nfrag, (int)kb_per_row, vec); break;
+        case BIE_BF16: hipLaunchKernelGGL(fp4_image_values_kernel<BIE_BF16>, grid, dim3(256), 0, st, v, bias, (uint4_t*)image, rows, K, nfrag, (int)kb_per_row, vec); break;
+        case BIE_F32: hipLaunchKernelGGL(fp4_image_values_kernel<BIE_F32>, grid, dim3(256), 0, st, v, bias, (uint4_t*)image, rows, K, nfrag, (int)kb_per_row, vec); break;
+        default: hipLaunchKernelGGL(fp4_image_values_kernel<3>, grid, dim3(256), 0, st, v, nullptr, (uint4_t*)image, rows, K, nfrag, (int)kb_per_row, vec); break;
     }
     return check_launch("fp4_image_values_kernel");
 }
 
-int binary_fp4_gemm_launch(const uint8_t* ximg, const uint8_t* wimg, float* y, long M, long N, long K, float scale, int tile, hipStream_t st) {
+template <int ODT>
+static void fp4_gemm_launch_dt(const uint8_t* ximg, const uint8_t* wimg, void* y, long M, long N, long K, float scale, const void* sa, const void* sw,
+                               int tile, hipStream_t st) {
     const int KT = (int)fp4_k_tiles(K), RBA = (int)fp4_row_blocks(M), RBB = (int)fp4_row_blocks(N);
     const long t256 = cdivl(M, 256) * cdivl(N, 256);
-    const char* ev = getenv("BIE_FP4_VAR");  // 1: burst form (A/B only)
+    const char* ev = getenv("BIE_FP4_VAR");  // 1: burst form (A/B only); 2..5: timing ablations of the lab build
     const int var = ev ? atoi(ev) : 0;
     // 256 x 256 tiles (one wave per SIMD, LDS reads at half the array's rate) once they fill most of the chip, else 128 x 128
     const bool big = tile == 256 || (tile != 128 && t256 >= 192);
+#define BIE_FP4_GO(WM_, VAR_, GRID_, TN_) \
+    hipLaunchKernelGGL((xnor_fp4_gemm_kernel<WM_, WM_, VAR_, ODT>), GRID_, dim3(256), 0, st, ximg, wimg, y, (int)M, (int)N, KT, RBA, RBB, TN_, scale, sa, sw)
     if (big) {
         const int tn = (int)cdivl(N, 256);
-        if (var == 1) hipLaunchKernelGGL((xnor_fp4_gemm_kernel<4, 4, 1>), dim3((unsigned)t256), dim3(256), 0, st, ximg, wimg, y, (int)M, (int)N, KT, RBA, RBB, tn, scale);
+        const dim3 grid((unsigned)t256);
+        if constexpr (ODT < 0) {
+            if (var == 1) { BIE_FP4_GO(4, 1, grid, tn); return; }
 #ifdef BIE_FP4_LAB
-        else if (var == 2) hipLaunchKernelGGL((xnor_fp4_gemm_kernel<4, 4, 2>), dim3((unsigned)t256), dim3(256), 0, st, ximg, wimg, y, (int)M, (int)N, KT, RBA, RBB, tn, scale);
-        else if (var == 3) hipLaunchKernelGGL((xnor_fp4_gemm_kernel<4, 4, 3>), dim3((unsigned)t256), dim3(256), 0, st, ximg, wimg, y, (int)M, (int)N, KT, RBA, RBB, tn, scale);
-        else if (var == 4) hipLaunchKernelGGL((xnor_fp4_gemm_kernel<4, 4, 4>), dim3((unsigned)t256), dim3(256), 0, st, ximg, wimg, y, (int)M, (int)N, KT, RBA, RBB, tn, scale);
-        else if (var == 5) hipLaunchKernelGGL((xnor_fp4_gemm_kernel<4, 4, 5>), dim3((unsigned)t256), dim3(256), 0, st, ximg, wimg, y, (int)M, (int)N, KT, RBA, RBB, tn, scale);
+            if (var == 2) { BIE_FP4_GO(4, 2, grid, tn); return; }
+            if (var == 3) { BIE_FP4_GO(4, 3, grid, tn); return; }
+            if (var == 4) { BIE_FP4_GO(4, 4, grid, tn); return; }
+            if (var == 5) { BIE_FP4_GO(4, 5, grid, tn); return; }
 #endif
-        else hipLaunchKernelGGL((xnor_fp4_gemm_kernel<4, 4, 0>), dim3((unsigned)t256), dim3(256), 0, st, ximg, wimg, y, (int)M, (int)N, KT, RBA, RBB, tn, scale);
+        }
+        BIE_FP4_GO(4, 0, grid, tn);
     } else {
         const int tn = (int)cdivl(N, 128);
         const dim3 grid((unsigned)(cdivl(M, 128) * tn));
-        if (var == 1) hipLaunchKernelGGL((xnor_fp4_gemm_kernel<2, 2, 1>), grid, dim3(256), 0, st, ximg, wimg, y, (int)M, (int)N, KT, RBA, RBB, tn, scale);
-        else hipLaunchKernelGGL((xnor_fp4_gemm_kernel<2, 2, 0>), grid, dim3(256), 0, st, ximg, wimg, y, (int)M, (int)N, KT, RBA, RBB, tn, scale);
+        if constexpr (ODT < 0) {
+            if (var == 1) { BIE_FP4_GO(2, 1, grid, tn); return; }
+        }
+        BIE_FP4_GO(2, 0, grid, tn);
     }
+#undef BIE_FP4_GO
+}
+
+// dtype < 0: y float = (K - 2*popc) * scale; else the layer epilogue in that dtype with device scalars sa / sw
+int binary_fp4_gemm_launch(const uint8_t* ximg, const uint8_t* wimg, void* y, long M, long N, long K, float scale, const void* sa, const void* sw, int dtype,
+                           int tile, hipStream_t st) {
+    if (dtype < 0) fp4_gemm_launch_dt<-1>(ximg, wimg, y, M, N, K, scale, nullptr, nullptr, tile, st);
+    else if (dtype == BIE_F16) fp4_gemm_launch_dt<BIE_F16>(ximg, wimg, y, M, N, K, 1.0f, sa, sw, tile, st);
+    else if (dtype == BIE_BF16) fp4_gemm_launch_dt<BIE_BF16>(ximg, wimg, y, M, N, K, 1.0f, sa, sw, tile, st);
+    else fp4_gemm_launch_dt<BIE_F32>(ximg, wimg, y, M, N, K, 1.0f, sa, sw, tile, st);
     return check_launch("xnor_fp4_gemm_kernel");
 }
 

@@ -83,7 +83,8 @@ int binary_linear_launch(const uint8_t* xp, const uint8_t* wp, float* y, long M,
 size_t binary_fp4_image_bytes(long rows, long K);
 int binary_fp4_image_launch(const uint8_t* rowpacked, uint8_t* image, long rows, long K, hipStream_t st);
 int binary_fp4_image_values_launch(const void* v, const void* bias, uint8_t* image, long rows, long K, int dtype, hipStream_t st);
-int binary_fp4_gemm_launch(const uint8_t* ximg, const uint8_t* wimg, float* y, long M, long N, long K, float scale, int tile, hipStream_t st);
+int binary_fp4_gemm_launch(const uint8_t* ximg, const uint8_t* wimg, void* y, long M, long N, long K, float scale, const void* sa, const void* sw, int dtype,
+                           int tile, hipStream_t st);
 int binary_matmul_batched_launch(const uint8_t* xp, const uint8_t* wp, float* y, long batch, long M, long N, long K, long stride_x,
                                  long stride_w, long stride_y, float scale, hipStream_t st);
 size_t binary_conv_workspace_bytes(int B, int C, int H, int W, int OC, int ks, int stride, int pad, int dil);
@@ -462,7 +463,17 @@ int bie_binary_linear_forward_fp4(const uint8_t* ximage, const uint8_t* wimage, 
     BIE_REQUIRE(K < (1L << 24) && M < (1L << 31) && N < (1L << 31), BIE_ERR_UNSUPPORTED, "bie_binary_linear_forward_fp4: K=%ld beyond the exact range of the fp32 accumulator (2^24)", K);
     BIE_REQUIRE(((reinterpret_cast<uintptr_t>(ximage) | reinterpret_cast<uintptr_t>(wimage)) & 15) == 0, BIE_ERR_INVALID_ARG, "bie_binary_linear_forward_fp4: images must be 16-byte aligned");
     const char* et = getenv("BIE_FP4_TILE");  // tuning / A-B only: 128 or 256
-    return binary_fp4_gemm_launch(ximage, wimage, y, M, N, K, scale, et ? atoi(et) : 0, as_stream(stream));
+    return binary_fp4_gemm_launch(ximage, wimage, y, M, N, K, scale, nullptr, nullptr, -1, et ? atoi(et) : 0, as_stream(stream));
+}
+
+int bie_binary_linear_layer_fp4(const uint8_t* ximage, const uint8_t* wimage, const void* scale_a, const void* scale_w, void* y, long M, long N, long K,
+                                int dtype, void* stream) {
+    BIE_REQUIRE(ximage && wimage && y && M > 0 && N > 0 && K > 0, BIE_ERR_INVALID_ARG, "bie_binary_linear_layer_fp4: M=%ld N=%ld K=%ld", M, N, K);
+    BIE_REQUIRE(dtype >= 0 && dtype <= 2, BIE_ERR_UNSUPPORTED, "bie_binary_linear_layer_fp4: dtype %d", dtype);
+    BIE_REQUIRE(K < (1L << 24) && M < (1L << 31) && N < (1L << 31), BIE_ERR_UNSUPPORTED, "bie_binary_linear_layer_fp4: K=%ld beyond the exact range of the fp32 accumulator (2^24)", K);
+    BIE_REQUIRE(((reinterpret_cast<uintptr_t>(ximage) | reinterpret_cast<uintptr_t>(wimage)) & 15) == 0, BIE_ERR_INVALID_ARG, "bie_binary_linear_layer_fp4: images must be 16-byte aligned");
+    const char* et = getenv("BIE_FP4_TILE");
+    return binary_fp4_gemm_launch(ximage, wimage, y, M, N, K, 1.0f, scale_a, scale_w, dtype, et ? atoi(et) : 0, as_stream(stream));
 }
 
 int bie_binary_matmul_batched(const uint8_t* xpacked, const uint8_t* wpacked, float* y, long batch, long M, long N, long K, long stride_x,

@@ -277,11 +277,17 @@ int bie_binary_linear_forward(const uint8_t* xpacked, const uint8_t* wpacked, fl
  *   bie_binary_fp4_image_from_values: values [rows, K] (dtype 0=f16 1=bf16 2=f32 3=int8), sign = ((v + bias[k]) >= 0) with the
  *     sum rounded in the tensor dtype (bias may be NULL) -> image; the bit packing of BinaryLinearCuda's set_activation
  *     (layers/qlinear/binary/cuda/layer.py:283) and bie_binary_pack_rows_u8 folded into the image pass.
- *   bie_binary_linear_forward_fp4: y[M, N] fp32 = (K - 2*popcount) * scale from two images (x: M rows, w: N rows). */
+ *   bie_binary_linear_forward_fp4: y[M, N] fp32 = (K - 2*popcount) * scale from two images (x: M rows, w: N rows).
+ *   bie_binary_linear_layer_fp4: the BinaryLinearCuda layer epilogue in the GEMM: y[M, N] (dtype 0=f16 1=bf16 2=f32) =
+ *     dt(dt(dt(K - 2*popcount) * scale_a) * scale_w), scale_a / scale_w device scalars of that dtype or NULL (= 1) -- the roundings
+ *     of `forward(...).to(input.dtype) * scale_a * scale_w` (layers/qlinear/binary/cuda/layer.py:58-63), as bie_binary_linear_fused.
+ *     With bie_binary_fp4_image_from_values(x, bias_a) in front: the whole layer forward at large M in two launches. */
 size_t bie_binary_fp4_image_bytes(long rows, long K);
 int bie_binary_fp4_image(const uint8_t* rowpacked, uint8_t* image, long rows, long K, void* stream);
 int bie_binary_fp4_image_from_values(const void* values, const void* bias, uint8_t* image, long rows, long K, int dtype, void* stream);
 int bie_binary_linear_forward_fp4(const uint8_t* ximage, const uint8_t* wimage, float* y, long M, long N, long K, float scale, void* stream);
+int bie_binary_linear_layer_fp4(const uint8_t* ximage, const uint8_t* wimage, const void* scale_a, const void* scale_w, void* y, long M, long N,
+                                long K, int dtype, void* stream);
 
 /* `batch` independent XNOR GEMMs in ONE launch: y[b][M, N] = (K - 2*popc(x[b] ^ w[b])) * scale, both operands row-packed
  * uint8 [rows, K/8]; strides in BYTES (packed operands) / ELEMENTS (y) between consecutive matrices.

@@ -161,3 +161,55 @@ def test_extension_forward_takes_the_matrix_pipe_for_large_m_and_matches_the_xno
     y4 = binary_linear_cutlass.forward(x, wp, 0.25, False, 0)
     wb = wp.cpu().numpy()
     assert np.array_equal(y4.cpu().numpy(), orc.binary_linear_rowpacked(orc.binary_pack_rows(x.float().cpu().numpy()), wb, K, 0.25))
+
+
+@pytest.mark.parametrize("tile", ["128", "256"])
+@pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,N,K", [(300, 264, 1024), (257, 100, 520), (512, 4096, 4096), (64, 72, 128)])
+def test_fp4_layer_epilogue_is_the_layer_expression(M, N, K, tdt, tile, monkeypatch):
+    """values -> image (bias add + sign) -> matrix-pipe GEMM with the `.to(dtype) * scale_a * scale_w` epilogue == the oracle's integers
+    pushed through the layer's own expression (reference layers/qlinear/binary/cuda/layer.py:58-63, 283); N % 8 != 0 takes the
+    element-store path, K = 520 the padded tail."""
+    from bitorch_engine.extensions._binary_common import pack_rows, xnor_layer_fp4
+    monkeypatch.setenv("BIE_FP4_TILE", tile)
+    gen = torch.Generator().manual_seed(M * 7 + N + K)
+    x = torch.randn((M, K), generator=gen).to(tdt)
+    b = (torch.randn(K, generator=gen) * 0.5).to(tdt)
+    w = torch.randn((N, K), generator=gen)
+    sa = torch.tensor(0.7312, dtype=tdt)
+    sw = torch.tensor(0.0131, dtype=tdt)
+    wrows = pack_rows(w.to(DEV))
+    y = xnor_layer_fp4(x.to(DEV), wrows, b.to(DEV), sa.to(DEV), sw.to(DEV)).cpu()
+    ints = orc.binary_linear_rowpacked(orc.binary_pack_rows((x + b).float().numpy()), orc.binary_pack_rows(w.numpy()), K)
+    expect = torch.from_numpy(ints.astype(np.float32)).to(tdt) * sa * sw
+    assert y.dtype == tdt and torch.equal(y, expect)
+    y1 = xnor_layer_fp4(x.to(DEV), wrows).cpu()  # no bias, no scales
+    ints1 = orc.binary_linear_rowpacked(orc.binary_pack_rows(x.float().numpy()), orc.binary_pack_rows(w.numpy()), K)
+    assert torch.equal(y1, torch.from_numpy(ints1.astype(np.float32)).to(tdt))
+
+
+def test_binary_cuda_layer_takes_the_matrix_pipe_at_large_m_and_matches_the_composed_forward(monkeypatch):
+    from bitorch_engine.layers.qlinear.binary.cuda import BinaryLinearCuda
+    from bitorch_engine.extensions import _binary_common
+    torch.manual_seed(3)
+    K, N = 1024, 384
+    layer = BinaryLinearCuda(K, N, dtype=torch.bfloat16)
+    layer.set_weight_data(torch.randn(N, K).to(torch.bfloat16))
+    layer.bias_a.data = (torch.randn(K) * 0.3).to(torch.bfloat16)
+    layer.eval().to(DEV)
+    layer.generate_quantized_weight(qweight_only=True)
+    x = torch.randn((3, 200, K)).to(torch.bfloat16).to(DEV)  # 600 rows
+    calls = []
+    orig = _binary_common.xnor_layer_fp4
+    monkeypatch.setattr("bitorch_engine.extensions.binary_linear_cuda.xnor_layer_fp4", lambda *a, **k: calls.append(1) or orig(*a, **k))
+    with torch.no_grad():
+        y = layer(x)
+    assert calls == [1] and y.shape == (3, 200, N) and y.dtype == torch.bfloat16
+    monkeypatch.setenv("BIE_FP4_MIN_M", "0")  # the XNOR composition: set_activation, pack, popcount GEMM, cast, two multiplies
+    with torch.no_grad():
+        y0 = layer(x)
+    assert calls == [1] and torch.equal(y, y0)
+    ints = orc.binary_linear_rowpacked(orc.binary_pack_rows((x + layer.bias_a).reshape(-1, K).float().cpu().numpy()),
+                                       orc.binary_pack_rows(layer.weight.data.float().cpu().numpy()), K)
+    expect = torch.from_numpy(ints.astype(np.float32)).to(torch.bfloat16) * layer.scale_a.cpu() * layer.scale_w.cpu()
+    assert torch.equal(y.reshape(-1, N).cpu(), expect)

@@ -36,7 +36,7 @@ for M in (128, 192, 256, 384, 512, 1024, 2048, 4096, 8192):
     row["xnor_us"] = round(us, 2); row["xnor_TOPs"] = round(ops / us / 1e6, 1)
     yx = y.clone()
     for tile in ("128", "256"):
-        for var in ("0", "1"):
+        for var in ("0",):
             os.environ["BIE_FP4_TILE"], os.environ["BIE_FP4_VAR"] = tile, var
             def run_g(st):
                 for wi in wimgs:
@@ -61,6 +61,24 @@ for M in (128, 192, 256, 384, 512, 1024, 2048, 4096, 8192):
             assert L.bie_binary_linear_forward_fp4(ximg.data_ptr(), wi.data_ptr(), y.data_ptr(), M, N, K, 1.0, st) == 0
     us = time_graph(capture(run_e), 10) / NS
     row["fp4_end_to_end_us"] = round(us, 2); row["fp4_end_to_end_TOPs"] = round(ops / us / 1e6, 1)
+    yb = torch.empty((M, N), dtype=BF16, device=dev)
+    bias_a = torch.randn(K, device=dev).to(BF16)
+    sa, sw = torch.tensor(0.7, device=dev).to(BF16), torch.tensor(0.01, device=dev).to(BF16)
+    def run_l(st):
+        for wi in wimgs:
+            assert L.bie_binary_fp4_image_from_values(xv.data_ptr(), bias_a.data_ptr(), ximg.data_ptr(), M, K, 1, st) == 0
+            assert L.bie_binary_linear_layer_fp4(ximg.data_ptr(), wi.data_ptr(), sa.data_ptr(), sw.data_ptr(), yb.data_ptr(), M, N, K, 1, st) == 0
+    us = time_graph(capture(run_l), 10) / NS
+    row["layer_fp4_us"] = round(us, 2); row["layer_fp4_TOPs"] = round(ops / us / 1e6, 1)
+    def run_lg(st):
+        for wi in wimgs:
+            assert L.bie_binary_linear_layer_fp4(ximg.data_ptr(), wi.data_ptr(), sa.data_ptr(), sw.data_ptr(), yb.data_ptr(), M, N, K, 1, st) == 0
+    row["layer_fp4_gemm_only_us"] = round(time_graph(capture(run_lg), 10) / NS, 2)
+    if L.bie_binary_linear_fused_ok(M, N, K):
+        def run_f(st):
+            for w in wsets:
+                assert L.bie_binary_linear_fused(xv.data_ptr(), bias_a.data_ptr(), w.data_ptr(), sa.data_ptr(), sw.data_ptr(), yb.data_ptr(), M, N, K, 1, 0, st) == 0
+        row["layer_xnor_one_launch_us"] = round(time_graph(capture(run_f), 10) / NS, 2)
     out[f"M{M}"] = row
     print(f"M{M}", json.dumps(row), flush=True)
 print(json.dumps(out))
