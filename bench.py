@@ -39,6 +39,7 @@ import torch  # noqa: E402
 GROUP, WBIT = 128, 4
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA
+FP4_MFMA_PEAK_TOPS = 10000.0  # dense FP4 MFMA (MI355X_MICROARCH.md: ~10 PF dense; 9.1 measured by its microbenchmark)
 XOR_POPC_PEAK_TOPS = 1260.0  # v_xor_b32 + v_bcnt_u32_b32 accumulate: 2 VALU per 32 binary MACs per lane
 BF16 = torch.bfloat16
 
@@ -319,9 +320,51 @@ def bench_binary(dev, L):
         rf = ({"bound": "hbm", "achieved": round(byts / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(byts / us / 1e3 / HBM_PEAK_GBS, 4)}
               if M < 16 else {"bound": "valu xor+bcnt", "achieved": round(tops, 1), "peak": XOR_POPC_PEAK_TOPS, "unit": "TOP/s", "frac": round(tops / XOR_POPC_PEAK_TOPS, 4)})
         out.append({"op": "binary linear 4096x4096", "M": M, "us_per_launch": round(us, 2), "TOP/s": round(tops, 1), "roofline": dict(rf, traffic=None)})
-    # the whole BinaryLinearCuda layer forward (activation bias + sign-pack of bf16 x, XNOR-popcount, cast, both scales) in one launch
+    # the same product on the matrix pipe (M >= 256): +-1 as FP4 operands of v_mfma_scale_f32_32x32x64_f8f6f4, bit-identical integers.
+    # Timed end to end from the same packed operands (x image pass + GEMM; the weight image is per-tensor, built once) and GEMM alone.
     bias_a = torch.randn(K, device=dev).to(BF16)
     sa, sw = torch.tensor(0.7, device=dev).to(BF16), torch.tensor(0.01, device=dev).to(BF16)
+    st0 = torch.cuda.current_stream().cuda_stream
+    wimgs = []
+    for w in wsets[:8]:
+        img = torch.empty(L.bie_binary_fp4_image_bytes(N, K), dtype=torch.uint8, device=dev)
+        if L.bie_binary_fp4_image(w.data_ptr(), img.data_ptr(), N, K, st0):
+            raise RuntimeError(L.bie_last_error().decode())
+        wimgs.append(img)
+    for M in (256, 512, 4096, 8192):
+        xp = torch.randint(0, 256, (M, K // 8), dtype=torch.int32, device=dev).to(torch.uint8)
+        xv = torch.randn((M, K), device=dev).to(BF16)
+        y = torch.empty((M, N), dtype=torch.float32, device=dev)
+        yb = torch.empty((M, N), dtype=BF16, device=dev)
+        ximg = torch.empty(L.bie_binary_fp4_image_bytes(M, K), dtype=torch.uint8, device=dev)
+
+        def chk(rc):
+            if rc:
+                raise RuntimeError(L.bie_last_error().decode())
+
+        def run_e2e(st):
+            for wi in wimgs:
+                chk(L.bie_binary_fp4_image(xp.data_ptr(), ximg.data_ptr(), M, K, st))
+                chk(L.bie_binary_linear_forward_fp4(ximg.data_ptr(), wi.data_ptr(), y.data_ptr(), M, N, K, 1.0, st))
+
+        def run_gemm(st):
+            for wi in wimgs:
+                chk(L.bie_binary_linear_forward_fp4(ximg.data_ptr(), wi.data_ptr(), y.data_ptr(), M, N, K, 1.0, st))
+
+        def run_layer(st):
+            for wi in wimgs:
+                chk(L.bie_binary_fp4_image_from_values(xv.data_ptr(), bias_a.data_ptr(), ximg.data_ptr(), M, K, 1, st))
+                chk(L.bie_binary_linear_layer_fp4(ximg.data_ptr(), wi.data_ptr(), sa.data_ptr(), sw.data_ptr(), yb.data_ptr(), M, N, K, 1, st))
+        reps = 10 if M < 4096 else 3
+        us_e, us_g, us_l = (time_graph(capture(f), reps) / len(wimgs) for f in (run_e2e, run_gemm, run_layer))
+        ops = 2.0 * M * K * N
+        out.append({"op": "binary linear 4096x4096 on the matrix pipe (FP4 +-1 operands, bit-identical): x image pass + GEMM from packed operands", "M": M,
+                    "us_per_call": round(us_e, 2), "TOP/s": round(ops / us_e / 1e6, 1), "gemm_only_us": round(us_g, 2),
+                    "layer_forward_bf16_two_launches_us": round(us_l, 2),
+                    "roofline": {"bound": "mfma fp4", "achieved": round(ops / us_g / 1e6, 1), "peak": FP4_MFMA_PEAK_TOPS, "unit": "TOP/s",
+                                 "frac": round(ops / us_g / 1e6 / FP4_MFMA_PEAK_TOPS, 4), "traffic": None,
+                                 "kernel": "bie::xnor_fp4_gemm_kernel (v_mfma_scale_f32_32x32x64_f8f6f4), GEMM alone"}})
+    # the whole BinaryLinearCuda layer forward (activation bias + sign-pack of bf16 x, XNOR-popcount, cast, both scales) in one launch
     for M in (1, 16, 64, 256):
         x = torch.randn((M, K), device=dev).to(BF16)
         yb = torch.empty((M, N), dtype=BF16, device=dev)
