@@ -184,6 +184,7 @@ __device__ __forceinline__ void mfma_fp4(float16_t& c, const v4i_t& a, const v4i
 }
 __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }  // >= 18 wait states: XDL write -> VALU read
 
+constexpr int imin(int a, int b) { return a < b ? a : b; }
 template <int I> struct ic_t { static constexpr int value = I; };
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -209,6 +210,10 @@ __global__ __launch_bounds__(256) void xnor_fp4_gemm_kernel(const uint8_t* __res
     constexpr int STAGE = NFR * 1024;
     constexpr int NR = WM + WN;              // fragment reads per k64 half
     constexpr int NM = WM * WN;              // MFMAs per k64 half
+    // Items between the MFMAs: a cluster's fragment reads go behind its FIRST MFMAs (RPM per MFMA: all issued by the middle of the
+    // cluster, so the lgkmcnt(0) in front of the next cluster finds them landed -- spread over the whole cluster the last read sat
+    // behind the last MFMA and its latency was exposed twice per stage), the refill pieces behind the remaining ones (DPM per MFMA).
+    constexpr int RPM = (2 * NR + NM - 1) / NM, M0 = (NR + RPM - 1) / RPM, DPM = (PW + (NM - M0) - 1) / (NM - M0);
     // timing ablations (lab build only, results are wrong): VAR 2: no LDS-DMA in the loop, 3: no fragment reads, 4: neither, 5: and no barrier
     constexpr bool DMA = VAR < 2 || VAR == 3, READS = VAR < 3, BARRIER = VAR < 5;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[3 * STAGE];
@@ -292,20 +297,18 @@ __global__ __launch_bounds__(256) void xnor_fp4_gemm_kernel(const uint8_t* __res
             static_for<0, NM>([&](auto mc) {
                 constexpr int m = decltype(mc)::value, i = m / WN, j = m % WN;
                 mfma_fp4(acc[i][j], PB[j], PA[i], e8m0_one);
-                if constexpr (READS) static_for<m * NR / NM, (m + 1) * NR / NM>([&](auto rc) { read_item(rc, ic_t<1>{}, so, QA, QB); });
+                if constexpr (READS) static_for<imin(m * RPM, NR), imin((m + 1) * RPM, NR)>([&](auto rc) { read_item(rc, ic_t<1>{}, so, QA, QB); });
             });
             wait_frags<0>(QA, QB);  // every LDS read of this stage has returned: its buffer may be refilled behind the barrier
             if constexpr (DMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");  // K tile kt+1 landed (kt+2 still in flight)
             if constexpr (BARRIER) __builtin_amdgcn_s_barrier();
-            constexpr int NI = NR + PW;  // items of the second half: next stage's first reads, then the refill pieces
             static_for<0, NM>([&](auto mc) {
                 constexpr int m = decltype(mc)::value, i = m / WN, j = m % WN;
                 mfma_fp4(acc[i][j], QB[j], QA[i], e8m0_one);
-                static_for<m * NI / NM, (m + 1) * NI / NM>([&](auto xc) {
-                    constexpr int x = decltype(xc)::value;
-                    if constexpr (x < NR) { if constexpr (READS) read_item(xc, ic_t<0>{}, sn, NA, NB); }
-                    else if constexpr (DMA) issue_piece(kt + 3, x - NR);
-                });
+                // the next stage's first reads behind the first MFMAs, the refill pieces behind the rest
+                if constexpr (READS) static_for<imin(m * RPM, NR), imin((m + 1) * RPM, NR)>([&](auto rc) { read_item(rc, ic_t<0>{}, sn, NA, NB); });
+                if constexpr (DMA && m >= M0)
+                    static_for<imin((m - M0) * DPM, PW), imin((m - M0 + 1) * DPM, PW)>([&](auto pc) { issue_piece(kt + 3, decltype(pc)::value); });
             });
         } else {
             read_frags<WM, 1024>(QA, a_addr + so);

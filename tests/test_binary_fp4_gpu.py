@@ -194,8 +194,8 @@ def test_binary_cuda_layer_takes_the_matrix_pipe_at_large_m_and_matches_the_comp
     torch.manual_seed(3)
     K, N = 1024, 384
     layer = BinaryLinearCuda(K, N, dtype=torch.bfloat16)
-    wt = torch.randn(N, K).to(torch.bfloat16)
-    layer.set_weight_data(wt.clone())
+    layer.set_weight_data(torch.randn(N, K).to(torch.bfloat16))
+    wt = layer.weight.data.float().cpu()  # the layer's own sign carriers (init_weight centres the weights before taking the sign)
     layer.bias_a.data = (torch.randn(K) * 0.3).to(torch.bfloat16)
     layer.eval().to(DEV)
     layer.generate_quantized_weight(qweight_only=True)
@@ -211,6 +211,6 @@ def test_binary_cuda_layer_takes_the_matrix_pipe_at_large_m_and_matches_the_comp
         y0 = layer(x)
     assert calls == [1] and torch.equal(y, y0)
     ints = orc.binary_linear_rowpacked(orc.binary_pack_rows((x + layer.bias_a.detach()).reshape(-1, K).float().cpu().numpy()),
-                                       orc.binary_pack_rows(wt.float().numpy()), K)
+                                       orc.binary_pack_rows(wt.numpy()), K)
     expect = torch.from_numpy(ints.astype(np.float32)).to(torch.bfloat16) * layer.scale_a.detach().cpu() * layer.scale_w.detach().cpu()
     assert torch.equal(y.reshape(-1, N).cpu(), expect)
