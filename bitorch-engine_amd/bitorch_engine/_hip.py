@@ -63,6 +63,8 @@ SIGNATURES = {
     "bie_binary_fp4_image_from_values": (_i, [_vp, _vp, _vp, _l, _l, _i, _vp]),
     "bie_binary_linear_forward_fp4": (_i, [_vp, _vp, _vp, _l, _l, _l, _f, _vp]),
     "bie_binary_linear_layer_fp4": (_i, [_vp] * 5 + [_l] * 3 + [_i, _vp]),
+    "bie_binary_conv2d_fp4_workspace_bytes": (_sz, [_i] * 8),
+    "bie_binary_conv2d_forward_fp4": (_i, [_vp] * 4 + [_sz] + [_i] * 9 + [_f, _i, _vp]),
     "bie_binary_matmul_batched": (_i, [_vp, _vp, _vp] + [_l] * 7 + [_f, _vp]),
     "bie_binary_linear_fused_ok": (_i, [_l] * 3),
     "bie_binary_linear_fused": (_i, [_vp] * 6 + [_l] * 3 + [_i, _i, _vp]),

@@ -174,6 +174,19 @@ def conv_weight_taps(wpacked, OC, C, ksize):
     return _cached(wpacked, ("taps", OC, C, ksize), convert)
 
 
+def conv_fp4_min_rows() -> int:
+    """Smallest number of output pixels (B * OH * OW) the matrix-pipe form of the conv serves (BIE_FP4_CONV_MIN_ROWS; 0 = off)."""
+    v = os.environ.get("BIE_FP4_CONV_MIN_ROWS")
+    return int(v) if v else 1024
+
+
+def conv_weight_fp4_image(wpacked, OC, C, ksize):
+    """FP4 image of the tap-major weight words (rows = OC, k = (tap, channel)), remembered on the packed tensor."""
+    from .q_linear_cuda import _cached
+    return _cached(wpacked, ("fp4taps", OC, C, ksize),
+                   lambda: fp4_image(conv_weight_taps(wpacked, OC, C, ksize).view(torch.uint8).reshape(OC, -1), OC, ksize * ksize * C))
+
+
 def conv2d(x, wpacked, OC, ksize, stride, pad, dil, scale):
     _hip.need_gpu(x, wpacked)
     x = x.contiguous()
@@ -182,6 +195,16 @@ def conv2d(x, wpacked, OC, ksize, stride, pad, dil, scale):
     OW = (W + 2 * pad - dil * (ksize - 1) - 1) // stride + 1
     y = torch.empty((B, OC, OH, OW), dtype=torch.float32, device=x.device)
     L = _hip.lib()
+    rows_min = conv_fp4_min_rows()
+    if rows_min and C % 32 == 0 and B * OH * OW >= rows_min and OC >= 64 and x.dtype in _hip._DT:
+        # large batch: the conv as a GEMM on the matrix pipe (+-1 as FP4 MFMA operands), bit-identical
+        wimg = conv_weight_fp4_image(wpacked, OC, C, ksize)
+        need = L.bie_binary_conv2d_fp4_workspace_bytes(B, C, H, W, ksize, stride, pad, dil)
+        ws = _hip.scratch(need, x.device)
+        rc = L.bie_binary_conv2d_forward_fp4(_hip.ptr(x), _hip.ptr(wimg), _hip.ptr(y), _hip.ptr(ws), ws.numel(), B, C, H, W, OC, ksize, stride, pad,
+                                             dil, float(scale), _hip.dt(x), _hip.stream())
+        _hip.check(rc, "bie_binary_conv2d_forward_fp4")
+        return y
     need = L.bie_binary_conv2d_workspace_bytes(B, C, H, W, OC, ksize, stride, pad, dil)
     ws = _hip.workspace(need, x.device)
     if L.bie_binary_conv2d_taps_ok(C, W, ksize) and (C * ksize * ksize) % 8 == 0:

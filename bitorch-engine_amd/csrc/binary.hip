@@ -1119,6 +1119,13 @@ size_t binary_conv_taps_lds_bytes(int C, int W, int ks) {
     return words * 4 <= 16384 ? words * 4 * 4 : 0;
 }
 
+int binary_pack_nhwc_bits_launch(const void* x, uint32_t* xbits, int B, int C, int HW, int dtype, hipStream_t st) {
+    const int CW = cdiv(C, 32);
+    dim3 grid((unsigned)cdivl((long)B * CW * HW, 256));
+    BIE_DT_SWITCH(dtype, hipLaunchKernelGGL(pack_nhwc_bits_kernel<DT>, grid, dim3(256), 0, st, x, xbits, B, C, HW, CW));
+    return check_launch("pack_nhwc_bits_kernel");
+}
+
 size_t binary_conv_taps_workspace_bytes(int B, int C, int H, int W) { return (size_t)B * H * W * cdiv(C, 32) * 4; }
 
 int binary_conv_weight_taps_launch(const uint8_t* wpacked, uint32_t* wtaps, int OC, int C, int ks, hipStream_t st) {

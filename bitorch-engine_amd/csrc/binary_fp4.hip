@@ -144,6 +144,37 @@ __global__ __launch_bounds__(256) void fp4_image_values_kernel(const void* __res
     if (f < nfrag) img[f * 64 + lane] = *reinterpret_cast<const uint4_t*>(&tile[wave][lane * 4]);
 }
 
+// Binary conv2d as the same GEMM: rows = output pixels (b, oy, ox), k' = (tap, channel) -- any k order works as long as both operands
+// use it, and tap-major is the order the channel-minor activation bits (pack_nhwc_bits_kernel: xbits[b][h][w][C/32]) and the tap-major
+// weight words (conv_weight_taps_kernel: wtaps[oc][tap][C/32]) already have.  A lane's 32 nibbles are ONE word of xbits (C % 32 == 0)
+// or, outside the picture, 32 x -1.0: the reference counts padding as -1 (binary_conv.cpp:319-365), which is bit 0 = 0xA here.
+// Replaces the bit-im2col image of binary_conv.cpp:319-365 for large batches (im2binary_col + the GEMM of :464-530).
+__global__ __launch_bounds__(256) void conv_fp4_image_kernel(const uint32_t* __restrict__ xbits, uint4_t* __restrict__ img, int H, int W, int CW, int OH, int OW,
+                                                             int ks, int stride, int pad, int dil, long rows, long nfrag, int kb_per_row,
+                                                             int words_per_row) {
+    const long f = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (f >= nfrag) return;
+    const int lane = threadIdx.x & 63;
+    const long rb = f / kb_per_row;
+    const int kb = (int)(f - rb * kb_per_row);
+    const long row = rb * 32 + (lane & 31);
+    const int wi = kb * 2 + (lane >> 5);
+    uint4_t o = {0u, 0u, 0u, 0u};
+    if (row < rows && wi < words_per_row) {
+        const int tap = wi / CW, cw = wi - tap * CW;
+        const int ti = tap / ks, tj = tap - ti * ks;
+        const int P = OH * OW;
+        const long b = row / P;
+        const int p = (int)(row - b * P);
+        const int oy = p / OW, ox = p - oy * OW;
+        const int iy = oy * stride - pad + ti * dil, ix = ox * stride - pad + tj * dil;
+        uint32_t w = 0u;  // outside the picture: every channel -1
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) w = xbits[((b * H + iy) * W + ix) * CW + cw];
+        o = uint4_t{fp4_from_bits8(w), fp4_from_bits8(w >> 8), fp4_from_bits8(w >> 16), fp4_from_bits8(w >> 24)};
+    }
+    img[f * 64 + lane] = o;
+}
+
 // ---- LDS fragment reads (hand-issued: the compiler must not order them against the LDS-DMA by its own alias rules) ----
 template <int OFF>
 __device__ __forceinline__ v4i_t lds_read16(uint32_t addr) {
@@ -197,13 +228,14 @@ __device__ __forceinline__ void static_for(F&& f) {
 // VAR 0: fragment reads and LDS-DMA pieces BETWEEN the MFMAs (one item per MFMA shadow: a lone in-order wave per SIMD overlaps
 //        nothing it does not interleave), branch-free stage body (look-ahead clamped to the last K tile);
 // VAR 1: the same pipeline with reads / DMA issued in bursts between the two 16-MFMA clusters of a stage (kept for the A/B).
-// ODT < 0: y fp32 = (K - 2*popc) * scale.  ODT = BIE_F16 / BF16 / F32: the BinaryLinearCuda layer epilogue, y (ODT) =
+// ODT = -1: y fp32 [M, N] = (K - 2*popc) * scale.  ODT = -2: the conv2d output, rows m = (image b, pixel p) of conv_p pixels, columns =
+// output channels: y fp32 [B, N, conv_p] (NCHW), y[(b * N + n) * conv_p + p].  ODT = BIE_F16 / BF16 / F32: the BinaryLinearCuda layer epilogue, y (ODT) =
 // dt(dt(dt(K - 2*popc) * scale_a) * scale_w) with scale_a / scale_w device scalars of that dtype (NULL = 1): the roundings of
 // `forward(...).to(input.dtype) * scale_a * scale_w` (layers/qlinear/binary/cuda/layer.py:58-63), as xnor_fused_kernel.
 template <int WM, int WN, int VAR, int ODT>
 __global__ __launch_bounds__(256) void xnor_fp4_gemm_kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B, void* __restrict__ yv, int M, int N,
                                                             int KT, int RBA, int RBB, int tiles_n, float scale, const void* __restrict__ scale_a,
-                                                            const void* __restrict__ scale_w) {
+                                                            const void* __restrict__ scale_w, int conv_p) {
     constexpr int AF = 2 * WM, BF = 2 * WN;  // 32-row blocks per workgroup tile
     constexpr int NFR = (AF + BF) * 2;       // 1 KiB fragments per stage (k = 128)
     constexpr int PW = NFR / 4;              // LDS-DMA pieces per wave and stage
@@ -349,7 +381,29 @@ __global__ __launch_bounds__(256) void xnor_fp4_gemm_kernel(const uint8_t* __res
     // four registers, FOUR CONSECUTIVE n: one 16-byte store per group (64 per lane instead of 256 dword stores -- the dword form was
     // store-issue bound: 13 us of fixed cost per launch, profiles/r03_fp4_c_k_slope.txt).
     const int m_l = lane & 31;
-    if constexpr (ODT < 0 || ODT == BIE_F32) {
+    if constexpr (ODT == -2) {
+        // NCHW scatter: for one register the 32 lanes of a half-wave hold 32 consecutive pixels of one channel -> dword stores, contiguous
+        // across lanes inside an image
+        float* y = (float*)yv;
+        const int n_l = 4 * (lane >> 5);
+#pragma unroll
+        for (int i = 0; i < WM; i++) {
+            const int m = (tile_m * AF + wy * WM + i) * 32 + m_l;
+            if (m < M) {
+                const int b = m / conv_p, p = m - b * conv_p;
+                float* yb = y + (long)b * N * conv_p + p;
+#pragma unroll
+                for (int j = 0; j < WN; j++) {
+                    const int n0 = (tile_n * BF + wx * WN + j) * 32 + n_l;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int n = n0 + 8 * (r >> 2) + (r & 3);
+                        if (n < N) yb[(long)n * conv_p] = acc[i][j][r] * scale;
+                    }
+                }
+            }
+        }
+    } else if constexpr (ODT < 0 || ODT == BIE_F32) {
         float* y = (float*)yv;
         float sa = 1.0f, sw = 1.0f;
         if constexpr (ODT == BIE_F32) {
@@ -457,7 +511,7 @@ int binary_fp4_image_values_launch(const void* v, const void* bias, uint8_t* ima
 
 template <int ODT>
 static void fp4_gemm_launch_dt(const uint8_t* ximg, const uint8_t* wimg, void* y, long M, long N, long K, float scale, const void* sa, const void* sw,
-                               int tile, hipStream_t st) {
+                               int tile, hipStream_t st, int conv_p = 0) {
     const int KT = (int)fp4_k_tiles(K), RBA = (int)fp4_row_blocks(M), RBB = (int)fp4_row_blocks(N);
     const long t256 = cdivl(M, 256) * cdivl(N, 256);
     const char* ev = getenv("BIE_FP4_VAR");  // 1: burst form (A/B only); 2..5: timing ablations of the lab build
@@ -465,11 +519,11 @@ static void fp4_gemm_launch_dt(const uint8_t* ximg, const uint8_t* wimg, void* y
     // 256 x 256 tiles (one wave per SIMD, LDS reads at half the array's rate) once they fill most of the chip, else 128 x 128
     const bool big = tile == 256 || (tile != 128 && t256 >= 192);
 #define BIE_FP4_GO(WM_, VAR_, GRID_, TN_) \
-    hipLaunchKernelGGL((xnor_fp4_gemm_kernel<WM_, WM_, VAR_, ODT>), GRID_, dim3(256), 0, st, ximg, wimg, y, (int)M, (int)N, KT, RBA, RBB, TN_, scale, sa, sw)
+    hipLaunchKernelGGL((xnor_fp4_gemm_kernel<WM_, WM_, VAR_, ODT>), GRID_, dim3(256), 0, st, ximg, wimg, y, (int)M, (int)N, KT, RBA, RBB, TN_, scale, sa, sw, conv_p)
     if (big) {
         const int tn = (int)cdivl(N, 256);
         const dim3 grid((unsigned)t256);
-        if constexpr (ODT < 0) {
+        if constexpr (ODT == -1) {
             if (var == 1) { BIE_FP4_GO(4, 1, grid, tn); return; }
 #ifdef BIE_FP4_LAB
             if (var == 2) { BIE_FP4_GO(4, 2, grid, tn); return; }
@@ -482,7 +536,7 @@ static void fp4_gemm_launch_dt(const uint8_t* ximg, const uint8_t* wimg, void* y
     } else {
         const int tn = (int)cdivl(N, 128);
         const dim3 grid((unsigned)(cdivl(M, 128) * tn));
-        if constexpr (ODT < 0) {
+        if constexpr (ODT == -1) {
             if (var == 1) { BIE_FP4_GO(2, 1, grid, tn); return; }
         }
         BIE_FP4_GO(2, 0, grid, tn);
@@ -498,6 +552,33 @@ int binary_fp4_gemm_launch(const uint8_t* ximg, const uint8_t* wimg, void* y, lo
     else if (dtype == BIE_BF16) fp4_gemm_launch_dt<BIE_BF16>(ximg, wimg, y, M, N, K, 1.0f, sa, sw, tile, st);
     else fp4_gemm_launch_dt<BIE_F32>(ximg, wimg, y, M, N, K, 1.0f, sa, sw, tile, st);
     return check_launch("xnor_fp4_gemm_kernel");
+}
+
+// conv2d forward on the matrix pipe: x [B, C, H, W] -> channel-minor sign bits (ws head, binary.hip's pack_nhwc_bits) -> FP4 image of the
+// (pixel, tap, channel) matrix -> GEMM against the weights' image with the NCHW epilogue.  C % 32 == 0.
+int binary_pack_nhwc_bits_launch(const void* x, uint32_t* xbits, int B, int C, int HW, int dtype, hipStream_t st);  // binary.hip
+size_t binary_conv_fp4_workspace_bytes(int B, int C, int H, int W, int ks, int stride, int pad, int dil) {
+    const int OH = (H + 2 * pad - dil * (ks - 1) - 1) / stride + 1, OW = (W + 2 * pad - dil * (ks - 1) - 1) / stride + 1;
+    if (OH <= 0 || OW <= 0) return 0;
+    const size_t xb = ((size_t)B * H * W * (C / 32) * 4 + 1023) & ~(size_t)1023;
+    return xb + binary_fp4_image_bytes((long)B * OH * OW, (long)ks * ks * C);
+}
+int binary_conv_fp4_launch(const void* x, const uint8_t* wimg, float* y, void* ws, int B, int C, int H, int W, int OC, int ks, int stride, int pad, int dil,
+                           float scale, int dtype, int tile, hipStream_t st) {
+    const int OH = (H + 2 * pad - dil * (ks - 1) - 1) / stride + 1, OW = (W + 2 * pad - dil * (ks - 1) - 1) / stride + 1;
+    const int CW = C / 32;
+    uint32_t* xbits = reinterpret_cast<uint32_t*>(ws);
+    uint8_t* ximg = reinterpret_cast<uint8_t*>(ws) + (((size_t)B * H * W * CW * 4 + 1023) & ~(size_t)1023);
+    int rc = binary_pack_nhwc_bits_launch(x, xbits, B, C, H * W, dtype, st);
+    if (rc) return rc;
+    const long rows = (long)B * OH * OW, Kp = (long)ks * ks * C;
+    const long kb_per_row = 2 * fp4_k_tiles(Kp), nfrag = fp4_row_blocks(rows) * kb_per_row;
+    hipLaunchKernelGGL(conv_fp4_image_kernel, dim3((unsigned)cdivl(nfrag, 4)), dim3(256), 0, st, xbits, (uint4_t*)ximg, H, W, CW, OH, OW, ks, stride, pad, dil, rows,
+                       nfrag, (int)kb_per_row, ks * ks * CW);
+    rc = check_launch("conv_fp4_image_kernel");
+    if (rc) return rc;
+    fp4_gemm_launch_dt<-2>(ximg, wimg, y, rows, OC, Kp, scale, nullptr, nullptr, tile, st, OH * OW);
+    return check_launch("xnor_fp4_gemm_kernel<conv>");
 }
 
 }  // namespace bie

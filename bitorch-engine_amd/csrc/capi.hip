@@ -85,6 +85,9 @@ int binary_fp4_image_launch(const uint8_t* rowpacked, uint8_t* image, long rows,
 int binary_fp4_image_values_launch(const void* v, const void* bias, uint8_t* image, long rows, long K, int dtype, hipStream_t st);
 int binary_fp4_gemm_launch(const uint8_t* ximg, const uint8_t* wimg, void* y, long M, long N, long K, float scale, const void* sa, const void* sw, int dtype,
                            int tile, hipStream_t st);
+size_t binary_conv_fp4_workspace_bytes(int B, int C, int H, int W, int ks, int stride, int pad, int dil);
+int binary_conv_fp4_launch(const void* x, const uint8_t* wimg, float* y, void* ws, int B, int C, int H, int W, int OC, int ks, int stride, int pad, int dil,
+                           float scale, int dtype, int tile, hipStream_t st);
 int binary_matmul_batched_launch(const uint8_t* xp, const uint8_t* wp, float* y, long batch, long M, long N, long K, long stride_x,
                                  long stride_w, long stride_y, float scale, hipStream_t st);
 size_t binary_conv_workspace_bytes(int B, int C, int H, int W, int OC, int ks, int stride, int pad, int dil);
@@ -474,6 +477,26 @@ int bie_binary_linear_layer_fp4(const uint8_t* ximage, const uint8_t* wimage, co
     BIE_REQUIRE(((reinterpret_cast<uintptr_t>(ximage) | reinterpret_cast<uintptr_t>(wimage)) & 15) == 0, BIE_ERR_INVALID_ARG, "bie_binary_linear_layer_fp4: images must be 16-byte aligned");
     const char* et = getenv("BIE_FP4_TILE");
     return binary_fp4_gemm_launch(ximage, wimage, y, M, N, K, 1.0f, scale_a, scale_w, dtype, et ? atoi(et) : 0, as_stream(stream));
+}
+
+size_t bie_binary_conv2d_fp4_workspace_bytes(int B, int C, int H, int W, int ksize, int stride, int pad, int dilation) {
+    if (B <= 0 || C <= 0 || C % 32 || H <= 0 || W <= 0 || ksize <= 0 || stride <= 0 || dilation <= 0 || pad < 0) return 0;
+    return binary_conv_fp4_workspace_bytes(B, C, H, W, ksize, stride, pad, dilation);
+}
+
+int bie_binary_conv2d_forward_fp4(const void* x, const uint8_t* wimage, float* y, void* workspace, size_t workspace_bytes, int B, int C, int H, int W, int OC,
+                                  int ksize, int stride, int pad, int dilation, float scale, int dtype, void* stream) {
+    BIE_REQUIRE(x && wimage && y && workspace, BIE_ERR_INVALID_ARG, "bie_binary_conv2d_forward_fp4: NULL tensor pointer");
+    BIE_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && OC > 0 && ksize > 0 && stride > 0 && dilation > 0 && pad >= 0, BIE_ERR_INVALID_ARG, "bie_binary_conv2d_forward_fp4: bad geometry");
+    BIE_REQUIRE(C % 32 == 0, BIE_ERR_UNSUPPORTED, "bie_binary_conv2d_forward_fp4: C=%d must be a multiple of 32 (use bie_binary_conv2d_forward_taps)", C);
+    BIE_REQUIRE(dtype >= 0 && dtype <= 2, BIE_ERR_UNSUPPORTED, "bie_binary_conv2d_forward_fp4: dtype %d", dtype);
+    const size_t need = binary_conv_fp4_workspace_bytes(B, C, H, W, ksize, stride, pad, dilation);
+    BIE_REQUIRE(need > 0, BIE_ERR_INVALID_ARG, "bie_binary_conv2d_forward_fp4: empty output");
+    BIE_REQUIRE(workspace_bytes >= need, BIE_ERR_WORKSPACE, "bie_binary_conv2d_forward_fp4: workspace of %zu bytes required, got %zu", need, workspace_bytes);
+    BIE_REQUIRE(((reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(wimage)) & 15) == 0, BIE_ERR_INVALID_ARG, "bie_binary_conv2d_forward_fp4: workspace and image must be 16-byte aligned");
+    BIE_REQUIRE((long)ksize * ksize * C < (1L << 24), BIE_ERR_UNSUPPORTED, "bie_binary_conv2d_forward_fp4: C*k*k beyond the exact range of the fp32 accumulator");
+    const char* et = getenv("BIE_FP4_TILE");
+    return binary_conv_fp4_launch(x, wimage, y, workspace, B, C, H, W, OC, ksize, stride, pad, dilation, scale, dtype, et ? atoi(et) : 0, as_stream(stream));
 }
 
 int bie_binary_matmul_batched(const uint8_t* xpacked, const uint8_t* wpacked, float* y, long batch, long M, long N, long K, long stride_x,

@@ -289,6 +289,16 @@ int bie_binary_linear_forward_fp4(const uint8_t* ximage, const uint8_t* wimage, 
 int bie_binary_linear_layer_fp4(const uint8_t* ximage, const uint8_t* wimage, const void* scale_a, const void* scale_w, void* y, long M, long N,
                                 long K, int dtype, void* stream);
 
+/* The same convolution on the matrix pipe for large batches (C % 32 == 0): channel-minor sign bits of x, the FP4 image of the
+ * (output pixel) x (tap, channel) matrix -- padding = -1.0 -- and the FP4 GEMM above with an NCHW epilogue; bit-identical to
+ * bie_binary_conv2d_forward.  wimage = bie_binary_fp4_image of the tap-major weight words of bie_binary_conv_weight_taps read as
+ * row-packed bytes (rows = OC, K = ksize*ksize*C): the k order (tap, channel) only has to be the same on both sides.
+ * Replaces binary_conv_cpp.forward (binary_conv.cpp:319-365 im2binary_col + :464-530). */
+size_t bie_binary_conv2d_fp4_workspace_bytes(int B, int C, int H, int W, int ksize, int stride, int pad, int dilation);
+int bie_binary_conv2d_forward_fp4(const void* x, const uint8_t* wimage, float* y, void* workspace, size_t workspace_bytes, int B, int C,
+                                  int H, int W, int OC, int ksize, int stride, int pad, int dilation, float scale, int dtype,
+                                  void* stream);
+
 /* `batch` independent XNOR GEMMs in ONE launch: y[b][M, N] = (K - 2*popc(x[b] ^ w[b])) * scale, both operands row-packed
  * uint8 [rows, K/8]; strides in BYTES (packed operands) / ELEMENTS (y) between consecutive matrices.
  * Replaces binary_linear_cutlass.matmul -> binary_batched_forward_cutlass

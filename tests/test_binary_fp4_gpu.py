@@ -214,3 +214,32 @@ def test_binary_cuda_layer_takes_the_matrix_pipe_at_large_m_and_matches_the_comp
                                        orc.binary_pack_rows(wt.numpy()), K)
     expect = torch.from_numpy(ints.astype(np.float32)).to(torch.bfloat16) * layer.scale_a.detach().cpu() * layer.scale_w.detach().cpu()
     assert torch.equal(y.reshape(-1, N).cpu(), expect)
+
+
+@pytest.mark.parametrize("tile", ["128", "256"])
+@pytest.mark.parametrize("B,C,H,W,OC,ks,st,pad,dil", [(2, 64, 7, 7, 64, 3, 1, 1, 1), (3, 32, 9, 11, 96, 3, 2, 1, 1), (2, 128, 8, 8, 72, 3, 1, 2, 2),
+                                                       (1, 64, 6, 5, 64, 1, 1, 0, 1), (4, 96, 5, 5, 130, 5, 1, 2, 1), (33, 512, 7, 7, 512, 3, 1, 1, 1)])
+def test_fp4_conv_equals_the_oracle_and_the_tap_form(B, C, H, W, OC, ks, st, pad, dil, tile, monkeypatch):
+    """The conv as an FP4 GEMM over (pixel) x (tap, channel) -- padding counted as -1, NCHW epilogue -- == orc_binary_conv2d (pinned to
+    the reference's binary_conv.cpp by tests/test_oracle_golden.py) == the XNOR tap form, bit for bit; strides, dilation, 1x1 and 5x5
+    kernels, ragged widths, OC not a multiple of 32, the ResNet-18 layer-4 shape."""
+    from bitorch_engine.extensions import binary_conv_cpp
+    from bitorch_engine.extensions._binary_common import pack_rows
+    monkeypatch.setenv("BIE_FP4_TILE", tile)
+    g = torch.Generator().manual_seed(B * 131 + C + H * 7 + OC)
+    x = torch.randn((B, C, H, W), generator=g)
+    w = torch.randn((OC, C, ks, ks), generator=g)
+    wp = pack_rows(w.reshape(OC, -1).to(DEV)).contiguous()
+    OH = (H + 2 * pad - dil * (ks - 1) - 1) // st + 1
+    OW = (W + 2 * pad - dil * (ks - 1) - 1) // st + 1
+    args = (wp, OC, B * OH * OW, C * ks * ks, ks, st, pad, dil, OW)
+    monkeypatch.setenv("BIE_FP4_CONV_MIN_ROWS", "1")
+    y = binary_conv_cpp.forward(x.to(DEV), *args)
+    assert ("fp4taps", OC, C, ks) in wp._bie_memo
+    yb = binary_conv_cpp.forward(x.to(torch.bfloat16).to(DEV), *args)  # bf16 activations: the signs of the rounded values
+    monkeypatch.setenv("BIE_FP4_CONV_MIN_ROWS", "0")
+    y0 = binary_conv_cpp.forward(x.to(DEV), *args)
+    ref = orc.binary_conv2d(x.numpy(), w.numpy(), st, pad, dil)
+    assert y.shape == (B, OC, OH, OW) and torch.equal(y, y0)
+    assert np.array_equal(y.cpu().numpy(), ref)
+    assert np.array_equal(yb.cpu().numpy(), orc.binary_conv2d(x.to(torch.bfloat16).float().numpy(), w.numpy(), st, pad, dil))
