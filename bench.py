@@ -383,7 +383,7 @@ def bench_binary(dev, L):
                                   "frac": round(byts / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None} if M < 16 else
                                  {"bound": "valu xor+bcnt", "achieved": round(2.0 * M * K * N / us / 1e6, 1), "peak": XOR_POPC_PEAK_TOPS,
                                   "unit": "TOP/s", "frac": round(2.0 * M * K * N / us / 1e6 / XOR_POPC_PEAK_TOPS, 4), "traffic": None})})
-    for B in (1, 32):
+    for B in (1, 32, 128):  # B = 128 (6272 output pixels) takes the matrix-pipe form (FP4 GEMM over (pixel) x (tap, channel))
         x = torch.randn((B, 512, 7, 7), device=dev)
         w = torch.randn((512, 512, 3, 3), device=dev)
         from bitorch_engine.extensions._binary_common import pack_rows

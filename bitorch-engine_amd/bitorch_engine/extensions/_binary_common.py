@@ -175,9 +175,11 @@ def conv_weight_taps(wpacked, OC, C, ksize):
 
 
 def conv_fp4_min_rows() -> int:
-    """Smallest number of output pixels (B * OH * OW) the matrix-pipe form of the conv serves (BIE_FP4_CONV_MIN_ROWS; 0 = off)."""
+    """Smallest number of output pixels (B * OH * OW) the matrix-pipe form of the conv serves (BIE_FP4_CONV_MIN_ROWS; 0 = off).
+    Measured on the ResNet-18 stage shapes (profiles/r03_fp4_g_conv_ab.txt): from ~3000 pixels up it is never slower than the XNOR tap
+    form (1.0-2.4x); below, its three launches and the small GEMM grid lose to the tap kernels."""
     v = os.environ.get("BIE_FP4_CONV_MIN_ROWS")
-    return int(v) if v else 1024
+    return int(v) if v else 3072
 
 
 def conv_weight_fp4_image(wpacked, OC, C, ksize):
