@@ -18,13 +18,10 @@
 // wave per SIMD), K step 128 per LDS stage, 3 stages (loads run two stages ahead), ONE barrier per stage placed between the two
 // k64 halves of a stage so that the first fragment reads of the next stage are issued under the second half's 16 MFMAs
 // (three rotating fragment register sets).  LDS traffic: 8 ds_read_b128 per 16 MFMAs (512 cycles) per wave = 64 B/clk/CU.
-#include "bie_common.h"
+#include "mfma_pipe.cuh"
 #include <stdlib.h>
 
 namespace bie {
-
-typedef int v8i_t __attribute__((ext_vector_type(8)));
-typedef int v4i_t __attribute__((ext_vector_type(4)));
 
 static inline long fp4_row_blocks(long rows) { return (rows + 31) / 32; }
 static inline long fp4_k_tiles(long K) { return (K + 127) / 128; }
@@ -175,34 +172,6 @@ __global__ __launch_bounds__(256) void conv_fp4_image_kernel(const uint32_t* __r
     img[f * 64 + lane] = o;
 }
 
-// ---- LDS fragment reads (hand-issued: the compiler must not order them against the LDS-DMA by its own alias rules) ----
-template <int OFF>
-__device__ __forceinline__ v4i_t lds_read16(uint32_t addr) {
-    v4i_t r;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
-    return r;
-}
-template <int N, int BASE>
-__device__ __forceinline__ void read_frags(v4i_t (&f)[N], uint32_t addr) {
-    static_assert(N == 1 || N == 2 || N == 4, "1, 2 or 4 fragments");
-    f[0] = lds_read16<BASE>(addr);
-    if constexpr (N >= 2) f[1] = lds_read16<BASE + 2048>(addr);
-    if constexpr (N >= 4) {
-        f[2] = lds_read16<BASE + 4096>(addr);
-        f[3] = lds_read16<BASE + 6144>(addr);
-    }
-}
-// s_waitcnt lgkmcnt(CNT) tied to the fragment registers it makes valid
-template <int CNT, int NA, int NB>
-__device__ __forceinline__ void wait_frags(v4i_t (&a)[NA], v4i_t (&b)[NB]) {
-    if constexpr (NA == 4 && NB == 4)
-        asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(CNT) : "memory");
-    else if constexpr (NA == 2 && NB == 2)
-        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]) : "n"(CNT) : "memory");
-    else
-        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a[0]), "+v"(b[0]) : "n"(CNT) : "memory");
-}
-
 // The MFMA as inline asm, on purpose.  Issued through the builtin the MFMAs are pure values: hipcc first sank all 96 of a three-stage
 // loop body below the hand-issued reads, and a zero-instruction asm fence on the accumulator ("+a") that pins them makes the hazard
 // recogniser put an s_nop between consecutive MFMAs -- one extra issue state costs a lone in-order wave ~28 cycles per MFMA here
@@ -213,18 +182,6 @@ __device__ __forceinline__ void wait_frags(v4i_t (&a)[NA], v4i_t (&b)[NB]) {
 __device__ __forceinline__ void mfma_fp4(float16_t& c, const v4i_t& a, const v4i_t& b, int scale) {
     asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0] cbsz:4 blgp:4" : "+a"(c) : "v"(a), "v"(b), "v"(scale));
 }
-__device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }  // >= 18 wait states: XDL write -> VALU read
-
-constexpr int imin(int a, int b) { return a < b ? a : b; }
-template <int I> struct ic_t { static constexpr int value = I; };
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(ic_t<I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
 // VAR 0: fragment reads and LDS-DMA pieces BETWEEN the MFMAs (one item per MFMA shadow: a lone in-order wave per SIMD overlaps
 //        nothing it does not interleave), branch-free stage body (look-ahead clamped to the last K tile);
 // VAR 1: the same pipeline with reads / DMA issued in bursts between the two 16-MFMA clusters of a stage (kept for the A/B).

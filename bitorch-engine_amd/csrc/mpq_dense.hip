@@ -1,0 +1,284 @@
+// W{1,2,4,8}A16 GEMM for large M: dequantise ONCE per call, then a dense bf16 / fp16 MFMA GEMM on the hand-ordered pipeline of
+// mfma_pipe.cuh.  Replaces the same branch of the reference as mpq_gemm.hip -- "materialise the fp16 weight, then cuBLAS"
+// (layers/qlinear/nbit/cuda/mpq_layer.py:59-63, unpack_qweight utils.py:30-51) -- with the same arithmetic: the weight values are
+// produced by dequant8 (mpq_frag_dequant.cuh: the reference's two roundings), accumulated in fp32, one rounding at the store.
+//
+// Why a second form: the fused kernel (mpq_gemm.hip) dequantises every weight tile once per 256-row M tile, in registers, beside the
+// MFMAs -- 6 VALU per weight at the reference's roundings, and the VALU + LDS stream alone takes 60-67 % of its loop
+// (profiles/r03_t_gemm_ablations.txt).  At M >= 1024 a tile is dequantised 4-16 times.  Here the weights are
+// dequantised once into MFMA FRAGMENT ORDER (K*N*2 bytes of scratch, L2 / MALL resident while the GEMM runs): fragment (nb, ks) =
+// columns 32*nb .. +31 x k 16*ks .. +15, lane l owns the 8 values of column 32*nb + (l & 31), k 16*ks + 8*(l >> 5) .. +7 -- what
+// v_mfma_f32_32x32x16 takes from that lane -- so one global_load_lds_dwordx4 per wave moves a fragment into LDS, contiguous on both
+// sides, no swizzle.  x stays row-major: its LDS image is [rows][32 k] with the 16-byte slot index XORed by (row >> 2) & 3, realised on
+// the SOURCE side of the LDS-DMA (lane l fetches the chunk that belongs in slot l), so the fragment reads are conflict-free.
+// The loop is binary_fp4.hip's: 4 waves as 2 x 2, wave tile 32*WM x 32*WN, K = 32 per stage (the same 32 KiB / 32 MFMAs per wave as an
+// FP4 stage of K = 128), 3 stages, one barrier per stage between its two MFMA clusters, reads behind a cluster's first MFMAs, refill
+// pieces behind the rest, MFMAs as ordered inline asm.
+#include "mpq_frag_dequant.cuh"
+#include "mfma_pipe.cuh"
+#include <stdlib.h>
+
+#pragma clang fp contract(off)
+
+namespace bie {
+
+// ---- pass 1: packed weights -> dequantised fragments -------------------------------------------------------------
+template <int DT, int WBIT, int ZM>
+__global__ __launch_bounds__(256) void mpq_dequant_frag_kernel(const uint32_t* __restrict__ qw, const uint16_t* __restrict__ scales, const void* __restrict__ zeros,
+                                                               uint4_t* __restrict__ img, int N, int gshift, long nfrag, int ks_per_col) {
+    const long f = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (f >= nfrag) return;
+    const int lane = threadIdx.x & 63;
+    const long nb = f / ks_per_col;
+    const int ks = (int)(f - nb * ks_per_col);
+    int n = (int)nb * 32 + (lane & 31);
+    if (n > N - 1) n = N - 1;  // columns past N: valid values nobody stores
+    const int c8 = ks * 2 + (lane >> 5);
+    const long g = (long)(c8 * 8) >> gshift;
+    const uint2_t raw = load_chunk<WBIT>(qw, c8, n, N);
+    const uint32_t sb = scales[g * N + n];
+    uint32_t zb;
+    if constexpr (ZM == ZM_ASYM) {
+        constexpr int NB = 32 / WBIT;
+        constexpr uint32_t M1 = (1u << WBIT) - 1u;
+        const uint32_t word = reinterpret_cast<const uint32_t*>(zeros)[g * (N / NB) + n / NB];
+        zb = ((word >> ((n % NB) * WBIT)) & M1) + 1u;
+    } else {
+        zb = reinterpret_cast<const uint16_t*>(zeros)[g * N + n];
+    }
+    img[f * 64 + lane] = dequant8<DT, WBIT, ZM>(raw, c8, make_col_params<DT, WBIT, ZM, (WBIT == 4)>(sb, zb));
+}
+
+// ---- pass 2: dense GEMM ----------------------------------------------------------------------------------------------
+template <int DT>
+__device__ __forceinline__ void mfma16(float16_t& c, const v4i_t& a, const v4i_t& b) {
+    if constexpr (DT == BIE_F16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+
+template <int DT, int WM, int WN>
+__global__ __launch_bounds__(256) void mpq_dense_gemm_kernel(const uint16_t* __restrict__ x, const uint8_t* __restrict__ wimg, const uint16_t* __restrict__ bias,
+                                                             uint16_t* __restrict__ y, int M, int N, int K, int tiles_n, int NB32) {
+    constexpr int AF = 2 * WM, BF = 2 * WN;  // 32-row / 32-column blocks per workgroup tile
+    constexpr int NFR = (AF + BF) * 2;       // KiB per stage (k = 32): x rows 64 bytes each, weight fragments 1 KiB per k16 step
+    constexpr int PW = NFR / 4;              // LDS-DMA pieces per wave and stage
+    constexpr int STAGE = NFR * 1024;
+    constexpr int NR = WM + WN, NM = WM * WN;
+    constexpr int RPM = (2 * NR + NM - 1) / NM, M0 = (NR + RPM - 1) / RPM, DPM = (PW + (NM - M0) - 1) / (NM - M0);
+    static_assert((AF * 2) % PW == 0, "a wave's pieces are all x pieces or all weight pieces");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[3 * STAGE];
+
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wy = wave >> 1, wx = wave & 1;
+    int bid = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);  // one contiguous run of tiles per XCD
+    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+    const int KT = K >> 5, KS = K >> 4;
+
+    // this wave's LDS-DMA sources.  Stage image: [x: AF*2 pieces of 16 rows x 64 bytes][weights: BF*2 fragments (column block, k16 step)]
+    const bool x_wave = wave * PW < AF * 2;
+    [[maybe_unused]] const long step = x_wave ? 64 : 2048;  // bytes per stage: 32 k of a row / two fragments
+    const uint8_t* src[PW];
+#pragma unroll
+    for (int j = 0; j < PW; j++) {
+        const int p = wave * PW + j;
+        if (x_wave) {
+            const int rt = p * 16 + (lane >> 2);  // row of the tile; LDS slot lane & 3 holds logical slot (lane & 3) ^ ((rt >> 2) & 3)
+            long m = (long)tile_m * (AF * 32) + rt;
+            if (m > M - 1) m = M - 1;
+            src[j] = reinterpret_cast<const uint8_t*>(x) + (m * K) * 2 + (((lane & 3) ^ ((rt >> 2) & 3)) << 4);
+        } else {
+            const int q = p - AF * 2;
+            long nb = (long)tile_n * BF + (q >> 1);
+            if (nb > NB32 - 1) nb = NB32 - 1;
+            src[j] = wimg + ((nb * KS + (q & 1)) * 64 + lane) * 16;
+        }
+    }
+    [[maybe_unused]] const int kt_last = KT - 1;
+    auto issue_piece = [&](int kt, int j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int ks = kt < kt_last ? kt : kt_last;  // a look-ahead past the end re-fetches the last tile into a buffer nobody reads again
+        auto* dst = (__attribute__((address_space(3))) unsigned char*)lds + (kt % 3) * STAGE + wave * (PW * 1024);
+        __builtin_amdgcn_global_load_lds(src[j] + ks * step, dst + j * 1024, 16, 0, 0);
+#endif
+    };
+
+    const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
+    const int rl = lane & 31, hh = lane >> 5, sw = (rl >> 2) & 3;
+    uint32_t a_addr[2];  // x fragment of k16 step s: row rl of the wave's first block, logical slot 2*s + hh
+    a_addr[0] = lds_base + (uint32_t)((wy * WM * 32 + rl) * 64 + ((hh ^ sw) << 4));
+    a_addr[1] = lds_base + (uint32_t)((wy * WM * 32 + rl) * 64 + (((2 + hh) ^ sw) << 4));
+    const uint32_t b_addr = lds_base + AF * 2048 + (wx * WN * 2) * 1024 + lane * 16;
+
+    float16_t acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; i++)
+#pragma unroll
+        for (int j = 0; j < WN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+    v4i_t XA[WM], XB[WN], YA[WM], YB[WN], ZA[WM], ZB[WN];
+    // fragment read R (0 .. NR-1) of k16 step H of the stage at byte offset so: the first WM are x row blocks (2 KiB apart)
+    auto read_item = [&](auto ic, auto hc, uint32_t so, v4i_t (&TA)[WM], v4i_t (&TB)[WN]) {
+        constexpr int R = decltype(ic)::value, H = decltype(hc)::value;
+        if constexpr (R < WM) TA[R] = lds_read16<R * 2048>(a_addr[H] + so);
+        else TB[R - WM] = lds_read16<(R - WM) * 2048 + H * 1024>(b_addr + so);
+    };
+
+#pragma unroll
+    for (int s = 0; s < 3; s++)
+#pragma unroll
+        for (int j = 0; j < PW; j++) issue_piece(s, j);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW) : "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, NR>([&](auto rc) { read_item(rc, ic_t<0>{}, 0u, XA, XB); });
+
+    auto stage = [&](int kt, v4i_t (&PA)[WM], v4i_t (&PB)[WN], v4i_t (&QA)[WM], v4i_t (&QB)[WN], v4i_t (&NA)[WM], v4i_t (&NB)[WN]) {
+        const uint32_t so = (uint32_t)(kt % 3) * STAGE, sn = (uint32_t)((kt + 1) % 3) * STAGE;
+        wait_frags<0>(PA, PB);
+        static_for<0, NM>([&](auto mc) {
+            constexpr int m = decltype(mc)::value, i = m / WN, j = m % WN;
+            mfma16<DT>(acc[i][j], PB[j], PA[i]);  // D = w_frag (rows = output features) x x_frag (columns = rows of x)
+            static_for<imin(m * RPM, NR), imin((m + 1) * RPM, NR)>([&](auto rc) { read_item(rc, ic_t<1>{}, so, QA, QB); });
+        });
+        wait_frags<0>(QA, QB);  // every LDS read of this stage has returned: its buffer may be refilled behind the barrier
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");  // K tile kt+1 landed (kt+2 still in flight)
+        __builtin_amdgcn_s_barrier();
+        static_for<0, NM>([&](auto mc) {
+            constexpr int m = decltype(mc)::value, i = m / WN, j = m % WN;
+            mfma16<DT>(acc[i][j], QB[j], QA[i]);
+            static_for<imin(m * RPM, NR), imin((m + 1) * RPM, NR)>([&](auto rc) { read_item(rc, ic_t<0>{}, sn, NA, NB); });
+            if constexpr (m >= M0)
+                static_for<imin((m - M0) * DPM, PW), imin((m - M0 + 1) * DPM, PW)>([&](auto pc) { issue_piece(kt + 3, decltype(pc)::value); });
+        });
+    };
+    int kt = 0;
+    for (; kt + 3 <= KT; kt += 3) {
+        stage(kt, XA, XB, YA, YB, ZA, ZB);
+        stage(kt + 1, ZA, ZB, XA, XB, YA, YB);
+        stage(kt + 2, YA, YB, ZA, ZB, XA, XB);
+    }
+    if (kt < KT) {
+        stage(kt, XA, XB, YA, YB, ZA, ZB);
+        if (kt + 1 < KT) stage(kt + 1, ZA, ZB, XA, XB, YA, YB);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the clamped look-ahead pieces / reads must not outlive the workgroup's LDS
+    mfma_drain();
+
+    // C/D layout: column = lane & 31 = row m of x, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) = output feature inside the 32-block.
+    // y = dt(dt(acc) + bias) as mpq_gemm.hip; the half-waves trade packed quads (v_permlane32_swap_b32) so that a lane stores 8
+    // consecutive features of its row: 16 bytes.
+    const bool vec_ok = (N & 7) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+    auto pack2 = [&](float lo, float hi) -> uint32_t {
+        if constexpr (DT == BIE_BF16) return pack_bf16x2(lo, hi);
+        else return f32_to_f16_bits(lo) | (f32_to_f16_bits(hi) << 16);
+    };
+    const bool has_bias = bias != nullptr;
+    const uint16_t* bsrc = has_bias ? bias : y;  // a valid address for the (discarded) loads of the no-bias case
+#pragma unroll
+    for (int i = 0; i < WM; i++) {
+        const int m = (tile_m * AF + wy * WM + i) * 32 + rl;
+        uint16_t* yr = y + (long)(m < M ? m : 0) * N;
+#pragma unroll
+        for (int j = 0; j < WN; j++) {
+            const int nb = (tile_n * BF + wx * WN + j) * 32;
+#pragma unroll
+            for (int qp = 0; qp < 2; qp++) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int n = nb + 8 * (2 * qp + (e >> 2)) + 4 * hh + (e & 3);
+                    const float r = dt_traits<DT>::round(acc[i][j][8 * qp + e]);
+                    const float rb = r + dt_traits<DT>::load(bsrc, has_bias ? (n < N ? n : N - 1) : 0);  // branch-free: clamped load + select
+                    v[e] = has_bias ? rb : r;
+                }
+                if (vec_ok) {
+                    const uint32_t p0 = pack2(v[0], v[1]), p1 = pack2(v[2], v[3]), p2 = pack2(v[4], v[5]), p3 = pack2(v[6], v[7]);
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(p0, p2, false, false);  // first operand's upper half <-> second's lower half
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(p1, p3, false, false);
+                    const int n = nb + 8 * (2 * qp + hh);
+                    if (m < M && n < N) *reinterpret_cast<uint4_t*>(yr + n) = uint4_t{s0[0], s1[0], s0[1], s1[1]};
+                } else if (m < M) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const int n = nb + 8 * (2 * qp + (e >> 2)) + 4 * hh + (e & 3);
+                        if (n < N) dt_traits<DT>::store(yr, n, v[e]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- launch plumbing ---------------------------------------------------------------------------------------------------
+static int env_int_dense(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+// Depends on (M, K, N) and the process environment only: bie_mpq_workspace_bytes has to reproduce the choice.
+bool mpq_dense_ok(int M, int K, int N) {
+    static const bool tuning = getenv("BIE_TUNING") != nullptr;
+    static const int on_once = env_int_dense("BIE_GEMM_DENSE", 1), min_once = env_int_dense("BIE_GEMM_DENSE_MIN_M", 1024);
+    const int on = tuning ? env_int_dense("BIE_GEMM_DENSE", 1) : on_once, min_m = tuning ? env_int_dense("BIE_GEMM_DENSE_MIN_M", 1024) : min_once;
+    if (!on || (K & 31) || (N & 7)) return false;
+    if (on == 2) return true;  // forced (tests: every shape the kernels can take)
+    return M >= min_m && (long)cdiv(M, 128) * cdiv(N, 128) >= 192;  // enough 128 x 128 tiles to fill the chip without a K split
+}
+
+size_t mpq_dense_workspace_bytes(int K, int N) { return (size_t)cdiv(N, 32) * 32 * K * 2; }
+
+template <int DT, int ZM>
+static void dequant_frag_launch(const int32_t* qw, const void* scales, const void* zeros, void* img, int K, int N, int w_bit, int gshift, hipStream_t st) {
+    const int KS = K / 16;
+    const long nfrag = (long)cdiv(N, 32) * KS;
+    const dim3 grid((unsigned)cdivl(nfrag, 4));
+#define BIE_DQ(WB) hipLaunchKernelGGL((mpq_dequant_frag_kernel<DT, WB, ZM>), grid, dim3(256), 0, st, (const uint32_t*)qw, (const uint16_t*)scales, zeros, (uint4_t*)img, N, gshift, nfrag, KS)
+    switch (w_bit) {
+        case 1: BIE_DQ(1); break;
+        case 2: BIE_DQ(2); break;
+        case 4: BIE_DQ(4); break;
+        default: BIE_DQ(8); break;
+    }
+#undef BIE_DQ
+}
+
+template <int DT>
+static void dense_gemm_launch(const void* x, const void* img, const void* bias, void* y, int M, int K, int N, hipStream_t st) {
+    const int NB32 = cdiv(N, 32);
+    const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
+    static const int tile_once = env_int_dense("BIE_GEMM_DENSE_TILE", 0);
+    const int tile = getenv("BIE_TUNING") ? env_int_dense("BIE_GEMM_DENSE_TILE", 0) : tile_once;
+    if (tile == 256 || (tile != 128 && t256 >= 192)) {
+        const int tn = cdiv(N, 256);
+        hipLaunchKernelGGL((mpq_dense_gemm_kernel<DT, 4, 4>), dim3((unsigned)t256), dim3(256), 0, st, (const uint16_t*)x, (const uint8_t*)img, (const uint16_t*)bias,
+                           (uint16_t*)y, M, N, K, tn, NB32);
+    } else {
+        const int tn = cdiv(N, 128);
+        hipLaunchKernelGGL((mpq_dense_gemm_kernel<DT, 2, 2>), dim3((unsigned)(cdiv(M, 128) * tn)), dim3(256), 0, st, (const uint16_t*)x, (const uint8_t*)img,
+                           (const uint16_t*)bias, (uint16_t*)y, M, N, K, tn, NB32);
+    }
+}
+
+// scratch: mpq_dense_workspace_bytes(K, N) bytes, 16-byte aligned
+int mpq_dense_launch(const void* x, const int32_t* qw, const void* scales, const void* zeros, const void* bias, void* y, void* scratch, int M, int K, int N,
+                     int w_bit, int gshift, int zm, int dtype, hipStream_t st) {
+    if (dtype == BIE_F16) {
+        if (zm == ZM_ASYM) dequant_frag_launch<BIE_F16, ZM_ASYM>(qw, scales, zeros, scratch, K, N, w_bit, gshift, st);
+        else if (zm == ZM_FUSED) dequant_frag_launch<BIE_F16, ZM_FUSED>(qw, scales, zeros, scratch, K, N, w_bit, gshift, st);
+        else dequant_frag_launch<BIE_F16, ZM_SYM>(qw, scales, zeros, scratch, K, N, w_bit, gshift, st);
+    } else {
+        if (zm == ZM_ASYM) dequant_frag_launch<BIE_BF16, ZM_ASYM>(qw, scales, zeros, scratch, K, N, w_bit, gshift, st);
+        else dequant_frag_launch<BIE_BF16, ZM_SYM>(qw, scales, zeros, scratch, K, N, w_bit, gshift, st);
+    }
+    int rc = check_launch("mpq_dequant_frag_kernel");
+    if (rc) return rc;
+    if (dtype == BIE_F16) dense_gemm_launch<BIE_F16>(x, scratch, bias, y, M, K, N, st);
+    else dense_gemm_launch<BIE_BF16>(x, scratch, bias, y, M, K, N, st);
+    return check_launch("mpq_dense_gemm_kernel");
+}
+
+}  // namespace bie

@@ -158,6 +158,29 @@ def test_mfma_gemm_every_tile_height_and_split(bm, S, monkeypatch):
             assert_close(y, ref, dt, f"BM={bm} S={S} dt={dt} asym={asym}")
 
 
+@pytest.mark.parametrize("tile", ["128", "256"])
+@pytest.mark.parametrize("dt,w_bit,asym", CASES)
+def test_dense_form_of_the_gemm_every_flavour(dt, w_bit, asym, tile, monkeypatch):
+    """mpq_dense.hip (dequantise once into MFMA fragment order + dense GEMM; the default for M >= 1024 on grids that fill the chip), forced
+    onto small ragged shapes: every bit width, sym / asym, both dtypes, both tile sizes, clamped rows and column blocks, bias, K tiles
+    1 / 2 / 34 (pipeline prologue and tail), group sizes below and above a stage."""
+    monkeypatch.setenv("BIE_TUNING", "1")
+    monkeypatch.setenv("BIE_GEMM_DENSE", "2")
+    monkeypatch.setenv("BIE_GEMM_DENSE_TILE", tile)
+    for (M, K, N, gs) in ((300, 1088, 520, 64), (33, 64, 264, 32), (130, 128, 72, 128)):
+        rng = np.random.default_rng(M + K + N + 31 * w_bit + asym + dt)
+        qw, scales, zeros, gen = rand_case(rng, K, N, w_bit, gs, dt, asym)
+        x = torch.randn((M, K), generator=gen).to(TDT[dt])
+        bias = torch.randn((N,), generator=gen).to(TDT[dt]) if M == 300 else None
+        y = hip_forward(x, qw, scales, zeros, None, w_bit, gs, asym, bias)
+        ref = oracle_forward(x, qw, scales, zeros, None, w_bit, gs, asym, dt, bias)
+        assert_close(y, ref, dt, f"dense dt={dt} w{w_bit} asym={asym} tile={tile} M={M} K={K} N={N}")
+        monkeypatch.setenv("BIE_GEMM_DENSE", "0")
+        y0 = hip_forward(x, qw, scales, zeros, None, w_bit, gs, asym, bias)  # the fused kernel on the same operands: same weights, fp32 sums
+        monkeypatch.setenv("BIE_GEMM_DENSE", "2")
+        assert_close(y, y0, dt, "dense vs fused")
+
+
 @pytest.mark.parametrize("K,N,gs,M", [(128, 64, 32, 1), (256, 260, 64, 4), (4096, 128, 128, 1), (1024, 2048, 1024, 2),
                                       (192, 132, 64, 16), (4096, 512, 32, 48), (2048, 1000, 128, 130), (64, 32, 64, 5)])
 @pytest.mark.parametrize("dt", [orc.F16, orc.BF16])
