@@ -176,40 +176,59 @@ __global__ __launch_bounds__(256) void mpq_dense_gemm_kernel(const uint16_t* __r
         if constexpr (DT == BIE_BF16) return pack_bf16x2(lo, hi);
         else return f32_to_f16_bits(lo) | (f32_to_f16_bits(hi) << 16);
     };
-    const bool has_bias = bias != nullptr;
-    const uint16_t* bsrc = has_bias ? bias : y;  // a valid address for the (discarded) loads of the no-bias case
-#pragma unroll
-    for (int i = 0; i < WM; i++) {
+    // Two lean paths (the branch is wave-uniform): without bias a value is rounded once, by the pack itself (v_cvt_pk: one VALU per
+    // two values); with bias the eight bias values of a (column block, register group) are loaded once and serve all WM row blocks.
+    // (The first form -- per value a clamped bias load, two roundings and a select -- was 9000 instructions per wave: ~11 us of fixed
+    // cost per launch, profiles/r03_dense_k_slope.txt.)
+    auto store8 = [&](int i, int j, int qp, const float (&v)[8]) {
         const int m = (tile_m * AF + wy * WM + i) * 32 + rl;
+        const int nb = (tile_n * BF + wx * WN + j) * 32;
         uint16_t* yr = y + (long)(m < M ? m : 0) * N;
+        if (vec_ok) {
+            const uint32_t p0 = pack2(v[0], v[1]), p1 = pack2(v[2], v[3]), p2 = pack2(v[4], v[5]), p3 = pack2(v[6], v[7]);
+            const auto s0 = __builtin_amdgcn_permlane32_swap(p0, p2, false, false);  // first operand's upper half <-> second's lower half
+            const auto s1 = __builtin_amdgcn_permlane32_swap(p1, p3, false, false);
+            const int n = nb + 8 * (2 * qp + hh);
+            if (m < M && n < N) *reinterpret_cast<uint4_t*>(yr + n) = uint4_t{s0[0], s1[0], s0[1], s1[1]};
+        } else if (m < M) {
 #pragma unroll
-        for (int j = 0; j < WN; j++) {
-            const int nb = (tile_n * BF + wx * WN + j) * 32;
-#pragma unroll
-            for (int qp = 0; qp < 2; qp++) {
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    const int n = nb + 8 * (2 * qp + (e >> 2)) + 4 * hh + (e & 3);
-                    const float r = dt_traits<DT>::round(acc[i][j][8 * qp + e]);
-                    const float rb = r + dt_traits<DT>::load(bsrc, has_bias ? (n < N ? n : N - 1) : 0);  // branch-free: clamped load + select
-                    v[e] = has_bias ? rb : r;
-                }
-                if (vec_ok) {
-                    const uint32_t p0 = pack2(v[0], v[1]), p1 = pack2(v[2], v[3]), p2 = pack2(v[4], v[5]), p3 = pack2(v[6], v[7]);
-                    const auto s0 = __builtin_amdgcn_permlane32_swap(p0, p2, false, false);  // first operand's upper half <-> second's lower half
-                    const auto s1 = __builtin_amdgcn_permlane32_swap(p1, p3, false, false);
-                    const int n = nb + 8 * (2 * qp + hh);
-                    if (m < M && n < N) *reinterpret_cast<uint4_t*>(yr + n) = uint4_t{s0[0], s1[0], s0[1], s1[1]};
-                } else if (m < M) {
-#pragma unroll
-                    for (int e = 0; e < 8; e++) {
-                        const int n = nb + 8 * (2 * qp + (e >> 2)) + 4 * hh + (e & 3);
-                        if (n < N) dt_traits<DT>::store(yr, n, v[e]);
-                    }
-                }
+            for (int e = 0; e < 8; e++) {
+                const int n = nb + 8 * (2 * qp + (e >> 2)) + 4 * hh + (e & 3);
+                if (n < N) dt_traits<DT>::store(yr, n, v[e]);
             }
         }
+    };
+    if (bias == nullptr) {
+#pragma unroll
+        for (int i = 0; i < WM; i++)
+#pragma unroll
+            for (int j = 0; j < WN; j++)
+#pragma unroll
+                for (int qp = 0; qp < 2; qp++) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) v[e] = acc[i][j][8 * qp + e];
+                    store8(i, j, qp, v);
+                }
+    } else {
+#pragma unroll
+        for (int j = 0; j < WN; j++)
+#pragma unroll
+            for (int qp = 0; qp < 2; qp++) {
+                float bv[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int n = (tile_n * BF + wx * WN + j) * 32 + 8 * (2 * qp + (e >> 2)) + 4 * hh + (e & 3);
+                    bv[e] = dt_traits<DT>::load(bias, n < N ? n : N - 1);
+                }
+#pragma unroll
+                for (int i = 0; i < WM; i++) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) v[e] = dt_traits<DT>::round(acc[i][j][8 * qp + e]) + bv[e];  // dt(dt(acc) + bias), as mpq_gemm.hip
+                    store8(i, j, qp, v);
+                }
+            }
     }
 }
 
@@ -219,6 +238,13 @@ static int env_int_dense(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
+// When: measured against the fused kernel on one box (profiles/r03_dense_ab.txt, r03_dense_k_slope.txt), both forms run the same
+// 0.93 us per 32 MFMAs per wave with every CU busy (0.62 is the bare bf16 MFMA stream at that load's clock: moving a stage's 32 KiB
+// into LDS and 64 KiB out of it costs the same 0.3 us whether the weights arrive dequantised or are dequantised beside the MFMAs).
+// What differs is per launch: this form pays a dequantise pass (K*N*(w/8 + 2) bytes) but only ~16 us of prologue + epilogue per
+// round of tiles and no K split, the fused one ~30 us.  So it wins when K is short and the tile grid is whole rounds of the 256 CUs
+// (4096x4096: 48 vs 63 us at M = 1024, 91 vs 111 at 2048, 136 vs 148 at 4096) and loses otherwise (4096x11008 M = 1024: 150 vs 126;
+// K = 11008 and K = 16384: equal or slower) -- the rule below.  BIE_GEMM_DENSE=0 switches it off, =2 forces it (tests).
 // Depends on (M, K, N) and the process environment only: bie_mpq_workspace_bytes has to reproduce the choice.
 bool mpq_dense_ok(int M, int K, int N) {
     static const bool tuning = getenv("BIE_TUNING") != nullptr;
@@ -226,7 +252,9 @@ bool mpq_dense_ok(int M, int K, int N) {
     const int on = tuning ? env_int_dense("BIE_GEMM_DENSE", 1) : on_once, min_m = tuning ? env_int_dense("BIE_GEMM_DENSE_MIN_M", 1024) : min_once;
     if (!on || (K & 31) || (N & 7)) return false;
     if (on == 2) return true;  // forced (tests: every shape the kernels can take)
-    return M >= min_m && (long)cdiv(M, 128) * cdiv(N, 128) >= 192;  // enough 128 x 128 tiles to fill the chip without a K split
+    const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
+    const long grid = t256 >= 192 ? t256 : (long)cdiv(M, 128) * cdiv(N, 128);  // the grid dense_gemm_launch will use
+    return M >= min_m && K <= 4096 && grid >= 256 && grid % 256 == 0;
 }
 
 size_t mpq_dense_workspace_bytes(int K, int N) { return (size_t)cdiv(N, 32) * 32 * K * 2; }

@@ -161,13 +161,13 @@ def test_mfma_gemm_every_tile_height_and_split(bm, S, monkeypatch):
 @pytest.mark.parametrize("tile", ["128", "256"])
 @pytest.mark.parametrize("dt,w_bit,asym", CASES)
 def test_dense_form_of_the_gemm_every_flavour(dt, w_bit, asym, tile, monkeypatch):
-    """mpq_dense.hip (dequantise once into MFMA fragment order + dense GEMM; the default for M >= 1024 on grids that fill the chip), forced
+    """mpq_dense.hip (dequantise once into MFMA fragment order + dense GEMM; opt-in with BIE_GEMM_DENSE=1, see the file header), forced
     onto small ragged shapes: every bit width, sym / asym, both dtypes, both tile sizes, clamped rows and column blocks, bias, K tiles
     1 / 2 / 34 (pipeline prologue and tail), group sizes below and above a stage."""
     monkeypatch.setenv("BIE_TUNING", "1")
     monkeypatch.setenv("BIE_GEMM_DENSE", "2")
     monkeypatch.setenv("BIE_GEMM_DENSE_TILE", tile)
-    for (M, K, N, gs) in ((300, 1088, 520, 64), (33, 64, 264, 32), (130, 128, 72, 128)):
+    for (M, K, N, gs) in ((300, 1088, 544, 64), (33, 64, 288, 32), (130, 128, 96, 128)):
         rng = np.random.default_rng(M + K + N + 31 * w_bit + asym + dt)
         qw, scales, zeros, gen = rand_case(rng, K, N, w_bit, gs, dt, asym)
         x = torch.randn((M, K), generator=gen).to(TDT[dt])

@@ -41,6 +41,24 @@ __global__ __launch_bounds__(THREADS) void k16(const int* in, float* out, unsign
     out[blockIdx.x * THREADS + threadIdx.x] = s;
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
+typedef short v8s __attribute__((ext_vector_type(8)));
+template <int NACC, int THREADS>
+__global__ __launch_bounds__(THREADS) void kbf(const int* in, float* out, unsigned long long* cyc, int iters) {
+    v8s a, b;
+    for (int i = 0; i < 8; i++) { a[i] = (short)(0x3f80 ^ (in[threadIdx.x + 64 * i] & 0x807f)); b[i] = (short)(0x3f80 ^ (in[threadIdx.x + 64 * i + 7] & 0x807f)); }
+    v16f acc[NACC];
+    for (int n = 0; n < NACC; n++) for (int r = 0; r < 16; r++) acc[n][r] = 0.f;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int n = 0; n < NACC; n++) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[n], 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+    for (int n = 0; n < NACC; n++) for (int r = 0; r < 16; r++) s += acc[n][r];
+    out[blockIdx.x * THREADS + threadIdx.x] = s;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
 template <class K>
 static void run(const char* name, K kern, int threads, int blocks, int nacc, double flop_per_mfma, const int* in, float* out, unsigned long long* cyc) {
     const int iters = 2000;
@@ -69,6 +87,7 @@ int main() {
         run("32x32x64 fp4,  4 acc, 1 wave/SIMD", k32<4, 4, 256>, 256, blocks, 4, F32, in, out, cyc);
         run("32x32x64 fp4,  4 acc, 2 waves/SIMD", k32<4, 4, 512>, 512, blocks, 4, F32, in, out, cyc);
         run("32x32x64 fp4,  4 acc, 4 waves/SIMD", k32<4, 4, 1024>, 1024, blocks, 4, F32, in, out, cyc);
+        run("32x32x16 bf16 (random +-[1,2) values), 16 acc, 1 wave/SIMD", kbf<16, 256>, 256, blocks, 16, 2.0 * 32 * 32 * 16, in, out, cyc);
         run("32x32x64 fp8 (e4m3), 16 acc, 1 wave/SIMD", k32<16, 0, 256>, 256, blocks, 16, F32, in, out, cyc);
         run("16x16x128 fp4, 16 acc, 1 wave/SIMD", k16<16, 4, 256>, 256, blocks, 16, F16, in, out, cyc);
         run("16x16x128 fp4, 16 acc, 2 waves/SIMD", k16<16, 4, 512>, 512, blocks, 16, F16, in, out, cyc);
