@@ -115,8 +115,10 @@ def pmc_gemm():
     another mpq_gemm.hip."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_gemm.json")))
-        sha = hashlib.sha256(open(os.path.join(ROOT, "bitorch-engine_amd", "csrc", "mpq_gemm.hip"), "rb").read()).hexdigest()[:16]
-        if d.get("gemm_source_sha") != sha:
+        h = hashlib.sha256()
+        for f in ("mpq_gemm.hip", "mpq_frag_dequant.cuh"):  # the fused kernel's sources (tools/pmc_gemm_json.py stamps the same hash)
+            h.update(open(os.path.join(ROOT, "bitorch-engine_amd", "csrc", f), "rb").read())
+        if d.get("gemm_source_sha") != h.hexdigest()[:16]:
             return None
         b = d["bf16"]
         return {"shape": d["shape"], "mfma_pipe_utilisation": b["mfma_pipe_utilisation"], "valu_per_mfma": b["instructions"]["valu_per_mfma"],
@@ -505,6 +507,7 @@ def cpu_baselines(budget_s=24.0):
 
 
 def main():
+    os.environ.setdefault("BIE_TUNING", "1")  # GEMM plan knobs re-read per launch (one getenv each; the timed regions are captured graphs)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -605,8 +608,23 @@ def main():
         # ---- compute-bound half on the metric's layer (first-class: its own event-timed region)
         guarded("gemm", lambda: B.gemm(4096, 4096, 4096, 24, 3, 7))
         if "roofline" in out.get("gemm", {}):
-            out["roofline_gemm"] = dict(out["gemm"]["roofline"], kernel="bie::mpq_gemm_kernel<bf16,w4,256x256x64 tile>", us_per_launch=out["gemm"]["us_per_launch"],
+            out["roofline_gemm"] = dict(out["gemm"]["roofline"], kernel=("bie::mpq_dequant_frag_kernel + bie::mpq_dense_gemm_kernel<bf16,256x256 tile> (dequantise once into MFMA fragment order, dense GEMM; both launches timed)"
+                                                if os.environ.get("BIE_GEMM_DENSE", "1") != "0" else "bie::mpq_gemm_kernel<bf16,w4,256x256x64 tile>"), us_per_launch=out["gemm"]["us_per_launch"],
                                         pmc=pmc_gemm())
+        # the fused form (dequantisation beside the MFMAs) on the same layers, same box: the A/B behind the dense form's dispatch rule
+        def fused_gemm():
+            old = {k: os.environ.get(k) for k in ("BIE_TUNING", "BIE_GEMM_DENSE")}
+            os.environ["BIE_TUNING"], os.environ["BIE_GEMM_DENSE"] = "1", "0"  # BIE_TUNING: the knob is re-read per launch
+            try:
+                return dict(B.gemm(4096, 4096, 4096, 24, 3, 7), kernel="bie::mpq_gemm_kernel<bf16,w4,256x256x64 tile> (BIE_GEMM_DENSE=0)")
+            finally:
+                for k, v in old.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+        if os.environ.get("BIE_TUNING"):
+            guarded("gemm_fused_form_4096x4096", fused_gemm)
         # ---- the same pass as per-layer launches (round 2's headline form), as 4 launches of 24 layers, and as dependent chains
         guarded("per_layer_launches_4096x4096", lambda: B.gemv(4096, 4096, 96, 10, 1))
         guarded("list_4x24_4096x4096", lambda: B.gemv_list(4096, 4096, 96, 24, 10, 2))
