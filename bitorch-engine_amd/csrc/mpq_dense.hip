@@ -243,8 +243,8 @@ static int env_int_dense(const char* name, int dflt) {
 // into LDS and 64 KiB out of it costs the same 0.3 us whether the weights arrive dequantised or are dequantised beside the MFMAs).
 // What differs is per launch: this form pays a dequantise pass (K*N*(w/8 + 2) bytes) but only ~16 us of prologue + epilogue per
 // round of tiles and no K split, the fused one ~30 us.  So it wins when K is short and the tile grid is whole rounds of the 256 CUs
-// (4096x4096: 48 vs 63 us at M = 1024, 91 vs 111 at 2048, 136 vs 148 at 4096) and loses otherwise (4096x11008 M = 1024: 150 vs 126;
-// K = 11008 and K = 16384: equal or slower) -- the rule below.  BIE_GEMM_DENSE=0 switches it off, =2 forces it (tests).
+// (4096x4096: 57 vs 61 us at M = 1024, 96 vs 102 at 2048, 124 vs 137 at 4096, 279 vs 301 at 8192) and loses otherwise (4096x11008
+// M = 1024: 150 vs 120; K = 8192 .. 16384: equal or slower) -- the rule below.  BIE_GEMM_DENSE=0 switches it off, =2 forces it (tests).
 // Depends on (M, K, N) and the process environment only: bie_mpq_workspace_bytes has to reproduce the choice.
 bool mpq_dense_ok(int M, int K, int N) {
     static const bool tuning = getenv("BIE_TUNING") != nullptr;
@@ -252,9 +252,14 @@ bool mpq_dense_ok(int M, int K, int N) {
     const int on = tuning ? env_int_dense("BIE_GEMM_DENSE", 1) : on_once, min_m = tuning ? env_int_dense("BIE_GEMM_DENSE_MIN_M", 1024) : min_once;
     if (!on || (K & 31) || (N & 7)) return false;
     if (on == 2) return true;  // forced (tests: every shape the kernels can take)
+    // profiles/r03_dense_ab2.txt (dense / fused time, 7 layer shapes x M = 512 .. 8192): with 256 x 256 tiles (>= 192 of them) the dense
+    // form is 0.90-0.98 of the fused time up to K = 5120 and 1.0-1.1 beyond (the dequantise pass grows with K*N, the GEMM does not gain);
+    // with 128 x 128 tiles it wins only on whole rounds of short-K square layers (0.93-0.94) and loses 1.1-1.7x elsewhere.
     const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
-    const long grid = t256 >= 192 ? t256 : (long)cdiv(M, 128) * cdiv(N, 128);  // the grid dense_gemm_launch will use
-    return M >= min_m && K <= 4096 && grid >= 256 && grid % 256 == 0;
+    if (M < min_m) return false;
+    if (t256 >= 192) return K <= 5120;  // the grid dense_gemm_launch will use: 256 x 256 tiles
+    const long g128 = (long)cdiv(M, 128) * cdiv(N, 128);
+    return K <= 4096 && g128 >= 256 && g128 % 256 == 0;
 }
 
 size_t mpq_dense_workspace_bytes(int K, int N) { return (size_t)cdiv(N, 32) * 32 * K * 2; }
