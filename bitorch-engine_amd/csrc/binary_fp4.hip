@@ -402,16 +402,25 @@ __global__ __launch_bounds__(256) void xnor_fp4_gemm_kernel(const uint8_t* __res
         // one 16-byte store (32 per lane)
         uint16_t* y = (uint16_t*)yv;
         const float sa = scale_a ? dt_traits<ODT>::load(scale_a, 0) : 1.0f, sw = scale_w ? dt_traits<ODT>::load(scale_w, 0) : 1.0f;
-        auto fin = [&](float c) {
-            float v = dt_traits<ODT>::round(c);
-            if (scale_a) v = dt_traits<ODT>::round(v * sa);
-            if (scale_w) v = dt_traits<ODT>::round(v * sw);
-            return v;
+        // The three roundings on PAIRS (the generic per-value form -- round, multiply, round, multiply, round, pack -- was 11 VALU per value,
+        // 2900 per wave): bf16: v_cvt_pk_bf16_f32 is rounding and pack in one; the two halves are widened (shift / mask), multiplied in
+        // fp32 (exact products of two bf16 values) and re-packed: 5.5 per value.  fp16: v_pk_mul_f16 IS dt(v * s) for fp16 operands
+        // (the fp32 product of two fp16 values is exact, so one rounding either way): 2.5 per value.
+        auto fin2 = [&](float c0, float c1) -> uint32_t {
+            if constexpr (ODT == BIE_BF16) {
+                uint32_t p = pack_bf16x2(c0, c1);
+                if (scale_a) p = pack_bf16x2(__uint_as_float(p << 16) * sa, __uint_as_float(p & 0xffff0000u) * sa);
+                if (scale_w) p = pack_bf16x2(__uint_as_float(p << 16) * sw, __uint_as_float(p & 0xffff0000u) * sw);
+                return p;
+            } else {
+                half2_t p = half2_t{(half_t)c0, (half_t)c1};
+                if (scale_a) p = p * half2_t{(half_t)sa, (half_t)sa};
+                if (scale_w) p = p * half2_t{(half_t)sw, (half_t)sw};
+                return __builtin_bit_cast(uint32_t, p);
+            }
         };
-        auto pack2 = [&](float lo, float hi) -> uint32_t {
-            if constexpr (ODT == BIE_BF16) return pack_bf16x2(lo, hi);
-            else return f32_to_f16_bits(lo) | (f32_to_f16_bits(hi) << 16);
-        };
+        auto lo_f32 = [&](uint32_t p) { return ODT == BIE_BF16 ? __uint_as_float(p << 16) : f16_bits_to_f32(p & 0xffffu); };
+        auto hi_f32 = [&](uint32_t p) { return ODT == BIE_BF16 ? __uint_as_float(p & 0xffff0000u) : f16_bits_to_f32(p >> 16); };
         const bool vec_ok = (N & 7) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
         const int half = lane >> 5;
 #pragma unroll
@@ -423,11 +432,10 @@ __global__ __launch_bounds__(256) void xnor_fp4_gemm_kernel(const uint8_t* __res
                 const int nb = (tile_n * BF + wx * WN + j) * 32;
 #pragma unroll
                 for (int qp = 0; qp < 2; qp++) {
-                    float v[8];
-#pragma unroll
-                    for (int e = 0; e < 8; e++) v[e] = fin(acc[i][j][8 * qp + e]);  // e < 4: group 2qp (n + 4*half + e), e >= 4: group 2qp + 1
+                    // registers 8qp .. 8qp+3: group 2qp (n + 4*half + e), 8qp+4 .. 8qp+7: group 2qp + 1
+                    const uint32_t p0 = fin2(acc[i][j][8 * qp], acc[i][j][8 * qp + 1]), p1 = fin2(acc[i][j][8 * qp + 2], acc[i][j][8 * qp + 3]);
+                    const uint32_t p2 = fin2(acc[i][j][8 * qp + 4], acc[i][j][8 * qp + 5]), p3 = fin2(acc[i][j][8 * qp + 6], acc[i][j][8 * qp + 7]);
                     if (vec_ok) {
-                        const uint32_t p0 = pack2(v[0], v[1]), p1 = pack2(v[2], v[3]), p2 = pack2(v[4], v[5]), p3 = pack2(v[6], v[7]);
                         const auto s0 = __builtin_amdgcn_permlane32_swap(p0, p2, false, false);  // first operand's upper half <-> second's lower half
                         const auto s1 = __builtin_amdgcn_permlane32_swap(p1, p3, false, false);
                         const int n = nb + 8 * (2 * qp + half);
@@ -436,7 +444,8 @@ __global__ __launch_bounds__(256) void xnor_fp4_gemm_kernel(const uint8_t* __res
 #pragma unroll
                         for (int e = 0; e < 8; e++) {
                             const int n = nb + 8 * (2 * qp + (e >> 2)) + 4 * half + (e & 3);
-                            if (n < N) dt_traits<ODT>::store(yr, n, v[e]);
+                            const uint32_t pe = e < 2 ? p0 : (e < 4 ? p1 : (e < 6 ? p2 : p3));
+                            if (n < N) dt_traits<ODT>::store(yr, n, (e & 1) ? hi_f32(pe) : lo_f32(pe));
                         }
                     }
                 }

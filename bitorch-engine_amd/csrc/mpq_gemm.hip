@@ -471,9 +471,10 @@ __global__ __launch_bounds__(256, (BM <= 128 ? 2 : 1)) void mpq_gemm_kernel(cons
                     if (S == 1) {
                         float o[4];
 #pragma unroll
-                        for (int c = 0; c < 4; c++) {
-                            o[c] = dt_traits<DT>::round(acc[f][t][4 * q + c]);
-                            if (use_bias) o[c] = o[c] + dt_traits<DT>::load(bias, n0 + c);
+                        for (int c = 0; c < 4; c++) o[c] = acc[f][t][4 * q + c];
+                        if (use_bias) {  // y = dt(dt(acc) + bias); without bias the pack below is the one rounding (an explicit round first costs 3 VALU per value)
+#pragma unroll
+                            for (int c = 0; c < 4; c++) o[c] = dt_traits<DT>::round(o[c]) + dt_traits<DT>::load(bias, n0 + c);
                         }
                         uint2_t pk;
                         if constexpr (DT == BIE_F16) {
