@@ -317,6 +317,28 @@ def test_mbwq_q4_dequant_and_forward(bits, M, perm):
     assert_close(y, ref, orc.F16, f"mbwq q{bits} M={M} perm={perm}")
 
 
+@pytest.mark.parametrize("bits", [2, 4])
+def test_mbwq_q4_forward_through_the_dense_form(bits, monkeypatch):
+    """The uniform MBWQ layers reach the MFMA GEMM with the one-rounding fma (ZM_FUSED); forced through mpq_dense.hip (no q_perm: the
+    gather path stays on the fused kernel) and compared with the oracle and with the fused kernel."""
+    from bitorch_engine.extensions import q_linear_cuda
+    monkeypatch.setenv("BIE_TUNING", "1")
+    rng = np.random.default_rng(bits * 77)
+    K, N, gs, M = 512, 256, 64, 200
+    qw, scales, zeros, gen = rand_case(rng, K, N, bits, gs, orc.F16, 0)
+    zeros = torch.randn(zeros.shape, generator=gen).half() * 0.05
+    q_perm = torch.zeros(K).to(torch.short)
+    Wo = orc.mbwq_q4_dequant(qw.numpy(), orc.torch_to_np(scales), orc.torch_to_np(zeros), None, bits, gs)
+    x = torch.randn((M, K), generator=gen).half()
+    ref = t16(orc.gemm(orc.torch_to_np(x), Wo, orc.F16), orc.F16)
+    ys = {}
+    for form in ("2", "0"):
+        monkeypatch.setenv("BIE_GEMM_DENSE", form)
+        ys[form] = q_linear_cuda.mbwq_q4_forward(x.to(DEV), qw.to(DEV), scales.to(DEV), zeros.to(DEV), gs, q_perm.to(DEV), bits)
+        assert_close(ys[form], ref, orc.F16, f"mbwq q{bits} dense={form}")
+    assert_close(ys["2"], ys["0"], orc.F16, "dense vs fused")
+
+
 @pytest.mark.parametrize("cfg", ["q_proj", "k_proj", "w3w2", "all6"])
 @pytest.mark.parametrize("M", [1, 2, 3, 7, 11, 16, 17, 33, 48, 64, 70])  # 3..48: matrix-pipe kernel (1-3 row blocks); > EXL2_GEMV_MAX_M (48): reconstruct + library GEMM
 def test_mbwq_exl2_dequant_and_forward(cfg, M):
