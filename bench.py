@@ -116,12 +116,12 @@ def pmc_gemm():
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_gemm.json")))
         h = hashlib.sha256()
-        for f in ("mpq_gemm.hip", "mpq_frag_dequant.cuh"):  # the fused kernel's sources (tools/pmc_gemm_json.py stamps the same hash)
+        for f in ("mpq_gemm.hip", "mpq_frag_dequant.cuh", "mpq_dense.hip", "mfma_pipe.cuh"):  # both GEMM forms (tools/pmc_gemm_json.py stamps the same hash)
             h.update(open(os.path.join(ROOT, "bitorch-engine_amd", "csrc", f), "rb").read())
         if d.get("gemm_source_sha") != h.hexdigest()[:16]:
             return None
         b = d["bf16"]
-        return {"shape": d["shape"], "mfma_pipe_utilisation": b["mfma_pipe_utilisation"], "valu_per_mfma": b["instructions"]["valu_per_mfma"],
+        return {"shape": d["shape"], "kernel": b.get("kernel"), "mfma_pipe_utilisation": b["mfma_pipe_utilisation"], "valu_per_mfma": b["instructions"]["valu_per_mfma"],
                 "fetch_bytes": b["fetch_bytes_corrected"], "write_bytes": b["write_bytes"], "algorithmic_bytes": b["algorithmic_bytes"]}
     except Exception:
         return None

@@ -1,0 +1,182 @@
+// W8A8 integer GEMM on the ordered-asm MFMA pipeline of mfma_pipe.cuh (v_mfma_i32_32x32x32_i8) -- the large-grid form of
+// intgemm.hip's int_gemm_kernel modes 1 (fp32 out, two scales) and 3 (raw int32), replacing the same reference code:
+// q8_linear_cutlass_kernel.cu:44-230 (CUTLASS int8 tensor-op GEMM + the scale epilogue of q8_linear_cutlass_forward).
+//   y[m][n] = epilogue( sum_k a[m][k] * w[n][k] )      a: [M, K] int8, w: [N, K] int8, both K-contiguous
+// Both operands are row-major with k contiguous, i.e. both are what x is to mpq_dense.hip: LDS image [rows][64 bytes] per stage
+// (K = 64 = two MFMA k steps), 16-byte slots XORed by (row >> 2) & 3 on the SOURCE side of the LDS-DMA, conflict-free fragment reads.
+// Loop, tiles and schedule are binary_fp4.hip's / mpq_dense.hip's (the bytes per stage and MFMAs per stage are the same by construction).
+// Exact int32 accumulation; the epilogues are int_gemm_kernel's, so the results are bit-identical to it.
+#include "mfma_pipe.cuh"
+#include <stdlib.h>
+
+namespace bie {
+
+typedef int int16v_t __attribute__((ext_vector_type(16)));
+typedef int int4v_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void mfma_i8(int16v_t& c, const v4i_t& a, const v4i_t& b) {
+    asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+
+// OUT_I32: y int32 = acc; else y fp32 = ((float)acc * scale_a) * scale_w
+template <bool OUT_I32, int WM, int WN>
+__global__ __launch_bounds__(256) void i8_pipe_gemm_kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ W, void* __restrict__ yv, int M, int N, int K,
+                                                           int tiles_n, float scale_a, float scale_w) {
+    constexpr int AF = 2 * WM, BF = 2 * WN;
+    constexpr int NFR = (AF + BF) * 2;  // KiB per stage (64 bytes per row)
+    constexpr int PW = NFR / 4;
+    constexpr int STAGE = NFR * 1024;
+    constexpr int NR = WM + WN, NM = WM * WN;
+    constexpr int RPM = (2 * NR + NM - 1) / NM, M0 = (NR + RPM - 1) / RPM, DPM = (PW + (NM - M0) - 1) / (NM - M0);
+    static_assert((AF * 2) % PW == 0, "a wave's pieces belong to one operand");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[3 * STAGE];
+
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wy = wave >> 1, wx = wave & 1;
+    int bid = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);  // one contiguous run of tiles per XCD
+    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+    const int KT = K >> 6;
+
+    // LDS-DMA sources: pieces of 16 rows x 64 bytes; [a rows of the tile][w rows of the tile]
+    const bool a_wave = wave * PW < AF * 2;
+    const uint8_t* src[PW];
+#pragma unroll
+    for (int j = 0; j < PW; j++) {
+        const int p = wave * PW + j;
+        const int rt = (a_wave ? p : p - AF * 2) * 16 + (lane >> 2);  // row of the operand's tile
+        long r = a_wave ? (long)tile_m * (AF * 32) + rt : (long)tile_n * (BF * 32) + rt;
+        const long rmax = (a_wave ? M : N) - 1;
+        if (r > rmax) r = rmax;
+        src[j] = (a_wave ? A : W) + r * K + (((lane & 3) ^ ((rt >> 2) & 3)) << 4);
+    }
+    [[maybe_unused]] const int kt_last = KT - 1;
+    auto issue_piece = [&](int kt, int j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int ks = kt < kt_last ? kt : kt_last;
+        auto* dst = (__attribute__((address_space(3))) unsigned char*)lds + (kt % 3) * STAGE + wave * (PW * 1024);
+        __builtin_amdgcn_global_load_lds(src[j] + (long)ks * 64, dst + j * 1024, 16, 0, 0);
+#endif
+    };
+
+    const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
+    const int rl = lane & 31, hh = lane >> 5, sw = (rl >> 2) & 3;
+    uint32_t a_addr[2], b_addr[2];  // k step s: logical slot 2*s + hh of row rl of the wave's first block
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        a_addr[s] = lds_base + (uint32_t)((wy * WM * 32 + rl) * 64 + (((2 * s + hh) ^ sw) << 4));
+        b_addr[s] = lds_base + AF * 2048 + (uint32_t)((wx * WN * 32 + rl) * 64 + (((2 * s + hh) ^ sw) << 4));
+    }
+
+    int16v_t acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; i++)
+#pragma unroll
+        for (int j = 0; j < WN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0;
+
+    v4i_t XA[WM], XB[WN], YA[WM], YB[WN], ZA[WM], ZB[WN];
+    auto read_item = [&](auto ic, auto hc, uint32_t so, v4i_t (&TA)[WM], v4i_t (&TB)[WN]) {
+        constexpr int R = decltype(ic)::value, H = decltype(hc)::value;
+        if constexpr (R < WM) TA[R] = lds_read16<R * 2048>(a_addr[H] + so);
+        else TB[R - WM] = lds_read16<(R - WM) * 2048>(b_addr[H] + so);
+    };
+
+#pragma unroll
+    for (int s = 0; s < 3; s++)
+#pragma unroll
+        for (int j = 0; j < PW; j++) issue_piece(s, j);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW) : "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, NR>([&](auto rc) { read_item(rc, ic_t<0>{}, 0u, XA, XB); });
+
+    auto stage = [&](int kt, v4i_t (&PA)[WM], v4i_t (&PB)[WN], v4i_t (&QA)[WM], v4i_t (&QB)[WN], v4i_t (&NA)[WM], v4i_t (&NB)[WN]) {
+        const uint32_t so = (uint32_t)(kt % 3) * STAGE, sn = (uint32_t)((kt + 1) % 3) * STAGE;
+        wait_frags<0>(PA, PB);
+        static_for<0, NM>([&](auto mc) {
+            constexpr int m = decltype(mc)::value, i = m / WN, j = m % WN;
+            mfma_i8(acc[i][j], PB[j], PA[i]);  // D = w_frag (rows = output features) x a_frag (columns = rows of a)
+            static_for<imin(m * RPM, NR), imin((m + 1) * RPM, NR)>([&](auto rc) { read_item(rc, ic_t<1>{}, so, QA, QB); });
+        });
+        wait_frags<0>(QA, QB);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+        __builtin_amdgcn_s_barrier();
+        static_for<0, NM>([&](auto mc) {
+            constexpr int m = decltype(mc)::value, i = m / WN, j = m % WN;
+            mfma_i8(acc[i][j], QB[j], QA[i]);
+            static_for<imin(m * RPM, NR), imin((m + 1) * RPM, NR)>([&](auto rc) { read_item(rc, ic_t<0>{}, sn, NA, NB); });
+            if constexpr (m >= M0)
+                static_for<imin((m - M0) * DPM, PW), imin((m - M0 + 1) * DPM, PW)>([&](auto pc) { issue_piece(kt + 3, decltype(pc)::value); });
+        });
+    };
+    int kt = 0;
+    for (; kt + 3 <= KT; kt += 3) {
+        stage(kt, XA, XB, YA, YB, ZA, ZB);
+        stage(kt + 1, ZA, ZB, XA, XB, YA, YB);
+        stage(kt + 2, YA, YB, ZA, ZB, XA, XB);
+    }
+    if (kt < KT) {
+        stage(kt, XA, XB, YA, YB, ZA, ZB);
+        if (kt + 1 < KT) stage(kt + 1, ZA, ZB, XA, XB, YA, YB);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    mfma_drain();
+
+    // C/D: column = lane & 31 = row m of a, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) = feature inside the 32-block: four consecutive n per
+    // register group -> 16-byte stores (N % 4 == 0 on this path)
+    const int n_l = 4 * hh;
+#pragma unroll
+    for (int i = 0; i < WM; i++) {
+        const int m = (tile_m * AF + wy * WM + i) * 32 + rl;
+        if (m < M) {
+#pragma unroll
+            for (int j = 0; j < WN; j++) {
+                const int n0 = (tile_n * BF + wx * WN + j) * 32 + n_l;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int n = n0 + 8 * q;
+                    if (n < N) {
+                        if constexpr (OUT_I32) {
+                            *reinterpret_cast<int4v_t*>((int*)yv + (long)m * N + n) = int4v_t{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                        } else {
+                            float4_t v;
+#pragma unroll
+                            for (int e = 0; e < 4; e++) v[e] = ((float)acc[i][j][4 * q + e] * scale_a) * scale_w;
+                            *reinterpret_cast<float4_t*>((float*)yv + (long)m * N + n) = v;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Shapes this form takes (K % 64 == 0 and N % 4 == 0 are the entry points' own preconditions): grids that give every wave work.
+bool i8_pipe_ok(int M, int N, int K, const void* A, const void* W, const void* y) {
+    static const int on = [] { const char* e = getenv("BIE_I8_PIPE"); return e ? atoi(e) : 1; }();
+    if (!on || (K & 63) || (N & 3) || M < 128 || N < 128) return false;
+    return ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+}
+
+int i8_pipe_launch(bool out_i32, const void* A, const void* W, void* y, int M, int N, int K, float sa, float sw, hipStream_t st) {
+    const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
+#define BIE_I8(OI, WMV, GRID, TN) \
+    hipLaunchKernelGGL((i8_pipe_gemm_kernel<OI, WMV, WMV>), dim3((unsigned)(GRID)), dim3(256), 0, st, (const uint8_t*)A, (const uint8_t*)W, y, M, N, K, TN, sa, sw)
+    if (t256 >= 192) {
+        const int tn = cdiv(N, 256);
+        if (out_i32) BIE_I8(true, 4, t256, tn);
+        else BIE_I8(false, 4, t256, tn);
+    } else {
+        const int tn = cdiv(N, 128);
+        const long g = (long)cdiv(M, 128) * tn;
+        if (out_i32) BIE_I8(true, 2, g, tn);
+        else BIE_I8(false, 2, g, tn);
+    }
+#undef BIE_I8
+    return check_launch("i8_pipe_gemm_kernel");
+}
+
+}  // namespace bie

@@ -633,8 +633,8 @@ def test_q4_forward_bit_exact_vs_oracle(dt, M, N, K):
     assert torch.equal(out, out2)
 
 
-@pytest.mark.parametrize("M,N,K", [(1, 4, 64), (33, 100, 320), (256, 384, 512), (129, 132, 4096)])
-def test_q8_forward_bit_exact_vs_oracle(M, N, K):
+@pytest.mark.parametrize("M,N,K", [(1, 4, 64), (33, 100, 320), (256, 384, 512), (129, 132, 4096), (300, 520, 64), (512, 3072, 1024), (1536, 8192, 192)])
+def test_q8_forward_bit_exact_vs_oracle(M, N, K):  # M, N >= 128: the pipeline kernel (intgemm_pipe.hip), both tile sizes, 1 / 3 / 16 / 64 K stages
     from bitorch_engine.extensions import q_linear_cutlass as qc
     rng = np.random.default_rng(M + N)
     a = rng.integers(-128, 128, (M, K)).astype(np.int8)

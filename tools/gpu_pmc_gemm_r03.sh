@@ -7,7 +7,7 @@ import csv, sys, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
     k = r.get("Kernel_Name", "")
-    if "mpq_gemm_kernel" not in k: continue
+    if "mpq_gemm_kernel" not in k and "mpq_dense_gemm_kernel" not in k: continue
     agg[k[:80]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in agg.items():
     print(k, {c: round(sum(v) / len(v), 1) for c, v in d.items()}, "n=", len(next(iter(d.values()))))
@@ -23,5 +23,5 @@ pass e $dt WRITE_SIZE
 pass f $dt GRBM_GUI_ACTIVE GRBM_COUNT
 done
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pmcg_stats -o p -- python $R/tools/gemm_only.py 4096 bf16 > /tmp/pmcg_stats.log 2>&1
-echo "== kernel stats (bf16)"; f=$(find /tmp/pmcg_stats -name "*kernel_stats.csv" | head -1); grep -i "mpq_gemm\|Name" "$f" | cut -c1-260
+echo "== kernel stats (bf16)"; f=$(find /tmp/pmcg_stats -name "*kernel_stats.csv" | head -1); grep -i "mpq_gemm\|mpq_dense\|mpq_dequant_frag\|Name" "$f" | cut -c1-260
 } 2>&1 | tee $R/gpurun_out/r03w_pmc_gemm.txt
