@@ -39,6 +39,7 @@ import torch  # noqa: E402
 GROUP, WBIT = 128, 4
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA
+I8_MFMA_PEAK_TOPS = 5000.0   # dense i8 MFMA (2x the bf16 rate)
 FP4_MFMA_PEAK_TOPS = 10000.0  # dense FP4 MFMA (MI355X_MICROARCH.md: ~10 PF dense; 9.1 measured by its microbenchmark)
 XOR_POPC_PEAK_TOPS = 1260.0  # v_xor_b32 + v_bcnt_u32_b32 accumulate: 2 VALU per 32 binary MACs per lane
 BF16 = torch.bfloat16
@@ -402,6 +403,37 @@ def bench_binary(dev, L):
     return out
 
 
+def bench_int_gemm(dev, L):
+    """W8A8 (bie_q8_gemm: int8 x int8 -> fp32 with two scales) and W4A4 (bie_q4_gemm, packed nibbles -> bf16) on the i8 matrix
+    cores, 4096^3 and the 4096 -> 11008 layer at M = 4096."""
+    out = []
+    for (M, N, K) in ((4096, 4096, 4096), (4096, 11008, 4096), (256, 4096, 4096)):
+        a8 = torch.randint(-128, 128, (M, K), dtype=torch.int8, device=dev)
+        ws8 = [torch.randint(-128, 128, (N, K), dtype=torch.int8, device=dev) for _ in range(4)]
+        y = torch.empty((M, N), dtype=torch.float32, device=dev)
+        a4 = torch.randint(-128, 128, (M, K // 2), dtype=torch.int8, device=dev)
+        ws4 = [torch.randint(-128, 128, (N, K // 2), dtype=torch.int8, device=dev) for _ in range(4)]
+        yb = torch.empty((M, N), dtype=BF16, device=dev)
+
+        def run8(st):
+            for w in ws8:
+                if L.bie_q8_gemm(a8.data_ptr(), w.data_ptr(), y.data_ptr(), M, N, K, 0.01, 0.02, st):
+                    raise RuntimeError(L.bie_last_error().decode())
+
+        def run4(st):
+            for w in ws4:
+                if L.bie_q4_gemm(a4.data_ptr(), w.data_ptr(), yb.data_ptr(), M, N, K, 0.3, 0.3, 1, 1, 0, 0, 0, st):
+                    raise RuntimeError(L.bie_last_error().decode())
+        for name, fn, kern in (("W8A8", run8, "bie::i8_pipe_gemm_kernel (v_mfma_i32_32x32x32_i8, ordered-asm pipeline)" if M >= 128 else "bie::int_gemm_kernel"),
+                               ("W4A4", run4, "bie::int_gemm_kernel (nibbles expanded to i8 in registers)")):
+            us = time_graph(capture(fn), 5) / 4
+            tops = 2.0 * M * N * K / us / 1e6
+            out.append({"op": f"{name} GEMM", "M": M, "N": N, "K": K, "us_per_launch": round(us, 2), "TOP/s": round(tops, 1),
+                        "roofline": {"bound": "mfma i8", "achieved": round(tops, 1), "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s",
+                                     "frac": round(tops / I8_MFMA_PEAK_TOPS, 4), "traffic": None, "kernel": kern}})
+    return out
+
+
 def cpu_baselines(budget_s=24.0):
     """The CPU restatement (oracle/bie_oracle.c, a "port": proved equal to the reference's CPU path on the golden vectors) timed on the
     host cores, SURVEY.md section 8d: for every workload a bounded sample at the best of {all, 32, 8} OpenMP threads and at one thread.
@@ -655,6 +687,7 @@ def main():
         guarded("c3_w2a16_4096x11008", lambda: B.gemv(4096, 11008, 40, 10, 42, w_bit=2))
         guarded("c3_w2a16_11008x4096", lambda: B.gemv(11008, 4096, 40, 10, 43, w_bit=2))
         guarded("c4_binary", lambda: bench_binary(dev, B.L))
+        guarded("f1_int_gemm", lambda: bench_int_gemm(dev, B.L))
         # ---- configs[4]'s layer on one GPU (the sharded run is `c5` under --gpus N)
         guarded("c5_single_gpu_8192x28672", lambda: B.gemm(4096, 8192, 28672, 2, 3, 31))
         # the same layer at M = 1 and its gate/up pair in one launch: what the decode kernel reaches once a launch is large (125 / 250 MB)

@@ -193,10 +193,13 @@ int q4_conv2d_launch(const int8_t* a_packed, const int8_t* w_packed, void* y, vo
 // intgemm_pipe.hip: W8A8 on the ordered-asm pipeline (256 x 256 / 128 x 128 tiles, LDS-DMA of both operands), bit-identical results
 bool i8_pipe_ok(int M, int N, int K, const void* A, const void* W, const void* y);
 int i8_pipe_launch(bool out_i32, const void* A, const void* W, void* y, int M, int N, int K, float sa, float sw, hipStream_t st);
+bool i4_pipe_ok(int M, int N, int K, const void* A, const void* W, const void* y);
+int i4_pipe_launch(int mode, const void* A, const void* W, void* y, int M, int N, int K, float sa, float sw, int dtype, hipStream_t st);
 
 int int_gemm_launch(int mode, const void* A, const void* W, void* y, int M, int N, int K, float sa, float sw, int dtype, int batch,
                     long strideA, long strideW, long strideY, hipStream_t st) {
     if ((mode == 1 || mode == 3) && batch == 1 && i8_pipe_ok(M, N, K, A, W, y)) return i8_pipe_launch(mode == 3, A, W, y, M, N, K, sa, sw, st);
+    if ((mode == 0 || mode == 2) && batch == 1 && i4_pipe_ok(M, N, K, A, W, y)) return i4_pipe_launch(mode, A, W, y, M, N, K, sa, sw, dtype, st);
     dim3 grid(cdiv(N, IG_BN), cdiv(M, IG_BM), batch);
 #define L(MODE, DT) hipLaunchKernelGGL((int_gemm_kernel<MODE, DT>), grid, dim3(256), 0, st, (const uint8_t*)A, (const uint8_t*)W, y, M, N, K, sa, sw, strideA, strideW, strideY)
     if (mode == 1) L(1, BIE_F32);

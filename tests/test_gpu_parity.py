@@ -615,8 +615,8 @@ def test_q4_quantize_pack_bit_exact(dt):
 
 
 @pytest.mark.parametrize("dt", ["f16", "bf16", "f32"])
-@pytest.mark.parametrize("M,N,K", [(1, 4, 64), (5, 36, 128), (128, 128, 256), (130, 260, 192), (257, 124, 1024)])
-def test_q4_forward_bit_exact_vs_oracle(dt, M, N, K):
+@pytest.mark.parametrize("M,N,K", [(1, 4, 64), (5, 36, 128), (128, 128, 256), (130, 260, 192), (257, 124, 1024), (300, 520, 128), (512, 3072, 1024), (1536, 8192, 384), (130, 260, 4096)])
+def test_q4_forward_bit_exact_vs_oracle(dt, M, N, K):  # M, N >= 128 and K % 128 == 0: the pipeline kernel (intgemm_pipe.hip), both tile sizes, 1 / 3 / 8 / 32 K stages
     from bitorch_engine.extensions import q_linear_cutlass as qc
     g = torch.Generator().manual_seed(M * 131 + N)
     x = torch.randn((M, K), generator=g).to(_TDT[dt])
