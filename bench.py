@@ -425,7 +425,7 @@ def bench_int_gemm(dev, L):
                 if L.bie_q4_gemm(a4.data_ptr(), w.data_ptr(), yb.data_ptr(), M, N, K, 0.3, 0.3, 1, 1, 0, 0, 0, st):
                     raise RuntimeError(L.bie_last_error().decode())
         for name, fn, kern in (("W8A8", run8, "bie::i8_pipe_gemm_kernel (v_mfma_i32_32x32x32_i8, ordered-asm pipeline)" if M >= 128 else "bie::int_gemm_kernel"),
-                               ("W4A4", run4, "bie::int_gemm_kernel (nibbles expanded to i8 in registers)")):
+                               ("W4A4", run4, "bie::i4_pipe_gemm_kernel (nibbles expanded to i8 beside the MFMAs, ordered-asm pipeline)" if M >= 128 else "bie::int_gemm_kernel")):
             us = time_graph(capture(fn), 5) / 4
             tops = 2.0 * M * N * K / us / 1e6
             out.append({"op": f"{name} GEMM", "M": M, "N": N, "K": K, "us_per_launch": round(us, 2), "TOP/s": round(tops, 1),

@@ -235,8 +235,17 @@ __global__ __launch_bounds__(256) void i4_pipe_gemm_kernel(const uint8_t* __rest
     // expansion item R of half E (0: first 8 bytes, 1: second) from the raw set (TA, TB)
     auto expand_item = [&](auto ic, auto ec, const v4i_t (&TA)[WM], const v4i_t (&TB)[WN]) {
         constexpr int R = decltype(ic)::value, E = decltype(ec)::value;
-        if constexpr (R < WM) EA[E][R] = E ? expand_q4_hi(TA[R]) : expand_q4_lo(TA[R]);
-        else EB[E][R - WM] = E ? expand_q4_hi(TB[R - WM]) : expand_q4_lo(TB[R - WM]);
+        // The zero-instruction asm pins the six VALU of an expansion to THIS slot of the stream.  Left to itself hipcc sinks them to just
+        // in front of the MFMA that consumes the operand -- and a VALU result read by the very next MFMA is a hazard the compiler pads
+        // for its own MFMAs but cannot see into an asm one: the MFMA took the register's previous content ((x << 4) before its mask),
+        // results off by a few units for K >= 384 (tools/dbg_q4.py).  Pinned here, every expansion sits >= 3 MFMAs ahead of its use.
+        if constexpr (R < WM) {
+            EA[E][R] = E ? expand_q4_hi(TA[R]) : expand_q4_lo(TA[R]);
+            asm volatile("" : "+v"(EA[E][R]));
+        } else {
+            EB[E][R - WM] = E ? expand_q4_hi(TB[R - WM]) : expand_q4_lo(TB[R - WM]);
+            asm volatile("" : "+v"(EB[E][R - WM]));
+        }
     };
 
 #pragma unroll
