@@ -243,3 +243,49 @@ def test_fp4_conv_equals_the_oracle_and_the_tap_form(B, C, H, W, OC, ks, st, pad
     assert y.shape == (B, OC, OH, OW) and torch.equal(y, y0)
     assert np.array_equal(y.cpu().numpy(), ref)
     assert np.array_equal(yb.cpu().numpy(), orc.binary_conv2d(x.to(torch.bfloat16).float().numpy(), w.numpy(), st, pad, dil))
+
+
+def test_fp4_entry_points_reject_what_they_cannot_take():
+    """Argument errors are status codes + bie_last_error(), never a crash or a silent fallback."""
+    from bitorch_engine import _hip
+    L = _hip.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    buf = torch.zeros(1 << 16, dtype=torch.uint8, device=DEV)
+    p = buf.data_ptr()
+    assert L.bie_binary_fp4_image_bytes(0, 128) == 0 and L.bie_binary_fp4_image_bytes(33, 129) == 2 * 2 * 2 * 1024
+    assert L.bie_binary_fp4_image(p, p + 4096, 32, 100, st) != 0 and b"K % 8" in L.bie_last_error()      # K not a multiple of 8 (bits form)
+    assert L.bie_binary_fp4_image(p, p + 4097, 32, 128, st) != 0 and b"aligned" in L.bie_last_error()    # image not 16-byte aligned
+    assert L.bie_binary_fp4_image_from_values(p, p, p + 4096, 32, 128, 3, st) != 0                       # int8 sign carriers take no bias
+    assert L.bie_binary_linear_forward_fp4(p, p + 4096, p + 8192, 32, 32, 1 << 24, 1.0, st) != 0 and b"2^24" in L.bie_last_error()
+    assert L.bie_binary_linear_layer_fp4(p, p + 4096, None, None, p + 8192, 32, 32, 128, 3, st) != 0       # dtype 3 has no layer epilogue
+    assert L.bie_binary_conv2d_fp4_workspace_bytes(1, 48, 7, 7, 3, 1, 1, 1) == 0                          # C % 32 != 0
+    assert L.bie_binary_conv2d_forward_fp4(p, p + 4096, p + 8192, p + 16384, 1 << 15, 1, 48, 7, 7, 64, 3, 1, 1, 1, 1.0, 0, st) != 0 and b"multiple of 32" in L.bie_last_error()
+    assert L.bie_binary_conv2d_forward_fp4(p, p + 4096, p + 8192, p + 16384, 16, 1, 64, 7, 7, 64, 3, 1, 1, 1, 1.0, 0, st) != 0 and b"workspace" in L.bie_last_error()
+    torch.cuda.synchronize()
+
+
+def test_fp4_paths_replay_in_a_captured_graph():
+    """The matrix-pipe forms are stream-ordered and allocation-free on the C side: a captured layer forward replays with new activations."""
+    from bitorch_engine.extensions._binary_common import pack_rows, xnor_layer_fp4
+    M, N, K = 512, 256, 1024
+    g = torch.Generator().manual_seed(4)
+    w = torch.randn((N, K), generator=g)
+    wrows = pack_rows(w.to(DEV))
+    x = torch.randn((M, K), generator=g).to(torch.bfloat16).to(DEV)
+    sa = torch.tensor(0.5, dtype=torch.bfloat16, device=DEV)
+    y_eager = xnor_layer_fp4(x, wrows, None, sa, None)  # also sizes the scratch buffer and builds the weight image before the capture
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        xnor_layer_fp4(x, wrows, None, sa, None)
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            y_cap = xnor_layer_fp4(x, wrows, None, sa, None)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y_cap, y_eager)
+    x.copy_(torch.randn((M, K), generator=g).to(torch.bfloat16))
+    graph.replay()
+    torch.cuda.synchronize()
+    ints = orc.binary_linear_rowpacked(orc.binary_pack_rows(x.float().cpu().numpy()), orc.binary_pack_rows(w.numpy()), K)
+    assert torch.equal(y_cap.cpu(), torch.from_numpy(ints.astype(np.float32)).to(torch.bfloat16) * sa.cpu())
