@@ -116,8 +116,9 @@ def pmc_gemm():
     another mpq_gemm.hip."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_gemm.json")))
+        dense = "mpq_dense_gemm_kernel" in (d.get("bf16", {}).get("kernel") or "")  # the sources of the kernel the counters belong to
         h = hashlib.sha256()
-        for f in ("mpq_gemm.hip", "mpq_frag_dequant.cuh", "mpq_dense.hip", "mfma_pipe.cuh"):  # both GEMM forms (tools/pmc_gemm_json.py stamps the same hash)
+        for f in (("mpq_dense.hip", "mfma_pipe.cuh", "mpq_frag_dequant.cuh") if dense else ("mpq_gemm.hip", "mpq_frag_dequant.cuh")):
             h.update(open(os.path.join(ROOT, "bitorch-engine_amd", "csrc", f), "rb").read())
         if d.get("gemm_source_sha") != h.hexdigest()[:16]:
             return None

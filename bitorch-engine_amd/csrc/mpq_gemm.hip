@@ -549,7 +549,9 @@ static GemmPlan plan_gemm(int M, int K, int N) {
                 const double pair = r > 256 ? 1.7 : 1.0;  // the round lasts as long as its busiest CU
                 units += (1.0 + 0.35 * busy) * pair;
             }
-            double t = units * (tps + 3) * c0[i];  // + pipeline fill and epilogue of a block, about three K tiles
+            // + pipeline fill and epilogue of a block: about three K tiles, six for the 256-row tile (profiles/r03_plan_sweep3.txt: with 3 the
+            // model tied (256, S = 16) with (128, S = 8) at 11008 -> 4096, M = 256 and took the former: 72 us against 46)
+            double t = units * (tps + (BM == 256 ? 6 : 3)) * c0[i];
             if (Sr > 1) t += 5.0 + (double)Sr * M * N * 8.0 / 6.0e6;
             if (t < best) { best = t; p.BM = BM; p.S = Sr; p.tiles_per_split = tps; }
         }

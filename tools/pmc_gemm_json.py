@@ -7,9 +7,11 @@ src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r0
 dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r03_pmc_gemm.json")
 
 
-def gemm_source_sha():
+def gemm_source_sha(kernel):
+    """Hash of the sources of the kernel the counters belong to (bench.py recomputes it the same way)."""
+    files = ("mpq_dense.hip", "mfma_pipe.cuh", "mpq_frag_dequant.cuh") if "mpq_dense_gemm_kernel" in (kernel or "") else ("mpq_gemm.hip", "mpq_frag_dequant.cuh")
     h = hashlib.sha256()
-    for f in ("mpq_gemm.hip", "mpq_frag_dequant.cuh", "mpq_dense.hip", "mfma_pipe.cuh"):
+    for f in files:
         h.update(open(os.path.join(ROOT, "bitorch-engine_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -26,7 +28,7 @@ out = {"source": "tools/gpu_pmc_gemm_r03.sh: rocprofv3 --kernel-trace --pmc <one
                  "(M=4096, K=4096, N=11008, no graph; counters of the GEMM kernel the dispatch picks for this shape, named per dtype); converted by tools/pmc_gemm_json.py",
        "units": "SQ_VALU_MFMA_BUSY_CYCLES sums 32 cycles per v_mfma_f32_32x32x16 over all 1024 SIMDs; GRBM_GUI_ACTIVE sums the 8 XCDs; SQ_WAVE_CYCLES / "
                 "SQ_WAIT_ANY in quad-cycles; FETCH_SIZE KiB doubled per MI355X_MICROARCH.md; profiled passes run at a lower clock than un-profiled ones",
-       "gemm_source_sha": gemm_source_sha(), "shape": "M4096_K4096_N11008"}
+       "gemm_source_sha": gemm_source_sha(vals["bf16"].get("kernel")), "shape": "M4096_K4096_N11008"}
 for dt, v in vals.items():
     if not v:
         continue
