@@ -677,6 +677,9 @@ def main():
         guarded("c2_list_M2_4096x11008", lambda: B.gemv_list(4096, 11008, 40, 40, 10, 18, M=2))   # batched decode: 40 layers, one launch
         guarded("c2_list_M8_4096x11008", lambda: B.gemv_list(4096, 11008, 40, 40, 10, 19, M=8))
         guarded("c2_list_M16_4096x11008", lambda: B.gemv_list(4096, 11008, 40, 40, 10, 20, M=16))
+        # 17 <= M <= 64 decode streams: the list in row blocks of <= 16 (one launch per block) against one MFMA-GEMM launch per layer
+        guarded("c2_list_M32_4096x11008", lambda: B.gemv_list(4096, 11008, 40, 40, 10, 21, M=32))
+        guarded("c2_gemv_M32_4096x11008", lambda: B.gemv(4096, 11008, 40, 10, 22, M=32))
         guarded("c2_act_order_4096x11008", lambda: bench_act_order(dev))
         guarded("c2_gemm_4096x11008", lambda: B.gemm(4096, 4096, 11008, 16, 3, 14))
         guarded("c2_gemm_11008x4096", lambda: B.gemm(4096, 11008, 4096, 16, 3, 15))
