@@ -22,7 +22,7 @@ class MPQForwardList:
     fp16 / bf16; the tensors' storage is frozen in the plan (update their CONTENTS, never rebind them).
 
     W4 with 16 < M <= 64 (a batch of decode streams): the rows are cut into ceil(M / 16) balanced blocks, each a plan of its own over
-    the row slices of every x / y (rows are independent, dependent chains stay inside their block); forward() issues the blocks'
+    the row slices of every x / y (rows are independent; `depends_on` chains are an M <= 2 feature and are refused); forward() issues the blocks'
     launches back to back.  Every block streams the weights once: 2 x 6.7 us per 4096x11008 layer at M = 32 against 22 us for one
     MFMA-GEMM launch per layer; beyond 64 rows the per-layer GEMM is the better form and the constructor refuses."""
 
