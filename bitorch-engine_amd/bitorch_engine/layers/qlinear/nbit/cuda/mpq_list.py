@@ -1,5 +1,5 @@
-"""Decode (M <= 2; W4: M <= 16 rows per launch, up to 64 rows as row blocks of <= 16) over a LIST of MPQ layers in ONE kernel launch
-per row block (bie_mpq_list_*, include/bie_hip.h).
+"""Decode (M <= 2; W4: M <= 32 rows per launch, up to 64 rows as two row blocks) over a LIST of MPQ layers in ONE kernel launch per row
+block (bie_mpq_list_*, include/bie_hip.h).
 
 The reference launches one `quant_mm_kernel` per layer on the default stream
 (layers/qlinear/nbit/cuda/mpq_layer.py:65 -> mpq_linear_cuda_kernel.cu:482-577).  A 4096x4096 W4 layer is 8.9 MB --
@@ -21,14 +21,14 @@ class MPQForwardList:
     EARLIER entry whose `y` tensor IS this entry's `x`).  All tensors on one GPU; x [M, K], y [M, N] contiguous, dtype
     fp16 / bf16; the tensors' storage is frozen in the plan (update their CONTENTS, never rebind them).
 
-    W4 with 16 < M <= 64 (a batch of decode streams): the rows are cut into ceil(M / 16) balanced blocks, each a plan of its own over
-    the row slices of every x / y (rows are independent; `depends_on` chains are an M <= 2 feature and are refused); forward() issues the blocks'
-    launches back to back.  Every block streams the weights once: 2 x 6.7 us per 4096x11008 layer at M = 32 against 22 us for one
-    MFMA-GEMM launch per layer; beyond 64 rows the per-layer GEMM is the better form and the constructor refuses."""
+    W4 with 32 < M <= 64 (a batch of decode streams): the rows are cut into two balanced blocks of <= 32, each a plan of its own over the
+    row slices of every x / y (rows are independent; `depends_on` chains are an M <= 2 feature and are refused); forward() issues the
+    blocks' launches back to back.  Every block streams the weights once; beyond 64 rows the per-layer GEMM is the better form and the
+    constructor refuses."""
 
     def __new__(cls, entries, w_bit=4, group_size=128, asym=False):
         M = entries[0]["x"].reshape(-1, entries[0]["x"].shape[-1]).shape[0] if entries else 0
-        if cls is MPQForwardList and w_bit == 4 and 16 < M <= 64:
+        if cls is MPQForwardList and w_bit == 4 and 32 < M <= 64:
             return _RowBlockedList(entries, w_bit, group_size, asym)
         return super().__new__(cls)
 
@@ -60,7 +60,7 @@ class MPQForwardList:
         self._entries = arr
         nbytes = L.bie_mpq_list_device_bytes(len(entries), arr, self.M, w_bit, group_size)
         if nbytes == 0:
-            raise RuntimeError("MPQForwardList: this list is outside the one-launch decode range (w_bit 4: 1 <= M <= 16, groups of 32/64/128/256; "
+            raise RuntimeError("MPQForwardList: this list is outside the one-launch decode range (w_bit 4: 1 <= M <= 32, groups of 32/64/128/256; "
                                "w_bit 2: M <= 2, groups of 64/128/256; K a multiple of one common group size)")
         self._mem = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
         base = (self._mem.data_ptr() + 255) // 256 * 256
@@ -105,11 +105,11 @@ class MPQForwardList:
 
 
 class _RowBlockedList:
-    """MPQForwardList for 16 < M <= 64: one single-launch plan per block of <= 16 rows (see MPQForwardList)."""
+    """MPQForwardList for 32 < M <= 64: one single-launch plan per block of <= 32 rows (see MPQForwardList)."""
 
     def __init__(self, entries, w_bit, group_size, asym):
         M = entries[0]["x"].reshape(-1, entries[0]["x"].shape[-1]).shape[0]
-        nb = (M + 15) // 16
+        nb = (M + 31) // 32
         cuts = [(M * b) // nb for b in range(nb + 1)]  # balanced blocks
         self.M = M
         self.blocks = []

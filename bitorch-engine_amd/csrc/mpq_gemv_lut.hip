@@ -682,7 +682,9 @@ struct LutmView {
     long ncat;                 // granule columns: tiles * 64
 };
 
-template <int DT, int ZM, int RPG, int NW, bool PF>  // PF: the next unit's loads in flight under the current one (costs ~40 registers)
+// RB: 16-row blocks of x served by one pass over the weights (RB = 2: 17 <= M <= 32 -- the lookups and the pairing are shared, a word
+// costs one more MFMA, the activations one more 16-byte load per row quad; list launches only)
+template <int DT, int ZM, int RPG, int NW, bool PF, int RB = 1>  // PF: the next unit's loads in flight under the current one (costs ~40 registers)
 __device__ __forceinline__ void lutm_body(const LutmView& lv, const int tile_local, const int gtile, const int slice, const unsigned epoch,
                                           unsigned* status, const unsigned tag_skew, const int spin_limit) {
     constexpr int NB = 8;
@@ -711,7 +713,9 @@ __device__ __forceinline__ void lutm_body(const LutmView& lv, const int tile_loc
     const uint32_t xlo = __builtin_amdgcn_readfirstlane((uint32_t)xb), xhi = __builtin_amdgcn_readfirstlane((uint32_t)(xb >> 32));  // unsigned: no sign extension
     const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((uint64_t)xhi << 32) | xlo), 0,
                                                          __builtin_amdgcn_readfirstlane((uint32_t)((long)M * lv.K * 2)), 0x00020000);
-    const uint32_t xvoff = c < M ? (uint32_t)(c * lv.K * 2 + kb * 16) : 0x80000000u;
+    uint32_t xvoff[RB];
+#pragma unroll
+    for (int b = 0; b < RB; b++) xvoff[b] = 16 * b + c < M ? (uint32_t)((16 * b + c) * lv.K * 2 + kb * 16) : 0x80000000u;
 
     const uint32_t* wcol = lv.qw + n4;
     auto load_params = [&](int unit, uint32_t (&sb)[4], uint32_t (&zb)[4]) {
@@ -727,18 +731,22 @@ __device__ __forceinline__ void lutm_body(const LutmView& lv, const int tile_loc
             zb[0] = z2.x & 0xffffu; zb[1] = z2.x >> 16; zb[2] = z2.y & 0xffffu; zb[3] = z2.y >> 16;
         }
     };
-    auto load_unit = [&](uint4_t (&w)[RQ], uint4_t (&xf)[RQ], int unit) {
+    auto load_unit = [&](uint4_t (&w)[RQ], uint4_t (&xf)[RB][RQ], int unit) {
 #pragma unroll
         for (int rq = 0; rq < RQ; rq++) {
             const long row = (long)unit * RPG + 4 * rq + kb;
             w[rq] = __builtin_nontemporal_load(reinterpret_cast<const uint4_t*>(wcol + row * N));
-            xf[rq] = __builtin_bit_cast(uint4_t, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xvoff, (uint32_t)((unit * RPG + 4 * rq) * 16), 0));
+#pragma unroll
+            for (int b = 0; b < RB; b++)
+                xf[b][rq] = __builtin_bit_cast(uint4_t, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xvoff[b], (uint32_t)((unit * RPG + 4 * rq) * 16), 0));
         }
     };
 
-    lutm_acc_t acc[4];
+    lutm_acc_t acc[RB][4];
 #pragma unroll
-    for (int f = 0; f < 4; f++) acc[f] = lutm_acc_t{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int b = 0; b < RB; b++)
+#pragma unroll
+        for (int f = 0; f < 4; f++) acc[b][f] = lutm_acc_t{0.0f, 0.0f, 0.0f, 0.0f};
 
     const uint32_t lane_addr = (uint32_t)((kb & 1) * 64 + c * 4);
     const uint32_t wavepat = (uint32_t)wave * 0x20202020u;  // byte = (wave << 5) | q
@@ -746,7 +754,7 @@ __device__ __forceinline__ void lutm_body(const LutmView& lv, const int tile_loc
     uint32_t m0f;
     asm("v_mov_b32 %0, 0x0f0f0f0f" : "=v"(m0f));
 
-    auto process_unit = [&](const uint4_t (&w)[RQ], const uint4_t (&xf)[RQ], const uint32_t (&sb)[4], const uint32_t (&zb)[4]) {
+    auto process_unit = [&](const uint4_t (&w)[RQ], const uint4_t (&xf)[RB][RQ], const uint32_t (&sb)[4], const uint32_t (&zb)[4]) {
         // ---- this lane's 16 entries (q = 4*kb .. 4*kb+3 of its four columns), each stored for both bank replicas;
         // 16-bit value in the low half of a dword
 #pragma unroll
@@ -800,14 +808,15 @@ __device__ __forceinline__ void lutm_body(const LutmView& lv, const int tile_loc
                 if (more) issue(lb, (st + 1) >> 2, (st + 1) & 3);
                 wait_pack(la, more, b);
             }
-            acc[f] = lutm_mfma<DT>(b, xf[rq], acc[f]);
+#pragma unroll
+            for (int rb = 0; rb < RB; rb++) acc[rb][f] = lutm_mfma<DT>(b, xf[rb][rq], acc[rb][f]);
         }
     };
 
     // one unit per wave is the normal plan (its rows, activations and constants are requested up front, constants first so that
     // the table is built under the row latency); further units of a wave (very wide layers) are taken one after the other
     uint4_t wa[RQ], wn[RQ];
-    uint4_t xa[RQ], xn[RQ];
+    uint4_t xa[RB][RQ], xn[RB][RQ];
     uint32_t sa[4] = {0, 0, 0, 0}, za[4] = {0, 0, 0, 0}, sn[4] = {0, 0, 0, 0}, zn[4] = {0, 0, 0, 0};
     if (!PF || g1 - g0 <= 1) {  // the per-layer plan: one unit per wave (more only on very wide layers)
         for (int g = g0; g < g1; g++) {
@@ -836,13 +845,15 @@ __device__ __forceinline__ void lutm_body(const LutmView& lv, const int tile_loc
     // output of tile column 16 * kb' + 4 * r + f for x row m.  red[wave][m][64]
     __syncthreads();
     float* red = reinterpret_cast<float*>(tab);
-    if (c < M) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const float4_t v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
-            *reinterpret_cast<float4_t*>(red + ((wave * M + c) * 64 + 16 * kb + 4 * r)) = v;
+    for (int b = 0; b < RB; b++)
+        if (16 * b + c < M) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float4_t v = {acc[b][0][r], acc[b][1][r], acc[b][2][r], acc[b][3][r]};
+                *reinterpret_cast<float4_t*>(red + ((wave * M + 16 * b + c) * 64 + 16 * kb + 4 * r)) = v;
+            }
         }
-    }
     __syncthreads();
     // wave w finishes x rows m = w, w + NW, ...: lane = column of the tile
     const int n = nt0 + lane;
@@ -912,8 +923,8 @@ __global__ __launch_bounds__(NW * 64, 2) void mpq_gemv_lutm_kernel(const LutArgs
 
 // ONE launch over a LIST of layers, 3 <= M <= 16 (bie_mpq_list_*): block b -> {entry, tile | slice << 20}; the entry's granules and
 // generation words are its own (tile numbers local to the entry).
-template <int DT, int ZM, int RPG, int NW, bool PF>
-__global__ __launch_bounds__(NW * 64, 2) void mpq_lutm_list_kernel(const ListEntry* __restrict__ ent, const uint2_t* __restrict__ blk, const int M,
+template <int DT, int ZM, int RPG, int NW, bool PF, int RB>
+__global__ __launch_bounds__(NW * 64, (RB == 1 ? 2 : 1)) void mpq_lutm_list_kernel(const ListEntry* __restrict__ ent, const uint2_t* __restrict__ blk, const int M,
                                                                   const unsigned epoch, unsigned* status, const unsigned tag_skew, const int spin_limit) {
     typedef const __attribute__((address_space(4))) uint2_t cu2_t;
     typedef const __attribute__((address_space(4))) ListEntry cent_t;
@@ -921,7 +932,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mpq_lutm_list_kernel(const ListEnt
     cent_t* e = (cent_t*)(uintptr_t)(ent + rec.x);
     const int tile = (int)(rec.y & 0xfffffu), slice = (int)(rec.y >> 20);
     const LutmView v{e->qw, e->scales, e->zeros, e->bias, e->y, e->x, e->gran, e->gen, e->N, M, e->K, e->G, e->S, e->gpw, e->hshift, (long)e->tiles * 64};
-    lutm_body<DT, ZM, RPG, NW, PF>(v, tile, tile, slice, epoch, status, tag_skew, spin_limit);
+    lutm_body<DT, ZM, RPG, NW, PF, RB>(v, tile, tile, slice, epoch, status, tag_skew, spin_limit);
 }
 
 #ifdef BIE_LAB_BUILD
@@ -1159,15 +1170,15 @@ static void lutm_launch(const LutArgs& a, int rpg, int grid, int zm, hipStream_t
 }
 
 // the list form of the matrix-pipe kernel (mpq_list.hip builds the entries and the block table)
-template <int DT, bool PF>
+template <int DT, bool PF, int RB>
 static void lutm_list_launch_dt(const ListEntry* ent, const uint2_t* blk, unsigned grid, int M, int rpg, int zm, unsigned epoch, unsigned* status,
                                 unsigned skew, int spin, hipStream_t st) {
 #define BIE_LUTML(ZMV)                                                                                                                               \
     switch (rpg) {                                                                                                                                   \
-        case 4: hipLaunchKernelGGL((mpq_lutm_list_kernel<DT, ZMV, 4, 8, PF>), dim3(grid), dim3(512), 0, st, ent, blk, M, epoch, status, skew, spin); break;   \
-        case 8: hipLaunchKernelGGL((mpq_lutm_list_kernel<DT, ZMV, 8, 8, PF>), dim3(grid), dim3(512), 0, st, ent, blk, M, epoch, status, skew, spin); break;   \
-        case 16: hipLaunchKernelGGL((mpq_lutm_list_kernel<DT, ZMV, 16, 8, PF>), dim3(grid), dim3(512), 0, st, ent, blk, M, epoch, status, skew, spin); break; \
-        default: hipLaunchKernelGGL((mpq_lutm_list_kernel<DT, ZMV, 32, 8, PF>), dim3(grid), dim3(512), 0, st, ent, blk, M, epoch, status, skew, spin); break; \
+        case 4: hipLaunchKernelGGL((mpq_lutm_list_kernel<DT, ZMV, 4, 8, PF, RB>), dim3(grid), dim3(512), 0, st, ent, blk, M, epoch, status, skew, spin); break;   \
+        case 8: hipLaunchKernelGGL((mpq_lutm_list_kernel<DT, ZMV, 8, 8, PF, RB>), dim3(grid), dim3(512), 0, st, ent, blk, M, epoch, status, skew, spin); break;   \
+        case 16: hipLaunchKernelGGL((mpq_lutm_list_kernel<DT, ZMV, 16, 8, PF, RB>), dim3(grid), dim3(512), 0, st, ent, blk, M, epoch, status, skew, spin); break; \
+        default: hipLaunchKernelGGL((mpq_lutm_list_kernel<DT, ZMV, 32, 8, PF, RB>), dim3(grid), dim3(512), 0, st, ent, blk, M, epoch, status, skew, spin); break; \
     }
     if (zm == ZM_ASYM) { BIE_LUTML(ZM_ASYM) }
     else { BIE_LUTML(ZM_SYM) }
@@ -1180,8 +1191,12 @@ int mpq_lutm_list_launch(const ListEntry* ent, const uint2_t* blk, unsigned grid
     const unsigned epoch = next_launch_epoch();
     // (the next-unit prefetch variant, PF = true, needs 139 registers: one 8-wave workgroup per CU instead of two -- measured 8.4 against
     //  6.7 us per 4096x11008 layer at M = 8, profiles/r03_z_lutm_list_ab.txt; not instantiated)
-    if (dtype == BIE_F16) lutm_list_launch_dt<BIE_F16, false>(ent, blk, grid, M, rpg, zm, epoch, device_status_word(), skew, spin, st);
-    else lutm_list_launch_dt<BIE_BF16, false>(ent, blk, grid, M, rpg, zm, epoch, device_status_word(), skew, spin, st);
+    // 17 <= M <= 32: two 16-row blocks of x per pass over the weights (one 8-wave workgroup per CU: ~135 registers)
+    if (M > 16) {
+        if (dtype == BIE_F16) lutm_list_launch_dt<BIE_F16, false, 2>(ent, blk, grid, M, rpg, zm, epoch, device_status_word(), skew, spin, st);
+        else lutm_list_launch_dt<BIE_BF16, false, 2>(ent, blk, grid, M, rpg, zm, epoch, device_status_word(), skew, spin, st);
+    } else if (dtype == BIE_F16) lutm_list_launch_dt<BIE_F16, false, 1>(ent, blk, grid, M, rpg, zm, epoch, device_status_word(), skew, spin, st);
+    else lutm_list_launch_dt<BIE_BF16, false, 1>(ent, blk, grid, M, rpg, zm, epoch, device_status_word(), skew, spin, st);
     return check_launch("mpq_lutm_list_kernel");
 }
 

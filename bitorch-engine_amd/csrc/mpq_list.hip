@@ -533,8 +533,8 @@ static void list_plan(int n, const bie_mpq_list_entry* ent, int w_bit, int group
 }
 
 static bool list_shape_ok(int n, const bie_mpq_list_entry* ent, int M, int w_bit, int group_size) {
-    if (n <= 0 || !ent || M < 1 || M > 16 || (w_bit != 4 && w_bit != 2)) return false;
-    if (M > 2 && w_bit != 4) return false;  // 3 <= M <= 16: the matrix-pipe list kernel (mpq_gemv_lut.hip), W4 only
+    if (n <= 0 || !ent || M < 1 || M > 32 || (w_bit != 4 && w_bit != 2)) return false;
+    if (M > 2 && w_bit != 4) return false;  // 3 <= M <= 32: the matrix-pipe list kernel (mpq_gemv_lut.hip; 17 .. 32 rows: two row blocks per pass), W4 only
     const int NB = 32 / w_bit;
     int gs0 = -1;
     for (int i = 0; i < n; i++) {
@@ -605,8 +605,8 @@ int mpq_list_create(MpqList** out, int n, const bie_mpq_list_entry* ent, int M, 
         if (asym) BIE_REQUIRE(ent[i].N % (32 / w_bit) == 0, BIE_ERR_INVALID_ARG, "bie_mpq_list_create: asym needs N %% %d == 0 (entry %d)", 32 / w_bit, i);
         if (M > 2) {
             BIE_REQUIRE(ent[i].depends_on < 0, BIE_ERR_UNSUPPORTED, "bie_mpq_list_create: dependent entries need M <= 2 (entry %d, M = %d)", i, M);
-            BIE_REQUIRE(ent[i].N % 4 == 0, BIE_ERR_UNSUPPORTED, "bie_mpq_list_create: 3 <= M <= 16 needs N %% 4 == 0 (entry %d)", i);
-            BIE_REQUIRE((reinterpret_cast<uintptr_t>(ent[i].x) & 15) == 0 && ent[i].K % 8 == 0, BIE_ERR_INVALID_ARG, "bie_mpq_list_create: 3 <= M <= 16 needs a 16-byte aligned x and K %% 8 == 0 (entry %d)", i);
+            BIE_REQUIRE(ent[i].N % 4 == 0, BIE_ERR_UNSUPPORTED, "bie_mpq_list_create: 3 <= M <= 32 needs N %% 4 == 0 (entry %d)", i);
+            BIE_REQUIRE((reinterpret_cast<uintptr_t>(ent[i].x) & 15) == 0 && ent[i].K % 8 == 0, BIE_ERR_INVALID_ARG, "bie_mpq_list_create: 3 <= M <= 32 needs a 16-byte aligned x and K %% 8 == 0 (entry %d)", i);
         }
         BIE_REQUIRE((reinterpret_cast<uintptr_t>(ent[i].x) & 3) == 0, BIE_ERR_INVALID_ARG, "bie_mpq_list_create: x of entry %d must be 4-byte aligned", i);
     }
@@ -733,7 +733,7 @@ int mpq_list_forward(MpqList* p, hipStream_t st) {
         const hipError_t e = hipMemsetAsync(p->d_done, 0, p->done_bytes, st);
         BIE_REQUIRE(e == hipSuccess, BIE_ERR_HIP, "bie_mpq_list_forward: hipMemsetAsync: %s", hipGetErrorString(e));
     }
-    if (p->lutm)  // 2 / 3 <= M <= 16: lookups feeding v_mfma_f32_16x16x32 (mpq_gemv_lut.hip), same entries and block table
+    if (p->lutm)  // 2 / 3 <= M <= 32: lookups feeding v_mfma_f32_16x16x32 (mpq_gemv_lut.hip), same entries and block table
         return mpq_lutm_list_launch(p->d_ent, p->d_blk, p->grid, p->M, p->rpg, p->zm, p->dtype, st);
     ListArgs a;
     a.ent = p->d_ent;

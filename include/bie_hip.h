@@ -105,7 +105,7 @@ int bie_mpq_forward_grouped(const void* x, int n_sets, const int32_t* const* qwe
                             void* workspace, size_t workspace_bytes, int M, int K, int w_bit, int group_size,
                             int asym, int dtype, void* stream);
 
-/* A LIST of decode layers (M <= 2; w_bit 4: M <= 16, batched / speculative decode) in ONE launch.  Entry i computes y_i[M, N_i] = x_i[M, K_i] . dequant(qweight_i) (+ bias_i)
+/* A LIST of decode layers (M <= 2; w_bit 4: M <= 32 -- 17 .. 32 rows as two row blocks per pass over the weights -- batched / speculative decode) in ONE launch.  Entry i computes y_i[M, N_i] = x_i[M, K_i] . dequant(qweight_i) (+ bias_i)
  * exactly as bie_mpq_forward with g_idx = NULL would; entries may differ in K, N and in their x / y buffers, while w_bit (4 or
  * 2), group_size, dtype (fp16 / bf16) and asym are common to the list.  `depends_on` >= 0 names an EARLIER entry whose y buffer
  * is this entry's x (a chain y_l -> x_{l+1}): the dependent entry's workgroups request their weight rows first and then wait for

@@ -1405,7 +1405,10 @@ def _list_case(specs, dt, w_bit, gs, asym, M, seed, chain=False):
                                                   (orc.BF16, 2, 128, 0, 1), (orc.F16, 2, 64, 1, 2), (orc.BF16, 4, 256, 0, 2),
                                                   # 3 <= M <= 16: the lookup / matrix-pipe kernel in list form (mpq_lutm_list_kernel)
                                                   (orc.BF16, 4, 128, 0, 3), (orc.F16, 4, 64, 1, 8), (orc.BF16, 4, 32, 0, 16), (orc.F16, 4, 256, 0, 5),
-                                                  (orc.BF16, 4, 128, 1, 16)])
+                                                  (orc.BF16, 4, 128, 1, 16),
+                                                  # 17 <= M <= 32: the same kernel with two 16-row blocks of x per pass over the weights
+                                                  (orc.BF16, 4, 128, 0, 17), (orc.F16, 4, 64, 1, 24), (orc.BF16, 4, 32, 1, 32), (orc.F16, 4, 256, 0, 31),
+                                                  (orc.BF16, 4, 64, 0, 32)])
 def test_list_forward_mixed_shapes_vs_oracle_and_single_calls(dt, w_bit, gs, asym, M):
     """bie_mpq_list_forward: entries with different K / N (ragged column tiles, N % 64 = 8, 40), bias on some, each with its own x;
     small list -> groups split over waves and K sliced over workgroups (tagged-granule reduction inside the launch).  Every entry
@@ -1460,15 +1463,15 @@ def test_list_forward_big_list_whole_k_per_workgroup_and_graph_replay(M):
             assert_close(entries[i]["y"], oracle_forward(newx[i], qw, scales, zeros, None, 4, 128, 0, orc.BF16, bias), orc.BF16, f"replay {rep} entry {i}")
 
 
-@pytest.mark.parametrize("dt,gs,asym,M", [(orc.BF16, 128, 0, 17), (orc.F16, 64, 1, 24), (orc.BF16, 128, 0, 40), (orc.BF16, 32, 0, 64)])
-def test_list_forward_row_blocks_for_17_to_64_rows(dt, gs, asym, M):
-    """16 < M <= 64: MPQForwardList cuts the rows into balanced blocks of <= 16, one single-launch plan per block over the row slices of
+@pytest.mark.parametrize("dt,gs,asym,M", [(orc.BF16, 128, 0, 33), (orc.F16, 64, 1, 40), (orc.BF16, 128, 0, 48), (orc.BF16, 32, 0, 64)])
+def test_list_forward_row_blocks_for_33_to_64_rows(dt, gs, asym, M):
+    """32 < M <= 64: MPQForwardList cuts the rows into two balanced blocks of <= 32, one single-launch plan per block over the row slices of
     every x / y; every entry against the oracle."""
     from bitorch_engine.layers.qlinear.nbit.cuda import MPQForwardList
     specs = [(1024, 208, True), (512, 528, False), (2048, 64, True)]
     entries, host = _list_case(specs, dt, 4, gs, asym, M, seed=7100 + M)
     plan = MPQForwardList(entries, w_bit=4, group_size=gs, asym=bool(asym))
-    assert plan.launches == (M + 15) // 16 and plan.M == M
+    assert plan.launches == 2 and plan.M == M
     plan()
     torch.cuda.synchronize()
     for i, (e, (x, qw, scales, zeros, bias)) in enumerate(zip(entries, host)):
