@@ -109,8 +109,9 @@ def test_list_plan_validation_without_a_device():
     ok = (E * 2)(E(8, 8, 8, 8, None, 8, 4096, 4096, -1, 0), E(8, 8, 8, 8, None, 8, 4096, 11008, -1, 0))
     n = L.bie_mpq_list_device_bytes(2, ok, 1, 4, 128)
     assert n >= 2 * 128 + (64 + 172) * 8
-    assert L.bie_mpq_list_device_bytes(2, ok, 3, 4, 128) > 0   # 3 <= M <= 16: the matrix-pipe list kernel (W4 only)
-    assert L.bie_mpq_list_device_bytes(2, ok, 17, 4, 128) == 0  # M > 16
+    assert L.bie_mpq_list_device_bytes(2, ok, 3, 4, 128) > 0   # 3 <= M <= 32: the matrix-pipe list kernel (W4 only)
+    assert L.bie_mpq_list_device_bytes(2, ok, 17, 4, 128) > 0  # 17 .. 32: two row blocks per pass
+    assert L.bie_mpq_list_device_bytes(2, ok, 33, 4, 128) == 0  # M > 32
     assert L.bie_mpq_list_device_bytes(2, ok, 3, 2, 128) == 0   # W2: M <= 2
     assert L.bie_mpq_list_device_bytes(2, ok, 1, 8, 128) == 0  # w_bit 8
     bad = (E * 1)(E(8, 8, 8, 8, None, 8, 4000, 64, -1, 0))
