@@ -636,7 +636,7 @@ __global__ __launch_bounds__(256) void mpq_gemv_lutc_kernel(const LutArgs a) {
 }
 
 // =====================================================================================================================
-// Matrix-pipe form (M <= 16): the products go to the otherwise idle MFMA unit.  v_mfma_f32_16x16x32 wants, per lane, the 8
+// Matrix-pipe form (M <= 16; 17 <= M <= 32 with two row blocks, RB = 2): the products go to the otherwise idle MFMA unit.  v_mfma_f32_16x16x32 wants, per lane, the 8
 // consecutive-k weights of ONE column -- exactly one packed W4 word.  Lane (kb, c) = (lane >> 4, lane & 15) loads FOUR adjacent
 // columns 4c .. 4c+3 of packed row 4*rq + kb with one 16-byte load (a wave instruction = 4 full 256-byte row segments), the
 // four words are the A fragments of four MFMAs: fragment f's row c is column 4c + f of the tile.  A word's eight table values
@@ -673,7 +673,7 @@ __device__ __forceinline__ void lutm_issue8(uint32_t (&l)[8], uint32_t ca, uint3
 }
 
 // what one workgroup of the matrix-pipe form needs about its layer: filled from the kernel arguments (one launch per layer / set of
-// layers sharing x) or from a device-resident ListEntry (bie_mpq_list_*, 3 <= M <= 16: many layers in one launch)
+// layers sharing x) or from a device-resident ListEntry (bie_mpq_list_*, 3 <= M <= 32: many layers in one launch)
 struct LutmView {
     const uint32_t* qw; const uint16_t* scales; const void* zeros; const uint16_t* bias; uint16_t* y; const uint16_t* x;
     unsigned long long* gran;  // [S-1][M][ncat] granules of the launch / of the list entry
@@ -907,8 +907,8 @@ __device__ __forceinline__ void lutm_body(const LutmView& lv, const int tile_loc
 }
 
 
-template <int DT, int ZM, int RPG, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void mpq_gemv_lutm_kernel(const LutArgs a) {
+template <int DT, int ZM, int RPG, int NW, int RB>
+__global__ __launch_bounds__(NW * 64, (RB == 1 ? 2 : 1)) void mpq_gemv_lutm_kernel(const LutArgs a) {
     const int tile = blockIdx.x % a.tiles_total;
     const int slice = blockIdx.x / a.tiles_total;
     int si = 0;
@@ -918,10 +918,10 @@ __global__ __launch_bounds__(NW * 64, 2) void mpq_gemv_lutm_kernel(const LutArgs
     const LutSet& ls = a.set[si];
     const LutmView v{ls.qw, ls.scales, ls.zeros, ls.bias, ls.y, a.x, a.gran, a.gen, ls.N, a.M, a.K, a.G, a.S, a.groups_per_wave, a.hshift,
                      (long)a.tiles_total * 64};
-    lutm_body<DT, ZM, RPG, NW, false>(v, tile - ls.tile_begin, tile, slice, a.epoch, a.status, a.tag_skew, a.spin_limit);
+    lutm_body<DT, ZM, RPG, NW, false, RB>(v, tile - ls.tile_begin, tile, slice, a.epoch, a.status, a.tag_skew, a.spin_limit);
 }
 
-// ONE launch over a LIST of layers, 3 <= M <= 16 (bie_mpq_list_*): block b -> {entry, tile | slice << 20}; the entry's granules and
+// ONE launch over a LIST of layers, 3 <= M <= 32 (bie_mpq_list_*): block b -> {entry, tile | slice << 20}; the entry's granules and
 // generation words are its own (tile numbers local to the entry).
 template <int DT, int ZM, int RPG, int NW, bool PF, int RB>
 __global__ __launch_bounds__(NW * 64, (RB == 1 ? 2 : 1)) void mpq_lutm_list_kernel(const ListEntry* __restrict__ ent, const uint2_t* __restrict__ blk, const int M,
@@ -948,7 +948,7 @@ static int lut_env(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
-// W4, implicit groups of 32 / 64 / 128 / 256 that tile K exactly.  FMA form: bf16, M <= 2.  Matrix-pipe form: fp16 / bf16, M <= 16.
+// W4, implicit groups of 32 / 64 / 128 / 256 that tile K exactly.  FMA form: bf16, M <= 2.  Matrix-pipe form: fp16 / bf16, M <= 16 per layer (17 .. 32 in list launches only).
 // Measured (4096x11008 / 4096x4096, us per launch): bf16 M = 1: FMA form 10.05 / 5.92, matrix-pipe 11.66 / 6.84 -> FMA form;
 // M = 2: 15.1 / 7.3 against 11.8 / 6.8; M = 4, 8, 16: 12.2 / 7.3, 13.0 / 7.9, 15.7 / 10.0 against the MFMA GEMM's 18.7-20.2 /
 // 10.5-12.2 -> matrix-pipe form for 2 <= M <= 16.  fp16 has no FMA form: matrix-pipe from M = 1 (11.5 us against the dot2
@@ -1154,20 +1154,24 @@ static void lutc_launch(const LutArgs& a, int rpg, int grid, int M, int zm, hipS
     }
 }
 
-template <int DT>
-static void lutm_launch(const LutArgs& a, int rpg, int grid, int zm, hipStream_t st) {
+template <int DT, int RB>
+static void lutm_launch_rb(const LutArgs& a, int rpg, int grid, int zm, hipStream_t st) {
 #define BIE_LUTM(ZMV)                                                                                                          \
     switch (rpg) {                                                                                                             \
-        case 4: hipLaunchKernelGGL((mpq_gemv_lutm_kernel<DT, ZMV, 4, 8>), dim3(grid), dim3(512), 0, st, a); break;             \
-        case 8: hipLaunchKernelGGL((mpq_gemv_lutm_kernel<DT, ZMV, 8, 8>), dim3(grid), dim3(512), 0, st, a); break;             \
-        case 16: hipLaunchKernelGGL((mpq_gemv_lutm_kernel<DT, ZMV, 16, 8>), dim3(grid), dim3(512), 0, st, a); break;           \
-        default: hipLaunchKernelGGL((mpq_gemv_lutm_kernel<DT, ZMV, 32, 8>), dim3(grid), dim3(512), 0, st, a); break;           \
+        case 4: hipLaunchKernelGGL((mpq_gemv_lutm_kernel<DT, ZMV, 4, 8, RB>), dim3(grid), dim3(512), 0, st, a); break;         \
+        case 8: hipLaunchKernelGGL((mpq_gemv_lutm_kernel<DT, ZMV, 8, 8, RB>), dim3(grid), dim3(512), 0, st, a); break;         \
+        case 16: hipLaunchKernelGGL((mpq_gemv_lutm_kernel<DT, ZMV, 16, 8, RB>), dim3(grid), dim3(512), 0, st, a); break;       \
+        default: hipLaunchKernelGGL((mpq_gemv_lutm_kernel<DT, ZMV, 32, 8, RB>), dim3(grid), dim3(512), 0, st, a); break;       \
     }
     if (zm == ZM_ASYM) { BIE_LUTM(ZM_ASYM) }
     else if (zm == ZM_FUSED) { BIE_LUTM(ZM_FUSED) }
     else { BIE_LUTM(ZM_SYM) }
 #undef BIE_LUTM
 }
+// Per-layer launches stay at M <= 16: with two row blocks (RB = 2, one workgroup per CU) a lone layer measured 22.7-28.9 us at
+// 4096x11008 for M = 17 .. 32 against 20.2-21.3 us for the MFMA GEMM -- the form pays only in list launches (9.4-10.5 us per layer).
+template <int DT>
+static void lutm_launch(const LutArgs& a, int rpg, int grid, int zm, hipStream_t st) { lutm_launch_rb<DT, 1>(a, rpg, grid, zm, st); }
 
 // the list form of the matrix-pipe kernel (mpq_list.hip builds the entries and the block table)
 template <int DT, bool PF, int RB>

@@ -128,7 +128,7 @@ for dt in (orc.F16, orc.BF16):
 
 
 @pytest.mark.parametrize("dt,w_bit,asym", CASES)
-@pytest.mark.parametrize("M", [1, 2, 3, 8, 9, 33, 70, 300])
+@pytest.mark.parametrize("M", [1, 2, 3, 8, 9, 17, 24, 32, 33, 70, 300])  # W4: 17 .. 32 = the lookup / matrix-pipe kernel with two row blocks
 def test_mpq_forward_vs_oracle(dt, w_bit, asym, M):
     rng = np.random.default_rng(1000 * w_bit + 10 * M + asym + 7 * dt)
     K, N, gs = 512, 384, 128
