@@ -335,7 +335,7 @@ def bench_binary(dev, L):
         if L.bie_binary_fp4_image(w.data_ptr(), img.data_ptr(), N, K, st0):
             raise RuntimeError(L.bie_last_error().decode())
         wimgs.append(img)
-    for M in (256, 512, 4096, 8192):
+    for M in (192, 512, 4096, 8192):
         xp = torch.randint(0, 256, (M, K // 8), dtype=torch.int32, device=dev).to(torch.uint8)
         xv = torch.randn((M, K), device=dev).to(BF16)
         y = torch.empty((M, N), dtype=torch.float32, device=dev)
@@ -396,7 +396,7 @@ def bench_binary(dev, L):
         try:
             us = time_graph(capture(fn), 20)
             tops = 2.0 * B * 49 * 512 * 4608 / us / 1e6
-            fp4 = B * 49 >= 3072  # the dispatch of extensions/_binary_common.py::conv2d: large batches run as an FP4 GEMM on the matrix pipe
+            fp4 = B * 49 >= 1024  # the dispatch of extensions/_binary_common.py::conv2d: large batches run as an FP4 GEMM on the matrix pipe
             peak = FP4_MFMA_PEAK_TOPS if fp4 else XOR_POPC_PEAK_TOPS
             out.append({"op": "binary conv 512->512 3x3 on 7x7", "B": B, "us_per_call": round(us, 2), "TOP/s": round(tops, 2),
                         "roofline": {"bound": "mfma fp4 (bits + image passes included in the time)" if fp4 else "valu xor+bcnt", "achieved": round(tops, 2),

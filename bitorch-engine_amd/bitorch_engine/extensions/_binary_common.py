@@ -45,7 +45,7 @@ def fp4_min_rows() -> int:
     """Smallest M served by the matrix-pipe (FP4 image) form of the binary GEMM; below it the XNOR kernels win (two extra small
     launches and a 4x larger activation operand).  BIE_FP4_MIN_M overrides (0 switches the form off)."""
     v = os.environ.get("BIE_FP4_MIN_M")
-    return int(v) if v else 256
+    return int(v) if v else 192
 
 
 def fp4_image(rowpacked: torch.Tensor, rows: int, K: int, out: torch.Tensor = None) -> torch.Tensor:
@@ -176,10 +176,10 @@ def conv_weight_taps(wpacked, OC, C, ksize):
 
 def conv_fp4_min_rows() -> int:
     """Smallest number of output pixels (B * OH * OW) the matrix-pipe form of the conv serves (BIE_FP4_CONV_MIN_ROWS; 0 = off).
-    Measured on the ResNet-18 stage shapes (profiles/r03_fp4_g_conv_ab.txt): from ~3000 pixels up it is never slower than the XNOR tap
-    form (1.0-2.4x); below, its three launches and the small GEMM grid lose to the tap kernels."""
+    Measured on the ResNet-18 stage shapes (profiles/r03_fp4_g_conv_ab.txt, r03_fp4_h_tile64.txt): with the 128 x 64 GEMM tile for small
+    grids it is ahead of the XNOR tap form from ~1000 pixels up (1.0-2.4x); below, its three launches lose to the tap kernels."""
     v = os.environ.get("BIE_FP4_CONV_MIN_ROWS")
-    return int(v) if v else 3072
+    return int(v) if v else 1024
 
 
 def conv_weight_fp4_image(wpacked, OC, C, ksize):

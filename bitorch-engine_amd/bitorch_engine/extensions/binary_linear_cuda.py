@@ -71,7 +71,7 @@ def forward(input: torch.Tensor, weights: torch.Tensor, bmm_type: int, transpose
 
 
 def layer_forward(input, bias_a, weights, bmm_type, scale_a, scale_w):
-    """BinaryLinearCuda's whole forward: M >= 256 on the matrix pipe in two launches (xnor_layer_fp4); M <= 64 (M <= 512 when K % 512 == 0) in one launch: `((x + bias_a) >= 0)` bits, XNOR-popcount,
+    """BinaryLinearCuda's whole forward: M >= 192 on the matrix pipe in two launches (xnor_layer_fp4); M <= 64 (M <= 512 when K % 512 == 0) in one launch: `((x + bias_a) >= 0)` bits, XNOR-popcount,
     `.to(dtype) * scale_a * scale_w` (reference layers/qlinear/binary/cuda/layer.py:58-63, 283-284).  None when the shape is
     outside the fused range (the caller then composes the separate steps)."""
     m, k = input.shape

@@ -499,6 +499,10 @@ static void fp4_gemm_launch_dt(const uint8_t* ximg, const uint8_t* wimg, void* y
 #endif
         }
         BIE_FP4_GO(4, 0, grid, tn);
+    } else if (tile == 64 || (tile != 128 && cdivl(M, 128) * cdivl(N, 128) < 192)) {
+        // mid M: 128 x 64 tiles (wave tile 64 x 32) double the workgroups when the 128 x 128 grid would leave CUs idle
+        const int tn = (int)cdivl(N, 64);
+        hipLaunchKernelGGL((xnor_fp4_gemm_kernel<2, 1, 0, ODT>), dim3((unsigned)(cdivl(M, 128) * tn)), dim3(256), 0, st, ximg, wimg, y, (int)M, (int)N, KT, RBA, RBB, tn, scale, sa, sw, conv_p);
     } else {
         const int tn = (int)cdivl(N, 128);
         const dim3 grid((unsigned)(cdivl(M, 128) * tn));

@@ -83,7 +83,7 @@ def test_fp4_image_from_values_equals_pack_rows_then_image(tdt, rows, K, with_bi
     assert torch.equal(img, ref)
 
 
-@pytest.mark.parametrize("tile", ["128", "256"])
+@pytest.mark.parametrize("tile", ["64", "128", "256"])
 @pytest.mark.parametrize("var", ["0", "1"])
 @pytest.mark.parametrize("M,N,K", [(1, 1, 8), (32, 32, 128), (130, 70, 264), (256, 256, 384), (300, 520, 1000), (257, 129, 2048), (512, 384, 4096)])
 def test_fp4_gemm_bit_exact_vs_oracle(M, N, K, tile, var, monkeypatch):
@@ -163,7 +163,7 @@ def test_extension_forward_takes_the_matrix_pipe_for_large_m_and_matches_the_xno
     assert np.array_equal(y4.cpu().numpy(), orc.binary_linear_rowpacked(orc.binary_pack_rows(x.float().cpu().numpy()), wb, K, 0.25))
 
 
-@pytest.mark.parametrize("tile", ["128", "256"])
+@pytest.mark.parametrize("tile", ["64", "128", "256"])
 @pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("M,N,K", [(300, 264, 1024), (257, 100, 520), (512, 4096, 4096), (64, 72, 128)])
 def test_fp4_layer_epilogue_is_the_layer_expression(M, N, K, tdt, tile, monkeypatch):
@@ -216,7 +216,7 @@ def test_binary_cuda_layer_takes_the_matrix_pipe_at_large_m_and_matches_the_comp
     assert torch.equal(y.reshape(-1, N).cpu(), expect)
 
 
-@pytest.mark.parametrize("tile", ["128", "256"])
+@pytest.mark.parametrize("tile", ["64", "128", "256"])
 @pytest.mark.parametrize("B,C,H,W,OC,ks,st,pad,dil", [(2, 64, 7, 7, 64, 3, 1, 1, 1), (3, 32, 9, 11, 96, 3, 2, 1, 1), (2, 128, 8, 8, 72, 3, 1, 2, 2),
                                                        (1, 64, 6, 5, 64, 1, 1, 0, 1), (4, 96, 5, 5, 130, 5, 1, 2, 1), (33, 512, 7, 7, 512, 3, 1, 1, 1)])
 def test_fp4_conv_equals_the_oracle_and_the_tap_form(B, C, H, W, OC, ks, st, pad, dil, tile, monkeypatch):

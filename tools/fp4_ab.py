@@ -35,7 +35,7 @@ for M in (128, 192, 256, 384, 512, 1024, 2048, 4096, 8192):
     us = time_graph(capture(run_x), 10) / NS
     row["xnor_us"] = round(us, 2); row["xnor_TOPs"] = round(ops / us / 1e6, 1)
     yx = y.clone()
-    for tile in ("128", "256"):
+    for tile in ("64", "128", "256"):
         for var in ("0",):
             os.environ["BIE_FP4_TILE"], os.environ["BIE_FP4_VAR"] = tile, var
             def run_g(st):
