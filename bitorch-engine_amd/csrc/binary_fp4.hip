@@ -212,8 +212,11 @@ __global__ __launch_bounds__(256) void xnor_fp4_gemm_kernel(const uint8_t* __res
     // workgroups are dealt round-robin over the 8 XCDs: give every XCD one contiguous run of tiles (shared x rows stay in its L2)
     int bid = blockIdx.x;
     const int nblk = gridDim.x;
-    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
-    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+    // tile rows per XCD run (profiles/r03_pipe_gm_ab.txt): 4 everywhere (128 x 128 tiles 41 vs 51 us at 4096^3, the bf16 layer epilogue 105 vs 112 us
+    // at M = 4096 8192x8192) except the 256 x 256 tile with fp32 output, whose 1 KiB output rows go out faster one tile row at a time (8192^3: 246 vs 282 us)
+    constexpr int GM = (ODT == -1 && WM == 4) ? 1 : BIE_PIPE_GM;
+    int tile_m, tile_n;
+    pipe_tile(bid, nblk, tiles_n, GM, tile_m, tile_n);
 
     // this wave's LDS-DMA sources: pieces wave*PW .. +PW-1 of the stage image [A fragments (row block, k half)] [B fragments]
     const uint8_t* src[PW];

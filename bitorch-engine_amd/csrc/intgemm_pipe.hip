@@ -35,8 +35,8 @@ __global__ __launch_bounds__(256) void i8_pipe_gemm_kernel(const uint8_t* __rest
     const int wy = wave >> 1, wx = wave & 1;
     int bid = blockIdx.x;
     const int nblk = gridDim.x;
-    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);  // one contiguous run of tiles per XCD
-    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+    int tile_m, tile_n;
+    pipe_tile(bid, nblk, tiles_n, BIE_PIPE_GM, tile_m, tile_n);  // one contiguous run of tiles per XCD, BIE_PIPE_GM tile rows deep
     const int KT = K >> 6;
 
     // LDS-DMA sources: pieces of 16 rows x 64 bytes; [a rows of the tile][w rows of the tile]
@@ -183,8 +183,8 @@ __global__ __launch_bounds__(256) void i4_pipe_gemm_kernel(const uint8_t* __rest
     const int wy = wave >> 1, wx = wave & 1;
     int bid = blockIdx.x;
     const int nblk = gridDim.x;
-    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
-    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+    int tile_m, tile_n;
+    pipe_tile(bid, nblk, tiles_n, BIE_PIPE_GM, tile_m, tile_n);
     const int KT = K >> 7;             // 128 values = 64 bytes per stage
     const long rowbytes = K >> 1;
 

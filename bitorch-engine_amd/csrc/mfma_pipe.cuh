@@ -44,6 +44,21 @@ __device__ __forceinline__ void wait_frags(v4i_t (&a)[NA], v4i_t (&b)[NB]) {
 __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }  // >= 18 wait states: XDL write -> VALU read
 
 constexpr int imin(int a, int b) { return a < b ? a : b; }
+// Workgroup -> output tile.  Workgroup b runs on XCD b & 7: every XCD gets one contiguous run of the tile sequence (runs differ by one tile
+// when the grid is not a multiple of 8), and the sequence goes down gm tile rows before moving one tile column on, so the workgroups an XCD
+// runs at once share gm row panels and (its CUs / gm) column panels in that XCD's L2 instead of one row panel and a column panel each
+// (dense W4A16 GEMM, M = 4096, 4096 -> 11008: gm 1 -> 4 is 2-10 % of the launch, profiles/r03_dense_gm_ab.txt).
+#ifndef BIE_PIPE_GM
+#define BIE_PIPE_GM 4
+#endif
+__device__ __forceinline__ void pipe_tile(int bid, int nblk, int tiles_n, int gm, int& tile_m, int& tile_n) {
+    const int xcd = bid & 7, per = nblk >> 3, rem = nblk & 7;
+    bid = xcd * per + (xcd < rem ? xcd : rem) + (bid >> 3);
+    const int grp = bid / (gm * tiles_n), first_m = grp * gm, left = nblk / tiles_n - first_m, rows = left < gm ? left : gm, r = bid - grp * gm * tiles_n;
+    tile_n = r / rows;
+    tile_m = first_m + (r - tile_n * rows);
+}
+
 template <int I> struct ic_t { static constexpr int value = I; };
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {

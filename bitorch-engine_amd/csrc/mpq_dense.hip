@@ -58,7 +58,7 @@ __device__ __forceinline__ void mfma16(float16_t& c, const v4i_t& a, const v4i_t
 
 template <int DT, int WM, int WN>
 __global__ __launch_bounds__(256) void mpq_dense_gemm_kernel(const uint16_t* __restrict__ x, const uint8_t* __restrict__ wimg, const uint16_t* __restrict__ bias,
-                                                             uint16_t* __restrict__ y, int M, int N, int K, int tiles_n, int NB32) {
+                                                             uint16_t* __restrict__ y, int M, int N, int K, int tiles_n, int NB32, int gm) {
     constexpr int AF = 2 * WM, BF = 2 * WN;  // 32-row / 32-column blocks per workgroup tile
     constexpr int NFR = (AF + BF) * 2;       // KiB per stage (k = 32): x rows 64 bytes each, weight fragments 1 KiB per k16 step
     constexpr int PW = NFR / 4;              // LDS-DMA pieces per wave and stage
@@ -72,8 +72,8 @@ __global__ __launch_bounds__(256) void mpq_dense_gemm_kernel(const uint16_t* __r
     const int wy = wave >> 1, wx = wave & 1;
     int bid = blockIdx.x;
     const int nblk = gridDim.x;
-    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);  // one contiguous run of tiles per XCD
-    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+    int tile_m, tile_n;
+    pipe_tile(bid, nblk, tiles_n, gm, tile_m, tile_n);
     const int KT = K >> 5, KS = K >> 4;
 
     // this wave's LDS-DMA sources.  Stage image: [x: AF*2 pieces of 16 rows x 64 bytes][weights: BF*2 fragments (column block, k16 step)]
@@ -252,12 +252,13 @@ bool mpq_dense_ok(int M, int K, int N) {
     const int on = tuning ? env_int_dense("BIE_GEMM_DENSE", 1) : on_once, min_m = tuning ? env_int_dense("BIE_GEMM_DENSE_MIN_M", 1024) : min_once;
     if (!on || (K & 31) || (N & 7)) return false;
     if (on == 2) return true;  // forced (tests: every shape the kernels can take)
-    // profiles/r03_dense_ab2.txt (dense / fused time, 7 layer shapes x M = 512 .. 8192): with 256 x 256 tiles (>= 192 of them) the dense
-    // form is 0.90-0.98 of the fused time up to K = 5120 and 1.0-1.1 beyond (the dequantise pass grows with K*N, the GEMM does not gain);
-    // with 128 x 128 tiles it wins only on whole rounds of short-K square layers (0.93-0.94) and loses 1.1-1.7x elsewhere.
+    // profiles/r03_dense_ab4_gm4.txt (dense / fused time, 7 layer shapes x M = 512 .. 8192, tiles walked gm = 4 rows deep per XCD run): with
+    // 256 x 256 tiles (>= 192 of them) the dense form is 0.89-0.98 of the fused time up to K = 5120 at every M >= 1024, and beyond that K from
+    // M = 4096 on (0.89-1.0; at M = 2048 1.04-1.08: the dequantise pass is K*N work that only M amortises); with 128 x 128 tiles it wins
+    // only on whole rounds of short-K square layers (0.82-0.93) and loses 1.05-1.6x elsewhere.
     const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
     if (M < min_m) return false;
-    if (t256 >= 192) return K <= 5120;  // the grid dense_gemm_launch will use: 256 x 256 tiles
+    if (t256 >= 192) return K <= 5120 || M >= 4096;
     const long g128 = (long)cdiv(M, 128) * cdiv(N, 128);
     return K <= 4096 && g128 >= 256 && g128 % 256 == 0;
 }
@@ -283,16 +284,19 @@ template <int DT>
 static void dense_gemm_launch(const void* x, const void* img, const void* bias, void* y, int M, int K, int N, hipStream_t st) {
     const int NB32 = cdiv(N, 32);
     const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
-    static const int tile_once = env_int_dense("BIE_GEMM_DENSE_TILE", 0);
-    const int tile = getenv("BIE_TUNING") ? env_int_dense("BIE_GEMM_DENSE_TILE", 0) : tile_once;
+    static const int tile_once = env_int_dense("BIE_GEMM_DENSE_TILE", 0), gm_once = env_int_dense("BIE_GEMM_DENSE_GM", 4);
+    const bool tuning = getenv("BIE_TUNING") != nullptr;
+    const int tile = tuning ? env_int_dense("BIE_GEMM_DENSE_TILE", 0) : tile_once;
+    int gm = tuning ? env_int_dense("BIE_GEMM_DENSE_GM", 4) : gm_once;  // tile rows an XCD's run walks down before moving one tile column on
+    if (gm < 1) gm = 1;
     if (tile == 256 || (tile != 128 && t256 >= 192)) {
         const int tn = cdiv(N, 256);
         hipLaunchKernelGGL((mpq_dense_gemm_kernel<DT, 4, 4>), dim3((unsigned)t256), dim3(256), 0, st, (const uint16_t*)x, (const uint8_t*)img, (const uint16_t*)bias,
-                           (uint16_t*)y, M, N, K, tn, NB32);
+                           (uint16_t*)y, M, N, K, tn, NB32, gm);
     } else {
         const int tn = cdiv(N, 128);
         hipLaunchKernelGGL((mpq_dense_gemm_kernel<DT, 2, 2>), dim3((unsigned)(cdiv(M, 128) * tn)), dim3(256), 0, st, (const uint16_t*)x, (const uint8_t*)img,
-                           (const uint16_t*)bias, (uint16_t*)y, M, N, K, tn, NB32);
+                           (const uint16_t*)bias, (uint16_t*)y, M, N, K, tn, NB32, gm);
     }
 }
 
