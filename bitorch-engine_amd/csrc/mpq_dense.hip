@@ -23,30 +23,40 @@
 namespace bie {
 
 // ---- pass 1: packed weights -> dequantised fragments -------------------------------------------------------------
-template <int DT, int WBIT, int ZM>
+// One wave takes FPW consecutive fragments of one 32-column block (FPW divides K / 16, so they share the block): FPW independent packed
+// loads in flight, FPW KiB of the image written back to back.
+template <int DT, int WBIT, int ZM, int FPW>
 __global__ __launch_bounds__(256) void mpq_dequant_frag_kernel(const uint32_t* __restrict__ qw, const uint16_t* __restrict__ scales, const void* __restrict__ zeros,
                                                                uint4_t* __restrict__ img, int N, int gshift, long nfrag, int ks_per_col) {
-    const long f = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (f >= nfrag) return;
+    const long f0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * FPW;
+    if (f0 >= nfrag) return;
     const int lane = threadIdx.x & 63;
-    const long nb = f / ks_per_col;
-    const int ks = (int)(f - nb * ks_per_col);
+    const long nb = f0 / ks_per_col;
+    const int ks0 = (int)(f0 - nb * ks_per_col);
     int n = (int)nb * 32 + (lane & 31);
     if (n > N - 1) n = N - 1;  // columns past N: valid values nobody stores
-    const int c8 = ks * 2 + (lane >> 5);
-    const long g = (long)(c8 * 8) >> gshift;
-    const uint2_t raw = load_chunk<WBIT>(qw, c8, n, N);
-    const uint32_t sb = scales[g * N + n];
-    uint32_t zb;
-    if constexpr (ZM == ZM_ASYM) {
-        constexpr int NB = 32 / WBIT;
-        constexpr uint32_t M1 = (1u << WBIT) - 1u;
-        const uint32_t word = reinterpret_cast<const uint32_t*>(zeros)[g * (N / NB) + n / NB];
-        zb = ((word >> ((n % NB) * WBIT)) & M1) + 1u;
-    } else {
-        zb = reinterpret_cast<const uint16_t*>(zeros)[g * N + n];
+    uint2_t raw[FPW];
+    uint32_t sb[FPW], zb[FPW];
+#pragma unroll
+    for (int i = 0; i < FPW; i++) {
+        const int c8 = (ks0 + i) * 2 + (lane >> 5);
+        const long g = (long)(c8 * 8) >> gshift;
+        raw[i] = load_chunk<WBIT>(qw, c8, n, N);
+        sb[i] = scales[g * N + n];
+        if constexpr (ZM == ZM_ASYM) {
+            constexpr int NB = 32 / WBIT;
+            constexpr uint32_t M1 = (1u << WBIT) - 1u;
+            const uint32_t word = reinterpret_cast<const uint32_t*>(zeros)[g * (N / NB) + n / NB];
+            zb[i] = ((word >> ((n % NB) * WBIT)) & M1) + 1u;
+        } else {
+            zb[i] = reinterpret_cast<const uint16_t*>(zeros)[g * N + n];
+        }
     }
-    img[f * 64 + lane] = dequant8<DT, WBIT, ZM>(raw, c8, make_col_params<DT, WBIT, ZM, (WBIT == 4)>(sb, zb));
+#pragma unroll
+    for (int i = 0; i < FPW; i++) {
+        const int c8 = (ks0 + i) * 2 + (lane >> 5);
+        img[(f0 + i) * 64 + lane] = dequant8<DT, WBIT, ZM>(raw[i], c8, make_col_params<DT, WBIT, ZM, (WBIT == 4)>(sb[i], zb[i]));
+    }
 }
 
 // ---- pass 2: dense GEMM ----------------------------------------------------------------------------------------------
@@ -269,14 +279,17 @@ template <int DT, int ZM>
 static void dequant_frag_launch(const int32_t* qw, const void* scales, const void* zeros, void* img, int K, int N, int w_bit, int gshift, hipStream_t st) {
     const int KS = K / 16;
     const long nfrag = (long)cdiv(N, 32) * KS;
-    const dim3 grid((unsigned)cdivl(nfrag, 4));
-#define BIE_DQ(WB) hipLaunchKernelGGL((mpq_dequant_frag_kernel<DT, WB, ZM>), grid, dim3(256), 0, st, (const uint32_t*)qw, (const uint16_t*)scales, zeros, (uint4_t*)img, N, gshift, nfrag, KS)
+    const int fpw = (KS & 7) == 0 ? 8 : 1;
+    const dim3 grid((unsigned)cdivl(nfrag / fpw, 4));
+#define BIE_DQ2(WB, F) hipLaunchKernelGGL((mpq_dequant_frag_kernel<DT, WB, ZM, F>), grid, dim3(256), 0, st, (const uint32_t*)qw, (const uint16_t*)scales, zeros, (uint4_t*)img, N, gshift, nfrag, KS)
+#define BIE_DQ(WB) do { if (fpw == 8) BIE_DQ2(WB, 8); else BIE_DQ2(WB, 1); } while (0)
     switch (w_bit) {
         case 1: BIE_DQ(1); break;
         case 2: BIE_DQ(2); break;
         case 4: BIE_DQ(4); break;
         default: BIE_DQ(8); break;
     }
+#undef BIE_DQ2
 #undef BIE_DQ
 }
 
