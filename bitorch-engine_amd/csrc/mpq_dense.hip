@@ -268,7 +268,9 @@ bool mpq_dense_ok(int M, int K, int N) {
     // only on whole rounds of short-K square layers (0.82-0.93) and loses 1.05-1.6x elsewhere.
     const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
     if (M < min_m) return false;
-    if (t256 >= 192) return K <= 5120 || M >= 4096;
+    // beyond K = 5120 from M = 4096 while the image (K*N*2 bytes) stays inside the 256 MiB MALL, from M = 8192 when it does not (8192 -> 28672, 470 MB:
+    // 1.007 at M = 4096 in the A/B, 1.02 in the bench's two-layer rotation, 0.954 at M = 8192)
+    if (t256 >= 192) return K <= 5120 || M >= ((long)K * N * 2 > (192l << 20) ? 8192 : 4096);
     const long g128 = (long)cdiv(M, 128) * cdiv(N, 128);
     return K <= 4096 && g128 >= 256 && g128 % 256 == 0;
 }
