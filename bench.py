@@ -74,8 +74,27 @@ def capture(run):
     return g
 
 
+PREROLL_S = float(os.environ.get("BIE_BENCH_PREROLL_S", "0.06"))  # untimed replays in front of every timed region
+
+
+def preroll(replay, seconds=None):
+    """Replay untimed until `seconds` of wall clock have passed: a region of a few milliseconds timed right after host-side set-up
+    (layer construction, capture) runs at the clock the idle chip was at, 7-10 % under the clock it holds under load (measured on the
+    headline: 0.62-0.64 of the roofline timed cold against 0.67-0.69 after 30 ms of the same launches, profiles/r03_bench_preroll.txt)."""
+    seconds = PREROLL_S if seconds is None else seconds
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        replay()
+        n += 1
+        if n % 8 == 0:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    return n
+
+
 def time_graph(g, reps):
-    """Microseconds per replay from HIP events on the current stream."""
+    """Microseconds per replay from HIP events on the current stream (after `preroll`)."""
+    preroll(g.replay)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
@@ -592,22 +611,43 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_region():
+        """EXACTLY K passes between two barriers: (wall seconds, max over ranks; GPU milliseconds between the events on this rank)."""
+        barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(args.steps if distributed else 1):  # one replay holds the K passes on a single GPU
+            step()
+        ev1.record()
+        barrier()
+        el = time.perf_counter() - t0
+        ms = ev0.elapsed_time(ev1)
+        if distributed:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, ms
+
     for _ in range(args.warmup if distributed else max(1, -(-args.warmup // args.steps))):  # at least W warm-up passes
         step()
-    barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps if distributed else 1):  # exactly K passes either way
+    # The W warm-up passes last about a millisecond and the K timed ones a few: timed right here the region runs at the clock of a
+    # chip that was idle through the host-side set-up.  That cold figure is reported (`cold_start`), then the same passes are replayed
+    # untimed for BIE_BENCH_PRECONDITION_S (0.3 s) and the K passes are timed again: `value` is the sustained rate.
+    cold_elapsed, cold_gpu_ms = timed_region()
+    pre_s = float(os.environ.get("BIE_BENCH_PRECONDITION_S", "0.3"))
+    pre_n = 0
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < pre_s and not distributed:
         step()
-    ev1.record()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    gpu_ms = ev0.elapsed_time(ev1)
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        pre_n += 1
+        if pre_n % 4 == 0:
+            torch.cuda.synchronize()
+    if distributed:  # every rank the same number of collectives
+        pre_n = max(1, int(pre_s / max(cold_elapsed, 1e-4)))
+        for _ in range(pre_n * args.steps):
+            step()
+    elapsed, gpu_ms = timed_region()
 
     ms_per_step = elapsed / args.steps * 1e3
     step_bytes = alg_bytes(1, K, N) * LAYERS
@@ -631,6 +671,11 @@ def main():
                          "kernel": "bie::mpq_list_kernel<bf16,sym,M=1,rpg=16,w4> (table-lookup dequant, buffer-addressed rows, v_pk_fma_f32; one launch walks the column tiles of every layer of the pass)",
                          "avg_launch_us": round(avg_us, 3), "us_per_layer": round(avg_us / LAYERS, 3),
                          "alg_bytes_per_launch": alg_bytes(1, K, N) * LAYERS},
+            # the same K passes timed straight after the W warm-up passes, before the untimed replays that bring the chip to its sustained clock
+            "cold_start": {"value": round(step_bytes * world / (cold_elapsed / args.steps) / 1e9, 2), "unit": "GB/s", "ms_per_step": round(cold_elapsed / args.steps * 1e3, 4),
+                           "roofline_frac": round(alg_bytes(1, K, N) * LAYERS / (cold_gpu_ms * 1e3 / launches * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
+            "preconditioning": {"untimed_passes_between_cold_and_timed_region": pre_n * args.steps, "seconds": pre_s,
+                                "why": "K = 20 passes last 3.4 ms: shorter than the chip's clock ramp from idle; `value` is the sustained rate, `cold_start` the first K passes"},
         }
 
     extras = rank == 0 and world == 1 and not args.no_extras and not args.only

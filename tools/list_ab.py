@@ -38,8 +38,9 @@ def list_case(k, n, nl, per_launch, chain=0, reps=20, seed=1):
                 p.forward()
         torch.cuda.synchronize()
         return {"K": k, "N": n, "layers": nl, "per_launch": per_launch, "nograph": True}
-    g = capture(lambda st: [p.forward(st) for p in plans])
-    us = time_graph(g, reps) / nl
+    passes = int(os.environ.get("LIST_AB_PASSES", "1"))  # passes per captured graph
+    g = capture(lambda st: [p.forward(st) for _ in range(passes) for p in plans])
+    us = time_graph(g, reps) / nl / passes
     b = alg_bytes(1, k, n)
     return {"K": k, "N": n, "layers": nl, "per_launch": per_launch, "chain": chain, "us_per_layer": round(us, 3), "frac": round(b / us / 1e3 / 8000.0, 4)}
 
