@@ -5,7 +5,8 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
 R=$PWD
 echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -q -m gpu -x 2>&1 | tail -4 | tee gpurun_out/r03_pytest_gpu_tail.txt
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-echo "== PMC fused GEMM"; bash tools/gpu_pmc_gemm_r03.sh > /dev/null 2>&1; tail -3 gpurun_out/r03w_pmc_gemm.txt | cut -c1-200
+echo "== PMC of the GEMM the dispatch picks"; bash tools/gpu_pmc_gemm_r03.sh > /dev/null 2>&1; tail -3 gpurun_out/r03w_pmc_gemm.txt | cut -c1-200
+python tools/pmc_gemm_json.py > /dev/null && cp profiles/r03_pmc_gemm.json gpurun_out/r03_pmc_gemm.json  # stamped with the current sources: the bench below attaches it
 echo "== PMC new MFMA kernels"
 cd /tmp
 pass() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d /tmp/pmcn_$name -o p -- python $R/tools/mfma_new_only.py > /tmp/pmcn_$name.log 2>&1; f=$(find /tmp/pmcn_$name -name "*counter_collection.csv" | head -1); echo "== $name"; python - "$f" <<'PY'
@@ -30,7 +31,7 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pmcn_st
 echo "== kernel stats"; f=$(find /tmp/pmcn_stats -name "*kernel_stats.csv" | head -1); head -8 "$f" | cut -c1-200
 } 2>&1 | tee $R/gpurun_out/r03_pmc_mfma_new.txt | cut -c1-260
 cd $R
-echo "== bench"; timeout 900 python bench.py > gpurun_out/r03_bench.json 2> gpurun_out/r03_bench.err; python - <<'PY'
+echo "== bench (the driver's flags)"; timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r03_bench.json 2> gpurun_out/r03_bench.err; python - <<'PY'
 import json
 d = json.loads([l for l in open('gpurun_out/r03_bench.json') if l.startswith('{')][-1])
 print({k: d[k] for k in ('metric', 'value', 'unit', 'ms_per_step')}); print(d['roofline']); print(d.get('roofline_gemm')); print(d.get('gemm_fused_form_4096x4096')); print(d['cpu_baseline'])
