@@ -181,6 +181,24 @@ def test_dense_form_of_the_gemm_every_flavour(dt, w_bit, asym, tile, monkeypatch
         assert_close(y, y0, dt, "dense vs fused")
 
 
+@pytest.mark.parametrize("gm", ["1", "3", "16"])
+@pytest.mark.parametrize("tile", ["128", "256"])
+def test_dense_form_tile_order(gm, tile, monkeypatch):
+    """The workgroup -> tile mapping of the pipeline GEMMs (pipe_tile, mfma_pipe.cuh): every tile exactly once whatever the tile rows per
+    XCD run (default 4) and the grid -- tile counts that are not multiples of 8, a last group of fewer rows, one tile row, one tile column."""
+    monkeypatch.setenv("BIE_TUNING", "1")
+    monkeypatch.setenv("BIE_GEMM_DENSE", "2")
+    monkeypatch.setenv("BIE_GEMM_DENSE_TILE", tile)
+    monkeypatch.setenv("BIE_GEMM_DENSE_GM", gm)
+    for (M, K, N) in ((1300, 128, 1440), (200, 64, 3000), (1700, 64, 200)):
+        rng = np.random.default_rng(M + K + N)
+        qw, scales, zeros, gen = rand_case(rng, K, N, 4, 64, orc.BF16, 0)
+        x = torch.randn((M, K), generator=gen).to(TDT[orc.BF16])
+        y = hip_forward(x, qw, scales, zeros, None, 4, 64, 0)
+        ref = oracle_forward(x, qw, scales, zeros, None, 4, 64, 0, orc.BF16)
+        assert_close(y, ref, orc.BF16, f"dense tile order gm={gm} tile={tile} M={M} N={N}")
+
+
 @pytest.mark.parametrize("K,N,gs,M", [(128, 64, 32, 1), (256, 260, 64, 4), (4096, 128, 128, 1), (1024, 2048, 1024, 2),
                                       (192, 132, 64, 16), (4096, 512, 32, 48), (2048, 1000, 128, 130), (64, 32, 64, 5)])
 @pytest.mark.parametrize("dt", [orc.F16, orc.BF16])
