@@ -30,7 +30,6 @@ SIGNATURES = {
     "bie_mpq_forward_grouped": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz] + [_i] * 6 + [_vp]),
     "bie_status_init": (_i, []),
     "bie_device_status": (ctypes.c_uint, [_i]),
-    "bie_test_forge_reducer": (None, [ctypes.c_uint, _i]),
     "bie_mpq_list_device_bytes": (_sz, [_i, _vp, _i, _i, _i]),
     "bie_mpq_list_create": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _sz]),
     "bie_mpq_list_forward": (_i, [_vp, _vp]),
@@ -87,8 +86,14 @@ SIGNATURES = {
 }
 
 
+# include/bie_hip_testing.h: fault-injection hooks, bound for tests/ only (nothing in this package calls them)
+TEST_HOOKS = {
+    "bie_test_forge_reducer": (None, [ctypes.c_uint, _i]),
+    "bie_test_forge_dependency": (None, [_i]),
+}
+
 _HOST_ONLY = ("bie_version", "bie_last_error", "bie_mbwq_rows", "bie_status_init", "bie_device_status", "bie_test_forge_reducer",
-              "bie_mpq_list_launches", "bie_mpq_list_destroy", "bie_mbwq_exl2_list_destroy")
+              "bie_test_forge_dependency", "bie_mpq_list_launches", "bie_mpq_list_destroy", "bie_mbwq_exl2_list_destroy")
 
 
 class ListEntry(ctypes.Structure):
@@ -113,7 +118,7 @@ def lib():
                 f"`make -C {os.path.dirname(os.path.dirname(LIB_PATH))}` or `python -c 'import __graft_entry__ as g; g.build()'`.")
         l = ctypes.CDLL(LIB_PATH)
         ns = _Lib()
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in list(SIGNATURES.items()) + list(TEST_HOOKS.items()):
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
@@ -193,32 +198,50 @@ _CAPTURED = set()  # keys of buffers that were handed out while their stream was
 
 def _grow(table, key, nbytes, device, zero):
     """Shared growth policy of workspace() / scratch(): geometric (a serving loop with slowly growing M must not reallocate at
-    every new maximum), never under stream capture (an allocation inside a capture is an error the caller can avoid with
-    presize_workspace), and an outgrown buffer is only retired -- kept alive forever -- if a captured graph may hold its
-    address; otherwise it is simply dropped."""
+    every new maximum).  An outgrown buffer is retired -- kept alive -- only if a captured graph may hold its address
+    (otherwise it is simply dropped); the key's capture mark goes with it.
+
+    Under stream capture nothing is allocated: a buffer created inside a capture would come from the graph's private pool and
+    its zero-fill would become a memset node that resets the generation words of the reduction protocol on every replay.
+    A plain `with torch.cuda.graph(g):` captures on torch's own capture stream, which has no buffer of its own even after a
+    warm-up: the capture then BORROWS the largest sufficient buffer another stream of the same device warmed up (launches of
+    one graph are stream-ordered among themselves; do not run eager bitorch_engine calls on the lending stream while that
+    graph replays).  Only when no stream of the device has a large enough buffer does the call fail, naming the stream."""
     buf = table.get(key)
+    capturing = torch.cuda.is_current_stream_capturing()
     if buf is not None and buf.numel() >= nbytes:
-        if torch.cuda.is_current_stream_capturing():
+        if capturing:
             _CAPTURED.add((id(table), key))
         return buf
-    if torch.cuda.is_current_stream_capturing():
-        raise RuntimeError(f"bitorch_engine: the per-stream scratch buffer has to grow to {nbytes} bytes while the stream is being "
-                           "captured; call bitorch_engine._hip.presize_workspace(nbytes) (or run the step once) before capturing")
+    if capturing:
+        lend = [(k, b) for k, b in table.items() if k[0] == key[0] and b.numel() >= nbytes]
+        if lend:
+            k, b = max(lend, key=lambda kb: kb[1].numel())
+            _CAPTURED.add((id(table), k))
+            return b
+        raise RuntimeError(f"bitorch_engine: stream {key[1]:#x} of device {key[0]} is being captured and no stream of that device has a "
+                           f"scratch buffer of {nbytes} bytes yet; run the step once before capturing, or call "
+                           "bitorch_engine._hip.presize_workspace(nbytes, device, stream) first")
     if buf is not None and (id(table), key) in _CAPTURED:
         _WS_RETIRED.append(buf)
+        _CAPTURED.discard((id(table), key))  # the new buffer has not been seen by any capture
     size = max(nbytes, 1 << 20, 2 * buf.numel() if buf is not None else 0)
     buf = (torch.zeros if zero else torch.empty)(size, dtype=torch.uint8, device=device)
     table[key] = buf
     return buf
 
 
-def workspace(nbytes: int, device) -> torch.Tensor:
+def _key(device, stream=None):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return (idx, (torch.cuda.current_stream(device) if stream is None else stream).cuda_stream)
+
+
+def workspace(nbytes: int, device, stream=None) -> torch.Tensor:
     """Per-(device, stream) scratch buffer with the zero-initialised ticket / generation head, grown on demand and reused
-    (stream-ordered reuse is safe).  See _grow() for the growth / retirement policy."""
+    (stream-ordered reuse is safe).  See _grow() for the growth / retirement / capture policy."""
     if nbytes == 0:
         return None
-    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
-    return _grow(_WS, key, nbytes, device, True)  # head = split-K counters, must start at 0
+    return _grow(_WS, _key(device, stream), nbytes, device, True)  # head = split-K counters, must start at 0
 
 
 _SCRATCH = {}
@@ -227,12 +250,11 @@ _SCRATCH = {}
 def scratch(nbytes: int, device) -> torch.Tensor:
     """Per-(device, stream) scratch WITHOUT the ticket / generation head (im2col buffers and the like): grown on demand,
     superseded buffers retired like workspace()'s."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
-    return _grow(_SCRATCH, key, nbytes, device, False)
+    return _grow(_SCRATCH, _key(device), nbytes, device, False)
 
 
-def presize_workspace(nbytes: int, device=None):
-    """Allocate the current stream's scratch buffer up front (e.g. for the largest prefill) so that it never regrows
-    after a decode graph has been captured."""
+def presize_workspace(nbytes: int, device=None, stream=None):
+    """Allocate the scratch buffer of `stream` (default: the current stream) up front (e.g. for the largest prefill) so that it
+    never regrows after a decode graph has been captured; call it before capturing, on any stream of the device."""
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    return workspace(nbytes, device)
+    return workspace(nbytes, device, stream)

@@ -34,6 +34,7 @@ int status_init();
 unsigned status_read(bool clear);
 int status_report(const char* fn);
 void test_forge_set(unsigned tag_skew, int spin_limit);
+void test_forge_dep_set(int extra);
 // mpq_gemm.hip
 bool mpq_gemm_ok(int M, int K, int N, int w_bit, int group_size, int dtype, bool has_gidx);
 size_t mpq_gemm_workspace_bytes(int M, int K, int N);
@@ -130,7 +131,9 @@ const char* bie_last_error(void) { return bie::get_error(); }
 
 int bie_status_init(void) { return status_init(); }
 unsigned bie_device_status(int clear) { return status_read(clear != 0); }
+// include/bie_hip_testing.h: fault injection for the fail-loud tests (not part of the drop-in ABI)
 void bie_test_forge_reducer(unsigned tag_skew, int spin_limit) { test_forge_set(tag_skew, spin_limit); }
+void bie_test_forge_dependency(int extra) { test_forge_dep_set(extra); }
 
 size_t bie_mpq_list_device_bytes(int n_entries, const bie_mpq_list_entry* entries, int M, int w_bit, int group_size) {
     return mpq_list_device_bytes(n_entries, entries, M, w_bit, group_size);

@@ -36,6 +36,7 @@ namespace bie {
 
 unsigned* device_status_word();  // status.hip: device pointer of the host-mapped status page (NULL before bie_status_init)
 void test_forge_get(unsigned* tag_skew, int* spin_limit);
+int test_forge_dep_get();
 int mpq_lutm_list_launch(const ListEntry* ent, const uint2_t* blk, unsigned grid, int M, int rpg, int zm, int dtype, hipStream_t st);  // mpq_gemv_lut.hip
 
 struct ListArgs {
@@ -46,6 +47,7 @@ struct ListArgs {
     unsigned tag_skew;    // testing aid: the reducer expects tag ^ tag_skew (forges a stale granule)
     int spin_limit;
     int M;
+    int dep_extra;        // testing aid (bie_test_forge_dependency): dependent entries wait for this many tiles more than exist
 };
 
 typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
@@ -310,9 +312,10 @@ __global__ __launch_bounds__(((VAR & 8) ? 256 : ((VAR & 16) ? 128 : ((VAR & 32) 
     // vector L1, so no agent-scope buffer_inv and its ~1.7 us are needed; the XCD L2s are kept coherent for device-local memory
     // by the fabric's probes), and the buffer may have been cached there by an earlier workgroup of this launch.
     const unsigned* dep = e->dep_done;
+    bool dep_poison = false;  // workgroup-uniform: the producer never finished -> NaN in y, the completion count still moves
     if (dep != nullptr) {
         if (threadIdx.x == 0) {
-            const unsigned target = (unsigned)e->dep_tiles;  // the counters are zeroed by a memset node before every launch
+            const unsigned target = (unsigned)(e->dep_tiles + a.dep_extra);  // the counters are zeroed by a memset node before every launch
             int spins = 0;
             unsigned seen;
             do {
@@ -320,9 +323,14 @@ __global__ __launch_bounds__(((VAR & 8) ? 256 : ((VAR & 16) ? 128 : ((VAR & 32) 
                 if (seen >= target) break;
                 __builtin_amdgcn_s_sleep(8);
             } while (++spins < a.spin_limit);
+            // NaN marks a poisoned producer (its y is NaN already); a timeout is reported and poisons this entry too, so that a C-ABI
+            // caller without a status page still gets no number
             if (seen < target && a.status) __hip_atomic_fetch_or(a.status, BIE_STATUS_DEP_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            tab[0] = seen < target ? 1u : 0u;  // the tables are not built yet: word 0 carries the verdict through the barrier
         }
         __syncthreads();
+        dep_poison = __builtin_amdgcn_readfirstlane((int)tab[0]) != 0;
+        __syncthreads();  // every wave has read the verdict before any wave writes its table
         asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     }
     BIE_LIST_STAMP(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st1 = wall_clock64();)  // the wave's first two units have landed
@@ -368,7 +376,7 @@ __global__ __launch_bounds__(((VAR & 8) ? 256 : ((VAR & 16) ? 128 : ((VAR & 32) 
         float v = 0.0f;
 #pragma unroll
         for (int w = 0; w < NW; w++) v += red[(w * MT + m) * 64 + lane];
-        tot[m] = v;
+        tot[m] = dep_poison ? __uint_as_float(0x7fc00000u) : v;  // a poisoned partial sum poisons the reducer's total as well
     }
 
     // ---- cross-workgroup reduction (wave 0 only): slices 0 .. S-2 publish {fp32, tag} granules, the last slice adds them in
@@ -377,7 +385,7 @@ __global__ __launch_bounds__(((VAR & 8) ? 256 : ((VAR & 16) ? 128 : ((VAR & 32) 
     const long ncat = (long)e2->tiles * 64;
     const long col = (long)tile * 64 + lane;
     unsigned long long* gran = e2->gran;
-    bool poisoned = false;
+    bool poisoned = dep_poison, red_timeout = false;
     if (S > 1) {
         if (slice != S - 1) {  // publisher: one 8-byte write-through store per column, no drain, no atomic
 #pragma unroll
@@ -407,7 +415,7 @@ __global__ __launch_bounds__(((VAR & 8) ? 256 : ((VAR & 16) ? 128 : ((VAR & 32) 
                     ready = __builtin_amdgcn_ballot_w64(!ready) == 0;  // wave-uniform: every lane's granules are in
                     if (!ready) __builtin_amdgcn_s_sleep(2);
                 } while (!ready && ++spins < a.spin_limit);
-                if (!ready) poisoned = true;  // wave-uniform
+                if (!ready) poisoned = red_timeout = true;  // wave-uniform
 #pragma unroll
                 for (int jj = 0; jj < 8; jj++)
                     if (s0 + jj < S - 1) v += __uint_as_float((unsigned)gv[jj]);
@@ -415,7 +423,7 @@ __global__ __launch_bounds__(((VAR & 8) ? 256 : ((VAR & 16) ? 128 : ((VAR & 32) 
             tot[m] = v + tot[m];
         }
         if (lane == 0) e2->gen[tile] = gen_next;  // a replay of this launch gets a different tag; visible at the kernel boundary
-        if (poisoned) {  // never a silent number: NaN in y and a bit in the status page the next C-ABI call reports
+        if (red_timeout) {  // never a silent number: NaN in y and a bit in the status page the next C-ABI call reports
 #pragma unroll
             for (int m = 0; m < MT; m++) tot[m] = __uint_as_float(0x7fc00000u);
             if (lane == 0 && a.status) __hip_atomic_fetch_or(a.status, BIE_STATUS_REDUCER_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -742,6 +750,7 @@ int mpq_list_forward(MpqList* p, hipStream_t st) {
     a.epoch = next_launch_epoch();
     test_forge_get(&a.tag_skew, &a.spin_limit);
     a.M = p->M;
+    a.dep_extra = test_forge_dep_get();
     static const int var = list_env("BIE_LIST_VAR", 1);  // tuning aid: 0 = scalar FMAs, 1 = v_pk_fma_f32 pairs, 2 / 3 = stream only
     const bool lab_ok = p->dtype == BIE_BF16 && p->zm == ZM_SYM && p->M == 1 && p->rpg == 16 && p->w_bit == 4;
     if (lab_ok && p->nw != 4) {

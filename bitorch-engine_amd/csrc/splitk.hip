@@ -62,6 +62,7 @@ static std::atomic<unsigned*> g_status_host{nullptr};
 static unsigned* g_status_dev = nullptr;
 static std::atomic<unsigned> g_forge_skew{0};
 static std::atomic<int> g_forge_spin{0};
+static std::atomic<int> g_forge_dep{0};
 
 int status_init() {
     if (g_status_host.load(std::memory_order_acquire)) return BIE_OK;
@@ -94,6 +95,8 @@ int status_report(const char* fn) {
     return BIE_ERR_DEVICE;
 }
 void test_forge_set(unsigned tag_skew, int spin_limit) { g_forge_skew.store(tag_skew); g_forge_spin.store(spin_limit); }
+void test_forge_dep_set(int extra) { g_forge_dep.store(extra); }
+int test_forge_dep_get() { return g_forge_dep.load(std::memory_order_relaxed); }
 void test_forge_get(unsigned* tag_skew, int* spin_limit) {
     *tag_skew = g_forge_skew.load(std::memory_order_relaxed);
     const int s = g_forge_spin.load(std::memory_order_relaxed);

@@ -59,9 +59,7 @@ const char* bie_last_error(void);
  * first and fails with BIE_ERR_DEVICE (clearing it) if an earlier launch raised it. */
 int bie_status_init(void);
 unsigned bie_device_status(int clear);
-/* Testing aid: make the reducers of subsequent launches expect tag ^ tag_skew and give up after spin_limit polls
- * (tag_skew = 0, spin_limit = 0 restores normal operation).  Forges a stale granule for the fail-loud tests. */
-void bie_test_forge_reducer(unsigned tag_skew, int spin_limit);
+/* (the fault-injection hooks the fail-loud tests use are NOT part of this ABI: include/bie_hip_testing.h) */
 
 /* ------------------------------------------------------------------------------------------ */
 /* MPQ (GPTQ-style) W{1,2,4,8}A16 linear                                                       */

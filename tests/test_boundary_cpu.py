@@ -13,8 +13,8 @@ from oracle import oracle as orc
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "bie_hip.h")).read()
+def declared_symbols(header="bie_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(bie_[a-z0-9_]+)\s*\(", text)))
 
@@ -27,6 +27,9 @@ def test_library_loads_and_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"libbie_hip.so does not export {s}"
     assert sorted(_hip.SIGNATURES) == syms, "ctypes signature table out of sync with include/bie_hip.h"
+    assert not [s for s in syms if "test" in s], "fault-injection hooks do not belong in the drop-in ABI header"
+    hooks = declared_symbols("bie_hip_testing.h")
+    assert sorted(_hip.TEST_HOOKS) == hooks and all(hasattr(lib, s) for s in hooks)
     assert lib.bie_version() == 300
 
 

@@ -1566,6 +1566,39 @@ def test_reducer_timeout_fails_loudly():
     assert L.bie_device_status(1) & 1
 
 
+def test_dependency_timeout_fails_loudly():
+    """A dependent list entry whose producer never finishes (forged: it waits for one tile more than the producer has) must not compute
+    from a stale x: NaN in its y AND in every y downstream of it (their completion counts still move, so nobody spins for long), status
+    bit 2 raised, the next launching call fails, and the plan is healthy afterwards (the kernel used to set the bit only)."""
+    from bitorch_engine import _hip
+    from bitorch_engine.layers.qlinear.nbit.cuda import MPQForwardList
+    L = _hip.lib()
+    entries, host = _list_case([(512, 512, False), (512, 512, True), (512, 256, False)], orc.BF16, 4, 128, 0, 1, seed=91, chain=True)
+    plan = MPQForwardList(entries, w_bit=4, group_size=128)
+    assert L.bie_device_status(1) == 0
+    L.bie_test_forge_reducer(0, 500)  # short spin bound
+    L.bie_test_forge_dependency(1)
+    try:
+        plan()
+        torch.cuda.synchronize()
+    finally:
+        L.bie_test_forge_dependency(0)
+        L.bie_test_forge_reducer(0, 0)
+    assert torch.isfinite(entries[0]["y"].float()).all(), "the head of the chain has no dependency"
+    assert torch.isnan(entries[1]["y"].float()).all(), "a timed-out dependent entry returned numbers"
+    assert torch.isnan(entries[2]["y"].float()).all(), "the entry downstream of a poisoned one returned numbers"
+    assert L.bie_device_status(0) & 2
+    with pytest.raises(RuntimeError, match="device status"):
+        plan()
+    assert L.bie_device_status(0) == 0
+    plan()
+    torch.cuda.synchronize()
+    xin = host[0][0]
+    for i, (e, (_, qw, scales, zeros, bias)) in enumerate(zip(entries, host)):
+        assert_close(e["y"], oracle_forward(xin, qw, scales, zeros, None, 4, 128, 0, orc.BF16, bias), orc.BF16, f"after the forged dependency timeout, layer {i}")
+        xin = e["y"].cpu()
+
+
 def test_binary_linear_cutlass_mm_and_batched_matmul_follow_the_reference_signatures():
     """binary_linear_cutlass.mm(x, y, kernel_id) -> int32 XOR-popcount accumulator (binary_linear_cutlass_kernel.cu:293-332,650-666);
     matmul(x, y, scale) batched in ONE launch, float32 exact and bfloat16 with the reference's bf16 arithmetic on the popcount."""
