@@ -3,6 +3,7 @@ layers/qlinear/nbit/cuda/mpq_layer.py (Function :14-121, layer :124-224); the ar
 HIP kernel family for every M (decode GEMV, MFMA GEMM) instead of the reference's
 "kernel for M<=32, else materialise the dense weight + cuBLAS" split (:59-65)."""
 import math
+import os
 import typing
 
 import torch
@@ -13,6 +14,100 @@ from bitorch_engine.utils.safe_import import import_extension
 from bitorch_engine.utils.model_helper import flatten_x, unflatten_x
 
 q_linear_cuda = import_extension("q_linear_cuda")
+
+# counters of the automatic sibling grouping (tests and tools read them; reset with .clear())
+GROUP_STATS = {"grouped_launches": 0, "served_from_group": 0, "single_launches": 0, "groups_confirmed": 0, "groups_dissolved": 0}
+AUTO_GROUP = os.environ.get("BIE_AUTO_GROUP", "1") != "0"
+GROUP_MAX_M = 16  # rows the grouped decode launch takes (bie_mpq_forward_grouped)
+
+
+def _x_key(x):
+    return (x.data_ptr(), x._version, tuple(x.shape), tuple(x.stride()), x.dtype, x.device)
+
+
+class SiblingGroup:
+    """MPQLinearCuda children of ONE parent module that may consume the same activation (q/k/v, gate/up): what
+    prepare_bie_layers() finds by structure and the first forward passes CONFIRM by observation, so that an unchanged caller
+
+        q = self.q_proj(h); k = self.k_proj(h); v = self.v_proj(h)
+
+    (reference call path: layers/qlinear/nbit/cuda/mpq_layer.py:206-224 -> one quant_mm_kernel launch per layer) runs ONE grouped
+    decode launch (bie_mpq_forward_grouped).  Protocol, per forward of the parent: the member that is called first (the LEADER) with
+    M <= 16 rows in eval mode launches the whole confirmed set on its x and parks the other members' outputs, keyed by the identity of x
+    (storage pointer, version counter, shape, strides); a member called next with the SAME tensor takes its parked output without
+    launching anything; a member called with anything else (o_proj sits beside q/k/v but eats the attention output) simply runs alone,
+    and is dropped from the set.  Nothing is assumed: a set is only formed from members that WERE observed receiving the leader's
+    tensor, and three rounds in which a parked output was not picked up dissolve the group."""
+
+    def __init__(self, members):
+        self.members = list(members)
+        self.leader = None
+        self.confirmed = None      # list of modules launched together (leader first), or None while observing
+        self.round_key = None      # identity of the leader's x in the current round
+        self.seen = []             # members observed with round_key in the current round
+        self.parked = {}           # id(module) -> (key, output)
+        self.unclaimed = 0
+        self.dead = False
+
+    def _finish_round(self):
+        if self.confirmed is None and self.leader is not None and len(self.seen) >= 2:
+            self.confirmed = list(self.seen)
+            GROUP_STATS["groups_confirmed"] += 1
+        elif self.confirmed is not None and self.parked:
+            self.unclaimed += 1
+            if self.unclaimed >= 3:
+                self.confirmed, self.dead = None, True
+                GROUP_STATS["groups_dissolved"] += 1
+        self.parked.clear()
+
+    def forward(self, module, x):
+        """Returns the module's output, or None when the module has to run by itself."""
+        if self.dead:
+            return None
+        key = _x_key(x)
+        hit = self.parked.pop(id(module), None)
+        if hit is not None and hit[0] == key:
+            self.unclaimed = 0
+            GROUP_STATS["served_from_group"] += 1
+            return hit[1]
+        if self.leader is None:
+            self.leader = module
+        if module is self.leader:
+            self._finish_round()
+            self.round_key, self.seen = key, [module]
+            if self.confirmed is not None:
+                outs = MPQLinearCuda.forward_grouped(self.confirmed, x, _from_group=True)
+                GROUP_STATS["grouped_launches"] += 1
+                for m, o in zip(self.confirmed[1:], outs[1:]):
+                    self.parked[id(m)] = (key, o)
+                return outs[0]
+            return None
+        if self.confirmed is None and key == self.round_key and module not in self.seen:
+            self.seen.append(module)      # observed: same tensor as the leader in this round
+        elif self.confirmed is not None and module in self.confirmed:
+            self.confirmed.remove(module)  # it was launched with the leader's x but asked for another one: not a sibling after all
+            if len(self.confirmed) < 2:
+                self.confirmed, self.dead = None, True
+                GROUP_STATS["groups_dissolved"] += 1
+        return None
+
+
+def find_sibling_groups(model: torch.nn.Module) -> int:
+    """Attach a SiblingGroup to every set of >= 2 MPQLinearCuda children of one parent that share in_channels / w_bit / group_size /
+    asym / dtype (called by utils.model_helper.prepare_bie_layers).  Returns the number of candidate groups."""
+    n = 0
+    for parent in model.modules():
+        kids = [c for c in parent.children() if isinstance(c, MPQLinearCuda)]
+        buckets = {}
+        for c in kids:
+            buckets.setdefault((c.in_channels, c.w_bit, c.group_size, bool(c.asym), c.dtype), []).append(c)
+        for members in buckets.values():
+            if len(members) >= 2 and members[0].w_bit == 4:
+                g = SiblingGroup(members)
+                for m in members:
+                    m._bie_group = g
+                n += 1
+    return n
 
 
 class MPQLinearCudaFunction(Function):
@@ -48,6 +143,7 @@ class MPQLinearCuda(MPQLinearBase):
         super().__init__(*args, **kwargs)
         self.qweight.layer_type = 1
         self._gidx_trivial = None
+        self._bie_group = None  # SiblingGroup, set by prepare_bie_layers (find_sibling_groups)
         self.check_parameters()
 
     def check_parameters(self) -> None:
@@ -96,12 +192,17 @@ class MPQLinearCuda(MPQLinearBase):
         # inference fast path: bias fused into the kernel epilogue; whether g_idx is the trivial k // group_size is
         # remembered on the g_idx tensor itself (keyed by its version), so load_state_dict / in-place edits invalidate it
         x2, lead = flatten_x(x)
+        if AUTO_GROUP and self._bie_group is not None and 0 < x2.shape[0] <= GROUP_MAX_M:
+            out = self._bie_group.forward(self, x)  # decode: siblings that share x run as ONE grouped launch (see SiblingGroup)
+            if out is not None:
+                return out
+        GROUP_STATS["single_launches"] += 1
         out = q_linear_cuda.mpq_forward_impl(x2, self.qweight.data, self.scales, self.zeros, self.g_idx, self.w_bit,
                                              self.asym, self.group_size, None if self.disable_bias else self.bias)
         return unflatten_x(out, lead)
 
     @staticmethod
-    def forward_grouped(layers: typing.Sequence["MPQLinearCuda"], x: torch.Tensor) -> typing.List[torch.Tensor]:
+    def forward_grouped(layers: typing.Sequence["MPQLinearCuda"], x: torch.Tensor, _from_group: bool = False) -> typing.List[torch.Tensor]:
         """Several layers that consume the SAME activation (q/k/v, gate/up of a transformer block) in ONE decode launch
         (bie_mpq_forward_grouped): the reference launches `quant_mm_kernel` once per layer (mpq_layer.py:65); at M <= 16 a
         launch of this size is mostly fixed cost, and three 4096x4096 projections in one grid take 10.1 us instead of 3 x 6.0.
@@ -115,6 +216,9 @@ class MPQLinearCuda(MPQLinearBase):
               and not (torch.is_grad_enabled() and x.requires_grad)
               and all(q_linear_cuda.gidx_is_trivial(l.g_idx, l.group_size) for l in layers))
         if not ok:
+            if _from_group:  # called by a SiblingGroup: the members' own forward would re-enter the group
+                return [unflatten_x(q_linear_cuda.mpq_forward_impl(x2, l.qweight.data, l.scales, l.zeros, l.g_idx, l.w_bit, l.asym, l.group_size,
+                                                                   None if l.disable_bias else l.bias), lead) for l in layers]
             return [l(x) for l in layers]
         sets = [(l.qweight.data, l.scales, l.zeros, None if l.disable_bias else l.bias) for l in layers]
         outs = q_linear_cuda.mpq_forward_grouped_impl(x2, sets, first.w_bit, first.asym, first.group_size)

@@ -67,6 +67,14 @@ def prepare_bie_layers(model: torch.nn.Module, layers=None) -> None:
     for i, module in enumerate(model.modules()):
         if i > 0 and isinstance(module, kinds):
             module.prepare_params()
+    # MI355X side of the same hook: MPQLinearCuda siblings that may share an input (q/k/v, gate/up) are registered as candidate groups;
+    # their first forward passes confirm which of them really receive the same tensor, and from then on ONE grouped decode launch
+    # serves them (layers/qlinear/nbit/cuda/mpq_layer.py::SiblingGroup).  The caller's code does not change.
+    try:
+        from bitorch_engine.layers.qlinear.nbit.cuda.mpq_layer import find_sibling_groups
+        find_sibling_groups(model)
+    except ImportError:
+        pass
 
 
 def pack_bie_layers(model: torch.nn.Module, qweight_only: bool = True, layers=None) -> None:

@@ -36,6 +36,11 @@ namespace bie {
 
 unsigned* device_status_word();                            // splitk.hip
 void test_forge_get(unsigned* tag_skew, int* spin_limit);  // splitk.hip
+// mpq_list.hip: the layer-list kernel with its entries in the kernel arguments (W4, M = 1, bf16: what bie_mpq_forward[_grouped] run on)
+bool mpq_list_inline_ok(int M, int K, long n_total, int w_bit, int group_size, int zm, int dtype);
+size_t mpq_list_inline_part_floats(int M, int K, int group_size, int tiles_total, int w_bit);
+int mpq_list_inline_launch(int nsets, const int32_t* const* qw, const void* const* scales, const void* const* zeros, const void* const* bias,
+                           void* const* y, const int* N, const void* x, unsigned* gen, float* gran, int K, int group_size, int zm, hipStream_t st);
 
 constexpr int LUT_MAX_SETS = 8;
 
@@ -1032,7 +1037,8 @@ size_t mpq_gemv_lut_part_floats(int M, int K, int group_size, int tiles_total, i
         const size_t f = p.S > 1 ? (size_t)(p.S - 1) * M * tiles_total * 64 * 2 : 0;
         if (f > need) need = f;
     }
-    return need;
+    const size_t inl = mpq_list_inline_part_floats(M, K, group_size, tiles_total, w_bit);
+    return inl > need ? inl : need;
 }
 
 // fp16 W4 FMA form
@@ -1208,6 +1214,10 @@ int mpq_lutm_list_launch(const ListEntry* ent, const uint2_t* blk, unsigned grid
 int mpq_gemv_lut_launch(int nsets, const int32_t* const* qw, const void* const* scales, const void* const* zeros,
                         const void* const* bias, void* const* y, const int* N, const void* x, unsigned* gen, float* gran,
                         int M, int K, int group_size, int zm, int dtype, hipStream_t st, int w_bit) {
+    long n_total = 0;
+    for (int i = 0; i < nsets; i++) n_total += N[i];
+    if (mpq_list_inline_ok(M, K, n_total, w_bit, group_size, zm, dtype))  // big W4 / M = 1 / bf16 launches: the list kernel's D16 form, entries in the kernel arguments
+        return mpq_list_inline_launch(nsets, qw, scales, zeros, bias, y, N, x, gen, gran, K, group_size, zm, st);
     LutArgs a;
     int tiles = 0;
     for (int i = 0; i < LUT_MAX_SETS; i++) {

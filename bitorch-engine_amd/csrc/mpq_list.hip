@@ -28,6 +28,7 @@
 #include "mpq_list.h"
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 #include <vector>
 
 #pragma clang fp contract(off)
@@ -48,6 +49,15 @@ struct ListArgs {
     int spin_limit;
     int M;
     int dep_extra;        // testing aid (bie_test_forge_dependency): dependent entries wait for this many tiles more than exist
+};
+
+// Inline form (bie_mpq_forward / bie_mpq_forward_grouped on the decode path): up to 8 entries that share K live in the KERNEL ARGUMENTS
+// (their x / y pointers change from call to call, so no device-resident plan), and a block finds its (entry, tile, slice) by
+// arithmetic: grid = S x tiles_total, slice-major; entry i owns the tiles [tile_begin_i, tile_begin_{i+1}) (tile_begin in pad0).
+constexpr int LIST_MAX_INLINE = 8;
+struct ListArgsInl : ListArgs {
+    int n_inl, tiles_total;
+    ListEntry inl[LIST_MAX_INLINE];
 };
 
 typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
@@ -81,21 +91,42 @@ __device__ unsigned long long g_list_stamps[65536 * 6];
 
 // VAR bit 0: v_pk_fma_f32 pairs; bit 1 (tuning aid): stream only -- rows, constants and x are loaded, nothing is looked up;
 // bit 2: registers capped at 64 (four workgroups = 32 waves per CU instead of three); bit 3: four waves per workgroup instead of eight
-template <int DT, int ZM, int MT, int RPG, int WB, int VAR>
-__global__ __launch_bounds__(((VAR & 8) ? 256 : ((VAR & 16) ? 128 : ((VAR & 32) ? 64 : 512))), ((VAR & 4) ? 8 : 1)) void mpq_list_kernel(const ListArgs a) {
+// bit 6: D16 form (W4, M = 1, bf16) -- 16-bit table entries, two tables per wave (the units of a pair) in the halves of one 4 KiB block,
+//        looked up with ds_read_u16_d16_hi (the load zeroes the low half: the register IS the fp32 value of the bf16 weight), both tables
+//        built before the pair's rows are needed, lookups pipelined in half-row chunks with counted lgkmcnt (three chunks in flight)
+template <int DT, int ZM, int MT, int RPG, int WB, int VAR, bool INL = false>
+__global__ __launch_bounds__(((VAR & 8) ? 256 : ((VAR & 16) ? 128 : ((VAR & 32) ? 64 : 512))), ((VAR & 4) ? 8 : 1)) void mpq_list_kernel(const std::conditional_t<INL, ListArgsInl, ListArgs> a) {
     constexpr int NW = (VAR & 8) ? 4 : ((VAR & 16) ? 2 : ((VAR & 32) ? 1 : 8));  // bits 4 / 5 (tuning aids): two / one wave per workgroup
     constexpr int NB = 32 / WB;      // weights per packed word
     constexpr int XD = NB / 2;       // x dwords (16-bit pairs) per packed word
     constexpr bool PK = (VAR & 1) != 0 && WB == 4 && DT == BIE_BF16;
     constexpr bool STREAM_ONLY = (VAR & 2) != 0;
+    constexpr bool D16 = (VAR & 64) != 0 && WB == 4 && MT == 1 && DT == BIE_BF16 && !STREAM_ONLY;
     __shared__ __attribute__((aligned(4096))) uint32_t tab[NW * 16 * 64];  // the only LDS object: starts at LDS address 0
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint2_t rec = *((cu2_t*)(uintptr_t)(a.blk + blockIdx.x));
-    cent_t* e = (cent_t*)(uintptr_t)(a.ent + rec.x);
-    const int tile = (int)(rec.y & 0xfffffu);
-    const int slice = (int)(rec.y >> 20);
+    uint2_t rec;
+    cent_t* e;
+    int tile, slice;
+    if constexpr (INL) {
+        const int tcat = (int)(blockIdx.x % (unsigned)a.tiles_total);
+        slice = (int)(blockIdx.x / (unsigned)a.tiles_total);
+        int si = 0;
+#pragma unroll
+        for (int i = 1; i < LIST_MAX_INLINE; i++)
+            if (i < a.n_inl && tcat >= (int)a.inl[i].pad0) si = i;
+        // the entry is read with scalar loads straight from the kernel-argument segment (constant address space)
+        const __attribute__((address_space(4))) char* kp = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+        e = (cent_t*)(kp + __builtin_offsetof(ListArgsInl, inl) + (size_t)si * sizeof(ListEntry));
+        tile = tcat - (int)e->pad0;
+        rec = uint2_t{(uint32_t)si, (uint32_t)tile};
+    } else {
+        rec = *((cu2_t*)(uintptr_t)(a.blk + blockIdx.x));
+        e = (cent_t*)(uintptr_t)(a.ent + rec.x);
+        tile = (int)(rec.y & 0xfffffu);
+        slice = (int)(rec.y >> 20);
+    }
     const int N = e->N, K = e->K, G = e->G, gpw = e->gpw, S = e->S, hshift = e->hshift;
     const int n = tile * 64 + lane;
     const int nl = n < N ? n : N - 1;  // clamp: out-of-range lanes load valid memory and are never stored
@@ -334,12 +365,142 @@ __global__ __launch_bounds__(((VAR & 8) ? 256 : ((VAR & 16) ? 128 : ((VAR & 32) 
         asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     }
     BIE_LIST_STAMP(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st1 = wall_clock64();)  // the wave's first two units have landed
-    for (int g = g0; g < g1; g += 2) {
-        process_group(wa, g, sa, za);
-        if (g + 2 < g1) { load_params(g + 2, sa, za); load_group(wa, g + 2); }
-        if (g + 1 < g1) {
-            process_group(wb, g + 1, sb2, zb2);
-            if (g + 3 < g1) { load_params(g + 3, sb2, zb2); load_group(wb, g + 3); }
+    if constexpr (D16) {
+        // ---- D16 form: see the template's header comment.  Requests in flight at any time: the rows of the current pair of units and
+        // the group constants of this pair and the next (requested before the rows, so a table never waits behind rows it does not need)
+        uint32_t tabw = (uint32_t)wave * 4096u + lane_addr;  // LDS byte address of (this wave, q = 0, this lane)
+        const uint32_t sel0 = sel_lo_hi<0>(), sel1 = sel_lo_hi<1>();
+        // Tables of a PAIR of units, built together: dword (q, lane) = T_A[q] | T_B[q] << 16, so the 32 entries go out as 8 x
+        // ds_write2st64_b32 (rows q, q + 1 are 64 dwords apart) instead of 32 sixteen-bit stores -- the launch is bound by the LDS array
+        // (one read per weight; profiles/r04_e_*), a store instruction costs what two reads cost.  ZM_SYM: fl(q*s) of both units in one
+        // v_cvt_pk_bf16_f32, the second rounding's subtraction per half on the dot unit (selector (1,0) with -z_A, (0,1) with -z_B).
+        auto build_tables = [&](uint32_t sbA, uint32_t zbA, uint32_t sbB, uint32_t zbB) {
+            const uint32_t tw = tabw + 0u;  // (a plain use: clang does not capture a variable a lambda names in asm operands only)
+            uint32_t D[16];
+            if constexpr (ZM == ZM_SYM) {
+                const float sA = bf16_bits_to_f32(sbA), sB = bf16_bits_to_f32(sbB), nzA = -bf16_bits_to_f32(zbA), nzB = -bf16_bits_to_f32(zbB);
+#pragma unroll
+                for (int q = 0; q < 16; q += 2) {
+                    const uint32_t A0 = pack_bf16x2((float)q * sA, (float)q * sB), A1 = pack_bf16x2((float)(q + 1) * sA, (float)(q + 1) * sB);
+                    float d0, d1, d2, d3;
+                    asm("v_dot2_f32_bf16 %0, %4, %6, %8\n\t"
+                        "v_dot2_f32_bf16 %1, %4, %7, %9\n\t"
+                        "v_dot2_f32_bf16 %2, %5, %6, %8\n\t"
+                        "v_dot2_f32_bf16 %3, %5, %7, %9\n\t"
+                        "s_nop 2"
+                        : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
+                        : "v"(A0), "v"(A1), "v"(sel0), "v"(sel1), "v"(nzA), "v"(nzB));
+                    D[q] = pack_bf16x2(d0, d1);
+                    D[q + 1] = pack_bf16x2(d2, d3);
+                }
+            } else {
+                const float sA = bf16_bits_to_f32(sbA), sB = bf16_bits_to_f32(sbB);
+                float zA = 0.0f, zB = 0.0f;
+                int zqA = 0, zqB = 0;
+                if constexpr (ZM == ZM_ASYM) { zqA = (int)zbA; zqB = (int)zbB; } else { zA = bf16_bits_to_f32(zbA); zB = bf16_bits_to_f32(zbB); }
+#pragma unroll
+                for (int q = 0; q < 16; q++)  // the entries are bf16 values: their fp32 patterns have empty low halves
+                    D[q] = (__float_as_uint(list_lut_entry<DT, ZM>((uint32_t)q, sA, zA, zqA)) >> 16) |
+                           (__float_as_uint(list_lut_entry<DT, ZM>((uint32_t)q, sB, zB, zqB)) & 0xffff0000u);
+            }
+#pragma unroll
+            for (int q = 0; q < 16; q += 2)
+                asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(tw), "v"(D[q]), "v"(D[q + 1]), "n"(q), "n"(q + 1));
+        };
+        float2_t accE = {0.0f, 0.0f}, accO = {0.0f, 0.0f};
+        auto process_unit = [&](auto half_c, const uint32_t (&w)[RPG], int g) {
+            constexpr int HALF = decltype(half_c)::value;
+            const uint32_t mask = m0f + 0u, wpat = wavepat + 0u, la = lane_addr + 0u;  // plain uses (see build_table)
+            uint32_t xs[RPG * 4];
+            {
+                cu32_t* xd = (cu32_t*)(uintptr_t)(xbase + (long)g * (RPG * 8));
+#pragma unroll
+                for (int i = 0; i < RPG * 4; i++) xs[i] = xd[i];
+            }
+#pragma unroll
+            for (int i = 0; i < RPG * 4; i += 8)  // landed in SGPRs before the first lookup: nothing but LDS traffic is counted by lgkmcnt below
+                asm volatile("" ::"s"(xs[i]), "s"(xs[i + 1]), "s"(xs[i + 2]), "s"(xs[i + 3]), "s"(xs[i + 4]), "s"(xs[i + 5]), "s"(xs[i + 6]), "s"(xs[i + 7]));
+            constexpr int NC = 2 * RPG;  // chunks: (row, even nibbles), (row, odd nibbles)
+            float t[3][4];
+            uint32_t wprep[2] = {0, 0};  // even / odd prepared word of the row being issued
+            auto issue = [&](int c, float (&tt)[4]) {  // c is a compile-time value after unrolling
+                const int u = c >> 1;
+                if ((c & 1) == 0) {
+                    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(wprep[0]) : "v"(w[u]), "v"(mask), "s"(wpat));
+                    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(wprep[1]) : "v"(w[u] >> 4), "v"(mask), "s"(wpat));
+                }
+                const uint32_t wp = wprep[c & 1];
+                const uint32_t a0 = list_lut_addr<0>(la, wp), a1 = list_lut_addr<1>(la, wp), a2 = list_lut_addr<2>(la, wp), a3 = list_lut_addr<3>(la, wp);
+                asm volatile("ds_read_u16_d16_hi %0, %1 offset:%2" : "=v"(tt[0]) : "v"(a0), "n"(2 * HALF));
+                asm volatile("ds_read_u16_d16_hi %0, %1 offset:%2" : "=v"(tt[1]) : "v"(a1), "n"(2 * HALF));
+                asm volatile("ds_read_u16_d16_hi %0, %1 offset:%2" : "=v"(tt[2]) : "v"(a2), "n"(2 * HALF));
+                asm volatile("ds_read_u16_d16_hi %0, %1 offset:%2" : "=v"(tt[3]) : "v"(a3), "n"(2 * HALF));
+            };
+            issue(0, t[0]);
+            issue(1, t[1]);
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                if (c + 2 < NC) issue(c + 2, t[(c + 2) % 3]);
+                __builtin_amdgcn_sched_barrier(0);
+                float(&tc)[4] = t[c % 3];
+                // the four activations of this chunk, bf16 -> fp32 on the scalar unit, HERE: as plain expressions the DAG linearisation hoists
+                // all 8 x RPG of them to the top of the unit, where they do not fit in SGPRs (112 spilled to VGPR lanes: a v_readlane per use)
+                uint32_t xu[4];
+                {
+                    const int u = c >> 1;
+                    if ((c & 1) == 0)
+                        asm volatile("s_lshl_b32 %0, %4, 16\n\ts_lshl_b32 %1, %5, 16\n\ts_lshl_b32 %2, %6, 16\n\ts_lshl_b32 %3, %7, 16"
+                                     : "=&s"(xu[0]), "=&s"(xu[1]), "=&s"(xu[2]), "=&s"(xu[3])
+                                     : "s"(xs[u * 4 + 0]), "s"(xs[u * 4 + 1]), "s"(xs[u * 4 + 2]), "s"(xs[u * 4 + 3])
+                                     : "scc");
+                    else
+                        asm volatile("s_and_b32 %0, %4, 0xffff0000\n\ts_and_b32 %1, %5, 0xffff0000\n\ts_and_b32 %2, %6, 0xffff0000\n\ts_and_b32 %3, %7, 0xffff0000"
+                                     : "=&s"(xu[0]), "=&s"(xu[1]), "=&s"(xu[2]), "=&s"(xu[3])
+                                     : "s"(xs[u * 4 + 0]), "s"(xs[u * 4 + 1]), "s"(xs[u * 4 + 2]), "s"(xs[u * 4 + 3])
+                                     : "scc");
+                }
+                const int behind = (NC - 1 - c) < 2 ? (NC - 1 - c) : 2;  // chunks issued after chunk c
+                if (behind == 2) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(tc[0]), "+v"(tc[1]), "+v"(tc[2]), "+v"(tc[3]));
+                else if (behind == 1) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(tc[0]), "+v"(tc[1]), "+v"(tc[2]), "+v"(tc[3]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tc[0]), "+v"(tc[1]), "+v"(tc[2]), "+v"(tc[3]));
+                if ((c & 1) == 0) {  // even nibbles k = 8u + 2i: the low halves of the x dwords
+                    accE = __builtin_elementwise_fma(float2_t{tc[0], tc[1]}, float2_t{__uint_as_float(xu[0]), __uint_as_float(xu[1])}, accE);
+                    accE = __builtin_elementwise_fma(float2_t{tc[2], tc[3]}, float2_t{__uint_as_float(xu[2]), __uint_as_float(xu[3])}, accE);
+                    asm volatile("" : "+v"(accE));
+                } else {
+                    accO = __builtin_elementwise_fma(float2_t{tc[0], tc[1]}, float2_t{__uint_as_float(xu[0]), __uint_as_float(xu[1])}, accO);
+                    accO = __builtin_elementwise_fma(float2_t{tc[2], tc[3]}, float2_t{__uint_as_float(xu[2]), __uint_as_float(xu[3])}, accO);
+                    asm volatile("" : "+v"(accO));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        uint32_t sC = 0, zC = 0, sD = 0, zD = 0;  // group constants of the NEXT pair of units
+        if (g0 + 2 < g1) load_params(g0 + 2, sC, zC);
+        if (g0 + 3 < g1) load_params(g0 + 3, sD, zD);
+        for (int g = g0; g < g1; g += 2) {
+            build_tables(sa, za, sb2, zb2);  // (an odd tail builds its second table from the constants of the unit before: never read)
+            process_unit(std::integral_constant<int, 0>{}, wa, g);
+            if (g + 2 < g1) load_group(wa, g + 2);
+            if (g + 1 < g1) {
+                process_unit(std::integral_constant<int, 1>{}, wb, g + 1);
+                if (g + 3 < g1) load_group(wb, g + 3);
+            }
+            sa = sC; za = zC; sb2 = sD; zb2 = zD;
+            if (g + 4 < g1) load_params(g + 4, sC, zC);
+            if (g + 5 < g1) load_params(g + 5, sD, zD);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every table access of this wave is done before the table block is reused below
+        acc[0][0] = accE.x + accO.x;
+        acc[0][1] = accE.y + accO.y;
+    } else {
+        for (int g = g0; g < g1; g += 2) {
+            process_group(wa, g, sa, za);
+            if (g + 2 < g1) { load_params(g + 2, sa, za); load_group(wa, g + 2); }
+            if (g + 1 < g1) {
+                process_group(wb, g + 1, sb2, zb2);
+                if (g + 3 < g1) { load_params(g + 3, sb2, zb2); load_group(wb, g + 3); }
+            }
         }
     }
 
@@ -764,6 +925,11 @@ int mpq_list_forward(MpqList* p, hipStream_t st) {
         else hipLaunchKernelGGL((mpq_list_kernel<BIE_BF16, ZM_SYM, 1, 16, 4, 11>), dim3(p->grid), dim3(256), 0, st, a);
         return check_launch("mpq_list_kernel<lab>");
     }
+    static const int d16 = list_env("BIE_LIST_D16", 1);  // the 16-bit-table form of the W4 / M = 1 / bf16 kernel (0: the fp32-table form)
+    if (d16 && p->w_bit == 4 && p->dtype == BIE_BF16 && p->M == 1 && p->nw == 4) {
+        list_launch_zm<BIE_BF16, 4, 1 | 64>(a, p->rpg, p->grid, 1, p->zm, st);
+        return check_launch("mpq_list_kernel<d16>");
+    }
     if (p->w_bit == 2) {
         if (p->dtype == BIE_F16) list_launch_zm<BIE_F16, 2, 0>(a, p->rpg, p->grid, p->M, p->zm, st);
         else list_launch_zm<BIE_BF16, 2, 0>(a, p->rpg, p->grid, p->M, p->zm, st);
@@ -772,6 +938,126 @@ int mpq_list_forward(MpqList* p, hipStream_t st) {
         else list_launch_zm<BIE_BF16, 4, 1>(a, p->rpg, p->grid, p->M, p->zm, st);
     }
     return check_launch("mpq_list_kernel");
+}
+
+// ---- inline form: bie_mpq_forward / bie_mpq_forward_grouped on the decode path (W4, M = 1, bf16) -------------------------------
+// The same kernel as the list launch (D16 form) with the entries in the kernel arguments.  Plan of a LONE launch: every wave gets
+// `gpw` consecutive units of one 64-column tile (a unit = a quantisation group, or 1 / H of one when the layer is too small to fill
+// the chip); about `want` waves in all, four per workgroup; K sliced over S workgroups per tile (tagged granules in the caller's
+// workspace, generation words in its head).
+struct InlinePlan { int rpg, G, H, gpw, S, nw; };
+
+static InlinePlan inline_plan(int K, int group_size, int tiles_total) {
+    static const int want = list_env("BIE_INL_WANT_WAVES", 4096);
+    static const int max_waves = list_env("BIE_INL_MAX_WAVES", 6144);
+    static const int force_h = list_env("BIE_INL_H", 0);
+    static const int force_gpw = list_env("BIE_INL_GPW", 0);
+    static const int nw_env = list_env("BIE_INL_NW", 4);
+    InlinePlan p;
+    p.nw = nw_env == 4 ? 4 : 8;
+    const int gs = group_size > K ? K : group_size;
+    int rpg = gs / 8, G = K / gs, H = 1;
+    if (force_h > 0) H = force_h;
+    else
+        while (H < 4 && rpg / (2 * H) >= 4 && (long)tiles_total * G * H < want) H *= 2;
+    while (H > 1 && (rpg % H || rpg / H < 4)) H /= 2;
+    p.H = H;
+    p.rpg = rpg / H;
+    p.G = G * H;
+    int gpw = force_gpw > 0 ? force_gpw : (int)cdivl((long)tiles_total * p.G, max_waves);
+    if (gpw < 1) gpw = 1;
+    if (gpw > p.G) gpw = p.G;
+    p.S = cdiv(p.G, gpw * p.nw);
+    p.gpw = cdiv(p.G, p.S * p.nw);  // even out
+    p.S = cdiv(p.G, p.gpw * p.nw);
+    return p;
+}
+
+// Measured (profiles/r04_h_inl_sweep.txt, us per lone launch, per-layer lookup kernel of mpq_gemv_lut.hip against this form): 4096x4096 5.9 / 6.6,
+// 4096x11008 9.7 / 10.1, q/k/v 9.8 / 10.1, gate/up 15.2 / 15.7, 8192x28672 31.3 / 29.9 -- a lone launch of a Llama-7B-sized layer is bound
+// by its ramp, its per-wave latency chain and the cross-workgroup reduction, not by instruction count, and the older kernel's 8 waves per
+// SIMD hide that chain better; the list form's leaner stream only pays from ~96 MB of packed weights per launch.
+bool mpq_list_inline_ok(int M, int K, long n_total, int w_bit, int group_size, int zm, int dtype) {
+    static const int enabled = list_env("BIE_DECODE_INLINE", 1);  // 0: never; 2: always (tuning)
+    static const long min_mb = list_env("BIE_DECODE_INLINE_MIN_MB", 96);
+    if (!enabled || M != 1 || w_bit != 4 || dtype != BIE_BF16 || (zm != ZM_SYM && zm != ZM_ASYM)) return false;
+    const int gs = group_size > K ? K : group_size;
+    if (!((gs == 32 || gs == 64 || gs == 128 || gs == 256) && K % gs == 0)) return false;
+    return enabled == 2 || (long)K / 2 * n_total >= min_mb * (1L << 20);
+}
+
+size_t mpq_list_inline_part_floats(int M, int K, int group_size, int tiles_total, int w_bit) {
+    if (M != 1 || w_bit != 4) return 0;
+    const int gs = group_size > K ? K : group_size;
+    if (!(gs == 32 || gs == 64 || gs == 128 || gs == 256) || K % gs) return 0;
+    const InlinePlan p = inline_plan(K, group_size, tiles_total);
+    return p.S > 1 ? (size_t)(p.S - 1) * M * tiles_total * 64 * 2 : 0;
+}
+
+template <int ZM, int NWV>
+static void inline_launch_rpg(const ListArgsInl& a, int rpg, unsigned grid, hipStream_t st) {
+    constexpr int VAR = 1 | (NWV == 4 ? 8 : 0) | 64;
+    constexpr int T = NWV * 64;
+    switch (rpg) {
+        case 4: hipLaunchKernelGGL((mpq_list_kernel<BIE_BF16, ZM, 1, 4, 4, VAR, true>), dim3(grid), dim3(T), 0, st, a); break;
+        case 8: hipLaunchKernelGGL((mpq_list_kernel<BIE_BF16, ZM, 1, 8, 4, VAR, true>), dim3(grid), dim3(T), 0, st, a); break;
+        case 16: hipLaunchKernelGGL((mpq_list_kernel<BIE_BF16, ZM, 1, 16, 4, VAR, true>), dim3(grid), dim3(T), 0, st, a); break;
+        default: hipLaunchKernelGGL((mpq_list_kernel<BIE_BF16, ZM, 1, 32, 4, VAR, true>), dim3(grid), dim3(T), 0, st, a); break;
+    }
+}
+
+int mpq_list_inline_launch(int nsets, const int32_t* const* qw, const void* const* scales, const void* const* zeros, const void* const* bias,
+                           void* const* y, const int* N, const void* x, unsigned* gen, float* gran, int K, int group_size, int zm, hipStream_t st) {
+    BIE_REQUIRE(nsets >= 1 && nsets <= LIST_MAX_INLINE, BIE_ERR_INVALID_ARG, "mpq_list_inline_launch: %d sets", nsets);
+    ListArgsInl a;
+    memset(&a, 0, sizeof(a));
+    int tiles = 0;
+    for (int i = 0; i < nsets; i++) tiles += cdiv(N[i], 64);
+    const InlinePlan p = inline_plan(K, group_size, tiles);
+    const int gs = group_size > K ? K : group_size;
+    const long Gq = K / gs;
+    unsigned long long* g8 = reinterpret_cast<unsigned long long*>(gran);
+    int tile0 = 0;
+    for (int i = 0; i < nsets; i++) {
+        ListEntry& e = a.inl[i];
+        const int t = cdiv(N[i], 64);
+        e.qw = reinterpret_cast<const uint32_t*>(qw[i]);
+        e.scales = reinterpret_cast<const uint16_t*>(scales[i]);
+        e.zeros = zeros[i];
+        e.bias = bias ? reinterpret_cast<const uint16_t*>(bias[i]) : nullptr;
+        e.x = reinterpret_cast<const uint16_t*>(x);
+        e.y = reinterpret_cast<uint16_t*>(y[i]);
+        e.gran = p.S > 1 ? g8 : nullptr;
+        if (p.S > 1) g8 += (size_t)(p.S - 1) * t * 64;
+        e.gen = gen + tile0;
+        e.N = N[i];
+        e.K = K;
+        e.G = p.G;
+        e.gpw = p.gpw;
+        e.S = p.S;
+        e.hshift = p.H == 4 ? 2 : (p.H == 2 ? 1 : 0);
+        e.tiles = t;
+        e.qw_bytes = (unsigned)((long)K / 8 * N[i] * 4);
+        e.sc_bytes = (unsigned)(Gq * N[i] * 2);
+        e.ze_bytes = zm == ZM_ASYM ? (unsigned)(Gq * (N[i] / 8) * 4) : (unsigned)(Gq * N[i] * 2);
+        e.pad0 = (unsigned)tile0;  // tile_begin of this entry in the concatenated grid
+        tile0 += t;
+    }
+    a.n_inl = nsets;
+    a.tiles_total = tiles;
+    a.status = device_status_word();
+    a.epoch = next_launch_epoch();
+    test_forge_get(&a.tag_skew, &a.spin_limit);
+    a.M = 1;
+    const unsigned grid = (unsigned)tiles * (unsigned)p.S;
+    if (p.nw == 4) {
+        if (zm == ZM_ASYM) inline_launch_rpg<ZM_ASYM, 4>(a, p.rpg, grid, st);
+        else inline_launch_rpg<ZM_SYM, 4>(a, p.rpg, grid, st);
+    } else {
+        if (zm == ZM_ASYM) inline_launch_rpg<ZM_ASYM, 8>(a, p.rpg, grid, st);
+        else inline_launch_rpg<ZM_SYM, 8>(a, p.rpg, grid, st);
+    }
+    return check_launch("mpq_list_kernel<inline>");
 }
 
 }  // namespace bie

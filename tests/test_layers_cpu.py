@@ -212,3 +212,36 @@ def test_cutlass_layer_classes_mirror_reference_api():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         l4.eval()(torch.randn(2, 64).half())
     assert Q4MatMul(dtype=torch.half).x_clip.dtype == torch.half
+
+
+def test_sibling_group_protocol_without_a_gpu(monkeypatch):
+    """SiblingGroup (layers/qlinear/nbit/cuda/mpq_layer.py): observation round, confirmation of the members that really received the
+    leader's tensor, parked outputs keyed by the identity of x, a non-sibling beside them (o_proj), an in-place update of x between
+    the calls (version counter), and dissolution when parked outputs are not picked up.  The launches are stubbed: host logic only."""
+    from bitorch_engine.layers.qlinear.nbit.cuda import mpq_layer
+    calls = []
+
+    def fake_grouped(layers, x, _from_group=False):
+        calls.append([l.name for l in layers])
+        return [f"{l.name}({x.data_ptr()},{x._version})" for l in layers]
+    monkeypatch.setattr(mpq_layer.MPQLinearCuda, "forward_grouped", staticmethod(fake_grouped))
+
+    class M:
+        def __init__(self, name):
+            self.name = name
+    q, k, v, o = M("q"), M("k"), M("v"), M("o")
+    g = mpq_layer.SiblingGroup([q, k, v, o])
+    h, a = torch.zeros(1, 8), torch.ones(1, 8)
+    assert [g.forward(m, t) for m, t in ((q, h), (k, h), (v, h), (o, a))] == [None] * 4 and not calls   # round 1: everybody alone
+    h2 = torch.zeros(1, 8)
+    out_q = g.forward(q, h2)                                                                       # round 2: one grouped launch
+    assert calls == [["q", "k", "v"]] and out_q.startswith("q(")
+    assert g.forward(k, h2).startswith("k(") and g.forward(v, h2).startswith("v(") and g.forward(o, a) is None and len(calls) == 1
+    h3 = torch.zeros(1, 8)
+    g.forward(q, h3)
+    h3.add_(1)                                                                                     # x changed in place: parked k is stale
+    assert g.forward(k, h3) is None and g.confirmed is not None and [m.name for m in g.confirmed] == ["q", "v"]
+    assert g.forward(v, h3) is None                                                                # v's parked output is stale too (same key)
+    for _ in range(4):                                                                             # nobody picks the parked outputs up
+        g.forward(q, torch.zeros(1, 8))
+    assert g.dead and g.forward(q, h) is None

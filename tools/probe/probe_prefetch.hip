@@ -23,6 +23,9 @@ struct Args {
     const char* pf;      // next layer's weights (or NULL)
     long pf_bytes;
     int N, rows_total, tiles, slices, pf_blocks, pf_mode, work, nt;
+    int tail_blocks;     // > 0: the first tail_blocks COMPUTE blocks touch the first tail_bytes of pf after their own rows are summed (fire and forget)
+    long tail_bytes;
+    int tail_xcd;        // 1: a block touches only the 256-byte segments whose consumer shares its XCD
 };
 
 // pf_mode 0: linear split of the lines over the prefetch blocks; 1: XCD-aware (a block touches the 256-byte column segments whose
@@ -83,6 +86,27 @@ __global__ __launch_bounds__(256) void consume(const Args a) {
             acc += f;
         }
     }
+    if (b < a.tail_blocks && a.pf != nullptr) {
+        asm volatile("" : "+v"(acc));  // after the wave's own rows
+        uint32_t v = 0;
+        if (a.tail_xcd && (a.tiles & 7) == 0) {
+            const long row_bytes = (long)a.N * 4;
+            const int xcd = b & 7, same = a.tail_blocks / 8, idx = b / 8, tiles_x = a.tiles / 8;
+            const long segs = a.tail_bytes / row_bytes * tiles_x;   // (row, tile of my class)
+            const long per = (segs + same - 1) / same;
+            for (long i = threadIdx.x; i < per * 2; i += 256) {
+                const long sg = (long)idx * per + i / 2;
+                if (sg < segs) asm volatile("global_load_dword %0, %1, off" : "+v"(v) : "v"(a.pf + (sg / tiles_x) * row_bytes + ((sg % tiles_x) * 8 + xcd) * 256L + (i & 1) * 128));
+            }
+        } else {
+            const long lines = a.tail_bytes / 128, per = (lines + a.tail_blocks - 1) / a.tail_blocks;
+            for (long i = threadIdx.x; i < per; i += 256) {
+                const long l = (long)b * per + i;
+                if (l < lines) asm volatile("global_load_dword %0, %1, off" : "+v"(v) : "v"(a.pf + l * 128));
+            }
+        }
+        asm volatile("" : "+v"(v));  // not waited for: s_endpgm drains
+    }
     __shared__ float red[4][64];
     red[wave][lane] = acc;
     __syncthreads();
@@ -90,7 +114,7 @@ __global__ __launch_bounds__(256) void consume(const Args a) {
 }
 
 static float run_chain(const std::vector<uint32_t*>& bufs, float* y0, float* y1, int N, int rows, int slices, int pf_blocks, int pf_mode, bool pf, int work,
-                       int nt, bool same_buffer, int reps) {
+                       int nt, bool same_buffer, int reps, int tail_blocks = 0, long tail_bytes = 0, int tail_xcd = 0) {
     hipStream_t st;
     CK(hipStreamCreate(&st));
     const int tiles = N / 64;
@@ -103,6 +127,7 @@ static float run_chain(const std::vector<uint32_t*>& bufs, float* y0, float* y1,
             a.pf = pf ? (const char*)bufs[(i + 1) % bufs.size()] : nullptr;
             a.pf_bytes = (long)rows * N * 4;
             a.N = N; a.rows_total = rows; a.tiles = tiles; a.slices = slices; a.pf_blocks = pf_blocks; a.pf_mode = pf_mode; a.work = work; a.nt = nt;
+            a.tail_blocks = tail_blocks; a.tail_bytes = tail_bytes; a.tail_xcd = tail_xcd;
             hipLaunchKernelGGL(consume, dim3(tiles * slices + pf_blocks), dim3(256), 0, st, a);
         }
     };
@@ -142,18 +167,20 @@ int main(int argc, char** argv) {
         const int nb = (int)(bufs.size());
         (void)nb;
         printf("== %s, %d rotating buffers (%.0f MB), grid %d x 256, us per launch (dependent chain, hipGraph)\n", s.name, NB, bytes * NB / 1e6, s.N / 64 * s.slices);
-        for (int work : {0, 10}) {
+        for (int work : {4, 10, 20}) {
             const float cold = run_chain(bufs, y0, y1, s.N, s.rows, s.slices, 0, 0, false, work, 1, false, 10);
-            const float cold_plain = run_chain(bufs, y0, y1, s.N, s.rows, s.slices, 0, 0, false, work, 0, false, 10);
             const float hot = run_chain(bufs, y0, y1, s.N, s.rows, s.slices, 0, 0, false, work, 0, true, 10);
-            printf("  work %2d: no prefetch (nt) %6.2f | (plain loads) %6.2f | same buffer every launch (cache-hot) %6.2f\n", work, cold, cold_plain, hot);
-            for (int pfb : {64, 256}) {
-                for (int mode : {0, 1, 2, 5}) {
-                    if ((mode & 3) && (s.N / 64) % 8) continue;
-                    const float t_nt = run_chain(bufs, y0, y1, s.N, s.rows, s.slices, pfb, mode, true, work, 1, false, 10);
-                    const float t_pl = run_chain(bufs, y0, y1, s.N, s.rows, s.slices, pfb, mode, true, work, 0, false, 10);
-                    printf("    prefetch next: %3d blocks, mode %d (%s%s): consumer nt %6.2f | plain %6.2f\n", pfb, mode,
-                           (mode & 3) == 0 ? "linear" : ((mode & 3) == 1 ? "same XCD" : "next XCD"), (mode & 4) ? ", every 64 B" : "", t_nt, t_pl);
+            printf("  work %2d: no prefetch %6.2f | same buffer every launch (cache-hot) %6.2f\n", work, cold, hot);
+            const int grid = s.N / 64 * s.slices;
+            for (int tb : {grid / 4 / 8 * 8, grid / 2 / 8 * 8, grid}) {
+                for (long mb : {1L, 2L, 4L, 8L, 1000L}) {
+                    long tbytes = mb * (1L << 20);
+                    if (tbytes > (long)bytes) tbytes = bytes;
+                    tbytes = tbytes / ((long)s.N * 4) * ((long)s.N * 4);
+                    const float t0 = run_chain(bufs, y0, y1, s.N, s.rows, s.slices, 0, 0, true, work, 1, false, 10, tb, tbytes, 0);
+                    const float t1 = run_chain(bufs, y0, y1, s.N, s.rows, s.slices, 0, 0, true, work, 1, false, 10, tb, tbytes, 1);
+                    printf("    tail prefetch by the first %4d of %d blocks, first %5.1f MB of the next layer: linear %6.2f | XCD-matched %6.2f\n", tb, grid, tbytes / 1048576.0, t0, t1);
+                    if (tbytes == (long)bytes) break;
                 }
             }
         }
