@@ -104,7 +104,7 @@ def time_graph(g, reps):
     return e0.elapsed_time(e1) * 1e3 / reps
 
 
-PMC_FILE = "r03_pmc_gemv.json"
+PMC_FILE = "r04_pmc_gemv.json"
 
 
 def kernel_source_sha():
@@ -520,9 +520,11 @@ def bench_binary(dev, L):
         w = torch.randn((512, 512, 3, 3), device=dev)
         from bitorch_engine.extensions._binary_common import pack_rows
         wp = pack_rows(w.reshape(512, -1)).contiguous()  # what BinaryConv2dCPP.generate_quantized_weight stores (eval mode)
-        fn = lambda st: binary_conv_cpp.forward(x, wp, 512, B * 49, 512 * 9, 3, 1, 1, 1, 7)
+        # 16 calls per graph replay: a replay costs ~10 us by itself (MI355X_MICROARCH.md "graph-replay-floor"; an EMPTY kernel timed one per
+        # replay reads 10.1 us, profiles/r04_l_conv_dbg.txt), which rounds 1-3 charged to this row at B = 1
+        fn = lambda st: [binary_conv_cpp.forward(x, wp, 512, B * 49, 512 * 9, 3, 1, 1, 1, 7) for _ in range(16)]
         try:
-            us = time_graph(capture(fn), 20)
+            us = time_graph(capture(fn), 20) / 16
             tops = 2.0 * B * 49 * 512 * 4608 / us / 1e6
             fp4 = B * 49 >= 1024  # the dispatch of extensions/_binary_common.py::conv2d: large batches run as an FP4 GEMM on the matrix pipe
             peak = FP4_MFMA_PEAK_TOPS if fp4 else XOR_POPC_PEAK_TOPS
@@ -791,7 +793,7 @@ def main():
                        "parallelism": "output-column sharding x%d + 1 all-gather/step" % world if distributed else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": (lambda t: None if t is None else t * LAYERS)(pmc_traffic(f"list{LAYERS}_{K}x{N}")),
-                         "kernel": "bie::mpq_list_kernel<bf16,sym,M=1,rpg=16,w4>", "avg_launch_us": round(avg_us, 3), "us_per_layer": round(avg_us / LAYERS, 3),
+                         "kernel": "bie::mpq_list_kernel<bf16,sym,M=1,rpg=16,w4,D16> (16-bit pair tables, ds_read_u16_d16_hi lookups, v_pk_fma_f32)", "avg_launch_us": round(avg_us, 3), "us_per_layer": round(avg_us / LAYERS, 3),
                          "alg_bytes_per_launch": alg_bytes(1, K, N) * LAYERS},
             # the same K passes timed straight after the W warm-up passes, before the untimed replays that bring the chip to its sustained clock
             "cold_start": {"value": round(step_bytes * world / (cold_elapsed / args.steps) / 1e9, 2), "unit": "GB/s", "ms_per_step": round(cold_elapsed / args.steps * 1e3, 4),

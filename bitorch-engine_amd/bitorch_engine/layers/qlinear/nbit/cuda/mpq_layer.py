@@ -102,7 +102,7 @@ def find_sibling_groups(model: torch.nn.Module) -> int:
         for c in kids:
             buckets.setdefault((c.in_channels, c.w_bit, c.group_size, bool(c.asym), c.dtype), []).append(c)
         for members in buckets.values():
-            if len(members) >= 2 and members[0].w_bit == 4:
+            if len(members) >= 2 and members[0].w_bit in (4, 2):
                 g = SiblingGroup(members)
                 for m in members:
                     m._bie_group = g
@@ -212,7 +212,8 @@ class MPQLinearCuda(MPQLinearBase):
         x2, lead = flatten_x(x)
         same = all(l.w_bit == first.w_bit and l.group_size == first.group_size and l.asym == first.asym and l.in_channels == first.in_channels
                    and l.scales.dtype == first.scales.dtype and not l.training for l in layers)
-        ok = (same and first.w_bit == 4 and 1 <= x2.shape[0] <= 16 and 2 <= len(layers) <= 8 and x2.dtype == first.scales.dtype
+        max_rows = 16 if first.w_bit == 4 else 2  # the grouped decode launch: W4 up to 16 rows (lookup / matrix-pipe kernel), W2 up to 2 (pair lookup)
+        ok = (same and first.w_bit in (4, 2) and 1 <= x2.shape[0] <= max_rows and 2 <= len(layers) <= 8 and x2.dtype == first.scales.dtype
               and not (torch.is_grad_enabled() and x.requires_grad)
               and all(q_linear_cuda.gidx_is_trivial(l.g_idx, l.group_size) for l in layers))
         if not ok:

@@ -549,7 +549,10 @@ def test_binary_conv_vs_reference_cpp_golden_and_resnet_shape():
 
 @pytest.mark.parametrize("B,C,H,W,OC,ks,st,pad,dil", [(2, 64, 14, 14, 64, 3, 1, 1, 1), (1, 24, 9, 11, 36, 3, 2, 1, 1), (3, 8, 7, 7, 4, 1, 1, 0, 1),
                                                      (2, 40, 12, 10, 70, 3, 1, 2, 2), (1, 128, 5, 17, 130, 5, 1, 2, 1), (2, 32, 8, 8, 64, 2, 2, 0, 1),
-                                                     (1, 64, 6, 300, 8, 7, 2, 3, 1)])
+                                                     (1, 64, 6, 300, 8, 7, 2, 3, 1),
+                                                     # small batches of the deep ResNet layers (the one-wave DMA-staged tap kernel)
+                                                     (1, 512, 7, 7, 512, 3, 1, 1, 1), (4, 512, 7, 7, 512, 3, 1, 1, 1), (2, 256, 14, 14, 256, 3, 1, 1, 1),
+                                                     (3, 128, 9, 11, 64, 3, 2, 1, 1), (1, 128, 28, 28, 128, 3, 1, 1, 1), (2, 256, 7, 7, 128, 1, 1, 0, 1)])
 def test_binary_conv_tap_form_equals_the_im2col_form_and_the_oracle(B, C, H, W, OC, ks, st, pad, dil):
     """The implicit conv (tap-major weights x channel-minor activation bits, no im2col image) against the round-1 bit-im2col path
     through the C ABI and against the oracle: strides, dilation, channel counts that are not multiples of 32, output widths that
@@ -926,7 +929,8 @@ def test_layer_level_grouped_forward_equals_the_separate_layers():
                     assert_close(y.reshape(-1, l.out_channels), ref.reshape(-1, l.out_channels), orc.BF16, f"grouped layers {lead}")
 
 
-def test_unmodified_module_tree_gets_grouped_launches_after_prepare_bie_layers():
+@pytest.mark.parametrize("w_bit", [4, 2])
+def test_unmodified_module_tree_gets_grouped_launches_after_prepare_bie_layers(w_bit):
     """a caller written against the reference's module API (q_proj(h), k_proj(h), v_proj(h), o_proj(a), gate(h2), up(h2),
     down(...)) is not changed; prepare_bie_layers() registers the sibling candidates, the first forward confirms who really shares an
     input, and from the second forward on q/k/v and gate/up each run as ONE grouped decode launch (counters), with the results of the
@@ -938,7 +942,7 @@ def test_unmodified_module_tree_gets_grouped_launches_after_prepare_bie_layers()
     g = torch.Generator().manual_seed(23)
 
     def lin(K, N):
-        layer = MPQLinearCuda(K, N, w_bit=4, dtype=torch.bfloat16, group_size=gs, dq_group_size=32, use_gba_quant=True, asym=False)
+        layer = MPQLinearCuda(K, N, w_bit=w_bit, dtype=torch.bfloat16, group_size=gs, dq_group_size=32, use_gba_quant=True, asym=False)
         layer.qweight.data = torch.randint(-2 ** 31, 2 ** 31 - 1, layer.qweight.shape, generator=g, dtype=torch.int64).to(torch.int32)
         return layer
 
@@ -972,8 +976,8 @@ def test_unmodified_module_tree_gets_grouped_launches_after_prepare_bie_layers()
     prepare_bie_layers(model)
     for m in model.modules():
         if isinstance(m, MPQLinearCuda):
-            m.scales = (torch.rand(m.scales.shape, generator=g) * 0.004 + 0.002).bfloat16()
-            m.zeros = (m.scales.float() * 7.5).bfloat16()
+            m.scales = (torch.rand(m.scales.shape, generator=g) * 0.004 + 0.002).bfloat16() * (1 if w_bit == 4 else 5)
+            m.zeros = (m.scales.float() * (2 ** w_bit - 1) / 2).bfloat16()
     model.to(DEV).eval()
     layers = [m for m in model.modules() if isinstance(m, MPQLinearCuda)]
     assert all(l._bie_group is not None for l in layers if l.in_channels == H) and all(l._bie_group is None for l in layers if l.in_channels == I)
