@@ -25,7 +25,8 @@ struct Args {
     int N, rows_total, tiles, slices, pf_blocks, pf_mode, work, nt;
     int tail_blocks;     // > 0: the first tail_blocks COMPUTE blocks touch the first tail_bytes of pf after their own rows are summed (fire and forget)
     long tail_bytes;
-    int tail_xcd;        // 1: a block touches only the 256-byte segments whose consumer shares its XCD
+    int tail_xcd;        // 1: a block touches only the 256-byte segments whose consumer shares its XCD; 2: page touch -- the first 8 blocks (one per XCD) touch one dword every tail_stride bytes of the WHOLE next layer (TLB warm-up)
+    long tail_stride;
 };
 
 // pf_mode 0: linear split of the lines over the prefetch blocks; 1: XCD-aware (a block touches the 256-byte column segments whose
@@ -86,7 +87,14 @@ __global__ __launch_bounds__(256) void consume(const Args a) {
             acc += f;
         }
     }
-    if (b < a.tail_blocks && a.pf != nullptr) {
+    if (a.tail_xcd == 2 && a.pf != nullptr) {
+        if (b < 8 && wave == 0) {
+            uint32_t v = 0;
+            for (long off = (long)lane * a.tail_stride; off < a.pf_bytes; off += 64 * a.tail_stride)
+                asm volatile("global_load_dword %0, %1, off" : "+v"(v) : "v"(a.pf + off));
+            asm volatile("" : "+v"(v));
+        }
+    } else if (b < a.tail_blocks && a.pf != nullptr) {
         asm volatile("" : "+v"(acc));  // after the wave's own rows
         uint32_t v = 0;
         if (a.tail_xcd && (a.tiles & 7) == 0) {
@@ -114,7 +122,7 @@ __global__ __launch_bounds__(256) void consume(const Args a) {
 }
 
 static float run_chain(const std::vector<uint32_t*>& bufs, float* y0, float* y1, int N, int rows, int slices, int pf_blocks, int pf_mode, bool pf, int work,
-                       int nt, bool same_buffer, int reps, int tail_blocks = 0, long tail_bytes = 0, int tail_xcd = 0) {
+                       int nt, bool same_buffer, int reps, int tail_blocks = 0, long tail_bytes = 0, int tail_xcd = 0, long tail_stride = 0) {
     hipStream_t st;
     CK(hipStreamCreate(&st));
     const int tiles = N / 64;
@@ -127,7 +135,7 @@ static float run_chain(const std::vector<uint32_t*>& bufs, float* y0, float* y1,
             a.pf = pf ? (const char*)bufs[(i + 1) % bufs.size()] : nullptr;
             a.pf_bytes = (long)rows * N * 4;
             a.N = N; a.rows_total = rows; a.tiles = tiles; a.slices = slices; a.pf_blocks = pf_blocks; a.pf_mode = pf_mode; a.work = work; a.nt = nt;
-            a.tail_blocks = tail_blocks; a.tail_bytes = tail_bytes; a.tail_xcd = tail_xcd;
+            a.tail_blocks = tail_blocks; a.tail_bytes = tail_bytes; a.tail_xcd = tail_xcd; a.tail_stride = tail_stride;
             hipLaunchKernelGGL(consume, dim3(tiles * slices + pf_blocks), dim3(256), 0, st, a);
         }
     };
@@ -167,22 +175,15 @@ int main(int argc, char** argv) {
         const int nb = (int)(bufs.size());
         (void)nb;
         printf("== %s, %d rotating buffers (%.0f MB), grid %d x 256, us per launch (dependent chain, hipGraph)\n", s.name, NB, bytes * NB / 1e6, s.N / 64 * s.slices);
-        for (int work : {4, 10, 20}) {
+        for (int work : {0, 4, 10}) {
             const float cold = run_chain(bufs, y0, y1, s.N, s.rows, s.slices, 0, 0, false, work, 1, false, 10);
-            const float hot = run_chain(bufs, y0, y1, s.N, s.rows, s.slices, 0, 0, false, work, 0, true, 10);
-            printf("  work %2d: no prefetch %6.2f | same buffer every launch (cache-hot) %6.2f\n", work, cold, hot);
-            const int grid = s.N / 64 * s.slices;
-            for (int tb : {grid / 4 / 8 * 8, grid / 2 / 8 * 8, grid}) {
-                for (long mb : {1L, 2L, 4L, 8L, 1000L}) {
-                    long tbytes = mb * (1L << 20);
-                    if (tbytes > (long)bytes) tbytes = bytes;
-                    tbytes = tbytes / ((long)s.N * 4) * ((long)s.N * 4);
-                    const float t0 = run_chain(bufs, y0, y1, s.N, s.rows, s.slices, 0, 0, true, work, 1, false, 10, tb, tbytes, 0);
-                    const float t1 = run_chain(bufs, y0, y1, s.N, s.rows, s.slices, 0, 0, true, work, 1, false, 10, tb, tbytes, 1);
-                    printf("    tail prefetch by the first %4d of %d blocks, first %5.1f MB of the next layer: linear %6.2f | XCD-matched %6.2f\n", tb, grid, tbytes / 1048576.0, t0, t1);
-                    if (tbytes == (long)bytes) break;
-                }
+            const float cold2 = run_chain(bufs, y0, y1, s.N, s.rows, s.slices, 0, 0, false, work, 1, false, 10);
+            printf("  work %2d: no prefetch %6.2f %6.2f |", work, cold, cold2);
+            for (long stride : {2L << 20, 64L << 10, 4L << 10}) {
+                const float t = run_chain(bufs, y0, y1, s.N, s.rows, s.slices, 0, 0, true, work, 1, false, 10, 8, 0, 2, stride);
+                printf(" page touch every %4ld KiB by one wave per XCD %6.2f |", stride >> 10, t);
             }
+            printf("\n");
         }
         for (auto b : bufs) CK(hipFree(b));
     }
