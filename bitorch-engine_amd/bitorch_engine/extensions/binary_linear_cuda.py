@@ -43,8 +43,8 @@ def w_pack(weights: torch.Tensor, bmm_type: int, transpose: bool) -> torch.Tenso
 def image_to_rows(image: torch.Tensor, n: int, k: int, bmm_type: int) -> torch.Tensor:
     """image -> row-packed [N, K/8] (remembered on the image tensor until it changes)."""
     kind = image_kind(bmm_type, n, k)
-    if kind is None:
-        return image.reshape(n, k // 8)
+    if kind is None:  # the image IS the row-packed matrix: hand out ONE view object per tensor version, so that conversions memoised on it
+        return _cached(image, ("rows", None, n, k), lambda: image.reshape(n, k // 8))  # (the FP4 weight image) are not rebuilt every forward (ADVICE r3)
 
     def convert():
         _hip.need_gpu(image)
@@ -60,8 +60,8 @@ def forward(input: torch.Tensor, weights: torch.Tensor, bmm_type: int, transpose
     if weights.dtype == torch.uint8:
         n = weights.numel() * 8 // k
         wp = image_to_rows(weights, n, k, bmm_type)
-    else:
-        wp = pack_rows(weights)
+    else:  # unpacked sign carriers (training-mode weight): packed once per tensor version, remembered on the weight tensor
+        wp = _cached(weights, ("rows_from_values",), lambda: pack_rows(weights).contiguous())
     wp = wp.contiguous()
     if fp4_ok(m, wp.shape[0], k) and (input.dtype in _hip._DT or input.dtype == torch.int8):
         return xnor_values_fp4(input, wp)  # large M: sign-pack folded into the FP4 image pass, GEMM on the matrix pipe (two launches)

@@ -14,7 +14,11 @@ def w_pack(weight: torch.Tensor, transpose: bool) -> torch.Tensor:
 
 def forward(input: torch.Tensor, weight: torch.Tensor, scale: float, transpose: bool, kernel_id: int) -> torch.Tensor:
     m, k = input.shape
-    wp = (weight if weight.dtype == torch.uint8 else w_pack(weight, transpose)).contiguous()
+    if weight.dtype == torch.uint8:
+        wp = weight.contiguous()
+    else:  # unpacked weight: packed once per tensor version (and with it the FP4 image memoised on the packed tensor)
+        from .q_linear_cuda import _cached
+        wp = _cached(weight, ("rows_from_values", bool(transpose)), lambda: w_pack(weight, transpose).contiguous())
     if fp4_ok(m, wp.shape[0], k):  # large M: sign-pack folded into the FP4 image pass, GEMM on the matrix pipe
         return xnor_values_fp4(input, wp, scale)
     return xnor_linear(pack_rows(input), wp, m, wp.shape[0], k, 0, scale)

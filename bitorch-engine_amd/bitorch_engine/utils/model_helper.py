@@ -154,10 +154,15 @@ def qweight_update_fn(qweight: torch.nn.Parameter, exp_avg_s: torch.Tensor = Non
     the HIP pack kernel (bie_mpq_pack == pack_fp_weight: round(w / s + z), clamp, bit-pack); the moment arithmetic in between is
     the reference's own sequence of torch elementwise ops in `dtype`, op for op, so every rounding lands where the reference's does
     (pinned to reference outputs: tests/golden/update_step.npz).  Like the reference, pack_fp_weight sees the zero points from
-    BEFORE this step's update_zeros."""
+    BEFORE this step's update_zeros.
+    PARITY MODE: the golden vectors come from the reference run on the CPU (the only place it runs in this container), so two ops are spelled
+    with torch's CPU-kernel roundings (_add_scaled_, the addcmul below).  The reference's MPQ update executes on CUDA tensors in practice,
+    where torch keeps `alpha` in fp32 and fuses differently: about a third of the first-moment elements then differ in the last bit from this
+    function, which can flip a re-packed integer now and then.  This is CPU-kernel parity, stated as such; GPU-kernel parity
+    would need vectors generated by the reference on a GPU."""
     from bitorch_engine.extensions import q_linear_cuda
     from bitorch_engine.layers.qlinear.nbit.layer import MPQWeightParameter
-    step.add_(1)
+    step.add_(1)  # FIRST, as the reference (utils/model_helper.py:401: the counter moves before the parameter kind is looked at, also when a branch then raises)
     if not isinstance(qweight, MPQWeightParameter):
         raise NotImplementedError("qweight_update_fn: only MPQWeightParameter is updated by this build (the binary / n-bit integer parameters need "
                                   "the reference's custom torch with gradients on integer tensors)")
