@@ -22,7 +22,10 @@ GROUP_MAX_M = 16  # rows the grouped decode launch takes (bie_mpq_forward_groupe
 
 
 def _x_key(x):
-    return (x.data_ptr(), x._version, tuple(x.shape), tuple(x.stride()), x.dtype, x.device)
+    """Identity of an activation tensor for the sibling protocol: same storage, same version, same view -- and the same STREAM: a parked
+    output is only handed to a sibling that is called on the stream the group launch was enqueued on (stream order is what makes it valid)."""
+    stream = torch.cuda.current_stream(x.device).cuda_stream if x.is_cuda else 0
+    return (x.data_ptr(), x._version, tuple(x.shape), tuple(x.stride()), x.dtype, x.device, stream)
 
 
 class SiblingGroup:

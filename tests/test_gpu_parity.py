@@ -1679,6 +1679,30 @@ def test_the_list_instances_bench_py_times_against_the_oracle(K, N, nl, w_bit):
         assert_close(y_all[i:i + 1], ref, orc.BF16, f"bench list instance {nl} x {K}x{N} w{w_bit}, layer {i}")
 
 
+@pytest.mark.parametrize("asym", [0, 1])
+def test_lone_decode_launches_of_100_mb_and_more_take_the_inline_list_form(asym):
+    """bie_mpq_forward / bie_mpq_forward_grouped at M = 1, W4, bf16 with >= 96 MB of packed weights per launch run the list kernel's D16
+    form with the entries in the kernel arguments (mpq_list_inline_launch: block -> (entry, tile, slice) by arithmetic, K sliced over
+    workgroups, granules in the caller's workspace): configs[4]'s 8192x28672 layer as one launch, and two 8192x14336 sets sharing x
+    as one grouped launch, against the oracle."""
+    from bitorch_engine.extensions import q_linear_cuda
+    K, gs, dt = 8192, 128, orc.BF16
+    rng = np.random.default_rng(77 + asym)
+    qw, scales, zeros, gen = rand_case(rng, K, 28672, 4, gs, dt, asym)
+    x = torch.randn((1, K), generator=gen).to(TDT[dt])
+    y = hip_forward(x, qw, scales, zeros, None, 4, gs, asym)
+    assert_close(y, oracle_forward(x, qw, scales, zeros, None, 4, gs, asym, dt), dt, f"inline list form, lone 8192x28672 asym={asym}")
+    y2 = hip_forward(x, qw, scales, zeros, None, 4, gs, asym)  # second launch into the same workspace: next granule generation
+    assert torch.equal(y, y2)
+    sets, refs = [], []
+    for i in range(2):
+        q2, s2, z2, _ = rand_case(np.random.default_rng(900 + i + asym), K, 14336, 4, gs, dt, asym)
+        sets.append(tuple(t.to(DEV) for t in (q2, s2, z2)) + (None,))
+        refs.append(oracle_forward(x, q2, s2, z2, None, 4, gs, asym, dt))
+    for yg, r in zip(q_linear_cuda.mpq_forward_grouped_impl(x.to(DEV), sets, 4, asym, gs), refs):
+        assert_close(yg, r, dt, f"inline list form, grouped 2 x 8192x14336 asym={asym}")
+
+
 def test_reducer_timeout_fails_loudly():
     """A reducer whose partial sums never arrive (forged: it is told to expect another tag) must not return a number: NaN in y,
     a bit in the status page, and the NEXT launching call fails with BIE_ERR_DEVICE (then the page is clear again)."""
