@@ -949,7 +949,7 @@ struct InlinePlan { int rpg, G, H, gpw, S, nw; };
 
 static InlinePlan inline_plan(int K, int group_size, int tiles_total) {
     static const int want = list_env("BIE_INL_WANT_WAVES", 4096);
-    static const int max_waves = list_env("BIE_INL_MAX_WAVES", 6144);
+    static const int max_waves = list_env("BIE_INL_MAX_WAVES", 16384);  // more waves than are resident at once: the second round starts staggered (117 MB: 29.3 against 31.0 us at 6144, 250 MB: 52.4 against 56.3; profiles/r04_t_inl_big_sweep.txt)
     static const int force_h = list_env("BIE_INL_H", 0);
     static const int force_gpw = list_env("BIE_INL_GPW", 0);
     static const int nw_env = list_env("BIE_INL_NW", 4);
