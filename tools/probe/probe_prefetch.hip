@@ -167,7 +167,7 @@ int main(int argc, char** argv) {
     CK(hipMemset(y0, 0, 1 << 20)); CK(hipMemset(y1, 0, 1 << 20));
     struct Shape { int N, rows, slices; const char* name; };
     const Shape shapes[] = {{4096, 512, 8, "4096x4096 (8.4 MB)"}, {11008, 512, 4, "4096x11008 (22.5 MB, tiles%8=4)"}, {12288, 512, 4, "4096x12288 q/k/v (25.2 MB)"},
-                            {4096, 1536, 8, "12288x4096 (25.2 MB)"}};
+                            {4096, 1536, 8, "12288x4096 (25.2 MB)"}, {22016, 512, 4, "4096x22016 gate/up (45.1 MB)"}};
     for (const Shape& s : shapes) {
         std::vector<uint32_t*> bufs(NB);
         const size_t bytes = (size_t)s.rows * s.N * 4;
