@@ -95,7 +95,7 @@ __device__ unsigned long long g_list_stamps[65536 * 6];
 //        looked up with ds_read_u16_d16_hi (the load zeroes the low half: the register IS the fp32 value of the bf16 weight), both tables
 //        built before the pair's rows are needed, lookups pipelined in half-row chunks with counted lgkmcnt (three chunks in flight)
 template <int DT, int ZM, int MT, int RPG, int WB, int VAR, bool INL = false>
-__global__ __launch_bounds__(((VAR & 8) ? 256 : ((VAR & 16) ? 128 : ((VAR & 32) ? 64 : 512))), ((VAR & 4) ? 8 : 1)) void mpq_list_kernel(const std::conditional_t<INL, ListArgsInl, ListArgs> a) {
+__global__ __launch_bounds__(((VAR & 8) ? 256 : ((VAR & 16) ? 128 : ((VAR & 32) ? 64 : 512))), ((VAR & 4) ? 8 : ((VAR & 128) ? 7 : 1))) void mpq_list_kernel(const std::conditional_t<INL, ListArgsInl, ListArgs> a) {
     constexpr int NW = (VAR & 8) ? 4 : ((VAR & 16) ? 2 : ((VAR & 32) ? 1 : 8));  // bits 4 / 5 (tuning aids): two / one wave per workgroup
     constexpr int NB = 32 / WB;      // weights per packed word
     constexpr int XD = NB / 2;       // x dwords (16-bit pairs) per packed word
@@ -421,7 +421,8 @@ __global__ __launch_bounds__(((VAR & 8) ? 256 : ((VAR & 16) ? 128 : ((VAR & 32) 
             for (int i = 0; i < RPG * 4; i += 8)  // landed in SGPRs before the first lookup: nothing but LDS traffic is counted by lgkmcnt below
                 asm volatile("" ::"s"(xs[i]), "s"(xs[i + 1]), "s"(xs[i + 2]), "s"(xs[i + 3]), "s"(xs[i + 4]), "s"(xs[i + 5]), "s"(xs[i + 6]), "s"(xs[i + 7]));
             constexpr int NC = 2 * RPG;  // chunks: (row, even nibbles), (row, odd nibbles)
-            float t[3][4];
+            constexpr int RING = (VAR & 2048) ? 2 : 3;  // chunks of lookups in flight (bit 11, lab: two -- 4 registers less)
+            float t[RING][4];
             uint32_t wprep[2] = {0, 0};  // even / odd prepared word of the row being issued
             auto issue = [&](int c, float (&tt)[4]) {  // c is a compile-time value after unrolling
                 const int u = c >> 1;
@@ -431,18 +432,23 @@ __global__ __launch_bounds__(((VAR & 8) ? 256 : ((VAR & 16) ? 128 : ((VAR & 32) 
                 }
                 const uint32_t wp = wprep[c & 1];
                 const uint32_t a0 = list_lut_addr<0>(la, wp), a1 = list_lut_addr<1>(la, wp), a2 = list_lut_addr<2>(la, wp), a3 = list_lut_addr<3>(la, wp);
+                if constexpr ((VAR & 256) != 0) {  // ablation (lab): no LDS reads -- the address registers stand in for the looked-up values
+                    tt[0] = __uint_as_float(a0); tt[1] = __uint_as_float(a1); tt[2] = __uint_as_float(a2); tt[3] = __uint_as_float(a3);
+                    asm volatile("" : "+v"(tt[0]), "+v"(tt[1]), "+v"(tt[2]), "+v"(tt[3]));
+                } else {
                 asm volatile("ds_read_u16_d16_hi %0, %1 offset:%2" : "=v"(tt[0]) : "v"(a0), "n"(2 * HALF));
                 asm volatile("ds_read_u16_d16_hi %0, %1 offset:%2" : "=v"(tt[1]) : "v"(a1), "n"(2 * HALF));
                 asm volatile("ds_read_u16_d16_hi %0, %1 offset:%2" : "=v"(tt[2]) : "v"(a2), "n"(2 * HALF));
                 asm volatile("ds_read_u16_d16_hi %0, %1 offset:%2" : "=v"(tt[3]) : "v"(a3), "n"(2 * HALF));
+                }
             };
             issue(0, t[0]);
-            issue(1, t[1]);
+            if constexpr (RING == 3) issue(1, t[1]);
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                if (c + 2 < NC) issue(c + 2, t[(c + 2) % 3]);
+                if (c + RING - 1 < NC) issue(c + RING - 1, t[(c + RING - 1) % RING]);
                 __builtin_amdgcn_sched_barrier(0);
-                float(&tc)[4] = t[c % 3];
+                float(&tc)[4] = t[c % RING];
                 // the four activations of this chunk, bf16 -> fp32 on the scalar unit, HERE: as plain expressions the DAG linearisation hoists
                 // all 8 x RPG of them to the top of the unit, where they do not fit in SGPRs (112 spilled to VGPR lanes: a v_readlane per use)
                 uint32_t xu[4];
@@ -459,11 +465,13 @@ __global__ __launch_bounds__(((VAR & 8) ? 256 : ((VAR & 16) ? 128 : ((VAR & 32) 
                                      : "s"(xs[u * 4 + 0]), "s"(xs[u * 4 + 1]), "s"(xs[u * 4 + 2]), "s"(xs[u * 4 + 3])
                                      : "scc");
                 }
-                const int behind = (NC - 1 - c) < 2 ? (NC - 1 - c) : 2;  // chunks issued after chunk c
+                const int behind = (NC - 1 - c) < RING - 1 ? (NC - 1 - c) : RING - 1;  // chunks issued after chunk c
                 if (behind == 2) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(tc[0]), "+v"(tc[1]), "+v"(tc[2]), "+v"(tc[3]));
                 else if (behind == 1) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(tc[0]), "+v"(tc[1]), "+v"(tc[2]), "+v"(tc[3]));
                 else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tc[0]), "+v"(tc[1]), "+v"(tc[2]), "+v"(tc[3]));
-                if ((c & 1) == 0) {  // even nibbles k = 8u + 2i: the low halves of the x dwords
+                if constexpr ((VAR & 512) != 0) {  // ablation (lab): no FMAs -- the looked-up values are only consumed
+                    asm volatile("" ::"v"(tc[0]), "v"(tc[1]), "v"(tc[2]), "v"(tc[3]), "s"(xu[0]), "s"(xu[1]), "s"(xu[2]), "s"(xu[3]));
+                } else if ((c & 1) == 0) {  // even nibbles k = 8u + 2i: the low halves of the x dwords
                     accE = __builtin_elementwise_fma(float2_t{tc[0], tc[1]}, float2_t{__uint_as_float(xu[0]), __uint_as_float(xu[1])}, accE);
                     accE = __builtin_elementwise_fma(float2_t{tc[2], tc[3]}, float2_t{__uint_as_float(xu[2]), __uint_as_float(xu[3])}, accE);
                     asm volatile("" : "+v"(accE));
@@ -479,7 +487,7 @@ __global__ __launch_bounds__(((VAR & 8) ? 256 : ((VAR & 16) ? 128 : ((VAR & 32) 
         if (g0 + 2 < g1) load_params(g0 + 2, sC, zC);
         if (g0 + 3 < g1) load_params(g0 + 3, sD, zD);
         for (int g = g0; g < g1; g += 2) {
-            build_tables(sa, za, sb2, zb2);  // (an odd tail builds its second table from the constants of the unit before: never read)
+            if constexpr ((VAR & 1024) == 0) build_tables(sa, za, sb2, zb2);  // (an odd tail builds its second table from the constants of the unit before: never read; bit 10: ablation, no tables)
             process_unit(std::integral_constant<int, 0>{}, wa, g);
             if (g + 2 < g1) load_group(wa, g + 2);
             if (g + 1 < g1) {
@@ -927,6 +935,21 @@ int mpq_list_forward(MpqList* p, hipStream_t st) {
     }
     static const int d16 = list_env("BIE_LIST_D16", 1);  // the 16-bit-table form of the W4 / M = 1 / bf16 kernel (0: the fp32-table form)
     if (d16 && p->w_bit == 4 && p->dtype == BIE_BF16 && p->M == 1 && p->nw == 4) {
+#ifdef BIE_LAB_BUILD
+        static const int ring2 = list_env("BIE_LIST_RING2", 0);  // lab builds: two lookup chunks in flight, 1 = default registers, 7 = 7 waves per SIMD forced
+        if (ring2 && p->rpg == 16 && p->zm == ZM_SYM) {
+            if (ring2 == 7) hipLaunchKernelGGL((mpq_list_kernel<BIE_BF16, ZM_SYM, 1, 16, 4, 1 | 8 | 64 | 2048 | 128>), dim3(p->grid), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((mpq_list_kernel<BIE_BF16, ZM_SYM, 1, 16, 4, 1 | 8 | 64 | 2048>), dim3(p->grid), dim3(256), 0, st, a);
+            return check_launch("mpq_list_kernel<d16,ring2>");
+        }
+        static const int abl = list_env("BIE_LIST_ABL", 0);  // lab builds: 1 no LDS reads, 2 no FMAs, 4 no table build (sums allowed: 3, 5, 6, 7)
+        if (abl && p->rpg == 16 && p->zm == ZM_SYM) {
+#define BIE_ABL(A) case A: hipLaunchKernelGGL((mpq_list_kernel<BIE_BF16, ZM_SYM, 1, 16, 4, 1 | 8 | 64 | (A << 8)>), dim3(p->grid), dim3(256), 0, st, a); break;
+            switch (abl) { BIE_ABL(1) BIE_ABL(2) BIE_ABL(3) BIE_ABL(4) BIE_ABL(5) BIE_ABL(6) BIE_ABL(7) default: break; }
+#undef BIE_ABL
+            return check_launch("mpq_list_kernel<d16,ablation>");
+        }
+#endif
         list_launch_zm<BIE_BF16, 4, 1 | 64>(a, p->rpg, p->grid, 1, p->zm, st);
         return check_launch("mpq_list_kernel<d16>");
     }
