@@ -1703,6 +1703,36 @@ def test_lone_decode_launches_of_100_mb_and_more_take_the_inline_list_form(asym)
         assert_close(yg, r, dt, f"inline list form, grouped 2 x 8192x14336 asym={asym}")
 
 
+def test_plain_graph_capture_after_a_warm_up_on_another_stream():
+    """`with torch.cuda.graph(g):` captures on torch's own capture stream, which has no scratch buffer even after a warm-up on
+    the current stream; the first MPQ call inside the capture used to raise.  Now it borrows the device's warmed buffer (bitorch_engine._hip._grow),
+    allocates nothing under capture, and the replay computes what the eager call computes -- also after the inputs change in place."""
+    from bitorch_engine import _hip
+    from bitorch_engine.extensions import q_linear_cuda
+    K, N, gs, dt = 2048, 512, 128, orc.BF16   # small: K sliced over workgroups -> the launch uses the workspace's granules and generation words
+    rng = np.random.default_rng(321)
+    qw, scales, zeros, gen = rand_case(rng, K, N, 4, gs, dt, 0)
+    d = lambda t: t.to(DEV)
+    qw_d, sc_d, ze_d = d(qw), d(scales), d(zeros)
+    x_static = torch.randn((1, K), generator=gen).to(TDT[dt]).to(DEV)
+    y_eager = q_linear_cuda.mpq_forward_impl(x_static, qw_d, sc_d, ze_d, None, 4, 0, gs)   # warm-up: allocates the current stream's workspace
+    torch.cuda.synchronize()
+    n_buffers = len(_hip._WS)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        y_static = q_linear_cuda.mpq_forward_impl(x_static, qw_d, sc_d, ze_d, None, 4, 0, gs)
+    assert len(_hip._WS) == n_buffers, "a workspace was allocated under capture"
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y_static, y_eager)
+    x2 = torch.randn((1, K), generator=gen).to(TDT[dt])
+    x_static.copy_(x2.to(DEV))
+    g.replay()
+    g.replay()
+    torch.cuda.synchronize()
+    assert_close(y_static, oracle_forward(x2, qw, scales, zeros, None, 4, gs, 0, dt), dt, "graph replay on a borrowed workspace")
+
+
 def test_reducer_timeout_fails_loudly():
     """A reducer whose partial sums never arrive (forged: it is told to expect another tag) must not return a number: NaN in y,
     a bit in the status page, and the NEXT launching call fails with BIE_ERR_DEVICE (then the page is clear again)."""
