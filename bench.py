@@ -231,7 +231,7 @@ class Bench:
                              "frac": round(b / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None}}
 
     # ---- a dependent chain as per-layer launches: x of layer i = y of layer i-1 inside chains of `chain` (what an unmodified caller issues)
-    def chain_launches(self, k, nl, chain, reps, seed, prefetch=True):
+    def chain_launches(self, k, nl, chain, reps, seed):
         gen = torch.Generator(device=self.dev).manual_seed(seed)
         s0 = 1.0 / (21.25 * k) ** 0.5
         layers = []
@@ -242,21 +242,18 @@ class Bench:
         ys = [torch.empty((1, k), dtype=BF16, device=self.dev) for _ in range(nl)]
         x0 = torch.randn((1, k), generator=gen, device=self.dev).to(BF16)
         ws = self.workspace(1, k, k)
-        pf = getattr(self.L, "bie_mpq_prefetch_next", None) if prefetch else None
 
         def run(st):
             for i, l in enumerate(layers):
-                if pf is not None and i + 1 < nl:
-                    pf(layers[i + 1][0].data_ptr(), layers[i + 1][0].numel() * 4)
                 self.forward(ys[i - 1] if i % chain else x0, l, ys[i], ws, 1, k, k, st)
         us = time_graph(capture(run), reps) / nl
         b = alg_bytes(1, k, k)
-        return {"M": 1, "K": k, "N": k, "layers": nl, "dependent_chain_length": chain, "us_per_layer": round(us, 3), "next_launch_weight_prefetch": bool(pf),
+        return {"M": 1, "K": k, "N": k, "layers": nl, "dependent_chain_length": chain, "us_per_layer": round(us, 3),
                 "finite": bool(torch.isfinite(ys[chain - 1].float()).all()),
                 "roofline": {"bound": "hbm", "achieved": round(b / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None}}
 
     # ---- the REAL decode step: Llama-7B's linear layers with true y -> x dependencies
-    def decode_step(self, n_layers, reps, seed, hidden=4096, inter=11008, prefetch=True):
+    def decode_step(self, n_layers, reps, seed, hidden=4096, inter=11008):
         """Per transformer layer: q/k/v (ONE grouped launch, shared x) -> o (x = q's output) -> gate/up (ONE grouped launch, x = o's
         output) -> down (x = gate's output) -> next layer's q/k/v (x = down's output): every launch reads what the previous one
         wrote, nothing else runs in between (the element-wise glue of a real model is left out, so this times the Q-Linear path
@@ -286,17 +283,12 @@ class Bench:
         ws = torch.zeros(1 << 24, dtype=torch.uint8, device=self.dev)
         arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
         calls = []
-        for i, (x, ls, ys) in enumerate(steps):
-            nxt = steps[i + 1][1] if (prefetch and i + 1 < len(steps)) else []
+        for (x, ls, ys) in steps:
             calls.append((x, len(ls), arr([l[0] for l in ls]), arr([l[1] for l in ls]), arr([l[2] for l in ls]), arr(ys),
-                          (ctypes.c_int * len(ls))(*[l[0].shape[1] for l in ls]), x.shape[1], nxt))
-        pf = getattr(self.L, "bie_mpq_prefetch_next", None) if prefetch else None
+                          (ctypes.c_int * len(ls))(*[l[0].shape[1] for l in ls]), x.shape[1]))
 
         def run(st):
-            for (x, cnt, q, s_, z, y, Narr, k, nxt) in calls:
-                if pf is not None:
-                    for l in nxt:  # the next launch's weights: touched by THIS launch's spare workgroups (weights do not depend on x)
-                        pf(l[0].data_ptr(), l[0].numel() * 4)
+            for (x, cnt, q, s_, z, y, Narr, k) in calls:
                 rc = self.L.bie_mpq_forward_grouped(x.data_ptr(), cnt, q, s_, z, None, y, Narr, ws.data_ptr(), ws.numel(), 1, k, WBIT, GROUP,
                                                     0, self._hip.BF16, st)
                 if rc:
@@ -307,9 +299,70 @@ class Bench:
         fin = h[n_layers].float()
         return {"what": "Llama-7B decode step, linear layers only: per layer grouped q/k/v -> o -> grouped gate/up -> down, true y -> x dependencies",
                 "layers": n_layers, "launches_per_layer": 4, "us_per_layer": round(us, 2), "us_per_step": round(us * n_layers, 1), "alg_bytes_per_layer": b,
-                "next_launch_weight_prefetch": bool(pf), "final_activation_rms": round(float(fin.pow(2).mean().sqrt()), 4), "finite": bool(torch.isfinite(fin).all()),
+                "final_activation_rms": round(float(fin.pow(2).mean().sqrt()), 4), "finite": bool(torch.isfinite(fin).all()),
                 "roofline": {"bound": "hbm", "achieved": round(b / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(b / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None}}
+
+    # ---- the same decode step through the UNCHANGED module API (MPQLinearCuda modules, prepare_bie_layers): what a caller of the reference gets
+    def decode_step_modules(self, n_layers, reps, seed, auto_group=True, hidden=4096, inter=11008):
+        """q_proj(h), k_proj(h), v_proj(h), o_proj(q), gate_proj(o), up_proj(o), down_proj(g) per block, written against the reference's module
+        API (layers/qlinear/nbit/cuda/mpq_layer.py:206-224); prepare_bie_layers() is the only model-level call.  With auto_group the sibling
+        launches are grouped by the library after one observed forward; without, every layer is its own launch (the reference's call pattern)."""
+        from bitorch_engine.layers.qlinear.nbit.cuda import MPQLinearCuda
+        from bitorch_engine.layers.qlinear.nbit.cuda import mpq_layer
+        from bitorch_engine.utils.model_helper import prepare_bie_layers
+        gen = torch.Generator(device=self.dev).manual_seed(seed)
+
+        def lin(k, n):
+            l = MPQLinearCuda(k, n, w_bit=WBIT, dtype=BF16, group_size=GROUP, dq_group_size=32, use_gba_quant=True, asym=False)
+            l.qweight.data = torch.empty(l.qweight.shape, dtype=torch.int32)
+            return l
+
+        class Block(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.q_proj, self.k_proj, self.v_proj, self.o_proj = lin(hidden, hidden), lin(hidden, hidden), lin(hidden, hidden), lin(hidden, hidden)
+                self.gate_proj, self.up_proj, self.down_proj = lin(hidden, inter), lin(hidden, inter), lin(inter, hidden)
+
+            def forward(self, h):
+                q, k, v = self.q_proj(h), self.k_proj(h), self.v_proj(h)   # noqa: F841  (k, v are computed: the attention that eats them is not this library's)
+                o = self.o_proj(q)
+                g, u = self.gate_proj(o), self.up_proj(o)                  # noqa: F841
+                return self.down_proj(g)
+        model = torch.nn.Sequential(*[Block() for _ in range(n_layers)])
+        prepare_bie_layers(model)
+        model.to(self.dev).eval()
+        for m in model.modules():
+            if isinstance(m, MPQLinearCuda):
+                k = m.in_channels
+                m.qweight.data = torch.randint(-2 ** 31, 2 ** 31 - 1, m.qweight.shape, dtype=torch.int32, generator=gen, device=self.dev)
+                s0 = 1.0 / (21.25 * k) ** 0.5
+                m.scales = (s0 * (0.8 + 0.4 * torch.rand(m.scales.shape, generator=gen, device=self.dev))).to(BF16)
+                m.zeros = (m.scales.float() * 7.5).to(BF16)
+        old = mpq_layer.AUTO_GROUP
+        mpq_layer.AUTO_GROUP = bool(auto_group)
+        try:
+            h0 = torch.randn((1, hidden), generator=gen, device=self.dev).to(BF16)
+            with torch.no_grad():
+                model(h0)  # the observation round (sibling groups are confirmed by what they receive)
+                model(h0)
+                torch.cuda.synchronize()
+                before = dict(mpq_layer.GROUP_STATS)
+                out = []
+
+                def run(_st):
+                    out[:] = [model(h0)]
+                g = capture(run)
+                stats = {k: mpq_layer.GROUP_STATS[k] - before[k] for k in ("grouped_launches", "served_from_group", "single_launches")}
+                us = time_graph(g, reps) / n_layers
+        finally:
+            mpq_layer.AUTO_GROUP = old
+        b = 3 * alg_bytes(1, hidden, hidden) - 2 * 2 * hidden + alg_bytes(1, hidden, hidden) + 2 * alg_bytes(1, hidden, inter) - 2 * hidden + alg_bytes(1, inter, hidden)
+        # capture() runs the callable twice (warm-up + capture): launches per forward = half of the counted ones
+        return {"what": "the same step through MPQLinearCuda modules + prepare_bie_layers, caller unchanged", "layers": n_layers, "auto_group": bool(auto_group),
+                "launches_per_layer": round((stats["grouped_launches"] + stats["single_launches"]) / 2 / n_layers, 2), "us_per_layer": round(us, 2),
+                "finite": bool(torch.isfinite(out[0].float()).all()),
+                "roofline": {"bound": "hbm", "achieved": round(b / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None}}
 
     # ---- M = 4096 prefill GEMM over `nl` distinct layers
     def gemm(self, M, k, n, nl, reps, seed):
@@ -819,7 +872,8 @@ def main():
             return v if v is None else {"error": str(v.get("error", "?"))[:80]}
         # ---- first-class rows: the real decode step, the drop-in per-layer launches, dependent chains, the prefill GEMM
         guarded("decode_step_llama7b", lambda: B.decode_step(32, 5, 77))
-        guarded("decode_step_llama7b_no_prefetch", lambda: B.decode_step(32, 5, 77, prefetch=False))
+        guarded("decode_step_modules_auto_grouped", lambda: B.decode_step_modules(16, 5, 78, auto_group=True))
+        guarded("decode_step_modules_one_launch_per_layer", lambda: B.decode_step_modules(16, 5, 78, auto_group=False))
         guarded("gemm", lambda: B.gemm(4096, 4096, 4096, 24, 3, 7))
         if "roofline" in extras.get("gemm", {}):
             out["roofline_gemm"] = dict(extras["gemm"]["roofline"], kernel=("bie::mpq_dequant_frag_kernel + bie::mpq_dense_gemm_kernel<bf16,256x256> (both launches timed)"
@@ -837,10 +891,11 @@ def main():
         guarded("grouped_gate_up_2x4096x11008", lambda: B.grouped(4096, (11008, 11008), 20, 10, 22, "gate/up projections in one launch"))
         guarded("c2_gemm_4096x11008", lambda: B.gemm(4096, 4096, 11008, 16, 3, 14))
         guarded("c2_gemm_11008x4096", lambda: B.gemm(4096, 11008, 4096, 16, 3, 15))
-        out["decode_step_llama7b"] = (lambda v: {k: v[k] for k in ("us_per_layer", "launches_per_layer", "layers", "next_launch_weight_prefetch", "finite") if k in v} | {"roofline_frac": v["roofline"]["frac"]}
+        out["decode_step_llama7b"] = (lambda v: {k: v[k] for k in ("us_per_layer", "launches_per_layer", "layers", "finite") if k in v} | {"roofline_frac": v["roofline"]["frac"]}
                                       if isinstance(v, dict) and "roofline" in v else v)(extras.get("decode_step_llama7b"))
         out["summary"] = {k: frac(k) for k in ("per_layer_launches_4096x4096", "chain8_4096x4096_launches", "c2_gemv_4096x11008", "c2_gemv_11008x4096", "c5_gemv_8192x28672",
-                                               "grouped_qkv_3x4096x4096", "grouped_gate_up_2x4096x11008", "c2_gemm_4096x11008", "c2_gemm_11008x4096", "decode_step_llama7b_no_prefetch")}
+                                               "grouped_qkv_3x4096x4096", "grouped_gate_up_2x4096x11008", "c2_gemm_4096x11008", "c2_gemm_11008x4096", "decode_step_modules_auto_grouped",
+                                               "decode_step_modules_one_launch_per_layer")}
         if not args.short:
             # the fused form (dequantisation beside the MFMAs) on the same layers, same box: the A/B behind the dense form's dispatch rule
             def fused_gemm():

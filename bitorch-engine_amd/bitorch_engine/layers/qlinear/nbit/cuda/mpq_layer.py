@@ -35,32 +35,52 @@ class SiblingGroup:
         q = self.q_proj(h); k = self.k_proj(h); v = self.v_proj(h)
 
     (reference call path: layers/qlinear/nbit/cuda/mpq_layer.py:206-224 -> one quant_mm_kernel launch per layer) runs ONE grouped
-    decode launch (bie_mpq_forward_grouped).  Protocol, per forward of the parent: the member that is called first (the LEADER) with
-    M <= 16 rows in eval mode launches the whole confirmed set on its x and parks the other members' outputs, keyed by the identity of x
-    (storage pointer, version counter, shape, strides); a member called next with the SAME tensor takes its parked output without
-    launching anything; a member called with anything else (o_proj sits beside q/k/v but eats the attention output) simply runs alone,
-    and is dropped from the set.  Nothing is assumed: a set is only formed from members that WERE observed receiving the leader's
-    tensor, and three rounds in which a parked output was not picked up dissolve the group."""
+    decode launch (bie_mpq_forward_grouped).  A round = one forward of the parent, delimited by the member that is called first.  The
+    first round is only observed: members that received the SAME tensor (storage pointer, version counter, shape, strides, stream)
+    form a set, led by the one that was called first -- several sets per parent are fine (a flat block holds q/k/v AND gate/up), and
+    o_proj, which sits beside q/k/v with the same shape but eats the attention output, ends up in none.  From then on a set's leader
+    launches the whole set on its x (M <= 16 rows, eval mode) and parks the other members' outputs under the identity of x; a member
+    called next with that tensor takes its parked output without launching anything; a member called with anything else, or before its
+    leader, runs alone and leaves its set.  Nothing is assumed from names, and parked outputs nobody picks up for three rounds dissolve
+    the group."""
 
     def __init__(self, members):
         self.members = list(members)
-        self.leader = None
-        self.confirmed = None      # list of modules launched together (leader first), or None while observing
-        self.round_key = None      # identity of the leader's x in the current round
-        self.seen = []             # members observed with round_key in the current round
+        self.first = None          # the member called first in a forward of the parent: a call of it starts a new round
+        self.sets = None           # confirmed: id(leader) -> [leader, member, ...]; None while observing
+        self.leader_of = {}        # id(member) -> its set's leader
+        self.trace = []            # (module, key) in call order, observation round only
+        self.rounds_observed = 0
         self.parked = {}           # id(module) -> (key, output)
         self.unclaimed = 0
         self.dead = False
 
+    def _dissolve(self):
+        self.sets, self.leader_of, self.dead = None, {}, True
+        self.parked.clear()
+        GROUP_STATS["groups_dissolved"] += 1
+
     def _finish_round(self):
-        if self.confirmed is None and self.leader is not None and len(self.seen) >= 2:
-            self.confirmed = list(self.seen)
-            GROUP_STATS["groups_confirmed"] += 1
-        elif self.confirmed is not None and self.parked:
+        if self.sets is None:
+            if self.trace:
+                self.rounds_observed += 1
+                by_key = {}
+                for m, k in self.trace:
+                    ms = by_key.setdefault(k, [])
+                    if m not in ms:
+                        ms.append(m)
+                sets = {id(ms[0]): ms for ms in by_key.values() if len(ms) >= 2}
+                if sets:
+                    self.sets = sets
+                    self.leader_of = {id(m): ms[0] for ms in sets.values() for m in ms}
+                    GROUP_STATS["groups_confirmed"] += len(sets)
+                elif self.rounds_observed >= 4:  # nobody shares an input here: stop looking
+                    self.dead = True
+            self.trace = []
+        elif self.parked:
             self.unclaimed += 1
             if self.unclaimed >= 3:
-                self.confirmed, self.dead = None, True
-                GROUP_STATS["groups_dissolved"] += 1
+                self._dissolve()
         self.parked.clear()
 
     def forward(self, module, x):
@@ -73,25 +93,32 @@ class SiblingGroup:
             self.unclaimed = 0
             GROUP_STATS["served_from_group"] += 1
             return hit[1]
-        if self.leader is None:
-            self.leader = module
-        if module is self.leader:
+        if self.first is None:
+            self.first = module
+        if module is self.first:
             self._finish_round()
-            self.round_key, self.seen = key, [module]
-            if self.confirmed is not None:
-                outs = MPQLinearCuda.forward_grouped(self.confirmed, x, _from_group=True)
-                GROUP_STATS["grouped_launches"] += 1
-                for m, o in zip(self.confirmed[1:], outs[1:]):
-                    self.parked[id(m)] = (key, o)
-                return outs[0]
+            if self.dead:
+                return None
+        if self.sets is None:
+            self.trace.append((module, key))
             return None
-        if self.confirmed is None and key == self.round_key and module not in self.seen:
-            self.seen.append(module)      # observed: same tensor as the leader in this round
-        elif self.confirmed is not None and module in self.confirmed:
-            self.confirmed.remove(module)  # it was launched with the leader's x but asked for another one: not a sibling after all
-            if len(self.confirmed) < 2:
-                self.confirmed, self.dead = None, True
-                GROUP_STATS["groups_dissolved"] += 1
+        leader = self.leader_of.get(id(module))
+        if leader is module:
+            members = self.sets[id(module)]
+            outs = MPQLinearCuda.forward_grouped(members, x, _from_group=True)
+            GROUP_STATS["grouped_launches"] += 1
+            for m, o in zip(members[1:], outs[1:]):
+                self.parked[id(m)] = (key, o)
+            return outs[0]
+        if leader is not None:  # launched with its leader's x but asked for another tensor (or called before its leader): not a sibling after all
+            members = self.sets[id(leader)]
+            members.remove(module)
+            del self.leader_of[id(module)]
+            if len(members) < 2:
+                del self.sets[id(leader)]
+                self.leader_of.pop(id(leader), None)
+                if not self.sets:
+                    self._dissolve()
         return None
 
 

@@ -215,8 +215,8 @@ def test_cutlass_layer_classes_mirror_reference_api():
 
 
 def test_sibling_group_protocol_without_a_gpu(monkeypatch):
-    """SiblingGroup (layers/qlinear/nbit/cuda/mpq_layer.py): observation round, confirmation of the members that really received the
-    leader's tensor, parked outputs keyed by the identity of x, a non-sibling beside them (o_proj), an in-place update of x between
+    """SiblingGroup (layers/qlinear/nbit/cuda/mpq_layer.py): observation round, sets formed from the members that really received one tensor
+    (two sets in a flat block: q/k/v and gate/up; o_proj in none), parked outputs keyed by the identity of x, an in-place update of x between
     the calls (version counter), and dissolution when parked outputs are not picked up.  The launches are stubbed: host logic only."""
     from bitorch_engine.layers.qlinear.nbit.cuda import mpq_layer
     calls = []
@@ -229,19 +229,28 @@ def test_sibling_group_protocol_without_a_gpu(monkeypatch):
     class M:
         def __init__(self, name):
             self.name = name
-    q, k, v, o = M("q"), M("k"), M("v"), M("o")
-    g = mpq_layer.SiblingGroup([q, k, v, o])
-    h, a = torch.zeros(1, 8), torch.ones(1, 8)
-    assert [g.forward(m, t) for m, t in ((q, h), (k, h), (v, h), (o, a))] == [None] * 4 and not calls   # round 1: everybody alone
-    h2 = torch.zeros(1, 8)
-    out_q = g.forward(q, h2)                                                                       # round 2: one grouped launch
-    assert calls == [["q", "k", "v"]] and out_q.startswith("q(")
-    assert g.forward(k, h2).startswith("k(") and g.forward(v, h2).startswith("v(") and g.forward(o, a) is None and len(calls) == 1
+    q, k, v, o, gate, up = (M(n) for n in ("q", "k", "v", "o", "gate", "up"))
+    g = mpq_layer.SiblingGroup([q, k, v, o, gate, up])
+    h, a, m = torch.zeros(1, 8), torch.ones(1, 8), torch.full((1, 8), 2.0)
+    flat = lambda hh, aa, mm: [g.forward(mod, t) for mod, t in ((q, hh), (k, hh), (v, hh), (o, aa), (gate, mm), (up, mm))]
+    assert flat(h, a, m) == [None] * 6 and not calls                                              # round 1: everybody alone, observed
+    h2, m2 = torch.zeros(1, 8), torch.full((1, 8), 2.0)
+    outs = flat(h2, a, m2)                                                                          # round 2: two grouped launches
+    assert calls == [["q", "k", "v"], ["gate", "up"]]
+    assert outs[0].startswith("q(") and outs[1].startswith("k(") and outs[2].startswith("v(") and outs[3] is None
+    assert outs[4].startswith("gate(") and outs[5].startswith("up(")
     h3 = torch.zeros(1, 8)
     g.forward(q, h3)
     h3.add_(1)                                                                                     # x changed in place: parked k is stale
-    assert g.forward(k, h3) is None and g.confirmed is not None and [m.name for m in g.confirmed] == ["q", "v"]
-    assert g.forward(v, h3) is None                                                                # v's parked output is stale too (same key)
-    for _ in range(4):                                                                             # nobody picks the parked outputs up
+    assert g.forward(k, h3) is None and [mm.name for mm in g.sets[id(q)]] == ["q", "v"]
+    assert g.forward(v, h3) is None and id(q) not in g.sets and id(gate) in g.sets                 # q's set is gone, gate/up lives on
+    calls.clear()
+    for _ in range(4):                                                                             # gate launches its set, nobody picks up
         g.forward(q, torch.zeros(1, 8))
-    assert g.dead and g.forward(q, h) is None
+        g.forward(gate, torch.ones(1, 8))
+    assert g.dead and g.forward(gate, m) is None
+    # a parent whose children never share an input stops observing
+    lone = mpq_layer.SiblingGroup([q, o])
+    for i in range(5):
+        assert lone.forward(q, torch.zeros(1, 8)) is None and lone.forward(o, torch.ones(1, 8)) is None
+    assert lone.dead

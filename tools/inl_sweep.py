@@ -15,5 +15,5 @@ out["qkv"] = B.grouped(4096, (4096, 4096, 4096), 20, 10, 4, "")["us_per_launch"]
 out["gate_up"] = B.grouped(4096, (11008, 11008), 12, 10, 5, "")["us_per_launch"]
 out["8192x28672"] = B.gemv(8192, 28672, 4, 10, 6)["us_per_launch"]
 if "--step" in sys.argv:
-    out["decode_step_us_per_layer"] = B.decode_step(16, 5, 77, prefetch=False)["us_per_layer"]
+    out["decode_step_us_per_layer"] = B.decode_step(16, 5, 77)["us_per_layer"]
 print(json.dumps(out))
