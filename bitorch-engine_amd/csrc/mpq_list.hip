@@ -1006,6 +1006,7 @@ bool mpq_list_inline_ok(int M, int K, long n_total, int w_bit, int group_size, i
     if (!enabled || M != 1 || w_bit != 4 || dtype != BIE_BF16 || (zm != ZM_SYM && zm != ZM_ASYM)) return false;
     const int gs = group_size > K ? K : group_size;
     if (!((gs == 32 || gs == 64 || gs == 128 || gs == 256) && K % gs == 0)) return false;
+    if ((long)K / 2 * n_total > 0xfffffff0L) return false;  // 32-bit buffer offsets (per set; the sum is a safe upper bound)
     return enabled == 2 || (long)K / 2 * n_total >= min_mb * (1L << 20);
 }
 
