@@ -430,7 +430,7 @@ def bench_exl2(dev):
             sc = (torch.rand((groups, N), device=dev) * 0.02 + 0.001).half()
             ze = (torch.randn((groups, N), device=dev) * 0.05).half()
             sets.append((qw, sc, ze))
-        _, rows = q_linear_cuda.mbwq_trans_qweight(sets[0][0], q_groups, True, K, groups, 4)
+        rows = [q_linear_cuda.mbwq_trans_qweight(s_[0], q_groups, True, K, groups, 4)[1] for s_ in sets][0]  # the load-time step, every tensor
         byts = row * N * 4 + 4 * groups * N + 6 * K + 2 * K + 2 * N
         for M in (1, 2):
             x = torch.randn((M, K), device=dev).half()

@@ -45,6 +45,7 @@ SIGNATURES = {
     "bie_mpq_sort_rows": (_i, [_vp] * 3 + [_i] * 3 + [_vp]),
     "bie_gather_cols": (_i, [_vp] * 3 + [_i] * 3 + [_vp]),
     "bie_mbwq_rows": (_i, [_vp, _i, _i, _vp]),
+    "bie_mbwq_exl2_shuffle": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "bie_mbwq_q4_dequant": (_i, [_vp] * 5 + [_i] * 4 + [_vp]),
     "bie_mbwq_exl2_dequant": (_i, [_vp] * 7 + [_i] * 3 + [_vp]),
     "bie_mbwq_workspace_bytes": (_sz, [_i, _i, _i]),

@@ -198,15 +198,34 @@ def mpq_grad_input(qweight, scales, qzeros, g_idx, grad_out, a_bit, w_bit, asym)
 
 
 # ---------------------------------------------------------------------------------------------- MBWQ
+EXL2_ROWS_LEN = 20  # BIE_EXL2_ROWS_LEN (include/bie_hip.h)
+
+
 def mbwq_trans_qweight(qweight, q_groups, use_mbw, height, groups, bits):
-    """Returns (qweight, rows[7]).  The reference's in-place shuffle is a no-op (exl2/config.h:16-21);
-    the band table needs q_groups on the host, like the reference's blocking cudaMemcpy (:562)."""
+    """Returns (qweight, rows).  Mixed-bit layout: like the reference (mbwq_linear_cuda_kernel.cu:602-625) this is the
+    load-time step that re-arranges the packed tensor IN PLACE for the kernels (its shuffle_kernel, :63-86 -- a no-op
+    in the reference's build, exl2/config.h:16-21; here the half-pair layout of bie_mbwq_exl2_shuffle) and returns the
+    band table: the reference's 7 ints followed by this library's group table (EXL2_ROWS_LEN ints in all; pass it on as
+    it comes).  Like the reference's kernel launch it needs the tensor on the GPU, and like its blocking cudaMemcpy
+    (:562) q_groups on the host.  Call it once per tensor."""
     import ctypes
-    rows = (ctypes.c_int * 7)()
     if use_mbw:
+        t = qweight.data if hasattr(qweight, "data") else qweight
+        _hip.need_gpu(t)
+        if t.dtype != torch.int32 or not t.is_contiguous():
+            raise RuntimeError("mbwq_trans_qweight: qweight must be a contiguous int32 tensor")
+        if getattr(qweight, "_bie_exl2_shuffled", False):
+            raise RuntimeError("mbwq_trans_qweight: this qweight has already been re-arranged (a second pass would scramble it)")
+        rows = (ctypes.c_int * EXL2_ROWS_LEN)()
         qg = q_groups.detach().to("cpu", torch.int16).contiguous()
-        rc = _hip.lib().bie_mbwq_rows(qg.data_ptr(), groups, height, ctypes.cast(rows, ctypes.c_void_p))
-        _hip.check(rc, "bie_mbwq_rows")
+        with torch.cuda.device(t.device):
+            rc = _hip.lib().bie_mbwq_exl2_shuffle(_hip.ptr(t), qg.data_ptr(), groups, height, t.shape[1],
+                                                  ctypes.cast(rows, ctypes.c_void_p), _hip.stream())
+        _hip.check(rc, "bie_mbwq_exl2_shuffle")
+        try:
+            qweight._bie_exl2_shuffled = True
+        except AttributeError:
+            pass
         return qweight, list(rows)
     if bits not in (2, 4):
         raise RuntimeError(f"Error: weight bit width:{bits} has not been supported yet!")
@@ -229,7 +248,9 @@ def mbwq_q42fp_weight(qweight, scales, zeros, group_size, bits, q_perm):
 
 def _rows_arg(rows):
     import ctypes
-    arr = (ctypes.c_int * 7)(*[int(r) for r in rows])
+    if len(rows) != EXL2_ROWS_LEN:
+        raise RuntimeError(f"exl2: the band table must be the {EXL2_ROWS_LEN}-int table mbwq_trans_qweight returned (got {len(rows)} ints)")
+    arr = (ctypes.c_int * EXL2_ROWS_LEN)(*[int(r) for r in rows])
     return arr, ctypes.cast(arr, ctypes.c_void_p)
 
 

@@ -137,7 +137,7 @@ class MBWQExl2ForwardList:
     """A list of exl2 (mixed 8/6/5/4/3/2-bit) decode layers in ONE launch (bie_mbwq_exl2_list_*): entry i is one
     `q_linear_cuda.mbwq_exl2_forward(x, qweight, scales, zeros, q_perm, q_group_map, rows)` call of the reference
     (mbwq_linear_cuda_kernel.cu:926-1007) with its own y.  entries: dicts with x, qweight, scales, zeros, q_perm (or None),
-    q_group_map, rows (the 7-int band table from mbwq_trans_qweight), y.  fp16, M <= 2."""
+    q_group_map, rows (the band table from mbwq_trans_qweight, which also re-arranged qweight), y.  fp16, M <= 2."""
 
     def __init__(self, entries):
         L = _hip.lib()
@@ -150,7 +150,9 @@ class MBWQExl2ForwardList:
             if x.dtype != torch.float16 or y.dtype != torch.float16:
                 raise RuntimeError("MBWQExl2ForwardList: fp16 only (as the reference kernels)")
             K, N = x.shape[-1], e["qweight"].shape[1]
-            rows = (ctypes.c_int * 7)(*[int(v) for v in e["rows"]])
+            if len(e["rows"]) != 20:
+                raise RuntimeError("MBWQExl2ForwardList: rows must be the 20-int table mbwq_trans_qweight returned")
+            rows = (ctypes.c_int * 20)(*[int(v) for v in e["rows"]])
             perm = e.get("q_perm")
             for t in (x, y, e["qweight"], e["scales"], e["zeros"], e["q_group_map"]):
                 if not t.is_contiguous():

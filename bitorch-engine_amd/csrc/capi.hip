@@ -54,6 +54,7 @@ int mpq_grad_input_launch(const void* gy, const int32_t* qw, const void* scales,
 size_t mbwq_workspace_bytes(int M, int K, int N);
 int mbwq_q4_dequant_launch(const int32_t* qw, const void* scales, const void* zeros, const int16_t* perm, void* out, int K,
                            int N, int bits, int group_size, hipStream_t st);
+int mbwq_exl2_shuffle_launch(int32_t* qw, const int* rows6, int K, int N, hipStream_t st);
 int mbwq_exl2_dequant_launch(const int32_t* qw, const void* scales, const void* zeros, const int16_t* perm,
                              const int16_t* gmap, const int* rows7, void* out, int K, int N, hipStream_t st);
 int mbwq_q4_forward_launch(const void* x, const int32_t* qw, const void* scales, const void* zeros, const int16_t* perm,
@@ -345,8 +346,53 @@ int bie_mbwq_q4_dequant(const int32_t* qweight, const void* scales, const void* 
     return mbwq_q4_dequant_launch(qweight, scales, zeros, q_perm, out, K, N, bits, group_size, as_stream(stream));
 }
 
+// The extended table: band ends + flags as bie_mbwq_rows, then per band the first group and log2(chunks per group).  REGULAR when
+// every band's groups hold the same power-of-two number of whole chunks (a shorter last group is fine: the index is a shift).
+int bie_mbwq_exl2_shuffle(int32_t* qweight, const int16_t* q_groups_host, int groups, int K, int N, int* rows_host, void* stream) {
+    BIE_REQUIRE(qweight && rows_host && N > 0, BIE_ERR_INVALID_ARG, "bie_mbwq_exl2_shuffle: bad argument");
+    int rc = bie_mbwq_rows(q_groups_host, groups, K, rows_host);
+    if (rc) return rc;
+    BIE_REQUIRE(K % 32 == 0, BIE_ERR_UNSUPPORTED, "bie_mbwq_exl2_shuffle: K=%d must be a multiple of 32", K);
+    for (int b = 0; b < 6; b++)
+        BIE_REQUIRE(rows_host[b] % 32 == 0, BIE_ERR_UNSUPPORTED, "bie_mbwq_exl2_shuffle: band boundary rows[%d]=%d must be a multiple of 32", b, rows_host[b]);
+    bool regular = true;
+    int gfirst[6] = {0, 0, 0, 0, 0, 0}, glog[6] = {0, 0, 0, 0, 0, 0}, gk[6] = {0, 0, 0, 0, 0, 0}, seen[6] = {0, 0, 0, 0, 0, 0};
+    int row = 0;
+    for (int i = 0; i < groups; i++) {
+        const int bits = (uint16_t)q_groups_host[2 * i];
+        const int band = bits == 8 ? 0 : (bits == 6 ? 1 : (bits == 5 ? 2 : (bits == 4 ? 3 : (bits == 3 ? 4 : 5))));
+        const int k = i < groups - 1 ? ((uint16_t)q_groups_host[2 * i + 3] - (uint16_t)q_groups_host[2 * i + 1]) * 32 / bits : K - row;
+        const int band_end = rows_host[band];
+        const bool last_of_band = row + k == band_end;
+        if (!seen[band]) {
+            seen[band] = 1;
+            gfirst[band] = i;
+            gk[band] = k;
+            int lg = 0;
+            while ((32 << lg) < k) lg++;
+            glog[band] = lg;
+            if ((32 << lg) != k && !last_of_band) regular = false;  // a lone (last) group of any length is fine: every chunk maps to it
+            if ((32 << lg) != k && last_of_band) glog[band] = 30;  // one group in the band: (c - cbs) >> 30 == 0
+        } else if (k != gk[band] && !(last_of_band && k < gk[band])) {
+            regular = false;
+        }
+        if (k % 32 != 0 || k <= 0) regular = false;
+        row += k;
+    }
+    for (int b = 0; b < 6; b++) {
+        rows_host[BIE_EXL2_ROWS_GFIRST + b] = gfirst[b];
+        rows_host[BIE_EXL2_ROWS_GLOG + b] = glog[b];
+    }
+    rows_host[6] |= BIE_EXL2_ROWS_SHUFFLED | (regular ? BIE_EXL2_ROWS_REGULAR : 0);
+    rows_host[BIE_EXL2_ROWS_LEN - 1] = BIE_EXL2_ROWS_TAG;
+    return mbwq_exl2_shuffle_launch(qweight, rows_host, K, N, as_stream(stream));
+}
+
 static int check_rows(const char* fn, const int* rows7, int K) {
     BIE_REQUIRE(rows7, BIE_ERR_INVALID_ARG, "%s: rows table is NULL", fn);
+    BIE_REQUIRE((rows7[6] & BIE_EXL2_ROWS_SHUFFLED), BIE_ERR_INVALID_ARG,
+                "%s: the band table does not carry the SHUFFLED mark: qweight must pass through bie_mbwq_exl2_shuffle (q_linear_cuda.mbwq_trans_qweight) once, and its table be used", fn);
+    BIE_REQUIRE(rows7[BIE_EXL2_ROWS_LEN - 1] == BIE_EXL2_ROWS_TAG, BIE_ERR_INVALID_ARG, "%s: the band table is not the %d-int table of bie_mbwq_exl2_shuffle", fn, BIE_EXL2_ROWS_LEN);
     int prev = 0;
     for (int b = 0; b < 6; b++) {
         BIE_REQUIRE(rows7[b] >= prev && rows7[b] % 32 == 0, BIE_ERR_UNSUPPORTED,

@@ -65,14 +65,108 @@ __device__ __forceinline__ void exl2_locate(const Exl2Rows& rows, int k, int& bi
     prow = row;
 }
 
-// 32 values of one column from BITS consecutive words (LSB-first stream)
+// ---- the chunk layout in HBM ("half-pair" layout, written once by exl2_shuffle_kernel below) -------------------------------------
+// The checkpoint stores the 32 values of a chunk as one LSB-first stream over BITS words (exl2/quant/qdq_*.cuh, QMODE 0).  The
+// reference re-arranges that stream at load time for its own extraction (shuffle_kernel, mbwq_linear_cuda_kernel.cu:63-86; its
+// build configures the hook as a no-op); this engine uses the same hook for a layout made for v_and_or_b32 + packed fp16:
+//   * pair j = (q[2j], q[2j+1]) occupies the SAME bit range [p, p+BITS) of the low and of the high 16-bit half of one word, so ONE
+//     v_and_or_b32 (mask both halves, OR the exponents) yields the fp16 pair (2^(10-p') + q[2j], 2^(10-p') + q[2j+1]) -- the field
+//     stays where it is, the exponent is chosen so that the field's lowest bit weighs 1 (p' = p - window base, p' + BITS <= 10);
+//   * a half holds F = 16 / BITS whole fields, pairs 0 .. BITS*F-1 are (word j / F, field j % F);
+//   * the R = 16 - F*BITS spare top bits of the halves (3-, 5-, 6-bit bands) form, word after word, a spare stream per half that
+//     holds the remaining 16 - BITS*F pairs.
+// Per pair: 1 VALU (+ one shift per 10-bit window of a word) instead of the 3-4 of window / mask / spread / mask on the stream.
+template <int I, int N, class Fn>
+__device__ __forceinline__ void exl2_static_for(Fn&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        exl2_static_for<I + 1, N>(f);
+    }
+}
+
+struct Exl2Piece {  // `len` bits at bit `src` of a half of word `d` are bits [dst, dst + len) of a spare-stream field
+    int d, src, len, dst;
+};
+
+template <int B>
+struct Exl2Lay {
+    static constexpr int F = 16 / B;
+    static constexpr int R = 16 - F * B;
+    static constexpr int MAIN = B * F;  // pairs in whole fields
+    // base of the 10-bit mantissa window the field at bit p of a half is read through
+    static constexpr int win(int p) {
+        int b0 = 0;
+        for (int q = 0; q <= p; q += B)
+            if (q + B - b0 > 10) b0 = q;
+        return b0;
+    }
+    // piece t of spare-stream field r (len == 0: the field has fewer pieces)
+    static constexpr Exl2Piece piece(int r, int t) {
+        int bit = r * B, need = B, dst = 0;
+        for (int i = 0;; i++) {
+            if (need <= 0 || R == 0) return Exl2Piece{0, 0, 0, 0};
+            const int d = bit / R, off = bit % R;
+            const int len = (R - off) < need ? (R - off) : need;
+            if (i == t) return Exl2Piece{d, F * B + off, len, dst};
+            bit += len; dst += len; need -= len;
+        }
+    }
+};
+
+// raw fields of pair J of a shuffled chunk: q[2J] | q[2J+1] << 16
+template <int BITS, int J>
+__device__ __forceinline__ uint32_t exl2_raw_pair(const uint32_t (&w)[8]) {
+    using L = Exl2Lay<BITS>;
+    constexpr uint32_t mask = (1u << BITS) - 1u;
+    if constexpr (J < L::MAIN) {
+        return (w[J / L::F] >> ((J % L::F) * BITS)) & (mask | (mask << 16));
+    } else {
+        uint32_t acc = 0;
+        exl2_static_for<0, BITS>([&](auto t) {
+            constexpr Exl2Piece pc = L::piece(J - L::MAIN, decltype(t)::value);
+            if constexpr (pc.len > 0) acc |= ((w[pc.d] >> pc.src) & (((1u << pc.len) - 1u) * 0x00010001u)) << pc.dst;
+        });
+        return acc;
+    }
+}
+
+// 32 values of one column from the BITS words of a shuffled chunk
 template <int BITS>
 __device__ __forceinline__ void exl2_extract32(const uint32_t (&w)[8], uint32_t (&q)[32]) {
+    exl2_static_for<0, 16>([&](auto j) {
+        constexpr int J = decltype(j)::value;
+        const uint32_t u = exl2_raw_pair<BITS, J>(w);
+        q[2 * J] = u & 0xffffu;
+        q[2 * J + 1] = u >> 16;
+    });
+}
+
+// the inverse: 32 values -> BITS words in the half-pair layout
+template <int BITS>
+__device__ __forceinline__ void exl2_pack32(const uint32_t (&q)[32], uint32_t (&w)[8]) {
+    using L = Exl2Lay<BITS>;
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = 0u;
+    exl2_static_for<0, 16>([&](auto j) {
+        constexpr int J = decltype(j)::value;
+        const uint32_t u = q[2 * J] | (q[2 * J + 1] << 16);
+        if constexpr (J < L::MAIN) {
+            w[J / L::F] |= u << ((J % L::F) * BITS);
+        } else {
+            exl2_static_for<0, BITS>([&](auto t) {
+                constexpr Exl2Piece pc = L::piece(J - L::MAIN, decltype(t)::value);
+                if constexpr (pc.len > 0) w[pc.d] |= ((u >> pc.dst) & (((1u << pc.len) - 1u) * 0x00010001u)) << pc.src;
+            });
+        }
+    });
+}
+
+// the checkpoint's form of a chunk: one LSB-first stream over BITS words
+template <int BITS>
+__device__ __forceinline__ void exl2_extract32_stream(const uint32_t (&w)[8], uint32_t (&q)[32]) {
     constexpr uint32_t mask = (1u << BITS) - 1u;
 #pragma unroll
     for (int j = 0; j < 32; j++) {
-        constexpr int dummy = 0;
-        (void)dummy;
         const int bitpos = j * BITS;
         const int wi = bitpos >> 5, sh = bitpos & 31;
         uint32_t v = w[wi] >> sh;
@@ -81,26 +175,49 @@ __device__ __forceinline__ void exl2_extract32(const uint32_t (&w)[8], uint32_t 
     }
 }
 
-// 16 fp16 pairs (1024 + q[2i], 1024 + q[2i+1]) of a chunk straight from the bitstream: a 32-bit window holding both
-// fields (funnel shift when it straddles two words), AND to the 2*BITS field bits, (t << (16-BITS)) | t puts the second
-// field at bit 16 (OR, not ADD: the overlap garbage lies outside the masks and cannot carry), AND-OR applies the field masks
-// and the 0x6400 exponent.  3-4 VALU per pair.
-template <int BITS>
-__device__ __forceinline__ void exl2_pairs16(const uint32_t (&w)[8], uint32_t (&P)[16]) {
-    constexpr uint32_t mask = (1u << BITS) - 1u;
-    constexpr uint32_t mask2 = (BITS == 16) ? 0xffffffffu : ((1u << (2 * BITS)) - 1u);
+// The exponent words 2^(10-lp) | 2^(10-lp) << 16 for the window positions lp = 0 .. 8, kept in registers behind an opaque move:
+// v_and_or_b32 and v_pk_add_f16 take no literal on gfx950 and only one scalar operand, and left to itself the compiler splits
+// the and-or into v_and_b32 + v_or_b32 with two literals.  Entries a kernel never uses are never materialised.
+struct Exl2Magic {
+    uint32_t m[9];
+    __device__ __forceinline__ Exl2Magic() {
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const int bitpos = 2 * i * BITS;
-        const int wi = bitpos >> 5, sh = bitpos & 31;
-        uint32_t v;
-        if (sh == 0) v = w[wi];
-        else if (sh + 2 * BITS <= 32) v = w[wi] >> sh;
-        else v = __builtin_amdgcn_alignbit(w[wi + 1], w[wi], sh);
-        const uint32_t t = v & mask2;
-        const uint32_t u = (t << (16 - BITS)) | t;
-        P[i] = (u & (mask | (mask << 16))) | 0x64006400u;
+        for (int lp = 0; lp < 9; lp++) {
+            const uint32_t c = (0x6400u - ((uint32_t)lp << 10)) * 0x00010001u;
+            asm("v_mov_b32 %0, %1" : "=v"(m[lp]) : "s"(c));
+        }
     }
+};
+
+__device__ __forceinline__ uint32_t exl2_and_or(uint32_t v, uint32_t mask, uint32_t orv) {
+    uint32_t r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "s"(mask), "v"(orv));
+    return r;
+}
+
+// 16 EXACT fp16 pairs (q[2i], q[2i+1]) of a shuffled chunk: v_and_or_b32 in place (exponent = 10 - field position inside the word's
+// current 10-bit window), then the exact packed subtraction of that power of two.  The spare-stream pairs are gathered piece by piece.
+template <int BITS>
+__device__ __forceinline__ void exl2_qpairs16(const uint32_t (&w)[8], const Exl2Magic& mg, half2_t (&Q)[16]) {
+    using L = Exl2Lay<BITS>;
+    constexpr uint32_t mask = (1u << BITS) - 1u;
+    exl2_static_for<0, 16>([&](auto j) {
+        constexpr int J = decltype(j)::value;
+        if constexpr (J < L::MAIN) {
+            constexpr int d = J / L::F, p = (J % L::F) * BITS;
+            constexpr int b0 = L::win(p), lp = p - b0;
+            const uint32_t v = b0 ? (w[d] >> b0) : w[d];
+            const uint32_t t = exl2_and_or(v, (mask << lp) * 0x00010001u, mg.m[lp]);
+            Q[J] = __builtin_bit_cast(half2_t, t) - __builtin_bit_cast(half2_t, mg.m[lp]);  // exact
+        } else {
+            uint32_t acc = mg.m[0];
+            exl2_static_for<0, BITS>([&](auto t) {
+                constexpr Exl2Piece pc = L::piece(J - L::MAIN, decltype(t)::value);
+                if constexpr (pc.len > 0) acc = exl2_and_or(w[pc.d] >> (pc.src - pc.dst), (((1u << pc.len) - 1u) << pc.dst) * 0x00010001u, acc);
+            });
+            Q[J] = __builtin_bit_cast(half2_t, acc) - __builtin_bit_cast(half2_t, mg.m[0]);  // exact
+        }
+    });
 }
 
 template <int BITS>
@@ -112,6 +229,35 @@ __device__ __forceinline__ void exl2_load_chunk(const uint32_t* __restrict__ qw,
 __device__ __forceinline__ uint16_t exl2_dq(uint32_t q, half_t s, half_t z) {
     const half_t r = __builtin_fmaf16((half_t)(float)q, s, -z);  // v_fma_f16, one rounding == __hfma2
     return __builtin_bit_cast(uint16_t, r);
+}
+
+// ---- the load-time re-arrangement (in place): LSB-first stream -> half-pair layout, one thread per (column, chunk) -----------------
+// Replaces shuffle_kernel (mbwq_linear_cuda_kernel.cu:63-86), run once by q_linear_cuda.mbwq_trans_qweight (:620).  A thread reads
+// all words of its chunk before it writes any, and chunks are disjoint: in place is safe.
+template <int BITS>
+__device__ __forceinline__ void exl2_shuffle_chunk(uint32_t* __restrict__ qw, long N, int prow, int n) {
+    uint32_t w[8], q[32];
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = i < BITS ? qw[(long)(prow + i) * N + n] : 0u;
+    exl2_extract32_stream<BITS>(w, q);
+    exl2_pack32<BITS>(q, w);
+#pragma unroll
+    for (int i = 0; i < BITS; i++) qw[(long)(prow + i) * N + n] = w[i];
+}
+__global__ __launch_bounds__(256) void exl2_shuffle_kernel(uint32_t* __restrict__ qw, Exl2Rows rows, int K, int N) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int k0 = blockIdx.y * 32;
+    if (n >= N || k0 >= K) return;
+    int bits, prow;
+    exl2_locate(rows, k0, bits, prow);
+    switch (bits) {
+        case 8: exl2_shuffle_chunk<8>(qw, N, prow, n); break;
+        case 6: exl2_shuffle_chunk<6>(qw, N, prow, n); break;
+        case 5: exl2_shuffle_chunk<5>(qw, N, prow, n); break;
+        case 4: exl2_shuffle_chunk<4>(qw, N, prow, n); break;
+        case 3: exl2_shuffle_chunk<3>(qw, N, prow, n); break;
+        default: exl2_shuffle_chunk<2>(qw, N, prow, n); break;
+    }
 }
 
 // ---- dense reconstruction: out[q_perm[k]][n] ------------------------------------------------------------
@@ -241,6 +387,8 @@ struct Exl2Call {  // everything one workgroup of the decode kernel needs (kerne
     unsigned long long* gran; unsigned* gen; uint16_t* y;
     Exl2Rows rows;
     int M, K, N, chunks_per_slab, S, colblocks;
+    int gfirst[6], glog[6];  // DIRECT form: first group of each band and log2(chunks per group) (bie_mbwq_exl2_shuffle: regular groups)
+    const uint16_t* xp;      // list form, DMODE 2: x[q_perm] (written by exl2_list_permute_kernel in front), or x itself without a q_perm
 };
 
 // STAGED (two x rows): the slab's activations are gathered through q_perm ONCE per workgroup into LDS.  !STAGED (one row): every wave
@@ -249,14 +397,31 @@ struct Exl2Call {  // everything one workgroup of the decode kernel needs (kerne
 // two rows 24.5 against 19.1 (profiles/r03_l_exl2_staged_x.txt).  Both forms are exact.
 // NARROW: the tensor has no 8 / 6 / 5-bit rows (host: rows7[2] == 0): those bands' prefetch sets (4 x up to 8 words) are what sets the
 // kernel's register count -- 151 with them (8-wave workgroups: ONE per CU), <= 128 without (two per CU).
-template <int MT, int EX2_NW, bool STAGED, bool NARROW>
+// DIRECT (one x row, regular groups -- every band's groups hold the same power-of-two number of whole chunks, bie_mbwq_exl2_shuffle
+// says so): NOTHING is staged.  A chunk's group is arithmetic on the band table, its 32 permutation indices are loaded by the wave
+// itself one round of the prefetch ahead of the gather that needs them, and the first packed words are requested at kernel entry
+// instead of behind a metadata round trip and a barrier.  Measured on the 32-layer list (4096x4096, 3/2-bit g32): the staging
+// prologue alone cost 0.6 of 2.3 us per layer (profiles/r04_exl2_ablation.txt).
+struct Exl2Groups {
+    int gfirst[6], glog[6];
+};
+// DMODE 2 (the list form): x arrives ALREADY permuted (xp = x[q_perm], one small launch in front for all entries of the list --
+// every column block of a layer needs the same 2 K bytes, gathering them per workgroup is 64-172 times redundant and a 32-lane
+// gather touches up to 32 cache lines).  A chunk's 32 activations are then 64 contiguous bytes: one s_load_dwordx16, the pairs go
+// into v_dot2c_f32_f16 as scalar operands -- no index loads, no gather, no LDS in the loop.
+typedef uint32_t exl2_u32x16 __attribute__((ext_vector_type(16)));
+template <int MT, int EX2_NW, bool STAGED, bool NARROW, int DMODE = 0>
 __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, const uint32_t* __restrict__ qw,
                                                 const uint16_t* __restrict__ scales, const uint16_t* __restrict__ zeros,
                                                 const uint16_t* __restrict__ perm, const uint16_t* __restrict__ gmap,
                                                 unsigned long long* __restrict__ gran, unsigned* __restrict__ gen,
                                                 uint16_t* __restrict__ y, const Exl2Rows rows, const int M, const int K, const int N,
                                                 const int chunks_per_slab, const int S, const int colblock, const int slab_idx,
-                                                const int colblocks, unsigned epoch, unsigned* status, unsigned tag_skew, int spin_limit) {
+                                                const int colblocks, unsigned epoch, unsigned* status, unsigned tag_skew, int spin_limit,
+                                                const Exl2Groups grp = Exl2Groups{}, const uint16_t* __restrict__ xp = nullptr) {
+    constexpr bool DIRECT = DMODE != 0;
+    constexpr bool XP = DMODE == 2;
+    static_assert(!DIRECT || (MT == 1 && !STAGED), "the direct forms serve one row of x");
     extern __shared__ __attribute__((aligned(16))) uint32_t smem2[];
     const int tid = threadIdx.x, lane = tid & 63;
     // the tile's generation is read ONCE, at kernel entry, by every wave: the reducer advances the word as soon as it is done, and a
@@ -280,7 +445,7 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
     uint16_t* perm_s = reinterpret_cast<uint16_t*>(smem2) + EX2_NW * (4 * MT * 32);  // !STAGED: [slab_k]
     uint16_t* gmap_s = STAGED ? x_s + MT * slab_k : perm_s + slab_k;           // [chunks_per_slab * 2]
     int two_groups = 0;  // does any chunk of the slab straddle two groups (group sizes below 32)?
-    {
+    if constexpr (!DIRECT) {
         const int nk = (c_end - c_begin) * 32;
         for (int i = tid; i < nk; i += EX2_NW * 64) {
             const int kx = perm ? (int)perm[c_begin * 32 + i] : c_begin * 32 + i;
@@ -297,50 +462,93 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
             gmap_s[2 * i + 1] = gb;
             two_groups |= (ga != gb);
         }
-        two_groups = __syncthreads_or(two_groups);  // the slab's metadata is in LDS; workgroup-uniform flag
+        two_groups = __builtin_amdgcn_readfirstlane(__syncthreads_or(two_groups));  // the slab's metadata is in LDS; workgroup-uniform flag
     }
     float acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; m++) acc[m] = 0.f;
-    const half2_t k1024 = half2_t{(half_t)1024.0f, (half_t)1024.0f};
+    const Exl2Magic magic;
+    // Packed rows and group constants through buffer descriptors: the row / group part of every address is wave-uniform (scalar
+    // offset), the column part one register per element size -- no 64-bit vector address arithmetic per load (it was 1.2 VALU per
+    // weight pair).  The host admits only tensors below 4 GB (exl2_buffer_ok).
+    const auto rsrc_of = [](const void* p) {
+        const uint64_t b = (uint64_t)(uintptr_t)p;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((uint64_t)hi << 32) | lo), 0, (int)0xfffffffcu, 0x00020000);
+    };
+    const auto rq = rsrc_of(qw), rs = rsrc_of(scales), rz = rsrc_of(zeros);
+    const uint32_t col4 = (uint32_t)nl * 4u, col2 = (uint32_t)nl * 2u;
+    const uint32_t row_bytes = (uint32_t)N * 4u, grow_bytes = (uint32_t)N * 2u;
     // The wave's chunks are taken BAND BY BAND: inside a band the bit width -- hence the number of loads per chunk -- is a compile-time
     // constant, every issue is unconditional (the look-ahead index is clamped to the band's last chunk: a harmless re-load), so the
     // compiler can wait with an exact vmcnt for the OLDEST chunk only.  (With the width switched at run time and `if (c < c_end)`
     // around the issues every wait came out as vmcnt(0..3): the 4-deep prefetch was really 1-deep and each of a wave's 8 chunks paid
     // a full memory latency -- PMC: 58 % of the wave time waiting.)
-    auto band = [&](auto bits_tag, auto two_tag, int cb0, int cb1, int prow0) {  // chunks [cb0, cb1) of this slab lie in one band starting at row prow0
+    const uint16_t* pp = perm ? perm : gmap;  // DIRECT without q_perm: the index load stays (any readable address), its value is not used
+    uint32_t pmask = perm ? 0xffffffffu : 0u;
+    asm volatile("" : "+v"(pmask));  // opaque: keeps the two cases one code path
+    // chunks [cb0, cb1) of this slab lie in one band starting at row prow0; DIRECT: the band's first chunk cbs is in group gbase, 2^glg chunks per group
+    auto band = [&](auto bits_tag, auto two_tag, int cb0, int cb1, int prow0, int cbs, int gbase, int glg) {
+        cb0 = __builtin_amdgcn_readfirstlane(cb0);  // scalars, said so: the row offsets below go into soffset
+        cb1 = __builtin_amdgcn_readfirstlane(cb1);
+        prow0 = __builtin_amdgcn_readfirstlane(prow0);
+        cbs = __builtin_amdgcn_readfirstlane(cbs);
+        gbase = __builtin_amdgcn_readfirstlane(gbase);
+        glg = __builtin_amdgcn_readfirstlane(glg);
         constexpr int BITS = decltype(bits_tag)::value;
         constexpr bool TWO = decltype(two_tag)::value;  // group constants per 16-k half (two loads more per chunk) or per chunk
         struct Chunk {
             uint32_t w[BITS];
             uint32_t s[2], z[2];
             uint32_t xraw[STAGED ? 1 : MT];  // !STAGED: this lane's gathered activation(s) of the chunk
+            uint32_t p;                      // DIRECT: this lane's permutation index for the NEXT chunk of this set
         };
         auto issue_w = [&](int c, Chunk& ch) {
             const int prow = prow0 + (c - cb0) * BITS;
 #pragma unroll
-            for (int i = 0; i < BITS; i++) ch.w[i] = __builtin_nontemporal_load(qw + (long)(prow + i) * N + nl);
+            for (int i = 0; i < BITS; i++) ch.w[i] = __builtin_amdgcn_raw_buffer_load_b32(rq, col4, (uint32_t)(prow + i) * row_bytes, 2);  // nt
         };
-        auto group_of = [&](int c, int half) -> int { return __builtin_amdgcn_readfirstlane((int)gmap_s[2 * (c - c_begin) + half]); };
+        auto group_of = [&](int c, int half) -> int {
+            if constexpr (DIRECT) return gbase + ((c - cbs) >> glg);
+            else return __builtin_amdgcn_readfirstlane((int)gmap_s[2 * (c - c_begin) + half]);
+        };
+        auto load_perm = [&](int c, Chunk& ch) {
+            const uint32_t idx = (uint32_t)c * 32u + (uint32_t)(lane & 31);
+            ch.p = pp[idx];  // raw: whatever touches the value here would wait for the load here
+        };
         auto issue_p = [&](int c, Chunk& ch) {
-            const int g0 = group_of(c, 0);
-            ch.s[0] = scales[(long)g0 * N + nl];
-            ch.z[0] = zeros[(long)g0 * N + nl];
+            const uint32_t g0 = (uint32_t)group_of(c, 0) * grow_bytes;
+            ch.s[0] = __builtin_amdgcn_raw_buffer_load_b16(rs, col2, g0, 0);
+            ch.z[0] = __builtin_amdgcn_raw_buffer_load_b16(rz, col2, g0, 0);
             if constexpr (TWO) {  // static load count per chunk either way
-                const int g1 = group_of(c, 1);
-                ch.s[1] = scales[(long)g1 * N + nl];
-                ch.z[1] = zeros[(long)g1 * N + nl];
+                const uint32_t g1 = (uint32_t)group_of(c, 1) * grow_bytes;
+                ch.s[1] = __builtin_amdgcn_raw_buffer_load_b16(rs, col2, g1, 0);
+                ch.z[1] = __builtin_amdgcn_raw_buffer_load_b16(rz, col2, g1, 0);
             }
-            if constexpr (!STAGED) {
-                const int pidx = (int)perm_s[(c - c_begin) * 32 + (lane & 31)];
+            if constexpr (!STAGED && !XP) {
+                int pidx;
+                if constexpr (DIRECT) {  // v_bfi_b32, no branch on `perm` around a load (a branch costs a wait per load)
+                    const uint32_t idx = (uint32_t)c * 32u + (uint32_t)(lane & 31);
+                    pidx = (int)((ch.p & pmask) | (idx & ~pmask));
+                }
+                else pidx = (int)perm_s[(c - c_begin) * 32 + (lane & 31)];
 #pragma unroll
                 for (int m = 0; m < MT; m++) ch.xraw[m] = x[(long)(m < M ? m : 0) * K + pidx];
             }
         };
         auto compute = [&](int set, int c, const Chunk& ch) {
-            const uint16_t* xw;
-            int xstride;
-            if constexpr (STAGED) {
+            const uint16_t* xw = nullptr;
+            int xstride = 0;
+            uint32_t xsc[16];
+            if constexpr (XP) {  // 64 contiguous bytes through the scalar cache, requested in front of the chunk's extraction
+                typedef const __attribute__((address_space(4))) uint4_t cx4_t;
+                cx4_t* xq = (cx4_t*)(uintptr_t)(xp + (long)c * 32);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint4_t v = xq[i];
+                    xsc[4 * i] = v.x; xsc[4 * i + 1] = v.y; xsc[4 * i + 2] = v.z; xsc[4 * i + 3] = v.w;
+                }
+            } else if constexpr (STAGED) {
                 xw = x_s + (c - c_begin) * 32;
                 xstride = slab_k;
             } else {
@@ -359,24 +567,29 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
             uint32_t w8[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) w8[i] = i < BITS ? ch.w[i] : 0u;
-            uint32_t P[16];
-            exl2_pairs16<BITS>(w8, P);
+            half2_t Q[16];
+            exl2_qpairs16<BITS>(w8, magic, Q);
 #pragma unroll
             for (int half = 0; half < 2; half++) {
                 const half_t sh = __builtin_bit_cast(half_t, (uint16_t)ch.s[TWO ? half : 0]);
                 const half_t zh = __builtin_bit_cast(half_t, (uint16_t)ch.z[TWO ? half : 0]);
                 const half2_t s2 = half2_t{sh, sh}, nz2 = half2_t{(half_t)-zh, (half_t)-zh};
                 uint4_t xv[MT][2];
+                if constexpr (!XP) {
 #pragma unroll
-                for (int m = 0; m < MT; m++) {
-                    const uint4_t* xp = reinterpret_cast<const uint4_t*>(xw + m * xstride + 16 * half);
-                    xv[m][0] = xp[0];
-                    xv[m][1] = xp[1];
+                    for (int m = 0; m < MT; m++) {
+                        const uint4_t* xq4 = reinterpret_cast<const uint4_t*>(xw + m * xstride + 16 * half);
+                        xv[m][0] = xq4[0];
+                        xv[m][1] = xq4[1];
+                    }
                 }
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
-                    const half2_t qh = __builtin_bit_cast(half2_t, P[8 * half + i]) - k1024;  // exact
-                    const half2_t r = __builtin_elementwise_fma(qh, s2, nz2);           // one rounding == __hfma2(q, s, -z)
+                    const half2_t r = __builtin_elementwise_fma(Q[8 * half + i], s2, nz2);  // one rounding == __hfma2(q, s, -z)
+                    if constexpr (XP) {
+                        acc[0] = __builtin_amdgcn_fdot2(r, __builtin_bit_cast(half2_t, xsc[8 * half + i]), acc[0], false);
+                        continue;
+                    }
 #pragma unroll
                     for (int m = 0; m < MT; m++) {
                         if (m >= M) continue;
@@ -393,23 +606,48 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
         if (first >= cb1) return;
         const int cnt = (cb1 - first + EX2_NW - 1) / EX2_NW;
         const int last = first + (cnt - 1) * EX2_NW;
-        auto at = [&](int jj) { const int c = first + jj * EX2_NW; return c < last ? c : last; };  // clamped look-ahead
-        auto issue = [&](int c, Chunk& ch) { issue_w(c, ch); issue_p(c, ch); };
+        auto at = [&](int jj) { const int c = first + jj * EX2_NW; return __builtin_amdgcn_readfirstlane(c < last ? c : last); };  // clamped look-ahead; a scalar
+        // words, group constants, the gather through the indices this set was given a round ago -- then the indices of its next chunk
+        auto issue = [&](int c, int c_next, Chunk& ch) {
+            issue_w(c, ch);
+            issue_p(c, ch);
+            if constexpr (DIRECT && !XP) load_perm(c_next, ch);
+        };
         Chunk c0, c1, c2, c3;
-        issue(at(0), c0);
-        issue(at(1), c1);
-        issue(at(2), c2);
-        issue(at(3), c3);
+        if constexpr (XP) {
+            issue(at(0), 0, c0);
+            issue(at(1), 0, c1);
+            issue(at(2), 0, c2);
+            issue(at(3), 0, c3);
+        } else if constexpr (DIRECT) {
+            load_perm(at(0), c0);
+            load_perm(at(1), c1);
+            load_perm(at(2), c2);
+            load_perm(at(3), c3);
+            issue_w(at(0), c0);  // the first words do not wait for the indices
+            issue_w(at(1), c1);
+            issue_w(at(2), c2);
+            issue_w(at(3), c3);
+            issue_p(at(0), c0); load_perm(at(4), c0);
+            issue_p(at(1), c1); load_perm(at(5), c1);
+            issue_p(at(2), c2); load_perm(at(6), c2);
+            issue_p(at(3), c3); load_perm(at(7), c3);
+        } else {
+            issue(at(0), 0, c0);
+            issue(at(1), 0, c1);
+            issue(at(2), 0, c2);
+            issue(at(3), 0, c3);
+        }
         int jj = 0;
         for (; jj + 4 < cnt; jj += 4) {  // a further group follows: four full steps, each re-filling the set it has just consumed
             compute(0, at(jj), c0);
-            issue(at(jj + 4), c0);
+            issue(at(jj + 4), at(jj + 8), c0);
             compute(1, at(jj + 1), c1);
-            issue(at(jj + 5), c1);
+            issue(at(jj + 5), at(jj + 9), c1);
             compute(2, at(jj + 2), c2);
-            issue(at(jj + 6), c2);
+            issue(at(jj + 6), at(jj + 10), c2);
             compute(3, at(jj + 3), c3);
-            issue(at(jj + 7), c3);
+            issue(at(jj + 7), at(jj + 11), c3);
         }
         compute(0, at(jj), c0);  // last group: nothing left to request
         if (jj + 1 < cnt) compute(1, at(jj + 1), c1);
@@ -426,6 +664,7 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
             const int prow_band = prow;
             prow += (cb1 - cb0) * bits;
             kprev = khi;
+            const int cbs = cb0;
             const int skip = cb0 < c_begin ? c_begin - cb0 : 0;  // clip to the slab
             cb0 += skip;
             if (cb1 > c_end) cb1 = c_end;
@@ -433,8 +672,9 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
                 const int p0 = prow_band + skip * bits;
 #define BIE_BAND(B)                                                                        \
     do {                                                                                   \
-        if (two_groups) band(std::integral_constant<int, B>{}, std::true_type{}, cb0, cb1, p0); \
-        else band(std::integral_constant<int, B>{}, std::false_type{}, cb0, cb1, p0);      \
+        if constexpr (DIRECT) band(std::integral_constant<int, B>{}, std::false_type{}, cb0, cb1, p0, cbs, grp.gfirst[b], grp.glog[b]); \
+        else if (two_groups) band(std::integral_constant<int, B>{}, std::true_type{}, cb0, cb1, p0, 0, 0, 0); \
+        else band(std::integral_constant<int, B>{}, std::false_type{}, cb0, cb1, p0, 0, 0, 0);      \
     } while (0)
                 if constexpr (NARROW) {
                     switch (b) {
@@ -514,11 +754,14 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
 }
 
 
-template <int MT, int EX2_NW, bool NARROW>
+template <int MT, int EX2_NW, bool NARROW, int DMODE>
 __global__ __launch_bounds__(EX2_NW * 64, (EX2_NW == 8 ? 2 : 1)) void exl2_gemv2_kernel(const Exl2Call c, unsigned epoch, unsigned* status, unsigned tag_skew,
                                                                                           int spin_limit) {
-    exl2_gemv2_body<MT, EX2_NW, (MT > 1), NARROW>(c.x, c.qw, c.scales, c.zeros, c.perm, c.gmap, c.gran, c.gen, c.y, c.rows, c.M, c.K, c.N,
-                                          c.chunks_per_slab, c.S, (int)blockIdx.x, (int)blockIdx.y, c.colblocks, epoch, status, tag_skew, spin_limit);
+    Exl2Groups grp;
+#pragma unroll
+    for (int i = 0; i < 6; i++) { grp.gfirst[i] = c.gfirst[i]; grp.glog[i] = c.glog[i]; }
+    exl2_gemv2_body<MT, EX2_NW, (MT > 1), NARROW, DMODE>(c.x, c.qw, c.scales, c.zeros, c.perm, c.gmap, c.gran, c.gen, c.y, c.rows, c.M, c.K, c.N,
+                                          c.chunks_per_slab, c.S, (int)blockIdx.x, (int)blockIdx.y, c.colblocks, epoch, status, tag_skew, spin_limit, grp);
 }
 
 // ---- exl2 for 3 <= M <= 64 on the matrix pipe (the reference keeps these rows in its fused kernel, exl2/q_gemm_kernel.cuh:90-549;
@@ -568,6 +811,7 @@ __global__ __launch_bounds__(EX2_NW * 64, OCC) void exl2_mfma_kernel(const Exl2C
     if (c_end > C) c_end = C;
     uint16_t* T = reinterpret_cast<uint16_t*>(smem2) + wave * (64 * EXL2_T_PITCH);          // wave-private [64 columns][EXL2_T_PITCH]
     uint16_t* gmap_s = reinterpret_cast<uint16_t*>(smem2) + EX2_NW * (64 * EXL2_T_PITCH);   // [chunks_per_slab * 2]
+    const Exl2Magic magic;
     int two_groups = 0;
     {
         for (int i = tid; i < (c_end - c_begin); i += EX2_NW * 64) {
@@ -583,7 +827,6 @@ __global__ __launch_bounds__(EX2_NW * 64, OCC) void exl2_mfma_kernel(const Exl2C
     for (int j = 0; j < 4; j++)
 #pragma unroll
         for (int rb = 0; rb < MB; rb++) acc[j][rb] = exl2_acc_t{0.f, 0.f, 0.f, 0.f};
-    const half2_t k1024 = half2_t{(half_t)1024.0f, (half_t)1024.0f};
     const int c16 = lane & 15, kb = lane >> 4;
     const uint16_t* xrow[MB];  // x here is the PERMUTED activation matrix [M][K]
 #pragma unroll
@@ -616,8 +859,8 @@ __global__ __launch_bounds__(EX2_NW * 64, OCC) void exl2_mfma_kernel(const Exl2C
             uint32_t w8[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) w8[i] = i < BITS ? ch.w[i] : 0u;
-            uint32_t P[16];
-            exl2_pairs16<BITS>(w8, P);
+            half2_t Q[16];
+            exl2_qpairs16<BITS>(w8, magic, Q);
             uint32_t r[16];
 #pragma unroll
             for (int half = 0; half < 2; half++) {
@@ -626,8 +869,7 @@ __global__ __launch_bounds__(EX2_NW * 64, OCC) void exl2_mfma_kernel(const Exl2C
                 const half2_t s2 = half2_t{sh, sh}, nz2 = half2_t{(half_t)-zh, (half_t)-zh};
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
-                    const half2_t qh = __builtin_bit_cast(half2_t, P[8 * half + i]) - k1024;  // exact
-                    r[8 * half + i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_fma(qh, s2, nz2));  // == __hfma2(q, s, -z)
+                    r[8 * half + i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_fma(Q[8 * half + i], s2, nz2));  // == __hfma2(q, s, -z)
                 }
             }
             uint4_t* tw = reinterpret_cast<uint4_t*>(T + lane * EXL2_T_PITCH);
@@ -809,7 +1051,7 @@ static size_t exl2_mfma_xp_offset(int M, int K, int N) {
 
 // ONE launch over a LIST of exl2 layers (bie_mbwq_exl2_list_*): block b -> {entry, column block | slab << 20} through a device table
 // (the MPQ list's idea, mpq_list.hip): a 4096x4096 3/2-bit layer is 5 MB -- far too little for a launch of its own.
-template <int MT, bool NARROW>
+template <int MT, bool NARROW, int DMODE>
 __device__ __forceinline__ void exl2_list_body(const Exl2Call* __restrict__ ent, const uint2_t* __restrict__ blk, unsigned epoch, unsigned* status,
                                                unsigned tag_skew, int spin_limit) {
     typedef const __attribute__((address_space(4))) uint2_t cu2_t;
@@ -819,14 +1061,24 @@ __device__ __forceinline__ void exl2_list_body(const Exl2Call* __restrict__ ent,
     Exl2Rows rows;
 #pragma unroll
     for (int i = 0; i < 6; i++) rows.r[i] = c->rows.r[i];
-    exl2_gemv2_body<MT, 8, (MT > 1), NARROW>(c->x, c->qw, c->scales, c->zeros, c->perm, c->gmap, c->gran, c->gen, c->y, rows, c->M, c->K, c->N,
+    Exl2Groups grp;
+#pragma unroll
+    for (int i = 0; i < 6; i++) { grp.gfirst[i] = c->gfirst[i]; grp.glog[i] = c->glog[i]; }
+    exl2_gemv2_body<MT, 8, (MT > 1), NARROW, DMODE>(c->x, c->qw, c->scales, c->zeros, c->perm, c->gmap, c->gran, c->gen, c->y, rows, c->M, c->K, c->N,
                                              c->chunks_per_slab, c->S, (int)(rec.y & 0xfffffu), (int)(rec.y >> 20), c->colblocks, epoch, status,
-                                             tag_skew, spin_limit);
+                                             tag_skew, spin_limit, grp, c->xp);
 }
-template <int MT, bool NARROW>
+template <int MT, bool NARROW, int DMODE>
 __global__ __launch_bounds__(512, 2) void exl2_list_kernel(const Exl2Call* __restrict__ ent, const uint2_t* __restrict__ blk, unsigned epoch,
                                                            unsigned* status, unsigned tag_skew, int spin_limit) {
-    exl2_list_body<MT, NARROW>(ent, blk, epoch, status, tag_skew, spin_limit);
+    exl2_list_body<MT, NARROW, DMODE>(ent, blk, epoch, status, tag_skew, spin_limit);
+}
+// xp = x[q_perm] for every entry of a list that has a q_perm (one row of x; entries without one read x in place)
+__global__ __launch_bounds__(256) void exl2_list_permute_kernel(const Exl2Call* __restrict__ ent) {
+    const Exl2Call& e = ent[blockIdx.y];
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (e.perm == nullptr || k >= e.K) return;
+    const_cast<uint16_t*>(e.xp)[k] = e.x[e.perm[k]];
 }
 // decode (M <= 2): column blocks x K slabs ~ 512 workgroups of 8 waves (two per CU -> one round), slabs in whole multiples of
 // 8 chunks so that the 8 waves of a workgroup get equal shares; at most BIE_WS_COUNTERS column blocks use the slab reduction
@@ -891,6 +1143,26 @@ int mbwq_q4_dequant_launch(const int32_t* qw, const void* scales, const void* ze
     return check_launch("mbwq_q4_dequant_kernel");
 }
 
+// in place: the checkpoint's LSB-first streams -> the half-pair layout every exl2 kernel of this library reads
+int mbwq_exl2_shuffle_launch(int32_t* qw, const int* rows6, int K, int N, hipStream_t st) {
+    Exl2Rows rows;
+    for (int i = 0; i < 6; i++) rows.r[i] = rows6[i];
+    dim3 grid(cdiv(N, 256), K / 32);
+    hipLaunchKernelGGL(exl2_shuffle_kernel, grid, dim3(256), 0, st, (uint32_t*)qw, rows, K, N);
+    return check_launch("exl2_shuffle_kernel");
+}
+
+static void exl2_fill_groups(Exl2Call& c, const int* rows_ext) {
+    for (int b = 0; b < 6; b++) {
+        c.gfirst[b] = rows_ext[BIE_EXL2_ROWS_GFIRST + b];
+        c.glog[b] = rows_ext[BIE_EXL2_ROWS_GLOG + b];
+    }
+}
+static bool exl2_direct_on() {
+    static const bool on = [] { const char* e = getenv("BIE_EXL2_DIRECT"); return !e || atoi(e) != 0; }();
+    return on;
+}
+
 int mbwq_exl2_dequant_launch(const int32_t* qw, const void* scales, const void* zeros, const int16_t* perm,
                              const int16_t* gmap, const int* rows7, void* out, int K, int N, hipStream_t st) {
     Exl2Rows rows;
@@ -926,8 +1198,9 @@ int mbwq_exl2_forward_launch(const void* x, const int32_t* qw, const void* scale
         int cps2, S, nw;
         exl2_decode_plan(M, K, N, cps2, S, nw);
         const int MT = M;
+        const bool direct = M == 1 && (rows7[6] & BIE_EXL2_ROWS_REGULAR) && exl2_direct_on();
         size_t lds2 = MT > 1 ? (size_t)cps2 * (32 * MT + 2) * sizeof(uint16_t)   // the slab's gathered activations (M rows) + group map
-                             : (size_t)nw * 4 * MT * 32 * sizeof(uint16_t) + (size_t)cps2 * 34 * sizeof(uint16_t);  // wave x buffers + q_perm + group map
+                             : (size_t)nw * 4 * MT * 32 * sizeof(uint16_t) + (direct ? 0 : (size_t)cps2 * 34 * sizeof(uint16_t));  // wave x buffers (+ q_perm + group map)
         const size_t red = (size_t)nw * MT * 64 * sizeof(float);
         if (lds2 < red) lds2 = red;
         dim3 grid2(colblocks, S);
@@ -938,17 +1211,18 @@ int mbwq_exl2_forward_launch(const void* x, const int32_t* qw, const void* scale
         int spin;
         test_forge_get(&skew, &spin);
         Exl2Call call{(const uint16_t*)x, (const uint32_t*)qw, (const uint16_t*)scales, (const uint16_t*)zeros, (const uint16_t*)perm,
-                      (const uint16_t*)gmap, gran, gen, (uint16_t*)y, rows, M, K, N, cps2, S, colblocks};
+                      (const uint16_t*)gmap, gran, gen, (uint16_t*)y, rows, M, K, N, cps2, S, colblocks, {}, {}, nullptr};
+        exl2_fill_groups(call, rows7);
         const bool narrow2 = rows7[2] == 0;  // no 8 / 6 / 5-bit rows
-#define L2(MTV, NWV)                                                                                                                        \
+#define L2(MTV, NWV, DIR)                                                                                                                        \
     do {                                                                                                                                    \
-        if (narrow2) hipLaunchKernelGGL((exl2_gemv2_kernel<MTV, NWV, true>), grid2, dim3(NWV * 64), lds2, st, call, epoch, device_status_word(), skew, spin); \
-        else hipLaunchKernelGGL((exl2_gemv2_kernel<MTV, NWV, false>), grid2, dim3(NWV * 64), lds2, st, call, epoch, device_status_word(), skew, spin);      \
+        if (narrow2) hipLaunchKernelGGL((exl2_gemv2_kernel<MTV, NWV, true, DIR>), grid2, dim3(NWV * 64), lds2, st, call, epoch, device_status_word(), skew, spin); \
+        else hipLaunchKernelGGL((exl2_gemv2_kernel<MTV, NWV, false, DIR>), grid2, dim3(NWV * 64), lds2, st, call, epoch, device_status_word(), skew, spin);      \
     } while (0)
         if (nw == 16) {
-            if (MT == 1) L2(1, 16); else L2(2, 16);
+            if (MT == 1) { if (direct) L2(1, 16, 1); else L2(1, 16, 0); } else L2(2, 16, 0);
         } else {
-            if (MT == 1) L2(1, 8); else L2(2, 8);
+            if (MT == 1) { if (direct) L2(1, 8, 1); else L2(1, 8, 0); } else L2(2, 8, 0);
         }
 #undef L2
         return check_launch("exl2_gemv2_kernel");
@@ -974,7 +1248,7 @@ int mbwq_exl2_forward_launch(const void* x, const int32_t* qw, const void* scale
             xin = xp;
         }
         Exl2Call call{xin, (const uint32_t*)qw, (const uint16_t*)scales, (const uint16_t*)zeros, nullptr,
-                      (const uint16_t*)gmap, reinterpret_cast<unsigned long long*>(part), gen, (uint16_t*)y, rows, M, K, N, cpsm, Sm, colblocks};
+                      (const uint16_t*)gmap, reinterpret_cast<unsigned long long*>(part), gen, (uint16_t*)y, rows, M, K, N, cpsm, Sm, colblocks, {}, {}, nullptr};
         const bool narrow = rows7[2] == 0;  // cumulative end of the 5-bit band: no 8 / 6 / 5-bit rows
 #define LM(MBV, NWV, OCCN, OCCW)                                                                                                                 \
     do {                                                                                                                                         \
@@ -1023,6 +1297,9 @@ int status_report(const char* fn);  // splitk.hip
 struct Exl2List {
     int n = 0, M = 1, max_k = 0;
     bool narrow = true;  // no entry has 8 / 6 / 5-bit rows: the leaner kernel instance
+    bool direct = false; // M == 1 and every entry has regular groups: nothing staged (exl2_gemv2_body, DMODE 1 / 2)
+    bool xp = false;     // DMODE 2: x permuted once per forward by exl2_list_permute_kernel
+    bool any_perm = false;
     unsigned grid = 0;
     size_t lds = 0;
     Exl2Call* d_ent = nullptr;
@@ -1075,7 +1352,9 @@ size_t exl2_list_device_bytes(int n, const bie_exl2_list_entry* e, int M) {
     exl2_list_plan(n, e, cps, S, &blocks, &gran, &lds, M);
     long tiles = 0;
     for (int i = 0; i < n; i++) tiles += cdiv(e[i].N, 64);
-    return align256((size_t)n * sizeof(Exl2Call)) + align256((size_t)blocks * 8) + align256((size_t)tiles * 4) + align256(gran);
+    size_t xp = 0;
+    for (int i = 0; i < n; i++) xp += align256((size_t)e[i].K * 2);
+    return align256((size_t)n * sizeof(Exl2Call)) + align256((size_t)blocks * 8) + align256((size_t)tiles * 4) + align256(gran) + xp;
 }
 
 int exl2_list_create(Exl2List** out, int n, const bie_exl2_list_entry* e, int M, void* device_mem, size_t device_bytes) {
@@ -1089,6 +1368,8 @@ int exl2_list_create(Exl2List** out, int n, const bie_exl2_list_entry* e, int M,
             prev = e[i].rows7[b];
         }
         BIE_REQUIRE(e[i].rows7[5] == e[i].K, BIE_ERR_INVALID_ARG, "bie_mbwq_exl2_list_create: entry %d: rows[5]=%d must equal K=%d", i, e[i].rows7[5], e[i].K);
+        BIE_REQUIRE((e[i].rows7[6] & BIE_EXL2_ROWS_SHUFFLED) && e[i].rows7[BIE_EXL2_ROWS_LEN - 1] == BIE_EXL2_ROWS_TAG, BIE_ERR_INVALID_ARG,
+                    "bie_mbwq_exl2_list_create: entry %d: the band table is not the one bie_mbwq_exl2_shuffle wrote (qweight must pass through it once)", i);
     }
     BIE_REQUIRE((reinterpret_cast<uintptr_t>(device_mem) & 255) == 0, BIE_ERR_INVALID_ARG, "bie_mbwq_exl2_list_create: the device buffer must be 256-byte aligned");
     std::vector<int> cps, S;
@@ -1098,13 +1379,16 @@ int exl2_list_create(Exl2List** out, int n, const bie_exl2_list_entry* e, int M,
     for (int i = 0; i < n; i++) tiles += cdiv(e[i].N, 64);
     const size_t o_blk = align256((size_t)n * sizeof(Exl2Call)), o_gen = o_blk + align256((size_t)blocks * 8), o_gran = o_gen + align256((size_t)tiles * 4);
     const size_t o_xp = o_gran + align256(gran);
-    BIE_REQUIRE(device_bytes >= o_xp, BIE_ERR_WORKSPACE, "bie_mbwq_exl2_list_create: device buffer of %zu bytes required, got %zu", o_xp, device_bytes);
+    size_t xp_bytes = 0;
+    for (int i = 0; i < n; i++) xp_bytes += align256((size_t)e[i].K * 2);
+    BIE_REQUIRE(device_bytes >= o_xp + xp_bytes, BIE_ERR_WORKSPACE, "bie_mbwq_exl2_list_create: device buffer of %zu bytes required, got %zu", o_xp + xp_bytes, device_bytes);
     char* base = static_cast<char*>(device_mem);
     std::vector<Exl2Call> he(n);
     std::vector<uint2_t> hb((size_t)blocks);
-    size_t b = 0, go = o_gran;
+    size_t b = 0, go = o_gran, xo = o_xp;
     long t0 = 0;
     int max_k = 0;
+    bool any_perm = false;
     for (int i = 0; i < n; i++) {
         Exl2Call& c = he[i];
         const int cb = cdiv(e[i].N, 64);
@@ -1116,6 +1400,10 @@ int exl2_list_create(Exl2List** out, int n, const bie_exl2_list_entry* e, int M,
         if (S[i] > 1) go += (size_t)(S[i] - 1) * M * cb * 64 * 8;
         c.gen = reinterpret_cast<unsigned*>(base + o_gen) + t0;
         for (int k = 0; k < 6; k++) c.rows.r[k] = e[i].rows7[k];
+        exl2_fill_groups(c, e[i].rows7);
+        c.xp = c.perm ? reinterpret_cast<const uint16_t*>(base + xo) : c.x;
+        xo += align256((size_t)e[i].K * 2);
+        if (c.perm) any_perm = true;
         c.M = M; c.K = e[i].K; c.N = e[i].N; c.chunks_per_slab = cps[i]; c.S = S[i]; c.colblocks = cb;
         BIE_REQUIRE(S[i] < 4096, BIE_ERR_UNSUPPORTED, "bie_mbwq_exl2_list_create: entry %d needs %d K slabs (< 4096)", i, S[i]);
         for (int sl = 0; sl < S[i]; sl++)
@@ -1128,8 +1416,16 @@ int exl2_list_create(Exl2List** out, int n, const bie_exl2_list_entry* e, int M,
     BIE_REQUIRE(err == hipSuccess, BIE_ERR_HIP, "bie_mbwq_exl2_list_create: uploading the plan: %s", hipGetErrorString(err));
     Exl2List* pl = new Exl2List();
     pl->n = n; pl->M = M; pl->grid = (unsigned)blocks; pl->lds = lds; pl->max_k = max_k;
-    for (int i = 0; i < n; i++)
+    pl->direct = M == 1 && exl2_direct_on();
+    pl->any_perm = any_perm;
+    for (int i = 0; i < n; i++) {
         if (e[i].rows7[2] != 0) pl->narrow = false;
+        if (!(e[i].rows7[6] & BIE_EXL2_ROWS_REGULAR)) pl->direct = false;
+    }
+    static const bool xp_on = [] { const char* ev = getenv("BIE_EXL2_XP"); return !ev || atoi(ev) != 0; }();
+    pl->xp = pl->direct && xp_on;
+    for (int i = 0; i < n; i++)
+        if (!e[i].q_perm && (reinterpret_cast<uintptr_t>(e[i].x) & 63) != 0) pl->xp = false;  // such an entry reads x itself through s_load_dwordx16
     pl->d_ent = reinterpret_cast<Exl2Call*>(base);
     pl->d_blk = reinterpret_cast<uint2_t*>(base + o_blk);
     *out = pl;
@@ -1144,13 +1440,18 @@ int exl2_list_forward(Exl2List* p, hipStream_t st) {
     int spin;
     test_forge_get(&skew, &spin);
     const unsigned epoch = next_launch_epoch();
-#define LL(MTV)                                                                                                                                  \
+#define LL(MTV, DIR)                                                                                                                                  \
     do {                                                                                                                                         \
-        if (p->narrow) hipLaunchKernelGGL((exl2_list_kernel<MTV, true>), dim3(p->grid), dim3(512), p->lds, st, p->d_ent, p->d_blk, epoch, device_status_word(), skew, spin); \
-        else hipLaunchKernelGGL((exl2_list_kernel<MTV, false>), dim3(p->grid), dim3(512), p->lds, st, p->d_ent, p->d_blk, epoch, device_status_word(), skew, spin);      \
+        if (p->narrow) hipLaunchKernelGGL((exl2_list_kernel<MTV, true, DIR>), dim3(p->grid), dim3(512), p->lds, st, p->d_ent, p->d_blk, epoch, device_status_word(), skew, spin); \
+        else hipLaunchKernelGGL((exl2_list_kernel<MTV, false, DIR>), dim3(p->grid), dim3(512), p->lds, st, p->d_ent, p->d_blk, epoch, device_status_word(), skew, spin);      \
     } while (0)
-    if (p->M == 1) LL(1);
-    else LL(2);
+    if (p->xp && p->any_perm) {
+        hipLaunchKernelGGL(exl2_list_permute_kernel, dim3(cdiv(p->max_k, 256), p->n), dim3(256), 0, st, p->d_ent);
+        rc = check_launch("exl2_list_permute_kernel");
+        if (rc) return rc;
+    }
+    if (p->M == 1) { if (p->xp) LL(1, 2); else if (p->direct) LL(1, 1); else LL(1, 0); }
+    else LL(2, 0);
 #undef LL
     return check_launch("exl2_list_kernel");
 }

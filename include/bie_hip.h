@@ -177,6 +177,27 @@ int bie_gather_cols(const void* x, const int32_t* perm, void* out, int M, int K,
  * (mbwq_linear_cuda_kernel.cu:559-600; its shuffle kernel is a no-op, exl2/config.h:16-21). */
 int bie_mbwq_rows(const int16_t* q_groups_host, int groups, int K, int* rows7_host);
 
+/* The load-time step of the mixed-bit layout: re-arranges qweight IN PLACE (device tensor, [rows_packed, N]) from the
+ * checkpoint's LSB-first chunk streams into the layout every bie_mbwq_exl2_* kernel reads, and writes the EXTENDED band table
+ * rows_host[BIE_EXL2_ROWS_LEN] (HOST) that those calls take.  This is the reference's shuffle hook: shuffle_kernel
+ * (mbwq_linear_cuda_kernel.cu:63-86), launched by q_linear_cuda.mbwq_trans_qweight (:602-625) on the tensor it returns; the
+ * reference's build leaves its shuffle functions empty (exl2/config.h:16-21), this library uses the hook for a layout made for
+ * v_and_or_b32 + packed fp16 ("half-pair" layout): 32 values of a chunk = 16 pairs (q[2j], q[2j+1]), a pair
+ * sits at the same bit range of the low and of the high half of one word.  Call it ONCE per tensor; a second call scrambles it
+ * (as a second shuffle_kernel pass would).  The kernels refuse a table without the SHUFFLED mark (a plain bie_mbwq_rows table).
+ *   rows_host[0..5]   cumulative k ends of the 8/6/5/4/3/2-bit bands, [6] kernel_p | BIE_EXL2_ROWS_SHUFFLED | BIE_EXL2_ROWS_REGULAR
+ *   rows_host[7..12]  first group of each band, [13..18] log2(chunks per group) of each band -- valid with REGULAR: every band's
+ *                     groups hold the same power-of-two number of whole 32-k chunks (the last one may be shorter); decode then
+ *                     needs no staged group map (exl2_gemv2_body<DIRECT>)
+ *   rows_host[19]     BIE_EXL2_ROWS_TAG */
+#define BIE_EXL2_ROWS_LEN 20
+#define BIE_EXL2_ROWS_SHUFFLED 0x100
+#define BIE_EXL2_ROWS_REGULAR 0x200
+#define BIE_EXL2_ROWS_GFIRST 7
+#define BIE_EXL2_ROWS_GLOG 13
+#define BIE_EXL2_ROWS_TAG 0x45584c32
+int bie_mbwq_exl2_shuffle(int32_t* qweight, const int16_t* q_groups_host, int groups, int K, int N, int* rows_host, void* stream);
+
 /* out[K, N] fp16: W[q_perm ? q_perm[k] : k][n] = fma(s, q, -z).  Replaces
  * q_linear_cuda.mbwq_q42fp_weight (mbwq_linear_cuda_kernel.cu:656-710, kernels :314-501). */
 int bie_mbwq_q4_dequant(const int32_t* qweight, const void* scales, const void* zeros,
@@ -186,7 +207,7 @@ int bie_mbwq_q4_dequant(const int32_t* qweight, const void* scales, const void* 
 /* out[K, N] fp16 for the mixed-bit layout, addressed exactly like the reference kernels do:
  * q_group_map is the DEVICE int16[2K] array of (group, rows-left-in-group) pairs built by
  * make_group_map (layers/qlinear/nbit/cuda/utils.py:150-187); rows7_host the HOST band table of
- * bie_mbwq_rows.  Replaces q_linear_cuda.mbwq_exl2fp_weight
+ * bie_mbwq_exl2_shuffle (BIE_EXL2_ROWS_LEN ints; qweight as that call left it).  Replaces q_linear_cuda.mbwq_exl2fp_weight
  * (mbwq_linear_cuda_kernel.cu:849-897, kernel :92-308). */
 int bie_mbwq_exl2_dequant(const int32_t* qweight, const void* scales, const void* zeros,
                           const int16_t* q_perm, const int16_t* q_group_map, const int* rows7_host,
@@ -218,12 +239,12 @@ int bie_mbwq_exl2_forward(const void* x, const int32_t* qweight, const void* sca
 typedef struct bie_exl2_list bie_exl2_list_t;
 typedef struct {
     const void* x;              /* [M, K] fp16 */
-    const int32_t* qweight;     /* [rows_packed, N] */
+    const int32_t* qweight;     /* [rows_packed, N], after bie_mbwq_exl2_shuffle */
     const void* scales;         /* [groups, N] fp16 */
     const void* zeros;          /* [groups, N] fp16 */
     const int16_t* q_perm;      /* [K] or NULL */
     const int16_t* q_group_map; /* [2K] device */
-    const int* rows7;           /* HOST band table of bie_mbwq_rows (read during create) */
+    const int* rows7;           /* HOST band table of bie_mbwq_exl2_shuffle, BIE_EXL2_ROWS_LEN ints (read during create) */
     void* y;                    /* [M, N] fp16 */
     int K, N;
     int reserved0, reserved1;   /* 0 */

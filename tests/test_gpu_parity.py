@@ -357,6 +357,18 @@ def test_mbwq_q4_forward_through_the_dense_form(bits, monkeypatch):
     assert_close(ys["2"], ys["0"], orc.F16, "dense vs fused")
 
 
+def exl2_load(qw_cpu, q_groups, K, groups):
+    """The load-time step (q_linear_cuda.mbwq_trans_qweight: in-place re-arrangement + band table) on a DEVICE COPY; the raw
+    checkpoint-order tensor stays with the caller for the oracle.  The table's first seven ints are the reference's."""
+    from bitorch_engine.extensions import q_linear_cuda
+    qd = qw_cpu.to(DEV).clone()
+    same, rows = q_linear_cuda.mbwq_trans_qweight(qd, q_groups, True, K, groups, 4)
+    ref = orc.exl2_rows(q_groups.numpy(), K)
+    assert same is qd and len(rows) == q_linear_cuda.EXL2_ROWS_LEN
+    assert rows[:6] == ref[:6] and (rows[6] & 0xff) == ref[6] and (rows[6] & 0x100)
+    return qd, rows
+
+
 @pytest.mark.parametrize("cfg", ["q_proj", "k_proj", "w3w2", "all6"])
 @pytest.mark.parametrize("M", [1, 2, 3, 7, 11, 16, 17, 33, 48, 64, 70])  # 3..48: matrix-pipe kernel (1-3 row blocks); > EXL2_GEMV_MAX_M (48): reconstruct + library GEMM
 def test_mbwq_exl2_dequant_and_forward(cfg, M):
@@ -374,13 +386,12 @@ def test_mbwq_exl2_dequant_and_forward(cfg, M):
     q_perm = torch.randperm(K, generator=gen).to(torch.short)
     gmap = make_group_map(q_groups, rows_packed)
     assert np.array_equal(gmap.numpy(), g[cfg + "_group_map"]), "make_group_map differs from the reference"
-    _, rows = q_linear_cuda.mbwq_trans_qweight(qw, q_groups, True, K, groups, 4)
-    assert rows == orc.exl2_rows(q_groups.numpy(), K)
-    Wd = q_linear_cuda.mbwq_exl2fp_weight(qw.to(DEV), scales.to(DEV), zeros.to(DEV), q_perm.to(DEV), gmap.to(DEV), rows)
+    qs, rows = exl2_load(qw, q_groups, K, groups)
+    Wd = q_linear_cuda.mbwq_exl2fp_weight(qs, scales.to(DEV), zeros.to(DEV), q_perm.to(DEV), gmap.to(DEV), rows)
     Wo = orc.exl2_dequant(qw.numpy(), orc.torch_to_np(scales), orc.torch_to_np(zeros), q_perm.numpy(), q_groups.numpy(), K)
     assert np.array_equal(orc.torch_to_np(Wd), Wo), f"exl2 dequant ({cfg}) not bit-exact"
     x = torch.randn((M, K), generator=gen).half()
-    y = q_linear_cuda.mbwq_exl2_forward(x.to(DEV), qw.to(DEV), scales.to(DEV), zeros.to(DEV), q_perm.to(DEV), gmap.to(DEV), rows, False)
+    y = q_linear_cuda.mbwq_exl2_forward(x.to(DEV), qs, scales.to(DEV), zeros.to(DEV), q_perm.to(DEV), gmap.to(DEV), rows, False)
     ref = t16(orc.gemm(orc.torch_to_np(x), Wo, orc.F16), orc.F16)
     assert_close(y, ref, orc.F16, f"exl2 {cfg} M={M}")
     if M in (16, 64):
@@ -390,12 +401,12 @@ def test_mbwq_exl2_dequant_and_forward(cfg, M):
         saved = q_linear_cuda.EXL2_GEMV_MAX_M
         q_linear_cuda.EXL2_GEMV_MAX_M = 64
         try:
-            y64 = q_linear_cuda.mbwq_exl2_forward(x.to(DEV), qw.to(DEV), scales.to(DEV), zeros.to(DEV), q_perm.to(DEV), gmap.to(DEV), rows, False)
+            y64 = q_linear_cuda.mbwq_exl2_forward(x.to(DEV), qs, scales.to(DEV), zeros.to(DEV), q_perm.to(DEV), gmap.to(DEV), rows, False)
         finally:
             q_linear_cuda.EXL2_GEMV_MAX_M = saved
         assert_close(y64, ref, orc.F16, f"exl2 {cfg} M={M} fused")
         L = _hip.lib()
-        xd, qd, sd, zd, gd = x.to(DEV), qw.to(DEV), scales.to(DEV), zeros.to(DEV), gmap.to(DEV)
+        xd, qd, sd, zd, gd = x.to(DEV), qs, scales.to(DEV), zeros.to(DEV), gmap.to(DEV)
         yn = torch.empty((M, N), dtype=torch.float16, device=DEV)
         ws = _hip.workspace(L.bie_mbwq_workspace_bytes(M, K, N), DEV)
         keep, rp = q_linear_cuda._rows_arg(rows)
@@ -404,6 +415,128 @@ def test_mbwq_exl2_dequant_and_forward(cfg, M):
         assert rc == 0
         Wn = orc.exl2_dequant(qw.numpy(), orc.torch_to_np(scales), orc.torch_to_np(zeros), None, q_groups.numpy(), K)
         assert_close(yn, t16(orc.gemm(orc.torch_to_np(x), Wn, orc.F16), orc.F16), orc.F16, f"exl2 {cfg} M={M} no q_perm")
+
+
+def exl2_half_pair_words(q, bits):
+    """The half-pair layout as DESIGN.md section 3 states it, in numpy: q [32, N] values of one chunk -> [bits, N] words.
+    F = 16 // bits whole fields per 16-bit half; pair j = (q[2j], q[2j+1]) for j < bits * F sits at bit (j % F) * bits of the low /
+    high half of word j // F; the remaining pairs fill, LSB first, the stream made of the R = 16 - F * bits spare top bits of the
+    halves of words 0, 1, ..."""
+    F = 16 // bits
+    R = 16 - F * bits
+    w = np.zeros((bits, q.shape[1]), dtype=np.uint64)
+    for j in range(16):
+        lo, hi = q[2 * j].astype(np.uint64), q[2 * j + 1].astype(np.uint64)
+        if j < bits * F:
+            p = (j % F) * bits
+            w[j // F] |= (lo << np.uint64(p)) | (hi << np.uint64(16 + p))
+        else:
+            for t in range(bits):
+                bit = (j - bits * F) * bits + t
+                d, off = bit // R, F * bits + bit % R
+                w[d] |= (((lo >> np.uint64(t)) & np.uint64(1)) << np.uint64(off)) | (((hi >> np.uint64(t)) & np.uint64(1)) << np.uint64(16 + off))
+    return w.astype(np.uint32)
+
+
+def test_exl2_load_time_layout_is_the_documented_one_and_the_kernels_refuse_an_unmarked_table():
+    """bie_mbwq_exl2_shuffle (behind q_linear_cuda.mbwq_trans_qweight, the reference's shuffle hook mbwq_linear_cuda_kernel.cu:63-86):
+    every chunk of every band (8/6/5/4/3/2 bit) re-arranged exactly as the layout is specified; a second pass on the same tensor
+    and a plain bie_mbwq_rows table are refused."""
+    import ctypes
+    from bitorch_engine import _hip
+    from bitorch_engine.extensions import q_linear_cuda
+    g = np.load(os.path.join(GOLDEN, "exl2_group_maps.npz"))
+    K, groups, rows_packed = [int(v) for v in g["all6_meta"]]
+    q_groups = torch.from_numpy(g["all6_q_groups"])
+    N = 200
+    rng = np.random.default_rng(11)
+    qw = torch.from_numpy(rng.integers(-2 ** 31, 2 ** 31 - 1, (rows_packed, N), dtype=np.int64).astype(np.int32))
+    qs, rows = exl2_load(qw, q_groups, K, groups)
+    raw = qw.numpy().view(np.uint32).astype(np.uint64)
+    want = np.zeros((rows_packed, N), dtype=np.uint32)
+    row, kprev = 0, 0
+    for b, bits in enumerate((8, 6, 5, 4, 3, 2)):
+        for _ in range((rows[b] - kprev) // 32):
+            stream = np.zeros(N, dtype=object)
+            for i in range(bits):
+                stream = stream + (raw[row + i].astype(object) << (32 * i))
+            q = np.stack([np.array([(int(v) >> (bits * j)) & ((1 << bits) - 1) for v in stream], dtype=np.uint32) for j in range(32)])
+            want[row:row + bits] = exl2_half_pair_words(q, bits)
+            row += bits
+        kprev = rows[b]
+    assert row == rows_packed
+    assert np.array_equal(qs.cpu().numpy().view(np.uint32), want), "the re-arranged tensor is not the documented half-pair layout"
+    with pytest.raises(RuntimeError, match="already been re-arranged"):
+        q_linear_cuda.mbwq_trans_qweight(qs, q_groups, True, K, groups, 4)
+    # a table that did not come from the load-time step: refused by every entry point, nothing launched
+    L = _hip.lib()
+    plain = (ctypes.c_int * 20)()
+    qg = q_groups.numpy().astype(np.int16)
+    assert L.bie_mbwq_rows(qg.ctypes.data, groups, K, ctypes.cast(plain, ctypes.c_void_p)) == 0
+    out = torch.empty((K, N), dtype=torch.float16, device=DEV)
+    dev = lambda a: torch.from_numpy(a).to(DEV)
+    sc, gm = torch.ones((groups, N), dtype=torch.float16, device=DEV), dev(g["all6_group_map"])
+    rc = L.bie_mbwq_exl2_dequant(_hip.ptr(qs), _hip.ptr(sc), _hip.ptr(sc), None, _hip.ptr(gm), ctypes.cast(plain, ctypes.c_void_p), _hip.ptr(out), K, N, groups, None)
+    assert rc == -1 and "SHUFFLED" in L.bie_last_error().decode()
+    with pytest.raises(RuntimeError, match="20-int table"):
+        q_linear_cuda.mbwq_exl2fp_weight(qs, sc, sc, torch.arange(K).short().to(DEV), gm, list(plain)[:7])
+
+
+@pytest.mark.parametrize("name", ["g64_g128_ragged", "one_group_per_band", "mixed_sizes", "g16", "g96"])
+def test_exl2_group_structures_direct_and_staged_decode(name):
+    """The decode kernel has two forms: DIRECT (regular groups -- every band's groups hold the same power-of-two number of whole
+    chunks, a shorter last group allowed: group index by shift on the band table, nothing staged) and the staged form (anything
+    else, and M = 2).  Both against the oracle on group structures of either kind; the REGULAR mark of the table says which ran."""
+    from bitorch_engine.extensions import q_linear_cuda
+    from bitorch_engine.layers.qlinear.nbit.cuda import MBWQExl2ForwardList
+    from bitorch_engine.layers.qlinear.nbit.cuda.utils import make_group_map
+    structures = {  # (bits, k per group) in band order 8 > 6 > 5 > 4 > 3 > 2
+        "g64_g128_ragged": ([(4, 64)] * 3 + [(4, 32)] + [(3, 128)] * 2 + [(3, 96)] + [(2, 64)] * 4, True),
+        "one_group_per_band": ([(6, 96), (4, 160), (2, 224)], True),
+        "mixed_sizes": ([(4, 32), (4, 64), (4, 32)] + [(2, 64)] * 4, False),
+        "g16": ([(4, 16)] * 8 + [(2, 16)] * 12, False),
+        "g96": ([(4, 96)] * 3 + [(2, 32)] * 4, False),
+    }
+    spec, regular = structures[name]
+    qg, row, K = [], 0, 0
+    for bits, k in spec:
+        qg += [bits, row]
+        row += k * bits // 32
+        K += k
+    assert K % 32 == 0
+    groups = len(spec)
+    q_groups = torch.tensor(qg, dtype=torch.short)
+    N = 328
+    rng = np.random.default_rng(K + groups)
+    gen = torch.Generator().manual_seed(K + groups)
+    qw = torch.from_numpy(rng.integers(-2 ** 31, 2 ** 31 - 1, (row, N), dtype=np.int64).astype(np.int32))
+    scales = (torch.rand((groups, N), generator=gen) * 0.02 + 0.001).half()
+    zeros = (torch.randn((groups, N), generator=gen) * 0.1).half()
+    q_perm = torch.randperm(K, generator=gen).to(torch.short)
+    gmap = make_group_map(q_groups, row)
+    qs, rows = exl2_load(qw, q_groups, K, groups)
+    assert bool(rows[6] & 0x200) == regular, f"{name}: REGULAR mark {rows[6]:#x}"
+    d = lambda t: t.to(DEV)
+    Wd = q_linear_cuda.mbwq_exl2fp_weight(qs, d(scales), d(zeros), d(q_perm), d(gmap), rows)
+    Wo = orc.exl2_dequant(qw.numpy(), orc.torch_to_np(scales), orc.torch_to_np(zeros), q_perm.numpy(), q_groups.numpy(), K)
+    assert np.array_equal(orc.torch_to_np(Wd), Wo), f"exl2 dequant ({name}) not bit-exact"
+    for M in (1, 2, 5):
+        x = torch.randn((M, K), generator=gen).half()
+        ref = t16(orc.gemm(orc.torch_to_np(x), Wo, orc.F16), orc.F16)
+        y = q_linear_cuda.mbwq_exl2_forward(d(x), qs, d(scales), d(zeros), d(q_perm), d(gmap), rows, False)
+        assert_close(y, ref, orc.F16, f"exl2 {name} M={M}")
+        if M <= 2:
+            ent = [{"x": d(x), "qweight": qs, "scales": d(scales), "zeros": d(zeros), "q_perm": d(q_perm), "q_group_map": d(gmap), "rows": rows,
+                    "y": torch.full((M, N), float("nan"), dtype=torch.float16, device=DEV)}]
+            MBWQExl2ForwardList(ent)()
+            assert_close(ent[0]["y"], ref, orc.F16, f"exl2 {name} M={M} list")
+    # no q_perm: the direct form keeps its index load and ignores the value
+    x = torch.randn((1, K), generator=gen).half()
+    Wn = orc.exl2_dequant(qw.numpy(), orc.torch_to_np(scales), orc.torch_to_np(zeros), None, q_groups.numpy(), K)
+    ent = [{"x": d(x), "qweight": qs, "scales": d(scales), "zeros": d(zeros), "q_perm": None, "q_group_map": d(gmap), "rows": rows,
+            "y": torch.full((1, N), float("nan"), dtype=torch.float16, device=DEV)}]
+    MBWQExl2ForwardList(ent)()
+    assert_close(ent[0]["y"], t16(orc.gemm(orc.torch_to_np(x), Wn, orc.F16), orc.F16), orc.F16, f"exl2 {name} list, no q_perm")
 
 
 def test_mbwq_layer_llama_shapes_w3w2_decode():
@@ -801,9 +934,9 @@ def test_exl2_decode_long_k_uses_several_slabs():
     scales = (torch.rand((groups, N), generator=gen) * 0.02 + 0.001).half()
     zeros = (torch.randn((groups, N), generator=gen) * 0.1).half()
     q_perm = torch.randperm(K, generator=gen).to(torch.short)
-    _, rows = q_linear_cuda.mbwq_trans_qweight(qw, q_groups, True, K, groups, 4)
+    qs, rows = exl2_load(qw, q_groups, K, groups)
     x = torch.randn((1, K), generator=gen).half()
-    y = q_linear_cuda.mbwq_exl2_forward(x.to(DEV), qw.to(DEV), scales.to(DEV), zeros.to(DEV), q_perm.to(DEV), gmap.to(DEV), rows, False)
+    y = q_linear_cuda.mbwq_exl2_forward(x.to(DEV), qs, scales.to(DEV), zeros.to(DEV), q_perm.to(DEV), gmap.to(DEV), rows, False)
     cols = np.arange(0, N, 257)
     Wo = orc.exl2_dequant(np.ascontiguousarray(qw.numpy()[:, cols]), orc.torch_to_np(scales[:, cols].contiguous()),
                           orc.torch_to_np(zeros[:, cols].contiguous()), q_perm.numpy(), q_groups.numpy(), K)
@@ -1269,14 +1402,14 @@ def test_full_size_exl2_w3w2_random_perm(K, N):
     zeros = (torch.randn((groups, N), generator=gen) * 0.05).half()
     q_perm = torch.randperm(K, generator=gen).to(torch.short)
     gmap = make_group_map(q_groups, row)
-    _, rows = q_linear_cuda.mbwq_trans_qweight(qw, q_groups, True, K, groups, 4)
+    qs, rows = exl2_load(qw, q_groups, K, groups)
     d = lambda t: t.to(DEV)
-    Wd = q_linear_cuda.mbwq_exl2fp_weight(d(qw), d(scales), d(zeros), d(q_perm), d(gmap), rows)
+    Wd = q_linear_cuda.mbwq_exl2fp_weight(qs, d(scales), d(zeros), d(q_perm), d(gmap), rows)
     Wo = orc.exl2_dequant(qw.numpy(), orc.torch_to_np(scales), orc.torch_to_np(zeros), q_perm.numpy(), q_groups.numpy(), K)
     assert np.array_equal(orc.torch_to_np(Wd), Wo), "exl2 dequant at full size not bit-exact"
     for M in (1, 2, 5, 16, 48, 64):
         x = torch.randn((M, K), generator=gen).half()
-        y = q_linear_cuda.mbwq_exl2_forward(d(x), d(qw), d(scales), d(zeros), d(q_perm), d(gmap), rows, False)
+        y = q_linear_cuda.mbwq_exl2_forward(d(x), qs, d(scales), d(zeros), d(q_perm), d(gmap), rows, False)
         ref = t16(orc.gemm(orc.torch_to_np(x), Wo, orc.F16), orc.F16)
         assert_close(y, ref, orc.F16, f"exl2 w3/w2 {K}x{N} M={M}")
 
@@ -1845,11 +1978,11 @@ def test_exl2_list_forward_equals_the_per_layer_calls(M):
         zeros = (torch.randn((groups, N), generator=gen) * 0.1).half()
         q_perm = torch.randperm(K, generator=gen).to(torch.short) if i % 3 != 2 else None
         gmap = make_group_map(q_groups, rows_packed)
-        _, rows = q_linear_cuda.mbwq_trans_qweight(qw, q_groups, True, K, groups, 4)
+        qs, rows = exl2_load(qw, q_groups, K, groups)
         x = torch.randn((M, K), generator=gen).half()
         Wo = orc.exl2_dequant(qw.numpy(), orc.torch_to_np(scales), orc.torch_to_np(zeros), None if q_perm is None else q_perm.numpy(), q_groups.numpy(), K)
         refs.append(t16(orc.gemm(orc.torch_to_np(x), Wo, orc.F16), orc.F16))
-        entries.append({"x": x.to(DEV), "qweight": qw.to(DEV), "scales": scales.to(DEV), "zeros": zeros.to(DEV),
+        entries.append({"x": x.to(DEV), "qweight": qs, "scales": scales.to(DEV), "zeros": zeros.to(DEV),
                         "q_perm": None if q_perm is None else q_perm.to(DEV), "q_group_map": gmap.to(DEV), "rows": rows,
                         "y": torch.full((M, N), float("nan"), dtype=torch.float16, device=DEV)})
     plan = MBWQExl2ForwardList(entries)

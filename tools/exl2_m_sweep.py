@@ -22,7 +22,7 @@ for _ in range(6):
     sc = (torch.rand((groups, N), device=dev) * 0.02 + 0.001).half()
     ze = (torch.randn((groups, N), device=dev) * 0.05).half()
     sets.append((qw, sc, ze))
-_, rows = q_linear_cuda.mbwq_trans_qweight(sets[0][0], q_groups, True, K, groups, 4)
+rows = [q_linear_cuda.mbwq_trans_qweight(s_[0], q_groups, True, K, groups, 4)[1] for s_ in sets][0]  # the load-time step, every tensor
 res = {}
 for M in (1, 2, 3, 4, 8, 16, 32, 33, 64):
     x = torch.randn((M, K), device=dev).half()

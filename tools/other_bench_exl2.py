@@ -52,7 +52,7 @@ for (K, N) in ((4096, 11008), (4096, 4096), (11008, 4096)):
         sc = (torch.rand((groups, N), generator=gen) * 0.02 + 0.001).half().to(dev)
         ze = (torch.randn((groups, N), generator=gen) * 0.05).half().to(dev)
         sets.append((qw, sc, ze))
-    _, rows = q_linear_cuda.mbwq_trans_qweight(sets[0][0], q_groups, True, K, groups, 4)
+    rows = [q_linear_cuda.mbwq_trans_qweight(s_[0], q_groups, True, K, groups, 4)[1] for s_ in sets][0]  # the load-time step, every tensor
     for M in (1, 4):
         x = torch.randn((M, K), generator=gen).half().to(dev)
         us = timeit(lambda s_: q_linear_cuda.mbwq_exl2_forward(x, s_[0], s_[1], s_[2], perm, gmap, rows, False), sets)
