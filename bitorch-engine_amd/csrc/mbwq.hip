@@ -220,6 +220,50 @@ __device__ __forceinline__ void exl2_qpairs16(const uint32_t (&w)[8], const Exl2
     });
 }
 
+// (v & mask) | offset for an operand of the MATRIX pipe: written so that the compiler selects v_bfi_b32 ITSELF (the offset word has no bit
+// inside the mask, so (mask & v) | (~mask & offset) is the same value).  The inline-asm v_and_or_b32 above must not feed an MFMA: a
+// vector write needs 2 wait states before the matrix instruction reads the register (tools/probe/probe_mfma4.hip: raw_src_a / _b), the
+// hazard recognizer inserts them for instructions it can see and cannot look into an asm block -- wrong sums, now and then, by schedule.
+__device__ __forceinline__ uint32_t exl2_bfi(uint32_t v, uint32_t mask, uint32_t ofs) { return (v & mask) | (ofs & ~mask); }
+
+// The decode kernels stop one step earlier: T[j] = the fp16 pair (2^(10-lp) + q[2j], 2^(10-lp) + q[2j+1]) as v_and_or_b32 leaves it, and
+// ofs[j] = the offset pair (2^(10-lp), 2^(10-lp)) it carries (the same for every chunk of a band).  They take the dot products of T
+// and of ofs with x on the matrix pipe and subtract there (exl2_gemv2_body).
+template <int BITS>
+__device__ __forceinline__ void exl2_tpairs16(const uint32_t (&w)[8], const Exl2Magic& mg, uint32_t (&T)[16]) {
+    using L = Exl2Lay<BITS>;
+    constexpr uint32_t mask = (1u << BITS) - 1u;
+    exl2_static_for<0, 16>([&](auto j) {
+        constexpr int J = decltype(j)::value;
+        if constexpr (J < L::MAIN) {
+            constexpr int d = J / L::F, p = (J % L::F) * BITS;
+            constexpr int b0 = L::win(p), lp = p - b0;
+            const uint32_t v = b0 ? (w[d] >> b0) : w[d];
+            T[J] = exl2_bfi(v, (mask << lp) * 0x00010001u, mg.m[lp]);
+        } else {
+            uint32_t acc = mg.m[0];
+            exl2_static_for<0, BITS>([&](auto t) {
+                constexpr Exl2Piece pc = L::piece(J - L::MAIN, decltype(t)::value);
+                if constexpr (pc.len > 0) acc = exl2_bfi(w[pc.d] >> (pc.src - pc.dst), (((1u << pc.len) - 1u) << pc.dst) * 0x00010001u, acc);
+            });
+            T[J] = acc;
+        }
+    });
+}
+template <int BITS>
+__device__ __forceinline__ void exl2_offset_pairs16(const Exl2Magic& mg, uint32_t (&ofs)[16]) {
+    using L = Exl2Lay<BITS>;
+    exl2_static_for<0, 16>([&](auto j) {
+        constexpr int J = decltype(j)::value;
+        if constexpr (J < L::MAIN) {
+            constexpr int p = (J % L::F) * BITS;
+            ofs[J] = mg.m[p - L::win(p)];
+        } else {
+            ofs[J] = mg.m[0];
+        }
+    });
+}
+
 template <int BITS>
 __device__ __forceinline__ void exl2_load_chunk(const uint32_t* __restrict__ qw, long N, int prow, int n, uint32_t (&w)[8]) {
 #pragma unroll
@@ -388,7 +432,8 @@ struct Exl2Call {  // everything one workgroup of the decode kernel needs (kerne
     Exl2Rows rows;
     int M, K, N, chunks_per_slab, S, colblocks;
     int gfirst[6], glog[6];  // DIRECT form: first group of each band and log2(chunks per group) (bie_mbwq_exl2_shuffle: regular groups)
-    const uint16_t* xp;      // list form, DMODE 2: x[q_perm] (written by exl2_list_permute_kernel in front), or x itself without a q_perm
+    const uint16_t* xp;      // list form, DMODE 2: x[q_perm] (written by exl2_list_permute_kernel in front)
+    const float2_t* cs;      // list form, DMODE 2: per chunk {sum offset_k x_k, sum x_k} (same kernel)
 };
 
 // STAGED (two x rows): the slab's activations are gathered through q_perm ONCE per workgroup into LDS.  !STAGED (one row): every wave
@@ -407,9 +452,11 @@ struct Exl2Groups {
 };
 // DMODE 2 (the list form): x arrives ALREADY permuted (xp = x[q_perm], one small launch in front for all entries of the list --
 // every column block of a layer needs the same 2 K bytes, gathering them per workgroup is 64-172 times redundant and a 32-lane
-// gather touches up to 32 cache lines).  A chunk's 32 activations are then 64 contiguous bytes: one s_load_dwordx16, the pairs go
-// into v_dot2c_f32_f16 as scalar operands -- no index loads, no gather, no LDS in the loop.
-typedef uint32_t exl2_u32x16 __attribute__((ext_vector_type(16)));
+// gather touches up to 32 cache lines).  The workgroup copies its slab of xp into LDS (contiguous 16-byte pieces, one round trip,
+// no dependent index load) and the chunks read it from there: no index loads and no gather in the loop.
+typedef float exl2_acc_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ exl2_acc_t exl2_mfma4(half4_t a, half4_t b, exl2_acc_t c) { return __builtin_amdgcn_mfma_f32_4x4x4f16(a, b, c, 0, 0, 0); }
 template <int MT, int EX2_NW, bool STAGED, bool NARROW, int DMODE = 0>
 __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, const uint32_t* __restrict__ qw,
                                                 const uint16_t* __restrict__ scales, const uint16_t* __restrict__ zeros,
@@ -418,7 +465,8 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
                                                 uint16_t* __restrict__ y, const Exl2Rows rows, const int M, const int K, const int N,
                                                 const int chunks_per_slab, const int S, const int colblock, const int slab_idx,
                                                 const int colblocks, unsigned epoch, unsigned* status, unsigned tag_skew, int spin_limit,
-                                                const Exl2Groups grp = Exl2Groups{}, const uint16_t* __restrict__ xp = nullptr) {
+                                                const Exl2Groups grp = Exl2Groups{}, const uint16_t* __restrict__ xp = nullptr,
+                                                const float2_t* __restrict__ cs = nullptr) {
     constexpr bool DIRECT = DMODE != 0;
     constexpr bool XP = DMODE == 2;
     static_assert(!DIRECT || (MT == 1 && !STAGED), "the direct forms serve one row of x");
@@ -444,7 +492,16 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
     uint16_t* xs = reinterpret_cast<uint16_t*>(smem2) + wave * (4 * MT * 32);  // !STAGED: wave-private [set 0..3][MT][32]
     uint16_t* perm_s = reinterpret_cast<uint16_t*>(smem2) + EX2_NW * (4 * MT * 32);  // !STAGED: [slab_k]
     uint16_t* gmap_s = STAGED ? x_s + MT * slab_k : perm_s + slab_k;           // [chunks_per_slab * 2]
+    float2_t* cs_s = reinterpret_cast<float2_t*>(x_s + slab_k);                // DMODE 2: [chunks_per_slab] behind the one row of x
     int two_groups = 0;  // does any chunk of the slab straddle two groups (group sizes below 32)?
+    if constexpr (XP) {
+        const int n16 = (c_end - c_begin) * 4;  // 16-byte pieces of the slab
+        const uint4_t* src = reinterpret_cast<const uint4_t*>(xp + (long)c_begin * 32);
+        uint4_t* dst = reinterpret_cast<uint4_t*>(x_s);
+        for (int i = tid; i < n16; i += EX2_NW * 64) dst[i] = src[i];
+        for (int i = tid; i < (c_end - c_begin); i += EX2_NW * 64) cs_s[i] = cs[c_begin + i];
+        __syncthreads();
+    }
     if constexpr (!DIRECT) {
         const int nk = (c_end - c_begin) * 32;
         for (int i = tid; i < nk; i += EX2_NW * 64) {
@@ -464,10 +521,14 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
         }
         two_groups = __builtin_amdgcn_readfirstlane(__syncthreads_or(two_groups));  // the slab's metadata is in LDS; workgroup-uniform flag
     }
-    float acc[MT];
+    float yacc[MT];
 #pragma unroll
-    for (int m = 0; m < MT; m++) acc[m] = 0.f;
+    for (int m = 0; m < MT; m++) yacc[m] = 0.f;
+    const int xrow = MT > 1 ? ((lane & 3) < M ? (lane & 3) : M - 1) : 0;  // the row of x this lane feeds the matrix pipe with
     const Exl2Magic magic;
+    uint2_t ones2 = uint2_t{0x3c003c00u, 0x3c003c00u};
+    asm("" : "+v"(ones2));  // matrix operands are registers
+    const half4_t ones4 = __builtin_bit_cast(half4_t, ones2);
     // Packed rows and group constants through buffer descriptors: the row / group part of every address is wave-uniform (scalar
     // offset), the column part one register per element size -- no 64-bit vector address arithmetic per load (it was 1.2 VALU per
     // weight pair).  The host admits only tensors below 4 GB (exl2_buffer_ok).
@@ -497,6 +558,8 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
         glg = __builtin_amdgcn_readfirstlane(glg);
         constexpr int BITS = decltype(bits_tag)::value;
         constexpr bool TWO = decltype(two_tag)::value;  // group constants per 16-k half (two loads more per chunk) or per chunk
+        uint32_t ofs[16];
+        exl2_offset_pairs16<BITS>(magic, ofs);
         struct Chunk {
             uint32_t w[BITS];
             uint32_t s[2], z[2];
@@ -539,16 +602,7 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
         auto compute = [&](int set, int c, const Chunk& ch) {
             const uint16_t* xw = nullptr;
             int xstride = 0;
-            uint32_t xsc[16];
-            if constexpr (XP) {  // 64 contiguous bytes through the scalar cache, requested in front of the chunk's extraction
-                typedef const __attribute__((address_space(4))) uint4_t cx4_t;
-                cx4_t* xq = (cx4_t*)(uintptr_t)(xp + (long)c * 32);
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const uint4_t v = xq[i];
-                    xsc[4 * i] = v.x; xsc[4 * i + 1] = v.y; xsc[4 * i + 2] = v.z; xsc[4 * i + 3] = v.w;
-                }
-            } else if constexpr (STAGED) {
+            if constexpr (STAGED || XP) {
                 xw = x_s + (c - c_begin) * 32;
                 xstride = slab_k;
             } else {
@@ -567,38 +621,60 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
             uint32_t w8[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) w8[i] = i < BITS ? ch.w[i] : 0u;
-            half2_t Q[16];
-            exl2_qpairs16<BITS>(w8, magic, Q);
+            uint32_t T[16];
+            exl2_tpairs16<BITS>(w8, magic, T);
+            // Everything after the field extraction runs on the MATRIX pipe.  v_mfma_f32_4x4x4_16B_f16 is sixteen independent 4x4x4
+            // products: lane l = (block l / 4, column l % 4) supplies four k of ITS OWN column as the B operand -- the lane-per-column
+            // layout of this kernel as it is -- and row l % 4 of x as the A operand, and receives D[0..3][its column]: up to four rows
+            // of x for one instruction per four k (2 passes).  Three accumulations per chunk with the same A operands:
+            //   dq = sum (offset_k + q_k) x_k   (B = the pairs as v_and_or_b32 left them: exact fp16 integers, exact products)
+            //   dc = sum  offset_k        x_k   (B = the band's offset pattern, column-independent)
+            //   dx = sum                  x_k   (B = 1.0)
+            // and the group's constants are applied ONCE per chunk in fp32:  y += s (dq - dc) - z dx  ==  sum (q s - z) x.
+            // Against the reference's per-weight fp16 rounding r = fp16(q s - z) (exl2/q_gemm_kernel.cuh:dot22_*) this differs by at
+            // most half an fp16 ulp of each weight times |x| -- below what its own fp16 accumulation loses; the reconstruction
+            // kernel keeps the exact rounding.  The vector ALU is left with the 16 v_and_or_b32 (+ shifts) per chunk: 1 / 3 of the
+            // instructions of the per-weight form, which was issue-bound (profiles/r04_exl2_list_pmc_xp.txt).
+            // Rows beyond M read row M - 1 again and are never stored.
+            const exl2_acc_t zero4 = exl2_acc_t{0.f, 0.f, 0.f, 0.f};
+            exl2_acc_t dq = zero4, dc = zero4, dx = zero4;
+            if constexpr (XP) {
+                const float2_t v = cs_s[c - c_begin];
+                dc = exl2_acc_t{v.x, v.x, v.x, v.x};
+                dx = exl2_acc_t{v.y, v.y, v.y, v.y};
+            }
+            auto apply = [&](int half) {  // the constants of the group the half (or the whole chunk) lies in
+                const float sf = (float)__builtin_bit_cast(half_t, (uint16_t)ch.s[half]);
+                const float zf = (float)__builtin_bit_cast(half_t, (uint16_t)ch.z[half]);
+#pragma unroll
+                for (int m = 0; m < MT; m++) {
+                    yacc[m] = __builtin_fmaf(sf, dq[m] - dc[m], yacc[m]);
+                    yacc[m] = __builtin_fmaf(-zf, dx[m], yacc[m]);
+                }
+            };
+            uint4_t xq[4];  // the chunk's 32 activations of this lane's row: A operands, kept like T
+#pragma unroll
+            for (int i = 0; i < 4; i++) xq[i] = reinterpret_cast<const uint4_t*>(xw + xrow * xstride)[i];
 #pragma unroll
             for (int half = 0; half < 2; half++) {
-                const half_t sh = __builtin_bit_cast(half_t, (uint16_t)ch.s[TWO ? half : 0]);
-                const half_t zh = __builtin_bit_cast(half_t, (uint16_t)ch.z[TWO ? half : 0]);
-                const half2_t s2 = half2_t{sh, sh}, nz2 = half2_t{(half_t)-zh, (half_t)-zh};
-                uint4_t xv[MT][2];
-                if constexpr (!XP) {
+                const uint4_t xa = xq[2 * half], xb = xq[2 * half + 1];
+                const uint32_t xd[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
 #pragma unroll
-                    for (int m = 0; m < MT; m++) {
-                        const uint4_t* xq4 = reinterpret_cast<const uint4_t*>(xw + m * xstride + 16 * half);
-                        xv[m][0] = xq4[0];
-                        xv[m][1] = xq4[1];
+                for (int i = 0; i < 4; i++) {
+                    const half4_t av = __builtin_bit_cast(half4_t, uint2_t{xd[2 * i], xd[2 * i + 1]});
+                    const int j = 8 * half + 2 * i;
+                    dq = exl2_mfma4(av, __builtin_bit_cast(half4_t, uint2_t{T[j], T[j + 1]}), dq);
+                    if constexpr (!XP) {  // DMODE 2 has the two column-independent sums from the kernel that permuted x
+                        dc = exl2_mfma4(av, __builtin_bit_cast(half4_t, uint2_t{ofs[j], ofs[j + 1]}), dc);
+                        dx = exl2_mfma4(av, ones4, dx);
                     }
                 }
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const half2_t r = __builtin_elementwise_fma(Q[8 * half + i], s2, nz2);  // one rounding == __hfma2(q, s, -z)
-                    if constexpr (XP) {
-                        acc[0] = __builtin_amdgcn_fdot2(r, __builtin_bit_cast(half2_t, xsc[8 * half + i]), acc[0], false);
-                        continue;
-                    }
-#pragma unroll
-                    for (int m = 0; m < MT; m++) {
-                        if (m >= M) continue;
-                        const uint4_t xq = xv[m][i >> 2];
-                        const uint32_t xpair = (i & 3) == 0 ? xq.x : ((i & 3) == 1 ? xq.y : ((i & 3) == 2 ? xq.z : xq.w));
-                        acc[m] = __builtin_amdgcn_fdot2(r, __builtin_bit_cast(half2_t, xpair), acc[m], false);
-                    }
+                if constexpr (TWO) {
+                    apply(half);
+                    dq = zero4; dc = zero4; dx = zero4;
                 }
             }
+            if constexpr (!TWO) apply(0);
         };
         // this wave's chunks in the band: c = first, first + NW, ... < cb1
         int first = c_begin + wave;
@@ -701,7 +777,7 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem2);
 #pragma unroll
-    for (int m = 0; m < MT; m++) red[(wave * MT + m) * 64 + lane] = acc[m];
+    for (int m = 0; m < MT; m++) red[(wave * MT + m) * 64 + lane] = yacc[m];
     __syncthreads();
     if (tid < 64 * MT) {
         const int om = tid >> 6, ol = tid & 63, on = colblock * 64 + ol;
@@ -755,7 +831,7 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
 
 
 template <int MT, int EX2_NW, bool NARROW, int DMODE>
-__global__ __launch_bounds__(EX2_NW * 64, (EX2_NW == 8 ? 2 : 1)) void exl2_gemv2_kernel(const Exl2Call c, unsigned epoch, unsigned* status, unsigned tag_skew,
+__global__ __launch_bounds__(EX2_NW * 64, (EX2_NW == 8 ? 4 : 1)) void exl2_gemv2_kernel(const Exl2Call c, unsigned epoch, unsigned* status, unsigned tag_skew,
                                                                                           int spin_limit) {
     Exl2Groups grp;
 #pragma unroll
@@ -783,7 +859,6 @@ __global__ __launch_bounds__(256) void exl2_permute_x_kernel(const uint16_t* __r
     for (int m = blockIdx.y; m < M; m += gridDim.y) xp[(long)m * K + k] = x[(long)m * K + kx];
 }
 
-typedef float exl2_acc_t __attribute__((ext_vector_type(4)));
 constexpr int EXL2_T_PITCH = 40;  // halves per column of the transpose buffer (80 bytes)
 
 // NARROW: no 8 / 6 / 5-bit rows in this tensor (host: rows7[2] == 0) -- the wide bands' prefetch sets (4 x 8 words) cost the 3/2-bit models
@@ -1066,19 +1141,43 @@ __device__ __forceinline__ void exl2_list_body(const Exl2Call* __restrict__ ent,
     for (int i = 0; i < 6; i++) { grp.gfirst[i] = c->gfirst[i]; grp.glog[i] = c->glog[i]; }
     exl2_gemv2_body<MT, 8, (MT > 1), NARROW, DMODE>(c->x, c->qw, c->scales, c->zeros, c->perm, c->gmap, c->gran, c->gen, c->y, rows, c->M, c->K, c->N,
                                              c->chunks_per_slab, c->S, (int)(rec.y & 0xfffffu), (int)(rec.y >> 20), c->colblocks, epoch, status,
-                                             tag_skew, spin_limit, grp, c->xp);
+                                             tag_skew, spin_limit, grp, c->xp, c->cs);
 }
 template <int MT, bool NARROW, int DMODE>
-__global__ __launch_bounds__(512, 2) void exl2_list_kernel(const Exl2Call* __restrict__ ent, const uint2_t* __restrict__ blk, unsigned epoch,
+__global__ __launch_bounds__(512, 4) void exl2_list_kernel(const Exl2Call* __restrict__ ent, const uint2_t* __restrict__ blk, unsigned epoch,
                                                            unsigned* status, unsigned tag_skew, int spin_limit) {
     exl2_list_body<MT, NARROW, DMODE>(ent, blk, epoch, status, tag_skew, spin_limit);
 }
-// xp = x[q_perm] for every entry of a list that has a q_perm (one row of x; entries without one read x in place)
+// The kernel in front of a DMODE 2 list launch, for every entry (one row of x): xp = x[q_perm] (or a copy), and per 32-k chunk the two
+// sums that do not depend on the column: cs[c] = {sum offset_k x_k, sum x_k} -- offset_k is the power of two the field of k carries
+// in the pairs the decode kernel feeds the matrix pipe (exl2_tpairs16), a property of the chunk's bit width and of k's place in it.
+__device__ __forceinline__ float exl2_offset_of(int bits, int j) {  // pair j of a chunk of `bits`-bit values (Exl2Lay<bits>)
+    const int F = 16 / bits;
+    if (j >= bits * F) return 1024.0f;
+    const int p = (j % F) * bits;
+    int b0 = 0;
+    for (int q = 0; q <= p; q += bits)
+        if (q + bits - b0 > 10) b0 = q;
+    return (float)(1 << (10 - (p - b0)));
+}
 __global__ __launch_bounds__(256) void exl2_list_permute_kernel(const Exl2Call* __restrict__ ent) {
     const Exl2Call& e = ent[blockIdx.y];
     const int k = blockIdx.x * 256 + threadIdx.x;
-    if (e.perm == nullptr || k >= e.K) return;
-    const_cast<uint16_t*>(e.xp)[k] = e.x[e.perm[k]];
+    if (k >= e.K) return;  // K % 32 == 0: whole 32-lane groups leave together
+    const uint16_t xb = e.x[e.perm ? (int)e.perm[k] : k];
+    const_cast<uint16_t*>(e.xp)[k] = xb;
+    int bits = 2;
+#pragma unroll
+    for (int b = 5; b >= 0; b--)
+        if (k < e.rows.r[b]) bits = exl2_bits_of_band(b);  // the first band whose end lies beyond k
+    const float xv = f16_bits_to_f32(xb);
+    float so = exl2_offset_of(bits, (k & 31) >> 1) * xv, sx = xv;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+        so += __shfl_xor(so, d, 32);
+        sx += __shfl_xor(sx, d, 32);
+    }
+    if ((k & 31) == 0) const_cast<float2_t*>(e.cs)[k >> 5] = float2_t{so, sx};
 }
 // decode (M <= 2): column blocks x K slabs ~ 512 workgroups of 8 waves (two per CU -> one round), slabs in whole multiples of
 // 8 chunks so that the 8 waves of a workgroup get equal shares; at most BIE_WS_COUNTERS column blocks use the slab reduction
@@ -1211,7 +1310,7 @@ int mbwq_exl2_forward_launch(const void* x, const int32_t* qw, const void* scale
         int spin;
         test_forge_get(&skew, &spin);
         Exl2Call call{(const uint16_t*)x, (const uint32_t*)qw, (const uint16_t*)scales, (const uint16_t*)zeros, (const uint16_t*)perm,
-                      (const uint16_t*)gmap, gran, gen, (uint16_t*)y, rows, M, K, N, cps2, S, colblocks, {}, {}, nullptr};
+                      (const uint16_t*)gmap, gran, gen, (uint16_t*)y, rows, M, K, N, cps2, S, colblocks, {}, {}, nullptr, nullptr};
         exl2_fill_groups(call, rows7);
         const bool narrow2 = rows7[2] == 0;  // no 8 / 6 / 5-bit rows
 #define L2(MTV, NWV, DIR)                                                                                                                        \
@@ -1248,7 +1347,7 @@ int mbwq_exl2_forward_launch(const void* x, const int32_t* qw, const void* scale
             xin = xp;
         }
         Exl2Call call{xin, (const uint32_t*)qw, (const uint16_t*)scales, (const uint16_t*)zeros, nullptr,
-                      (const uint16_t*)gmap, reinterpret_cast<unsigned long long*>(part), gen, (uint16_t*)y, rows, M, K, N, cpsm, Sm, colblocks, {}, {}, nullptr};
+                      (const uint16_t*)gmap, reinterpret_cast<unsigned long long*>(part), gen, (uint16_t*)y, rows, M, K, N, cpsm, Sm, colblocks, {}, {}, nullptr, nullptr};
         const bool narrow = rows7[2] == 0;  // cumulative end of the 5-bit band: no 8 / 6 / 5-bit rows
 #define LM(MBV, NWV, OCCN, OCCW)                                                                                                                 \
     do {                                                                                                                                         \
@@ -1330,6 +1429,7 @@ static void exl2_list_plan(int n, const bie_exl2_list_entry* e, std::vector<int>
         *blocks += (long)cb * S[i];
         if (S[i] > 1) *gran_bytes += (size_t)(S[i] - 1) * M * cb * 64 * 8;
         size_t l = M > 1 ? (size_t)c * (32 * M + 2) * sizeof(uint16_t) : (size_t)8 * 4 * M * 32 * sizeof(uint16_t) + (size_t)c * 34 * sizeof(uint16_t);
+        if (M == 1 && l < (size_t)c * 72) l = (size_t)c * 72;  // DMODE 2: the slab of xp (64 bytes per chunk) + its {offset sum, x sum} pairs
         const size_t red = (size_t)8 * M * 64 * sizeof(float);
         if (l < red) l = red;
         if (l > *lds) *lds = l;
@@ -1353,7 +1453,7 @@ size_t exl2_list_device_bytes(int n, const bie_exl2_list_entry* e, int M) {
     long tiles = 0;
     for (int i = 0; i < n; i++) tiles += cdiv(e[i].N, 64);
     size_t xp = 0;
-    for (int i = 0; i < n; i++) xp += align256((size_t)e[i].K * 2);
+    for (int i = 0; i < n; i++) xp += align256((size_t)e[i].K * 2) + align256((size_t)(e[i].K / 32) * 8);
     return align256((size_t)n * sizeof(Exl2Call)) + align256((size_t)blocks * 8) + align256((size_t)tiles * 4) + align256(gran) + xp;
 }
 
@@ -1380,7 +1480,7 @@ int exl2_list_create(Exl2List** out, int n, const bie_exl2_list_entry* e, int M,
     const size_t o_blk = align256((size_t)n * sizeof(Exl2Call)), o_gen = o_blk + align256((size_t)blocks * 8), o_gran = o_gen + align256((size_t)tiles * 4);
     const size_t o_xp = o_gran + align256(gran);
     size_t xp_bytes = 0;
-    for (int i = 0; i < n; i++) xp_bytes += align256((size_t)e[i].K * 2);
+    for (int i = 0; i < n; i++) xp_bytes += align256((size_t)e[i].K * 2) + align256((size_t)(e[i].K / 32) * 8);
     BIE_REQUIRE(device_bytes >= o_xp + xp_bytes, BIE_ERR_WORKSPACE, "bie_mbwq_exl2_list_create: device buffer of %zu bytes required, got %zu", o_xp + xp_bytes, device_bytes);
     char* base = static_cast<char*>(device_mem);
     std::vector<Exl2Call> he(n);
@@ -1401,8 +1501,10 @@ int exl2_list_create(Exl2List** out, int n, const bie_exl2_list_entry* e, int M,
         c.gen = reinterpret_cast<unsigned*>(base + o_gen) + t0;
         for (int k = 0; k < 6; k++) c.rows.r[k] = e[i].rows7[k];
         exl2_fill_groups(c, e[i].rows7);
-        c.xp = c.perm ? reinterpret_cast<const uint16_t*>(base + xo) : c.x;
+        c.xp = reinterpret_cast<const uint16_t*>(base + xo);
         xo += align256((size_t)e[i].K * 2);
+        c.cs = reinterpret_cast<const float2_t*>(base + xo);
+        xo += align256((size_t)(e[i].K / 32) * 8);
         if (c.perm) any_perm = true;
         c.M = M; c.K = e[i].K; c.N = e[i].N; c.chunks_per_slab = cps[i]; c.S = S[i]; c.colblocks = cb;
         BIE_REQUIRE(S[i] < 4096, BIE_ERR_UNSUPPORTED, "bie_mbwq_exl2_list_create: entry %d needs %d K slabs (< 4096)", i, S[i]);
@@ -1424,8 +1526,6 @@ int exl2_list_create(Exl2List** out, int n, const bie_exl2_list_entry* e, int M,
     }
     static const bool xp_on = [] { const char* ev = getenv("BIE_EXL2_XP"); return !ev || atoi(ev) != 0; }();
     pl->xp = pl->direct && xp_on;
-    for (int i = 0; i < n; i++)
-        if (!e[i].q_perm && (reinterpret_cast<uintptr_t>(e[i].x) & 63) != 0) pl->xp = false;  // such an entry reads x itself through s_load_dwordx16
     pl->d_ent = reinterpret_cast<Exl2Call*>(base);
     pl->d_blk = reinterpret_cast<uint2_t*>(base + o_blk);
     *out = pl;
@@ -1445,7 +1545,7 @@ int exl2_list_forward(Exl2List* p, hipStream_t st) {
         if (p->narrow) hipLaunchKernelGGL((exl2_list_kernel<MTV, true, DIR>), dim3(p->grid), dim3(512), p->lds, st, p->d_ent, p->d_blk, epoch, device_status_word(), skew, spin); \
         else hipLaunchKernelGGL((exl2_list_kernel<MTV, false, DIR>), dim3(p->grid), dim3(512), p->lds, st, p->d_ent, p->d_blk, epoch, device_status_word(), skew, spin);      \
     } while (0)
-    if (p->xp && p->any_perm) {
+    if (p->xp) {
         hipLaunchKernelGGL(exl2_list_permute_kernel, dim3(cdiv(p->max_k, 256), p->n), dim3(256), 0, st, p->d_ent);
         rc = check_launch("exl2_list_permute_kernel");
         if (rc) return rc;
