@@ -1144,7 +1144,7 @@ __device__ __forceinline__ void exl2_list_body(const Exl2Call* __restrict__ ent,
                                              tag_skew, spin_limit, grp, c->xp, c->cs);
 }
 template <int MT, bool NARROW, int DMODE>
-__global__ __launch_bounds__(512, 4) void exl2_list_kernel(const Exl2Call* __restrict__ ent, const uint2_t* __restrict__ blk, unsigned epoch,
+__global__ __launch_bounds__(512, ((DMODE == 2 && NARROW) ? 6 : 4)) void exl2_list_kernel(const Exl2Call* __restrict__ ent, const uint2_t* __restrict__ blk, unsigned epoch,
                                                            unsigned* status, unsigned tag_skew, int spin_limit) {
     exl2_list_body<MT, NARROW, DMODE>(ent, blk, epoch, status, tag_skew, spin_limit);
 }
