@@ -48,7 +48,8 @@ class MBWQLinearCuda(MPQLinearBase):
         super().__init__(*args, **kwargs)
         self.qweight.layer_type = 2
         self.use_mbw, self.groups, self.rows_packed = use_mbw, groups, rows_packed
-        self.rows = [0] * 7  # rows_8, rows_6, rows_5, rows_4, rows_3, rows_2 (cumulative k), kernel_p bit mask
+        self.rows = [0] * 7  # rows_8, rows_6, rows_5, rows_4, rows_3, rows_2 (cumulative k), kernel_p bit mask (prepare_params: + the group table)
+        self._bie_group = None  # SiblingGroup, set by prepare_bie_layers (mpq_layer.find_sibling_groups)
         self.check_parameters()
 
     def check_parameters(self) -> None:
@@ -125,8 +126,44 @@ class MBWQLinearCuda(MPQLinearBase):
     def exl2fp_weight(qweight, scales, zeros, q_perm, q_group_map, rows) -> torch.Tensor:
         return q_linear_cuda.mbwq_exl2fp_weight(qweight, scales, zeros, q_perm, q_group_map, rows)
 
+    def _channel_scale_is_one(self) -> bool:
+        """Memoised on the tensor's identity and version counter (a blocking read, once)."""
+        cs = self.channel_scale
+        key = (cs.data_ptr(), cs._version, tuple(cs.shape))
+        if getattr(self, "_cs_one_key", None) != key:
+            self._cs_one_key, self._cs_one = key, bool((cs == 1).all().item())
+        return self._cs_one
+
+    @staticmethod
+    def forward_grouped(layers: typing.Sequence["MBWQLinearCuda"], x: torch.Tensor, _from_group: bool = False) -> typing.List[torch.Tensor]:
+        """Mixed-bit layers that consume the SAME one-row activation (q/k/v, gate/up) in two launches instead of one
+        gemm_half_q_half_kernel launch per layer (mbwq_linear_cuda_kernel.cu:926-1007): bie_mbwq_exl2_forward_grouped.  Groupable:
+        eval mode, one row of fp16 x, every channel_scale all ones (x * 1 is x: the members do share their input), regular groups.
+        Anything else runs the members one by one."""
+        x2, lead = flatten_x(x)
+        ok = (2 <= len(layers) <= 8 and x2.shape[0] == 1 and x2.dtype == torch.half and not (torch.is_grad_enabled() and x.requires_grad)
+              and all(l.use_mbw and not l.training and l.q_group_map is not None and l.in_channels == layers[0].in_channels
+                      and l._channel_scale_is_one() for l in layers))
+        outs = None
+        if ok:
+            outs = q_linear_cuda.mbwq_exl2_forward_grouped(x2, [(l.qweight.data, l.scales, l.zeros, l.q_perm, l.q_group_map, l.rows) for l in layers])
+        if outs is None:
+            if _from_group:  # called by a SiblingGroup: the members' own forward would re-enter the group
+                return [l._forward_alone(x) for l in layers]
+            return [l(x) for l in layers]
+        return [unflatten_x(o if l.disable_bias else o + l.bias, lead) for l, o in zip(layers, outs)]
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        x = x.mul(self.channel_scale)
+        from .mpq_layer import AUTO_GROUP
+        if AUTO_GROUP and getattr(self, "_bie_group", None) is not None and self.use_mbw and not self.training and x.numel() == x.shape[-1]:
+            out = self._bie_group.forward(self, x)  # decode: siblings that share x run as one grouped call (mpq_layer.SiblingGroup)
+            if out is not None:
+                return out
+        return self._forward_alone(x)
+
+    def _forward_alone(self, x: torch.Tensor) -> torch.Tensor:
+        if not (self.use_mbw and not self.training and self._channel_scale_is_one()):  # x * 1: one elementwise launch per call for nothing
+            x = x.mul(self.channel_scale)
         extra = (self.q_group_map, self.rows) if self.use_mbw else ()
         out = MBWQLinearCudaFunction.apply(x, self.qweight, self.use_mbw, self.training, self.scales, self.zeros,
                                            self.group_size, self.q_perm, self.w_bit, self.privileged_grad, *extra)

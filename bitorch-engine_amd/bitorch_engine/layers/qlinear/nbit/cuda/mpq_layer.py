@@ -29,7 +29,7 @@ def _x_key(x):
 
 
 class SiblingGroup:
-    """MPQLinearCuda children of ONE parent module that may consume the same activation (q/k/v, gate/up): what
+    """MPQLinearCuda (or mixed-bit MBWQLinearCuda) children of ONE parent module that may consume the same activation (q/k/v, gate/up): what
     prepare_bie_layers() finds by structure and the first forward passes CONFIRM by observation, so that an unchanged caller
 
         q = self.q_proj(h); k = self.k_proj(h); v = self.v_proj(h)
@@ -107,7 +107,7 @@ class SiblingGroup:
         leader = self.leader_of.get(id(module))
         if leader is module:
             members = self.sets[id(module)]
-            outs = MPQLinearCuda.forward_grouped(members, x, _from_group=True)
+            outs = type(module).forward_grouped(members, x, _from_group=True)
             GROUP_STATS["grouped_launches"] += 1
             for m, o in zip(members[1:], outs[1:]):
                 self.parked[id(m)] = (key, o)
@@ -125,16 +125,21 @@ class SiblingGroup:
 
 
 def find_sibling_groups(model: torch.nn.Module) -> int:
-    """Attach a SiblingGroup to every set of >= 2 MPQLinearCuda children of one parent that share in_channels / w_bit / group_size /
-    asym / dtype (called by utils.model_helper.prepare_bie_layers).  Returns the number of candidate groups."""
+    """Attach a SiblingGroup to every set of >= 2 children of one parent that could run as one grouped decode launch: MPQLinearCuda
+    layers sharing in_channels / w_bit / group_size / asym / dtype, and mixed-bit (exl2) MBWQLinearCuda layers sharing in_channels
+    (called by utils.model_helper.prepare_bie_layers).  Returns the number of candidate groups."""
+    from .mbwq_layer import MBWQLinearCuda
     n = 0
     for parent in model.modules():
-        kids = [c for c in parent.children() if isinstance(c, MPQLinearCuda)]
         buckets = {}
-        for c in kids:
-            buckets.setdefault((c.in_channels, c.w_bit, c.group_size, bool(c.asym), c.dtype), []).append(c)
+        for c in parent.children():
+            if isinstance(c, MPQLinearCuda):
+                if c.w_bit in (4, 2):
+                    buckets.setdefault(("mpq", c.in_channels, c.w_bit, c.group_size, bool(c.asym), c.dtype), []).append(c)
+            elif isinstance(c, MBWQLinearCuda) and c.use_mbw:
+                buckets.setdefault(("exl2", c.in_channels), []).append(c)
         for members in buckets.values():
-            if len(members) >= 2 and members[0].w_bit in (4, 2):
+            if len(members) >= 2:
                 g = SiblingGroup(members)
                 for m in members:
                     m._bie_group = g

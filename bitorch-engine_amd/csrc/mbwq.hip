@@ -18,6 +18,7 @@
 #pragma clang fp contract(off)
 
 #include <vector>
+#include <cstring>
 
 namespace bie {
 unsigned* device_status_word();                            // splitk.hip
@@ -1179,12 +1180,69 @@ __global__ __launch_bounds__(256) void exl2_list_permute_kernel(const Exl2Call* 
     }
     if ((k & 31) == 0) const_cast<float2_t*>(e.cs)[k >> 5] = float2_t{so, sx};
 }
+// ---- a GROUP of up to 8 exl2 layers that consume the same one-row x (q / k / v, gate / up), everything in the kernel arguments ----------
+// bie_mbwq_exl2_forward_grouped: no plan object and no device table -- the call descriptors travel in the kernel-argument segment and
+// are read from there with scalar loads, so x and the outputs may be new tensors on every call.  Two launches: the permute kernel
+// (xp_i = x[q_perm_i] and the two per-chunk sums, every member has its own q_perm) and the DMODE 2 decode body over all members.
+constexpr int EXL2_GROUP_MAX = 8;
+struct Exl2GroupArgs {
+    int n, max_k;
+    int first_block[EXL2_GROUP_MAX + 1];  // prefix sums of colblocks * S
+    Exl2Call ent[EXL2_GROUP_MAX];
+};
+template <bool NARROW>
+__global__ __launch_bounds__(512, (NARROW ? 6 : 4)) void exl2_group_kernel(const Exl2GroupArgs a, unsigned epoch, unsigned* status, unsigned tag_skew, int spin_limit) {
+    typedef const __attribute__((address_space(4))) Exl2Call ccall_t;
+    int ei = 0;
+#pragma unroll
+    for (int i = 1; i < EXL2_GROUP_MAX; i++)
+        if (i < a.n && (int)blockIdx.x >= a.first_block[i]) ei = i;
+    const __attribute__((address_space(4))) char* kp = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    ccall_t* c = (ccall_t*)(kp + __builtin_offsetof(Exl2GroupArgs, ent) + (size_t)ei * sizeof(Exl2Call));
+    const int local = (int)blockIdx.x - a.first_block[ei];
+    Exl2Rows rows;
+#pragma unroll
+    for (int i = 0; i < 6; i++) rows.r[i] = c->rows.r[i];
+    Exl2Groups grp;
+#pragma unroll
+    for (int i = 0; i < 6; i++) { grp.gfirst[i] = c->gfirst[i]; grp.glog[i] = c->glog[i]; }
+    const int cb = c->colblocks;
+    exl2_gemv2_body<1, 8, false, NARROW, 2>(c->x, c->qw, c->scales, c->zeros, c->perm, c->gmap, c->gran, c->gen, c->y, rows, 1, c->K, c->N,
+                                            c->chunks_per_slab, c->S, local % cb, local / cb, cb, epoch, status, tag_skew, spin_limit, grp, c->xp, c->cs);
+}
+__global__ __launch_bounds__(256) void exl2_group_permute_kernel(const Exl2GroupArgs a) {
+    typedef const __attribute__((address_space(4))) Exl2Call ccall_t;
+    const __attribute__((address_space(4))) char* kp = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    ccall_t* e = (ccall_t*)(kp + __builtin_offsetof(Exl2GroupArgs, ent) + (size_t)blockIdx.y * sizeof(Exl2Call));
+    const int K = e->K;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    const uint16_t* perm = e->perm;
+    const uint16_t xb = e->x[perm ? (int)perm[k] : k];
+    const_cast<uint16_t*>(e->xp)[k] = xb;
+    int bits = 2;
+#pragma unroll
+    for (int b = 5; b >= 0; b--)
+        if (k < e->rows.r[b]) bits = exl2_bits_of_band(b);
+    const float xv = f16_bits_to_f32(xb);
+    float so = exl2_offset_of(bits, (k & 31) >> 1) * xv, sx = xv;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+        so += __shfl_xor(so, d, 32);
+        sx += __shfl_xor(sx, d, 32);
+    }
+    if ((k & 31) == 0) const_cast<float2_t*>(e->cs)[k >> 5] = float2_t{so, sx};
+}
+
 // decode (M <= 2): column blocks x K slabs ~ 512 workgroups of 8 waves (two per CU -> one round), slabs in whole multiples of
 // 8 chunks so that the 8 waves of a workgroup get equal shares; at most BIE_WS_COUNTERS column blocks use the slab reduction
 static void exl2_decode_plan(int M, int K, int N, int& cps, int& S, int& nw) {
     const int C = K / 32, colblocks = cdiv(N, 64);
     const int CPS_MAX = 768 / M;  // the slab's x (q_perm applied, M rows) / group-map copy in LDS: 64 M + 4 bytes per chunk (<= 52 KiB)
-    if (colblocks >= 160 && M == 1) {  // wide layers: 16-wave workgroups, one K slab (more only when K is too long for the LDS copy).
+    static const int nw16_min = [] { const char* ev = getenv("BIE_EXL2_NW16_MIN"); return ev ? atoi(ev) : 160; }();
+    static const int want_wgs = [] { const char* ev = getenv("BIE_EXL2_PLAN_WGS"); return ev && atoi(ev) > 0 ? atoi(ev) : 512; }();
+    static const int min_cpw = [] { const char* ev = getenv("BIE_EXL2_MIN_CPW"); return ev && atoi(ev) > 0 ? atoi(ev) : 4; }();
+    if (colblocks >= nw16_min && M == 1) {  // wide layers: 16-wave workgroups, one K slab (more only when K is too long for the LDS copy).
         // M = 2 keeps the 8-wave form: 1024-thread workgroups cap a wave at 128 registers and the two-row variant spilled 1096 dwords
         nw = 16;
         S = cdiv(C, CPS_MAX);
@@ -1194,10 +1252,10 @@ static void exl2_decode_plan(int M, int K, int N, int& cps, int& S, int& nw) {
         return;
     }
     nw = 8;
-    int want = (512 + colblocks / 2) / colblocks;
+    int want = (want_wgs + colblocks / 2) / colblocks;
     if (want < 1) want = 1;
     cps = cdiv(cdiv(C, want), nw) * nw;
-    if (cps < 4 * nw) cps = 4 * nw;  // at least four chunks per wave: the depth of the kernel's prefetch
+    if (cps < min_cpw * nw) cps = min_cpw * nw;  // at least four chunks per wave: the depth of the kernel's prefetch
     if (cps > CPS_MAX) cps = CPS_MAX;
     if (cps > C) cps = C;
     S = cdiv(C, cps);
@@ -1418,7 +1476,8 @@ static void exl2_list_plan(int n, const bie_exl2_list_entry* e, std::vector<int>
     *blocks = 0; *gran_bytes = 0; *lds = 0;
     for (int i = 0; i < n; i++) {
         const int C = e[i].K / 32, cb = cdiv(e[i].N, 64);
-        int want = (int)((2048 + colblocks_all / 2) / colblocks_all);
+        static const int wgs = [] { const char* ev = getenv("BIE_EXL2_LIST_WGS"); return ev && atoi(ev) > 0 ? atoi(ev) : 2048; }();
+        int want = (int)((wgs + colblocks_all / 2) / colblocks_all);
         if (want < 1) want = 1;
         int c = cdiv(cdiv(C, want), 8) * 8;
         if (c < 32) c = 32;
@@ -1554,6 +1613,76 @@ int exl2_list_forward(Exl2List* p, hipStream_t st) {
     else LL(2, 0);
 #undef LL
     return check_launch("exl2_list_kernel");
+}
+
+// ---- the group call (bie_mbwq_exl2_forward_grouped) -----------------------------------------------------------------------------
+static bool exl2_group_entry_ok(const bie_exl2_list_entry& e) {
+    return e.K > 0 && e.N > 0 && e.K % 32 == 0 && e.rows7 && (e.rows7[6] & BIE_EXL2_ROWS_SHUFFLED) && e.rows7[BIE_EXL2_ROWS_LEN - 1] == BIE_EXL2_ROWS_TAG &&
+           (e.rows7[6] & BIE_EXL2_ROWS_REGULAR) && e.rows7[5] == e.K;
+}
+bool exl2_group_ok(int n, const bie_exl2_list_entry* e) {
+    if (n < 1 || n > EXL2_GROUP_MAX || !e || !exl2_direct_on()) return false;
+    long cbs = 0;
+    for (int i = 0; i < n; i++) {
+        if (!exl2_group_entry_ok(e[i])) return false;
+        cbs += cdiv(e[i].N, 64);
+    }
+    return cbs <= BIE_WS_COUNTERS;  // one generation word per column block in the workspace head
+}
+// behind the 16 KiB head: granules of the K slabs, then per member xp (K fp16) and cs (K / 32 float2)
+size_t exl2_group_workspace_bytes(int n, const bie_exl2_list_entry* e) {
+    if (!exl2_group_ok(n, e)) return 0;
+    std::vector<int> cps, S;
+    long blocks; size_t gran, lds;
+    exl2_list_plan(n, e, cps, S, &blocks, &gran, &lds, 1);
+    size_t tot = align256(gran);
+    for (int i = 0; i < n; i++) tot += align256((size_t)e[i].K * 2) + align256((size_t)(e[i].K / 32) * 8);
+    return tot;
+}
+int exl2_group_forward(int n, const bie_exl2_list_entry* e, const void* x, float* head, char* body, hipStream_t st) {
+    std::vector<int> cps, S;
+    long blocks; size_t gran, lds;
+    exl2_list_plan(n, e, cps, S, &blocks, &gran, &lds, 1);
+    Exl2GroupArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.n = n;
+    size_t go = 0, xo = align256(gran);
+    long t0 = 0;
+    bool narrow = true;
+    unsigned* gen = reinterpret_cast<unsigned*>(head) + BIE_WS_GEN_OFFSET;
+    for (int i = 0; i < n; i++) {
+        Exl2Call& c = a.ent[i];
+        const int cb = cdiv(e[i].N, 64);
+        c.x = (const uint16_t*)(x ? x : e[i].x);
+        c.qw = (const uint32_t*)e[i].qweight; c.scales = (const uint16_t*)e[i].scales; c.zeros = (const uint16_t*)e[i].zeros;
+        c.perm = (const uint16_t*)e[i].q_perm; c.gmap = (const uint16_t*)e[i].q_group_map; c.y = (uint16_t*)e[i].y;
+        c.gran = S[i] > 1 ? reinterpret_cast<unsigned long long*>(body + go) : nullptr;
+        if (S[i] > 1) go += (size_t)(S[i] - 1) * cb * 64 * 8;
+        c.gen = gen + t0;
+        for (int k = 0; k < 6; k++) c.rows.r[k] = e[i].rows7[k];
+        exl2_fill_groups(c, e[i].rows7);
+        c.xp = reinterpret_cast<const uint16_t*>(body + xo);
+        xo += align256((size_t)e[i].K * 2);
+        c.cs = reinterpret_cast<const float2_t*>(body + xo);
+        xo += align256((size_t)(e[i].K / 32) * 8);
+        c.M = 1; c.K = e[i].K; c.N = e[i].N; c.chunks_per_slab = cps[i]; c.S = S[i]; c.colblocks = cb;
+        BIE_REQUIRE(S[i] < 4096, BIE_ERR_UNSUPPORTED, "bie_mbwq_exl2_forward_grouped: member %d needs %d K slabs (< 4096)", i, S[i]);
+        a.first_block[i] = (int)(i == 0 ? 0 : a.first_block[i - 1] + (long)cdiv(e[i - 1].N, 64) * S[i - 1]);
+        if (e[i].K > a.max_k) a.max_k = e[i].K;
+        if (e[i].rows7[2] != 0) narrow = false;
+        t0 += cb;
+    }
+    a.first_block[n] = (int)blocks;
+    unsigned skew;
+    int spin;
+    test_forge_get(&skew, &spin);
+    const unsigned epoch = next_launch_epoch();
+    hipLaunchKernelGGL(exl2_group_permute_kernel, dim3(cdiv(a.max_k, 256), n), dim3(256), 0, st, a);
+    int rc = check_launch("exl2_group_permute_kernel");
+    if (rc) return rc;
+    if (narrow) hipLaunchKernelGGL((exl2_group_kernel<true>), dim3((unsigned)blocks), dim3(512), lds, st, a, epoch, device_status_word(), skew, spin);
+    else hipLaunchKernelGGL((exl2_group_kernel<false>), dim3((unsigned)blocks), dim3(512), lds, st, a, epoch, device_status_word(), skew, spin);
+    return check_launch("exl2_group_kernel");
 }
 
 void exl2_list_destroy(Exl2List* p) { delete p; }

@@ -255,6 +255,17 @@ int bie_mbwq_exl2_list_create(bie_exl2_list_t** plan, int n_entries, const bie_e
 int bie_mbwq_exl2_list_forward(bie_exl2_list_t* plan, void* stream);
 void bie_mbwq_exl2_list_destroy(bie_exl2_list_t* plan);
 
+/* Up to 8 exl2 layers that consume the SAME one-row activation x (q / k / v, gate / up -- every layer has its own q_perm) in two
+ * stream-ordered launches and without a plan object: the member descriptors travel in the kernel arguments, so x and the outputs
+ * may be new buffers on every call (members[i].x is ignored).  Members need tables carrying BIE_EXL2_ROWS_REGULAR; fp16, M = 1.
+ * Workspace: zero-filled once (head words as for bie_mbwq_exl2_forward; a buffer may serve both), of
+ * bie_mbwq_exl2_grouped_workspace_bytes (0 = not groupable: call bie_mbwq_exl2_forward per member).  The reference launches
+ * gemm_half_q_half_kernel once per layer (mbwq_linear_cuda_kernel.cu:926-1007): at 4096x4096 three launches take 3 x 6.7 us here,
+ * the group 11.6 us. */
+size_t bie_mbwq_exl2_grouped_workspace_bytes(int n_members, const bie_exl2_list_entry* members);
+int bie_mbwq_exl2_forward_grouped(const void* x, int n_members, const bie_exl2_list_entry* members, void* workspace,
+                                  size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* Binary (1-bit W / 1-bit A) linear + conv2d, XNOR-popcount                                     */
 /* ------------------------------------------------------------------------------------------ */

@@ -55,7 +55,8 @@ def assert_close(y, ref, dt, what=""):
     y, ref = to_f32(y), to_f32(ref)
     ulp = 2.0 ** -7 if dt == orc.BF16 else (2.0 ** -10 if dt == orc.F16 else 2.0 ** -22)  # one ulp, worst case within a binade
     tol = 1e-3 * np.abs(ref).max() + ulp * np.abs(ref)
-    bad = np.abs(y - ref) > tol
+    bad = ~(np.abs(y - ref) <= tol)  # written so that a NaN / inf on either side is BAD (x > tol is False for NaN)
+    bad &= ~((y == ref) & np.isinf(ref))  # the same infinity on both sides is agreement
     if bad.any():
         idx = np.argwhere(bad)
         rows, cols = np.unique(idx[:, 0]), np.unique(idx[:, 1])
@@ -1140,6 +1141,156 @@ def test_unmodified_module_tree_gets_grouped_launches_after_prepare_bie_layers(w
         for l in layers:
             l._bie_group = None
         assert torch.equal(yp, model(xp))
+
+
+def _exl2_layer(K, N, spec, gen, bias=False):
+    """An MBWQLinearCuda (exl2) layer with random packed weights; returns (layer, raw qweight, q_groups list)."""
+    from bitorch_engine.layers.qlinear.nbit.cuda import MBWQLinearCuda
+    qg, row, kk = [], 0, 0
+    for bits, k in spec:
+        qg += [bits, row]
+        row += k * bits // 32
+        kk += k
+    assert kk == K
+    groups = len(spec)
+    layer = MBWQLinearCuda(in_channels=K, out_channels=N, w_bit=4, dtype=torch.half, group_size=32, dq_group_size=1, use_gba_quant=True, asym=False,
+                           dq_mode=2, use_mbw=True, groups=groups, rows_packed=row, disable_bias=not bias)
+    qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (row, N), generator=gen, dtype=torch.int64).to(torch.int32)
+    layer.set_qweight_data(qw.clone())
+    layer.set_scales((torch.rand((groups, N), generator=gen) * 0.02 + 0.001).half())
+    layer.set_zeros((torch.randn((groups, N), generator=gen) * 0.05).half())
+    layer.q_perm = torch.randperm(K, generator=gen).to(torch.short)
+    layer.q_groups = torch.tensor(qg, dtype=torch.short)
+    if bias:
+        layer.bias.data = torch.randn((N,), generator=gen).half() * 0.1
+    return layer, qw, qg
+
+
+def test_exl2_grouped_forward_against_the_oracle_and_the_single_launches():
+    """bie_mbwq_exl2_forward_grouped through MBWQLinearCuda.forward_grouped: three mixed-bit layers with their own q_perm, band tables and
+    widths (one with a bias) on ONE x -- every output against the oracle; an irregular member (groups of 96) sends the whole set to the
+    single launches, same numbers."""
+    from bitorch_engine.layers.qlinear.nbit.cuda import MBWQLinearCuda
+    gen = torch.Generator().manual_seed(77)
+    K = 1024
+    specs = [[(4, 64)] * 4 + [(3, 32)] * 16 + [(2, 128)] * 2, [(3, 32)] * 16 + [(2, 32)] * 16, [(6, 32)] * 2 + [(4, 128)] * 3 + [(2, 64)] * 9]
+    made = [_exl2_layer(K, N, sp, gen, bias=(i == 1)) for i, (N, sp) in enumerate(zip((328, 512, 200), specs))]
+    layers = [m[0] for m in made]
+    for l in layers:
+        l.eval().to(DEV)
+        l.prepare_params()
+    x = torch.randn((1, K), generator=gen).half()
+    refs = []
+    for l, qw, qg in made:
+        Wo = orc.exl2_dequant(qw.numpy(), orc.torch_to_np(l.scales.cpu()), orc.torch_to_np(l.zeros.cpu()), l.q_perm.cpu().numpy(), np.array(qg, np.int16), K)
+        r = orc.gemm(orc.torch_to_np(x), Wo, orc.F16)
+        if not l.disable_bias:
+            r = orc.torch_to_np((t16(r, orc.F16).float() + l.bias.float().cpu()).half())
+        refs.append(t16(r, orc.F16))
+    from bitorch_engine import _hip
+    with torch.no_grad():
+        outs = MBWQLinearCuda.forward_grouped(layers, x.to(DEV))
+        for i, (o, r) in enumerate(zip(outs, refs)):
+            assert o.shape == (1, layers[i].out_channels)
+            assert_close(o, r, orc.F16, f"exl2 grouped member {i}")
+        again = MBWQLinearCuda.forward_grouped(layers, x.to(DEV))
+        assert all(torch.equal(a, b) for a, b in zip(outs, again)) and all(a.data_ptr() != b.data_ptr() for a, b in zip(outs, again))
+        singles = [l(x.to(DEV)) for l in layers]
+        for i, (o, sgl) in enumerate(zip(outs, singles)):
+            assert_close(o, sgl.float().cpu().half(), orc.F16, f"exl2 grouped member {i} vs its own launch")
+        # an irregular member: not groupable, the set falls back to one launch per member
+        odd, qw, qg = _exl2_layer(K, 136, [(4, 96)] * 4 + [(2, 32)] * 20, gen)
+        odd.eval().to(DEV)
+        odd.prepare_params()
+        assert not (odd.rows[6] & 0x200)
+        mixed = MBWQLinearCuda.forward_grouped([layers[0], odd], x.to(DEV))
+        assert torch.equal(mixed[0], singles[0])
+        Wo = orc.exl2_dequant(qw.numpy(), orc.torch_to_np(odd.scales.cpu()), orc.torch_to_np(odd.zeros.cpu()), odd.q_perm.cpu().numpy(), np.array(qg, np.int16), K)
+        assert_close(mixed[1], t16(orc.gemm(orc.torch_to_np(x), Wo, orc.F16), orc.F16), orc.F16, "irregular member alone")
+
+
+def test_unmodified_exl2_module_tree_gets_grouped_calls_after_prepare_bie_layers():
+    """mixed-bit layers behind the reference's module API -- q_proj(h), k_proj(h), v_proj(h), o_proj(a), gate(h2), up(h2),
+    down(..) -- run q/k/v and gate/up as ONE grouped call each from the second forward on (counters), with the numbers of the layers'
+    own launches; a channel_scale that is not all ones keeps its layer out."""
+    from bitorch_engine.layers.qlinear.nbit.cuda import MBWQLinearCuda
+    from bitorch_engine.layers.qlinear.nbit.cuda import mpq_layer
+    from bitorch_engine.utils.model_helper import prepare_bie_layers
+    H, I = 512, 768
+    g = torch.Generator().manual_seed(29)
+    spec = lambda K: [(4, 64)] * 2 + [(3, 32)] * 8 + [(2, 64)] * 2 if K == 512 else [(3, 32)] * (K // 64) + [(2, 32)] * (K // 64)
+    lin = lambda K, N: _exl2_layer(K, N, spec(K), g)[0]
+
+    class Attn(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.q_proj, self.k_proj, self.v_proj, self.o_proj = lin(H, H), lin(H, H), lin(H, H), lin(H, H)
+
+        def forward(self, h):
+            q, k, v = self.q_proj(h), self.k_proj(h), self.v_proj(h)
+            return self.o_proj(torch.tanh(q + k) * v)
+
+    class Mlp(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.gate_proj, self.up_proj, self.down_proj = lin(H, I), lin(H, I), lin(I, H)
+
+        def forward(self, h):
+            return self.down_proj(torch.sigmoid(self.gate_proj(h)) * self.up_proj(h))
+
+    class Block(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.self_attn, self.mlp = Attn(), Mlp()
+
+        def forward(self, h):
+            h = h + self.self_attn(h)
+            return h + self.mlp(h)
+
+    model = torch.nn.Sequential(Block(), Block())
+    for m in model.modules():
+        if isinstance(m, MBWQLinearCuda):  # small weights: the activations of the random net stay far from the fp16 range
+            m.set_scales(m.scales * 0.2)
+            m.set_zeros(m.zeros * 0.2)
+    model.to(DEV).eval()
+    prepare_bie_layers(model)
+    layers = [m for m in model.modules() if isinstance(m, MBWQLinearCuda)]
+    assert len(layers) == 14 and all(len(l.rows) == 20 for l in layers)
+    assert all(l._bie_group is not None for l in layers if l.in_channels == H) and all(l._bie_group is None for l in layers if l.in_channels == I)
+    xs = [torch.randn((1, H), generator=g).half().to(DEV) for _ in range(4)]
+    with torch.no_grad():
+        saved = [l._bie_group for l in layers]
+        for l in layers:
+            l._bie_group = None
+        refs = [model(x) for x in xs]            # every layer by itself
+        for l, grp in zip(layers, saved):
+            l._bie_group = grp
+        mpq_layer.GROUP_STATS.update({k: 0 for k in mpq_layer.GROUP_STATS})
+        y0 = model(xs[0])                          # observation round
+        assert mpq_layer.GROUP_STATS["grouped_launches"] == 0
+        assert_close(y0, refs[0], orc.F16, "observation round")
+        for x, r in zip(xs[1:], refs[1:]):
+            before = dict(mpq_layer.GROUP_STATS)
+            y = model(x)
+            d = {k: mpq_layer.GROUP_STATS[k] - before[k] for k in before}
+            assert d["grouped_launches"] == 4 and d["served_from_group"] == 6, d   # per block: q/k/v and gate/up
+            assert_close(y, r, orc.F16, "grouped rounds")
+        assert mpq_layer.GROUP_STATS["groups_confirmed"] == 4 and mpq_layer.GROUP_STATS["groups_dissolved"] == 0
+        # a member whose channel_scale is not all ones does not share its input with the others: the set runs member by member, same numbers
+        blk = model[0].self_attn
+        blk.k_proj.channel_scale = blk.k_proj.channel_scale * 0.5
+        for l in layers:
+            l._bie_group = None
+        r = model(xs[1])
+        for l, grp in zip(layers, saved):
+            l._bie_group = grp
+        assert_close(model(xs[1]), r, orc.F16, "a scaled member")
+        # several rows: the layers' own path
+        xp = torch.cat(xs + xs[:1], 0)
+        yp = model(xp)
+        for l in layers:
+            l._bie_group = None
+        assert torch.isfinite(yp.float()).all() and torch.equal(yp, model(xp))
 
 
 def test_grouped_forward_with_a_column_count_that_is_not_a_multiple_of_4():

@@ -224,9 +224,10 @@ def test_sibling_group_protocol_without_a_gpu(monkeypatch):
     def fake_grouped(layers, x, _from_group=False):
         calls.append([l.name for l in layers])
         return [f"{l.name}({x.data_ptr()},{x._version})" for l in layers]
-    monkeypatch.setattr(mpq_layer.MPQLinearCuda, "forward_grouped", staticmethod(fake_grouped))
 
-    class M:
+    class M:  # the group launches through the members' own class (MPQLinearCuda.forward_grouped / MBWQLinearCuda.forward_grouped)
+        forward_grouped = staticmethod(fake_grouped)
+
         def __init__(self, name):
             self.name = name
     q, k, v, o, gate, up = (M(n) for n in ("q", "k", "v", "o", "gate", "up"))
