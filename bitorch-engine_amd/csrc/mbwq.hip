@@ -470,7 +470,8 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
                                                 const float2_t* __restrict__ cs = nullptr) {
     constexpr bool DIRECT = DMODE != 0;
     constexpr bool XP = DMODE == 2;
-    static_assert(!DIRECT || (MT == 1 && !STAGED), "the direct forms serve one row of x");
+    static_assert(!DIRECT || !STAGED, "the direct forms stage nothing");
+    static_assert(!XP || MT == 1, "the pre-permuted form serves one row of x");
     extern __shared__ __attribute__((aligned(16))) uint32_t smem2[];
     const int tid = threadIdx.x, lane = tid & 63;
     // the tile's generation is read ONCE, at kernel entry, by every wave: the reducer advances the word as soon as it is done, and a
@@ -837,7 +838,7 @@ __global__ __launch_bounds__(EX2_NW * 64, (EX2_NW == 8 ? 4 : 1)) void exl2_gemv2
     Exl2Groups grp;
 #pragma unroll
     for (int i = 0; i < 6; i++) { grp.gfirst[i] = c.gfirst[i]; grp.glog[i] = c.glog[i]; }
-    exl2_gemv2_body<MT, EX2_NW, (MT > 1), NARROW, DMODE>(c.x, c.qw, c.scales, c.zeros, c.perm, c.gmap, c.gran, c.gen, c.y, c.rows, c.M, c.K, c.N,
+    exl2_gemv2_body<MT, EX2_NW, (MT > 1 && DMODE == 0), NARROW, DMODE>(c.x, c.qw, c.scales, c.zeros, c.perm, c.gmap, c.gran, c.gen, c.y, c.rows, c.M, c.K, c.N,
                                           c.chunks_per_slab, c.S, (int)blockIdx.x, (int)blockIdx.y, c.colblocks, epoch, status, tag_skew, spin_limit, grp);
 }
 
@@ -1236,13 +1237,13 @@ __global__ __launch_bounds__(256) void exl2_group_permute_kernel(const Exl2Group
 
 // decode (M <= 2): column blocks x K slabs ~ 512 workgroups of 8 waves (two per CU -> one round), slabs in whole multiples of
 // 8 chunks so that the 8 waves of a workgroup get equal shares; at most BIE_WS_COUNTERS column blocks use the slab reduction
-static void exl2_decode_plan(int M, int K, int N, int& cps, int& S, int& nw) {
+static void exl2_decode_plan(int M, int K, int N, int& cps, int& S, int& nw, bool direct = false) {
     const int C = K / 32, colblocks = cdiv(N, 64);
     const int CPS_MAX = 768 / M;  // the slab's x (q_perm applied, M rows) / group-map copy in LDS: 64 M + 4 bytes per chunk (<= 52 KiB)
     static const int nw16_min = [] { const char* ev = getenv("BIE_EXL2_NW16_MIN"); return ev ? atoi(ev) : 160; }();
     static const int want_wgs = [] { const char* ev = getenv("BIE_EXL2_PLAN_WGS"); return ev && atoi(ev) > 0 ? atoi(ev) : 512; }();
     static const int min_cpw = [] { const char* ev = getenv("BIE_EXL2_MIN_CPW"); return ev && atoi(ev) > 0 ? atoi(ev) : 4; }();
-    if (colblocks >= nw16_min && M == 1) {  // wide layers: 16-wave workgroups, one K slab (more only when K is too long for the LDS copy).
+    if (colblocks >= nw16_min && (M == 1 || direct)) {  // wide layers: 16-wave workgroups, one K slab (more only when K is too long for the LDS copy).
         // M = 2 keeps the 8-wave form: 1024-thread workgroups cap a wave at 128 registers and the two-row variant spilled 1096 dwords
         nw = 16;
         S = cdiv(C, CPS_MAX);
@@ -1260,6 +1261,8 @@ static void exl2_decode_plan(int M, int K, int N, int& cps, int& S, int& nw) {
     if (cps > C) cps = C;
     S = cdiv(C, cps);
 }
+
+static int exl2_decode_mt(int M) { return M <= 1 ? 1 : (M <= 2 ? 2 : 4); }  // rows of x the decode kernel is instantiated for
 
 static int exl2_slabs(int K, int N) {
     const int C = K / 32;
@@ -1284,7 +1287,7 @@ size_t mbwq_workspace_bytes(int M, int K, int N) {
     size_t c = (size_t)S * mc * N * sizeof(float);
     int cps2, S2, nw2;
     exl2_decode_plan(M, K, N, cps2, S2, nw2);
-    const size_t d = M <= 2 && S2 > 1 ? (size_t)(S2 - 1) * M * cdiv(N, 64) * 64 * 8 : 0;  // decode granules (unused when the fp32 kernel takes over)
+    const size_t d = M <= 4 && S2 > 1 ? (size_t)(S2 - 1) * exl2_decode_mt(M) * cdiv(N, 64) * 64 * 8 : 0;  // decode granules (unused when another kernel takes over)
     if (d > c) c = d;
     const size_t e = exl2_mfma_granule_bytes(M, K, N);  // 3 <= M <= 64: granules of the matrix-pipe kernel's K slabs
     if (e > c) c = e;
@@ -1349,15 +1352,16 @@ int mbwq_exl2_forward_launch(const void* x, const int32_t* qw, const void* scale
     Exl2Rows rows;
     for (int i = 0; i < 6; i++) rows.r[i] = rows7[i];
     const bool slab_ok = !(cdiv(N, 64) > BIE_WS_COUNTERS && K / 32 > 768);  // K slabs need one generation word per column block
-    if (M <= 2 && slab_ok) {  // decode path.  (The packed-fp16 kernel instantiated for 4 / 8 rows measured SLOWER than the fp32 kernel below:
+    const bool regular = (rows7[6] & BIE_EXL2_ROWS_REGULAR) && exl2_direct_on();
+    if ((M <= 2 || (M <= 4 && regular)) && slab_ok) {  // decode path: up to four rows ride on one v_mfma_f32_4x4x4 (DIRECT form; the staged form has LDS for two).  (The packed-fp16 kernel instantiated for 4 / 8 rows measured SLOWER than the fp32 kernel below:
                    //  33.3 / 46.2 us against 28.0 / 39.9 us at 4096x11008 M = 3 / 8 -- 178-256 registers, one wave per SIMD.)
         const int colblocks = cdiv(N, 64);
         int cps2, S, nw;
-        exl2_decode_plan(M, K, N, cps2, S, nw);
-        const int MT = M;
-        const bool direct = M == 1 && (rows7[6] & BIE_EXL2_ROWS_REGULAR) && exl2_direct_on();
-        size_t lds2 = MT > 1 ? (size_t)cps2 * (32 * MT + 2) * sizeof(uint16_t)   // the slab's gathered activations (M rows) + group map
-                             : (size_t)nw * 4 * MT * 32 * sizeof(uint16_t) + (direct ? 0 : (size_t)cps2 * 34 * sizeof(uint16_t));  // wave x buffers (+ q_perm + group map)
+        exl2_decode_plan(M, K, N, cps2, S, nw, regular);
+        const int MT = exl2_decode_mt(M);
+        const bool direct = regular;
+        size_t lds2 = (MT > 1 && !direct) ? (size_t)cps2 * (32 * MT + 2) * sizeof(uint16_t)   // the slab's gathered activations (M rows) + group map
+                                          : (size_t)nw * 4 * MT * 32 * sizeof(uint16_t) + (direct ? 0 : (size_t)cps2 * 34 * sizeof(uint16_t));  // wave x buffers (+ q_perm + group map)
         const size_t red = (size_t)nw * MT * 64 * sizeof(float);
         if (lds2 < red) lds2 = red;
         dim3 grid2(colblocks, S);
@@ -1376,10 +1380,16 @@ int mbwq_exl2_forward_launch(const void* x, const int32_t* qw, const void* scale
         if (narrow2) hipLaunchKernelGGL((exl2_gemv2_kernel<MTV, NWV, true, DIR>), grid2, dim3(NWV * 64), lds2, st, call, epoch, device_status_word(), skew, spin); \
         else hipLaunchKernelGGL((exl2_gemv2_kernel<MTV, NWV, false, DIR>), grid2, dim3(NWV * 64), lds2, st, call, epoch, device_status_word(), skew, spin);      \
     } while (0)
-        if (nw == 16) {
-            if (MT == 1) { if (direct) L2(1, 16, 1); else L2(1, 16, 0); } else L2(2, 16, 0);
+        if (nw == 16) {  // the staged form has 16 waves for one row only
+            if (MT == 1) { if (direct) L2(1, 16, 1); else L2(1, 16, 0); }
+            else if (MT == 2) L2(2, 16, 1);
+            else L2(4, 16, 1);
+        } else if (MT == 1) {
+            if (direct) L2(1, 8, 1); else L2(1, 8, 0);
+        } else if (MT == 2) {
+            if (direct) L2(2, 8, 1); else L2(2, 8, 0);
         } else {
-            if (MT == 1) { if (direct) L2(1, 8, 1); else L2(1, 8, 0); } else L2(2, 8, 0);
+            L2(4, 8, 1);
         }
 #undef L2
         return check_launch("exl2_gemv2_kernel");
