@@ -448,6 +448,19 @@ def bench_exl2(dev):
         out.append({"op": "exl2 w3/w2 g32 decode, layer list in one launch", "M": 1, "K": K, "N": N, "layers": nset, "us_per_layer": round(us, 2),
                     "roofline": {"bound": "hbm", "achieved": round(byts / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": round(byts / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None}})
+        # siblings on ONE x (every layer its own q_perm): bie_mbwq_exl2_forward_grouped, two launches per group -- what MBWQLinearCuda layers behind
+        # prepare_bie_layers() run for q / k / v and gate / up
+        for nmem in ((3, 2) if N == K else (2,)):
+            if nset < 2 * nmem:
+                continue
+            xg = torch.randn((1, K), device=dev).half()
+            grps = [[(s_[0], s_[1], s_[2], perm, gmap, rows) for s_ in sets[i:i + nmem]] for i in range(0, nset - nmem + 1, nmem)]
+            g = capture(lambda st: [q_linear_cuda.mbwq_exl2_forward_grouped(xg, m) for m in grps])
+            us = time_graph(g, 10) / len(grps)
+            out.append({"op": f"exl2 w3/w2 g32 decode, {nmem} siblings on one x in one grouped call (2 launches)", "M": 1, "K": K, "N": N, "members": nmem,
+                        "us_per_group": round(us, 2), "us_per_layer": round(us / nmem, 2),
+                        "roofline": {"bound": "hbm", "achieved": round(nmem * byts / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": round(nmem * byts / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None}})
         # mid-size batches: M <= 48 the decode stream feeding v_mfma_f32_16x16x32_f16 (x permute launch + exl2_mfma_kernel); beyond, HIP
         # reconstruct + library GEMM (the reference's split for M > 32, mbwq_linear_cuda_kernel.cu:947-957)
         for M in (8, 16, 32, 64):
@@ -926,6 +939,10 @@ def main():
             guarded("c2_gemv_M32_4096x11008", lambda: B.gemv(4096, 11008, 40, 10, 22, M=32))
             guarded("c2_act_order_4096x11008", lambda: bench_act_order(dev))
             guarded("c3_exl2", lambda: bench_exl2(dev))
+            if isinstance(extras.get("c3_exl2"), list):  # configs[2] in the short line: the list form and the sibling groups, fraction of the HBM roofline
+                for r_ in extras["c3_exl2"]:
+                    if "layer list" in r_["op"] or "siblings" in r_["op"]:
+                        out["summary"][("c3_exl2_list_" if "layer list" in r_["op"] else f"c3_exl2_group{r_.get('members')}_") + f"{r_['K']}x{r_['N']}"] = r_["roofline"]["frac"]
             guarded("c3_w2a16_list_4096x4096", lambda: B.gemv_list(4096, 4096, 96, 96, 10, 44, w_bit=2))
             guarded("c3_w2a16_4096x4096", lambda: B.gemv(4096, 4096, 64, 10, 41, w_bit=2))
             guarded("c3_w2a16_4096x11008", lambda: B.gemv(4096, 11008, 40, 10, 42, w_bit=2))

@@ -1262,7 +1262,7 @@ static void exl2_decode_plan(int M, int K, int N, int& cps, int& S, int& nw, boo
     S = cdiv(C, cps);
 }
 
-static int exl2_decode_mt(int M) { return M <= 1 ? 1 : (M <= 2 ? 2 : 4); }  // rows of x the decode kernel is instantiated for
+static int exl2_decode_mt(int M) { return M <= 1 ? 1 : 2; }  // rows of x the decode kernel is instantiated for
 
 static int exl2_slabs(int K, int N) {
     const int C = K / 32;
@@ -1287,7 +1287,7 @@ size_t mbwq_workspace_bytes(int M, int K, int N) {
     size_t c = (size_t)S * mc * N * sizeof(float);
     int cps2, S2, nw2;
     exl2_decode_plan(M, K, N, cps2, S2, nw2);
-    const size_t d = M <= 4 && S2 > 1 ? (size_t)(S2 - 1) * exl2_decode_mt(M) * cdiv(N, 64) * 64 * 8 : 0;  // decode granules (unused when another kernel takes over)
+    const size_t d = M <= 2 && S2 > 1 ? (size_t)(S2 - 1) * exl2_decode_mt(M) * cdiv(N, 64) * 64 * 8 : 0;  // decode granules (unused when another kernel takes over)
     if (d > c) c = d;
     const size_t e = exl2_mfma_granule_bytes(M, K, N);  // 3 <= M <= 64: granules of the matrix-pipe kernel's K slabs
     if (e > c) c = e;
@@ -1353,7 +1353,8 @@ int mbwq_exl2_forward_launch(const void* x, const int32_t* qw, const void* scale
     for (int i = 0; i < 6; i++) rows.r[i] = rows7[i];
     const bool slab_ok = !(cdiv(N, 64) > BIE_WS_COUNTERS && K / 32 > 768);  // K slabs need one generation word per column block
     const bool regular = (rows7[6] & BIE_EXL2_ROWS_REGULAR) && exl2_direct_on();
-    if ((M <= 2 || (M <= 4 && regular)) && slab_ok) {  // decode path: up to four rows ride on one v_mfma_f32_4x4x4 (DIRECT form; the staged form has LDS for two).  (The packed-fp16 kernel instantiated for 4 / 8 rows measured SLOWER than the fp32 kernel below:
+    if (M <= 2 && slab_ok) {  // decode path.  (Three and four rows would ride on the same v_mfma_f32_4x4x4, but the direct form then gathers four rows
+                              //  per chunk and spills: 14.2 / 35.2 / 39.3 us at M = 4 against 13.3 / 22.2 / 19.4 on the matrix-pipe kernel below.)  (The packed-fp16 kernel instantiated for 4 / 8 rows measured SLOWER than the fp32 kernel below:
                    //  33.3 / 46.2 us against 28.0 / 39.9 us at 4096x11008 M = 3 / 8 -- 178-256 registers, one wave per SIMD.)
         const int colblocks = cdiv(N, 64);
         int cps2, S, nw;
@@ -1382,14 +1383,11 @@ int mbwq_exl2_forward_launch(const void* x, const int32_t* qw, const void* scale
     } while (0)
         if (nw == 16) {  // the staged form has 16 waves for one row only
             if (MT == 1) { if (direct) L2(1, 16, 1); else L2(1, 16, 0); }
-            else if (MT == 2) L2(2, 16, 1);
-            else L2(4, 16, 1);
+            else L2(2, 16, 1);
         } else if (MT == 1) {
             if (direct) L2(1, 8, 1); else L2(1, 8, 0);
-        } else if (MT == 2) {
-            if (direct) L2(2, 8, 1); else L2(2, 8, 0);
         } else {
-            L2(4, 8, 1);
+            if (direct) L2(2, 8, 1); else L2(2, 8, 0);
         }
 #undef L2
         return check_launch("exl2_gemv2_kernel");
