@@ -1247,6 +1247,8 @@ static void exl2_decode_plan(int M, int K, int N, int& cps, int& S, int& nw, boo
         // M = 2 keeps the 8-wave form: 1024-thread workgroups cap a wave at 128 registers and the two-row variant spilled 1096 dwords
         nw = 16;
         S = cdiv(C, CPS_MAX);
+        static const int s16 = [] { const char* ev = getenv("BIE_EXL2_NW16_SLABS"); return ev ? atoi(ev) : 0; }();  // tuning: K slabs wanted for 16-wave workgroups
+        if (s16 > S) S = s16;
         cps = cdiv(cdiv(C, S), nw) * nw;
         if (cps > C) cps = C;
         S = cdiv(C, cps);
@@ -1476,7 +1478,7 @@ static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 // column blocks x K slabs, 8-wave workgroups; ~`want` workgroups in all (two per CU and four rounds), a slab at least 4 chunks
 // per wave (the depth of the kernel's prefetch) and at most CPS_MAX chunks (the LDS copy of the slab's q_perm / group map)
 static void exl2_list_plan(int n, const bie_exl2_list_entry* e, std::vector<int>& cps, std::vector<int>& S, long* blocks, size_t* gran_bytes,
-                           size_t* lds, int M) {
+                           size_t* lds, int M, int target_wgs = 0) {
     const int CPS_MAX = 768 / M;
     long colblocks_all = 0;
     for (int i = 0; i < n; i++) colblocks_all += cdiv(e[i].N, 64);
@@ -1484,7 +1486,8 @@ static void exl2_list_plan(int n, const bie_exl2_list_entry* e, std::vector<int>
     *blocks = 0; *gran_bytes = 0; *lds = 0;
     for (int i = 0; i < n; i++) {
         const int C = e[i].K / 32, cb = cdiv(e[i].N, 64);
-        static const int wgs = [] { const char* ev = getenv("BIE_EXL2_LIST_WGS"); return ev && atoi(ev) > 0 ? atoi(ev) : 2048; }();
+        static const int wgs_env = [] { const char* ev = getenv("BIE_EXL2_LIST_WGS"); return ev && atoi(ev) > 0 ? atoi(ev) : 0; }();
+        const int wgs = wgs_env ? wgs_env : (target_wgs ? target_wgs : 2048);
         int want = (int)((wgs + colblocks_all / 2) / colblocks_all);
         if (want < 1) want = 1;
         int c = cdiv(cdiv(C, want), 8) * 8;
@@ -1624,6 +1627,7 @@ int exl2_list_forward(Exl2List* p, hipStream_t st) {
 }
 
 // ---- the group call (bie_mbwq_exl2_forward_grouped) -----------------------------------------------------------------------------
+constexpr int EXL2_GROUP_WGS = 768;  // one round of three workgroups per CU (2 - 3 members: 18.0-18.7 us against 20.4-21.3 with the list's 2048)
 static bool exl2_group_entry_ok(const bie_exl2_list_entry& e) {
     return e.K > 0 && e.N > 0 && e.K % 32 == 0 && e.rows7 && (e.rows7[6] & BIE_EXL2_ROWS_SHUFFLED) && e.rows7[BIE_EXL2_ROWS_LEN - 1] == BIE_EXL2_ROWS_TAG &&
            (e.rows7[6] & BIE_EXL2_ROWS_REGULAR) && e.rows7[5] == e.K;
@@ -1642,7 +1646,7 @@ size_t exl2_group_workspace_bytes(int n, const bie_exl2_list_entry* e) {
     if (!exl2_group_ok(n, e)) return 0;
     std::vector<int> cps, S;
     long blocks; size_t gran, lds;
-    exl2_list_plan(n, e, cps, S, &blocks, &gran, &lds, 1);
+    exl2_list_plan(n, e, cps, S, &blocks, &gran, &lds, 1, EXL2_GROUP_WGS);
     size_t tot = align256(gran);
     for (int i = 0; i < n; i++) tot += align256((size_t)e[i].K * 2) + align256((size_t)(e[i].K / 32) * 8);
     return tot;
@@ -1650,7 +1654,7 @@ size_t exl2_group_workspace_bytes(int n, const bie_exl2_list_entry* e) {
 int exl2_group_forward(int n, const bie_exl2_list_entry* e, const void* x, float* head, char* body, hipStream_t st) {
     std::vector<int> cps, S;
     long blocks; size_t gran, lds;
-    exl2_list_plan(n, e, cps, S, &blocks, &gran, &lds, 1);
+    exl2_list_plan(n, e, cps, S, &blocks, &gran, &lds, 1, EXL2_GROUP_WGS);
     Exl2GroupArgs a;
     std::memset(&a, 0, sizeof(a));
     a.n = n;
