@@ -439,15 +439,18 @@ def bench_exl2(dev):
             out.append({"op": "exl2 w3/w2 g32 decode, one launch per layer", "M": M, "K": K, "N": N, "us_per_launch": round(us, 2),
                         "roofline": {"bound": "hbm", "achieved": round(byts / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": round(byts / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None}})
-        # the same layers, each with its own x, as ONE launch (bie_mbwq_exl2_list_*)
+        # the same layers, each with its own x, as ONE launch (bie_mbwq_exl2_list_*); four rows of x ride on the same matrix instruction
         from bitorch_engine.layers.qlinear.nbit.cuda import MBWQExl2ForwardList
-        ents = [{"x": torch.randn((1, K), device=dev).half(), "qweight": s_[0], "scales": s_[1], "zeros": s_[2], "q_perm": perm, "q_group_map": gmap,
-                 "rows": rows, "y": torch.empty((1, N), dtype=torch.float16, device=dev)} for s_ in sets]
-        plan = MBWQExl2ForwardList(ents)
-        us = time_graph(capture(lambda st: [plan.forward(st) for _ in range(4)]), 10) / (nset * 4)
-        out.append({"op": "exl2 w3/w2 g32 decode, layer list in one launch", "M": 1, "K": K, "N": N, "layers": nset, "us_per_layer": round(us, 2),
-                    "roofline": {"bound": "hbm", "achieved": round(byts / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": round(byts / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None}})
+        for Ml in (1, 4):
+            ents = [{"x": torch.randn((Ml, K), device=dev).half(), "qweight": s_[0], "scales": s_[1], "zeros": s_[2], "q_perm": perm, "q_group_map": gmap,
+                     "rows": rows, "y": torch.empty((Ml, N), dtype=torch.float16, device=dev)} for s_ in sets]
+            plan = MBWQExl2ForwardList(ents)
+            us = time_graph(capture(lambda st: [plan.forward(st) for _ in range(4)]), 10) / (nset * 4)
+            bl = byts + 2 * (Ml - 1) * (K + N)
+            out.append({"op": "exl2 w3/w2 g32 decode, layer list in one launch", "M": Ml, "K": K, "N": N, "layers": nset, "us_per_layer": round(us, 2),
+                        "roofline": {"bound": "hbm", "achieved": round(bl / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": round(bl / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None}})
+            del plan, ents
         # siblings on ONE x (every layer its own q_perm): bie_mbwq_exl2_forward_grouped, two launches per group -- what MBWQLinearCuda layers behind
         # prepare_bie_layers() run for q / k / v and gate / up
         for nmem in ((3, 2) if N == K else (2,)):
@@ -941,7 +944,7 @@ def main():
             guarded("c3_exl2", lambda: bench_exl2(dev))
             if isinstance(extras.get("c3_exl2"), list):  # configs[2] in the short line: the list form and the sibling groups, fraction of the HBM roofline
                 for r_ in extras["c3_exl2"]:
-                    if "layer list" in r_["op"] or "siblings" in r_["op"]:
+                    if ("layer list" in r_["op"] and r_["M"] == 1) or "siblings" in r_["op"]:
                         out["summary"][("c3_exl2_list_" if "layer list" in r_["op"] else f"c3_exl2_group{r_.get('members')}_") + f"{r_['K']}x{r_['N']}"] = r_["roofline"]["frac"]
             guarded("c3_w2a16_list_4096x4096", lambda: B.gemv_list(4096, 4096, 96, 96, 10, 44, w_bit=2))
             guarded("c3_w2a16_4096x4096", lambda: B.gemv(4096, 4096, 64, 10, 41, w_bit=2))

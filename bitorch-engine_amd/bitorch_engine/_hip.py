@@ -39,8 +39,8 @@ SIGNATURES = {
     "bie_mbwq_exl2_list_create": (_i, [_vp, _i, _vp, _i, _vp, _sz]),
     "bie_mbwq_exl2_list_forward": (_i, [_vp, _vp]),
     "bie_mbwq_exl2_list_destroy": (None, [_vp]),
-    "bie_mbwq_exl2_grouped_workspace_bytes": (_sz, [_i, _vp]),
-    "bie_mbwq_exl2_forward_grouped": (_i, [_vp, _i, _vp, _vp, _sz, _vp]),
+    "bie_mbwq_exl2_grouped_workspace_bytes": (_sz, [_i, _vp, _i]),
+    "bie_mbwq_exl2_forward_grouped": (_i, [_vp, _i, _i, _vp, _vp, _sz, _vp]),
     "bie_mpq_dequant": (_i, [_vp] * 5 + [_i] * 6 + [_vp]),
     "bie_mpq_pack": (_i, [_vp] * 5 + [_i] * 6 + [_vp]),
     "bie_mpq_grad_input": (_i, [_vp] * 6 + [_i] * 7 + [_vp]),

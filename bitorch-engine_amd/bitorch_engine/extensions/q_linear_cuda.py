@@ -324,16 +324,16 @@ def mbwq_exl2_forward(x, qweight, scales, zeros, q_perm, q_group_map, rows, use_
 
 
 def mbwq_exl2_forward_grouped(x, members):
-    """Up to 8 exl2 layers on the SAME one-row x in two launches (bie_mbwq_exl2_forward_grouped).  members: sequence of
+    """Up to 8 exl2 layers on the SAME x [M <= 4, K] in two launches (bie_mbwq_exl2_forward_grouped).  members: sequence of
     (qweight, scales, zeros, q_perm or None, q_group_map, rows) as `mbwq_exl2_forward` takes them.  Returns the outputs
-    ([1, N_i] fp16, new tensors), or None when the set is outside the grouped range (irregular groups, K % 32, too many
+    ([M, N_i] fp16, new tensors), or None when the set is outside the grouped range (irregular groups, K % 32, too many
     column blocks) -- the caller then runs the members one by one."""
     import ctypes
     _hip.need_gpu(x, *[t for m in members for t in m[:5] if t is not None])
-    if x.dtype != torch.float16 or x.dim() != 2 or x.shape[0] != 1 or not 1 <= len(members) <= 8:
+    if x.dtype != torch.float16 or x.dim() != 2 or not 1 <= x.shape[0] <= 4 or not 1 <= len(members) <= 8:
         return None
     x = x.contiguous()
-    K = x.shape[1]
+    M, K = x.shape
     L = _hip.lib()
     arr = (_hip.Exl2ListEntry * len(members))()
     keep, outs = [], []
@@ -341,15 +341,15 @@ def mbwq_exl2_forward_grouped(x, members):
         N = qweight.shape[1]
         tabl, rp = _rows_arg(rows)
         sc, ze = scales.contiguous(), zeros.contiguous()
-        y = torch.empty((1, N), dtype=torch.float16, device=x.device)
+        y = torch.empty((M, N), dtype=torch.float16, device=x.device)
         arr[i] = _hip.Exl2ListEntry(None, qweight.data_ptr(), sc.data_ptr(), ze.data_ptr(), None if q_perm is None else q_perm.data_ptr(),
                                     q_group_map.data_ptr(), rp, y.data_ptr(), K, N, 0, 0)
         keep.append((tabl, sc, ze))
         outs.append(y)
-    nbytes = L.bie_mbwq_exl2_grouped_workspace_bytes(len(members), arr)
+    nbytes = L.bie_mbwq_exl2_grouped_workspace_bytes(len(members), arr, M)
     if nbytes == 0:
         return None
     ws = _hip.workspace(nbytes, x.device)
-    rc = L.bie_mbwq_exl2_forward_grouped(_hip.ptr(x), len(members), arr, _hip.ptr(ws), ws.numel(), _hip.stream())
+    rc = L.bie_mbwq_exl2_forward_grouped(_hip.ptr(x), M, len(members), arr, _hip.ptr(ws), ws.numel(), _hip.stream())
     _hip.check(rc, "bie_mbwq_exl2_forward_grouped")
     return outs

@@ -67,9 +67,9 @@ size_t exl2_list_device_bytes(int n, const bie_exl2_list_entry* e, int M);
 int exl2_list_create(Exl2List** out, int n, const bie_exl2_list_entry* e, int M, void* device_mem, size_t device_bytes);
 int exl2_list_forward(Exl2List* p, hipStream_t st);
 void exl2_list_destroy(Exl2List* p);
-bool exl2_group_ok(int n, const bie_exl2_list_entry* e);
-size_t exl2_group_workspace_bytes(int n, const bie_exl2_list_entry* e);
-int exl2_group_forward(int n, const bie_exl2_list_entry* e, const void* x, float* head, char* body, hipStream_t st);
+bool exl2_group_ok(int n, const bie_exl2_list_entry* e, int M);
+size_t exl2_group_workspace_bytes(int n, const bie_exl2_list_entry* e, int M);
+int exl2_group_forward(int n, const bie_exl2_list_entry* e, const void* x, int M, float* head, char* body, hipStream_t st);
 // binary.hip
 int pack_rows_launch(const void* a, uint8_t* out, long n_bytes, int dtype, hipStream_t st);
 int pack_cols_launch(const void* w, uint8_t* out, long N, long K, int dtype, hipStream_t st);
@@ -445,22 +445,22 @@ int bie_mbwq_exl2_list_create(bie_exl2_list_t** plan, int n_entries, const bie_e
 int bie_mbwq_exl2_list_forward(bie_exl2_list_t* plan, void* stream) { return exl2_list_forward(reinterpret_cast<Exl2List*>(plan), as_stream(stream)); }
 void bie_mbwq_exl2_list_destroy(bie_exl2_list_t* plan) { exl2_list_destroy(reinterpret_cast<Exl2List*>(plan)); }
 
-size_t bie_mbwq_exl2_grouped_workspace_bytes(int n_members, const bie_exl2_list_entry* members) {
-    const size_t b = exl2_group_workspace_bytes(n_members, members);
+size_t bie_mbwq_exl2_grouped_workspace_bytes(int n_members, const bie_exl2_list_entry* members, int M) {
+    const size_t b = exl2_group_workspace_bytes(n_members, members, M);
     return b ? WS_HEAD + b : 0;
 }
-int bie_mbwq_exl2_forward_grouped(const void* x, int n_members, const bie_exl2_list_entry* members, void* workspace, size_t workspace_bytes, void* stream) {
+int bie_mbwq_exl2_forward_grouped(const void* x, int M, int n_members, const bie_exl2_list_entry* members, void* workspace, size_t workspace_bytes, void* stream) {
     BIE_REQUIRE(x && members && n_members >= 1, BIE_ERR_INVALID_ARG, "bie_mbwq_exl2_forward_grouped: bad argument");
-    BIE_REQUIRE(exl2_group_ok(n_members, members), BIE_ERR_UNSUPPORTED,
-                "bie_mbwq_exl2_forward_grouped: takes 1..8 members with K %% 32 == 0, tables from bie_mbwq_exl2_shuffle carrying the REGULAR mark, at most %d column blocks in all", BIE_WS_COUNTERS);
+    BIE_REQUIRE(exl2_group_ok(n_members, members, M), BIE_ERR_UNSUPPORTED,
+                "bie_mbwq_exl2_forward_grouped: takes 1..4 rows of x and 1..8 members with K %% 32 == 0, tables from bie_mbwq_exl2_shuffle carrying the REGULAR mark, at most %d column blocks in all", BIE_WS_COUNTERS);
     for (int i = 0; i < n_members; i++)
         BIE_REQUIRE(members[i].qweight && members[i].scales && members[i].zeros && members[i].q_group_map && members[i].y, BIE_ERR_INVALID_ARG,
                     "bie_mbwq_exl2_forward_grouped: NULL tensor pointer in member %d", i);
-    const size_t need = bie_mbwq_exl2_grouped_workspace_bytes(n_members, members);
+    const size_t need = bie_mbwq_exl2_grouped_workspace_bytes(n_members, members, M);
     BIE_REQUIRE(workspace && workspace_bytes >= need, BIE_ERR_WORKSPACE, "bie_mbwq_exl2_forward_grouped: workspace of %zu bytes required, got %zu", need, workspace_bytes);
     int rc = status_report("bie_mbwq_exl2_forward_grouped");
     if (rc) return rc;
-    return exl2_group_forward(n_members, members, x, (float*)workspace, (char*)workspace + WS_HEAD, as_stream(stream));
+    return exl2_group_forward(n_members, members, x, M, (float*)workspace, (char*)workspace + WS_HEAD, as_stream(stream));
 }
 
 // ---------------------------------------------------------------------------------------------- binary

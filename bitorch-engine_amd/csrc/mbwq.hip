@@ -471,7 +471,6 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
     constexpr bool DIRECT = DMODE != 0;
     constexpr bool XP = DMODE == 2;
     static_assert(!DIRECT || !STAGED, "the direct forms stage nothing");
-    static_assert(!XP || MT == 1, "the pre-permuted form serves one row of x");
     extern __shared__ __attribute__((aligned(16))) uint32_t smem2[];
     const int tid = threadIdx.x, lane = tid & 63;
     // the tile's generation is read ONCE, at kernel entry, by every wave: the reducer advances the word as soon as it is done, and a
@@ -494,14 +493,18 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
     uint16_t* xs = reinterpret_cast<uint16_t*>(smem2) + wave * (4 * MT * 32);  // !STAGED: wave-private [set 0..3][MT][32]
     uint16_t* perm_s = reinterpret_cast<uint16_t*>(smem2) + EX2_NW * (4 * MT * 32);  // !STAGED: [slab_k]
     uint16_t* gmap_s = STAGED ? x_s + MT * slab_k : perm_s + slab_k;           // [chunks_per_slab * 2]
-    float2_t* cs_s = reinterpret_cast<float2_t*>(x_s + slab_k);                // DMODE 2: [chunks_per_slab] behind the one row of x
+    float2_t* cs_s = reinterpret_cast<float2_t*>(x_s + MT * slab_k);           // DMODE 2: [MT][chunks_per_slab] behind the rows of x
     int two_groups = 0;  // does any chunk of the slab straddle two groups (group sizes below 32)?
     if constexpr (XP) {
-        const int n16 = (c_end - c_begin) * 4;  // 16-byte pieces of the slab
-        const uint4_t* src = reinterpret_cast<const uint4_t*>(xp + (long)c_begin * 32);
-        uint4_t* dst = reinterpret_cast<uint4_t*>(x_s);
-        for (int i = tid; i < n16; i += EX2_NW * 64) dst[i] = src[i];
-        for (int i = tid; i < (c_end - c_begin); i += EX2_NW * 64) cs_s[i] = cs[c_begin + i];
+        const int n16 = (c_end - c_begin) * 4;  // 16-byte pieces of a row's slab
+#pragma unroll
+        for (int m = 0; m < MT; m++) {  // rows beyond M copy row M - 1: never stored, never out of bounds
+            const int mr = m < M ? m : M - 1;
+            const uint4_t* src = reinterpret_cast<const uint4_t*>(xp + (long)mr * K + (long)c_begin * 32);
+            uint4_t* dst = reinterpret_cast<uint4_t*>(x_s + m * slab_k);
+            for (int i = tid; i < n16; i += EX2_NW * 64) dst[i] = src[i];
+            for (int i = tid; i < (c_end - c_begin); i += EX2_NW * 64) cs_s[m * chunks_per_slab + i] = cs[(long)mr * C + c_begin + i];
+        }
         __syncthreads();
     }
     if constexpr (!DIRECT) {
@@ -526,7 +529,7 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
     float yacc[MT];
 #pragma unroll
     for (int m = 0; m < MT; m++) yacc[m] = 0.f;
-    const int xrow = MT > 1 ? ((lane & 3) < M ? (lane & 3) : M - 1) : 0;  // the row of x this lane feeds the matrix pipe with
+    const int xrow = MT > 1 ? ((lane & 3) < M ? (lane & 3) : M - 1) : 0;  // the row of x this lane feeds the matrix pipe with (MT <= 4)
     const Exl2Magic magic;
     uint2_t ones2 = uint2_t{0x3c003c00u, 0x3c003c00u};
     asm("" : "+v"(ones2));  // matrix operands are registers
@@ -641,9 +644,12 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
             const exl2_acc_t zero4 = exl2_acc_t{0.f, 0.f, 0.f, 0.f};
             exl2_acc_t dq = zero4, dc = zero4, dx = zero4;
             if constexpr (XP) {
-                const float2_t v = cs_s[c - c_begin];
-                dc = exl2_acc_t{v.x, v.x, v.x, v.x};
-                dx = exl2_acc_t{v.y, v.y, v.y, v.y};
+#pragma unroll
+                for (int m = 0; m < MT; m++) {
+                    const float2_t v = cs_s[m * chunks_per_slab + (c - c_begin)];
+                    dc[m] = v.x;
+                    dx[m] = v.y;
+                }
             }
             auto apply = [&](int half) {  // the constants of the group the half (or the whole chunk) lies in
                 const float sf = (float)__builtin_bit_cast(half_t, (uint16_t)ch.s[half]);
@@ -1141,12 +1147,12 @@ __device__ __forceinline__ void exl2_list_body(const Exl2Call* __restrict__ ent,
     Exl2Groups grp;
 #pragma unroll
     for (int i = 0; i < 6; i++) { grp.gfirst[i] = c->gfirst[i]; grp.glog[i] = c->glog[i]; }
-    exl2_gemv2_body<MT, 8, (MT > 1), NARROW, DMODE>(c->x, c->qw, c->scales, c->zeros, c->perm, c->gmap, c->gran, c->gen, c->y, rows, c->M, c->K, c->N,
+    exl2_gemv2_body<MT, 8, (MT > 1 && DMODE == 0), NARROW, DMODE>(c->x, c->qw, c->scales, c->zeros, c->perm, c->gmap, c->gran, c->gen, c->y, rows, c->M, c->K, c->N,
                                              c->chunks_per_slab, c->S, (int)(rec.y & 0xfffffu), (int)(rec.y >> 20), c->colblocks, epoch, status,
                                              tag_skew, spin_limit, grp, c->xp, c->cs);
 }
 template <int MT, bool NARROW, int DMODE>
-__global__ __launch_bounds__(512, ((DMODE == 2 && NARROW) ? 6 : 4)) void exl2_list_kernel(const Exl2Call* __restrict__ ent, const uint2_t* __restrict__ blk, unsigned epoch,
+__global__ __launch_bounds__(512, ((DMODE == 2 && NARROW && MT == 1) ? 6 : 4)) void exl2_list_kernel(const Exl2Call* __restrict__ ent, const uint2_t* __restrict__ blk, unsigned epoch,
                                                            unsigned* status, unsigned tag_skew, int spin_limit) {
     exl2_list_body<MT, NARROW, DMODE>(ent, blk, epoch, status, tag_skew, spin_limit);
 }
@@ -1162,24 +1168,33 @@ __device__ __forceinline__ float exl2_offset_of(int bits, int j) {  // pair j of
         if (q + bits - b0 > 10) b0 = q;
     return (float)(1 << (10 - (p - b0)));
 }
+// position k of every row of x: xp[m][k] = x[m][q_perm[k]]; the 32 lanes of a chunk reduce its two sums (cs[m][k / 32])
+__device__ __forceinline__ void exl2_permute_rows(const uint16_t* __restrict__ x, const uint16_t* __restrict__ perm, uint16_t* __restrict__ xp,
+                                                  float2_t* __restrict__ cs, const Exl2Rows& rows, int M, int K, int k) {
+    const int src = perm ? (int)perm[k] : k;
+    int bits = 2;
+#pragma unroll
+    for (int b = 5; b >= 0; b--)
+        if (k < rows.r[b]) bits = exl2_bits_of_band(b);  // the first band whose end lies beyond k
+    const float ofs = exl2_offset_of(bits, (k & 31) >> 1);
+    for (int m = 0; m < M; m++) {
+        const uint16_t xb = x[(long)m * K + src];
+        xp[(long)m * K + k] = xb;
+        const float xv = f16_bits_to_f32(xb);
+        float so = ofs * xv, sx = xv;
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) {
+            so += __shfl_xor(so, d, 32);
+            sx += __shfl_xor(sx, d, 32);
+        }
+        if ((k & 31) == 0) cs[(long)m * (K >> 5) + (k >> 5)] = float2_t{so, sx};
+    }
+}
 __global__ __launch_bounds__(256) void exl2_list_permute_kernel(const Exl2Call* __restrict__ ent) {
     const Exl2Call& e = ent[blockIdx.y];
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= e.K) return;  // K % 32 == 0: whole 32-lane groups leave together
-    const uint16_t xb = e.x[e.perm ? (int)e.perm[k] : k];
-    const_cast<uint16_t*>(e.xp)[k] = xb;
-    int bits = 2;
-#pragma unroll
-    for (int b = 5; b >= 0; b--)
-        if (k < e.rows.r[b]) bits = exl2_bits_of_band(b);  // the first band whose end lies beyond k
-    const float xv = f16_bits_to_f32(xb);
-    float so = exl2_offset_of(bits, (k & 31) >> 1) * xv, sx = xv;
-#pragma unroll
-    for (int d = 1; d < 32; d <<= 1) {
-        so += __shfl_xor(so, d, 32);
-        sx += __shfl_xor(sx, d, 32);
-    }
-    if ((k & 31) == 0) const_cast<float2_t*>(e.cs)[k >> 5] = float2_t{so, sx};
+    exl2_permute_rows(e.x, e.perm, const_cast<uint16_t*>(e.xp), const_cast<float2_t*>(e.cs), e.rows, e.M, e.K, k);
 }
 // ---- a GROUP of up to 8 exl2 layers that consume the same one-row x (q / k / v, gate / up), everything in the kernel arguments ----------
 // bie_mbwq_exl2_forward_grouped: no plan object and no device table -- the call descriptors travel in the kernel-argument segment and
@@ -1191,8 +1206,8 @@ struct Exl2GroupArgs {
     int first_block[EXL2_GROUP_MAX + 1];  // prefix sums of colblocks * S
     Exl2Call ent[EXL2_GROUP_MAX];
 };
-template <bool NARROW>
-__global__ __launch_bounds__(512, (NARROW ? 6 : 4)) void exl2_group_kernel(const Exl2GroupArgs a, unsigned epoch, unsigned* status, unsigned tag_skew, int spin_limit) {
+template <int MT, bool NARROW>
+__global__ __launch_bounds__(512, ((NARROW && MT == 1) ? 6 : 4)) void exl2_group_kernel(const Exl2GroupArgs a, unsigned epoch, unsigned* status, unsigned tag_skew, int spin_limit) {
     typedef const __attribute__((address_space(4))) Exl2Call ccall_t;
     int ei = 0;
 #pragma unroll
@@ -1208,7 +1223,7 @@ __global__ __launch_bounds__(512, (NARROW ? 6 : 4)) void exl2_group_kernel(const
 #pragma unroll
     for (int i = 0; i < 6; i++) { grp.gfirst[i] = c->gfirst[i]; grp.glog[i] = c->glog[i]; }
     const int cb = c->colblocks;
-    exl2_gemv2_body<1, 8, false, NARROW, 2>(c->x, c->qw, c->scales, c->zeros, c->perm, c->gmap, c->gran, c->gen, c->y, rows, 1, c->K, c->N,
+    exl2_gemv2_body<MT, 8, false, NARROW, 2>(c->x, c->qw, c->scales, c->zeros, c->perm, c->gmap, c->gran, c->gen, c->y, rows, c->M, c->K, c->N,
                                             c->chunks_per_slab, c->S, local % cb, local / cb, cb, epoch, status, tag_skew, spin_limit, grp, c->xp, c->cs);
 }
 __global__ __launch_bounds__(256) void exl2_group_permute_kernel(const Exl2GroupArgs a) {
@@ -1218,21 +1233,10 @@ __global__ __launch_bounds__(256) void exl2_group_permute_kernel(const Exl2Group
     const int K = e->K;
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= K) return;
-    const uint16_t* perm = e->perm;
-    const uint16_t xb = e->x[perm ? (int)perm[k] : k];
-    const_cast<uint16_t*>(e->xp)[k] = xb;
-    int bits = 2;
+    Exl2Rows rows;
 #pragma unroll
-    for (int b = 5; b >= 0; b--)
-        if (k < e->rows.r[b]) bits = exl2_bits_of_band(b);
-    const float xv = f16_bits_to_f32(xb);
-    float so = exl2_offset_of(bits, (k & 31) >> 1) * xv, sx = xv;
-#pragma unroll
-    for (int d = 1; d < 32; d <<= 1) {
-        so += __shfl_xor(so, d, 32);
-        sx += __shfl_xor(sx, d, 32);
-    }
-    if ((k & 31) == 0) const_cast<float2_t*>(e->cs)[k >> 5] = float2_t{so, sx};
+    for (int i = 0; i < 6; i++) rows.r[i] = e->rows.r[i];
+    exl2_permute_rows(e->x, e->perm, const_cast<uint16_t*>(e->xp), const_cast<float2_t*>(e->cs), rows, e->M, K, k);
 }
 
 // decode (M <= 2): column blocks x K slabs ~ 512 workgroups of 8 waves (two per CU -> one round), slabs in whole multiples of
@@ -1477,8 +1481,15 @@ static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
 // column blocks x K slabs, 8-wave workgroups; ~`want` workgroups in all (two per CU and four rounds), a slab at least 4 chunks
 // per wave (the depth of the kernel's prefetch) and at most CPS_MAX chunks (the LDS copy of the slab's q_perm / group map)
+static int exl2_rows_mt(int M) { return M <= 1 ? 1 : (M <= 2 ? 2 : 4); }  // rows of x the list / group kernels are instantiated for
+static bool exl2_all_regular(int n, const bie_exl2_list_entry* e) {
+    for (int i = 0; i < n; i++)
+        if (!e[i].rows7 || !(e[i].rows7[6] & BIE_EXL2_ROWS_REGULAR)) return false;
+    return true;
+}
 static void exl2_list_plan(int n, const bie_exl2_list_entry* e, std::vector<int>& cps, std::vector<int>& S, long* blocks, size_t* gran_bytes,
-                           size_t* lds, int M, int target_wgs = 0) {
+                           size_t* lds, int Mrows, int target_wgs = 0) {
+    const int M = exl2_rows_mt(Mrows);  // everything below is sized for the instantiated row count
     const int CPS_MAX = 768 / M;
     long colblocks_all = 0;
     for (int i = 0; i < n; i++) colblocks_all += cdiv(e[i].N, 64);
@@ -1497,22 +1508,27 @@ static void exl2_list_plan(int n, const bie_exl2_list_entry* e, std::vector<int>
         cps[i] = c;
         S[i] = cdiv(C, c);
         *blocks += (long)cb * S[i];
-        if (S[i] > 1) *gran_bytes += (size_t)(S[i] - 1) * M * cb * 64 * 8;
+        if (S[i] > 1) *gran_bytes += (size_t)(S[i] - 1) * M * cb * 64 * 8;  // M = the instantiated row count
         size_t l = M > 1 ? (size_t)c * (32 * M + 2) * sizeof(uint16_t) : (size_t)8 * 4 * M * 32 * sizeof(uint16_t) + (size_t)c * 34 * sizeof(uint16_t);
-        if (M == 1 && l < (size_t)c * 72) l = (size_t)c * 72;  // DMODE 2: the slab of xp (64 bytes per chunk) + its {offset sum, x sum} pairs
+        if (l < (size_t)c * 72 * M) l = (size_t)c * 72 * M;  // DMODE 2: per row the slab of xp (64 bytes per chunk) + its {offset sum, x sum} pairs
         const size_t red = (size_t)8 * M * 64 * sizeof(float);
         if (l < red) l = red;
         if (l > *lds) *lds = l;
     }
 }
 
+static bool exl2_xp_on() {
+    static const bool on = [] { const char* ev = getenv("BIE_EXL2_XP"); return !ev || atoi(ev) != 0; }();
+    return on;
+}
+// M <= 2 always (staged form); 3 and 4 rows ride on the same matrix instruction in the pre-permuted form (regular groups)
 static bool exl2_list_ok(int n, const bie_exl2_list_entry* e, int M) {
-    if (n <= 0 || !e || M < 1 || M > 2) return false;
+    if (n <= 0 || !e || M < 1 || M > 4) return false;
     for (int i = 0; i < n; i++) {
         if (e[i].K <= 0 || e[i].N <= 0 || e[i].K % 32 || !e[i].rows7) return false;
         if (cdiv(e[i].N, 64) >= (1 << 20)) return false;
     }
-    return true;
+    return M <= 2 || (exl2_all_regular(n, e) && exl2_direct_on() && exl2_xp_on());
 }
 
 size_t exl2_list_device_bytes(int n, const bie_exl2_list_entry* e, int M) {
@@ -1523,13 +1539,13 @@ size_t exl2_list_device_bytes(int n, const bie_exl2_list_entry* e, int M) {
     long tiles = 0;
     for (int i = 0; i < n; i++) tiles += cdiv(e[i].N, 64);
     size_t xp = 0;
-    for (int i = 0; i < n; i++) xp += align256((size_t)e[i].K * 2) + align256((size_t)(e[i].K / 32) * 8);
+    for (int i = 0; i < n; i++) xp += align256((size_t)M * e[i].K * 2) + align256((size_t)M * (e[i].K / 32) * 8);
     return align256((size_t)n * sizeof(Exl2Call)) + align256((size_t)blocks * 8) + align256((size_t)tiles * 4) + align256(gran) + xp;
 }
 
 int exl2_list_create(Exl2List** out, int n, const bie_exl2_list_entry* e, int M, void* device_mem, size_t device_bytes) {
     BIE_REQUIRE(out && e && device_mem, BIE_ERR_INVALID_ARG, "bie_mbwq_exl2_list_create: NULL argument");
-    BIE_REQUIRE(exl2_list_ok(n, e, M), BIE_ERR_UNSUPPORTED, "bie_mbwq_exl2_list_create: a list takes 1 <= M <= 2 and K %% 32 == 0 (fp16 only)");
+    BIE_REQUIRE(exl2_list_ok(n, e, M), BIE_ERR_UNSUPPORTED, "bie_mbwq_exl2_list_create: a list takes 1 <= M <= 2 (3, 4 when every entry's table carries the REGULAR mark) and K %% 32 == 0 (fp16 only)");
     for (int i = 0; i < n; i++) {
         BIE_REQUIRE(e[i].x && e[i].qweight && e[i].scales && e[i].zeros && e[i].q_group_map && e[i].y, BIE_ERR_INVALID_ARG, "bie_mbwq_exl2_list_create: NULL tensor pointer in entry %d", i);
         int prev = 0;
@@ -1550,7 +1566,7 @@ int exl2_list_create(Exl2List** out, int n, const bie_exl2_list_entry* e, int M,
     const size_t o_blk = align256((size_t)n * sizeof(Exl2Call)), o_gen = o_blk + align256((size_t)blocks * 8), o_gran = o_gen + align256((size_t)tiles * 4);
     const size_t o_xp = o_gran + align256(gran);
     size_t xp_bytes = 0;
-    for (int i = 0; i < n; i++) xp_bytes += align256((size_t)e[i].K * 2) + align256((size_t)(e[i].K / 32) * 8);
+    for (int i = 0; i < n; i++) xp_bytes += align256((size_t)M * e[i].K * 2) + align256((size_t)M * (e[i].K / 32) * 8);
     BIE_REQUIRE(device_bytes >= o_xp + xp_bytes, BIE_ERR_WORKSPACE, "bie_mbwq_exl2_list_create: device buffer of %zu bytes required, got %zu", o_xp + xp_bytes, device_bytes);
     char* base = static_cast<char*>(device_mem);
     std::vector<Exl2Call> he(n);
@@ -1567,14 +1583,14 @@ int exl2_list_create(Exl2List** out, int n, const bie_exl2_list_entry* e, int M,
         c.qw = (const uint32_t*)e[i].qweight; c.scales = (const uint16_t*)e[i].scales; c.zeros = (const uint16_t*)e[i].zeros;
         c.perm = (const uint16_t*)e[i].q_perm; c.gmap = (const uint16_t*)e[i].q_group_map; c.y = (uint16_t*)e[i].y;
         c.gran = S[i] > 1 ? reinterpret_cast<unsigned long long*>(base + go) : nullptr;
-        if (S[i] > 1) go += (size_t)(S[i] - 1) * M * cb * 64 * 8;
+        if (S[i] > 1) go += (size_t)(S[i] - 1) * exl2_rows_mt(M) * cb * 64 * 8;
         c.gen = reinterpret_cast<unsigned*>(base + o_gen) + t0;
         for (int k = 0; k < 6; k++) c.rows.r[k] = e[i].rows7[k];
         exl2_fill_groups(c, e[i].rows7);
         c.xp = reinterpret_cast<const uint16_t*>(base + xo);
-        xo += align256((size_t)e[i].K * 2);
+        xo += align256((size_t)M * e[i].K * 2);
         c.cs = reinterpret_cast<const float2_t*>(base + xo);
-        xo += align256((size_t)(e[i].K / 32) * 8);
+        xo += align256((size_t)M * (e[i].K / 32) * 8);
         if (c.perm) any_perm = true;
         c.M = M; c.K = e[i].K; c.N = e[i].N; c.chunks_per_slab = cps[i]; c.S = S[i]; c.colblocks = cb;
         BIE_REQUIRE(S[i] < 4096, BIE_ERR_UNSUPPORTED, "bie_mbwq_exl2_list_create: entry %d needs %d K slabs (< 4096)", i, S[i]);
@@ -1594,8 +1610,7 @@ int exl2_list_create(Exl2List** out, int n, const bie_exl2_list_entry* e, int M,
         if (e[i].rows7[2] != 0) pl->narrow = false;
         if (!(e[i].rows7[6] & BIE_EXL2_ROWS_REGULAR)) pl->direct = false;
     }
-    static const bool xp_on = [] { const char* ev = getenv("BIE_EXL2_XP"); return !ev || atoi(ev) != 0; }();
-    pl->xp = pl->direct && xp_on;
+    pl->xp = exl2_all_regular(n, e) && exl2_direct_on() && exl2_xp_on();
     pl->d_ent = reinterpret_cast<Exl2Call*>(base);
     pl->d_blk = reinterpret_cast<uint2_t*>(base + o_blk);
     *out = pl;
@@ -1620,8 +1635,13 @@ int exl2_list_forward(Exl2List* p, hipStream_t st) {
         rc = check_launch("exl2_list_permute_kernel");
         if (rc) return rc;
     }
-    if (p->M == 1) { if (p->xp) LL(1, 2); else if (p->direct) LL(1, 1); else LL(1, 0); }
-    else LL(2, 0);
+    if (p->xp) {
+        if (p->M == 1) LL(1, 2); else if (p->M == 2) LL(2, 2); else LL(4, 2);
+    } else if (p->M == 1) {
+        if (p->direct) LL(1, 1); else LL(1, 0);
+    } else {
+        LL(2, 0);
+    }
 #undef LL
     return check_launch("exl2_list_kernel");
 }
@@ -1632,8 +1652,8 @@ static bool exl2_group_entry_ok(const bie_exl2_list_entry& e) {
     return e.K > 0 && e.N > 0 && e.K % 32 == 0 && e.rows7 && (e.rows7[6] & BIE_EXL2_ROWS_SHUFFLED) && e.rows7[BIE_EXL2_ROWS_LEN - 1] == BIE_EXL2_ROWS_TAG &&
            (e.rows7[6] & BIE_EXL2_ROWS_REGULAR) && e.rows7[5] == e.K;
 }
-bool exl2_group_ok(int n, const bie_exl2_list_entry* e) {
-    if (n < 1 || n > EXL2_GROUP_MAX || !e || !exl2_direct_on()) return false;
+bool exl2_group_ok(int n, const bie_exl2_list_entry* e, int M) {
+    if (n < 1 || n > EXL2_GROUP_MAX || !e || !exl2_direct_on() || M < 1 || M > 4) return false;
     long cbs = 0;
     for (int i = 0; i < n; i++) {
         if (!exl2_group_entry_ok(e[i])) return false;
@@ -1642,19 +1662,20 @@ bool exl2_group_ok(int n, const bie_exl2_list_entry* e) {
     return cbs <= BIE_WS_COUNTERS;  // one generation word per column block in the workspace head
 }
 // behind the 16 KiB head: granules of the K slabs, then per member xp (K fp16) and cs (K / 32 float2)
-size_t exl2_group_workspace_bytes(int n, const bie_exl2_list_entry* e) {
-    if (!exl2_group_ok(n, e)) return 0;
+size_t exl2_group_workspace_bytes(int n, const bie_exl2_list_entry* e, int M) {
+    if (!exl2_group_ok(n, e, M)) return 0;
     std::vector<int> cps, S;
     long blocks; size_t gran, lds;
-    exl2_list_plan(n, e, cps, S, &blocks, &gran, &lds, 1, EXL2_GROUP_WGS);
+    exl2_list_plan(n, e, cps, S, &blocks, &gran, &lds, M, EXL2_GROUP_WGS);
     size_t tot = align256(gran);
-    for (int i = 0; i < n; i++) tot += align256((size_t)e[i].K * 2) + align256((size_t)(e[i].K / 32) * 8);
+    for (int i = 0; i < n; i++) tot += align256((size_t)M * e[i].K * 2) + align256((size_t)M * (e[i].K / 32) * 8);
     return tot;
 }
-int exl2_group_forward(int n, const bie_exl2_list_entry* e, const void* x, float* head, char* body, hipStream_t st) {
+int exl2_group_forward(int n, const bie_exl2_list_entry* e, const void* x, int M, float* head, char* body, hipStream_t st) {
     std::vector<int> cps, S;
     long blocks; size_t gran, lds;
-    exl2_list_plan(n, e, cps, S, &blocks, &gran, &lds, 1, EXL2_GROUP_WGS);
+    exl2_list_plan(n, e, cps, S, &blocks, &gran, &lds, M, EXL2_GROUP_WGS);
+    const int MT = exl2_rows_mt(M);
     Exl2GroupArgs a;
     std::memset(&a, 0, sizeof(a));
     a.n = n;
@@ -1669,15 +1690,15 @@ int exl2_group_forward(int n, const bie_exl2_list_entry* e, const void* x, float
         c.qw = (const uint32_t*)e[i].qweight; c.scales = (const uint16_t*)e[i].scales; c.zeros = (const uint16_t*)e[i].zeros;
         c.perm = (const uint16_t*)e[i].q_perm; c.gmap = (const uint16_t*)e[i].q_group_map; c.y = (uint16_t*)e[i].y;
         c.gran = S[i] > 1 ? reinterpret_cast<unsigned long long*>(body + go) : nullptr;
-        if (S[i] > 1) go += (size_t)(S[i] - 1) * cb * 64 * 8;
+        if (S[i] > 1) go += (size_t)(S[i] - 1) * MT * cb * 64 * 8;
         c.gen = gen + t0;
         for (int k = 0; k < 6; k++) c.rows.r[k] = e[i].rows7[k];
         exl2_fill_groups(c, e[i].rows7);
         c.xp = reinterpret_cast<const uint16_t*>(body + xo);
-        xo += align256((size_t)e[i].K * 2);
+        xo += align256((size_t)M * e[i].K * 2);
         c.cs = reinterpret_cast<const float2_t*>(body + xo);
-        xo += align256((size_t)(e[i].K / 32) * 8);
-        c.M = 1; c.K = e[i].K; c.N = e[i].N; c.chunks_per_slab = cps[i]; c.S = S[i]; c.colblocks = cb;
+        xo += align256((size_t)M * (e[i].K / 32) * 8);
+        c.M = M; c.K = e[i].K; c.N = e[i].N; c.chunks_per_slab = cps[i]; c.S = S[i]; c.colblocks = cb;
         BIE_REQUIRE(S[i] < 4096, BIE_ERR_UNSUPPORTED, "bie_mbwq_exl2_forward_grouped: member %d needs %d K slabs (< 4096)", i, S[i]);
         a.first_block[i] = (int)(i == 0 ? 0 : a.first_block[i - 1] + (long)cdiv(e[i - 1].N, 64) * S[i - 1]);
         if (e[i].K > a.max_k) a.max_k = e[i].K;
@@ -1692,8 +1713,13 @@ int exl2_group_forward(int n, const bie_exl2_list_entry* e, const void* x, float
     hipLaunchKernelGGL(exl2_group_permute_kernel, dim3(cdiv(a.max_k, 256), n), dim3(256), 0, st, a);
     int rc = check_launch("exl2_group_permute_kernel");
     if (rc) return rc;
-    if (narrow) hipLaunchKernelGGL((exl2_group_kernel<true>), dim3((unsigned)blocks), dim3(512), lds, st, a, epoch, device_status_word(), skew, spin);
-    else hipLaunchKernelGGL((exl2_group_kernel<false>), dim3((unsigned)blocks), dim3(512), lds, st, a, epoch, device_status_word(), skew, spin);
+#define LG(MTV)                                                                                                                                             \
+    do {                                                                                                                                                    \
+        if (narrow) hipLaunchKernelGGL((exl2_group_kernel<MTV, true>), dim3((unsigned)blocks), dim3(512), lds, st, a, epoch, device_status_word(), skew, spin); \
+        else hipLaunchKernelGGL((exl2_group_kernel<MTV, false>), dim3((unsigned)blocks), dim3(512), lds, st, a, epoch, device_status_word(), skew, spin);      \
+    } while (0)
+    if (MT == 1) LG(1); else if (MT == 2) LG(2); else LG(4);
+#undef LG
     return check_launch("exl2_group_kernel");
 }
 

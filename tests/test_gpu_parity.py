@@ -1198,6 +1198,16 @@ def test_exl2_grouped_forward_against_the_oracle_and_the_single_launches():
         singles = [l(x.to(DEV)) for l in layers]
         for i, (o, sgl) in enumerate(zip(outs, singles)):
             assert_close(o, sgl.float().cpu().half(), orc.F16, f"exl2 grouped member {i} vs its own launch")
+        # two to four rows of x: same two launches, every row against its own single-row result (same kernel body, same sums)
+        for M in (2, 3, 4):
+            xm = torch.randn((M, K), generator=gen).half()
+            xm[0] = x[0]
+            outs_m = MBWQLinearCuda.forward_grouped(layers, xm.to(DEV))
+            for i, (o, l) in enumerate(zip(outs_m, layers)):
+                assert o.shape == (M, l.out_channels)
+                assert torch.equal(o[0], outs[i][0]), f"row 0 of member {i} at M={M} differs from the one-row call"
+                rows_alone = torch.cat([MBWQLinearCuda.forward_grouped(layers, xm[r:r + 1].to(DEV))[i] for r in range(M)], 0)
+                assert torch.equal(o, rows_alone), f"member {i}, M={M}: rows differ from one-row calls"
         # an irregular member: not groupable, the set falls back to one launch per member
         odd, qw, qg = _exl2_layer(K, 136, [(4, 96)] * 4 + [(2, 32)] * 20, gen)
         odd.eval().to(DEV)
@@ -2106,7 +2116,7 @@ def test_binary_linear_cutlass_mm_and_batched_matmul_follow_the_reference_signat
     assert outb.dtype == torch.bfloat16 and torch.equal(outb.cpu(), refb)
 
 
-@pytest.mark.parametrize("M", [1, 2])
+@pytest.mark.parametrize("M", [1, 2, 3, 4])  # 3, 4: regular groups only (the golden configs are) -- four rows ride on one v_mfma_f32_4x4x4
 def test_exl2_list_forward_equals_the_per_layer_calls(M):
     """bie_mbwq_exl2_list_*: several mixed-bit layers (different K / N / band tables, with and without q_perm) in ONE launch must
     give, entry by entry, exactly what bie_mbwq_exl2_forward gives (same kernel body, same slab plan or not: the fp32 sums
