@@ -407,6 +407,62 @@ def verify_list_outputs(B, plan, layers, y_all, K, N):
     return bool(ok and float(y_all.float().abs().max()) > 0)
 
 
+def bench_exl2_decode_step(dev, n_layers=16, reps=10, hidden=4096, inter=11008):
+    """configs[2] as serving sees it: a Llama-7B-shaped decode step over mixed 3/2-bit (exl2, g32 rows, every layer its own random q_perm) layers
+    with TRUE y -> x dependencies -- per transformer layer q/k/v in one grouped call (bie_mbwq_exl2_forward_grouped) -> o (x = q's output) ->
+    gate/up grouped (x = o's output) -> down (x = gate's output) -> next layer; scales drawn so that the activations keep unit variance."""
+    from bitorch_engine.extensions import q_linear_cuda
+    from bitorch_engine.layers.qlinear.nbit.cuda.utils import make_group_map
+    gen = torch.Generator().manual_seed(9)
+    meta = {}
+
+    def layer(K, N):
+        if K not in meta:
+            qg, row = [], 0
+            for b in (3, 2):
+                for _ in range(K // 2 // 32):
+                    qg += [b, row]
+                    row += b
+            q_groups = torch.tensor(qg, dtype=torch.short)
+            meta[K] = (q_groups, row, len(qg) // 2, make_group_map(q_groups, row).to(dev))
+        q_groups, row, groups, gmap = meta[K]
+        qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (row, N), dtype=torch.int32, device=dev)
+        s0 = 1.0 / (3.0 * K) ** 0.5  # q - zero ~ uniform on a few levels: unit-variance outputs for unit-variance inputs, roughly
+        sc = (s0 * (0.8 + 0.4 * torch.rand((groups, N), device=dev))).half()
+        zq = torch.cat([torch.full((groups // 2, N), 3.5, device=dev), torch.full((groups - groups // 2, N), 1.5, device=dev)], 0)  # mid level of the 3- / 2-bit halves
+        ze = (sc.float() * zq).half()
+        perm = torch.randperm(K, generator=gen).to(torch.short).to(dev)
+        _, rows = q_linear_cuda.mbwq_trans_qweight(qw, q_groups, True, K, groups, 4)
+        return (qw, sc, ze, perm, gmap, rows), row * N * 4 + 4 * groups * N + 2 * K
+    blocks, byts = [], 0
+    for _ in range(n_layers):
+        blk = {}
+        for name, (K, N, cnt) in (("qkv", (hidden, hidden, 3)), ("o", (hidden, hidden, 1)), ("gu", (hidden, inter, 2)), ("down", (inter, hidden, 1))):
+            made = [layer(K, N) for _ in range(cnt)]
+            blk[name] = [m[0] for m in made]
+            byts += sum(m[1] for m in made)
+        blocks.append(blk)
+    h0 = torch.randn((1, hidden), device=dev).half()
+    out = []
+
+    def run(_st):
+        h = h0
+        for blk in blocks:
+            q = q_linear_cuda.mbwq_exl2_forward_grouped(h, blk["qkv"])[0]
+            o = q_linear_cuda.mbwq_exl2_forward(q, *blk["o"][0], False)
+            g = q_linear_cuda.mbwq_exl2_forward_grouped(o, blk["gu"])[0]
+            h = q_linear_cuda.mbwq_exl2_forward(g, *blk["down"][0], False)
+        out[:] = [h]
+    g = capture(run)
+    us = time_graph(g, reps) / n_layers
+    b = byts / n_layers
+    fin = out[0].float()
+    return {"op": "exl2 w3/w2 g32 Llama-7B decode step, linear layers only: grouped q/k/v -> o -> grouped gate/up -> down, true y -> x dependencies (6 launches per layer)",
+            "M": 1, "K": hidden, "N": inter, "layers": n_layers, "us_per_layer": round(us, 2), "alg_bytes_per_layer": int(b),
+            "final_activation_rms": round(float(fin.pow(2).mean().sqrt()), 4), "finite": bool(torch.isfinite(fin).all()),
+            "roofline": {"bound": "hbm", "achieved": round(b / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None}}
+
+
 def bench_exl2(dev):
     """configs[2]: exl2 mixed 3/2-bit decode (g32 rows, random q_perm), Llama-7B shapes, fp16 (the reference kernel is fp16 only)."""
     from bitorch_engine.extensions import q_linear_cuda
@@ -942,6 +998,9 @@ def main():
             guarded("c2_gemv_M32_4096x11008", lambda: B.gemv(4096, 11008, 40, 10, 22, M=32))
             guarded("c2_act_order_4096x11008", lambda: bench_act_order(dev))
             guarded("c3_exl2", lambda: bench_exl2(dev))
+            guarded("c3_exl2_decode_step_llama7b", lambda: bench_exl2_decode_step(dev))
+            if isinstance(extras.get("c3_exl2_decode_step_llama7b"), dict) and "roofline" in extras["c3_exl2_decode_step_llama7b"]:
+                out["summary"]["c3_exl2_decode_step_llama7b"] = {"frac": extras["c3_exl2_decode_step_llama7b"]["roofline"]["frac"], "us": extras["c3_exl2_decode_step_llama7b"]["us_per_layer"]}
             if isinstance(extras.get("c3_exl2"), list):  # configs[2] in the short line: the list form and the sibling groups, fraction of the HBM roofline
                 for r_ in extras["c3_exl2"]:
                     if ("layer list" in r_["op"] and r_["M"] == 1) or "siblings" in r_["op"]:

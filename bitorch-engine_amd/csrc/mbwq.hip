@@ -443,6 +443,17 @@ struct Exl2Call {  // everything one workgroup of the decode kernel needs (kerne
 // two rows 24.5 against 19.1 (profiles/r03_l_exl2_staged_x.txt).  Both forms are exact.
 // NARROW: the tensor has no 8 / 6 / 5-bit rows (host: rows7[2] == 0): those bands' prefetch sets (4 x up to 8 words) are what sets the
 // kernel's register count -- 151 with them (8-wave workgroups: ONE per CU), <= 128 without (two per CU).
+// the power of two the field of pair j carries in the pairs of exl2_tpairs16 (chunk of `bits`-bit values, Exl2Lay<bits>)
+__device__ __forceinline__ float exl2_offset_of(int bits, int j) {  // pair j of a chunk of `bits`-bit values (Exl2Lay<bits>)
+    const int F = 16 / bits;
+    if (j >= bits * F) return 1024.0f;
+    const int p = (j % F) * bits;
+    int b0 = 0;
+    for (int q = 0; q <= p; q += bits)
+        if (q + bits - b0 > 10) b0 = q;
+    return (float)(1 << (10 - (p - b0)));
+}
+
 // DIRECT (one x row, regular groups -- every band's groups hold the same power-of-two number of whole chunks, bie_mbwq_exl2_shuffle
 // says so): NOTHING is staged.  A chunk's group is arithmetic on the band table, its 32 permutation indices are loaded by the wave
 // itself one round of the prefetch ahead of the gather that needs them, and the first packed words are requested at kernel entry
@@ -496,16 +507,47 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
     float2_t* cs_s = reinterpret_cast<float2_t*>(x_s + MT * slab_k);           // DMODE 2: [MT][chunks_per_slab] behind the rows of x
     int two_groups = 0;  // does any chunk of the slab straddle two groups (group sizes below 32)?
     if constexpr (XP) {
-        const int n16 = (c_end - c_begin) * 4;  // 16-byte pieces of a row's slab
+        if (xp != nullptr) {  // uniform: the kernel in front has permuted x and summed the chunks
+            const int n16 = (c_end - c_begin) * 4;  // 16-byte pieces of a row's slab
 #pragma unroll
-        for (int m = 0; m < MT; m++) {  // rows beyond M copy row M - 1: never stored, never out of bounds
-            const int mr = m < M ? m : M - 1;
-            const uint4_t* src = reinterpret_cast<const uint4_t*>(xp + (long)mr * K + (long)c_begin * 32);
-            uint4_t* dst = reinterpret_cast<uint4_t*>(x_s + m * slab_k);
-            for (int i = tid; i < n16; i += EX2_NW * 64) dst[i] = src[i];
-            for (int i = tid; i < (c_end - c_begin); i += EX2_NW * 64) cs_s[m * chunks_per_slab + i] = cs[(long)mr * C + c_begin + i];
+            for (int m = 0; m < MT; m++) {  // rows beyond M copy row M - 1: never stored, never out of bounds
+                const int mr = m < M ? m : M - 1;
+                const uint4_t* src = reinterpret_cast<const uint4_t*>(xp + (long)mr * K + (long)c_begin * 32);
+                uint4_t* dst = reinterpret_cast<uint4_t*>(x_s + m * slab_k);
+                for (int i = tid; i < n16; i += EX2_NW * 64) dst[i] = src[i];
+                for (int i = tid; i < (c_end - c_begin); i += EX2_NW * 64) cs_s[m * chunks_per_slab + i] = cs[(long)mr * C + c_begin + i];
+            }
+            __syncthreads();
+        } else {  // the group call: this workgroup permutes its own slab (one launch less; the list form amortises a kernel in front instead)
+            const int nk = (c_end - c_begin) * 32;
+            for (int i = tid; i < nk; i += EX2_NW * 64) {
+                const int kx = perm ? (int)perm[c_begin * 32 + i] : c_begin * 32 + i;
+#pragma unroll
+                for (int m = 0; m < MT; m++) x_s[m * slab_k + i] = x[(long)(m < M ? m : M - 1) * K + kx];
+            }
+            __syncthreads();
+            for (int ci = wave; ci < c_end - c_begin; ci += EX2_NW) {  // a chunk's two sums: its 32 values on the lanes of each half-wave (row m, m + 1)
+                const int k0 = (c_begin + ci) * 32;
+                int bits = 2;
+#pragma unroll
+                for (int b = 5; b >= 0; b--)
+                    if (k0 < rows.r[b]) bits = exl2_bits_of_band(b);
+                const float ofs = exl2_offset_of(bits, (lane & 31) >> 1);
+#pragma unroll
+                for (int m0 = 0; m0 < MT; m0 += 2) {
+                    const int m = m0 + (lane >> 5);
+                    const float xv = f16_bits_to_f32(x_s[(m < MT ? m : 0) * slab_k + ci * 32 + (lane & 31)]);
+                    float so = ofs * xv, sx = xv;
+#pragma unroll
+                    for (int d = 1; d < 32; d <<= 1) {
+                        so += __shfl_xor(so, d, 32);
+                        sx += __shfl_xor(sx, d, 32);
+                    }
+                    if ((lane & 31) == 0 && m < MT) cs_s[m * chunks_per_slab + ci] = float2_t{so, sx};
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     if constexpr (!DIRECT) {
         const int nk = (c_end - c_begin) * 32;
@@ -1159,15 +1201,6 @@ __global__ __launch_bounds__(512, ((DMODE == 2 && NARROW && MT == 1) ? 6 : 4)) v
 // The kernel in front of a DMODE 2 list launch, for every entry (one row of x): xp = x[q_perm] (or a copy), and per 32-k chunk the two
 // sums that do not depend on the column: cs[c] = {sum offset_k x_k, sum x_k} -- offset_k is the power of two the field of k carries
 // in the pairs the decode kernel feeds the matrix pipe (exl2_tpairs16), a property of the chunk's bit width and of k's place in it.
-__device__ __forceinline__ float exl2_offset_of(int bits, int j) {  // pair j of a chunk of `bits`-bit values (Exl2Lay<bits>)
-    const int F = 16 / bits;
-    if (j >= bits * F) return 1024.0f;
-    const int p = (j % F) * bits;
-    int b0 = 0;
-    for (int q = 0; q <= p; q += bits)
-        if (q + bits - b0 > 10) b0 = q;
-    return (float)(1 << (10 - (p - b0)));
-}
 // position k of every row of x: xp[m][k] = x[m][q_perm[k]]; the 32 lanes of a chunk reduce its two sums (cs[m][k / 32])
 __device__ __forceinline__ void exl2_permute_rows(const uint16_t* __restrict__ x, const uint16_t* __restrict__ perm, uint16_t* __restrict__ xp,
                                                   float2_t* __restrict__ cs, const Exl2Rows& rows, int M, int K, int k) {
@@ -1676,6 +1709,10 @@ int exl2_group_forward(int n, const bie_exl2_list_entry* e, const void* x, int M
     long blocks; size_t gran, lds;
     exl2_list_plan(n, e, cps, S, &blocks, &gran, &lds, M, EXL2_GROUP_WGS);
     const int MT = exl2_rows_mt(M);
+    // the permute kernel in front (two launches) against every workgroup permuting its own slab (one launch, BIE_EXL2_GROUP_PREPASS=0): measured
+    // 12.2 / 14.2 / 14.9 against 12.7 / 18.7 / 19.6 us for 3 x 4096x4096 / 2 x 4096x11008 / 2 x 11008x4096 -- the dependent gather in front of every
+    // workgroup's first word costs more than the launch it saves (profiles/r04_exl2_ablation.txt)
+    static const bool prepass = [] { const char* ev = getenv("BIE_EXL2_GROUP_PREPASS"); return !ev || atoi(ev) != 0; }();
     Exl2GroupArgs a;
     std::memset(&a, 0, sizeof(a));
     a.n = n;
@@ -1694,10 +1731,12 @@ int exl2_group_forward(int n, const bie_exl2_list_entry* e, const void* x, int M
         c.gen = gen + t0;
         for (int k = 0; k < 6; k++) c.rows.r[k] = e[i].rows7[k];
         exl2_fill_groups(c, e[i].rows7);
-        c.xp = reinterpret_cast<const uint16_t*>(body + xo);
-        xo += align256((size_t)M * e[i].K * 2);
-        c.cs = reinterpret_cast<const float2_t*>(body + xo);
-        xo += align256((size_t)M * (e[i].K / 32) * 8);
+        if (prepass) {
+            c.xp = reinterpret_cast<const uint16_t*>(body + xo);
+            xo += align256((size_t)M * e[i].K * 2);
+            c.cs = reinterpret_cast<const float2_t*>(body + xo);
+            xo += align256((size_t)M * (e[i].K / 32) * 8);
+        }
         c.M = M; c.K = e[i].K; c.N = e[i].N; c.chunks_per_slab = cps[i]; c.S = S[i]; c.colblocks = cb;
         BIE_REQUIRE(S[i] < 4096, BIE_ERR_UNSUPPORTED, "bie_mbwq_exl2_forward_grouped: member %d needs %d K slabs (< 4096)", i, S[i]);
         a.first_block[i] = (int)(i == 0 ? 0 : a.first_block[i - 1] + (long)cdiv(e[i - 1].N, 64) * S[i - 1]);
@@ -1710,9 +1749,12 @@ int exl2_group_forward(int n, const bie_exl2_list_entry* e, const void* x, int M
     int spin;
     test_forge_get(&skew, &spin);
     const unsigned epoch = next_launch_epoch();
-    hipLaunchKernelGGL(exl2_group_permute_kernel, dim3(cdiv(a.max_k, 256), n), dim3(256), 0, st, a);
-    int rc = check_launch("exl2_group_permute_kernel");
-    if (rc) return rc;
+    int rc = BIE_OK;
+    if (prepass) {
+        hipLaunchKernelGGL(exl2_group_permute_kernel, dim3(cdiv(a.max_k, 256), n), dim3(256), 0, st, a);
+        rc = check_launch("exl2_group_permute_kernel");
+        if (rc) return rc;
+    }
 #define LG(MTV)                                                                                                                                             \
     do {                                                                                                                                                    \
         if (narrow) hipLaunchKernelGGL((exl2_group_kernel<MTV, true>), dim3((unsigned)blocks), dim3(512), lds, st, a, epoch, device_status_word(), skew, spin); \
