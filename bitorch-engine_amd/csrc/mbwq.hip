@@ -1313,6 +1313,12 @@ static int exl2_slabs(int K, int N) {
     return cps;
 }
 
+// A lone layer with a long K runs as a group of ONE (permute kernel + the pre-permuted decode body): 11008x4096 11.6 against 12.2 us, 14336x4096 12.2
+// against 13.6, 28672x8192 26.4 against 39.1; at K <= 8192 the lone direct launch is ahead (profiles/r04_exl2_ablation.txt)
+constexpr int EXL2_LONE_AS_GROUP_MIN_K = 10240;
+static size_t exl2_lone_group_bytes(int M, int K, int N);
+int exl2_group_forward(int n, const bie_exl2_list_entry* e, const void* x, int M, float* head, char* body, hipStream_t st);
+
 size_t mbwq_workspace_bytes(int M, int K, int N) {
     size_t a = 0;
     for (int w : {2, 4}) {
@@ -1330,6 +1336,8 @@ size_t mbwq_workspace_bytes(int M, int K, int N) {
     if (d > c) c = d;
     const size_t e = exl2_mfma_granule_bytes(M, K, N);  // 3 <= M <= 64: granules of the matrix-pipe kernel's K slabs
     if (e > c) c = e;
+    const size_t g1 = exl2_lone_group_bytes(M, K, N);
+    if (g1 > c) c = g1;
     size_t r = a > b ? a : b;
     return r > c ? r : c;
 }
@@ -1356,6 +1364,10 @@ static void exl2_fill_groups(Exl2Call& c, const int* rows_ext) {
         c.gfirst[b] = rows_ext[BIE_EXL2_ROWS_GFIRST + b];
         c.glog[b] = rows_ext[BIE_EXL2_ROWS_GLOG + b];
     }
+}
+static bool exl2_xp_on() {
+    static const bool on = [] { const char* ev = getenv("BIE_EXL2_XP"); return !ev || atoi(ev) != 0; }();
+    return on;
 }
 static bool exl2_direct_on() {
     static const bool on = [] { const char* e = getenv("BIE_EXL2_DIRECT"); return !e || atoi(e) != 0; }();
@@ -1392,6 +1404,13 @@ int mbwq_exl2_forward_launch(const void* x, const int32_t* qw, const void* scale
     for (int i = 0; i < 6; i++) rows.r[i] = rows7[i];
     const bool slab_ok = !(cdiv(N, 64) > BIE_WS_COUNTERS && K / 32 > 768);  // K slabs need one generation word per column block
     const bool regular = (rows7[6] & BIE_EXL2_ROWS_REGULAR) && exl2_direct_on();
+    static const int lone_min_k = [] { const char* ev = getenv("BIE_EXL2_LONE_AS_GROUP_MIN_K"); return ev ? atoi(ev) : EXL2_LONE_AS_GROUP_MIN_K; }();
+    if (M <= 2 && regular && K >= lone_min_k && K % 32 == 0 && cdiv(N, 64) <= BIE_WS_COUNTERS && exl2_xp_on()) {
+        bie_exl2_list_entry one{};
+        one.x = x; one.qweight = qw; one.scales = scales; one.zeros = zeros; one.q_perm = perm; one.q_group_map = gmap; one.rows7 = rows7; one.y = y;
+        one.K = K; one.N = N;
+        return exl2_group_forward(1, &one, x, M, head, reinterpret_cast<char*>(part), st);
+    }
     if (M <= 2 && slab_ok) {  // decode path.  (Three and four rows would ride on the same v_mfma_f32_4x4x4, but the direct form then gathers four rows
                               //  per chunk and spills: 14.2 / 35.2 / 39.3 us at M = 4 against 13.3 / 22.2 / 19.4 on the matrix-pipe kernel below.)  (The packed-fp16 kernel instantiated for 4 / 8 rows measured SLOWER than the fp32 kernel below:
                    //  33.3 / 46.2 us against 28.0 / 39.9 us at 4096x11008 M = 3 / 8 -- 178-256 registers, one wave per SIMD.)
@@ -1550,10 +1569,6 @@ static void exl2_list_plan(int n, const bie_exl2_list_entry* e, std::vector<int>
     }
 }
 
-static bool exl2_xp_on() {
-    static const bool on = [] { const char* ev = getenv("BIE_EXL2_XP"); return !ev || atoi(ev) != 0; }();
-    return on;
-}
 // M <= 2 always (staged form); 3 and 4 rows ride on the same matrix instruction in the pre-permuted form (regular groups)
 static bool exl2_list_ok(int n, const bie_exl2_list_entry* e, int M) {
     if (n <= 0 || !e || M < 1 || M > 4) return false;
@@ -1703,6 +1718,15 @@ size_t exl2_group_workspace_bytes(int n, const bie_exl2_list_entry* e, int M) {
     size_t tot = align256(gran);
     for (int i = 0; i < n; i++) tot += align256((size_t)M * e[i].K * 2) + align256((size_t)M * (e[i].K / 32) * 8);
     return tot;
+}
+static size_t exl2_lone_group_bytes(int M, int K, int N) {  // upper bound without the band table: the plan only reads K and N
+    if (M < 1 || M > 2 || K % 32 != 0 || K <= 0 || N <= 0) return 0;
+    bie_exl2_list_entry one{};
+    one.K = K; one.N = N;
+    std::vector<int> cps, S;
+    long blocks; size_t gran, lds;
+    exl2_list_plan(1, &one, cps, S, &blocks, &gran, &lds, M, EXL2_GROUP_WGS);
+    return align256(gran) + align256((size_t)M * K * 2) + align256((size_t)M * (K / 32) * 8);
 }
 int exl2_group_forward(int n, const bie_exl2_list_entry* e, const void* x, int M, float* head, char* body, hipStream_t st) {
     std::vector<int> cps, S;

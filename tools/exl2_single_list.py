@@ -10,7 +10,7 @@ from bitorch_engine.layers.qlinear.nbit.cuda.utils import make_group_map
 from bitorch_engine.layers.qlinear.nbit.cuda import MBWQExl2ForwardList
 dev = torch.device("cuda", 0)
 gen = torch.Generator().manual_seed(5)
-for (K, N) in ((4096, 4096), (4096, 11008), (11008, 4096), (4096, 12288)):
+for (K, N) in ((4096, 4096), (4096, 11008), (11008, 4096), (4096, 12288), (8192, 8192), (14336, 4096), (28672, 8192)):
     qg, row = [], 0
     for b in (3, 2):
         for _ in range(K // 2 // 32):
@@ -33,4 +33,7 @@ for (K, N) in ((4096, 4096), (4096, 11008), (11008, 4096), (4096, 12288)):
                                    "y": torch.empty((1, N), dtype=torch.float16, device=dev)} for s_ in grp]) for grp in groups_]
     g2 = capture(lambda st: [p.forward(st) for p in plans])
     usl = min(time_graph(g2, 10) for _ in range(3)) / len(plans)
+    g3 = capture(lambda st: [q_linear_cuda.mbwq_exl2_forward_grouped(x, [(s_[0], s_[1], s_[2], perm, gmap, rows)]) for s_ in sets])
+    usg = min(time_graph(g3, 10) for _ in range(3)) / nset
+    print(f"{K}x{N}: group call with ONE member {usg:.2f} us")
     print(f"{K}x{N}: per-layer launch {us1:.2f} us ({byts / us1 / 8e6:.3f})   {NE}-entry list (2 launches) {usl:.2f} us per list = {usl / NE:.2f} per layer ({NE * byts / usl / 8e6:.3f})")
