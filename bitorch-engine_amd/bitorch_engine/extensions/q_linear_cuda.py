@@ -106,14 +106,26 @@ def mpq_forward_impl(x, qweight, scales, zeros, g_idx, w_bit, asym, group_size, 
         y = torch.matmul(x, W.to(x.dtype))
         y = y if bias is None else y + bias
         return y if out is None else out.copy_(y)
-    if out is not None and (out.shape != (M, N) or out.dtype != x.dtype or out.device != x.device or not out.is_contiguous()):
-        raise RuntimeError("mpq_forward_impl: out must be a contiguous [M, N] tensor of x's dtype on x's device")
+    pitched = out is not None and out.dim() == 2 and not out.is_contiguous() and out.stride(1) == 1 and out.stride(0) >= N
+    if out is not None and (out.shape != (M, N) or out.dtype != x.dtype or out.device != x.device or not (out.is_contiguous() or pitched)):
+        raise RuntimeError("mpq_forward_impl: out must be an [M, N] tensor of x's dtype on x's device, contiguous or a column range of a wider "
+                           "row-major tensor (unit column stride)")
     y = torch.empty((M, N), dtype=x.dtype, device=x.device) if out is None else out
     if M == 0:
         return y
     L = _hip.lib()
     need = L.bie_mpq_workspace_bytes(M, K, N, w_bit)
     ws = _hip.workspace(need, x.device)
+    if pitched:
+        # the GEMM epilogue stores straight into the column range (bie_mpq_forward_pitched); shapes it does not take: tight buffer + one copy
+        rc = -2 if gptr is not None else L.bie_mpq_forward_pitched(
+            _hip.ptr(x), _hip.ptr(qweight), _hip.ptr(scales.contiguous()), _hip.ptr(zeros.contiguous()), _hip.ptr(bias), out.data_ptr(), out.stride(0),
+            _hip.ptr(ws), 0 if ws is None else ws.numel(), M, K, N, w_bit, group_size, int(bool(asym)), _hip.dt(x), _hip.stream())
+        if rc == 0:
+            return out
+        if rc != -2:  # BIE_ERR_UNSUPPORTED
+            _hip.check(rc, "bie_mpq_forward_pitched")
+        return out.copy_(mpq_forward_impl(x, qweight, scales, zeros, g_idx, w_bit, asym, group_size, bias, trivial_gidx, None))
     rc = L.bie_mpq_forward(_hip.ptr(x), _hip.ptr(qweight), _hip.ptr(scales.contiguous()), _hip.ptr(zeros.contiguous()),
                            _hip.ptr(gptr), _hip.ptr(bias), _hip.ptr(y), _hip.ptr(ws), 0 if ws is None else ws.numel(),
                            M, K, N, w_bit, group_size, int(bool(asym)), _hip.dt(x), _hip.stream())

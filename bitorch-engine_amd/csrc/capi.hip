@@ -38,6 +38,10 @@ void test_forge_dep_set(int extra);
 // mpq_gemm.hip
 bool mpq_gemm_ok(int M, int K, int N, int w_bit, int group_size, int dtype, bool has_gidx);
 size_t mpq_gemm_workspace_bytes(int M, int K, int N);
+int mpq_gemm_launch_ld(const void* x, const int32_t* qw, const void* scales, const void* zeros, const void* bias, void* y,
+                       float* part, int M, int K, int N, int w_bit, int group_size, int zm, int dtype, const uint16_t* perm,
+                       hipStream_t st, int ldy);
+bool mpq_gemm_pitch_ok(int M, int K, int N, int ldy);
 int mpq_gemm_launch(const void* x, const int32_t* qw, const void* scales, const void* zeros, const void* bias, void* y,
                     float* part, int M, int K, int N, int w_bit, int group_size, int zm, int dtype, const uint16_t* perm,
                     hipStream_t st);
@@ -199,6 +203,30 @@ int bie_mpq_forward(const void* x, const int32_t* qweight, const void* scales, c
         if (rc) return rc;
     }
     return BIE_OK;
+}
+
+// y is a column range of a wider row-major destination: row m of the result goes to y + m * ldy (elements).  Served by the MFMA GEMM range
+// (the prefill shapes a column-sharded layer runs); anything else reports BIE_ERR_UNSUPPORTED and the caller keeps its copy.
+int bie_mpq_forward_pitched(const void* x, const int32_t* qweight, const void* scales, const void* zeros, const void* bias, void* y, int ldy,
+                            void* workspace, size_t workspace_bytes, int M, int K, int N, int w_bit, int group_size, int asym, int dtype,
+                            void* stream) {
+    if (ldy == N)
+        return bie_mpq_forward(x, qweight, scales, zeros, nullptr, bias, y, workspace, workspace_bytes, M, K, N, w_bit, group_size, asym, dtype, stream);
+    int rc = validate_mpq("bie_mpq_forward_pitched", K, N, w_bit, group_size, dtype);
+    if (rc) return rc;
+    BIE_REQUIRE(x && qweight && scales && zeros && y && M > 0, BIE_ERR_INVALID_ARG, "bie_mpq_forward_pitched: bad argument");
+    if (asym) BIE_REQUIRE(N % (32 / w_bit) == 0, BIE_ERR_INVALID_ARG, "bie_mpq_forward_pitched: asym needs N %% %d == 0", 32 / w_bit);
+    static const int lut_max_m = []() { const char* e = getenv("BIE_LUT_MAX_M"); return e ? atoi(e) : 16; }();
+    BIE_REQUIRE(M > lut_max_m && M > 8 && mpq_gemm_ok(M, K, N, w_bit, group_size, dtype, false) && mpq_gemm_pitch_ok(M, K, N, ldy) &&
+                    (reinterpret_cast<uintptr_t>(y) & 7) == 0,
+                BIE_ERR_UNSUPPORTED, "bie_mpq_forward_pitched: M=%d K=%d N=%d ldy=%d is outside the range of the MFMA GEMM's pitched epilogue (M > %d, ldy %% 4 == 0, ldy >= N, no split-K plan, y 8-byte aligned)",
+                M, K, N, ldy, lut_max_m > 8 ? lut_max_m : 8);
+    const size_t need = bie_mpq_workspace_bytes(M, K, N, w_bit);
+    BIE_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), BIE_ERR_WORKSPACE, "bie_mpq_forward_pitched: workspace of %zu bytes required, got %zu", need, workspace_bytes);
+    rc = status_report("bie_mpq_forward_pitched");
+    if (rc) return rc;
+    float* part = reinterpret_cast<float*>(workspace) + WS_HEAD / sizeof(float);
+    return mpq_gemm_launch_ld(x, qweight, scales, zeros, bias, y, part, M, K, N, w_bit, group_size, asym ? 1 : 0, dtype, nullptr, as_stream(stream), ldy);
 }
 
 int bie_workspace_init(void* workspace, size_t workspace_bytes, void* stream) {

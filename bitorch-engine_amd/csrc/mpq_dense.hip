@@ -68,7 +68,7 @@ __device__ __forceinline__ void mfma16(float16_t& c, const v4i_t& a, const v4i_t
 
 template <int DT, int WM, int WN>
 __global__ __launch_bounds__(256) void mpq_dense_gemm_kernel(const uint16_t* __restrict__ x, const uint8_t* __restrict__ wimg, const uint16_t* __restrict__ bias,
-                                                             uint16_t* __restrict__ y, int M, int N, int K, int tiles_n, int NB32, int gm) {
+                                                             uint16_t* __restrict__ y, int M, int N, int K, int tiles_n, int NB32, int gm, int ldy) {
     constexpr int AF = 2 * WM, BF = 2 * WN;  // 32-row / 32-column blocks per workgroup tile
     constexpr int NFR = (AF + BF) * 2;       // KiB per stage (k = 32): x rows 64 bytes each, weight fragments 1 KiB per k16 step
     constexpr int PW = NFR / 4;              // LDS-DMA pieces per wave and stage
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void mpq_dense_gemm_kernel(const uint16_t* __r
     // C/D layout: column = lane & 31 = row m of x, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) = output feature inside the 32-block.
     // y = dt(dt(acc) + bias) as mpq_gemm.hip; the half-waves trade packed quads (v_permlane32_swap_b32) so that a lane stores 8
     // consecutive features of its row: 16 bytes.
-    const bool vec_ok = (N & 7) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+    const bool vec_ok = (N & 7) == 0 && (ldy & 7) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;  // ldy: the row pitch of y in elements (N, or a wider destination's)
     auto pack2 = [&](float lo, float hi) -> uint32_t {
         if constexpr (DT == BIE_BF16) return pack_bf16x2(lo, hi);
         else return f32_to_f16_bits(lo) | (f32_to_f16_bits(hi) << 16);
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void mpq_dense_gemm_kernel(const uint16_t* __r
     auto store8 = [&](int i, int j, int qp, const float (&v)[8]) {
         const int m = (tile_m * AF + wy * WM + i) * 32 + rl;
         const int nb = (tile_n * BF + wx * WN + j) * 32;
-        uint16_t* yr = y + (long)(m < M ? m : 0) * N;
+        uint16_t* yr = y + (long)(m < M ? m : 0) * ldy;
         if (vec_ok) {
             const uint32_t p0 = pack2(v[0], v[1]), p1 = pack2(v[2], v[3]), p2 = pack2(v[4], v[5]), p3 = pack2(v[6], v[7]);
             const auto s0 = __builtin_amdgcn_permlane32_swap(p0, p2, false, false);  // first operand's upper half <-> second's lower half
@@ -296,7 +296,7 @@ static void dequant_frag_launch(const int32_t* qw, const void* scales, const voi
 }
 
 template <int DT>
-static void dense_gemm_launch(const void* x, const void* img, const void* bias, void* y, int M, int K, int N, hipStream_t st) {
+static void dense_gemm_launch(const void* x, const void* img, const void* bias, void* y, int M, int K, int N, int ldy, hipStream_t st) {
     const int NB32 = cdiv(N, 32);
     const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
     static const int tile_once = env_int_dense("BIE_GEMM_DENSE_TILE", 0), gm_once = env_int_dense("BIE_GEMM_DENSE_GM", 4);
@@ -307,17 +307,17 @@ static void dense_gemm_launch(const void* x, const void* img, const void* bias, 
     if (tile == 256 || (tile != 128 && t256 >= 192)) {
         const int tn = cdiv(N, 256);
         hipLaunchKernelGGL((mpq_dense_gemm_kernel<DT, 4, 4>), dim3((unsigned)t256), dim3(256), 0, st, (const uint16_t*)x, (const uint8_t*)img, (const uint16_t*)bias,
-                           (uint16_t*)y, M, N, K, tn, NB32, gm);
+                           (uint16_t*)y, M, N, K, tn, NB32, gm, ldy);
     } else {
         const int tn = cdiv(N, 128);
         hipLaunchKernelGGL((mpq_dense_gemm_kernel<DT, 2, 2>), dim3((unsigned)(cdiv(M, 128) * tn)), dim3(256), 0, st, (const uint16_t*)x, (const uint8_t*)img,
-                           (const uint16_t*)bias, (uint16_t*)y, M, N, K, tn, NB32, gm);
+                           (const uint16_t*)bias, (uint16_t*)y, M, N, K, tn, NB32, gm, ldy);
     }
 }
 
 // scratch: mpq_dense_workspace_bytes(K, N) bytes, 16-byte aligned
 int mpq_dense_launch(const void* x, const int32_t* qw, const void* scales, const void* zeros, const void* bias, void* y, void* scratch, int M, int K, int N,
-                     int w_bit, int gshift, int zm, int dtype, hipStream_t st) {
+                     int w_bit, int gshift, int zm, int dtype, hipStream_t st, int ldy) {
     if (dtype == BIE_F16) {
         if (zm == ZM_ASYM) dequant_frag_launch<BIE_F16, ZM_ASYM>(qw, scales, zeros, scratch, K, N, w_bit, gshift, st);
         else if (zm == ZM_FUSED) dequant_frag_launch<BIE_F16, ZM_FUSED>(qw, scales, zeros, scratch, K, N, w_bit, gshift, st);
@@ -328,8 +328,8 @@ int mpq_dense_launch(const void* x, const int32_t* qw, const void* scales, const
     }
     int rc = check_launch("mpq_dequant_frag_kernel");
     if (rc) return rc;
-    if (dtype == BIE_F16) dense_gemm_launch<BIE_F16>(x, scratch, bias, y, M, K, N, st);
-    else dense_gemm_launch<BIE_BF16>(x, scratch, bias, y, M, K, N, st);
+    if (dtype == BIE_F16) dense_gemm_launch<BIE_F16>(x, scratch, bias, y, M, K, N, ldy, st);
+    else dense_gemm_launch<BIE_BF16>(x, scratch, bias, y, M, K, N, ldy, st);
     return check_launch("mpq_dense_gemm_kernel");
 }
 

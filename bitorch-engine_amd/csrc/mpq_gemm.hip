@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, (BM <= 128 ? 2 : 1)) void mpq_gemm_kernel(cons
                                                           const uint16_t* __restrict__ scales, const void* __restrict__ zeros,
                                                           const uint16_t* __restrict__ bias, const uint16_t* __restrict__ perm,
                                                           float* __restrict__ part, uint16_t* __restrict__ y, int M, int K, int N,
-                                                          int gshift, int tiles_per_split, int S, int m_tiles, int n_tiles) {
+                                                          int gshift, int tiles_per_split, int S, int m_tiles, int n_tiles, int ldy) {
     constexpr int TM = BM / 32;              // 32-row accumulator tiles per wave
     constexpr int NF = GEMM_NF;
     constexpr int A_CHUNKS = BM * 8 / 256;   // 16-byte chunks staged per thread per tile
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256, (BM <= 128 ? 2 : 1)) void mpq_gemm_kernel(cons
                             pk.x = pack_bf16x2(o[0], o[1]);
                             pk.y = pack_bf16x2(o[2], o[3]);
                         }
-                        *reinterpret_cast<uint2_t*>(y + (long)row * N + n0) = pk;
+                        *reinterpret_cast<uint2_t*>(y + (long)row * ldy + n0) = pk;  // ldy: the row pitch of y (N, or a wider destination's)
                     } else {
                         float4_t v = {acc[f][t][4 * q], acc[f][t][4 * q + 1], acc[f][t][4 * q + 2], acc[f][t][4 * q + 3]};
                         *reinterpret_cast<float4_t*>(part + ((long)split * M + row) * N + n0) = v;
@@ -574,7 +574,7 @@ bool mpq_gemm_ok(int M, int K, int N, int w_bit, int group_size, int dtype, bool
 bool mpq_dense_ok(int M, int K, int N);
 size_t mpq_dense_workspace_bytes(int K, int N);
 int mpq_dense_launch(const void* x, const int32_t* qw, const void* scales, const void* zeros, const void* bias, void* y, void* scratch, int M, int K, int N,
-                     int w_bit, int gshift, int zm, int dtype, hipStream_t st);
+                     int w_bit, int gshift, int zm, int dtype, hipStream_t st, int ldy);
 
 size_t mpq_gemm_workspace_bytes(int M, int K, int N) {
     if (K % GEMM_BK) return 0;
@@ -588,6 +588,7 @@ struct GemmArgs {
     const void* x; const int32_t* qw; const void* scales; const void* zeros; const void* bias; const uint16_t* perm;
     float* part; void* y; int M, K, N, gshift;
     hipStream_t st;
+    int ldy;
 };
 
 template <int DT, int WBIT, int ZM, bool PERM, bool GPT>
@@ -598,7 +599,7 @@ static int gemm_launch_bm(const GemmPlan& p, const GemmArgs& a) {
 #define L(BMV)                                                                                                          \
     hipLaunchKernelGGL((mpq_gemm_kernel<DT, WBIT, ZM, BMV, PERM, GPT>), grid, dim3(256), lds, a.st, (const uint16_t*)a.x, \
                        (const uint32_t*)a.qw, (const uint16_t*)a.scales, a.zeros, (const uint16_t*)a.bias, a.perm, a.part, \
-                       (uint16_t*)a.y, a.M, a.K, a.N, a.gshift, p.tiles_per_split, p.S, m_tiles, n_tiles)
+                       (uint16_t*)a.y, a.M, a.K, a.N, a.gshift, p.tiles_per_split, p.S, m_tiles, n_tiles, a.ldy)
     switch (p.BM) {
         case 32: L(32); break;
         case 64: L(64); break;
@@ -625,9 +626,22 @@ static int gemm_launch_mpq_w(const GemmPlan& p, const GemmArgs& a, int w_bit, bo
     }
 }
 
+// ldy: the row pitch of y in elements (N for a tight [M, N]; a wider destination lets a column shard's epilogue store straight into
+// its column range of the full output -- SURVEY section 8e).  The split-K finalize pass writes tight rows only.
+int mpq_gemm_launch_ld(const void* x, const int32_t* qw, const void* scales, const void* zeros, const void* bias, void* y,
+                       float* part, int M, int K, int N, int w_bit, int group_size, int zm, int dtype, const uint16_t* perm,
+                       hipStream_t st, int ldy);
 int mpq_gemm_launch(const void* x, const int32_t* qw, const void* scales, const void* zeros, const void* bias, void* y,
                     float* part, int M, int K, int N, int w_bit, int group_size, int zm, int dtype, const uint16_t* perm,
                     hipStream_t st) {
+    return mpq_gemm_launch_ld(x, qw, scales, zeros, bias, y, part, M, K, N, w_bit, group_size, zm, dtype, perm, st, N);
+}
+bool mpq_gemm_pitch_ok(int M, int K, int N, int ldy) {  // a pitched destination: 8-byte stores need ldy % 4 == 0, and no split-K finalize pass
+    return ldy >= N && (ldy & 3) == 0 && (ldy == N || plan_gemm(M, K, N).S == 1 || mpq_dense_ok(M, K, N));
+}
+int mpq_gemm_launch_ld(const void* x, const int32_t* qw, const void* scales, const void* zeros, const void* bias, void* y,
+                       float* part, int M, int K, int N, int w_bit, int group_size, int zm, int dtype, const uint16_t* perm,
+                       hipStream_t st, int ldy) {
     const GemmPlan p = plan_gemm(M, K, N);
     int gshift = 31;  // group_size >= K: a single group
     bool gpt = true;
@@ -637,8 +651,12 @@ int mpq_gemm_launch(const void* x, const int32_t* qw, const void* scales, const 
         gpt = (group_size % GEMM_BK) == 0;
     }
     if (!perm && mpq_dense_ok(M, K, N) && (zm != ZM_FUSED || dtype == BIE_F16))  // large M: dequantise once into `part`, dense MFMA GEMM
-        return mpq_dense_launch(x, qw, scales, zeros, bias, y, part, M, K, N, w_bit, gshift, zm, dtype, st);
-    const GemmArgs a{x, qw, scales, zeros, bias, perm, part, y, M, K, N, gshift, st};
+        return mpq_dense_launch(x, qw, scales, zeros, bias, y, part, M, K, N, w_bit, gshift, zm, dtype, st, ldy);
+    if (ldy != N && p.S > 1) {
+        set_error("mpq_gemm_launch: a pitched destination (ldy=%d, N=%d) is not served by the split-K plan of this shape", ldy, N);
+        return BIE_ERR_UNSUPPORTED;
+    }
+    const GemmArgs a{x, qw, scales, zeros, bias, perm, part, y, M, K, N, gshift, st, ldy};
     int rc;
     if (zm == ZM_FUSED) {  // MBWQ uniform: fp16, 2/4 bit, optional q_perm gather
         if (dtype != BIE_F16 || !(w_bit == 2 || w_bit == 4)) {

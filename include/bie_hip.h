@@ -89,6 +89,16 @@ int bie_mpq_forward(const void* x, const int32_t* qweight, const void* scales, c
                     size_t workspace_bytes, int M, int K, int N, int w_bit, int group_size, int asym,
                     int dtype, void* stream);
 
+/* bie_mpq_forward whose result is a column range of a wider row-major destination: row m goes to y + m * ldy (elements; ldy >= N,
+ * ldy % 4 == 0, y 8-byte aligned).  A column-sharded layer lets the GEMM epilogue store its shard straight into
+ * out[:, lo:hi] instead of copying it there.  Implicit groups only (no g_idx).  Served by the MFMA GEMM range (M above the decode
+ * kernels', shapes without a split-K plan); everything else returns BIE_ERR_UNSUPPORTED and launches nothing -- the caller keeps
+ * its tight buffer + copy.  ldy == N is bie_mpq_forward.  No reference counterpart (its GEMM writes a fresh tensor,
+ * mpq_layer.py:59-65). */
+int bie_mpq_forward_pitched(const void* x, const int32_t* qweight, const void* scales, const void* zeros, const void* bias, void* y,
+                            int ldy, void* workspace, size_t workspace_bytes, int M, int K, int N, int w_bit, int group_size, int asym,
+                            int dtype, void* stream);
+
 /* Several weight sets that share ONE activation x[M, K] (q/k/v projections, gate/up of an MLP): set i has
  * qweight[i] [K*w/32, N[i]], scales[i] / zeros[i] [G, N[i]], bias[i] (array or entry may be NULL), y[i] [M, N[i]].
  * Semantically n_sets calls of bie_mpq_forward with g_idx = NULL; for decode (M <= 2, bf16, W4) the column tiles of

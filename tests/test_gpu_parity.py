@@ -1303,6 +1303,34 @@ def test_unmodified_exl2_module_tree_gets_grouped_calls_after_prepare_bie_layers
         assert torch.isfinite(yp.float()).all() and torch.equal(yp, model(xp))
 
 
+@pytest.mark.parametrize("shape", [(1024, 4096, 1024, 4096, 256), (256, 512, 384, 1024, 64), (192, 2048, 3584, 28672, 7168), (40, 512, 256, 768, 512), (4, 512, 256, 768, 0)])
+def test_forward_into_a_column_range_of_a_wider_output(shape):
+    """bie_mpq_forward_pitched (a column shard's GEMM epilogue stores straight into out[:, lo:hi]): the pitched result is
+    bit-equal to the tight one for the dense and the fused MFMA form, the rest of the destination is untouched, and shapes outside the
+    pitched range (decode kernels, split-K plans) take the tight buffer + copy path with the same result."""
+    from bitorch_engine.extensions import q_linear_cuda
+    M, K, N, NT, lo = shape
+    rng = np.random.default_rng(M + K + N)
+    qw, scales, zeros, _ = rand_case(rng, K, N, 4, 128, orc.BF16, 0)
+    qd, sd, zd = qw.to(DEV), scales.to(DEV), zeros.to(DEV)
+    xm = torch.randn((M, K), generator=torch.Generator().manual_seed(M)).bfloat16().to(DEV)
+    g_idx = (torch.arange(K, dtype=torch.int32) // 128).to(DEV)
+    tight = q_linear_cuda.mpq_forward_impl(xm, qd, sd, zd, g_idx, 4, False, 128)
+    wide = torch.full((M, NT), 7.0, dtype=torch.bfloat16, device=DEV)
+    view = wide[:, lo:lo + N]
+    assert not view.is_contiguous() or NT == N
+    got = q_linear_cuda.mpq_forward_impl(xm, qd, sd, zd, g_idx, 4, False, 128, out=view)
+    assert got.data_ptr() == view.data_ptr()
+    assert torch.equal(view, tight), "pitched epilogue differs from the tight one"
+    keep = torch.ones(NT, dtype=torch.bool)
+    keep[lo:lo + N] = False
+    assert bool((wide[:, keep.to(DEV)] == 7.0).all()), "stores outside the column range"
+    bias = torch.randn((N,), generator=torch.Generator().manual_seed(1)).bfloat16().to(DEV)
+    tb = q_linear_cuda.mpq_forward_impl(xm, qd, sd, zd, g_idx, 4, False, 128, bias)
+    q_linear_cuda.mpq_forward_impl(xm, qd, sd, zd, g_idx, 4, False, 128, bias, out=view)
+    assert torch.equal(view, tb)
+
+
 def test_grouped_forward_with_a_column_count_that_is_not_a_multiple_of_4():
     """N % 4 != 0 in one set: the grouped entry point must leave the 16-byte-load kernels and fall back to one launch per set."""
     from bitorch_engine.extensions import q_linear_cuda
