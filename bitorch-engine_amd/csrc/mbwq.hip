@@ -739,46 +739,35 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
             issue_p(c, ch);
             if constexpr (DIRECT && !XP) load_perm(c_next, ch);
         };
-        Chunk c0, c1, c2, c3;
-        if constexpr (XP) {
-            issue(at(0), 0, c0);
-            issue(at(1), 0, c1);
-            issue(at(2), 0, c2);
-            issue(at(3), 0, c3);
-        } else if constexpr (DIRECT) {
-            load_perm(at(0), c0);
-            load_perm(at(1), c1);
-            load_perm(at(2), c2);
-            load_perm(at(3), c3);
-            issue_w(at(0), c0);  // the first words do not wait for the indices
-            issue_w(at(1), c1);
-            issue_w(at(2), c2);
-            issue_w(at(3), c3);
-            issue_p(at(0), c0); load_perm(at(4), c0);
-            issue_p(at(1), c1); load_perm(at(5), c1);
-            issue_p(at(2), c2); load_perm(at(6), c2);
-            issue_p(at(3), c3); load_perm(at(7), c3);
+        // Chunks in flight: as many as fit ~16 packed words (4 of <= 4-bit, 3 of 5-bit, 2 of 6- / 8-bit chunks): the same bytes in flight for
+        // every band, and the register count of the kernel no longer set by its widest band (4 x 8 words: 32 registers for a band most
+        // tensors do not have -- the mixed 6 / 5 / 4-bit instances ran at 96-128 registers, two workgroups per CU, half the rate of the
+        // 3 / 2-bit ones).
+        constexpr int DEPTH = BITS >= 6 ? 2 : (BITS == 5 ? 3 : 4);
+        Chunk cs[DEPTH];
+        if constexpr (DIRECT && !XP) {
+            exl2_static_for<0, DEPTH>([&](auto i) { load_perm(at(decltype(i)::value), cs[decltype(i)::value]); });
+            exl2_static_for<0, DEPTH>([&](auto i) { issue_w(at(decltype(i)::value), cs[decltype(i)::value]); });  // the first words do not wait for the indices
+            exl2_static_for<0, DEPTH>([&](auto i) {
+                constexpr int I = decltype(i)::value;
+                issue_p(at(I), cs[I]);
+                load_perm(at(I + DEPTH), cs[I]);
+            });
         } else {
-            issue(at(0), 0, c0);
-            issue(at(1), 0, c1);
-            issue(at(2), 0, c2);
-            issue(at(3), 0, c3);
+            exl2_static_for<0, DEPTH>([&](auto i) { issue(at(decltype(i)::value), 0, cs[decltype(i)::value]); });
         }
         int jj = 0;
-        for (; jj + 4 < cnt; jj += 4) {  // a further group follows: four full steps, each re-filling the set it has just consumed
-            compute(0, at(jj), c0);
-            issue(at(jj + 4), at(jj + 8), c0);
-            compute(1, at(jj + 1), c1);
-            issue(at(jj + 5), at(jj + 9), c1);
-            compute(2, at(jj + 2), c2);
-            issue(at(jj + 6), at(jj + 10), c2);
-            compute(3, at(jj + 3), c3);
-            issue(at(jj + 7), at(jj + 11), c3);
+        for (; jj + DEPTH < cnt; jj += DEPTH) {  // a further round follows: DEPTH full steps, each re-filling the set it has just consumed
+            exl2_static_for<0, DEPTH>([&](auto i) {
+                constexpr int I = decltype(i)::value;
+                compute(I, at(jj + I), cs[I]);
+                issue(at(jj + DEPTH + I), at(jj + 2 * DEPTH + I), cs[I]);
+            });
         }
-        compute(0, at(jj), c0);  // last group: nothing left to request
-        if (jj + 1 < cnt) compute(1, at(jj + 1), c1);
-        if (jj + 2 < cnt) compute(2, at(jj + 2), c2);
-        if (jj + 3 < cnt) compute(3, at(jj + 3), c3);
+        exl2_static_for<0, DEPTH>([&](auto i) {  // last round: nothing left to request
+            constexpr int I = decltype(i)::value;
+            if (jj + I < cnt) compute(I, at(jj + I), cs[I]);
+        });
     };
     {
         int kprev = 0, prow = 0;

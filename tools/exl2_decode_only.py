@@ -14,8 +14,11 @@ gen = torch.Generator().manual_seed(5)
 res = []
 for (K, N) in ((4096, 4096), (4096, 11008), (11008, 4096)):
     qg, row = [], 0
-    for b in (3, 2):
-        for _ in range(K // 2 // 32):
+    MIX = os.environ.get("EXL2_MIX", "3:1,2:1")  # bits:share, in band order
+    mix = [(int(a.split(":")[0]), int(a.split(":")[1])) for a in MIX.split(",")]
+    tot = sum(w for _, w in mix)
+    for b, w in mix:
+        for _ in range(K // 32 * w // tot):
             qg += [b, row]; row += b
     groups = len(qg) // 2
     q_groups = torch.tensor(qg, dtype=torch.short)
@@ -37,4 +40,4 @@ for (K, N) in ((4096, 4096), (4096, 11008), (11008, 4096)):
     g2 = capture(lambda st: [plan.forward(st) for _ in range(4)])
     usl = min(time_graph(g2, 10) for _ in range(3)) / (nset * 4)
     res.append(f"{K}x{N}: per-layer {us1:.2f} us ({byts / us1 / 8e6:.3f})  list {usl:.2f} us/layer ({byts / usl / 8e6:.3f})")
-print(os.environ.get("BIE_HIP_LIB", "./default/x").split("/")[-2], "direct=" + os.environ.get("BIE_EXL2_DIRECT", "1"), " | ".join(res))
+print(os.environ.get("EXL2_MIX", ""), os.environ.get("BIE_HIP_LIB", "./default/x").split("/")[-2], "direct=" + os.environ.get("BIE_EXL2_DIRECT", "1"), " | ".join(res))
