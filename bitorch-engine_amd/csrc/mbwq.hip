@@ -230,11 +230,11 @@ __device__ __forceinline__ uint32_t exl2_bfi(uint32_t v, uint32_t mask, uint32_t
 // The decode kernels stop one step earlier: T[j] = the fp16 pair (2^(10-lp) + q[2j], 2^(10-lp) + q[2j+1]) as v_and_or_b32 leaves it, and
 // ofs[j] = the offset pair (2^(10-lp), 2^(10-lp)) it carries (the same for every chunk of a band).  They take the dot products of T
 // and of ofs with x on the matrix pipe and subtract there (exl2_gemv2_body).
-template <int BITS>
+template <int BITS, int J0 = 0, int J1 = 16>
 __device__ __forceinline__ void exl2_tpairs16(const uint32_t (&w)[8], const Exl2Magic& mg, uint32_t (&T)[16]) {
     using L = Exl2Lay<BITS>;
     constexpr uint32_t mask = (1u << BITS) - 1u;
-    exl2_static_for<0, 16>([&](auto j) {
+    exl2_static_for<J0, J1>([&](auto j) {
         constexpr int J = decltype(j)::value;
         if constexpr (J < L::MAIN) {
             constexpr int d = J / L::F, p = (J % L::F) * BITS;
@@ -669,7 +669,6 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
 #pragma unroll
             for (int i = 0; i < 8; i++) w8[i] = i < BITS ? ch.w[i] : 0u;
             uint32_t T[16];
-            exl2_tpairs16<BITS>(w8, magic, T);
             // Everything after the field extraction runs on the MATRIX pipe.  v_mfma_f32_4x4x4_16B_f16 is sixteen independent 4x4x4
             // products: lane l = (block l / 4, column l % 4) supplies four k of ITS OWN column as the B operand -- the lane-per-column
             // layout of this kernel as it is -- and row l % 4 of x as the A operand, and receives D[0..3][its column]: up to four rows
@@ -702,12 +701,11 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
                     yacc[m] = __builtin_fmaf(-zf, dx[m], yacc[m]);
                 }
             };
-            uint4_t xq[4];  // the chunk's 32 activations of this lane's row: A operands, kept like T
-#pragma unroll
-            for (int i = 0; i < 4; i++) xq[i] = reinterpret_cast<const uint4_t*>(xw + xrow * xstride)[i];
-#pragma unroll
-            for (int half = 0; half < 2; half++) {
-                const uint4_t xa = xq[2 * half], xb = xq[2 * half + 1];
+            // half a chunk at a time -- extraction of 8 pairs, their 4 (x 3) matrix instructions -- so that 8, not 16, operand pairs are live
+            exl2_static_for<0, 2>([&](auto hh) {
+                constexpr int half = decltype(hh)::value;
+                exl2_tpairs16<BITS, 8 * half, 8 * half + 8>(w8, magic, T);
+                const uint4_t xa = reinterpret_cast<const uint4_t*>(xw + xrow * xstride)[2 * half], xb = reinterpret_cast<const uint4_t*>(xw + xrow * xstride)[2 * half + 1];
                 const uint32_t xd[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
@@ -723,7 +721,8 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
                     apply(half);
                     dq = zero4; dc = zero4; dx = zero4;
                 }
-            }
+                __builtin_amdgcn_sched_barrier(0);
+            });
             if constexpr (!TWO) apply(0);
         };
         // this wave's chunks in the band: c = first, first + NW, ... < cb1
@@ -1183,7 +1182,7 @@ __device__ __forceinline__ void exl2_list_body(const Exl2Call* __restrict__ ent,
                                              tag_skew, spin_limit, grp, c->xp, c->cs);
 }
 template <int MT, bool NARROW, int DMODE>
-__global__ __launch_bounds__(512, ((DMODE == 2 && NARROW && MT == 1) ? 6 : 4)) void exl2_list_kernel(const Exl2Call* __restrict__ ent, const uint2_t* __restrict__ blk, unsigned epoch,
+__global__ __launch_bounds__(512, ((DMODE == 2 && MT == 1) ? 6 : 4)) void exl2_list_kernel(const Exl2Call* __restrict__ ent, const uint2_t* __restrict__ blk, unsigned epoch,
                                                            unsigned* status, unsigned tag_skew, int spin_limit) {
     exl2_list_body<MT, NARROW, DMODE>(ent, blk, epoch, status, tag_skew, spin_limit);
 }
@@ -1229,7 +1228,7 @@ struct Exl2GroupArgs {
     Exl2Call ent[EXL2_GROUP_MAX];
 };
 template <int MT, bool NARROW>
-__global__ __launch_bounds__(512, ((NARROW && MT == 1) ? 6 : 4)) void exl2_group_kernel(const Exl2GroupArgs a, unsigned epoch, unsigned* status, unsigned tag_skew, int spin_limit) {
+__global__ __launch_bounds__(512, (MT == 1 ? 6 : 4)) void exl2_group_kernel(const Exl2GroupArgs a, unsigned epoch, unsigned* status, unsigned tag_skew, int spin_limit) {
     typedef const __attribute__((address_space(4))) Exl2Call ccall_t;
     int ei = 0;
 #pragma unroll
