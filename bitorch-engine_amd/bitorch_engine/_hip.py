@@ -49,6 +49,7 @@ SIGNATURES = {
     "bie_gather_cols": (_i, [_vp] * 3 + [_i] * 3 + [_vp]),
     "bie_mbwq_rows": (_i, [_vp, _i, _i, _vp]),
     "bie_mbwq_exl2_shuffle": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "bie_mbwq_exl2_table": (_i, [_vp, _i, _i, _vp]),
     "bie_mbwq_q4_dequant": (_i, [_vp] * 5 + [_i] * 4 + [_vp]),
     "bie_mbwq_exl2_dequant": (_i, [_vp] * 7 + [_i] * 3 + [_vp]),
     "bie_mbwq_workspace_bytes": (_sz, [_i, _i, _i]),
@@ -96,7 +97,7 @@ TEST_HOOKS = {
     "bie_test_forge_dependency": (None, [_i]),
 }
 
-_HOST_ONLY = ("bie_version", "bie_last_error", "bie_mbwq_rows", "bie_status_init", "bie_device_status", "bie_test_forge_reducer",
+_HOST_ONLY = ("bie_version", "bie_last_error", "bie_mbwq_rows", "bie_mbwq_exl2_table", "bie_status_init", "bie_device_status", "bie_test_forge_reducer",
               "bie_test_forge_dependency", "bie_mpq_list_launches", "bie_mpq_list_destroy", "bie_mbwq_exl2_list_destroy")
 
 

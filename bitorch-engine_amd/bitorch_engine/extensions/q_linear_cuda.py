@@ -226,7 +226,7 @@ def mbwq_trans_qweight(qweight, q_groups, use_mbw, height, groups, bits):
         _hip.need_gpu(t)
         if t.dtype != torch.int32 or not t.is_contiguous():
             raise RuntimeError("mbwq_trans_qweight: qweight must be a contiguous int32 tensor")
-        if getattr(qweight, "_bie_exl2_shuffled", False):
+        if getattr(qweight, "_bie_exl2_shuffled", None) == (t.data_ptr(), t._version):  # new contents (copy_, a new .data) may be prepared again
             raise RuntimeError("mbwq_trans_qweight: this qweight has already been re-arranged (a second pass would scramble it)")
         rows = (ctypes.c_int * EXL2_ROWS_LEN)()
         qg = q_groups.detach().to("cpu", torch.int16).contiguous()
@@ -235,7 +235,7 @@ def mbwq_trans_qweight(qweight, q_groups, use_mbw, height, groups, bits):
                                                   ctypes.cast(rows, ctypes.c_void_p), _hip.stream())
         _hip.check(rc, "bie_mbwq_exl2_shuffle")
         try:
-            qweight._bie_exl2_shuffled = True
+            qweight._bie_exl2_shuffled = (t.data_ptr(), t._version)
         except AttributeError:
             pass
         return qweight, list(rows)

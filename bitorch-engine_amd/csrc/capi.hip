@@ -379,13 +379,13 @@ int bie_mbwq_q4_dequant(const int32_t* qweight, const void* scales, const void* 
 
 // The extended table: band ends + flags as bie_mbwq_rows, then per band the first group and log2(chunks per group).  REGULAR when
 // every band's groups hold the same power-of-two number of whole chunks (a shorter last group is fine: the index is a shift).
-int bie_mbwq_exl2_shuffle(int32_t* qweight, const int16_t* q_groups_host, int groups, int K, int N, int* rows_host, void* stream) {
-    BIE_REQUIRE(qweight && rows_host && N > 0, BIE_ERR_INVALID_ARG, "bie_mbwq_exl2_shuffle: bad argument");
+int bie_mbwq_exl2_table(const int16_t* q_groups_host, int groups, int K, int* rows_host) {  // host only: the table bie_mbwq_exl2_shuffle returns
+    BIE_REQUIRE(rows_host, BIE_ERR_INVALID_ARG, "bie_mbwq_exl2_table: bad argument");
     int rc = bie_mbwq_rows(q_groups_host, groups, K, rows_host);
     if (rc) return rc;
-    BIE_REQUIRE(K % 32 == 0, BIE_ERR_UNSUPPORTED, "bie_mbwq_exl2_shuffle: K=%d must be a multiple of 32", K);
+    BIE_REQUIRE(K % 32 == 0, BIE_ERR_UNSUPPORTED, "bie_mbwq_exl2_table: K=%d must be a multiple of 32", K);
     for (int b = 0; b < 6; b++)
-        BIE_REQUIRE(rows_host[b] % 32 == 0, BIE_ERR_UNSUPPORTED, "bie_mbwq_exl2_shuffle: band boundary rows[%d]=%d must be a multiple of 32", b, rows_host[b]);
+        BIE_REQUIRE(rows_host[b] % 32 == 0, BIE_ERR_UNSUPPORTED, "bie_mbwq_exl2_table: band boundary rows[%d]=%d must be a multiple of 32", b, rows_host[b]);
     bool regular = true;
     int gfirst[6] = {0, 0, 0, 0, 0, 0}, glog[6] = {0, 0, 0, 0, 0, 0}, gk[6] = {0, 0, 0, 0, 0, 0}, seen[6] = {0, 0, 0, 0, 0, 0};
     int row = 0;
@@ -416,6 +416,13 @@ int bie_mbwq_exl2_shuffle(int32_t* qweight, const int16_t* q_groups_host, int gr
     }
     rows_host[6] |= BIE_EXL2_ROWS_SHUFFLED | (regular ? BIE_EXL2_ROWS_REGULAR : 0);
     rows_host[BIE_EXL2_ROWS_LEN - 1] = BIE_EXL2_ROWS_TAG;
+    return BIE_OK;
+}
+
+int bie_mbwq_exl2_shuffle(int32_t* qweight, const int16_t* q_groups_host, int groups, int K, int N, int* rows_host, void* stream) {
+    BIE_REQUIRE(qweight && rows_host && N > 0, BIE_ERR_INVALID_ARG, "bie_mbwq_exl2_shuffle: bad argument");
+    int rc = bie_mbwq_exl2_table(q_groups_host, groups, K, rows_host);
+    if (rc) return rc;
     return mbwq_exl2_shuffle_launch(qweight, rows_host, K, N, as_stream(stream));
 }
 

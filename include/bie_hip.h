@@ -207,6 +207,9 @@ int bie_mbwq_rows(const int16_t* q_groups_host, int groups, int K, int* rows7_ho
 #define BIE_EXL2_ROWS_GLOG 13
 #define BIE_EXL2_ROWS_TAG 0x45584c32
 int bie_mbwq_exl2_shuffle(int32_t* qweight, const int16_t* q_groups_host, int groups, int K, int N, int* rows_host, void* stream);
+/* The table alone (pure host code, nothing launched): what bie_mbwq_exl2_shuffle writes to rows_host.  For a tensor that a previous run
+ * re-arranged and saved: load it as it is and take its table from here. */
+int bie_mbwq_exl2_table(const int16_t* q_groups_host, int groups, int K, int* rows_host);
 
 /* out[K, N] fp16: W[q_perm ? q_perm[k] : k][n] = fma(s, q, -z).  Replaces
  * q_linear_cuda.mbwq_q42fp_weight (mbwq_linear_cuda_kernel.cu:656-710, kernels :314-501). */

@@ -72,6 +72,50 @@ def test_mbwq_rows_host_function_matches_oracle_and_reference_tables(golden_dir)
     assert L.bie_mbwq_rows(bad.ctypes.data, 1, 32, ctypes.cast(rows, ctypes.c_void_p)) == -2
 
 
+def test_exl2_table_host_function_marks_regular_group_structures_and_their_shifts(golden_dir):
+    """bie_mbwq_exl2_table (host only; what bie_mbwq_exl2_shuffle returns beside re-arranging the tensor): the reference's 7 ints first, the
+    SHUFFLED mark, REGULAR exactly when every band's groups hold the same power-of-two number of whole 32-k chunks (a shorter last group
+    allowed), and per band the first group and log2(chunks per group) the direct decode form derives a chunk's group from -- checked
+    against the group map the reference builds (make_group_map) for every chunk."""
+    import torch
+    from bitorch_engine import _hip
+    from bitorch_engine.layers.qlinear.nbit.cuda.utils import make_group_map
+    L = _hip.lib()
+    g = np.load(os.path.join(golden_dir, "exl2_group_maps.npz"))
+    cases = [(np.ascontiguousarray(g[c + "_q_groups"]), int(g[c + "_meta"][0]), True) for c in ("q_proj", "k_proj", "w3w2", "all6")]
+    for spec, regular in (([(4, 64)] * 3 + [(4, 32)] + [(3, 128)] * 2 + [(3, 96)] + [(2, 64)] * 4, True), ([(6, 96), (4, 160), (2, 224)], True),
+                          ([(4, 32), (4, 64), (4, 32)] + [(2, 64)] * 4, False), ([(4, 16)] * 8 + [(2, 16)] * 12, False), ([(4, 96)] * 3 + [(2, 32)] * 4, False)):
+        qg, row, K = [], 0, 0
+        for bits, k in spec:
+            qg += [bits, row]
+            row += k * bits // 32
+            K += k
+        cases.append((np.array(qg, np.int16), K, regular))
+    for qg, K, regular in cases:
+        groups = qg.size // 2
+        t = (ctypes.c_int * 20)()
+        assert L.bie_mbwq_exl2_table(qg.ctypes.data, groups, K, ctypes.cast(t, ctypes.c_void_p)) == 0
+        t = list(t)
+        ref = orc.exl2_rows(qg, K)
+        assert t[:6] == ref[:6] and (t[6] & 0xff) == ref[6] and (t[6] & 0x100) and t[19] == 0x45584c32
+        assert bool(t[6] & 0x200) == regular, (qg.tolist(), hex(t[6]))
+        if not regular:
+            continue
+        rows_packed = int(sum(((int(qg[2 * i + 3]) - int(qg[2 * i + 1])) if i < groups - 1 else 0) for i in range(groups)))
+        bits_l = qg[0::2].astype(int)
+        k_per = [(int(qg[2 * i + 3]) - int(qg[2 * i + 1])) * 32 // int(bits_l[i]) for i in range(groups - 1)]
+        k_per.append(K - sum(k_per))
+        rows_packed += k_per[-1] * int(bits_l[-1]) // 32
+        gmap = make_group_map(torch.from_numpy(qg), rows_packed).numpy()  # (group, rows left) per k
+        band_end, kprev = t[:6], 0
+        for b in range(6):
+            for c in range(kprev // 32, band_end[b] // 32):
+                want = int(gmap[2 * (32 * c)])
+                got = t[7 + b] + ((c - kprev // 32) >> t[13 + b])
+                assert got == want, (b, c, got, want)
+            kprev = band_end[b]
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from bitorch_engine import _hip
     monkeypatch.setattr(_hip, "_lib", None)
