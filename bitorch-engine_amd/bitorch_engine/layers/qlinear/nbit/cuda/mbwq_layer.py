@@ -131,6 +131,8 @@ class MBWQLinearCuda(MPQLinearBase):
         cs = self.channel_scale
         key = (cs.data_ptr(), cs._version, tuple(cs.shape))
         if getattr(self, "_cs_one_key", None) != key:
+            if cs.is_cuda and torch.cuda.is_current_stream_capturing():
+                return False  # no host read under capture: this call multiplies (the reference's path); the next uncaptured call settles it
             self._cs_one_key, self._cs_one = key, bool((cs == 1).all().item())
         return self._cs_one
 
