@@ -3,16 +3,18 @@
 //     q_perm gather of x -> served by the MPQ GEMV / MFMA GEMM kernels in ZM_FUSED mode
 //     (replaces gemm_half_q4/q2_half_gptq_kernel, exl2/q_gemm_kernel_gptq.cuh:35-328, and
 //     reconstruct_q4/q2_gptq_kernel, mbwq_linear_cuda_kernel.cu:314-501);
-//   * exl2: K is ordered in bands 8,6,5,4,3,2 bit; inside a band 32 consecutive k of one column are a
+//   * exl2: K is ordered in bands 8,6,5,4,3,2 bit; in the checkpoint 32 consecutive k of one column are a
 //     `bits`-word LSB-first bitstream down `bits` consecutive packed rows (QMODE=0 dequant primitives,
-//     exl2/quant/qdq_{2,3,4,5,6,8}.cuh).  Replaces reconstruct_exl2_kernel
-//     (mbwq_linear_cuda_kernel.cu:92-308) and gemm_half_q_half_kernel (exl2/q_gemm_kernel.cuh:90-549).
-//     One lane owns one column and walks 32-k chunks: `bits` coalesced dword loads per chunk, bit
-//     extraction with compile-time shifts (v_alignbit for the straddling fields), fp16 fma dequant
-//     (exactly the reference's single-rounding __hfma2), fp32 accumulation.  Decode (M <= 2) runs
-//     exl2_gemv2_kernel (packed fp16 pairs, v_dot2_f32_f16, loads issued chunks ahead); 3 <= M <= 32
-//     the scalar exl2_gemv_kernel in passes of 8 rows; larger M is routed by the Python front-end to
-//     reconstruct + library GEMM like the reference.
+//     exl2/quant/qdq_{2,3,4,5,6,8}.cuh); the load-time step (exl2_shuffle_kernel: the reference's shuffle_kernel
+//     hook, mbwq_linear_cuda_kernel.cu:63-86) re-arranges every chunk into the half-pair layout below, which is
+//     what all kernels of this file read.  Replaces reconstruct_exl2_kernel (mbwq_linear_cuda_kernel.cu:92-308)
+//     and gemm_half_q_half_kernel (exl2/q_gemm_kernel.cuh:90-549).  One lane owns one column and walks 32-k
+//     chunks: `bits` coalesced dword loads per chunk, one v_and_or_b32 per pair of values.
+//       - decode (M <= 2; lists and sibling groups up to four rows): exl2_gemv2_body -- the pairs go to the matrix
+//         pipe as they are (v_mfma_f32_4x4x4_16B_f16, lane = column), scale and zero applied once per chunk in fp32;
+//       - 3 <= M <= 64: exl2_mfma_kernel (per-weight fp16 fma dequant == the reference's __hfma2, LDS transpose into
+//         v_mfma_f32_16x16x32_f16); beyond: the Python front-end reconstructs + library GEMM like the reference;
+//       - reconstruction (exl2_dequant_kernel): the reference's single-rounding __hfma2, bit-exact.
 #include "bie_common.h"
 
 #pragma clang fp contract(off)
@@ -419,12 +421,10 @@ __global__ __launch_bounds__(256) void exl2_gemv_kernel(const uint16_t* __restri
     }
 }
 
-// ---- exl2 decode GEMV (M <= 2): one column per lane, 16 waves per block interleave the 32-k chunks of the block's K slab ----
-// Per chunk: `bits` coalesced dword loads, pair extraction (exl2_pairs16), then the dequant and the dot product run on PACKED
-// fp16: the pairs are the halves 1024+q, v_pk_add_f16 / v_pk_fma_f16 reproduce the
-// reference's single-rounding __hfma2(q, s, -z) exactly, v_dot2_f32_f16 accumulates in fp32 against x pairs broadcast from
-// LDS (x is gathered through q_perm once per block, as fp16).  ~3.5 VALU per weight instead of ~6.5 in the scalar-fp32
-// kernel below, and no finalize launch when one slab covers K.
+// ---- exl2 decode GEMV (M <= 2; four rows in the list / group forms): one column per lane, the waves of a block interleave the 32-k chunks of its K slab ----
+// Per chunk: `bits` coalesced dword loads, one v_and_or_b32 per pair (exl2_tpairs16), the sums on the matrix pipe and the group's
+// scale / zero once per chunk in fp32 (exl2_gemv2_body has the derivation and the three ways x reaches the waves); K slabs are
+// reduced in the kernel by tagged granules: no finalize launch.
 // EX2_NW waves per workgroup: 16 (one workgroup per CU) when the column blocks alone fill most of the chip (measured 17.8 us
 // against 19.4 us at 4096x11008), 8 (two per CU) + K slabs for narrower layers (4096x4096: 7.9 us against 9.1 us)
 struct Exl2Call {  // everything one workgroup of the decode kernel needs (kernel arguments, or an entry of a device-resident list)
@@ -454,7 +454,7 @@ __device__ __forceinline__ float exl2_offset_of(int bits, int j) {  // pair j of
     return (float)(1 << (10 - (p - b0)));
 }
 
-// DIRECT (one x row, regular groups -- every band's groups hold the same power-of-two number of whole chunks, bie_mbwq_exl2_shuffle
+// DIRECT (one or two x rows, regular groups -- every band's groups hold the same power-of-two number of whole chunks, bie_mbwq_exl2_shuffle
 // says so): NOTHING is staged.  A chunk's group is arithmetic on the band table, its 32 permutation indices are loaded by the wave
 // itself one round of the prefetch ahead of the gather that needs them, and the first packed words are requested at kernel entry
 // instead of behind a metadata round trip and a barrier.  Measured on the 32-layer list (4096x4096, 3/2-bit g32): the staging
@@ -1186,7 +1186,7 @@ __global__ __launch_bounds__(512, ((DMODE == 2 && MT == 1) ? 6 : 4)) void exl2_l
                                                            unsigned* status, unsigned tag_skew, int spin_limit) {
     exl2_list_body<MT, NARROW, DMODE>(ent, blk, epoch, status, tag_skew, spin_limit);
 }
-// The kernel in front of a DMODE 2 list launch, for every entry (one row of x): xp = x[q_perm] (or a copy), and per 32-k chunk the two
+// The kernel in front of a DMODE 2 list launch, for every entry (and every row of x): xp = x[q_perm] (or a copy), and per 32-k chunk the two
 // sums that do not depend on the column: cs[c] = {sum offset_k x_k, sum x_k} -- offset_k is the power of two the field of k carries
 // in the pairs the decode kernel feeds the matrix pipe (exl2_tpairs16), a property of the chunk's bit width and of k's place in it.
 // position k of every row of x: xp[m][k] = x[m][q_perm[k]]; the 32 lanes of a chunk reduce its two sums (cs[m][k / 32])
