@@ -336,13 +336,13 @@ def mbwq_exl2_forward(x, qweight, scales, zeros, q_perm, q_group_map, rows, use_
 
 
 def mbwq_exl2_forward_grouped(x, members):
-    """Up to 8 exl2 layers on the SAME x [M <= 4, K] in two launches (bie_mbwq_exl2_forward_grouped).  members: sequence of
+    """Up to 8 exl2 layers on the SAME x [M <= 16, K] in two launches (bie_mbwq_exl2_forward_grouped).  members: sequence of
     (qweight, scales, zeros, q_perm or None, q_group_map, rows) as `mbwq_exl2_forward` takes them.  Returns the outputs
     ([M, N_i] fp16, new tensors), or None when the set is outside the grouped range (irregular groups, K % 32, too many
     column blocks) -- the caller then runs the members one by one."""
     import ctypes
     _hip.need_gpu(x, *[t for m in members for t in m[:5] if t is not None])
-    if x.dtype != torch.float16 or x.dim() != 2 or not 1 <= x.shape[0] <= 4 or not 1 <= len(members) <= 8:
+    if x.dtype != torch.float16 or x.dim() != 2 or not 1 <= x.shape[0] <= 16 or not 1 <= len(members) <= 8:
         return None
     x = x.contiguous()
     M, K = x.shape

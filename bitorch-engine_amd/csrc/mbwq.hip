@@ -509,7 +509,7 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
     if constexpr (XP) {
         if (xp != nullptr) {  // uniform: the kernel in front has permuted x and summed the chunks
             const int n16 = (c_end - c_begin) * 4;  // 16-byte pieces of a row's slab
-#pragma unroll
+#pragma unroll 1
             for (int m = 0; m < MT; m++) {  // rows beyond M copy row M - 1: never stored, never out of bounds
                 const int mr = m < M ? m : M - 1;
                 const uint4_t* src = reinterpret_cast<const uint4_t*>(xp + (long)mr * K + (long)c_begin * 32);
@@ -571,7 +571,7 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
     float yacc[MT];
 #pragma unroll
     for (int m = 0; m < MT; m++) yacc[m] = 0.f;
-    const int xrow = MT > 1 ? ((lane & 3) < M ? (lane & 3) : M - 1) : 0;  // the row of x this lane feeds the matrix pipe with (MT <= 4)
+    const int xrow = MT > 1 ? ((lane & 3) < M ? (lane & 3) : M - 1) : 0;  // the row of x this lane feeds the matrix pipe with (MT <= 4; more rows: per row group)
     const Exl2Magic magic;
     uint2_t ones2 = uint2_t{0x3c003c00u, 0x3c003c00u};
     asm("" : "+v"(ones2));  // matrix operands are registers
@@ -684,7 +684,7 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
             // Rows beyond M read row M - 1 again and are never stored.
             const exl2_acc_t zero4 = exl2_acc_t{0.f, 0.f, 0.f, 0.f};
             exl2_acc_t dq = zero4, dc = zero4, dx = zero4;
-            if constexpr (XP) {
+            if constexpr (XP && MT <= 4) {
 #pragma unroll
                 for (int m = 0; m < MT; m++) {
                     const float2_t v = cs_s[m * chunks_per_slab + (c - c_begin)];
@@ -696,11 +696,46 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
                 const float sf = (float)__builtin_bit_cast(half_t, (uint16_t)ch.s[half]);
                 const float zf = (float)__builtin_bit_cast(half_t, (uint16_t)ch.z[half]);
 #pragma unroll
-                for (int m = 0; m < MT; m++) {
+                for (int m = 0; m < (MT <= 4 ? MT : 4); m++) {
                     yacc[m] = __builtin_fmaf(sf, dq[m] - dc[m], yacc[m]);
                     yacc[m] = __builtin_fmaf(-zf, dx[m], yacc[m]);
                 }
             };
+            if constexpr (MT > 4) {
+                // Eight / sixteen rows of x (the pre-permuted form only): MT / 4 matrix instructions per four k -- row group rg feeds rows 4 rg .. 4 rg + 3
+                // as the A operand (lane l: row 4 rg + l % 4) against the SAME B operand, one extraction for all rows.
+                static_assert(MT <= 4 || (XP && !TWO), "more than four rows: the pre-permuted form");
+                constexpr int RG = MT / 4;
+                exl2_acc_t dqr[RG];
+#pragma unroll
+                for (int rg = 0; rg < RG; rg++) dqr[rg] = zero4;
+                exl2_static_for<0, 2>([&](auto hh) {
+                    constexpr int half = decltype(hh)::value;
+                    exl2_tpairs16<BITS, 8 * half, 8 * half + 8>(w8, magic, T);
+                    exl2_static_for<0, RG>([&](auto rr) {
+                        constexpr int rg = decltype(rr)::value;
+                        const int mr = 4 * rg + (lane & 3);
+                        const uint16_t* xr = xw + (mr < M ? mr : M - 1) * xstride;
+                        const uint4_t xa = reinterpret_cast<const uint4_t*>(xr)[2 * half], xb = reinterpret_cast<const uint4_t*>(xr)[2 * half + 1];
+                        const uint32_t xd[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const int j = 8 * half + 2 * i;
+                            dqr[rg] = exl2_mfma4(__builtin_bit_cast(half4_t, uint2_t{xd[2 * i], xd[2 * i + 1]}), __builtin_bit_cast(half4_t, uint2_t{T[j], T[j + 1]}), dqr[rg]);
+                        }
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                const float sf = (float)__builtin_bit_cast(half_t, (uint16_t)ch.s[0]);
+                const float zf = (float)__builtin_bit_cast(half_t, (uint16_t)ch.z[0]);
+#pragma unroll
+                for (int m = 0; m < MT; m++) {
+                    const float2_t v = cs_s[m * chunks_per_slab + (c - c_begin)];
+                    yacc[m] = __builtin_fmaf(sf, dqr[m >> 2][m & 3] - v.x, yacc[m]);
+                    yacc[m] = __builtin_fmaf(-zf, v.y, yacc[m]);
+                }
+                return;
+            }
             // half a chunk at a time -- extraction of 8 pairs, their 4 (x 3) matrix instructions -- so that 8, not 16, operand pairs are live
             exl2_static_for<0, 2>([&](auto hh) {
                 constexpr int half = decltype(hh)::value;
@@ -742,7 +777,7 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
         // every band, and the register count of the kernel no longer set by its widest band (4 x 8 words: 32 registers for a band most
         // tensors do not have -- the mixed 6 / 5 / 4-bit instances ran at 96-128 registers, two workgroups per CU, half the rate of the
         // 3 / 2-bit ones).
-        constexpr int DEPTH = BITS >= 6 ? 2 : (BITS == 5 ? 3 : 4);
+        constexpr int DEPTH = (BITS >= 6 || MT >= 8) ? 2 : (BITS == 5 ? 3 : 4);  // eight / sixteen rows: the accumulators take the registers of two sets
         Chunk cs[DEPTH];
         if constexpr (DIRECT && !XP) {
             exl2_static_for<0, DEPTH>([&](auto i) { load_perm(at(decltype(i)::value), cs[decltype(i)::value]); });
@@ -817,8 +852,9 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
 #pragma unroll
     for (int m = 0; m < MT; m++) red[(wave * MT + m) * 64 + lane] = yacc[m];
     __syncthreads();
-    if (tid < 64 * MT) {
-        const int om = tid >> 6, ol = tid & 63, on = colblock * 64 + ol;
+    // wave w finishes rows w, w + EX2_NW, ... (eight and sixteen rows of x: more rows than waves)
+    for (int om = tid >> 6; om < MT; om += EX2_NW) {
+        const int ol = tid & 63, on = colblock * 64 + ol;
         float tot = 0.f;
 #pragma unroll
         for (int wv = 0; wv < EX2_NW; wv++) tot += red[(wv * MT + om) * 64 + ol];
@@ -833,7 +869,7 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
             if (slab != S - 1) {
                 const unsigned long long gval = ((unsigned long long)tag << 32) | __float_as_uint(tot);
                 __hip_atomic_store(gran + ((long)slab * MT + om) * ncat + col, gval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return;
+                continue;
             }
             float v = 0.0f;
             for (int s0 = 0; s0 < S - 1; s0 += 4) {
@@ -861,7 +897,7 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
                 }
             }
             tot = v + tot;
-            if (tid == 0) gen[colblock] = gen_next;  // the next launch (or a replay of this one) tags differently
+            if (tid == 0) gen[colblock] = gen_next;  // the next launch (or a replay of this one) tags differently (a kernel boundary lies between)
         }
         if (om < M && on < N) y[(long)om * N + on] = f32_to_f16_bits(tot);
     }
@@ -1521,7 +1557,8 @@ static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
 // column blocks x K slabs, 8-wave workgroups; ~`want` workgroups in all (two per CU and four rounds), a slab at least 4 chunks
 // per wave (the depth of the kernel's prefetch) and at most CPS_MAX chunks (the LDS copy of the slab's q_perm / group map)
-static int exl2_rows_mt(int M) { return M <= 1 ? 1 : (M <= 2 ? 2 : 4); }  // rows of x the list / group kernels are instantiated for
+constexpr int EXL2_XP_MAX_M = 16;  // rows of x of the pre-permuted decode form (four per matrix instruction, up to four instructions per four k)
+static int exl2_rows_mt(int M) { return M <= 1 ? 1 : (M <= 2 ? 2 : (M <= 4 ? 4 : (M <= 8 ? 8 : 16))); }  // rows of x the list / group kernels are instantiated for
 static bool exl2_all_regular(int n, const bie_exl2_list_entry* e) {
     for (int i = 0; i < n; i++)
         if (!e[i].rows7 || !(e[i].rows7[6] & BIE_EXL2_ROWS_REGULAR)) return false;
@@ -1559,7 +1596,7 @@ static void exl2_list_plan(int n, const bie_exl2_list_entry* e, std::vector<int>
 
 // M <= 2 always (staged form); 3 and 4 rows ride on the same matrix instruction in the pre-permuted form (regular groups)
 static bool exl2_list_ok(int n, const bie_exl2_list_entry* e, int M) {
-    if (n <= 0 || !e || M < 1 || M > 4) return false;
+    if (n <= 0 || !e || M < 1 || M > EXL2_XP_MAX_M) return false;
     for (int i = 0; i < n; i++) {
         if (e[i].K <= 0 || e[i].N <= 0 || e[i].K % 32 || !e[i].rows7) return false;
         if (cdiv(e[i].N, 64) >= (1 << 20)) return false;
@@ -1672,7 +1709,13 @@ int exl2_list_forward(Exl2List* p, hipStream_t st) {
         if (rc) return rc;
     }
     if (p->xp) {
-        if (p->M == 1) LL(1, 2); else if (p->M == 2) LL(2, 2); else LL(4, 2);
+        switch (exl2_rows_mt(p->M)) {
+            case 1: LL(1, 2); break;
+            case 2: LL(2, 2); break;
+            case 4: LL(4, 2); break;
+            case 8: LL(8, 2); break;
+            default: LL(16, 2); break;
+        }
     } else if (p->M == 1) {
         if (p->direct) LL(1, 1); else LL(1, 0);
     } else {
@@ -1689,7 +1732,7 @@ static bool exl2_group_entry_ok(const bie_exl2_list_entry& e) {
            (e.rows7[6] & BIE_EXL2_ROWS_REGULAR) && e.rows7[5] == e.K;
 }
 bool exl2_group_ok(int n, const bie_exl2_list_entry* e, int M) {
-    if (n < 1 || n > EXL2_GROUP_MAX || !e || !exl2_direct_on() || M < 1 || M > 4) return false;
+    if (n < 1 || n > EXL2_GROUP_MAX || !e || !exl2_direct_on() || M < 1 || M > EXL2_XP_MAX_M) return false;
     long cbs = 0;
     for (int i = 0; i < n; i++) {
         if (!exl2_group_entry_ok(e[i])) return false;
@@ -1772,7 +1815,13 @@ int exl2_group_forward(int n, const bie_exl2_list_entry* e, const void* x, int M
         if (narrow) hipLaunchKernelGGL((exl2_group_kernel<MTV, true>), dim3((unsigned)blocks), dim3(512), lds, st, a, epoch, device_status_word(), skew, spin); \
         else hipLaunchKernelGGL((exl2_group_kernel<MTV, false>), dim3((unsigned)blocks), dim3(512), lds, st, a, epoch, device_status_word(), skew, spin);      \
     } while (0)
-    if (MT == 1) LG(1); else if (MT == 2) LG(2); else LG(4);
+    switch (MT) {
+        case 1: LG(1); break;
+        case 2: LG(2); break;
+        case 4: LG(4); break;
+        case 8: LG(8); break;
+        default: LG(16); break;
+    }
 #undef LG
     return check_launch("exl2_group_kernel");
 }

@@ -1199,7 +1199,7 @@ def test_exl2_grouped_forward_against_the_oracle_and_the_single_launches():
         for i, (o, sgl) in enumerate(zip(outs, singles)):
             assert_close(o, sgl.float().cpu().half(), orc.F16, f"exl2 grouped member {i} vs its own launch")
         # two to four rows of x: same two launches, every row against its own single-row result (same kernel body, same sums)
-        for M in (2, 3, 4):
+        for M in (2, 3, 4, 6, 8):
             xm = torch.randn((M, K), generator=gen).half()
             xm[0] = x[0]
             outs_m = MBWQLinearCuda.forward_grouped(layers, xm.to(DEV))
@@ -2144,7 +2144,7 @@ def test_binary_linear_cutlass_mm_and_batched_matmul_follow_the_reference_signat
     assert outb.dtype == torch.bfloat16 and torch.equal(outb.cpu(), refb)
 
 
-@pytest.mark.parametrize("M", [1, 2, 3, 4])  # 3, 4: regular groups only (the golden configs are) -- four rows ride on one v_mfma_f32_4x4x4
+@pytest.mark.parametrize("M", [1, 2, 3, 4, 7, 8, 13, 16])  # > 2: regular groups only (the golden configs are) -- four rows ride on one v_mfma_f32_4x4x4, up to four of them per four k
 def test_exl2_list_forward_equals_the_per_layer_calls(M):
     """bie_mbwq_exl2_list_*: several mixed-bit layers (different K / N / band tables, with and without q_perm) in ONE launch must
     give, entry by entry, exactly what bie_mbwq_exl2_forward gives (same kernel body, same slab plan or not: the fp32 sums
