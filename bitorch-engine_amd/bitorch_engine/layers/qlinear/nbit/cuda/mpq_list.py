@@ -137,7 +137,7 @@ class MBWQExl2ForwardList:
     """A list of exl2 (mixed 8/6/5/4/3/2-bit) decode layers in ONE launch (bie_mbwq_exl2_list_*): entry i is one
     `q_linear_cuda.mbwq_exl2_forward(x, qweight, scales, zeros, q_perm, q_group_map, rows)` call of the reference
     (mbwq_linear_cuda_kernel.cu:926-1007) with its own y.  entries: dicts with x, qweight, scales, zeros, q_perm (or None),
-    q_group_map, rows (the band table from mbwq_trans_qweight, which also re-arranged qweight), y.  fp16, M <= 2 (M <= 4 with regular groups)."""
+    q_group_map, rows (the band table from mbwq_trans_qweight, which also re-arranged qweight), y.  fp16, M <= 2 (M <= 16 with regular groups)."""
 
     def __init__(self, entries):
         L = _hip.lib()
@@ -164,7 +164,7 @@ class MBWQExl2ForwardList:
         self._keep = keep
         nbytes = L.bie_mbwq_exl2_list_device_bytes(len(entries), arr, self.M)
         if nbytes == 0:
-            raise RuntimeError("MBWQExl2ForwardList: outside the one-launch decode range (1 <= M <= 2, or <= 4 with regular groups; K % 32 == 0)")
+            raise RuntimeError("MBWQExl2ForwardList: outside the one-launch decode range (1 <= M <= 2, or <= 16 with regular groups; K % 32 == 0)")
         self._mem = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
         base = (self._mem.data_ptr() + 255) // 256 * 256
         handle = ctypes.c_void_p()

@@ -487,7 +487,7 @@ size_t bie_mbwq_exl2_grouped_workspace_bytes(int n_members, const bie_exl2_list_
 int bie_mbwq_exl2_forward_grouped(const void* x, int M, int n_members, const bie_exl2_list_entry* members, void* workspace, size_t workspace_bytes, void* stream) {
     BIE_REQUIRE(x && members && n_members >= 1, BIE_ERR_INVALID_ARG, "bie_mbwq_exl2_forward_grouped: bad argument");
     BIE_REQUIRE(exl2_group_ok(n_members, members, M), BIE_ERR_UNSUPPORTED,
-                "bie_mbwq_exl2_forward_grouped: takes 1..4 rows of x and 1..8 members with K %% 32 == 0, tables from bie_mbwq_exl2_shuffle carrying the REGULAR mark, at most %d column blocks in all", BIE_WS_COUNTERS);
+                "bie_mbwq_exl2_forward_grouped: takes 1..16 rows of x and 1..8 members with K %% 32 == 0, tables from bie_mbwq_exl2_shuffle carrying the REGULAR mark, at most %d column blocks in all", BIE_WS_COUNTERS);
     for (int i = 0; i < n_members; i++)
         BIE_REQUIRE(members[i].qweight && members[i].scales && members[i].zeros && members[i].q_group_map && members[i].y, BIE_ERR_INVALID_ARG,
                     "bie_mbwq_exl2_forward_grouped: NULL tensor pointer in member %d", i);

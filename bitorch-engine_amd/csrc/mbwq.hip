@@ -1618,7 +1618,7 @@ size_t exl2_list_device_bytes(int n, const bie_exl2_list_entry* e, int M) {
 
 int exl2_list_create(Exl2List** out, int n, const bie_exl2_list_entry* e, int M, void* device_mem, size_t device_bytes) {
     BIE_REQUIRE(out && e && device_mem, BIE_ERR_INVALID_ARG, "bie_mbwq_exl2_list_create: NULL argument");
-    BIE_REQUIRE(exl2_list_ok(n, e, M), BIE_ERR_UNSUPPORTED, "bie_mbwq_exl2_list_create: a list takes 1 <= M <= 2 (3, 4 when every entry's table carries the REGULAR mark) and K %% 32 == 0 (fp16 only)");
+    BIE_REQUIRE(exl2_list_ok(n, e, M), BIE_ERR_UNSUPPORTED, "bie_mbwq_exl2_list_create: a list takes 1 <= M <= 2 (up to 16 when every entry's table carries the REGULAR mark) and K %% 32 == 0 (fp16 only)");
     for (int i = 0; i < n; i++) {
         BIE_REQUIRE(e[i].x && e[i].qweight && e[i].scales && e[i].zeros && e[i].q_group_map && e[i].y, BIE_ERR_INVALID_ARG, "bie_mbwq_exl2_list_create: NULL tensor pointer in entry %d", i);
         int prev = 0;

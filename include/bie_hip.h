@@ -243,7 +243,7 @@ int bie_mbwq_exl2_forward(const void* x, const int32_t* qweight, const void* sca
                           const int* rows7_host, void* y, void* workspace, size_t workspace_bytes,
                           int M, int K, int N, int groups, void* stream);
 
-/* A LIST of exl2 decode layers (M <= 2; M <= 4 when every entry's table carries BIE_EXL2_ROWS_REGULAR; fp16) in ONE launch: entry i is exactly one bie_mbwq_exl2_forward call (its own x, packed
+/* A LIST of exl2 decode layers (M <= 2; M <= 16 when every entry's table carries BIE_EXL2_ROWS_REGULAR; fp16) in ONE launch: entry i is exactly one bie_mbwq_exl2_forward call (its own x, packed
  * matrix, band table, q_perm / q_group_map, y).  A 4096x4096 3/2-bit layer is 5 MB -- a lone launch of that size never leaves its
  * start-up transient (0.13-0.17 of the HBM roofline per layer launch); the list form walks the column blocks of every layer in one
  * grid.  Same contract as bie_mpq_list_*: caller-allocated device buffer of bie_mbwq_exl2_list_device_bytes, create uploads the
@@ -268,10 +268,10 @@ int bie_mbwq_exl2_list_create(bie_exl2_list_t** plan, int n_entries, const bie_e
 int bie_mbwq_exl2_list_forward(bie_exl2_list_t* plan, void* stream);
 void bie_mbwq_exl2_list_destroy(bie_exl2_list_t* plan);
 
-/* Up to 8 exl2 layers that consume the SAME activation x[M, K], M <= 4 (q / k / v, gate / up -- every layer has its own q_perm) in two
+/* Up to 8 exl2 layers that consume the SAME activation x[M, K], M <= 16 (q / k / v, gate / up -- every layer has its own q_perm) in two
  * stream-ordered launches and without a plan object: the member descriptors travel in the kernel arguments, so x and the outputs
  * ([M, N_i] each) may be new buffers on every call (members[i].x is ignored).  Members need tables carrying BIE_EXL2_ROWS_REGULAR; fp16.
- * The rows beyond the first cost no weight traffic: four rows ride on one v_mfma_f32_4x4x4.
+ * The rows beyond the first cost no weight traffic: four rows ride on one v_mfma_f32_4x4x4 (measured against lone calls: ahead up to 8 rows).
  * Workspace: zero-filled once (head words as for bie_mbwq_exl2_forward; a buffer may serve both), of
  * bie_mbwq_exl2_grouped_workspace_bytes (0 = not groupable: call bie_mbwq_exl2_forward per member).  The reference launches
  * gemm_half_q_half_kernel once per layer (mbwq_linear_cuda_kernel.cu:926-1007): at 4096x4096 three launches take 3 x 6.7 us here,
