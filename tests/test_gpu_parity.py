@@ -1219,6 +1219,52 @@ def test_exl2_grouped_forward_against_the_oracle_and_the_single_launches():
         assert_close(mixed[1], t16(orc.gemm(orc.torch_to_np(x), Wo, orc.F16), orc.F16), orc.F16, "irregular member alone")
 
 
+def test_exl2_grouped_call_under_graph_replay_and_the_limits_of_the_row_counts():
+    """The grouped call (two launches, scratch from the per-stream workspace) captured in a HIP graph and replayed on NEW activations written
+    into the captured input; and the row limits: a list of three or more rows needs regular groups, a group call never takes more than 16."""
+    from bitorch_engine.extensions import q_linear_cuda
+    from bitorch_engine.layers.qlinear.nbit.cuda import MBWQLinearCuda, MBWQExl2ForwardList
+    gen = torch.Generator().manual_seed(5)
+    K = 512
+    made = [_exl2_layer(K, N, [(4, 64)] * 2 + [(3, 32)] * 8 + [(2, 64)] * 2, gen) for N in (192, 328)]
+    layers = [m[0] for m in made]
+    for l in layers:
+        l.eval().to(DEV)
+        l.prepare_params()
+    members = [(l.qweight.data, l.scales, l.zeros, l.q_perm, l.q_group_map, l.rows) for l in layers]
+    for M in (1, 4):
+        xs = [torch.randn((M, K), generator=gen).half().to(DEV) for _ in range(3)]
+        eager = [q_linear_cuda.mbwq_exl2_forward_grouped(x, members) for x in xs]
+        xin = xs[0].clone()
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            q_linear_cuda.mbwq_exl2_forward_grouped(xin, members)  # warm-up on the capture stream: its workspace exists
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            outs = q_linear_cuda.mbwq_exl2_forward_grouped(xin, members)
+        for x, want in zip(xs, eager):
+            xin.copy_(x)
+            g.replay()
+            torch.cuda.synchronize()
+            for o, w in zip(outs, want):
+                assert torch.equal(o, w), f"graph replay differs from the eager call (M={M})"
+    odd = _exl2_layer(K, 136, [(4, 96)] * 4 + [(2, 32)] * 4, gen)[0]
+    odd.eval().to(DEV)
+    odd.prepare_params()
+    ent = lambda l, M: {"x": torch.zeros((M, K), dtype=torch.half, device=DEV), "qweight": l.qweight.data, "scales": l.scales, "zeros": l.zeros, "q_perm": l.q_perm,
+                        "q_group_map": l.q_group_map, "rows": l.rows, "y": torch.empty((M, l.out_channels), dtype=torch.half, device=DEV)}
+    MBWQExl2ForwardList([ent(odd, 2)])()            # irregular groups: two rows are fine (staged form)
+    with pytest.raises(RuntimeError, match="outside the one-launch decode range"):
+        MBWQExl2ForwardList([ent(odd, 3)])
+    with pytest.raises(RuntimeError, match="outside the one-launch decode range"):
+        MBWQExl2ForwardList([ent(layers[0], 17)])
+    MBWQExl2ForwardList([ent(layers[0], 16)])()
+    assert q_linear_cuda.mbwq_exl2_forward_grouped(torch.zeros((17, K), dtype=torch.half, device=DEV), members) is None
+    assert q_linear_cuda.mbwq_exl2_forward_grouped(torch.zeros((1, K), dtype=torch.half, device=DEV), members + [(odd.qweight.data, odd.scales, odd.zeros, odd.q_perm, odd.q_group_map, odd.rows)]) is None
+    torch.cuda.synchronize()
+
+
 def test_unmodified_exl2_module_tree_gets_grouped_calls_after_prepare_bie_layers():
     """mixed-bit layers behind the reference's module API -- q_proj(h), k_proj(h), v_proj(h), o_proj(a), gate(h2), up(h2),
     down(..) -- run q/k/v and gate/up as ONE grouped call each from the second forward on (counters), with the numbers of the layers'
