@@ -1342,11 +1342,17 @@ def test_unmodified_exl2_module_tree_gets_grouped_calls_after_prepare_bie_layers
             l._bie_group = grp
         assert_close(model(xs[1]), r, orc.F16, "a scaled member")
         # several rows: the layers' own path
-        xp = torch.cat(xs + xs[:1], 0)
-        yp = model(xp)
+        # a few rows (<= 8): still grouped -- another kernel than the members' own at this row count (no per-weight rounding): tolerance;
+        # more rows: the layers' own path, untouched
+        x5, x12 = torch.cat(xs + xs[:1], 0), torch.cat(xs * 3, 0)
+        before = dict(mpq_layer.GROUP_STATS)
+        y5, y12 = model(x5), model(x12)
+        assert mpq_layer.GROUP_STATS["grouped_launches"] - before["grouped_launches"] == 4
         for l in layers:
             l._bie_group = None
-        assert torch.isfinite(yp.float()).all() and torch.equal(yp, model(xp))
+        assert torch.isfinite(y5.float()).all() and torch.isfinite(y12.float()).all()
+        assert_close(y5, model(x5).float().cpu().half(), orc.F16, "five rows, grouped against alone")
+        assert torch.equal(y12, model(x12))
 
 
 @pytest.mark.parametrize("shape", [(1024, 4096, 1024, 4096, 256), (256, 512, 384, 1024, 64), (192, 2048, 3584, 28672, 7168), (40, 512, 256, 768, 512), (4, 512, 256, 768, 0)])
