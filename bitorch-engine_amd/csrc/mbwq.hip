@@ -481,6 +481,11 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
                                                 const float2_t* __restrict__ cs = nullptr) {
     constexpr bool DIRECT = DMODE != 0;
     constexpr bool XP = DMODE == 2;
+    // XW (eight / sixteen rows): x for that many rows does not fit a workgroup's K slab in LDS (16 rows x 4096 k = 128 KiB; cutting K into slabs
+    // brought their reductions back: 8.4 us per layer at 16 rows).  The kernel in front writes xp and the chunk sums CHUNK-MAJOR ([chunk][row][32],
+    // rows beyond M repeating row M - 1): a chunk's activations for all rows are 64 MT contiguous bytes that the WAVE requests with the chunk's packed
+    // words (one 16-byte load per lane) and parks in a wave-private LDS ring -- no workgroup staging, no barrier, one K slab.
+    constexpr bool XW = XP && MT >= 8;
     static_assert(!DIRECT || !STAGED, "the direct forms stage nothing");
     extern __shared__ __attribute__((aligned(16))) uint32_t smem2[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -506,7 +511,7 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
     uint16_t* gmap_s = STAGED ? x_s + MT * slab_k : perm_s + slab_k;           // [chunks_per_slab * 2]
     float2_t* cs_s = reinterpret_cast<float2_t*>(x_s + MT * slab_k);           // DMODE 2: [MT][chunks_per_slab] behind the rows of x
     int two_groups = 0;  // does any chunk of the slab straddle two groups (group sizes below 32)?
-    if constexpr (XP) {
+    if constexpr (XP && !XW) {
         if (xp != nullptr) {  // uniform: the kernel in front has permuted x and summed the chunks
             const int n16 = (c_end - c_begin) * 4;  // 16-byte pieces of a row's slab
 #pragma unroll 1
@@ -612,6 +617,8 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
             uint32_t s[2], z[2];
             uint32_t xraw[STAGED ? 1 : MT];  // !STAGED: this lane's gathered activation(s) of the chunk
             uint32_t p;                      // DIRECT: this lane's permutation index for the NEXT chunk of this set
+            uint4_t xw4;                     // XW: this lane's 16 bytes of the chunk's [row][32] activations
+            float2_t csv;                    // XW: {offset sum, x sum} of row lane % MT
         };
         auto issue_w = [&](int c, Chunk& ch) {
             const int prow = prow0 + (c - cb0) * BITS;
@@ -635,6 +642,10 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
                 ch.s[1] = __builtin_amdgcn_raw_buffer_load_b16(rs, col2, g1, 0);
                 ch.z[1] = __builtin_amdgcn_raw_buffer_load_b16(rz, col2, g1, 0);
             }
+            if constexpr (XW) {
+                ch.xw4 = *reinterpret_cast<const uint4_t*>(xp + (long)c * (MT * 32) + (lane & (MT * 4 - 1)) * 8);
+                ch.csv = cs[(long)c * MT + (lane & (MT - 1))];
+            }
             if constexpr (!STAGED && !XP) {
                 int pidx;
                 if constexpr (DIRECT) {  // v_bfi_b32, no branch on `perm` around a load (a branch costs a wait per load)
@@ -649,7 +660,17 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
         auto compute = [&](int set, int c, const Chunk& ch) {
             const uint16_t* xw = nullptr;
             int xstride = 0;
-            if constexpr (STAGED || XP) {
+            const float2_t* csw = nullptr;
+            if constexpr (XW) {
+                uint16_t* ring = reinterpret_cast<uint16_t*>(smem2) + (wave * 2 + set) * (MT * 36);  // per (wave, set): MT x 64 bytes of x + MT x 8 bytes of sums
+                if (lane < MT * 4) *reinterpret_cast<uint4_t*>(ring + lane * 8) = ch.xw4;
+                if (lane < MT) reinterpret_cast<float2_t*>(ring + MT * 32)[lane] = ch.csv;
+                asm volatile("" ::: "memory");  // same wave writes then reads (see below)
+                __builtin_amdgcn_wave_barrier();
+                xw = ring;
+                xstride = 32;
+                csw = reinterpret_cast<const float2_t*>(ring + MT * 32);
+            } else if constexpr (STAGED || XP) {
                 xw = x_s + (c - c_begin) * 32;
                 xstride = slab_k;
             } else {
@@ -730,10 +751,12 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
                 const float zf = (float)__builtin_bit_cast(half_t, (uint16_t)ch.z[0]);
 #pragma unroll
                 for (int m = 0; m < MT; m++) {
-                    const float2_t v = cs_s[m * chunks_per_slab + (c - c_begin)];
+                    const float2_t v = csw[m];
                     yacc[m] = __builtin_fmaf(sf, dqr[m >> 2][m & 3] - v.x, yacc[m]);
                     yacc[m] = __builtin_fmaf(-zf, v.y, yacc[m]);
                 }
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();  // the ring slot is rewritten by this set's next chunk
                 return;
             }
             // half a chunk at a time -- extraction of 8 pairs, their 4 (x 3) matrix instructions -- so that 8, not 16, operand pairs are live
@@ -1226,17 +1249,20 @@ __global__ __launch_bounds__(512, ((DMODE == 2 && MT == 1) ? 6 : 4)) void exl2_l
 // sums that do not depend on the column: cs[c] = {sum offset_k x_k, sum x_k} -- offset_k is the power of two the field of k carries
 // in the pairs the decode kernel feeds the matrix pipe (exl2_tpairs16), a property of the chunk's bit width and of k's place in it.
 // position k of every row of x: xp[m][k] = x[m][q_perm[k]]; the 32 lanes of a chunk reduce its two sums (cs[m][k / 32])
+// M >= 5 (kernels instantiated for 8 / 16 rows): chunk-major, xp[chunk][row][32] and cs[chunk][row], rows beyond M repeating row M - 1
 __device__ __forceinline__ void exl2_permute_rows(const uint16_t* __restrict__ x, const uint16_t* __restrict__ perm, uint16_t* __restrict__ xp,
                                                   float2_t* __restrict__ cs, const Exl2Rows& rows, int M, int K, int k) {
+    const int MT = M <= 4 ? 0 : (M <= 8 ? 8 : 16);
     const int src = perm ? (int)perm[k] : k;
     int bits = 2;
 #pragma unroll
     for (int b = 5; b >= 0; b--)
         if (k < rows.r[b]) bits = exl2_bits_of_band(b);  // the first band whose end lies beyond k
     const float ofs = exl2_offset_of(bits, (k & 31) >> 1);
-    for (int m = 0; m < M; m++) {
-        const uint16_t xb = x[(long)m * K + src];
-        xp[(long)m * K + k] = xb;
+    for (int m = 0; m < (MT ? MT : M); m++) {
+        const uint16_t xb = x[(long)(m < M ? m : M - 1) * K + src];
+        if (MT) xp[((long)(k >> 5) * MT + m) * 32 + (k & 31)] = xb;
+        else xp[(long)m * K + k] = xb;
         const float xv = f16_bits_to_f32(xb);
         float so = ofs * xv, sx = xv;
 #pragma unroll
@@ -1244,7 +1270,10 @@ __device__ __forceinline__ void exl2_permute_rows(const uint16_t* __restrict__ x
             so += __shfl_xor(so, d, 32);
             sx += __shfl_xor(sx, d, 32);
         }
-        if ((k & 31) == 0) cs[(long)m * (K >> 5) + (k >> 5)] = float2_t{so, sx};
+        if ((k & 31) == 0) {
+            if (MT) cs[(long)(k >> 5) * MT + m] = float2_t{so, sx};
+            else cs[(long)m * (K >> 5) + (k >> 5)] = float2_t{so, sx};
+        }
     }
 }
 __global__ __launch_bounds__(256) void exl2_list_permute_kernel(const Exl2Call* __restrict__ ent) {
@@ -1558,6 +1587,7 @@ static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 // column blocks x K slabs, 8-wave workgroups; ~`want` workgroups in all (two per CU and four rounds), a slab at least 4 chunks
 // per wave (the depth of the kernel's prefetch) and at most CPS_MAX chunks (the LDS copy of the slab's q_perm / group map)
 constexpr int EXL2_XP_MAX_M = 16;  // rows of x of the pre-permuted decode form (four per matrix instruction, up to four instructions per four k)
+static int exl2_xp_rows(int M) { return M <= 4 ? M : (M <= 8 ? 8 : 16); }  // rows the permute kernel writes (chunk-major and padded from five rows on)
 static int exl2_rows_mt(int M) { return M <= 1 ? 1 : (M <= 2 ? 2 : (M <= 4 ? 4 : (M <= 8 ? 8 : 16))); }  // rows of x the list / group kernels are instantiated for
 static bool exl2_all_regular(int n, const bie_exl2_list_entry* e) {
     for (int i = 0; i < n; i++)
@@ -1567,7 +1597,7 @@ static bool exl2_all_regular(int n, const bie_exl2_list_entry* e) {
 static void exl2_list_plan(int n, const bie_exl2_list_entry* e, std::vector<int>& cps, std::vector<int>& S, long* blocks, size_t* gran_bytes,
                            size_t* lds, int Mrows, int target_wgs = 0) {
     const int M = exl2_rows_mt(Mrows);  // everything below is sized for the instantiated row count
-    const int CPS_MAX = 768 / M;
+    const int CPS_MAX = M >= 8 ? (1 << 20) : 768 / M;  // eight / sixteen rows: x travels per wave and chunk, no slab of it in LDS
     long colblocks_all = 0;
     for (int i = 0; i < n; i++) colblocks_all += cdiv(e[i].N, 64);
     cps.resize(n); S.resize(n);
@@ -1587,7 +1617,8 @@ static void exl2_list_plan(int n, const bie_exl2_list_entry* e, std::vector<int>
         *blocks += (long)cb * S[i];
         if (S[i] > 1) *gran_bytes += (size_t)(S[i] - 1) * M * cb * 64 * 8;  // M = the instantiated row count
         size_t l = M > 1 ? (size_t)c * (32 * M + 2) * sizeof(uint16_t) : (size_t)8 * 4 * M * 32 * sizeof(uint16_t) + (size_t)c * 34 * sizeof(uint16_t);
-        if (l < (size_t)c * 72 * M) l = (size_t)c * 72 * M;  // DMODE 2: per row the slab of xp (64 bytes per chunk) + its {offset sum, x sum} pairs
+        if (M < 8 && l < (size_t)c * 72 * M) l = (size_t)c * 72 * M;  // DMODE 2: per row the slab of xp (64 bytes per chunk) + its {offset sum, x sum} pairs
+        if (M >= 8) l = (size_t)8 * 2 * M * 72;                        // eight / sixteen rows: per (wave, set) ring slot of M x (64 + 8) bytes
         const size_t red = (size_t)8 * M * 64 * sizeof(float);
         if (l < red) l = red;
         if (l > *lds) *lds = l;
@@ -1612,7 +1643,7 @@ size_t exl2_list_device_bytes(int n, const bie_exl2_list_entry* e, int M) {
     long tiles = 0;
     for (int i = 0; i < n; i++) tiles += cdiv(e[i].N, 64);
     size_t xp = 0;
-    for (int i = 0; i < n; i++) xp += align256((size_t)M * e[i].K * 2) + align256((size_t)M * (e[i].K / 32) * 8);
+    for (int i = 0; i < n; i++) xp += align256((size_t)exl2_xp_rows(M) * e[i].K * 2) + align256((size_t)exl2_xp_rows(M) * (e[i].K / 32) * 8);
     return align256((size_t)n * sizeof(Exl2Call)) + align256((size_t)blocks * 8) + align256((size_t)tiles * 4) + align256(gran) + xp;
 }
 
@@ -1639,7 +1670,7 @@ int exl2_list_create(Exl2List** out, int n, const bie_exl2_list_entry* e, int M,
     const size_t o_blk = align256((size_t)n * sizeof(Exl2Call)), o_gen = o_blk + align256((size_t)blocks * 8), o_gran = o_gen + align256((size_t)tiles * 4);
     const size_t o_xp = o_gran + align256(gran);
     size_t xp_bytes = 0;
-    for (int i = 0; i < n; i++) xp_bytes += align256((size_t)M * e[i].K * 2) + align256((size_t)M * (e[i].K / 32) * 8);
+    for (int i = 0; i < n; i++) xp_bytes += align256((size_t)exl2_xp_rows(M) * e[i].K * 2) + align256((size_t)exl2_xp_rows(M) * (e[i].K / 32) * 8);
     BIE_REQUIRE(device_bytes >= o_xp + xp_bytes, BIE_ERR_WORKSPACE, "bie_mbwq_exl2_list_create: device buffer of %zu bytes required, got %zu", o_xp + xp_bytes, device_bytes);
     char* base = static_cast<char*>(device_mem);
     std::vector<Exl2Call> he(n);
@@ -1661,9 +1692,9 @@ int exl2_list_create(Exl2List** out, int n, const bie_exl2_list_entry* e, int M,
         for (int k = 0; k < 6; k++) c.rows.r[k] = e[i].rows7[k];
         exl2_fill_groups(c, e[i].rows7);
         c.xp = reinterpret_cast<const uint16_t*>(base + xo);
-        xo += align256((size_t)M * e[i].K * 2);
+        xo += align256((size_t)exl2_xp_rows(M) * e[i].K * 2);
         c.cs = reinterpret_cast<const float2_t*>(base + xo);
-        xo += align256((size_t)M * (e[i].K / 32) * 8);
+        xo += align256((size_t)exl2_xp_rows(M) * (e[i].K / 32) * 8);
         if (c.perm) any_perm = true;
         c.M = M; c.K = e[i].K; c.N = e[i].N; c.chunks_per_slab = cps[i]; c.S = S[i]; c.colblocks = cb;
         BIE_REQUIRE(S[i] < 4096, BIE_ERR_UNSUPPORTED, "bie_mbwq_exl2_list_create: entry %d needs %d K slabs (< 4096)", i, S[i]);
@@ -1747,7 +1778,7 @@ size_t exl2_group_workspace_bytes(int n, const bie_exl2_list_entry* e, int M) {
     long blocks; size_t gran, lds;
     exl2_list_plan(n, e, cps, S, &blocks, &gran, &lds, M, EXL2_GROUP_WGS);
     size_t tot = align256(gran);
-    for (int i = 0; i < n; i++) tot += align256((size_t)M * e[i].K * 2) + align256((size_t)M * (e[i].K / 32) * 8);
+    for (int i = 0; i < n; i++) tot += align256((size_t)exl2_xp_rows(M) * e[i].K * 2) + align256((size_t)exl2_xp_rows(M) * (e[i].K / 32) * 8);
     return tot;
 }
 static size_t exl2_lone_group_bytes(int M, int K, int N) {  // upper bound without the band table: the plan only reads K and N
@@ -1767,7 +1798,8 @@ int exl2_group_forward(int n, const bie_exl2_list_entry* e, const void* x, int M
     // the permute kernel in front (two launches) against every workgroup permuting its own slab (one launch, BIE_EXL2_GROUP_PREPASS=0): measured
     // 12.2 / 14.2 / 14.9 against 12.7 / 18.7 / 19.6 us for 3 x 4096x4096 / 2 x 4096x11008 / 2 x 11008x4096 -- the dependent gather in front of every
     // workgroup's first word costs more than the launch it saves (profiles/r04_exl2_ablation.txt)
-    static const bool prepass = [] { const char* ev = getenv("BIE_EXL2_GROUP_PREPASS"); return !ev || atoi(ev) != 0; }();
+    static const bool prepass_env = [] { const char* ev = getenv("BIE_EXL2_GROUP_PREPASS"); return !ev || atoi(ev) != 0; }();
+    const bool prepass = prepass_env || MT >= 8;  // eight / sixteen rows exist in the pre-permuted, chunk-major form only
     Exl2GroupArgs a;
     std::memset(&a, 0, sizeof(a));
     a.n = n;
@@ -1788,9 +1820,9 @@ int exl2_group_forward(int n, const bie_exl2_list_entry* e, const void* x, int M
         exl2_fill_groups(c, e[i].rows7);
         if (prepass) {
             c.xp = reinterpret_cast<const uint16_t*>(body + xo);
-            xo += align256((size_t)M * e[i].K * 2);
+            xo += align256((size_t)exl2_xp_rows(M) * e[i].K * 2);
             c.cs = reinterpret_cast<const float2_t*>(body + xo);
-            xo += align256((size_t)M * (e[i].K / 32) * 8);
+            xo += align256((size_t)exl2_xp_rows(M) * (e[i].K / 32) * 8);
         }
         c.M = M; c.K = e[i].K; c.N = e[i].N; c.chunks_per_slab = cps[i]; c.S = S[i]; c.colblocks = cb;
         BIE_REQUIRE(S[i] < 4096, BIE_ERR_UNSUPPORTED, "bie_mbwq_exl2_forward_grouped: member %d needs %d K slabs (< 4096)", i, S[i]);
