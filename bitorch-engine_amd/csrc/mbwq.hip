@@ -41,6 +41,11 @@ struct Exl2Rows {
     int r[6];  // cumulative k boundaries of the 8,6,5,4,3,2-bit bands
 };
 
+constexpr int EXL2_XW_MIN_MT = 8;  // from this many (instantiated) rows on, x travels per wave and chunk (chunk-major xp / cs); measured at 4: 2.29 / 5.67 / 4.66 us per layer against 1.84 / 4.31 / 4.99 of the slab form
+__host__ __device__ __forceinline__ int exl2_xp_rows_d(int M) {  // rows the permute kernel writes: M itself below the threshold, padded to 4 / 8 / 16 from it on
+    const int mt = M <= 1 ? 1 : (M <= 2 ? 2 : (M <= 4 ? 4 : (M <= 8 ? 8 : 16)));
+    return mt >= EXL2_XW_MIN_MT ? mt : M;
+}
 __host__ __device__ __forceinline__ int exl2_bits_of_band(int b) {
     return b == 0 ? 8 : (b == 1 ? 6 : (b == 2 ? 5 : (b == 3 ? 4 : (b == 4 ? 3 : 2))));
 }
@@ -485,7 +490,7 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
     // brought their reductions back: 8.4 us per layer at 16 rows).  The kernel in front writes xp and the chunk sums CHUNK-MAJOR ([chunk][row][32],
     // rows beyond M repeating row M - 1): a chunk's activations for all rows are 64 MT contiguous bytes that the WAVE requests with the chunk's packed
     // words (one 16-byte load per lane) and parks in a wave-private LDS ring -- no workgroup staging, no barrier, one K slab.
-    constexpr bool XW = XP && MT >= 8;
+    constexpr bool XW = XP && MT >= EXL2_XW_MIN_MT;
     static_assert(!DIRECT || !STAGED, "the direct forms stage nothing");
     extern __shared__ __attribute__((aligned(16))) uint32_t smem2[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -662,7 +667,7 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
             int xstride = 0;
             const float2_t* csw = nullptr;
             if constexpr (XW) {
-                uint16_t* ring = reinterpret_cast<uint16_t*>(smem2) + (wave * 2 + set) * (MT * 36);  // per (wave, set): MT x 64 bytes of x + MT x 8 bytes of sums
+                uint16_t* ring = reinterpret_cast<uint16_t*>(smem2) + (wave * 2 + (set & 1)) * (MT * 36);  // per (wave, set): MT x 64 bytes of x + MT x 8 bytes of sums
                 if (lane < MT * 4) *reinterpret_cast<uint4_t*>(ring + lane * 8) = ch.xw4;
                 if (lane < MT) reinterpret_cast<float2_t*>(ring + MT * 32)[lane] = ch.csv;
                 asm volatile("" ::: "memory");  // same wave writes then reads (see below)
@@ -708,7 +713,9 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
             if constexpr (XP && MT <= 4) {
 #pragma unroll
                 for (int m = 0; m < MT; m++) {
-                    const float2_t v = cs_s[m * chunks_per_slab + (c - c_begin)];
+                    float2_t v;
+                    if constexpr (XW) v = csw[m];
+                    else v = cs_s[m * chunks_per_slab + (c - c_begin)];
                     dc[m] = v.x;
                     dx[m] = v.y;
                 }
@@ -782,6 +789,10 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
                 __builtin_amdgcn_sched_barrier(0);
             });
             if constexpr (!TWO) apply(0);
+            if constexpr (XW) {
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();  // the ring slot is rewritten two chunks on
+            }
         };
         // this wave's chunks in the band: c = first, first + NW, ... < cb1
         int first = c_begin + wave;
@@ -1252,7 +1263,7 @@ __global__ __launch_bounds__(512, ((DMODE == 2 && MT == 1) ? 6 : 4)) void exl2_l
 // M >= 5 (kernels instantiated for 8 / 16 rows): chunk-major, xp[chunk][row][32] and cs[chunk][row], rows beyond M repeating row M - 1
 __device__ __forceinline__ void exl2_permute_rows(const uint16_t* __restrict__ x, const uint16_t* __restrict__ perm, uint16_t* __restrict__ xp,
                                                   float2_t* __restrict__ cs, const Exl2Rows& rows, int M, int K, int k) {
-    const int MT = M <= 4 ? 0 : (M <= 8 ? 8 : 16);
+    const int MT = exl2_xp_rows_d(M) >= EXL2_XW_MIN_MT ? exl2_xp_rows_d(M) : 0;
     const int src = perm ? (int)perm[k] : k;
     int bits = 2;
 #pragma unroll
@@ -1587,7 +1598,7 @@ static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 // column blocks x K slabs, 8-wave workgroups; ~`want` workgroups in all (two per CU and four rounds), a slab at least 4 chunks
 // per wave (the depth of the kernel's prefetch) and at most CPS_MAX chunks (the LDS copy of the slab's q_perm / group map)
 constexpr int EXL2_XP_MAX_M = 16;  // rows of x of the pre-permuted decode form (four per matrix instruction, up to four instructions per four k)
-static int exl2_xp_rows(int M) { return M <= 4 ? M : (M <= 8 ? 8 : 16); }  // rows the permute kernel writes (chunk-major and padded from five rows on)
+static int exl2_xp_rows(int M) { return exl2_xp_rows_d(M); }  // rows the permute kernel writes (chunk-major and padded from five rows on)
 static int exl2_rows_mt(int M) { return M <= 1 ? 1 : (M <= 2 ? 2 : (M <= 4 ? 4 : (M <= 8 ? 8 : 16))); }  // rows of x the list / group kernels are instantiated for
 static bool exl2_all_regular(int n, const bie_exl2_list_entry* e) {
     for (int i = 0; i < n; i++)
@@ -1597,7 +1608,7 @@ static bool exl2_all_regular(int n, const bie_exl2_list_entry* e) {
 static void exl2_list_plan(int n, const bie_exl2_list_entry* e, std::vector<int>& cps, std::vector<int>& S, long* blocks, size_t* gran_bytes,
                            size_t* lds, int Mrows, int target_wgs = 0) {
     const int M = exl2_rows_mt(Mrows);  // everything below is sized for the instantiated row count
-    const int CPS_MAX = M >= 8 ? (1 << 20) : 768 / M;  // eight / sixteen rows: x travels per wave and chunk, no slab of it in LDS
+    const int CPS_MAX = M >= EXL2_XW_MIN_MT ? (1 << 20) : 768 / M;  // eight / sixteen rows: x travels per wave and chunk, no slab of it in LDS
     long colblocks_all = 0;
     for (int i = 0; i < n; i++) colblocks_all += cdiv(e[i].N, 64);
     cps.resize(n); S.resize(n);
@@ -1617,8 +1628,8 @@ static void exl2_list_plan(int n, const bie_exl2_list_entry* e, std::vector<int>
         *blocks += (long)cb * S[i];
         if (S[i] > 1) *gran_bytes += (size_t)(S[i] - 1) * M * cb * 64 * 8;  // M = the instantiated row count
         size_t l = M > 1 ? (size_t)c * (32 * M + 2) * sizeof(uint16_t) : (size_t)8 * 4 * M * 32 * sizeof(uint16_t) + (size_t)c * 34 * sizeof(uint16_t);
-        if (M < 8 && l < (size_t)c * 72 * M) l = (size_t)c * 72 * M;  // DMODE 2: per row the slab of xp (64 bytes per chunk) + its {offset sum, x sum} pairs
-        if (M >= 8) l = (size_t)8 * 2 * M * 72;                        // eight / sixteen rows: per (wave, set) ring slot of M x (64 + 8) bytes
+        if (M < EXL2_XW_MIN_MT && l < (size_t)c * 72 * M) l = (size_t)c * 72 * M;  // DMODE 2: per row the slab of xp (64 bytes per chunk) + its {offset sum, x sum} pairs
+        if (M >= EXL2_XW_MIN_MT) l = (size_t)8 * 2 * M * 72;                        // eight / sixteen rows: per (wave, set) ring slot of M x (64 + 8) bytes
         const size_t red = (size_t)8 * M * 64 * sizeof(float);
         if (l < red) l = red;
         if (l > *lds) *lds = l;
@@ -1799,7 +1810,7 @@ int exl2_group_forward(int n, const bie_exl2_list_entry* e, const void* x, int M
     // 12.2 / 14.2 / 14.9 against 12.7 / 18.7 / 19.6 us for 3 x 4096x4096 / 2 x 4096x11008 / 2 x 11008x4096 -- the dependent gather in front of every
     // workgroup's first word costs more than the launch it saves (profiles/r04_exl2_ablation.txt)
     static const bool prepass_env = [] { const char* ev = getenv("BIE_EXL2_GROUP_PREPASS"); return !ev || atoi(ev) != 0; }();
-    const bool prepass = prepass_env || MT >= 8;  // eight / sixteen rows exist in the pre-permuted, chunk-major form only
+    const bool prepass = prepass_env || MT >= EXL2_XW_MIN_MT;  // eight / sixteen rows exist in the pre-permuted, chunk-major form only
     Exl2GroupArgs a;
     std::memset(&a, 0, sizeof(a));
     a.n = n;

@@ -271,7 +271,7 @@ void bie_mbwq_exl2_list_destroy(bie_exl2_list_t* plan);
 /* Up to 8 exl2 layers that consume the SAME activation x[M, K], M <= 16 (q / k / v, gate / up -- every layer has its own q_perm) in two
  * stream-ordered launches and without a plan object: the member descriptors travel in the kernel arguments, so x and the outputs
  * ([M, N_i] each) may be new buffers on every call (members[i].x is ignored).  Members need tables carrying BIE_EXL2_ROWS_REGULAR; fp16.
- * The rows beyond the first cost no weight traffic: four rows ride on one v_mfma_f32_4x4x4 (measured against lone calls: ahead up to 8 rows).
+ * The rows beyond the first cost no weight traffic: four rows ride on one v_mfma_f32_4x4x4 (measured against lone calls: ahead at every row count up to 16).
  * Workspace: zero-filled once (head words as for bie_mbwq_exl2_forward; a buffer may serve both), of
  * bie_mbwq_exl2_grouped_workspace_bytes (0 = not groupable: call bie_mbwq_exl2_forward per member).  The reference launches
  * gemm_half_q_half_kernel once per layer (mbwq_linear_cuda_kernel.cu:926-1007): at 4096x4096 three launches take 3 x 6.7 us here,

@@ -1198,8 +1198,9 @@ def test_exl2_grouped_forward_against_the_oracle_and_the_single_launches():
         singles = [l(x.to(DEV)) for l in layers]
         for i, (o, sgl) in enumerate(zip(outs, singles)):
             assert_close(o, sgl.float().cpu().half(), orc.F16, f"exl2 grouped member {i} vs its own launch")
-        # two to four rows of x: same two launches, every row against its own single-row result (same kernel body, same sums)
-        for M in (2, 3, 4, 6, 8):
+        # two to sixteen rows of x: same two launches, every row against its own single-row result (same sums whatever the instance:
+        # 1 / 2 / 4 rows with the slab of x in LDS, 8 / 16 rows with x per wave and chunk)
+        for M in (2, 3, 4, 6, 8, 13, 16):
             xm = torch.randn((M, K), generator=gen).half()
             xm[0] = x[0]
             outs_m = MBWQLinearCuda.forward_grouped(layers, xm.to(DEV))
@@ -1341,18 +1342,18 @@ def test_unmodified_exl2_module_tree_gets_grouped_calls_after_prepare_bie_layers
         for l, grp in zip(layers, saved):
             l._bie_group = grp
         assert_close(model(xs[1]), r, orc.F16, "a scaled member")
-        # several rows: the layers' own path
-        # a few rows (<= 8): still grouped -- another kernel than the members' own at this row count (no per-weight rounding): tolerance;
+        # a few rows (<= 16): still grouped -- another kernel than the members' own at this row count (no per-weight rounding): tolerance;
         # more rows: the layers' own path, untouched
-        x5, x12 = torch.cat(xs + xs[:1], 0), torch.cat(xs * 3, 0)
+        x5, x12, x20 = torch.cat(xs + xs[:1], 0), torch.cat(xs * 3, 0), torch.cat(xs * 5, 0)
         before = dict(mpq_layer.GROUP_STATS)
-        y5, y12 = model(x5), model(x12)
-        assert mpq_layer.GROUP_STATS["grouped_launches"] - before["grouped_launches"] == 4
+        y5, y12, y20 = model(x5), model(x12), model(x20)
+        assert mpq_layer.GROUP_STATS["grouped_launches"] - before["grouped_launches"] == 8
         for l in layers:
             l._bie_group = None
-        assert torch.isfinite(y5.float()).all() and torch.isfinite(y12.float()).all()
+        assert all(torch.isfinite(y.float()).all() for y in (y5, y12, y20))
         assert_close(y5, model(x5).float().cpu().half(), orc.F16, "five rows, grouped against alone")
-        assert torch.equal(y12, model(x12))
+        assert_close(y12, model(x12).float().cpu().half(), orc.F16, "twelve rows, grouped against alone")
+        assert torch.equal(y20, model(x20))
 
 
 @pytest.mark.parametrize("shape", [(1024, 4096, 1024, 4096, 256), (256, 512, 384, 1024, 64), (192, 2048, 3584, 28672, 7168), (40, 512, 256, 768, 512), (4, 512, 256, 768, 0)])
