@@ -1380,6 +1380,7 @@ static int exl2_slabs(int K, int N) {
 // A lone layer with a long K runs as a group of ONE (permute kernel + the pre-permuted decode body): 11008x4096 11.6 against 12.2 us, 14336x4096 12.2
 // against 13.6, 28672x8192 26.4 against 39.1; at K <= 8192 the lone direct launch is ahead (profiles/r04_exl2_ablation.txt)
 constexpr int EXL2_LONE_AS_GROUP_MIN_K = 10240;
+constexpr int EXL2_XP_MAX_M = 16;  // rows of x of the pre-permuted decode form (four per matrix instruction, up to four instructions per four k)
 static size_t exl2_lone_group_bytes(int M, int K, int N);
 int exl2_group_forward(int n, const bie_exl2_list_entry* e, const void* x, int M, float* head, char* body, hipStream_t st);
 
@@ -1469,7 +1470,10 @@ int mbwq_exl2_forward_launch(const void* x, const int32_t* qw, const void* scale
     const bool slab_ok = !(cdiv(N, 64) > BIE_WS_COUNTERS && K / 32 > 768);  // K slabs need one generation word per column block
     const bool regular = (rows7[6] & BIE_EXL2_ROWS_REGULAR) && exl2_direct_on();
     static const int lone_min_k = [] { const char* ev = getenv("BIE_EXL2_LONE_AS_GROUP_MIN_K"); return ev ? atoi(ev) : EXL2_LONE_AS_GROUP_MIN_K; }();
-    if (M <= 2 && regular && K >= lone_min_k && K % 32 == 0 && cdiv(N, 64) <= BIE_WS_COUNTERS && exl2_xp_on()) {
+    static const int lone_rows_lo = [] { const char* ev = getenv("BIE_EXL2_LONE_ROWS_LO"); return ev ? atoi(ev) : 1 << 30; }();
+    static const int lone_rows_hi = [] { const char* ev = getenv("BIE_EXL2_LONE_ROWS_HI"); return ev ? atoi(ev) : 0; }();
+    const bool rows_as_group = M >= lone_rows_lo && M <= lone_rows_hi && M <= EXL2_XP_MAX_M;
+    if (((M <= 2 && K >= lone_min_k) || rows_as_group) && regular && K % 32 == 0 && cdiv(N, 64) <= BIE_WS_COUNTERS && exl2_xp_on()) {
         bie_exl2_list_entry one{};
         one.x = x; one.qweight = qw; one.scales = scales; one.zeros = zeros; one.q_perm = perm; one.q_group_map = gmap; one.rows7 = rows7; one.y = y;
         one.K = K; one.N = N;
@@ -1597,7 +1601,6 @@ static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
 // column blocks x K slabs, 8-wave workgroups; ~`want` workgroups in all (two per CU and four rounds), a slab at least 4 chunks
 // per wave (the depth of the kernel's prefetch) and at most CPS_MAX chunks (the LDS copy of the slab's q_perm / group map)
-constexpr int EXL2_XP_MAX_M = 16;  // rows of x of the pre-permuted decode form (four per matrix instruction, up to four instructions per four k)
 static int exl2_xp_rows(int M) { return exl2_xp_rows_d(M); }  // rows the permute kernel writes (chunk-major and padded from five rows on)
 static int exl2_rows_mt(int M) { return M <= 1 ? 1 : (M <= 2 ? 2 : (M <= 4 ? 4 : (M <= 8 ? 8 : 16))); }  // rows of x the list / group kernels are instantiated for
 static bool exl2_all_regular(int n, const bie_exl2_list_entry* e) {
@@ -1793,13 +1796,13 @@ size_t exl2_group_workspace_bytes(int n, const bie_exl2_list_entry* e, int M) {
     return tot;
 }
 static size_t exl2_lone_group_bytes(int M, int K, int N) {  // upper bound without the band table: the plan only reads K and N
-    if (M < 1 || M > 2 || K % 32 != 0 || K <= 0 || N <= 0) return 0;
+    if (M < 1 || M > EXL2_XP_MAX_M || K % 32 != 0 || K <= 0 || N <= 0) return 0;
     bie_exl2_list_entry one{};
     one.K = K; one.N = N;
     std::vector<int> cps, S;
     long blocks; size_t gran, lds;
     exl2_list_plan(1, &one, cps, S, &blocks, &gran, &lds, M, EXL2_GROUP_WGS);
-    return align256(gran) + align256((size_t)M * K * 2) + align256((size_t)M * (K / 32) * 8);
+    return align256(gran) + align256((size_t)exl2_xp_rows(M) * K * 2) + align256((size_t)exl2_xp_rows(M) * (K / 32) * 8);
 }
 int exl2_group_forward(int n, const bie_exl2_list_entry* e, const void* x, int M, float* head, char* body, hipStream_t st) {
     std::vector<int> cps, S;
