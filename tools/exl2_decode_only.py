@@ -17,8 +17,11 @@ for (K, N) in ((4096, 4096), (4096, 11008), (11008, 4096)):
     MIX = os.environ.get("EXL2_MIX", "3:1,2:1")  # bits:share, in band order
     mix = [(int(a.split(":")[0]), int(a.split(":")[1])) for a in MIX.split(",")]
     tot = sum(w for _, w in mix)
-    for b, w in mix:
-        for _ in range(K // 32 * w // tot):
+    left = K // 32
+    for i, (b, w) in enumerate(mix):
+        cnt = left if i == len(mix) - 1 else K // 32 * w // tot  # the last band takes the remainder: every chunk of K belongs to a group
+        left -= cnt
+        for _ in range(cnt):
             qg += [b, row]; row += b
     groups = len(qg) // 2
     q_groups = torch.tensor(qg, dtype=torch.short)
