@@ -1220,6 +1220,46 @@ def test_exl2_grouped_forward_against_the_oracle_and_the_single_launches():
         assert_close(mixed[1], t16(orc.gemm(orc.torch_to_np(x), Wo, orc.F16), orc.F16), orc.F16, "irregular member alone")
 
 
+@pytest.mark.parametrize("M", [1, 4, 5, 8, 16])
+def test_exl2_grouped_and_list_calls_with_k_slabs_against_the_oracle(M):
+    """K = 4096 with few column blocks: the plans cut K into slabs (S > 1), so the tagged-granule reduction across workgroups runs in every
+    row form -- the slab of x in LDS (1 / 4 rows) and x per wave and chunk (8 / 16 rows; 5 rows run the 8-row instance with rows repeated).
+    Wide and narrow band tables, ragged N, each member its own q_perm.  Grouped call and list launch against the oracle, and against each other."""
+    from bitorch_engine.extensions import q_linear_cuda
+    from bitorch_engine.layers.qlinear.nbit.cuda import MBWQLinearCuda, MBWQExl2ForwardList
+    gen = torch.Generator().manual_seed(4096 + M)
+    K = 4096
+    specs = [[(4, 128)] * 8 + [(3, 32)] * 48 + [(2, 64)] * 24, [(8, 32)] * 4 + [(6, 64)] * 6 + [(5, 32)] * 16 + [(4, 64)] * 16 + [(3, 32)] * 32 + [(2, 128)] * 8]
+    assert all(sum(k for _, k in sp) == K for sp in specs)
+    made = [_exl2_layer(K, N, sp, gen) for N, sp in zip((200, 328), specs)]
+    layers = [m[0] for m in made]
+    for l in layers:
+        l.eval().to(DEV)
+        l.prepare_params()
+        assert l.rows[6] & 0x200  # regular structure
+    x = (torch.randn((M, K), generator=gen) * 0.5).half()
+    refs = []
+    for l, qw, qg in made:
+        Wo = orc.exl2_dequant(qw.numpy(), orc.torch_to_np(l.scales.cpu()), orc.torch_to_np(l.zeros.cpu()), l.q_perm.cpu().numpy(), np.array(qg, np.int16), K)
+        refs.append(t16(orc.gemm(orc.torch_to_np(x), Wo, orc.F16), orc.F16))
+    members = [(l.qweight.data, l.scales, l.zeros, l.q_perm, l.q_group_map, l.rows) for l in layers]
+    xd = x.to(DEV)
+    outs = q_linear_cuda.mbwq_exl2_forward_grouped(xd, members)
+    assert outs is not None
+    for i, (o, r) in enumerate(zip(outs, refs)):
+        assert_close(o, r, orc.F16, f"grouped call, K slabs, member {i} M={M}")
+    again = q_linear_cuda.mbwq_exl2_forward_grouped(xd, members)  # the generation words of the reduction advance from call to call
+    assert all(torch.equal(a, b) for a, b in zip(outs, again))
+    entries = [{"x": xd, "qweight": l.qweight.data, "scales": l.scales, "zeros": l.zeros, "q_perm": l.q_perm, "q_group_map": l.q_group_map, "rows": l.rows,
+                "y": torch.full((M, l.out_channels), float("nan"), dtype=torch.half, device=DEV)} for l in layers]
+    plan = MBWQExl2ForwardList(entries)
+    for _ in range(3):
+        plan()
+    torch.cuda.synchronize()
+    for i, (e, r) in enumerate(zip(entries, refs)):
+        assert_close(e["y"], r, orc.F16, f"list launch, K slabs, entry {i} M={M}")
+
+
 def test_exl2_grouped_call_under_graph_replay_and_the_limits_of_the_row_counts():
     """The grouped call (two launches, scratch from the per-stream workspace) captured in a HIP graph and replayed on NEW activations written
     into the captured input; and the row limits: a list of three or more rows needs regular groups, a group call never takes more than 16."""
