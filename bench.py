@@ -497,7 +497,7 @@ def bench_exl2(dev):
                                      "frac": round(byts / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None}})
         # the same layers, each with its own x, as ONE launch (bie_mbwq_exl2_list_*); four rows of x ride on the same matrix instruction
         from bitorch_engine.layers.qlinear.nbit.cuda import MBWQExl2ForwardList
-        for Ml in (1, 4, 8, 16):
+        for Ml in (1, 2, 4, 8, 16):
             ents = [{"x": torch.randn((Ml, K), device=dev).half(), "qweight": s_[0], "scales": s_[1], "zeros": s_[2], "q_perm": perm, "q_group_map": gmap,
                      "rows": rows, "y": torch.empty((Ml, N), dtype=torch.float16, device=dev)} for s_ in sets]
             plan = MBWQExl2ForwardList(ents)

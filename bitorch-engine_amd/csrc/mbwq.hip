@@ -41,11 +41,8 @@ struct Exl2Rows {
     int r[6];  // cumulative k boundaries of the 8,6,5,4,3,2-bit bands
 };
 
-constexpr int EXL2_XW_MIN_MT = 8;  // from this many (instantiated) rows on, x travels per wave and chunk (chunk-major xp / cs); measured at 4: 2.29 / 5.67 / 4.66 us per layer against 1.84 / 4.31 / 4.99 of the slab form
-__host__ __device__ __forceinline__ int exl2_xp_rows_d(int M) {  // rows the permute kernel writes: M itself below the threshold, padded to 4 / 8 / 16 from it on
-    const int mt = M <= 1 ? 1 : (M <= 2 ? 2 : (M <= 4 ? 4 : (M <= 8 ? 8 : 16)));
-    return mt >= EXL2_XW_MIN_MT ? mt : M;
-}
+// rows of x the pre-permuted decode form is instantiated for (and the kernel in front writes: chunk-major, rows beyond M repeating row M - 1)
+__host__ __device__ __forceinline__ int exl2_xp_rows_d(int M) { return M <= 1 ? 1 : (M <= 2 ? 2 : (M <= 4 ? 4 : (M <= 8 ? 8 : 16))); }
 __host__ __device__ __forceinline__ int exl2_bits_of_band(int b) {
     return b == 0 ? 8 : (b == 1 ? 6 : (b == 2 ? 5 : (b == 3 ? 4 : (b == 4 ? 3 : 2))));
 }
@@ -474,6 +471,10 @@ struct Exl2Groups {
 typedef float exl2_acc_t __attribute__((ext_vector_type(4)));
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ exl2_acc_t exl2_mfma4(half4_t a, half4_t b, exl2_acc_t c) { return __builtin_amdgcn_mfma_f32_4x4x4f16(a, b, c, 0, 0, 0); }
+// the same instruction with ONE block's A operand broadcast to all sixteen (cbsz = 4): lanes 4 ABID .. 4 ABID + 3 hold rows 0..3 of the 4 x 4 A block,
+// every block multiplies it with its own B (tools/probe/probe_mfma_bcast.hip: semantics checked on gfx950)
+template <int ABID>
+__device__ __forceinline__ exl2_acc_t exl2_mfma4_bcast(half4_t a, half4_t b, exl2_acc_t c) { return __builtin_amdgcn_mfma_f32_4x4x4f16(a, b, c, 4, ABID, 0); }
 template <int MT, int EX2_NW, bool STAGED, bool NARROW, int DMODE = 0>
 __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, const uint32_t* __restrict__ qw,
                                                 const uint16_t* __restrict__ scales, const uint16_t* __restrict__ zeros,
@@ -486,11 +487,17 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
                                                 const float2_t* __restrict__ cs = nullptr) {
     constexpr bool DIRECT = DMODE != 0;
     constexpr bool XP = DMODE == 2;
-    // XW (eight / sixteen rows): x for that many rows does not fit a workgroup's K slab in LDS (16 rows x 4096 k = 128 KiB; cutting K into slabs
-    // brought their reductions back: 8.4 us per layer at 16 rows).  The kernel in front writes xp and the chunk sums CHUNK-MAJOR ([chunk][row][32],
-    // rows beyond M repeating row M - 1): a chunk's activations for all rows are 64 MT contiguous bytes that the WAVE requests with the chunk's packed
-    // words (one 16-byte load per lane) and parks in a wave-private LDS ring -- no workgroup staging, no barrier, one K slab.
-    constexpr bool XW = XP && MT >= EXL2_XW_MIN_MT;
+    // XW (two rows and more): the kernel in front writes xp and the chunk sums CHUNK-MAJOR ([chunk][row][32], rows beyond M repeating row M - 1): a
+    // chunk's activations for all rows are 64 MT contiguous bytes that the WAVE requests with the chunk's packed words -- no workgroup staging and no
+    // barrier in front of the first weight request (a workgroup of a group call lives for four chunks per wave: the staging round trip was a third
+    // of it), and no LDS limit on the slab (x for 16 rows x 4096 k would be 128 KiB).  The matrix instruction's A operand is the same 4 x 4 block of x
+    // for all sixteen column blocks of the wave: it is BROADCAST by the instruction (cbsz = 4, abid = the block that holds it), so lane l = (block b,
+    // row r) keeps in ONE register pair the four k of step b % 8 (row group b / 8) of row r -- the whole [MT][32] block of the chunk is one 8-byte
+    // load per lane (two at sixteen rows), no LDS ring, no 16-byte LDS reads per step (they were the LDS pipe's load at 8 / 16 rows); the chunk's
+    // {offset sum, x sum} pairs are wave-uniform: scalar loads.
+    constexpr bool XW = XP;  // (an earlier form of DMODE 2 copied the workgroup's K slab of xp into LDS: a staging round trip in front of every workgroup's first weight
+                             //  request and 16-byte LDS reads per step -- sibling groups 12.5 / 15.9 / 20.4 us at 1 / 2 / 4 rows against 11.6 / 11.9 / 12.3, lists at 4 / 8 / 16 rows
+                             //  1.86 / 4.53 / 8.37 us per layer against 1.41 / 1.81 / 2.83: profiles/r04_exl2_ablation.txt)
     static_assert(!DIRECT || !STAGED, "the direct forms stage nothing");
     extern __shared__ __attribute__((aligned(16))) uint32_t smem2[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -514,51 +521,7 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
     uint16_t* xs = reinterpret_cast<uint16_t*>(smem2) + wave * (4 * MT * 32);  // !STAGED: wave-private [set 0..3][MT][32]
     uint16_t* perm_s = reinterpret_cast<uint16_t*>(smem2) + EX2_NW * (4 * MT * 32);  // !STAGED: [slab_k]
     uint16_t* gmap_s = STAGED ? x_s + MT * slab_k : perm_s + slab_k;           // [chunks_per_slab * 2]
-    float2_t* cs_s = reinterpret_cast<float2_t*>(x_s + MT * slab_k);           // DMODE 2: [MT][chunks_per_slab] behind the rows of x
     int two_groups = 0;  // does any chunk of the slab straddle two groups (group sizes below 32)?
-    if constexpr (XP && !XW) {
-        if (xp != nullptr) {  // uniform: the kernel in front has permuted x and summed the chunks
-            const int n16 = (c_end - c_begin) * 4;  // 16-byte pieces of a row's slab
-#pragma unroll 1
-            for (int m = 0; m < MT; m++) {  // rows beyond M copy row M - 1: never stored, never out of bounds
-                const int mr = m < M ? m : M - 1;
-                const uint4_t* src = reinterpret_cast<const uint4_t*>(xp + (long)mr * K + (long)c_begin * 32);
-                uint4_t* dst = reinterpret_cast<uint4_t*>(x_s + m * slab_k);
-                for (int i = tid; i < n16; i += EX2_NW * 64) dst[i] = src[i];
-                for (int i = tid; i < (c_end - c_begin); i += EX2_NW * 64) cs_s[m * chunks_per_slab + i] = cs[(long)mr * C + c_begin + i];
-            }
-            __syncthreads();
-        } else {  // the group call: this workgroup permutes its own slab (one launch less; the list form amortises a kernel in front instead)
-            const int nk = (c_end - c_begin) * 32;
-            for (int i = tid; i < nk; i += EX2_NW * 64) {
-                const int kx = perm ? (int)perm[c_begin * 32 + i] : c_begin * 32 + i;
-#pragma unroll
-                for (int m = 0; m < MT; m++) x_s[m * slab_k + i] = x[(long)(m < M ? m : M - 1) * K + kx];
-            }
-            __syncthreads();
-            for (int ci = wave; ci < c_end - c_begin; ci += EX2_NW) {  // a chunk's two sums: its 32 values on the lanes of each half-wave (row m, m + 1)
-                const int k0 = (c_begin + ci) * 32;
-                int bits = 2;
-#pragma unroll
-                for (int b = 5; b >= 0; b--)
-                    if (k0 < rows.r[b]) bits = exl2_bits_of_band(b);
-                const float ofs = exl2_offset_of(bits, (lane & 31) >> 1);
-#pragma unroll
-                for (int m0 = 0; m0 < MT; m0 += 2) {
-                    const int m = m0 + (lane >> 5);
-                    const float xv = f16_bits_to_f32(x_s[(m < MT ? m : 0) * slab_k + ci * 32 + (lane & 31)]);
-                    float so = ofs * xv, sx = xv;
-#pragma unroll
-                    for (int d = 1; d < 32; d <<= 1) {
-                        so += __shfl_xor(so, d, 32);
-                        sx += __shfl_xor(sx, d, 32);
-                    }
-                    if ((lane & 31) == 0 && m < MT) cs_s[m * chunks_per_slab + ci] = float2_t{so, sx};
-                }
-            }
-            __syncthreads();
-        }
-    }
     if constexpr (!DIRECT) {
         const int nk = (c_end - c_begin) * 32;
         for (int i = tid; i < nk; i += EX2_NW * 64) {
@@ -581,6 +544,10 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
     float yacc[MT];
 #pragma unroll
     for (int m = 0; m < MT; m++) yacc[m] = 0.f;
+    typedef const __attribute__((address_space(4))) float2_t cfloat2_t;
+    // XW: where in a chunk's [MT][32] block this lane's A-operand pair lies (halves): row 4 (lane / 32) + lane % 4 (the last row again beyond MT), k = 4 ((lane / 4) % 8)
+    const int xa_row = 4 * (lane >> 5) + (lane & 3);
+    const int xa_off = (xa_row < MT ? xa_row : MT - 1) * 32 + 4 * ((lane >> 2) & 7);
     const int xrow = MT > 1 ? ((lane & 3) < M ? (lane & 3) : M - 1) : 0;  // the row of x this lane feeds the matrix pipe with (MT <= 4; more rows: per row group)
     const Exl2Magic magic;
     uint2_t ones2 = uint2_t{0x3c003c00u, 0x3c003c00u};
@@ -622,8 +589,9 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
             uint32_t s[2], z[2];
             uint32_t xraw[STAGED ? 1 : MT];  // !STAGED: this lane's gathered activation(s) of the chunk
             uint32_t p;                      // DIRECT: this lane's permutation index for the NEXT chunk of this set
-            uint4_t xw4;                     // XW: this lane's 16 bytes of the chunk's [row][32] activations
-            float2_t csv;                    // XW: {offset sum, x sum} of row lane % MT
+            uint2_t xa[XW ? (MT + 7) / 8 : 1];  // XW: this lane's A-operand pair(s): row (lane % 4) of row group (lane / 32) [+ 2], k = 4 ((lane / 4) % 8) .. + 3
+            float2_t csv[XW && MT <= 4 ? MT : 1];  // XW, up to four rows: {offset sum, x sum} of every row (wave-uniform: scalar registers)
+            uint2_t csl;                           // XW, eight / sixteen rows (fp32 bit patterns): the pair of row lane % MT (32 / 64 scalar registers per two chunks in flight do not exist)
         };
         auto issue_w = [&](int c, Chunk& ch) {
             const int prow = prow0 + (c - cb0) * BITS;
@@ -648,8 +616,16 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
                 ch.z[1] = __builtin_amdgcn_raw_buffer_load_b16(rz, col2, g1, 0);
             }
             if constexpr (XW) {
-                ch.xw4 = *reinterpret_cast<const uint4_t*>(xp + (long)c * (MT * 32) + (lane & (MT * 4 - 1)) * 8);
-                ch.csv = cs[(long)c * MT + (lane & (MT - 1))];
+                const uint16_t* xc = xp + (long)c * (MT * 32);
+                ch.xa[0] = *reinterpret_cast<const uint2_t*>(xc + xa_off);
+                if constexpr (MT > 8) ch.xa[1] = *reinterpret_cast<const uint2_t*>(xc + xa_off + 8 * 32);  // row groups 2, 3
+                if constexpr (MT <= 4) {
+                    const cfloat2_t* cc = (const cfloat2_t*)cs + (long)c * MT;  // constant address space: scalar loads (written by the kernel in front)
+#pragma unroll
+                    for (int m = 0; m < MT; m++) ch.csv[m] = cc[m];
+                } else {
+                    ch.csl = reinterpret_cast<const uint2_t*>(cs)[(long)c * MT + (lane & (MT - 1))];
+                }
             }
             if constexpr (!STAGED && !XP) {
                 int pidx;
@@ -667,15 +643,8 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
             int xstride = 0;
             const float2_t* csw = nullptr;
             if constexpr (XW) {
-                uint16_t* ring = reinterpret_cast<uint16_t*>(smem2) + (wave * 2 + (set & 1)) * (MT * 36);  // per (wave, set): MT x 64 bytes of x + MT x 8 bytes of sums
-                if (lane < MT * 4) *reinterpret_cast<uint4_t*>(ring + lane * 8) = ch.xw4;
-                if (lane < MT) reinterpret_cast<float2_t*>(ring + MT * 32)[lane] = ch.csv;
-                asm volatile("" ::: "memory");  // same wave writes then reads (see below)
-                __builtin_amdgcn_wave_barrier();
-                xw = ring;
-                xstride = 32;
-                csw = reinterpret_cast<const float2_t*>(ring + MT * 32);
-            } else if constexpr (STAGED || XP) {
+                csw = ch.csv;
+            } else if constexpr (STAGED) {
                 xw = x_s + (c - c_begin) * 32;
                 xstride = slab_k;
             } else {
@@ -713,9 +682,7 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
             if constexpr (XP && MT <= 4) {
 #pragma unroll
                 for (int m = 0; m < MT; m++) {
-                    float2_t v;
-                    if constexpr (XW) v = csw[m];
-                    else v = cs_s[m * chunks_per_slab + (c - c_begin)];
+                    const float2_t v = csw[m];
                     dc[m] = v.x;
                     dx[m] = v.y;
                 }
@@ -742,15 +709,11 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
                     exl2_tpairs16<BITS, 8 * half, 8 * half + 8>(w8, magic, T);
                     exl2_static_for<0, RG>([&](auto rr) {
                         constexpr int rg = decltype(rr)::value;
-                        const int mr = 4 * rg + (lane & 3);
-                        const uint16_t* xr = xw + (mr < M ? mr : M - 1) * xstride;
-                        const uint4_t xa = reinterpret_cast<const uint4_t*>(xr)[2 * half], xb = reinterpret_cast<const uint4_t*>(xr)[2 * half + 1];
-                        const uint32_t xd[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-#pragma unroll
-                        for (int i = 0; i < 4; i++) {
-                            const int j = 8 * half + 2 * i;
-                            dqr[rg] = exl2_mfma4(__builtin_bit_cast(half4_t, uint2_t{xd[2 * i], xd[2 * i + 1]}), __builtin_bit_cast(half4_t, uint2_t{T[j], T[j + 1]}), dqr[rg]);
-                        }
+                        exl2_static_for<0, 4>([&](auto ii) {
+                            constexpr int i = decltype(ii)::value;
+                            constexpr int j = 8 * half + 2 * i;
+                            dqr[rg] = exl2_mfma4_bcast<(rg & 1) * 8 + 4 * half + i>(__builtin_bit_cast(half4_t, ch.xa[rg >> 1]), __builtin_bit_cast(half4_t, uint2_t{T[j], T[j + 1]}), dqr[rg]);
+                        });
                     });
                     __builtin_amdgcn_sched_barrier(0);
                 });
@@ -758,18 +721,24 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
                 const float zf = (float)__builtin_bit_cast(half_t, (uint16_t)ch.z[0]);
 #pragma unroll
                 for (int m = 0; m < MT; m++) {
-                    const float2_t v = csw[m];
-                    yacc[m] = __builtin_fmaf(sf, dqr[m >> 2][m & 3] - v.x, yacc[m]);
-                    yacc[m] = __builtin_fmaf(-zf, v.y, yacc[m]);
+                    const float so = __builtin_bit_cast(float, __builtin_amdgcn_readlane((int)ch.csl.x, m));  // row m's pair sits in lane m
+                    const float sx = __builtin_bit_cast(float, __builtin_amdgcn_readlane((int)ch.csl.y, m));
+                    yacc[m] = __builtin_fmaf(sf, dqr[m >> 2][m & 3] - so, yacc[m]);
+                    yacc[m] = __builtin_fmaf(-zf, sx, yacc[m]);
                 }
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_wave_barrier();  // the ring slot is rewritten by this set's next chunk
                 return;
             }
             // half a chunk at a time -- extraction of 8 pairs, their 4 (x 3) matrix instructions -- so that 8, not 16, operand pairs are live
             exl2_static_for<0, 2>([&](auto hh) {
                 constexpr int half = decltype(hh)::value;
                 exl2_tpairs16<BITS, 8 * half, 8 * half + 8>(w8, magic, T);
+                if constexpr (XW) {
+                    exl2_static_for<0, 4>([&](auto ii) {
+                        constexpr int i = decltype(ii)::value;
+                        constexpr int j = 8 * half + 2 * i;
+                        dq = exl2_mfma4_bcast<4 * half + i>(__builtin_bit_cast(half4_t, ch.xa[0]), __builtin_bit_cast(half4_t, uint2_t{T[j], T[j + 1]}), dq);
+                    });
+                } else {
                 const uint4_t xa = reinterpret_cast<const uint4_t*>(xw + xrow * xstride)[2 * half], xb = reinterpret_cast<const uint4_t*>(xw + xrow * xstride)[2 * half + 1];
                 const uint32_t xd[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
 #pragma unroll
@@ -782,6 +751,7 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
                         dx = exl2_mfma4(av, ones4, dx);
                     }
                 }
+                }
                 if constexpr (TWO) {
                     apply(half);
                     dq = zero4; dc = zero4; dx = zero4;
@@ -789,10 +759,6 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
                 __builtin_amdgcn_sched_barrier(0);
             });
             if constexpr (!TWO) apply(0);
-            if constexpr (XW) {
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_wave_barrier();  // the ring slot is rewritten two chunks on
-            }
         };
         // this wave's chunks in the band: c = first, first + NW, ... < cb1
         int first = c_begin + wave;
@@ -811,7 +777,7 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
         // every band, and the register count of the kernel no longer set by its widest band (4 x 8 words: 32 registers for a band most
         // tensors do not have -- the mixed 6 / 5 / 4-bit instances ran at 96-128 registers, two workgroups per CU, half the rate of the
         // 3 / 2-bit ones).
-        constexpr int DEPTH = (BITS >= 6 || MT >= 8) ? 2 : (BITS == 5 ? 3 : 4);  // eight / sixteen rows: the accumulators take the registers of two sets
+        constexpr int DEPTH = (BITS >= 6 || (XW && MT > 1)) ? 2 : (BITS == 5 ? 3 : 4);  // the per-wave x form: two (its x rows and, from eight rows, the accumulators take the registers of the other two sets; measured with 3 / 4: slower)
         Chunk cs[DEPTH];
         if constexpr (DIRECT && !XP) {
             exl2_static_for<0, DEPTH>([&](auto i) { load_perm(at(decltype(i)::value), cs[decltype(i)::value]); });
@@ -1260,20 +1226,19 @@ __global__ __launch_bounds__(512, ((DMODE == 2 && MT == 1) ? 6 : 4)) void exl2_l
 // sums that do not depend on the column: cs[c] = {sum offset_k x_k, sum x_k} -- offset_k is the power of two the field of k carries
 // in the pairs the decode kernel feeds the matrix pipe (exl2_tpairs16), a property of the chunk's bit width and of k's place in it.
 // position k of every row of x: xp[m][k] = x[m][q_perm[k]]; the 32 lanes of a chunk reduce its two sums (cs[m][k / 32])
-// M >= 5 (kernels instantiated for 8 / 16 rows): chunk-major, xp[chunk][row][32] and cs[chunk][row], rows beyond M repeating row M - 1
+// M >= 2 (the per-wave form, instantiated for 2 / 4 / 8 / 16 rows): chunk-major, xp[chunk][row][32] and cs[chunk][row], rows beyond M repeating row M - 1
 __device__ __forceinline__ void exl2_permute_rows(const uint16_t* __restrict__ x, const uint16_t* __restrict__ perm, uint16_t* __restrict__ xp,
-                                                  float2_t* __restrict__ cs, const Exl2Rows& rows, int M, int K, int k) {
-    const int MT = exl2_xp_rows_d(M) >= EXL2_XW_MIN_MT ? exl2_xp_rows_d(M) : 0;
+                                                  float2_t* __restrict__ cs, const Exl2Rows& rows, int M, int K, int k, int m) {
+    const int MT = exl2_xp_rows_d(M);
     const int src = perm ? (int)perm[k] : k;
     int bits = 2;
 #pragma unroll
     for (int b = 5; b >= 0; b--)
         if (k < rows.r[b]) bits = exl2_bits_of_band(b);  // the first band whose end lies beyond k
     const float ofs = exl2_offset_of(bits, (k & 31) >> 1);
-    for (int m = 0; m < (MT ? MT : M); m++) {
+    {   // one (k, row) per thread: the grid's z dimension walks the rows the decode kernel is instantiated for (MT, or M below the threshold)
         const uint16_t xb = x[(long)(m < M ? m : M - 1) * K + src];
-        if (MT) xp[((long)(k >> 5) * MT + m) * 32 + (k & 31)] = xb;
-        else xp[(long)m * K + k] = xb;
+        xp[((long)(k >> 5) * MT + m) * 32 + (k & 31)] = xb;
         const float xv = f16_bits_to_f32(xb);
         float so = ofs * xv, sx = xv;
 #pragma unroll
@@ -1282,8 +1247,7 @@ __device__ __forceinline__ void exl2_permute_rows(const uint16_t* __restrict__ x
             sx += __shfl_xor(sx, d, 32);
         }
         if ((k & 31) == 0) {
-            if (MT) cs[(long)(k >> 5) * MT + m] = float2_t{so, sx};
-            else cs[(long)m * (K >> 5) + (k >> 5)] = float2_t{so, sx};
+            cs[(long)(k >> 5) * MT + m] = float2_t{so, sx};
         }
     }
 }
@@ -1291,7 +1255,7 @@ __global__ __launch_bounds__(256) void exl2_list_permute_kernel(const Exl2Call* 
     const Exl2Call& e = ent[blockIdx.y];
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= e.K) return;  // K % 32 == 0: whole 32-lane groups leave together
-    exl2_permute_rows(e.x, e.perm, const_cast<uint16_t*>(e.xp), const_cast<float2_t*>(e.cs), e.rows, e.M, e.K, k);
+    exl2_permute_rows(e.x, e.perm, const_cast<uint16_t*>(e.xp), const_cast<float2_t*>(e.cs), e.rows, e.M, e.K, k, (int)blockIdx.z);
 }
 // ---- a GROUP of up to 8 exl2 layers that consume the same one-row x (q / k / v, gate / up), everything in the kernel arguments ----------
 // bie_mbwq_exl2_forward_grouped: no plan object and no device table -- the call descriptors travel in the kernel-argument segment and
@@ -1333,7 +1297,7 @@ __global__ __launch_bounds__(256) void exl2_group_permute_kernel(const Exl2Group
     Exl2Rows rows;
 #pragma unroll
     for (int i = 0; i < 6; i++) rows.r[i] = e->rows.r[i];
-    exl2_permute_rows(e->x, e->perm, const_cast<uint16_t*>(e->xp), const_cast<float2_t*>(e->cs), rows, e->M, K, k);
+    exl2_permute_rows(e->x, e->perm, const_cast<uint16_t*>(e->xp), const_cast<float2_t*>(e->cs), rows, e->M, K, k, (int)blockIdx.z);
 }
 
 // decode (M <= 2): column blocks x K slabs ~ 512 workgroups of 8 waves (two per CU -> one round), slabs in whole multiples of
@@ -1609,9 +1573,9 @@ static bool exl2_all_regular(int n, const bie_exl2_list_entry* e) {
     return true;
 }
 static void exl2_list_plan(int n, const bie_exl2_list_entry* e, std::vector<int>& cps, std::vector<int>& S, long* blocks, size_t* gran_bytes,
-                           size_t* lds, int Mrows, int target_wgs = 0) {
+                           size_t* lds, int Mrows, bool xp, int target_wgs = 0) {
     const int M = exl2_rows_mt(Mrows);  // everything below is sized for the instantiated row count
-    const int CPS_MAX = M >= EXL2_XW_MIN_MT ? (1 << 20) : 768 / M;  // eight / sixteen rows: x travels per wave and chunk, no slab of it in LDS
+    const int CPS_MAX = xp ? (1 << 20) : 768 / M;  // the pre-permuted form: x travels per wave and chunk in registers, no slab of it in LDS
     long colblocks_all = 0;
     for (int i = 0; i < n; i++) colblocks_all += cdiv(e[i].N, 64);
     cps.resize(n); S.resize(n);
@@ -1631,29 +1595,30 @@ static void exl2_list_plan(int n, const bie_exl2_list_entry* e, std::vector<int>
         *blocks += (long)cb * S[i];
         if (S[i] > 1) *gran_bytes += (size_t)(S[i] - 1) * M * cb * 64 * 8;  // M = the instantiated row count
         size_t l = M > 1 ? (size_t)c * (32 * M + 2) * sizeof(uint16_t) : (size_t)8 * 4 * M * 32 * sizeof(uint16_t) + (size_t)c * 34 * sizeof(uint16_t);
-        if (M < EXL2_XW_MIN_MT && l < (size_t)c * 72 * M) l = (size_t)c * 72 * M;  // DMODE 2: per row the slab of xp (64 bytes per chunk) + its {offset sum, x sum} pairs
-        if (M >= EXL2_XW_MIN_MT) l = (size_t)8 * 2 * M * 72;                        // eight / sixteen rows: per (wave, set) ring slot of M x (64 + 8) bytes
+        if (xp) l = 0;  // nothing but the block reduction below
         const size_t red = (size_t)8 * M * 64 * sizeof(float);
         if (l < red) l = red;
         if (l > *lds) *lds = l;
     }
 }
 
-// M <= 2 always (staged form); 3 and 4 rows ride on the same matrix instruction in the pre-permuted form (regular groups)
+// does a list run the pre-permuted form (DMODE 2)?  Regular group structures in every entry.
+static bool exl2_list_xp(int n, const bie_exl2_list_entry* e) { return exl2_all_regular(n, e) && exl2_direct_on() && exl2_xp_on(); }
+// M <= 2 always (staged form); up to sixteen rows in the pre-permuted form (regular groups)
 static bool exl2_list_ok(int n, const bie_exl2_list_entry* e, int M) {
     if (n <= 0 || !e || M < 1 || M > EXL2_XP_MAX_M) return false;
     for (int i = 0; i < n; i++) {
         if (e[i].K <= 0 || e[i].N <= 0 || e[i].K % 32 || !e[i].rows7) return false;
         if (cdiv(e[i].N, 64) >= (1 << 20)) return false;
     }
-    return M <= 2 || (exl2_all_regular(n, e) && exl2_direct_on() && exl2_xp_on());
+    return M <= 2 || exl2_list_xp(n, e);
 }
 
 size_t exl2_list_device_bytes(int n, const bie_exl2_list_entry* e, int M) {
     if (!exl2_list_ok(n, e, M)) return 0;
     std::vector<int> cps, S;
     long blocks; size_t gran, lds;
-    exl2_list_plan(n, e, cps, S, &blocks, &gran, &lds, M);
+    exl2_list_plan(n, e, cps, S, &blocks, &gran, &lds, M, exl2_list_xp(n, e));
     long tiles = 0;
     for (int i = 0; i < n; i++) tiles += cdiv(e[i].N, 64);
     size_t xp = 0;
@@ -1678,7 +1643,7 @@ int exl2_list_create(Exl2List** out, int n, const bie_exl2_list_entry* e, int M,
     BIE_REQUIRE((reinterpret_cast<uintptr_t>(device_mem) & 255) == 0, BIE_ERR_INVALID_ARG, "bie_mbwq_exl2_list_create: the device buffer must be 256-byte aligned");
     std::vector<int> cps, S;
     long blocks; size_t gran, lds;
-    exl2_list_plan(n, e, cps, S, &blocks, &gran, &lds, M);
+    exl2_list_plan(n, e, cps, S, &blocks, &gran, &lds, M, exl2_list_xp(n, e));
     long tiles = 0;
     for (int i = 0; i < n; i++) tiles += cdiv(e[i].N, 64);
     const size_t o_blk = align256((size_t)n * sizeof(Exl2Call)), o_gen = o_blk + align256((size_t)blocks * 8), o_gran = o_gen + align256((size_t)tiles * 4);
@@ -1728,7 +1693,7 @@ int exl2_list_create(Exl2List** out, int n, const bie_exl2_list_entry* e, int M,
         if (e[i].rows7[2] != 0) pl->narrow = false;
         if (!(e[i].rows7[6] & BIE_EXL2_ROWS_REGULAR)) pl->direct = false;
     }
-    pl->xp = exl2_all_regular(n, e) && exl2_direct_on() && exl2_xp_on();
+    pl->xp = exl2_list_xp(n, e);
     pl->d_ent = reinterpret_cast<Exl2Call*>(base);
     pl->d_blk = reinterpret_cast<uint2_t*>(base + o_blk);
     *out = pl;
@@ -1749,7 +1714,7 @@ int exl2_list_forward(Exl2List* p, hipStream_t st) {
         else hipLaunchKernelGGL((exl2_list_kernel<MTV, false, DIR>), dim3(p->grid), dim3(512), p->lds, st, p->d_ent, p->d_blk, epoch, device_status_word(), skew, spin);      \
     } while (0)
     if (p->xp) {
-        hipLaunchKernelGGL(exl2_list_permute_kernel, dim3(cdiv(p->max_k, 256), p->n), dim3(256), 0, st, p->d_ent);
+        hipLaunchKernelGGL(exl2_list_permute_kernel, dim3(cdiv(p->max_k, 256), p->n, exl2_xp_rows(p->M)), dim3(256), 0, st, p->d_ent);
         rc = check_launch("exl2_list_permute_kernel");
         if (rc) return rc;
     }
@@ -1790,7 +1755,7 @@ size_t exl2_group_workspace_bytes(int n, const bie_exl2_list_entry* e, int M) {
     if (!exl2_group_ok(n, e, M)) return 0;
     std::vector<int> cps, S;
     long blocks; size_t gran, lds;
-    exl2_list_plan(n, e, cps, S, &blocks, &gran, &lds, M, EXL2_GROUP_WGS);
+    exl2_list_plan(n, e, cps, S, &blocks, &gran, &lds, M, true, EXL2_GROUP_WGS);
     size_t tot = align256(gran);
     for (int i = 0; i < n; i++) tot += align256((size_t)exl2_xp_rows(M) * e[i].K * 2) + align256((size_t)exl2_xp_rows(M) * (e[i].K / 32) * 8);
     return tot;
@@ -1801,19 +1766,17 @@ static size_t exl2_lone_group_bytes(int M, int K, int N) {  // upper bound witho
     one.K = K; one.N = N;
     std::vector<int> cps, S;
     long blocks; size_t gran, lds;
-    exl2_list_plan(1, &one, cps, S, &blocks, &gran, &lds, M, EXL2_GROUP_WGS);
+    exl2_list_plan(1, &one, cps, S, &blocks, &gran, &lds, M, true, EXL2_GROUP_WGS);
     return align256(gran) + align256((size_t)exl2_xp_rows(M) * K * 2) + align256((size_t)exl2_xp_rows(M) * (K / 32) * 8);
 }
 int exl2_group_forward(int n, const bie_exl2_list_entry* e, const void* x, int M, float* head, char* body, hipStream_t st) {
     std::vector<int> cps, S;
     long blocks; size_t gran, lds;
-    exl2_list_plan(n, e, cps, S, &blocks, &gran, &lds, M, EXL2_GROUP_WGS);
+    exl2_list_plan(n, e, cps, S, &blocks, &gran, &lds, M, true, EXL2_GROUP_WGS);
     const int MT = exl2_rows_mt(M);
-    // the permute kernel in front (two launches) against every workgroup permuting its own slab (one launch, BIE_EXL2_GROUP_PREPASS=0): measured
-    // 12.2 / 14.2 / 14.9 against 12.7 / 18.7 / 19.6 us for 3 x 4096x4096 / 2 x 4096x11008 / 2 x 11008x4096 -- the dependent gather in front of every
-    // workgroup's first word costs more than the launch it saves (profiles/r04_exl2_ablation.txt)
-    static const bool prepass_env = [] { const char* ev = getenv("BIE_EXL2_GROUP_PREPASS"); return !ev || atoi(ev) != 0; }();
-    const bool prepass = prepass_env || MT >= EXL2_XW_MIN_MT;  // eight / sixteen rows exist in the pre-permuted, chunk-major form only
+    // the permute kernel in front (two launches); every workgroup permuting its own slab instead (one launch) measured slower: 12.7 / 18.7 / 19.6 against
+    // 12.2 / 14.2 / 14.9 us for 3 x 4096x4096 / 2 x 4096x11008 / 2 x 11008x4096 -- the dependent gather in front of every workgroup's first word costs
+    // more than the launch it saves (profiles/r04_exl2_ablation.txt)
     Exl2GroupArgs a;
     std::memset(&a, 0, sizeof(a));
     a.n = n;
@@ -1832,12 +1795,10 @@ int exl2_group_forward(int n, const bie_exl2_list_entry* e, const void* x, int M
         c.gen = gen + t0;
         for (int k = 0; k < 6; k++) c.rows.r[k] = e[i].rows7[k];
         exl2_fill_groups(c, e[i].rows7);
-        if (prepass) {
-            c.xp = reinterpret_cast<const uint16_t*>(body + xo);
-            xo += align256((size_t)exl2_xp_rows(M) * e[i].K * 2);
-            c.cs = reinterpret_cast<const float2_t*>(body + xo);
-            xo += align256((size_t)exl2_xp_rows(M) * (e[i].K / 32) * 8);
-        }
+        c.xp = reinterpret_cast<const uint16_t*>(body + xo);
+        xo += align256((size_t)exl2_xp_rows(M) * e[i].K * 2);
+        c.cs = reinterpret_cast<const float2_t*>(body + xo);
+        xo += align256((size_t)exl2_xp_rows(M) * (e[i].K / 32) * 8);
         c.M = M; c.K = e[i].K; c.N = e[i].N; c.chunks_per_slab = cps[i]; c.S = S[i]; c.colblocks = cb;
         BIE_REQUIRE(S[i] < 4096, BIE_ERR_UNSUPPORTED, "bie_mbwq_exl2_forward_grouped: member %d needs %d K slabs (< 4096)", i, S[i]);
         a.first_block[i] = (int)(i == 0 ? 0 : a.first_block[i - 1] + (long)cdiv(e[i - 1].N, 64) * S[i - 1]);
@@ -1851,11 +1812,9 @@ int exl2_group_forward(int n, const bie_exl2_list_entry* e, const void* x, int M
     test_forge_get(&skew, &spin);
     const unsigned epoch = next_launch_epoch();
     int rc = BIE_OK;
-    if (prepass) {
-        hipLaunchKernelGGL(exl2_group_permute_kernel, dim3(cdiv(a.max_k, 256), n), dim3(256), 0, st, a);
-        rc = check_launch("exl2_group_permute_kernel");
-        if (rc) return rc;
-    }
+    hipLaunchKernelGGL(exl2_group_permute_kernel, dim3(cdiv(a.max_k, 256), n, exl2_xp_rows(M)), dim3(256), 0, st, a);
+    rc = check_launch("exl2_group_permute_kernel");
+    if (rc) return rc;
 #define LG(MTV)                                                                                                                                             \
     do {                                                                                                                                                    \
         if (narrow) hipLaunchKernelGGL((exl2_group_kernel<MTV, true>), dim3((unsigned)blocks), dim3(512), lds, st, a, epoch, device_status_word(), skew, spin); \
