@@ -520,13 +520,14 @@ def bench_exl2(dev):
                         "us_per_group": round(us, 2), "us_per_layer": round(us / nmem, 2),
                         "roofline": {"bound": "hbm", "achieved": round(nmem * byts / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": round(nmem * byts / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None}})
-        # mid-size batches: M <= 48 the decode stream feeding v_mfma_f32_16x16x32_f16 (x permute launch + exl2_mfma_kernel); beyond, HIP
-        # reconstruct + library GEMM (the reference's split for M > 32, mbwq_linear_cuda_kernel.cu:947-957)
-        for M in (8, 16, 32, 64):
+        # more rows in one lone call: up to 16 the permute kernel + the pre-permuted decode body (a group of one, two launches); up to 48 the decode stream
+        # feeding v_mfma_f32_16x16x32_f16 (x permute launch + exl2_mfma_kernel); beyond, HIP reconstruct + library GEMM (the reference's split for
+        # M > 32, mbwq_linear_cuda_kernel.cu:947-957)
+        for M in (4, 8, 16, 32, 64):
             x = torch.randn((M, K), device=dev).half()
             g = capture(lambda st: [q_linear_cuda.mbwq_exl2_forward(x, s_[0], s_[1], s_[2], perm, gmap, rows, False) for s_ in sets[:4]])
             us = time_graph(g, 5) / 4
-            out.append({"op": "exl2 w3/w2 g32, " + ("fused matrix-pipe kernel" if M <= q_linear_cuda.EXL2_GEMV_MAX_M else "reconstruct + library GEMM"),
+            out.append({"op": "exl2 w3/w2 g32, " + ("lone call: permute kernel + pre-permuted decode body" if M <= 16 else "fused matrix-pipe kernel" if M <= q_linear_cuda.EXL2_GEMV_MAX_M else "reconstruct + library GEMM"),
                         "M": M, "K": K, "N": N, "us_per_launch": round(us, 2), "TFLOP/s": round(2.0 * M * K * N / us / 1e6, 2),
                         "roofline": {"bound": "hbm", "achieved": round((byts + 2 * M * (K + N)) / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": round((byts + 2 * M * (K + N)) / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None}})

@@ -1341,9 +1341,12 @@ static int exl2_slabs(int K, int N) {
     return cps;
 }
 
-// A lone layer with a long K runs as a group of ONE (permute kernel + the pre-permuted decode body): 11008x4096 11.6 against 12.2 us, 14336x4096 12.2
-// against 13.6, 28672x8192 26.4 against 39.1; at K <= 8192 the lone direct launch is ahead (profiles/r04_exl2_ablation.txt)
+// When a lone layer runs as a group of ONE (permute kernel + the pre-permuted decode body, two launches), measured (profiles/r04_exl2_ablation.txt):
+//  one / two rows with a long K: 11008x4096 11.6 against 12.2 us, 14336x4096 12.2 against 13.6, 28672x8192 26.4 against 39.1; at K <= 8192 the direct launch is ahead at one row
+//  two rows from 32 Mi weights: 4096x11008 10.6 against 13.4 us (4096x4096: 8.3 against 7.6, stays direct)
+//  3 ... 16 rows always: 8.1-11.4 / 11.2-16.9 / 11.7-18.7 us against 11.3-12.9 / 20.1-21.6 / 17.5-19.4 of the fused matrix-pipe kernel (4096^2 / 4096x11008 / 11008x4096)
 constexpr int EXL2_LONE_AS_GROUP_MIN_K = 10240;
+constexpr long EXL2_LONE_AS_GROUP_M2_MIN_WEIGHTS = 32l << 20;
 constexpr int EXL2_XP_MAX_M = 16;  // rows of x of the pre-permuted decode form (four per matrix instruction, up to four instructions per four k)
 static size_t exl2_lone_group_bytes(int M, int K, int N);
 int exl2_group_forward(int n, const bie_exl2_list_entry* e, const void* x, int M, float* head, char* body, hipStream_t st);
@@ -1434,10 +1437,10 @@ int mbwq_exl2_forward_launch(const void* x, const int32_t* qw, const void* scale
     const bool slab_ok = !(cdiv(N, 64) > BIE_WS_COUNTERS && K / 32 > 768);  // K slabs need one generation word per column block
     const bool regular = (rows7[6] & BIE_EXL2_ROWS_REGULAR) && exl2_direct_on();
     static const int lone_min_k = [] { const char* ev = getenv("BIE_EXL2_LONE_AS_GROUP_MIN_K"); return ev ? atoi(ev) : EXL2_LONE_AS_GROUP_MIN_K; }();
-    static const int lone_rows_lo = [] { const char* ev = getenv("BIE_EXL2_LONE_ROWS_LO"); return ev ? atoi(ev) : 1 << 30; }();
-    static const int lone_rows_hi = [] { const char* ev = getenv("BIE_EXL2_LONE_ROWS_HI"); return ev ? atoi(ev) : 0; }();
+    static const int lone_rows_lo = [] { const char* ev = getenv("BIE_EXL2_LONE_ROWS_LO"); return ev ? atoi(ev) : 3; }();
+    static const int lone_rows_hi = [] { const char* ev = getenv("BIE_EXL2_LONE_ROWS_HI"); return ev ? atoi(ev) : EXL2_XP_MAX_M; }();
     const bool rows_as_group = M >= lone_rows_lo && M <= lone_rows_hi && M <= EXL2_XP_MAX_M;
-    if (((M <= 2 && K >= lone_min_k) || rows_as_group) && regular && K % 32 == 0 && cdiv(N, 64) <= BIE_WS_COUNTERS && exl2_xp_on()) {
+    if (((M <= 2 && K >= lone_min_k) || (M == 2 && (long)K * N >= EXL2_LONE_AS_GROUP_M2_MIN_WEIGHTS) || rows_as_group) && regular && K % 32 == 0 && cdiv(N, 64) <= BIE_WS_COUNTERS && exl2_xp_on()) {
         bie_exl2_list_entry one{};
         one.x = x; one.qweight = qw; one.scales = scales; one.zeros = zeros; one.q_perm = perm; one.q_group_map = gmap; one.rows7 = rows7; one.y = y;
         one.K = K; one.N = N;

@@ -230,8 +230,10 @@ size_t bie_mbwq_workspace_bytes(int M, int K, int N);
 
 /* y[M, N] fp16 = x[:, q_perm] . dequant.  Replace q_linear_cuda.mbwq_q4_forward
  * (mbwq_linear_cuda_kernel.cu:742-825) and q_linear_cuda.mbwq_exl2_forward (:926-1007).
- * bie_mbwq_exl2_forward: one pass over the packed weight for M <= 64 (M <= 2 the decode kernel; 3 <= M <= 64 the same stream on the
- * matrix pipe, after one x[:, q_perm] launch into the workspace; the reference's fused range is M <= 32, exl2/q_gemm_kernel.cuh:90-549);
+ * bie_mbwq_exl2_forward: one pass over the packed weight for M <= 64 (M <= 2 the decode kernel; 3 <= M <= 16 with a table carrying
+ * BIE_EXL2_ROWS_REGULAR the permute kernel + the pre-permuted decode body, a group of one; otherwise up to 64 rows the same stream on
+ * the 16x16x32 matrix instruction, after one x[:, q_perm] launch into the workspace; the reference's fused range is M <= 32,
+ * exl2/q_gemm_kernel.cuh:90-549);
  * larger M is served in passes of 8 rows -- callers reconstruct (bie_mbwq_exl2_dequant) and use a dense GEMM there, as the
  * reference does (:947-957).  q_perm may be NULL (no act-order). */
 int bie_mbwq_q4_forward(const void* x, const int32_t* qweight, const void* scales,
