@@ -140,10 +140,10 @@ class MBWQLinearCuda(MPQLinearBase):
     def forward_grouped(layers: typing.Sequence["MBWQLinearCuda"], x: torch.Tensor, _from_group: bool = False) -> typing.List[torch.Tensor]:
         """Mixed-bit layers that consume the SAME one-row activation (q/k/v, gate/up) in two launches instead of one
         gemm_half_q_half_kernel launch per layer (mbwq_linear_cuda_kernel.cu:926-1007): bie_mbwq_exl2_forward_grouped.  Groupable:
-        eval mode, up to sixteen rows of fp16 x (measured: 3 x 4096x4096 at 8 / 16 rows 19.5 / 27.7 us grouped against 35.2 / 38.5 us alone), every channel_scale all ones (x * 1 is x: the members do share their input), regular groups.
+        eval mode, up to 48 rows of fp16 x in slabs of sixteen (measured: 3 x 4096x4096 at 8 / 16 / 32 rows 14.0 / 20.7 / 41 us grouped against 35 / 38 / 71 us alone), every channel_scale all ones (x * 1 is x: the members do share their input), regular groups.
         Anything else runs the members one by one."""
         x2, lead = flatten_x(x)
-        ok = (2 <= len(layers) <= 8 and 1 <= x2.shape[0] <= 16 and x2.dtype == torch.half and not (torch.is_grad_enabled() and x.requires_grad)
+        ok = (2 <= len(layers) <= 8 and 1 <= x2.shape[0] <= q_linear_cuda.EXL2_GROUP_MAX_ROWS and x2.dtype == torch.half and not (torch.is_grad_enabled() and x.requires_grad)
               and all(l.use_mbw and not l.training and l.q_group_map is not None and l.in_channels == layers[0].in_channels
                       and l._channel_scale_is_one() for l in layers))
         outs = None
@@ -157,7 +157,7 @@ class MBWQLinearCuda(MPQLinearBase):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         from .mpq_layer import AUTO_GROUP
-        if AUTO_GROUP and getattr(self, "_bie_group", None) is not None and self.use_mbw and not self.training and 0 < x.numel() <= 16 * x.shape[-1]:
+        if AUTO_GROUP and getattr(self, "_bie_group", None) is not None and self.use_mbw and not self.training and 0 < x.numel() <= q_linear_cuda.EXL2_GROUP_MAX_ROWS * x.shape[-1]:
             out = self._bie_group.forward(self, x)  # decode: siblings that share x run as one grouped call (mpq_layer.SiblingGroup)
             if out is not None:
                 return out

@@ -1200,7 +1200,7 @@ def test_exl2_grouped_forward_against_the_oracle_and_the_single_launches():
             assert_close(o, sgl.float().cpu().half(), orc.F16, f"exl2 grouped member {i} vs its own launch")
         # two to sixteen rows of x: same two launches, every row against its own single-row result (same sums whatever the instance:
         # 1 / 2 / 4 rows with the slab of x in LDS, 8 / 16 rows with x per wave and chunk)
-        for M in (2, 3, 4, 6, 8, 13, 16):
+        for M in (2, 3, 4, 6, 8, 13, 16, 20, 33, 48):  # beyond 16: one two-launch call per slab of 16 rows
             xm = torch.randn((M, K), generator=gen).half()
             xm[0] = x[0]
             outs_m = MBWQLinearCuda.forward_grouped(layers, xm.to(DEV))
@@ -1301,7 +1301,7 @@ def test_exl2_grouped_call_under_graph_replay_and_the_limits_of_the_row_counts()
     with pytest.raises(RuntimeError, match="outside the one-launch decode range"):
         MBWQExl2ForwardList([ent(layers[0], 17)])
     MBWQExl2ForwardList([ent(layers[0], 16)])()
-    assert q_linear_cuda.mbwq_exl2_forward_grouped(torch.zeros((17, K), dtype=torch.half, device=DEV), members) is None
+    assert q_linear_cuda.mbwq_exl2_forward_grouped(torch.zeros((q_linear_cuda.EXL2_GROUP_MAX_ROWS + 1, K), dtype=torch.half, device=DEV), members) is None
     assert q_linear_cuda.mbwq_exl2_forward_grouped(torch.zeros((1, K), dtype=torch.half, device=DEV), members + [(odd.qweight.data, odd.scales, odd.zeros, odd.q_perm, odd.q_group_map, odd.rows)]) is None
     torch.cuda.synchronize()
 
@@ -1382,18 +1382,19 @@ def test_unmodified_exl2_module_tree_gets_grouped_calls_after_prepare_bie_layers
         for l, grp in zip(layers, saved):
             l._bie_group = grp
         assert_close(model(xs[1]), r, orc.F16, "a scaled member")
-        # a few rows (<= 16): still grouped -- another kernel than the members' own at this row count (no per-weight rounding): tolerance;
-        # more rows: the layers' own path, untouched
-        x5, x12, x20 = torch.cat(xs + xs[:1], 0), torch.cat(xs * 3, 0), torch.cat(xs * 5, 0)
+        # a few rows (<= 48, slabs of sixteen): still grouped -- another kernel than the members' own at this row count (no per-weight
+        # rounding): tolerance; more rows: the layers' own path, untouched
+        x5, x12, x20, x52 = torch.cat(xs + xs[:1], 0), torch.cat(xs * 3, 0), torch.cat(xs * 5, 0), torch.cat(xs * 13, 0)
         before = dict(mpq_layer.GROUP_STATS)
-        y5, y12, y20 = model(x5), model(x12), model(x20)
-        assert mpq_layer.GROUP_STATS["grouped_launches"] - before["grouped_launches"] == 8
+        y5, y12, y20, y52 = model(x5), model(x12), model(x20), model(x52)
+        assert mpq_layer.GROUP_STATS["grouped_launches"] - before["grouped_launches"] == 12
         for l in layers:
             l._bie_group = None
-        assert all(torch.isfinite(y.float()).all() for y in (y5, y12, y20))
+        assert all(torch.isfinite(y.float()).all() for y in (y5, y12, y20, y52))
         assert_close(y5, model(x5).float().cpu().half(), orc.F16, "five rows, grouped against alone")
         assert_close(y12, model(x12).float().cpu().half(), orc.F16, "twelve rows, grouped against alone")
-        assert torch.equal(y20, model(x20))
+        assert_close(y20, model(x20).float().cpu().half(), orc.F16, "twenty rows (two slabs), grouped against alone")
+        assert torch.equal(y52, model(x52))
 
 
 @pytest.mark.parametrize("shape", [(1024, 4096, 1024, 4096, 256), (256, 512, 384, 1024, 64), (192, 2048, 3584, 28672, 7168), (40, 512, 256, 768, 512), (4, 512, 256, 768, 0)])

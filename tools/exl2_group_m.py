@@ -23,7 +23,7 @@ for (K, N, nm) in ((4096, 4096, 3), (4096, 11008, 2)):
              (torch.rand((groups, N), device=dev) * 0.02 + 0.001).half(), (torch.randn((groups, N), device=dev) * 0.05).half()) for _ in range(nset)]
     rows = [q_linear_cuda.mbwq_trans_qweight(s_[0], q_groups, True, K, groups, 4)[1] for s_ in sets][0]
     grps = [[(s_[0], s_[1], s_[2], perm, gmap, rows) for s_ in sets[i:i + nm]] for i in range(0, nset, nm)]
-    for M in (1, 2, 4, 8, 16):
+    for M in (1, 2, 4, 8, 16, 32):
         x = torch.randn((M, K), device=dev).half()
         g = capture(lambda st: [q_linear_cuda.mbwq_exl2_forward(x, s_[0], s_[1], s_[2], perm, gmap, rows, False) for s_ in sets])
         us1 = min(time_graph(g, 10) for _ in range(3)) / len(grps)
