@@ -642,11 +642,21 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
             const uint16_t* xw = nullptr;
             int xstride = 0;
             const float2_t* csw = nullptr;
+            // GB (one row, gathered per chunk): lane l < 32 holds x[q_perm[32 c + l]]; two DPP moves inside each quad put the four k of the quad into the
+            // register pair of its first lane -- lane 4 b = row 0 of block b -- and the matrix instruction broadcasts block b's A operand for step b
+            // (cbsz = 4, abid = b): no LDS round trip (2-byte store, wave barrier, four 16-byte reads per chunk) between the gather and the matrix pipe
+            constexpr bool GB = !STAGED && !XP && MT == 1;
+            uint2_t agb = uint2_t{0u, 0u};
             if constexpr (XW) {
                 csw = ch.csv;
             } else if constexpr (STAGED) {
                 xw = x_s + (c - c_begin) * 32;
                 xstride = slab_k;
+            } else if constexpr (GB) {
+                const int xr = (int)ch.xraw[0];
+                const int nb = __builtin_amdgcn_mov_dpp(xr, 0xF5, 0xf, 0xf, true);       // quad_perm [1, 1, 3, 3]: the neighbour's value
+                const uint32_t pr = (uint32_t)xr | ((uint32_t)nb << 16);                  // lanes 0 / 2 of a quad: the pairs (k, k + 1) / (k + 2, k + 3)
+                agb = uint2_t{pr, (uint32_t)__builtin_amdgcn_mov_dpp((int)pr, 0xAA, 0xf, 0xf, true)};  // quad_perm [2, 2, 2, 2]
             } else {
                 uint16_t* xwr = xs + set * (MT * 32);
                 if (lane < 32) {
@@ -737,6 +747,15 @@ __device__ __forceinline__ void exl2_gemv2_body(const uint16_t* __restrict__ x, 
                         constexpr int i = decltype(ii)::value;
                         constexpr int j = 8 * half + 2 * i;
                         dq = exl2_mfma4_bcast<4 * half + i>(__builtin_bit_cast(half4_t, ch.xa[0]), __builtin_bit_cast(half4_t, uint2_t{T[j], T[j + 1]}), dq);
+                    });
+                } else if constexpr (GB) {
+                    exl2_static_for<0, 4>([&](auto ii) {
+                        constexpr int i = decltype(ii)::value;
+                        constexpr int j = 8 * half + 2 * i;
+                        const half4_t av = __builtin_bit_cast(half4_t, agb);
+                        dq = exl2_mfma4_bcast<4 * half + i>(av, __builtin_bit_cast(half4_t, uint2_t{T[j], T[j + 1]}), dq);
+                        dc = exl2_mfma4_bcast<4 * half + i>(av, __builtin_bit_cast(half4_t, uint2_t{ofs[j], ofs[j + 1]}), dc);
+                        dx = exl2_mfma4_bcast<4 * half + i>(av, ones4, dx);
                     });
                 } else {
                 const uint4_t xa = reinterpret_cast<const uint4_t*>(xw + xrow * xstride)[2 * half], xb = reinterpret_cast<const uint4_t*>(xw + xrow * xstride)[2 * half + 1];
