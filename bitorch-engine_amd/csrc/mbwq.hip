@@ -466,8 +466,9 @@ struct Exl2Groups {
 };
 // DMODE 2 (the list form): x arrives ALREADY permuted (xp = x[q_perm], one small launch in front for all entries of the list --
 // every column block of a layer needs the same 2 K bytes, gathering them per workgroup is 64-172 times redundant and a 32-lane
-// gather touches up to 32 cache lines).  The workgroup copies its slab of xp into LDS (contiguous 16-byte pieces, one round trip,
-// no dependent index load) and the chunks read it from there: no index loads and no gather in the loop.
+// gather touches up to 32 cache lines), chunk-major, together with the two column-independent sums of every chunk.  A wave requests its chunk's
+// block of xp with the chunk's words -- one 8-byte load per lane, the matrix instruction's A operand as it is (see XW in the body): no index
+// loads, no gather and no LDS in the loop.
 typedef float exl2_acc_t __attribute__((ext_vector_type(4)));
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ exl2_acc_t exl2_mfma4(half4_t a, half4_t b, exl2_acc_t c) { return __builtin_amdgcn_mfma_f32_4x4x4f16(a, b, c, 0, 0, 0); }
