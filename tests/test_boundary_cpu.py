@@ -72,6 +72,44 @@ def test_mbwq_rows_host_function_matches_oracle_and_reference_tables(golden_dir)
     assert L.bie_mbwq_rows(bad.ctypes.data, 1, 32, ctypes.cast(rows, ctypes.c_void_p)) == -2
 
 
+def test_exl2_grouped_and_lone_workspace_sizes_are_host_functions_of_the_tables():
+    """bie_mbwq_exl2_grouped_workspace_bytes / bie_mbwq_workspace_bytes (host only: they read K, N and the host band tables, never a tensor):
+    a group is sized for 1 ... 16 rows of x (its x block and chunk sums are written for the instantiated row count 1 / 2 / 4 / 8 / 16), refuses 17
+    rows, an irregular member and more than 8 members; a lone call's workspace covers the group-of-one path it may take for every row count."""
+    from bitorch_engine import _hip
+    L = _hip.lib()
+
+    def table(spec):
+        qg, row, K = [], 0, 0
+        for bits, k in spec:
+            qg += [bits, row]
+            row += k * bits // 32
+            K += k
+        qg = np.array(qg, np.int16)
+        t = (ctypes.c_int * 20)()
+        assert L.bie_mbwq_exl2_table(qg.ctypes.data, qg.size // 2, K, ctypes.cast(t, ctypes.c_void_p)) == 0
+        return t, K
+    reg, K = table([(4, 128)] * 8 + [(3, 32)] * 48 + [(2, 64)] * 24)
+    odd, K2 = table([(4, 96)] * 32 + [(2, 32)] * 32)
+    assert K == K2 == 4096 and (reg[6] & 0x200) and not (odd[6] & 0x200)
+    fake = 0x10000  # tensor pointers are not read by the size functions
+    ent = lambda t, N: _hip.Exl2ListEntry(fake, fake, fake, fake, fake, fake, ctypes.cast(t, ctypes.c_void_p), fake, K, N, 0, 0)
+    two = (_hip.Exl2ListEntry * 2)(ent(reg, 4096), ent(reg, 11008))
+    sizes = [L.bie_mbwq_exl2_grouped_workspace_bytes(2, two, M) for M in (1, 2, 3, 4, 5, 8, 9, 16)]
+    assert all(s > 16384 for s in sizes) and sizes == sorted(sizes)
+    assert sizes[2] == sizes[3] and sizes[4] == sizes[5] and sizes[6] == sizes[7]   # 3 -> 4, 5 -> 8, 9 -> 16 rows instantiated
+    xrows = lambda M: 2 * (M * K * 2 + M * (K // 32) * 8)                            # both members' x block + chunk sums
+    assert sizes[7] - sizes[5] >= xrows(16) - xrows(8)
+    assert L.bie_mbwq_exl2_grouped_workspace_bytes(2, two, 17) == 0 and L.bie_mbwq_exl2_grouped_workspace_bytes(2, two, 0) == 0
+    mixed = (_hip.Exl2ListEntry * 2)(ent(reg, 4096), ent(odd, 4096))
+    assert L.bie_mbwq_exl2_grouped_workspace_bytes(2, mixed, 1) == 0
+    nine = (_hip.Exl2ListEntry * 9)(*[ent(reg, 256)] * 9)
+    assert L.bie_mbwq_exl2_grouped_workspace_bytes(9, nine, 1) == 0 and L.bie_mbwq_exl2_grouped_workspace_bytes(8, nine, 1) > 0
+    one = (_hip.Exl2ListEntry * 1)(ent(reg, 4096))
+    for M in (1, 2, 3, 8, 16):
+        assert L.bie_mbwq_workspace_bytes(M, K, 4096) >= L.bie_mbwq_exl2_grouped_workspace_bytes(1, one, M) - 16384, M
+
+
 def test_exl2_table_host_function_marks_regular_group_structures_and_their_shifts(golden_dir):
     """bie_mbwq_exl2_table (host only; what bie_mbwq_exl2_shuffle returns beside re-arranging the tensor): the reference's 7 ints first, the
     SHUFFLED mark, REGULAR exactly when every band's groups hold the same power-of-two number of whole 32-k chunks (a shorter last group
