@@ -1021,7 +1021,10 @@ def main():
     # ---- configs[4] sharded: 8192 x 28672, M = 4096, N / world column shards + all-gather (separate and overlapped)
     if distributed and not args.only:
         from bitorch_engine.distributed import bench_column_sharded
-        c5 = bench_column_sharded(B, world, rank, dev, M=4096, K=8192, N=28672, reps=5)
+        try:  # reporting only: the headline line must come out whatever this leg does (it has run under gloo on CPU and on no RCCL node yet)
+            c5 = bench_column_sharded(B, world, rank, dev, M=4096, K=8192, N=28672, reps=5)
+        except Exception as e:
+            c5 = {"error": str(e)[:300]}
         if rank == 0:
             extras["c5"] = c5
             out["c5"] = {k: c5[k] for k in list(c5)[:12]} if isinstance(c5, dict) else c5
