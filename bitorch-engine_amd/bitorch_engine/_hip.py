@@ -50,6 +50,7 @@ SIGNATURES = {
     "bie_mbwq_rows": (_i, [_vp, _i, _i, _vp]),
     "bie_mbwq_exl2_shuffle": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "bie_mbwq_exl2_table": (_i, [_vp, _i, _i, _vp]),
+    "bie_mbwq_exl2_unshuffle": (_i, [_vp, _vp, _i, _i, _vp]),
     "bie_mbwq_q4_dequant": (_i, [_vp] * 5 + [_i] * 4 + [_vp]),
     "bie_mbwq_exl2_dequant": (_i, [_vp] * 7 + [_i] * 3 + [_vp]),
     "bie_mbwq_workspace_bytes": (_sz, [_i, _i, _i]),
@@ -209,9 +210,12 @@ def _grow(table, key, nbytes, device, zero):
     Under stream capture nothing is allocated: a buffer created inside a capture would come from the graph's private pool and
     its zero-fill would become a memset node that resets the generation words of the reduction protocol on every replay.
     A plain `with torch.cuda.graph(g):` captures on torch's own capture stream, which has no buffer of its own even after a
-    warm-up: the capture then BORROWS the largest sufficient buffer another stream of the same device warmed up (launches of
-    one graph are stream-ordered among themselves; do not run eager bitorch_engine calls on the lending stream while that
-    graph replays).  Only when no stream of the device has a large enough buffer does the call fail, naming the stream."""
+    warm-up: the capture then TAKES OVER the largest sufficient buffer another stream of the same device warmed up -- the buffer
+    moves to the capturing stream's key and the stream that warmed it up allocates a fresh one at its next eager call, so a
+    replaying graph and eager calls never share generation words or scratch (a workspace has ONE owner stream at any time;
+    `torch.cuda.graph` synchronises the device before capturing, so nothing enqueued earlier still uses the buffer).  Buffers a
+    capture already used are never handed to another stream's capture.  Only when no stream of the device has a free, large
+    enough buffer does the call fail, naming the stream."""
     buf = table.get(key)
     capturing = torch.cuda.is_current_stream_capturing()
     if buf is not None and buf.numel() >= nbytes:
@@ -219,14 +223,18 @@ def _grow(table, key, nbytes, device, zero):
             _CAPTURED.add((id(table), key))
         return buf
     if capturing:
-        lend = [(k, b) for k, b in table.items() if k[0] == key[0] and b.numel() >= nbytes]
-        if lend:
-            k, b = max(lend, key=lambda kb: kb[1].numel())
-            _CAPTURED.add((id(table), k))
+        free = [(k, b) for k, b in table.items() if k[0] == key[0] and k != key and b.numel() >= nbytes and (id(table), k) not in _CAPTURED]
+        if free:
+            k, b = max(free, key=lambda kb: kb[1].numel())
+            del table[k]  # its stream allocates a new one at its next eager call
+            if buf is not None and (id(table), key) in _CAPTURED:
+                _WS_RETIRED.append(buf)  # nodes captured earlier on this stream keep their (smaller) buffer
+            table[key] = b
+            _CAPTURED.add((id(table), key))
             return b
         raise RuntimeError(f"bitorch_engine: stream {key[1]:#x} of device {key[0]} is being captured and no stream of that device has a "
-                           f"scratch buffer of {nbytes} bytes yet; run the step once before capturing, or call "
-                           "bitorch_engine._hip.presize_workspace(nbytes, device, stream) first")
+                           f"free scratch buffer of {nbytes} bytes; run the step once (eagerly, on any stream) before capturing, or call "
+                           "bitorch_engine._hip.presize_workspace(nbytes, device, stream) with the capturing stream first")
     if buf is not None and (id(table), key) in _CAPTURED:
         _WS_RETIRED.append(buf)
         _CAPTURED.discard((id(table), key))  # the new buffer has not been seen by any capture

@@ -16,7 +16,9 @@ def forward(input: torch.Tensor, weight: torch.Tensor, scale: float, transpose: 
     m, k = input.shape
     if weight.dtype == torch.uint8:
         wp = weight.contiguous()
-    else:  # unpacked weight: packed once per tensor version (and with it the FP4 image memoised on the packed tensor)
+    elif weight.requires_grad:  # under training: `.data` writes (optimiser, clamp) do not advance the version counter -- pack every call
+        wp = w_pack(weight, transpose).contiguous()
+    else:  # frozen unpacked weight: packed once per tensor version (and with it the FP4 image memoised on the packed tensor)
         from .q_linear_cuda import _cached
         wp = _cached(weight, ("rows_from_values", bool(transpose)), lambda: w_pack(weight, transpose).contiguous())
     if fp4_ok(m, wp.shape[0], k):  # large M: sign-pack folded into the FP4 image pass, GEMM on the matrix pipe

@@ -226,7 +226,8 @@ def mbwq_trans_qweight(qweight, q_groups, use_mbw, height, groups, bits):
         _hip.need_gpu(t)
         if t.dtype != torch.int32 or not t.is_contiguous():
             raise RuntimeError("mbwq_trans_qweight: qweight must be a contiguous int32 tensor")
-        if getattr(qweight, "_bie_exl2_shuffled", None) == (t.data_ptr(), t._version):  # new contents (copy_, a new .data) may be prepared again
+        ver = qweight._version  # the caller's tensor / Parameter: `.data` carries a fresh counter that always reads 0
+        if getattr(qweight, "_bie_exl2_shuffled", None) == (t.data_ptr(), ver):  # new contents (copy_, a new .data) may be prepared again
             raise RuntimeError("mbwq_trans_qweight: this qweight has already been re-arranged (a second pass would scramble it)")
         rows = (ctypes.c_int * EXL2_ROWS_LEN)()
         qg = q_groups.detach().to("cpu", torch.int16).contiguous()
@@ -235,13 +236,25 @@ def mbwq_trans_qweight(qweight, q_groups, use_mbw, height, groups, bits):
                                                   ctypes.cast(rows, ctypes.c_void_p), _hip.stream())
         _hip.check(rc, "bie_mbwq_exl2_shuffle")
         try:
-            qweight._bie_exl2_shuffled = (t.data_ptr(), t._version)
+            qweight._bie_exl2_shuffled = (t.data_ptr(), qweight._version)
         except AttributeError:
             pass
         return qweight, list(rows)
     if bits not in (2, 4):
         raise RuntimeError(f"Error: weight bit width:{bits} has not been supported yet!")
     return qweight, []
+
+
+def mbwq_exl2_stream_copy(qweight, rows):
+    """A COPY of a re-arranged exl2 tensor in the checkpoint's own form (the LSB-first chunk streams the reference stores and, its
+    shuffle being a no-op, also saves after prepare_params): bie_mbwq_exl2_unshuffle on a clone.  What MBWQLinearCuda's state_dict
+    hook writes, so that a saved checkpoint is the reference's format and `load -> prepare_params` re-arranges exactly once."""
+    t = (qweight.data if hasattr(qweight, "data") else qweight).detach().clone()
+    _hip.need_gpu(t)
+    keep, rp = _rows_arg(rows)
+    rc = _hip.lib().bie_mbwq_exl2_unshuffle(_hip.ptr(t), rp, int(rows[5]), t.shape[1], _hip.stream())
+    _hip.check(rc, "bie_mbwq_exl2_unshuffle")
+    return t
 
 
 def mbwq_q42fp_weight(qweight, scales, zeros, group_size, bits, q_perm):
@@ -260,8 +273,9 @@ def mbwq_q42fp_weight(qweight, scales, zeros, group_size, bits, q_perm):
 
 def _rows_arg(rows):
     import ctypes
-    if len(rows) != EXL2_ROWS_LEN:
-        raise RuntimeError(f"exl2: the band table must be the {EXL2_ROWS_LEN}-int table mbwq_trans_qweight returned (got {len(rows)} ints)")
+    if rows is None or len(rows) != EXL2_ROWS_LEN:
+        raise RuntimeError(f"exl2: the band table must be the {EXL2_ROWS_LEN}-int table mbwq_trans_qweight returned for THIS tensor "
+                           f"(got {'none: the tensor was (re)loaded and not prepared' if rows is None else str(len(rows)) + ' ints'})")
     arr = (ctypes.c_int * EXL2_ROWS_LEN)(*[int(r) for r in rows])
     return arr, ctypes.cast(arr, ctypes.c_void_p)
 

@@ -50,7 +50,56 @@ class MBWQLinearCuda(MPQLinearBase):
         self.use_mbw, self.groups, self.rows_packed = use_mbw, groups, rows_packed
         self.rows = [0] * 7  # rows_8, rows_6, rows_5, rows_4, rows_3, rows_2 (cumulative k), kernel_p bit mask (prepare_params: + the group table)
         self._bie_group = None  # SiblingGroup, set by prepare_bie_layers (mpq_layer.find_sibling_groups)
+        self._exl2_mark = None  # (data_ptr, _version) of qweight as prepare_params left it (the private half-pair layout); see _exl2_current
         self.check_parameters()
+        self._register_state_dict_hook(MBWQLinearCuda._checkpoint_format_hook)
+
+    # ---- the private layout never leaves the process ---------------------------------------------------------------------------------
+    # prepare_params() re-arranges the mixed-bit qweight in place for the kernels (q_linear_cuda.mbwq_trans_qweight; the reference's own
+    # shuffle hook is a no-op, exl2/config.h:16-21, so ITS tensor is the checkpoint's stream before and after).  Three rules keep the
+    # on-disk contract and make a stale tensor fail loudly instead of multiplying garbage:
+    #   * state_dict() writes qweight BACK in the stream form (a copy; bie_mbwq_exl2_unshuffle): a saved checkpoint is the reference's;
+    #   * tensors that arrive through load_state_dict / a new .data are streams: the mark no longer matches, forward() refuses until
+    #     prepare_params() has run again (which re-arranges exactly once);
+    #   * .to() / .cuda() move the bytes as they are: _apply carries the mark over.
+    def _exl2_current(self) -> bool:
+        # the PARAMETER's version counter (`.data` hands out a fresh counter that always reads 0); writes through `.data` / raw pointers
+        # are invisible to it, as they are to autograd
+        return self._exl2_mark == (self.qweight.data_ptr(), self.qweight._version)
+
+    def _require_prepared(self):
+        if self.use_mbw and not self._exl2_current():
+            raise RuntimeError("MBWQLinearCuda: qweight changed since prepare_params() (load_state_dict, a new .data, or never prepared): its "
+                               "contents are the checkpoint's chunk streams, not the layout the kernels read; call prepare_params() again")
+
+    def _apply(self, fn, *args, **kwargs):
+        was = self.use_mbw and self._exl2_mark is not None and self._exl2_current()
+        out = super()._apply(fn, *args, **kwargs)
+        if was:
+            self._exl2_mark = (self.qweight.data_ptr(), self.qweight._version)
+            try:
+                self.qweight._bie_exl2_shuffled = self._exl2_mark
+            except AttributeError:
+                pass
+        return out
+
+    @staticmethod
+    def _checkpoint_format_hook(module, state_dict, prefix, local_metadata):
+        key = prefix + "qweight"
+        if module.use_mbw and key in state_dict and module._exl2_mark is not None and module._exl2_current():
+            state_dict[key] = q_linear_cuda.mbwq_exl2_stream_copy(module.qweight, module.rows)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+        if prefix + "qweight" in state_dict:
+            self._forget_layout()
+
+    def _forget_layout(self):
+        """qweight holds checkpoint streams again: no table of the private layout may stay attached to it (unpack_qweight and the static
+        *fp_weight helpers read qweight.rows): until prepare_params() runs, every exl2 call on this tensor fails on the table."""
+        self._exl2_mark = None
+        self.rows = [0] * 7
+        self.qweight.rows = None
 
     def check_parameters(self) -> None:
         assert self.dtype == torch.half, f"The value of dtype ({self.dtype}) must be torch.half."
@@ -72,6 +121,8 @@ class MBWQLinearCuda(MPQLinearBase):
         """Like the reference (:205-237): exl2 tensors whose shapes differ from the constructor's guess are
         adopted as they come."""
         own = self.state_dict()
+        if "qweight" in own:
+            own["qweight"] = self.qweight.data  # the tensor itself, not the stream copy the checkpoint hook hands out
         for name, value in state_dict.items():
             if name not in own:
                 if strict:
@@ -83,6 +134,8 @@ class MBWQLinearCuda(MPQLinearBase):
                 print(f"Warning: Shape mismatch for: {name}, expected: {own[name].shape}, got: {value.shape}. "
                       f"Use the value in state_dict directly.")
                 own[name].data = value.data
+            if name == "qweight":
+                self._forget_layout()  # the checkpoint's streams: prepare_params() has to run (again)
         if not strict:
             missing = set(own.keys()) - set(state_dict.keys())
             if missing:
@@ -103,6 +156,7 @@ class MBWQLinearCuda(MPQLinearBase):
             if self.use_mbw:
                 self.qweight.data, self.rows = q_linear_cuda.mbwq_trans_qweight(self.qweight, self.q_groups, True,
                                                                                 height, groups, self.w_bit)
+                self._exl2_mark = (self.qweight.data_ptr(), self.qweight._version)
                 if self.q_group_map is None:
                     self.q_group_map = make_group_map(self.q_groups, self.qweight.shape[0])
                 self.qweight.q_group_map, self.qweight.rows = self.q_group_map, self.rows
@@ -111,10 +165,9 @@ class MBWQLinearCuda(MPQLinearBase):
             for name in ("qzeros_zeros", "qzeros_scales", "qscales_zeros", "qscales_scales", "qstatistic"):
                 if hasattr(self, name):
                     delattr(self, name)
-            if self.disable_bias:
-                del self.bias
-            del self.wf
-            del self.g_idx
+            for name in (("bias",) if self.disable_bias else ()) + ("wf", "g_idx"):
+                if hasattr(self, name):  # a second prepare_params() (after a checkpoint was loaded into a prepared layer) finds them gone
+                    delattr(self, name)
         except Exception as e:
             raise RuntimeError(f"Error occurred during parameter preparation in MBWQLinearCuda layer: {e}")
 
@@ -137,12 +190,20 @@ class MBWQLinearCuda(MPQLinearBase):
         return self._cs_one
 
     @staticmethod
-    def forward_grouped(layers: typing.Sequence["MBWQLinearCuda"], x: torch.Tensor, _from_group: bool = False) -> typing.List[torch.Tensor]:
+    def forward_grouped(layers: typing.Sequence["MBWQLinearCuda"], x: torch.Tensor) -> typing.List[torch.Tensor]:
         """Mixed-bit layers that consume the SAME one-row activation (q/k/v, gate/up) in two launches instead of one
         gemm_half_q_half_kernel launch per layer (mbwq_linear_cuda_kernel.cu:926-1007): bie_mbwq_exl2_forward_grouped.  Groupable:
         eval mode, up to 48 rows of fp16 x in slabs of sixteen (measured: 3 x 4096x4096 at 8 / 16 / 32 rows 14.0 / 20.7 / 41 us grouped against 35 / 38 / 71 us alone), every channel_scale all ones (x * 1 is x: the members do share their input), regular groups.
         Anything else runs the members one by one."""
+        outs = MBWQLinearCuda._grouped_or_none(layers, x)
+        return outs if outs is not None else [l(x) for l in layers]
+
+    @staticmethod
+    def _grouped_or_none(layers, x):
+        """The grouped call, or None when this call is not one it takes (mpq_layer.SiblingGroup then lets every member run alone)."""
         x2, lead = flatten_x(x)
+        for l in layers:
+            l._require_prepared()
         ok = (2 <= len(layers) <= 8 and 1 <= x2.shape[0] <= q_linear_cuda.EXL2_GROUP_MAX_ROWS and x2.dtype == torch.half and not (torch.is_grad_enabled() and x.requires_grad)
               and all(l.use_mbw and not l.training and l.q_group_map is not None and l.in_channels == layers[0].in_channels
                       and l._channel_scale_is_one() for l in layers))
@@ -150,9 +211,7 @@ class MBWQLinearCuda(MPQLinearBase):
         if ok:
             outs = q_linear_cuda.mbwq_exl2_forward_grouped(x2, [(l.qweight.data, l.scales, l.zeros, l.q_perm, l.q_group_map, l.rows) for l in layers])
         if outs is None:
-            if _from_group:  # called by a SiblingGroup: the members' own forward would re-enter the group
-                return [l._forward_alone(x) for l in layers]
-            return [l(x) for l in layers]
+            return None
         return [unflatten_x(o if l.disable_bias else o + l.bias, lead) for l, o in zip(layers, outs)]
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -164,6 +223,7 @@ class MBWQLinearCuda(MPQLinearBase):
         return self._forward_alone(x)
 
     def _forward_alone(self, x: torch.Tensor) -> torch.Tensor:
+        self._require_prepared()
         if not (self.use_mbw and not self.training and self._channel_scale_is_one()):  # x * 1: one elementwise launch per call for nothing
             x = x.mul(self.channel_scale)
         extra = (self.q_group_map, self.rows) if self.use_mbw else ()

@@ -16,14 +16,18 @@ from bitorch_engine.utils.model_helper import flatten_x, unflatten_x
 q_linear_cuda = import_extension("q_linear_cuda")
 
 # counters of the automatic sibling grouping (tests and tools read them; reset with .clear())
-GROUP_STATS = {"grouped_launches": 0, "served_from_group": 0, "single_launches": 0, "groups_confirmed": 0, "groups_dissolved": 0}
+GROUP_STATS = {"grouped_launches": 0, "served_from_group": 0, "single_launches": 0, "groups_confirmed": 0, "groups_dissolved": 0,
+               "not_groupable": 0}
 AUTO_GROUP = os.environ.get("BIE_AUTO_GROUP", "1") != "0"
 GROUP_MAX_M = 16  # rows the grouped decode launch takes (bie_mpq_forward_grouped)
 
 
 def _x_key(x):
     """Identity of an activation tensor for the sibling protocol: same storage, same version, same view -- and the same STREAM: a parked
-    output is only handed to a sibling that is called on the stream the group launch was enqueued on (stream order is what makes it valid)."""
+    output is only handed to a sibling that is called on the stream the group launch was enqueued on (stream order is what makes it valid).
+    An address names a tensor only while that tensor is ALIVE (the caching allocator hands a freed block, at version 0, to the next
+    temporary of the same size): every place that stores a key stores the tensor beside it, so that no other tensor can come to carry
+    the key while it is comparable (SiblingGroup.trace / .parked)."""
     stream = torch.cuda.current_stream(x.device).cuda_stream if x.is_cuda else 0
     return (x.data_ptr(), x._version, tuple(x.shape), tuple(x.stride()), x.dtype, x.device, stream)
 
@@ -42,16 +46,22 @@ class SiblingGroup:
     launches the whole set on its x (M <= 16 rows, eval mode) and parks the other members' outputs under the identity of x; a member
     called next with that tensor takes its parked output without launching anything; a member called with anything else, or before its
     leader, runs alone and leaves its set.  Nothing is assumed from names, and parked outputs nobody picks up for three rounds dissolve
-    the group."""
+    the group.
+
+    The reference keeps no state between calls (mpq_layer.py:206-224), so this protocol must never be able to answer with another
+    tensor's result: every trace / parked entry holds a STRONG REFERENCE to the x it was keyed on until the round ends, which pins the
+    storage -- a caller doing `q_proj(h * a); k_proj(h * b)` gets two temporaries at two addresses, two keys, and no group.  (The cost:
+    one round's inputs and parked outputs stay allocated until the parent's next forward.)"""
 
     def __init__(self, members):
         self.members = list(members)
         self.first = None          # the member called first in a forward of the parent: a call of it starts a new round
         self.sets = None           # confirmed: id(leader) -> [leader, member, ...]; None while observing
         self.leader_of = {}        # id(member) -> its set's leader
-        self.trace = []            # (module, key) in call order, observation round only
+        self.trace = []            # (module, key, x) in call order, observation round only; x is held so its address cannot be recycled
         self.rounds_observed = 0
-        self.parked = {}           # id(module) -> (key, output)
+        self.parked = {}           # id(module) -> (key, x, output); output None = the leader could not group this call, run alone
+        self.ungroupable = 0       # consecutive leader calls the grouped launch refused
         self.unclaimed = 0
         self.dead = False
 
@@ -65,7 +75,7 @@ class SiblingGroup:
             if self.trace:
                 self.rounds_observed += 1
                 by_key = {}
-                for m, k in self.trace:
+                for m, k, _x in self.trace:
                     ms = by_key.setdefault(k, [])
                     if m not in ms:
                         ms.append(m)
@@ -89,10 +99,12 @@ class SiblingGroup:
             return None
         key = _x_key(x)
         hit = self.parked.pop(id(module), None)
-        if hit is not None and hit[0] == key:
+        if hit is not None and hit[0] == key:  # hit[1] is the leader's x, alive since the launch: the key cannot name another tensor
             self.unclaimed = 0
+            if hit[2] is None:
+                return None
             GROUP_STATS["served_from_group"] += 1
-            return hit[1]
+            return hit[2]
         if self.first is None:
             self.first = module
         if module is self.first:
@@ -100,17 +112,27 @@ class SiblingGroup:
             if self.dead:
                 return None
         if self.sets is None:
-            self.trace.append((module, key))
+            self.trace.append((module, key, x))
             if len(self.trace) > 8 * len(self.members):  # the member that opened the round is not called once per forward: rounds cannot be told apart
                 self.trace, self.dead = [], True
             return None
         leader = self.leader_of.get(id(module))
         if leader is module:
             members = self.sets[id(module)]
-            outs = type(module).forward_grouped(members, x, _from_group=True)
+            outs = type(module)._grouped_or_none(members, x)
+            if outs is None:  # not a call the grouped launch takes (dtype, rows, explicit g_idx ...): everybody runs alone, nobody is evicted
+                GROUP_STATS["not_groupable"] += 1
+                self.ungroupable += 1
+                if self.ungroupable >= 3:
+                    self._dissolve()
+                    return None
+                for m in members[1:]:
+                    self.parked[id(m)] = (key, x, None)
+                return None
+            self.ungroupable = 0
             GROUP_STATS["grouped_launches"] += 1
             for m, o in zip(members[1:], outs[1:]):
-                self.parked[id(m)] = (key, o)
+                self.parked[id(m)] = (key, x, o)
             return outs[0]
         if leader is not None:  # launched with its leader's x but asked for another tensor (or called before its leader): not a sibling after all
             members = self.sets[id(leader)]
@@ -239,12 +261,18 @@ class MPQLinearCuda(MPQLinearBase):
         return unflatten_x(out, lead)
 
     @staticmethod
-    def forward_grouped(layers: typing.Sequence["MPQLinearCuda"], x: torch.Tensor, _from_group: bool = False) -> typing.List[torch.Tensor]:
+    def forward_grouped(layers: typing.Sequence["MPQLinearCuda"], x: torch.Tensor) -> typing.List[torch.Tensor]:
         """Several layers that consume the SAME activation (q/k/v, gate/up of a transformer block) in ONE decode launch
         (bie_mpq_forward_grouped): the reference launches `quant_mm_kernel` once per layer (mpq_layer.py:65); at M <= 16 a
         launch of this size is mostly fixed cost, and three 4096x4096 projections in one grid take 10.1 us instead of 3 x 6.0.
         Falls back to the layers' own forward when the set is not groupable (training, different bit widths / group sizes /
         dtypes, explicit g_idx, more than 16 rows or 8 layers)."""
+        outs = MPQLinearCuda._grouped_or_none(layers, x)
+        return outs if outs is not None else [l(x) for l in layers]
+
+    @staticmethod
+    def _grouped_or_none(layers, x):
+        """The grouped launch, or None when this call is not one it takes."""
         first = layers[0]
         x2, lead = flatten_x(x)
         same = all(l.w_bit == first.w_bit and l.group_size == first.group_size and l.asym == first.asym and l.in_channels == first.in_channels
@@ -254,10 +282,7 @@ class MPQLinearCuda(MPQLinearBase):
               and not (torch.is_grad_enabled() and x.requires_grad)
               and all(q_linear_cuda.gidx_is_trivial(l.g_idx, l.group_size) for l in layers))
         if not ok:
-            if _from_group:  # called by a SiblingGroup: the members' own forward would re-enter the group
-                return [unflatten_x(q_linear_cuda.mpq_forward_impl(x2, l.qweight.data, l.scales, l.zeros, l.g_idx, l.w_bit, l.asym, l.group_size,
-                                                                   None if l.disable_bias else l.bias), lead) for l in layers]
-            return [l(x) for l in layers]
+            return None
         sets = [(l.qweight.data, l.scales, l.zeros, None if l.disable_bias else l.bias) for l in layers]
         outs = q_linear_cuda.mpq_forward_grouped_impl(x2, sets, first.w_bit, first.asym, first.group_size)
         return [unflatten_x(o, lead) for o in outs]

@@ -58,7 +58,7 @@ int mpq_grad_input_launch(const void* gy, const int32_t* qw, const void* scales,
 size_t mbwq_workspace_bytes(int M, int K, int N);
 int mbwq_q4_dequant_launch(const int32_t* qw, const void* scales, const void* zeros, const int16_t* perm, void* out, int K,
                            int N, int bits, int group_size, hipStream_t st);
-int mbwq_exl2_shuffle_launch(int32_t* qw, const int* rows6, int K, int N, hipStream_t st);
+int mbwq_exl2_shuffle_launch(int32_t* qw, const int* rows6, int K, int N, hipStream_t st, bool inverse);
 int mbwq_exl2_dequant_launch(const int32_t* qw, const void* scales, const void* zeros, const int16_t* perm,
                              const int16_t* gmap, const int* rows7, void* out, int K, int N, hipStream_t st);
 int mbwq_q4_forward_launch(const void* x, const int32_t* qw, const void* scales, const void* zeros, const int16_t* perm,
@@ -423,7 +423,7 @@ int bie_mbwq_exl2_shuffle(int32_t* qweight, const int16_t* q_groups_host, int gr
     BIE_REQUIRE(qweight && rows_host && N > 0, BIE_ERR_INVALID_ARG, "bie_mbwq_exl2_shuffle: bad argument");
     int rc = bie_mbwq_exl2_table(q_groups_host, groups, K, rows_host);
     if (rc) return rc;
-    return mbwq_exl2_shuffle_launch(qweight, rows_host, K, N, as_stream(stream));
+    return mbwq_exl2_shuffle_launch(qweight, rows_host, K, N, as_stream(stream), false);
 }
 
 static int check_rows(const char* fn, const int* rows7, int K) {
@@ -439,6 +439,13 @@ static int check_rows(const char* fn, const int* rows7, int K) {
     }
     BIE_REQUIRE(rows7[5] == K, BIE_ERR_INVALID_ARG, "%s: rows[5]=%d must equal K=%d", fn, rows7[5], K);
     return BIE_OK;
+}
+
+int bie_mbwq_exl2_unshuffle(int32_t* qweight, const int* rows_host, int K, int N, void* stream) {
+    BIE_REQUIRE(qweight && N > 0 && K > 0, BIE_ERR_INVALID_ARG, "bie_mbwq_exl2_unshuffle: bad argument");
+    int rc = check_rows("bie_mbwq_exl2_unshuffle", rows_host, K);
+    if (rc) return rc;
+    return mbwq_exl2_shuffle_launch(qweight, rows_host, K, N, as_stream(stream), true);
 }
 
 int bie_mbwq_exl2_dequant(const int32_t* qweight, const void* scales, const void* zeros, const int16_t* q_perm,

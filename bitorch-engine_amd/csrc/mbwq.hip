@@ -293,6 +293,34 @@ __device__ __forceinline__ void exl2_shuffle_chunk(uint32_t* __restrict__ qw, lo
 #pragma unroll
     for (int i = 0; i < BITS; i++) qw[(long)(prow + i) * N + n] = w[i];
 }
+// the way back (for writing a checkpoint in the reference's format from a prepared layer): half-pair layout -> LSB-first stream
+template <int BITS>
+__device__ __forceinline__ void exl2_pack32_stream(const uint32_t (&q)[32], uint32_t (&w)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = 0u;
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+        const int bitpos = j * BITS;
+        const int wi = bitpos >> 5, sh = bitpos & 31;
+        w[wi] |= q[j] << sh;
+        if (sh + BITS > 32) w[wi + 1] |= q[j] >> (32 - sh);
+    }
+}
+template <int BITS, bool INVERSE>
+__device__ __forceinline__ void exl2_reshuffle_chunk(uint32_t* __restrict__ qw, long N, int prow, int n) {
+    if constexpr (!INVERSE) {
+        exl2_shuffle_chunk<BITS>(qw, N, prow, n);
+    } else {
+        uint32_t w[8], q[32];
+#pragma unroll
+        for (int i = 0; i < 8; i++) w[i] = i < BITS ? qw[(long)(prow + i) * N + n] : 0u;
+        exl2_extract32<BITS>(w, q);
+        exl2_pack32_stream<BITS>(q, w);
+#pragma unroll
+        for (int i = 0; i < BITS; i++) qw[(long)(prow + i) * N + n] = w[i];
+    }
+}
+template <bool INVERSE>
 __global__ __launch_bounds__(256) void exl2_shuffle_kernel(uint32_t* __restrict__ qw, Exl2Rows rows, int K, int N) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     const int k0 = blockIdx.y * 32;
@@ -300,12 +328,12 @@ __global__ __launch_bounds__(256) void exl2_shuffle_kernel(uint32_t* __restrict_
     int bits, prow;
     exl2_locate(rows, k0, bits, prow);
     switch (bits) {
-        case 8: exl2_shuffle_chunk<8>(qw, N, prow, n); break;
-        case 6: exl2_shuffle_chunk<6>(qw, N, prow, n); break;
-        case 5: exl2_shuffle_chunk<5>(qw, N, prow, n); break;
-        case 4: exl2_shuffle_chunk<4>(qw, N, prow, n); break;
-        case 3: exl2_shuffle_chunk<3>(qw, N, prow, n); break;
-        default: exl2_shuffle_chunk<2>(qw, N, prow, n); break;
+        case 8: exl2_reshuffle_chunk<8, INVERSE>(qw, N, prow, n); break;
+        case 6: exl2_reshuffle_chunk<6, INVERSE>(qw, N, prow, n); break;
+        case 5: exl2_reshuffle_chunk<5, INVERSE>(qw, N, prow, n); break;
+        case 4: exl2_reshuffle_chunk<4, INVERSE>(qw, N, prow, n); break;
+        case 3: exl2_reshuffle_chunk<3, INVERSE>(qw, N, prow, n); break;
+        default: exl2_reshuffle_chunk<2, INVERSE>(qw, N, prow, n); break;
     }
 }
 
@@ -1403,11 +1431,14 @@ int mbwq_q4_dequant_launch(const int32_t* qw, const void* scales, const void* ze
 }
 
 // in place: the checkpoint's LSB-first streams -> the half-pair layout every exl2 kernel of this library reads
-int mbwq_exl2_shuffle_launch(int32_t* qw, const int* rows6, int K, int N, hipStream_t st) {
+int mbwq_exl2_shuffle_launch(int32_t* qw, const int* rows6, int K, int N, hipStream_t st, bool inverse) {
     Exl2Rows rows;
     for (int i = 0; i < 6; i++) rows.r[i] = rows6[i];
     dim3 grid(cdiv(N, 256), K / 32);
-    hipLaunchKernelGGL(exl2_shuffle_kernel, grid, dim3(256), 0, st, (uint32_t*)qw, rows, K, N);
+    if (inverse)
+        hipLaunchKernelGGL(exl2_shuffle_kernel<true>, grid, dim3(256), 0, st, (uint32_t*)qw, rows, K, N);
+    else
+        hipLaunchKernelGGL(exl2_shuffle_kernel<false>, grid, dim3(256), 0, st, (uint32_t*)qw, rows, K, N);
     return check_launch("exl2_shuffle_kernel");
 }
 

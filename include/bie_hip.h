@@ -210,6 +210,11 @@ int bie_mbwq_exl2_shuffle(int32_t* qweight, const int16_t* q_groups_host, int gr
 /* The table alone (pure host code, nothing launched): what bie_mbwq_exl2_shuffle writes to rows_host.  For a tensor that a previous run
  * re-arranged and saved: load it as it is and take its table from here. */
 int bie_mbwq_exl2_table(const int16_t* q_groups_host, int groups, int K, int* rows_host);
+/* The way back, IN PLACE: a tensor bie_mbwq_exl2_shuffle re-arranged -> the checkpoint's LSB-first chunk streams (bit-exact inverse).
+ * rows_host = the table that shuffle returned.  Used to WRITE checkpoints: a state_dict of a prepared layer holds the reference's
+ * format (its shuffle is a no-op, exl2/config.h:16-21, so what the reference saves after prepare_params is the stream), never
+ * this library's private layout. */
+int bie_mbwq_exl2_unshuffle(int32_t* qweight, const int* rows_host, int K, int N, void* stream);
 
 /* out[K, N] fp16: W[q_perm ? q_perm[k] : k][n] = fma(s, q, -z).  Replaces
  * q_linear_cuda.mbwq_q42fp_weight (mbwq_linear_cuda_kernel.cu:656-710, kernels :314-501). */

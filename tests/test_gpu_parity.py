@@ -483,6 +483,56 @@ def test_exl2_load_time_layout_is_the_documented_one_and_the_kernels_refuse_an_u
         q_linear_cuda.mbwq_exl2fp_weight(qs, sc, sc, torch.arange(K).short().to(DEV), gm, list(plain)[:7])
 
 
+def test_exl2_state_dict_is_the_reference_format_and_a_reloaded_tensor_is_prepared_exactly_once(tmp_path):
+    """prepare_params() re-arranges the mixed-bit qweight in place (the reference's shuffle hook is a no-op, so ITS
+    saved tensor is the checkpoint's stream).  (1) state_dict() of a prepared layer holds the ORIGINAL words bit for bit
+    (bie_mbwq_exl2_unshuffle is the exact inverse, every band width); (2) saved -> loaded into a fresh layer -> prepare_params() gives the
+    same outputs; (3) loading into the PREPARED layer makes forward() fail loudly until prepare_params() ran again -- never a second
+    shuffle, never unshuffled words under a shuffled table; (4) .cpu()/.to() keep a prepared layer usable."""
+    g = torch.Generator().manual_seed(77)
+    K, N = 512, 256
+    spec = [(8, 32), (6, 64), (5, 32), (4, 128), (3, 128), (2, 128)]
+    layer, qw, qg = _exl2_layer(K, N, spec, g)
+    layer.eval().to(DEV)
+    layer.prepare_params()
+    x = torch.randn((3, K), generator=g).half().to(DEV)
+    y0 = layer(x).clone()
+    assert not torch.equal(layer.qweight.data.cpu(), qw)            # the private layout really differs from the stream
+    sd = layer.state_dict()
+    assert torch.equal(sd["qweight"].cpu(), qw), "state_dict() does not hold the checkpoint's streams"
+    assert torch.equal(layer(x), y0)                                 # ... and the layer's own tensor was not touched
+    path = str(tmp_path / "exl2.pt")
+    torch.save(sd, path)
+    fresh, _, _ = _exl2_layer(K, N, spec, torch.Generator().manual_seed(1))
+    fresh.load_state_dict(torch.load(path))
+    fresh.eval().to(DEV)
+    with pytest.raises(RuntimeError, match="prepare_params"):
+        fresh(x)                                                     # loaded, not prepared: refuses
+    fresh.prepare_params()
+    assert torch.equal(fresh(x), y0)
+    # (3) into the prepared layer, through a parent module (the nn.Module machinery) and through the layer's own tolerant loader
+    parent = torch.nn.Sequential(layer)
+    parent.load_state_dict({"0." + k: v for k, v in sd.items()})
+    with pytest.raises(RuntimeError, match="prepare_params"):
+        layer(x)
+    with pytest.raises(RuntimeError):
+        layer.exl2fp_weight(layer.qweight.data, layer.scales, layer.zeros, layer.q_perm, layer.q_group_map, layer.qweight.rows)
+    layer.prepare_params()
+    assert torch.equal(layer(x), y0)
+    with pytest.raises(RuntimeError, match="already been re-arranged"):
+        layer.prepare_params()                                       # a second pass over the same contents is refused, as before
+    layer.load_state_dict(sd)
+    with pytest.raises(RuntimeError, match="prepare_params"):
+        layer(x)
+    layer.prepare_params()
+    assert torch.equal(layer(x), y0)
+    # (4) device moves carry the prepared state
+    layer.cpu()
+    layer.to(DEV)
+    assert torch.equal(layer(x), y0)
+    assert torch.equal(layer.state_dict()["qweight"].cpu(), qw)
+
+
 @pytest.mark.parametrize("name", ["g64_g128_ragged", "one_group_per_band", "mixed_sizes", "g16", "g96"])
 def test_exl2_group_structures_direct_and_staged_decode(name):
     """The decode kernel has two forms: DIRECT (regular groups -- every band's groups hold the same power-of-two number of whole
@@ -1397,6 +1447,76 @@ def test_unmodified_exl2_module_tree_gets_grouped_calls_after_prepare_bie_layers
         assert torch.equal(y52, model(x52))
 
 
+@pytest.mark.parametrize("kind", ["mpq_bf16", "mpq_f16", "exl2"])
+def test_sibling_projections_fed_freed_temporaries_are_never_grouped(kind):
+    """a parent that gives every projection its OWN temporary -- q_proj(h * a); k_proj(h * b);
+    v_proj(h.clone()) -- frees each one before the next is made, and the caching allocator places the next at the same address
+    (asserted below: without the group the addresses DO repeat on this allocator).  The sibling protocol must never answer k_proj
+    with W_k . (h * a): every output equals the layer's own lone launch bit for bit, on every round, and no group is confirmed.  The
+    reference keeps no state between calls (layers/qlinear/nbit/cuda/mpq_layer.py:206-224)."""
+    from bitorch_engine.layers.qlinear.nbit.cuda import MPQLinearCuda, MBWQLinearCuda
+    from bitorch_engine.layers.qlinear.nbit.cuda import mpq_layer
+    from bitorch_engine.utils.model_helper import prepare_bie_layers
+    H, gs = 512, 128
+    g = torch.Generator().manual_seed(31)
+    tdt = torch.bfloat16 if kind == "mpq_bf16" else torch.half
+
+    def lin():
+        if kind == "exl2":
+            return _exl2_layer(H, H, [(4, 64)] * 2 + [(3, 32)] * 8 + [(2, 64)] * 2, g)[0]
+        layer = MPQLinearCuda(H, H, w_bit=4, dtype=tdt, group_size=gs, dq_group_size=32, use_gba_quant=True, asym=False)
+        layer.qweight.data = torch.randint(-2 ** 31, 2 ** 31 - 1, layer.qweight.shape, generator=g, dtype=torch.int64).to(torch.int32)
+        return layer
+
+    class Attn(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.q_proj, self.k_proj, self.v_proj = lin(), lin(), lin()
+            self.addresses = []
+
+        def forward(self, h):
+            outs = []
+            for proj, f in ((self.q_proj, lambda t: t * 1.0), (self.k_proj, lambda t: t * 10.0), (self.v_proj, lambda t: t.clone())):
+                t = f(h)                       # a temporary: dies before the next one is made
+                self.addresses.append(t.data_ptr())
+                outs.append(proj(t))
+                del t
+            return outs
+
+    model = Attn()
+    if kind == "exl2":
+        model.to(DEV).eval()
+        prepare_bie_layers(model)
+    else:
+        prepare_bie_layers(model)
+        for m in model.children():
+            m.scales = (torch.rand(m.scales.shape, generator=g) * 0.004 + 0.002).to(tdt)
+            m.zeros = (m.scales.float() * 7.5).to(tdt)
+        model.to(DEV).eval()
+    layers = list(model.children())
+    assert all(l._bie_group is not None for l in layers) and layers[0]._bie_group is layers[1]._bie_group
+    hs = [torch.randn((1, H), generator=g).to(tdt).to(DEV) for _ in range(6)]
+    with torch.no_grad():
+        saved = [l._bie_group for l in layers]
+        for l in layers:
+            l._bie_group = None
+        refs = [[o.clone() for o in model(h)] for h in hs]    # every layer alone
+        recycled = len(set(model.addresses)) < len(model.addresses)
+        for l, grp in zip(layers, saved):
+            l._bie_group = grp
+        mpq_layer.GROUP_STATS.update({k: 0 for k in mpq_layer.GROUP_STATS})
+        for rnd, (h, ref) in enumerate(zip(hs, refs)):
+            outs = model(h)
+            for name, o, r in zip("qkv", outs, ref):
+                assert torch.equal(o, r), f"round {rnd}: {name}_proj returned something else than its own launch on its own input"
+        # k's input is 10 x q's: had k been served q's parked result the outputs above would differ by that factor
+        assert float(refs[0][1].float().abs().max()) > 0
+    assert recycled, "the allocator did not recycle the temporaries' block here: the test would not have caught the defect"
+    assert mpq_layer.GROUP_STATS["groups_confirmed"] == 0 and mpq_layer.GROUP_STATS["grouped_launches"] == 0 and mpq_layer.GROUP_STATS["served_from_group"] == 0
+    assert layers[0]._bie_group.dead     # four rounds without a shared input: the group stopped looking (and holds nothing any more)
+    assert not layers[0]._bie_group.trace and not layers[0]._bie_group.parked
+
+
 @pytest.mark.parametrize("shape", [(1024, 4096, 1024, 4096, 256), (256, 512, 384, 1024, 64), (192, 2048, 3584, 28672, 7168), (40, 512, 256, 768, 512), (4, 512, 256, 768, 0)])
 def test_forward_into_a_column_range_of_a_wider_output(shape):
     """bie_mpq_forward_pitched (a column shard's GEMM epilogue stores straight into out[:, lo:hi]): the pitched result is
@@ -2147,6 +2267,24 @@ def test_plain_graph_capture_after_a_warm_up_on_another_stream():
     g.replay()
     torch.cuda.synchronize()
     assert_close(y_static, oracle_forward(x2, qw, scales, zeros, None, 4, gs, 0, dt), dt, "graph replay on a borrowed workspace")
+    # the buffer MOVED to the capture -- the warming stream has none now and allocates its own at its next eager call, so a
+    # replaying graph and eager calls (unordered streams) never share generation words, granules or scratch
+    cur = _hip._key(torch.device(DEV))
+    assert cur not in _hip._WS, "the capture borrowed a live stream's workspace instead of taking it over"
+    graph_bufs = {b.data_ptr() for b in _hip._WS.values()}
+    side = torch.cuda.Stream()
+    x3 = torch.randn((1, K), generator=gen).to(TDT[dt])
+    x3_d = x3.to(DEV)
+    ref2, ref3 = oracle_forward(x2, qw, scales, zeros, None, 4, gs, 0, dt), oracle_forward(x3, qw, scales, zeros, None, 4, gs, 0, dt)
+    torch.cuda.synchronize()
+    for _ in range(20):  # graph replays on a side stream, eager calls on the current one, no ordering between them
+        with torch.cuda.stream(side):
+            g.replay()
+        y3 = q_linear_cuda.mpq_forward_impl(x3_d, qw_d, sc_d, ze_d, None, 4, 0, gs)
+    torch.cuda.synchronize()
+    assert _hip._WS[cur].data_ptr() not in graph_bufs
+    assert_close(y_static, ref2, dt, "graph replay beside eager calls")
+    assert_close(y3, ref3, dt, "eager calls beside a replaying graph")
 
 
 def test_reducer_timeout_fails_loudly():
