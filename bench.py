@@ -743,11 +743,12 @@ def cpu_baselines(check_layers=(), check_x=(), check_y=(), budget_s=24.0):
         res.append({"workload": "oracle_check_of_timed_launch", "verified": bool(ok), "rows": len(check_layers)})
     rng = np.random.default_rng(0)
     gen = torch.Generator().manual_seed(0)
-    # thread counts: the OpenMP split of these small problems over every core of a 256-thread box is slower than one thread (0.06 GB/s
-    # at 256 threads against 1.6 at 8: BENCH_r02); the sweep is {32, 8, 1}, plus all cores only on hosts with at most 64
+    # thread counts: ALL host cores and one thread, with 32 and 8 between them as the scaling evidence.  The M = 1
+    # legs run the list form (orc_mpq_forward_list_f32acc: one statically partitioned OpenMP region over the 64-column blocks of
+    # several layers -- the CPU twin of the GPU's list launch), so that every core of a 256-thread host has work
     big = min(cores, 32)
-    default_sets = sorted(({cores} if cores <= 64 else set()) | {big, min(cores, 8), 1}, reverse=True)
-    few_sets = sorted({big, 1}, reverse=True)
+    default_sets = sorted({cores, big, min(cores, 8), 1}, reverse=True)
+    few_sets = sorted({cores, big, 1}, reverse=True)
 
     def w4_layer(k, n):
         qw = rng.integers(-2 ** 31, 2 ** 31 - 1, (k * WBIT // 32, n), dtype=np.int64).astype(np.int32)
@@ -755,13 +756,15 @@ def cpu_baselines(check_layers=(), check_x=(), check_y=(), budget_s=24.0):
         ze = (sc.float() * torch.rand((k // GROUP, n), generator=gen) * 15).to(BF16)
         return qw, orc.torch_to_np(sc), orc.torch_to_np(ze)
 
-    # ---- M = 1 fused dequant + GEMV
-    for (k, n) in ((4096, 4096), (4096, 11008), (8192, 28672)):
-        qw, sc, ze = w4_layer(k, n)
-        x = orc.torch_to_np(torch.randn((1, k), generator=gen).to(BF16))
-        run(f"w4a16_gemv_M1_{k}x{n}", lambda: orc.mpq_forward(x, qw, sc, ze, None, WBIT, GROUP, 0, orc.BF16), alg_bytes(1, k, n), "GB/s",
-            f"layer GEMV (M=1, {k}x{n} w4 g128 bf16, orc_mpq_forward_f32acc)", per_run_s=0.5 if k * n < 1e8 else 1.0,
-            thread_sets=None if k * n < 1e8 else few_sets)
+    # ---- M = 1 fused dequant + GEMV over a list of layers (each with its own x), like the timed GPU launch
+    for (k, n, nl) in ((4096, 4096, 16), (4096, 11008, 6), (8192, 28672, 2)):
+        lst = []
+        for _ in range(nl):
+            qw, sc, ze = w4_layer(k, n)
+            lst.append((orc.torch_to_np(torch.randn((1, k), generator=gen).to(BF16)), qw, sc, ze))
+        run(f"w4a16_gemv_M1_{k}x{n}", lambda: orc.mpq_forward_list(lst, 1, WBIT, GROUP, 0, orc.BF16), alg_bytes(1, k, n) * nl, "GB/s",
+            f"list of {nl} layer GEMVs (M=1, {k}x{n} w4 g128 bf16, orc_mpq_forward_list_f32acc: the reference's two roundings per weight, fp32 accumulate)",
+            per_run_s=0.5, thread_sets=default_sets if k * n < 1e8 else few_sets)
     # ---- M = 4096 on the metric's layer: dequant only, GEMM only (sampled rows), both
     k = n = 4096
     qw, sc, ze = w4_layer(k, n)
@@ -1033,9 +1036,10 @@ def main():
         try:
             bl = cpu_baselines(layers[:2], plan_x(plan)[:2], y_all[:2])
             head = [b for b in bl if b["workload"] == "w4a16_gemv_M1_4096x4096"]
-            best = dict(max(head, key=lambda b: b["value"]))  # the headline shape at its best thread count
+            best = dict(max(head, key=lambda b: b["value"]))  # the headline shape at its best thread count ...
             best["threads_used"] = best["cores"]
             best["nproc"] = os.cpu_count()
+            best["by_threads"] = {str(b["cores"]): b["value"] for b in head}  # ... with all cores, 32, 8 and one thread beside it
             out["cpu_baseline"] = best
             out["verified_vs_oracle"] = next((b["verified"] for b in bl if b["workload"] == "oracle_check_of_timed_launch"), None)
             extras["cpu_baselines"] = bl            # every workload of SURVEY.md section 8d at {all, 32, 8, 1} threads (bounded samples)

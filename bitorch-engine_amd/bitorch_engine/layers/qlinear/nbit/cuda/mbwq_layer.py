@@ -122,7 +122,7 @@ class MBWQLinearCuda(MPQLinearBase):
         adopted as they come."""
         own = self.state_dict()
         if "qweight" in own:
-            own["qweight"] = self.qweight.data  # the tensor itself, not the stream copy the checkpoint hook hands out
+            own["qweight"] = self.qweight.detach()  # the tensor itself (detach() shares its version counter), not the stream copy the checkpoint hook hands out
         for name, value in state_dict.items():
             if name not in own:
                 if strict:
@@ -133,7 +133,12 @@ class MBWQLinearCuda(MPQLinearBase):
             elif name in ("scales", "zeros", "q_perm", "q_groups", "q_group_map", "qweight"):
                 print(f"Warning: Shape mismatch for: {name}, expected: {own[name].shape}, got: {value.shape}. "
                       f"Use the value in state_dict directly.")
-                own[name].data = value.data
+                target = self._parameters.get(name)
+                if target is None:
+                    target = self._buffers.get(name)
+                # state_dict() hands out detached aliases: re-pointing one of THOSE (what the reference's loop does, :228-231) leaves
+                # the module's own tensor untouched; adopt the value on the registered parameter / buffer itself
+                (own[name] if target is None else target).data = value.data
             if name == "qweight":
                 self._forget_layout()  # the checkpoint's streams: prepare_params() has to run (again)
         if not strict:

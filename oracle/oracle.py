@@ -132,6 +132,27 @@ def mpq_forward(x, qweight, scales, zeros, g_idx, w_bit, group_size, asym, dt):
     return y
 
 
+class _ListEntry(ctypes.Structure):
+    _fields_ = [("x", ctypes.c_void_p), ("qweight", ctypes.c_void_p), ("scales", ctypes.c_void_p), ("zeros", ctypes.c_void_p),
+                ("g_idx", ctypes.c_void_p), ("y", ctypes.c_void_p), ("K", ctypes.c_int), ("N", ctypes.c_int)]
+
+
+def mpq_forward_list(layers, M, w_bit, group_size, asym, dt):
+    """orc_mpq_forward_list_f32acc: several layers (x, qweight, scales, zeros) in ONE statically partitioned OpenMP region -- the CPU twin of
+    the GPU's list launch (work items = 64-column blocks of every layer).  Returns the list of outputs."""
+    arr = (_ListEntry * len(layers))()
+    keep, ys = [], []
+    for i, (x, qweight, scales, zeros) in enumerate(layers):
+        x, qweight, scales, zeros = _c(x), _c(qweight, np.int32), _c(scales), _c(zeros)
+        K, N = x.shape[1], qweight.shape[1]
+        y = _out((M, N), dt)
+        arr[i] = _ListEntry(x.ctypes.data, qweight.ctypes.data, scales.ctypes.data, zeros.ctypes.data, None, y.ctypes.data, K, N)
+        keep.append((x, qweight, scales, zeros))
+        ys.append(y)
+    lib().orc_mpq_forward_list_f32acc(len(layers), arr, M, w_bit, group_size, int(asym), dt)
+    return ys
+
+
 def mbwq_q4_dequant(qweight, scales, zeros, q_perm, bits, group_size):
     qweight = _c(qweight, np.int32)
     K = qweight.shape[0] * 32 // bits

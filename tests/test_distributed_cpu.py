@@ -113,6 +113,46 @@ def test_column_sharded_layer_gloo(tmp_path, world, asym):
         assert res["shape"] == (2, 3, 768)
 
 
+def _worker_c5(rank, world, port, out_dir):
+    """configs[4]'s exact partition: N = 28672 over 8 ranks = 8 x 3584 columns (28 blocks of 128 each), K cut down so that the CPU
+    oracle finishes in seconds (the partition is along N; K only scales the per-rank compute), M = 37 rows in tiles of 16 (16, 16, 5)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "bitorch-engine_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bitorch_engine.distributed import ColumnShardedMPQLinear, column_range
+    qweight, scales, zeros, g_idx, bias, _, w_bit, gs = _make(False, K=128, N=28672, gs=64)
+    layer = ColumnShardedMPQLinear(qweight, scales, zeros, g_idx, bias, w_bit, gs, False, rank, world, forward_impl=_oracle_impl)
+    ok = layer.ranges == [(r * 3584, (r + 1) * 3584) for r in range(8)] and tuple(layer.qweight.shape) == (16, 3584)
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn((37, 128), generator=g).half()
+    full = _oracle_impl(x, qweight, scales, zeros, g_idx, w_bit, False, gs, bias)
+    res = {"partition": ok}
+    res["allgather"] = torch.equal(layer(x), full)
+    res["overlapped"] = torch.equal(layer.forward_overlapped(x, m_tile=16), full)
+    res["direct"] = torch.equal(layer.forward_direct(x, m_tile=16), full)
+    for name, fn in (("overlapped_rank_major", layer.forward_overlapped), ("direct_rank_major", layer.forward_direct)):
+        rm = fn(x, m_tile=16, interleave=False)
+        res[name] = tuple(rm.shape) == (8, 37, 3584) and all(torch.equal(rm[r], full[:, r * 3584:(r + 1) * 3584]) for r in range(8))
+    # every rank took part in every collective: the gathered result holds all eight column blocks, and the world really is 8
+    res["world"] = dist.get_world_size() == 8
+    torch.save(res, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_c5_partition_world_size_8_all_three_schedules_gloo(tmp_path):
+    """N = 28672 -> 8 x 3584 across EIGHT processes, the plain all-gather, the M-tiled overlapped schedule and the
+    direct exchange, interleaved and rank-major, with a ragged last row tile -- every rank's assembled y equals the unsharded layer."""
+    port = _free_port()
+    mp.spawn(_worker_c5, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    for r in range(8):
+        res = torch.load(os.path.join(tmp_path, f"r{r}.pt"))
+        assert all(res.values()), f"rank {r}: {res}"
+
+
 def test_column_ranges_cover_and_align():
     sys.path.insert(0, os.path.join(ROOT, "bitorch-engine_amd"))
     from bitorch_engine.distributed import column_range

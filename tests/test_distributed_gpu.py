@@ -47,6 +47,13 @@ def _worker(rank, world, port, asym, out_dir):
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     from bitorch_engine.distributed import ColumnShardedMPQLinear
     from bitorch_engine.extensions import q_linear_cuda
+    # the first multi-GPU lease must PROVE the exchange ran over RCCL with every rank in it
+    ones = torch.ones(1, device=dev)
+    dist.all_reduce(ones)
+    ids = torch.empty(world, dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(ids, torch.tensor([rank], dtype=torch.int32, device=dev))
+    saw_world = (dist.get_backend() == "nccl" and dist.get_world_size() == world and int(ones.item()) == world
+                 and ids.cpu().tolist() == list(range(world)))
     qweight, scales, zeros, g_idx, bias, w_bit, gs, g = _make(asym)
     d = lambda t: t.to(dev)
     layer = ColumnShardedMPQLinear(d(qweight), d(scales), d(zeros), d(g_idx), d(bias), w_bit, gs, asym, rank, world)
@@ -62,7 +69,7 @@ def _worker(rank, world, port, asym, out_dir):
             if not good:
                 print(f"rank {rank}: {name} M={M} differs", flush=True)
             ok = ok and good
-    torch.save({"ok": ok}, os.path.join(out_dir, f"r{rank}.pt"))
+    torch.save({"ok": ok, "saw_world": saw_world, "world": world}, os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -76,4 +83,6 @@ def test_column_sharded_layer_rccl(tmp_path, asym):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, asym, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
-        assert torch.load(os.path.join(tmp_path, f"r{r}.pt"))["ok"], f"rank {r}: sharded output differs from the unsharded HIP forward"
+        res = torch.load(os.path.join(tmp_path, f"r{r}.pt"))
+        assert res["saw_world"] and res["world"] == world, f"rank {r}: the RCCL group did not hold all {world} ranks"
+        assert res["ok"], f"rank {r}: sharded output differs from the unsharded HIP forward"
