@@ -24,6 +24,7 @@ SIGNATURES = {
     "bie_version": (_i, []),
     "bie_last_error": (ctypes.c_char_p, []),
     "bie_mpq_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "bie_mpq_workspace_bytes_gidx": (_sz, [_i, _i, _i, _i]),
     "bie_mpq_forward": (_i, [_vp] * 8 + [_sz] + [_i] * 7 + [_vp]),
     "bie_mpq_forward_pitched": (_i, [_vp] * 6 + [_i, _vp, _sz] + [_i] * 7 + [_vp]),
     "bie_workspace_init": (_i, [_vp, _sz, _vp]),

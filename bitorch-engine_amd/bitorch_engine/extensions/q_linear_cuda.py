@@ -97,15 +97,11 @@ def mpq_forward_impl(x, qweight, scales, zeros, g_idx, w_bit, asym, group_size, 
         so = act_order_sorted(qweight, g_idx, w_bit, group_size)
         if so is not None:
             x, qweight, trivial_gidx = gather_cols(x, so[0]), so[1], True
+    # g_idx that is NOT a permutation of k // group_size (unequal groups): decode rows run the generic kernel, prefill (M > 32) the
+    # per-k dequantise into the MFMA fragment image + the dense kernel (bie_mpq_forward picks it when the workspace has room for the
+    # image: bie_mpq_workspace_bytes_gidx) -- the split the reference makes for every M > 32 (layers/qlinear/nbit/cuda/mpq_layer.py:59-62),
+    # without a vendor GEMM
     gptr = None if trivial_gidx else g_idx.to(torch.int32).contiguous()
-    if gptr is not None and M > 32:
-        # g_idx that is NOT a permutation of k // group_size (unequal groups): the fused kernels need whole groups per packed
-        # row; for prefill the dense weight is materialised once by the HIP dequant kernel and the plain GEMM goes to the vendor
-        # library -- the split the reference makes for every M > 32 (layers/qlinear/nbit/cuda/mpq_layer.py:59-62)
-        W = mpq_dequant(qweight, scales, zeros, gptr, w_bit, asym, group_size)
-        y = torch.matmul(x, W.to(x.dtype))
-        y = y if bias is None else y + bias
-        return y if out is None else out.copy_(y)
     pitched = out is not None and out.dim() == 2 and not out.is_contiguous() and out.stride(1) == 1 and out.stride(0) >= N
     if out is not None and (out.shape != (M, N) or out.dtype != x.dtype or out.device != x.device or not (out.is_contiguous() or pitched)):
         raise RuntimeError("mpq_forward_impl: out must be an [M, N] tensor of x's dtype on x's device, contiguous or a column range of a wider "
@@ -114,7 +110,7 @@ def mpq_forward_impl(x, qweight, scales, zeros, g_idx, w_bit, asym, group_size, 
     if M == 0:
         return y
     L = _hip.lib()
-    need = L.bie_mpq_workspace_bytes(M, K, N, w_bit)
+    need = (L.bie_mpq_workspace_bytes if gptr is None else L.bie_mpq_workspace_bytes_gidx)(M, K, N, w_bit)
     ws = _hip.workspace(need, x.device)
     if pitched:
         # the GEMM epilogue stores straight into the column range (bie_mpq_forward_pitched); shapes it does not take: tight buffer + one copy
@@ -315,9 +311,9 @@ def mbwq_q4_forward(x, qweight, scales, zeros, group_size, q_perm, bits):
     return y
 
 
-# rows of x served by the fused exl2 kernels (one pass over the packed weight): M <= 2 the decode kernel, 3 <= M <= 48 the same
+# rows of x served by the streaming exl2 kernels (one pass over the packed weight): M <= 2 the decode kernel, 3 <= M <= 48 the same
 # stream feeding v_mfma_f32_16x16x32_f16 (the reference keeps these in its fused kernel, exl2/q_gemm_kernel.cuh:90-549); beyond:
-# reconstruct + library GEMM.  Measured at 4096x11008, 3/2-bit g32, random q_perm (profiles/r03_x_exl2_mfma.txt): M = 3...16
+# the library's own prefill form (csrc/mbwq.hip: exl2_dequant_frag_kernel + mpq_dense_gemm_kernel; the switch is BIE_EXL2_DENSE_MIN_M there).  Measured at 4096x11008, 3/2-bit g32, random q_perm (profiles/r03_x_exl2_mfma.txt): M = 3...16
 # 22.8-23.8 us, 32 39.3, 33 43.4, 64 59.2 against 48.1-51.4 us for reconstruct + library GEMM.  BIE_EXL2_MAX_M pins the switch for
 # tools/ (8 = the round-2 split; the C-ABI itself takes M <= 64).
 EXL2_GEMV_MAX_M = int(os.environ.get("BIE_EXL2_MAX_M", "48"))
@@ -334,11 +330,10 @@ def mbwq_exl2_forward(x, qweight, scales, zeros, q_perm, q_group_map, rows, use_
     y = torch.empty((M, N), dtype=torch.float16, device=x.device)
     if M == 0:
         return y
-    if use_cublas or M > EXL2_GEMV_MAX_M:
-        # prefill: reconstruct the fp16 weight once with the HIP kernel and hand the plain dense GEMM to the vendor library,
-        # the same split the reference makes (mbwq_linear_cuda_kernel.cu:968-1002: reconstruct + at::matmul); the streaming
-        # kernel below re-reads the packed weight once per 8 rows of x and is the decode path
-        return torch.matmul(x, mbwq_exl2fp_weight(qweight, scales, zeros, q_perm, q_group_map, rows))
+    # One entry point for every M: M <= 2 the decode kernels, 3 <= M <= 48 the same stream on the matrix pipe, beyond that the prefill
+    # form -- dequantise once into the MFMA fragment image, x[:, q_perm], dense MFMA GEMM (bie_mbwq_exl2_forward; the reference's
+    # split is reconstruct + at::matmul, mbwq_linear_cuda_kernel.cu:968-1002, which `use_cublas` selects there: here the flag changes
+    # nothing, there is no vendor GEMM on this path)
     L = _hip.lib()
     ws = _hip.workspace(L.bie_mbwq_workspace_bytes(M, K, N), x.device)
     keep, rp = _rows_arg(rows)

@@ -54,6 +54,11 @@ int mpq_sort_rows_launch(const int32_t* qw, const int32_t* perm, int32_t* out, i
 int gather_cols_launch(const void* x, const int32_t* perm, void* out, int M, int K, int elem_bytes, hipStream_t st);
 int mpq_grad_input_launch(const void* gy, const int32_t* qw, const void* scales, const void* zeros, const int32_t* g_idx,
                           void* gx, int M, int K, int N, int w_bit, int group_size, int asym, int dtype, hipStream_t st);
+// mpq_dense.hip
+bool mpq_dense_shape_ok(int K, int N);
+size_t mpq_dense_workspace_bytes(int K, int N);
+int mpq_dense_gidx_launch(const void* x, const int32_t* qw, const void* scales, const void* zeros, const int32_t* g_idx, const void* bias, void* y, void* scratch,
+                          int M, int K, int N, int w_bit, int asym, int dtype, hipStream_t st);
 // mbwq.hip
 size_t mbwq_workspace_bytes(int M, int K, int N);
 int mbwq_q4_dequant_launch(const int32_t* qw, const void* scales, const void* zeros, const int16_t* perm, void* out, int K,
@@ -154,6 +159,16 @@ int bie_mpq_list_forward(bie_mpq_list_t* plan, void* stream) { return mpq_list_f
 int bie_mpq_list_launches(const bie_mpq_list_t* plan) { return mpq_list_launches(reinterpret_cast<const MpqList*>(plan)); }
 void bie_mpq_list_destroy(bie_mpq_list_t* plan) { mpq_list_destroy(reinterpret_cast<MpqList*>(plan)); }
 
+// explicit g_idx that is not a permutation of k // group_size, prefill: per-k dequantise into the fragment image + the dense GEMM (mpq_dense.hip)
+static bool gidx_dense_ok(int M, int K, int N, int dtype) { return M > 32 && (dtype == BIE_F16 || dtype == BIE_BF16) && mpq_dense_shape_ok(K, N); }
+
+size_t bie_mpq_workspace_bytes_gidx(int M, int K, int N, int w_bit) {
+    const size_t base = bie_mpq_workspace_bytes(M, K, N, w_bit);
+    if (base == 0 || !gidx_dense_ok(M, K, N, BIE_F16)) return base;
+    const size_t img = WS_HEAD + mpq_dense_workspace_bytes(K, N);
+    return img > base ? img : base;
+}
+
 size_t bie_mpq_workspace_bytes(int M, int K, int N, int w_bit) {
     if (M <= 0 || K <= 0 || N <= 0 || !(w_bit == 1 || w_bit == 2 || w_bit == 4 || w_bit == 8)) return 0;
     size_t a = M <= 16 ? mpq_gemv_workspace_bytes(M, K, N, w_bit) : 0;
@@ -194,6 +209,11 @@ int bie_mpq_forward(const void* x, const int32_t* qweight, const void* scales, c
         return mpq_gemv_launch(x, qweight, scales, zeros, bias, y, head, M, K, N, w_bit, group_size, asym ? 1 : 0, dtype, nullptr, st);
     if (gemm_ok)
         return mpq_gemm_launch(x, qweight, scales, zeros, bias, y, part, M, K, N, w_bit, group_size, asym ? 1 : 0, dtype, nullptr, st);
+    // explicit irregular g_idx, prefill: the reference materialises the dense weight and calls cuBLAS (mpq_layer.py:59-63); here the
+    // per-k dequantise writes the MFMA fragment image and the dense kernel multiplies -- when the caller sized the workspace for it
+    // (bie_mpq_workspace_bytes_gidx); a smaller workspace keeps the generic kernel below
+    if (has_gidx && gidx_dense_ok(M, K, N, dtype) && workspace_bytes >= WS_HEAD + mpq_dense_workspace_bytes(K, N))
+        return mpq_dense_gidx_launch(x, qweight, scales, zeros, g_idx, bias, y, part, M, K, N, w_bit, asym ? 1 : 0, dtype, st);
     // generic path (explicit g_idx / odd shapes / fp32), GENERIC_M_CHUNK rows at a time
     const size_t esz = dtype == BIE_F32 ? 4 : 2;
     for (int m0 = 0; m0 < M; m0 += GENERIC_M_CHUNK) {

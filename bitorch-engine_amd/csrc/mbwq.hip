@@ -370,6 +370,49 @@ __global__ __launch_bounds__(256) void exl2_dequant_kernel(const uint32_t* __res
     }
 }
 
+// ---- prefill: the same values straight into the MFMA fragment image of mpq_dense.hip (packed k order; x is gathered by q_perm) -----
+// Fragment (nb, ks) = columns 32*nb .. +31 x k 16*ks .. +15; lane l of it owns the 8 values of column 32*nb + (l & 31), k 16*ks +
+// 8*(l >> 5) .. +7 as four fp16 pairs in k order.  A thread takes one (column, 32-chunk): four 16-byte stores, each 512 contiguous bytes
+// per 32 lanes.  Replaces reconstruct_exl2_kernel + at::matmul of the reference's prefill branch (mbwq_linear_cuda_kernel.cu:849-897,
+// 968-1002) with the reference's rounding per weight (exl2_dq: one v_fma_f16).
+__global__ __launch_bounds__(256) void exl2_dequant_frag_kernel(const uint32_t* __restrict__ qw, const uint16_t* __restrict__ scales,
+                                                                const uint16_t* __restrict__ zeros, const uint16_t* __restrict__ gmap,
+                                                                uint4_t* __restrict__ img, Exl2Rows rows, int K, int N) {
+    const int nraw = blockIdx.x * 256 + threadIdx.x;  // up to the padded column count: columns past N repeat column N - 1 (nobody stores them)
+    const int k0 = blockIdx.y * 32;
+    if (nraw >= ((N + 31) & ~31) || k0 >= K) return;
+    const int n = nraw < N ? nraw : N - 1;
+    int bits, prow;
+    exl2_locate(rows, k0, bits, prow);
+    uint32_t w[8], q[32];
+    switch (bits) {
+        case 8: exl2_load_chunk<8>(qw, N, prow, n, w); exl2_extract32<8>(w, q); break;
+        case 6: exl2_load_chunk<6>(qw, N, prow, n, w); exl2_extract32<6>(w, q); break;
+        case 5: exl2_load_chunk<5>(qw, N, prow, n, w); exl2_extract32<5>(w, q); break;
+        case 4: exl2_load_chunk<4>(qw, N, prow, n, w); exl2_extract32<4>(w, q); break;
+        case 3: exl2_load_chunk<3>(qw, N, prow, n, w); exl2_extract32<3>(w, q); break;
+        default: exl2_load_chunk<2>(qw, N, prow, n, w); exl2_extract32<2>(w, q); break;
+    }
+    const long KS = K >> 4;
+    const long nb = nraw >> 5;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        const int g = gmap[2 * (k0 + 16 * half)];
+        const half_t s = __builtin_bit_cast(half_t, scales[(long)g * N + n]);
+        const half_t z = __builtin_bit_cast(half_t, zeros[(long)g * N + n]);
+#pragma unroll
+        for (int h8 = 0; h8 < 2; h8++) {
+            uint32_t o[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int j = 16 * half + 8 * h8 + 2 * i;
+                o[i] = (uint32_t)exl2_dq(q[j], s, z) | ((uint32_t)exl2_dq(q[j + 1], s, z) << 16);
+            }
+            img[(nb * KS + (k0 >> 4) + half) * 64 + h8 * 32 + (nraw & 31)] = uint4_t{o[0], o[1], o[2], o[3]};
+        }
+    }
+}
+
 // uniform q4/q2: out[q_perm ? q_perm[k] : k][n] = fma(s, q, -z)
 __global__ __launch_bounds__(256) void mbwq_q4_dequant_kernel(const uint32_t* __restrict__ qw, const uint16_t* __restrict__ scales,
                                                               const uint16_t* __restrict__ zeros, const uint16_t* __restrict__ perm,
@@ -1399,7 +1442,27 @@ constexpr int EXL2_XP_MAX_M = 16;  // rows of x of the pre-permuted decode form 
 static size_t exl2_lone_group_bytes(int M, int K, int N);
 int exl2_group_forward(int n, const bie_exl2_list_entry* e, const void* x, int M, float* head, char* body, hipStream_t st);
 
+// prefill form of the mixed-bit layout: rows of x from which the dequantise-once image + dense GEMM (mpq_dense.hip) replaces the
+// streaming kernels (which read the packed weight once per 16 rows).  BIE_EXL2_DENSE_MIN_M moves the switch (tools/).
+bool mpq_dense_shape_ok(int K, int N);
+size_t mpq_dense_workspace_bytes(int K, int N);
+int mpq_dense_gemm_only_launch(const void* x, const void* img, const void* bias, void* y, int M, int K, int N, int dtype, hipStream_t st, int ldy);
+static int exl2_dense_min_m() {
+    static const int v = [] { const char* e = getenv("BIE_EXL2_DENSE_MIN_M"); return e ? atoi(e) : 49; }();
+    const char* t = getenv("BIE_TUNING");
+    if (t) { const char* e = getenv("BIE_EXL2_DENSE_MIN_M"); return e ? atoi(e) : 49; }
+    return v;
+}
+static bool exl2_dense_ok(int M, int K, int N) { return M >= exl2_dense_min_m() && mpq_dense_shape_ok(K, N); }
+static size_t exl2_dense_bytes(int M, int K, int N) {  // [image][x[:, q_perm]]
+    return exl2_dense_ok(M, K, N) ? mpq_dense_workspace_bytes(K, N) + (((size_t)M * K * 2 + 255) & ~(size_t)255) : 0;
+}
+
 size_t mbwq_workspace_bytes(int M, int K, int N) {
+    if (exl2_dense_ok(M, K, N)) {  // the uniform q4 / q2 kernels of the same workspace function keep their own needs below
+        const size_t f = exl2_dense_bytes(M, K, N), b0 = mpq_gemm_workspace_bytes(M, K, N);
+        return f > b0 ? f : b0;
+    }
     size_t a = 0;
     for (int w : {2, 4}) {
         size_t t = M <= 8 ? mpq_gemv_workspace_bytes(M, K, N, w) : 0;
@@ -1485,6 +1548,22 @@ int mbwq_exl2_forward_launch(const void* x, const int32_t* qw, const void* scale
                              hipStream_t st) {
     Exl2Rows rows;
     for (int i = 0; i < 6; i++) rows.r[i] = rows7[i];
+    if (exl2_dense_ok(M, K, N)) {  // prefill: dequantise once into the fragment image, x[:, q_perm], dense MFMA GEMM -- three launches, no vendor GEMM
+        char* img = reinterpret_cast<char*>(part);
+        hipLaunchKernelGGL(exl2_dequant_frag_kernel, dim3(cdiv(cdiv(N, 32) * 32, 256), K / 32), dim3(256), 0, st, (const uint32_t*)qw, (const uint16_t*)scales,
+                           (const uint16_t*)zeros, (const uint16_t*)gmap, (uint4_t*)img, rows, K, N);
+        int rc = check_launch("exl2_dequant_frag_kernel");
+        if (rc) return rc;
+        const void* xin = x;
+        if (perm) {
+            uint16_t* xp = reinterpret_cast<uint16_t*>(img + mpq_dense_workspace_bytes(K, N));
+            hipLaunchKernelGGL(exl2_permute_x_kernel, dim3(cdiv(K, 256), M < 256 ? M : 256), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)perm, xp, M, K);
+            rc = check_launch("exl2_permute_x_kernel");
+            if (rc) return rc;
+            xin = xp;
+        }
+        return mpq_dense_gemm_only_launch(xin, img, nullptr, y, M, K, N, BIE_F16, st, N);
+    }
     const bool slab_ok = !(cdiv(N, 64) > BIE_WS_COUNTERS && K / 32 > 768);  // K slabs need one generation word per column block
     const bool regular = (rows7[6] & BIE_EXL2_ROWS_REGULAR) && exl2_direct_on();
     static const int lone_min_k = [] { const char* ev = getenv("BIE_EXL2_LONE_AS_GROUP_MIN_K"); return ev ? atoi(ev) : EXL2_LONE_AS_GROUP_MIN_K; }();

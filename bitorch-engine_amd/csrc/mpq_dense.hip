@@ -17,8 +17,13 @@
 #include "mpq_frag_dequant.cuh"
 #include "mfma_pipe.cuh"
 #include <stdlib.h>
+#include <type_traits>
 
 #pragma clang fp contract(off)
+
+#ifndef BIE_DENSE_LAB
+#define BIE_DENSE_LAB 0  // compile-time ablation switch of tools/dense_lab.py (0 = product code): 1 no epilogue stores, 2 no main loop,
+#endif                   // 3 the round-4 epilogue (64 rows x 16 bytes per store instruction)
 
 namespace bie {
 
@@ -57,6 +62,46 @@ __global__ __launch_bounds__(256) void mpq_dequant_frag_kernel(const uint32_t* _
         const int c8 = (ks0 + i) * 2 + (lane >> 5);
         img[(f0 + i) * 64 + lane] = dequant8<DT, WBIT, ZM>(raw[i], c8, make_col_params<DT, WBIT, ZM, (WBIT == 4)>(sb[i], zb[i]));
     }
+}
+
+// The same image for an EXPLICIT g_idx that is not a permutation of k // group_size (unequal groups: the act-order forms that ARE such a
+// permutation are re-ordered at load time, q_linear_cuda.act_order_sorted): every k carries its own group, so the 8 values of a lane are
+// dequantised one by one with the scalar functions (same roundings).  Replaces the reference's dense weight of the M > 32 branch for such
+// checkpoints (unpack_qweight with g_idx, layers/qlinear/nbit/cuda/utils.py:36-51) -- rare, not tuned, but no vendor GEMM behind it.
+template <int DT, int WBIT, bool ASYM>
+__global__ __launch_bounds__(256) void mpq_dequant_frag_gidx_kernel(const uint32_t* __restrict__ qw, const uint16_t* __restrict__ scales, const void* __restrict__ zeros,
+                                                                    const int32_t* __restrict__ g_idx, uint4_t* __restrict__ img, int N, long nfrag, int ks_per_col) {
+    const long f = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (f >= nfrag) return;
+    const int lane = threadIdx.x & 63;
+    const long nb = f / ks_per_col;
+    const int ks = (int)(f - nb * ks_per_col);
+    int n = (int)nb * 32 + (lane & 31);
+    if (n > N - 1) n = N - 1;
+    constexpr int NBW = 32 / WBIT;
+    constexpr uint32_t M1 = (1u << WBIT) - 1u;
+    const int k0 = ks * 16 + 8 * (lane >> 5);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int k = k0 + e;
+        const uint32_t q = (qw[(long)(k / NBW) * N + n] >> ((k % NBW) * WBIT)) & M1;
+        const long g = g_idx[k];
+        const float sc = dt_traits<DT>::load(scales, g * N + n);
+        if constexpr (ASYM) {
+            const uint32_t word = reinterpret_cast<const uint32_t*>(zeros)[g * (N / NBW) + n / NBW];
+            v[e] = dequant_scalar_asym<DT>(q, sc, (int)((word >> ((n % NBW) * WBIT)) & M1) + 1);
+        } else {
+            v[e] = dequant_scalar_sym<DT>(q, sc, dt_traits<DT>::load(zeros, g * N + n));
+        }
+    }
+    uint32_t o[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if constexpr (DT == BIE_BF16) o[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
+        else o[i] = f32_to_f16_bits(v[2 * i]) | (f32_to_f16_bits(v[2 * i + 1]) << 16);
+    }
+    img[f * 64 + lane] = uint4_t{o[0], o[1], o[2], o[3]};
 }
 
 // ---- pass 2: dense GEMM ----------------------------------------------------------------------------------------------
@@ -115,10 +160,12 @@ __global__ __launch_bounds__(256) void mpq_dense_gemm_kernel(const uint16_t* __r
     };
 
     const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
-    const int rl = lane & 31, hh = lane >> 5, sw = (rl >> 2) & 3;
     uint32_t a_addr[2];  // x fragment of k16 step s: row rl of the wave's first block, logical slot 2*s + hh
-    a_addr[0] = lds_base + (uint32_t)((wy * WM * 32 + rl) * 64 + ((hh ^ sw) << 4));
-    a_addr[1] = lds_base + (uint32_t)((wy * WM * 32 + rl) * 64 + (((2 + hh) ^ sw) << 4));
+    {
+        const int rl = lane & 31, hh = lane >> 5, sw = (rl >> 2) & 3;
+        a_addr[0] = lds_base + (uint32_t)((wy * WM * 32 + rl) * 64 + ((hh ^ sw) << 4));
+        a_addr[1] = lds_base + (uint32_t)((wy * WM * 32 + rl) * 64 + (((2 + hh) ^ sw) << 4));
+    }
     const uint32_t b_addr = lds_base + AF * 2048 + (wx * WN * 2) * 1024 + lane * 16;
 
     float16_t acc[WM][WN];
@@ -166,6 +213,9 @@ __global__ __launch_bounds__(256) void mpq_dense_gemm_kernel(const uint16_t* __r
         });
     };
     int kt = 0;
+#if BIE_DENSE_LAB == 2
+    kt = KT;
+#endif
     for (; kt + 3 <= KT; kt += 3) {
         stage(kt, XA, XB, YA, YB, ZA, ZB);
         stage(kt + 1, ZA, ZB, XA, XB, YA, YB);
@@ -178,28 +228,102 @@ __global__ __launch_bounds__(256) void mpq_dense_gemm_kernel(const uint16_t* __r
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the clamped look-ahead pieces / reads must not outlive the workgroup's LDS
     mfma_drain();
 
+    int le = threadIdx.x & 63;
+    asm volatile("" : "+v"(le));  // everything the epilogue derives from the lane id is computed HERE, not carried through the loop (512 registers: no room)
+    const int rl = le & 31, hh = le >> 5;
     // C/D layout: column = lane & 31 = row m of x, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) = output feature inside the 32-block.
-    // y = dt(dt(acc) + bias) as mpq_gemm.hip; the half-waves trade packed quads (v_permlane32_swap_b32) so that a lane stores 8
+    // y = dt(dt(acc) + bias) as mpq_gemm.hip; the half-waves trade packed quads (v_permlane32_swap_b32) so that a lane holds 8
     // consecutive features of its row: 16 bytes.
     const bool vec_ok = (N & 7) == 0 && (ldy & 7) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;  // ldy: the row pitch of y in elements (N, or a wider destination's)
     auto pack2 = [&](float lo, float hi) -> uint32_t {
         if constexpr (DT == BIE_BF16) return pack_bf16x2(lo, hi);
         else return f32_to_f16_bits(lo) | (f32_to_f16_bits(hi) << 16);
     };
-    // Two lean paths (the branch is wave-uniform): without bias a value is rounded once, by the pack itself (v_cvt_pk: one VALU per
-    // two values); with bias the eight bias values of a (column block, register group) are loaded once and serve all WM row blocks.
-    // (The first form -- per value a clamped bias load, two roundings and a select -- was 9000 instructions per wave: ~11 us of fixed
-    // cost per launch, profiles/r03_dense_k_slope.txt.)
+    // the eight consecutive features (column block j, quad pair qp, half hh) of row rl as one 16-byte word
+    auto pack8 = [&](const float (&v)[8]) -> uint4_t {
+        const uint32_t p0 = pack2(v[0], v[1]), p1 = pack2(v[2], v[3]), p2 = pack2(v[4], v[5]), p3 = pack2(v[6], v[7]);
+        const auto s0 = __builtin_amdgcn_permlane32_swap(p0, p2, false, false);  // first operand's upper half <-> second's lower half
+        const auto s1 = __builtin_amdgcn_permlane32_swap(p1, p3, false, false);
+        return uint4_t{s0[0], s1[0], s0[1], s1[1]};
+    };
+#if BIE_DENSE_LAB == 1
+    if (M == -12345)  // never: the accumulators stay live, nothing is stored
+#endif
+#if BIE_DENSE_LAB != 3
+    if (vec_ok) {
+        // Row-contiguous stores through the wave's own quarter of the (now idle) stage buffers.  A lane owns features of ONE row, so a
+        // direct store instruction touches 64 rows x 16 bytes = 64 partial lines (the round-4 epilogue: store-issue-bound, ~7 B/clk/CU,
+        // MI355X_MICROARCH.md "epilogue store tail"; ~10 us of the 4096^3 launch).  Here a block of 32 rows x (32 * WN) features goes to
+        // LDS as [row][16-byte chunk ^ (row & 15)] (ds_write_b128, conflict-free: the 8 lanes of a store group hit 8 different chunks)
+        // and comes back with 16 consecutive lanes on one row: a store instruction writes 64 / (4 * WN) rows x (64 * WN) contiguous bytes
+        // -- whole 128-byte lines.  No barrier: the region is private to the wave (its own lgkmcnt orders write -> read).
+        static_assert(WN == 4 || WN == 2, "row pitch of the staging block: 16 or 8 chunks");
+        constexpr int CH = 4 * WN;        // 16-byte chunks per staged row (32 * WN features)
+        constexpr int RPI = 64 / CH;      // rows one read / store instruction covers
+        constexpr int BLK = 32 * CH * 16; // bytes of one staged block (32 rows)
+        __builtin_amdgcn_s_barrier();     // every wave is out of the loop: nobody reads stage data any more
+        const uint32_t stg = lds_base + (uint32_t)wave * (2 * BLK);  // two blocks per wave: block i + 1 is written while block i drains
+        const int rrow = le / CH, rch = le % CH;
+        auto staged = [&](auto has_bias) {
+            constexpr bool HB = decltype(has_bias)::value;
+#pragma unroll
+            for (int i = 0; i < WM; i++) {
+                const uint32_t blk = stg + (uint32_t)(i & 1) * BLK;
+#pragma unroll
+                for (int j = 0; j < WN; j++) {
+#pragma unroll
+                    for (int qp = 0; qp < 2; qp++) {
+                        float v[8];
+#pragma unroll
+                        for (int e = 0; e < 8; e++) {
+                            v[e] = acc[i][j][8 * qp + e];
+                            if constexpr (HB) {  // dt(dt(acc) + bias), as mpq_gemm.hip
+                                const int n = (tile_n * BF + wx * WN + j) * 32 + 8 * (2 * qp + (e >> 2)) + 4 * hh + (e & 3);
+                                v[e] = dt_traits<DT>::round(v[e]) + dt_traits<DT>::load(bias, n < N ? n : N - 1);
+                            }
+                        }
+                        const uint4_t w = pack8(v);
+                        const int ch = 4 * j + 2 * qp + hh;
+                        const uint32_t a = blk + (uint32_t)(rl * (CH * 16) + ((ch ^ (rl & (CH - 1))) << 4));
+                        asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(w) : "memory");
+                        __builtin_amdgcn_sched_barrier(0);  // one 8-value group at a time: the 256 accumulators leave the AGPRs as they are packed
+                    }
+                }
+                uint4_t w[32 / RPI];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int t = 0; t < 32 / RPI; t++) {
+                    const int r = t * RPI + rrow;
+                    const uint32_t a = blk + (uint32_t)(r * (CH * 16) + ((rch ^ (r & (CH - 1))) << 4));
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(w[t]) : "v"(a) : "memory");
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);  // the reads return by the wait, not by data dependence: nothing that uses w[] may move up
+#pragma unroll
+                for (int t = 0; t < 32 / RPI; t++) {
+                    const int r = t * RPI + rrow;
+                    const int m = (tile_m * AF + wy * WM + i) * 32 + r;
+                    const int n = (tile_n * BF + wx * WN) * 32 + 8 * rch;
+                    asm volatile("" : "+v"(w[t]));
+                    if (m < M && n < N) *reinterpret_cast<uint4_t*>(y + (long)m * ldy + n) = w[t];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if (bias == nullptr) staged(std::false_type{});
+        else staged(std::true_type{});
+        return;
+    }
+#endif
+    // direct stores (odd N / pitch / alignment; BIE_DENSE_LAB == 3: the round-4 epilogue)
     auto store8 = [&](int i, int j, int qp, const float (&v)[8]) {
         const int m = (tile_m * AF + wy * WM + i) * 32 + rl;
         const int nb = (tile_n * BF + wx * WN + j) * 32;
         uint16_t* yr = y + (long)(m < M ? m : 0) * ldy;
         if (vec_ok) {
-            const uint32_t p0 = pack2(v[0], v[1]), p1 = pack2(v[2], v[3]), p2 = pack2(v[4], v[5]), p3 = pack2(v[6], v[7]);
-            const auto s0 = __builtin_amdgcn_permlane32_swap(p0, p2, false, false);  // first operand's upper half <-> second's lower half
-            const auto s1 = __builtin_amdgcn_permlane32_swap(p1, p3, false, false);
+            const uint4_t w = pack8(v);
             const int n = nb + 8 * (2 * qp + hh);
-            if (m < M && n < N) *reinterpret_cast<uint4_t*>(yr + n) = uint4_t{s0[0], s1[0], s0[1], s1[1]};
+            if (m < M && n < N) *reinterpret_cast<uint4_t*>(yr + n) = w;
         } else if (m < M) {
 #pragma unroll
             for (int e = 0; e < 8; e++) {
@@ -208,6 +332,9 @@ __global__ __launch_bounds__(256) void mpq_dense_gemm_kernel(const uint16_t* __r
             }
         }
     };
+#if BIE_DENSE_LAB == 1
+    if (M == -12345)
+#endif
     if (bias == nullptr) {
 #pragma unroll
         for (int i = 0; i < WM; i++)
@@ -313,6 +440,32 @@ static void dense_gemm_launch(const void* x, const void* img, const void* bias, 
         hipLaunchKernelGGL((mpq_dense_gemm_kernel<DT, 2, 2>), dim3((unsigned)(cdiv(M, 128) * tn)), dim3(256), 0, st, (const uint16_t*)x, (const uint8_t*)img,
                            (const uint16_t*)bias, (uint16_t*)y, M, N, K, tn, NB32, gm, ldy);
     }
+}
+
+// the GEMM alone on an image somebody else wrote (mbwq.hip: the mixed-bit layout's own dequantise pass)
+bool mpq_dense_shape_ok(int K, int N) { return (K & 31) == 0 && (N & 7) == 0; }
+int mpq_dense_gemm_only_launch(const void* x, const void* img, const void* bias, void* y, int M, int K, int N, int dtype, hipStream_t st, int ldy) {
+    if (dtype == BIE_F16) dense_gemm_launch<BIE_F16>(x, img, bias, y, M, K, N, ldy, st);
+    else dense_gemm_launch<BIE_BF16>(x, img, bias, y, M, K, N, ldy, st);
+    return check_launch("mpq_dense_gemm_kernel");
+}
+
+// explicit, irregular g_idx: per-k groups (mpq_dequant_frag_gidx_kernel), then the same GEMM
+int mpq_dense_gidx_launch(const void* x, const int32_t* qw, const void* scales, const void* zeros, const int32_t* g_idx, const void* bias, void* y, void* scratch,
+                          int M, int K, int N, int w_bit, int asym, int dtype, hipStream_t st) {
+    const int KS = K / 16;
+    const long nfrag = (long)cdiv(N, 32) * KS;
+    const dim3 grid((unsigned)cdivl(nfrag, 4));
+#define BIE_DQG3(DTV, WB, AS) hipLaunchKernelGGL((mpq_dequant_frag_gidx_kernel<DTV, WB, AS>), grid, dim3(256), 0, st, (const uint32_t*)qw, (const uint16_t*)scales, zeros, g_idx, (uint4_t*)scratch, N, nfrag, KS)
+#define BIE_DQG2(DTV, WB) do { if (asym) BIE_DQG3(DTV, WB, true); else BIE_DQG3(DTV, WB, false); } while (0)
+#define BIE_DQG(DTV) do { switch (w_bit) { case 1: BIE_DQG2(DTV, 1); break; case 2: BIE_DQG2(DTV, 2); break; case 4: BIE_DQG2(DTV, 4); break; default: BIE_DQG2(DTV, 8); break; } } while (0)
+    if (dtype == BIE_F16) BIE_DQG(BIE_F16); else BIE_DQG(BIE_BF16);
+#undef BIE_DQG
+#undef BIE_DQG2
+#undef BIE_DQG3
+    int rc = check_launch("mpq_dequant_frag_gidx_kernel");
+    if (rc) return rc;
+    return mpq_dense_gemm_only_launch(x, scratch, bias, y, M, K, N, dtype, st, N);
 }
 
 // scratch: mpq_dense_workspace_bytes(K, N) bytes, 16-byte aligned

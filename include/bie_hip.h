@@ -74,6 +74,11 @@ unsigned bie_device_status(int clear);
  * zero-filled, or to recover a workspace after a launch that did not complete (device reset, aborted graph). */
 int bie_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
 size_t bie_mpq_workspace_bytes(int M, int K, int N, int w_bit);
+/* The same for a call that passes an EXPLICIT g_idx which is not a permutation of k // group_size (unequal groups) with M > 32: room for
+ * the dequantised MFMA fragment image, so that bie_mpq_forward runs "per-k dequantise + dense MFMA GEMM" instead of the row-chunked generic
+ * kernel.  The reference's branch for those calls is unpack_qweight(g_idx) + torch.matmul (layers/qlinear/nbit/cuda/mpq_layer.py:59-63,
+ * utils.py:36-51); with a workspace of only bie_mpq_workspace_bytes the call still works (generic kernel). */
+size_t bie_mpq_workspace_bytes_gidx(int M, int K, int N, int w_bit);
 
 /* y = x . dequant(qweight) (+ bias).
  * Replaces q_linear_cuda.mpq_forward (layers/qlinear/nbit/cuda/q_linear_cuda.cpp:258-270 ->
