@@ -1024,6 +1024,32 @@ __global__ __launch_bounds__(256) void exl2_permute_x_kernel(const uint16_t* __r
     for (int m = blockIdx.y; m < M; m += gridDim.y) xp[(long)m * K + k] = x[(long)m * K + kx];
 }
 
+// The same for MANY rows (prefill): a workgroup stages whole rows of x in LDS with 16-byte loads, gathers from LDS (two-byte reads, any
+// order) and writes 16 bytes per lane -- HBM sees x once and xp once, both streamed (the per-element form above touches a 64-byte line per
+// two-byte read: 41 us at 4096 x 4096 against the ~13 us of 64 MB at the streaming rate).  K % 8 == 0; rows of up to 32768 elements.
+__global__ __launch_bounds__(256) void exl2_permute_rows_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ perm,
+                                                                uint16_t* __restrict__ xp, int M, int K) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_pr[];
+    uint16_t* row = reinterpret_cast<uint16_t*>(smem_pr);
+    const int K8 = K >> 3;
+    for (int m = blockIdx.x; m < M; m += gridDim.x) {
+        const uint4_t* src = reinterpret_cast<const uint4_t*>(x + (long)m * K);
+        for (int i = threadIdx.x; i < K8; i += 256) reinterpret_cast<uint4_t*>(row)[i] = src[i];
+        __syncthreads();
+        uint4_t* dst = reinterpret_cast<uint4_t*>(xp + (long)m * K);
+        for (int i = threadIdx.x; i < K8; i += 256) {
+            const uint4_t p = reinterpret_cast<const uint4_t*>(perm)[i];  // eight source columns
+            uint4_t o;
+            o.x = (uint32_t)row[p.x & 0xffffu] | ((uint32_t)row[p.x >> 16] << 16);
+            o.y = (uint32_t)row[p.y & 0xffffu] | ((uint32_t)row[p.y >> 16] << 16);
+            o.z = (uint32_t)row[p.z & 0xffffu] | ((uint32_t)row[p.z >> 16] << 16);
+            o.w = (uint32_t)row[p.w & 0xffffu] | ((uint32_t)row[p.w >> 16] << 16);
+            dst[i] = o;
+        }
+        __syncthreads();
+    }
+}
+
 constexpr int EXL2_T_PITCH = 40;  // halves per column of the transpose buffer (80 bytes)
 
 // NARROW: no 8 / 6 / 5-bit rows in this tensor (host: rows7[2] == 0) -- the wide bands' prefetch sets (4 x 8 words) cost the 3/2-bit models
@@ -1446,7 +1472,8 @@ int exl2_group_forward(int n, const bie_exl2_list_entry* e, const void* x, int M
 // streaming kernels (which read the packed weight once per 16 rows).  BIE_EXL2_DENSE_MIN_M moves the switch (tools/).
 bool mpq_dense_shape_ok(int K, int N);
 size_t mpq_dense_workspace_bytes(int K, int N);
-int mpq_dense_gemm_only_launch(const void* x, const void* img, const void* bias, void* y, int M, int K, int N, int dtype, hipStream_t st, int ldy);
+size_t mpq_dense_part_bytes(int M, int K, int N);
+int mpq_dense_gemm_only_launch(const void* x, const void* img, const void* bias, void* y, int M, int K, int N, int dtype, hipStream_t st, int ldy, float* part);
 static int exl2_dense_min_m() {
     static const int v = [] { const char* e = getenv("BIE_EXL2_DENSE_MIN_M"); return e ? atoi(e) : 49; }();
     const char* t = getenv("BIE_TUNING");
@@ -1454,8 +1481,9 @@ static int exl2_dense_min_m() {
     return v;
 }
 static bool exl2_dense_ok(int M, int K, int N) { return M >= exl2_dense_min_m() && mpq_dense_shape_ok(K, N); }
-static size_t exl2_dense_bytes(int M, int K, int N) {  // [image][x[:, q_perm]]
-    return exl2_dense_ok(M, K, N) ? mpq_dense_workspace_bytes(K, N) + (((size_t)M * K * 2 + 255) & ~(size_t)255) : 0;
+static size_t exl2_dense_xp_bytes(int M, int K) { return ((size_t)M * K * 2 + 255) & ~(size_t)255; }
+static size_t exl2_dense_bytes(int M, int K, int N) {  // [image][x[:, q_perm]][fp32 partial sums of the K splits]
+    return exl2_dense_ok(M, K, N) ? mpq_dense_workspace_bytes(K, N) + exl2_dense_xp_bytes(M, K) + mpq_dense_part_bytes(M, K, N) : 0;
 }
 
 size_t mbwq_workspace_bytes(int M, int K, int N) {
@@ -1557,12 +1585,16 @@ int mbwq_exl2_forward_launch(const void* x, const int32_t* qw, const void* scale
         const void* xin = x;
         if (perm) {
             uint16_t* xp = reinterpret_cast<uint16_t*>(img + mpq_dense_workspace_bytes(K, N));
-            hipLaunchKernelGGL(exl2_permute_x_kernel, dim3(cdiv(K, 256), M < 256 ? M : 256), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)perm, xp, M, K);
-            rc = check_launch("exl2_permute_x_kernel");
+            if ((K & 7) == 0 && K <= 32768 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(perm) & 15) == 0)
+                hipLaunchKernelGGL(exl2_permute_rows_kernel, dim3(M < 2048 ? M : 2048), dim3(256), (size_t)K * 2, st, (const uint16_t*)x, (const uint16_t*)perm, xp, M, K);
+            else
+                hipLaunchKernelGGL(exl2_permute_x_kernel, dim3(cdiv(K, 256), M < 256 ? M : 256), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)perm, xp, M, K);
+            rc = check_launch("exl2_permute_rows_kernel");
             if (rc) return rc;
             xin = xp;
         }
-        return mpq_dense_gemm_only_launch(xin, img, nullptr, y, M, K, N, BIE_F16, st, N);
+        float* psum = mpq_dense_part_bytes(M, K, N) ? reinterpret_cast<float*>(img + mpq_dense_workspace_bytes(K, N) + exl2_dense_xp_bytes(M, K)) : nullptr;
+        return mpq_dense_gemm_only_launch(xin, img, nullptr, y, M, K, N, BIE_F16, st, N, psum);
     }
     const bool slab_ok = !(cdiv(N, 64) > BIE_WS_COUNTERS && K / 32 > 768);  // K slabs need one generation word per column block
     const bool regular = (rows7[6] & BIE_EXL2_ROWS_REGULAR) && exl2_direct_on();

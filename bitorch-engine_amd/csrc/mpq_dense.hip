@@ -113,7 +113,8 @@ __device__ __forceinline__ void mfma16(float16_t& c, const v4i_t& a, const v4i_t
 
 template <int DT, int WM, int WN>
 __global__ __launch_bounds__(256) void mpq_dense_gemm_kernel(const uint16_t* __restrict__ x, const uint8_t* __restrict__ wimg, const uint16_t* __restrict__ bias,
-                                                             uint16_t* __restrict__ y, int M, int N, int K, int tiles_n, int NB32, int gm, int ldy) {
+                                                             uint16_t* __restrict__ y, int M, int N, int K, int tiles_n, int NB32, int gm, int ldy,
+                                                             float* __restrict__ part, int kt_per_split) {
     constexpr int AF = 2 * WM, BF = 2 * WN;  // 32-row / 32-column blocks per workgroup tile
     constexpr int NFR = (AF + BF) * 2;       // KiB per stage (k = 32): x rows 64 bytes each, weight fragments 1 KiB per k16 step
     constexpr int PW = NFR / 4;              // LDS-DMA pieces per wave and stage
@@ -129,7 +130,18 @@ __global__ __launch_bounds__(256) void mpq_dense_gemm_kernel(const uint16_t* __r
     const int nblk = gridDim.x;
     int tile_m, tile_n;
     pipe_tile(bid, nblk, tiles_n, gm, tile_m, tile_n);
-    const int KT = K >> 5, KS = K >> 4;
+    // K split over blockIdx.y (few tiles, long K: the mixed-bit layout's prefill at 49 <= M < 1024): split s takes the stages
+    // [s * kt_per_split, ...) and leaves its fp32 sums in part[s][M][N] for launch_splitk_finalize; part == nullptr: the whole K, y directly
+    const int KS = K >> 4;
+    // (128 x 128 tiles only: the 256 x 256 instance has no register to spare for it and never needs it)
+    constexpr bool SPLITK = WM == 2 && WN == 2;
+    int kt0 = 0, KT = K >> 5;
+    if constexpr (SPLITK) {
+        if (part) {
+            kt0 = (int)blockIdx.y * kt_per_split;
+            KT = (K >> 5) - kt0 < kt_per_split ? (K >> 5) - kt0 : kt_per_split;
+        }
+    }
 
     // this wave's LDS-DMA sources.  Stage image: [x: AF*2 pieces of 16 rows x 64 bytes][weights: BF*2 fragments (column block, k16 step)]
     const bool x_wave = wave * PW < AF * 2;
@@ -142,12 +154,12 @@ __global__ __launch_bounds__(256) void mpq_dense_gemm_kernel(const uint16_t* __r
             const int rt = p * 16 + (lane >> 2);  // row of the tile; LDS slot lane & 3 holds logical slot (lane & 3) ^ ((rt >> 2) & 3)
             long m = (long)tile_m * (AF * 32) + rt;
             if (m > M - 1) m = M - 1;
-            src[j] = reinterpret_cast<const uint8_t*>(x) + (m * K) * 2 + (((lane & 3) ^ ((rt >> 2) & 3)) << 4);
+            src[j] = reinterpret_cast<const uint8_t*>(x) + (m * K) * 2 + (((lane & 3) ^ ((rt >> 2) & 3)) << 4) + (long)kt0 * 64;
         } else {
             const int q = p - AF * 2;
             long nb = (long)tile_n * BF + (q >> 1);
             if (nb > NB32 - 1) nb = NB32 - 1;
-            src[j] = wimg + ((nb * KS + (q & 1)) * 64 + lane) * 16;
+            src[j] = wimg + ((nb * KS + (q & 1)) * 64 + lane) * 16 + (long)kt0 * 2048;
         }
     }
     [[maybe_unused]] const int kt_last = KT - 1;
@@ -231,6 +243,21 @@ __global__ __launch_bounds__(256) void mpq_dense_gemm_kernel(const uint16_t* __r
     int le = threadIdx.x & 63;
     asm volatile("" : "+v"(le));  // everything the epilogue derives from the lane id is computed HERE, not carried through the loop (512 registers: no room)
     const int rl = le & 31, hh = le >> 5;
+    if constexpr (SPLITK) if (part != nullptr) {  // K split: fp32 partial sums, four consecutive features per lane and register quad (16-byte stores)
+        float* pr = part + (long)blockIdx.y * M * N;
+#pragma unroll
+        for (int i = 0; i < WM; i++) {
+            const int m = (tile_m * AF + wy * WM + i) * 32 + rl;
+#pragma unroll
+            for (int j = 0; j < WN; j++)
+#pragma unroll
+                for (int rq = 0; rq < 4; rq++) {
+                    const int n = (tile_n * BF + wx * WN + j) * 32 + 8 * rq + 4 * hh;
+                    if (m < M && n < N) *reinterpret_cast<float4_t*>(pr + (long)m * N + n) = float4_t{acc[i][j][4 * rq], acc[i][j][4 * rq + 1], acc[i][j][4 * rq + 2], acc[i][j][4 * rq + 3]};
+                }
+        }
+        return;
+    }
     // C/D layout: column = lane & 31 = row m of x, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) = output feature inside the 32-block.
     // y = dt(dt(acc) + bias) as mpq_gemm.hip; the half-waves trade packed quads (v_permlane32_swap_b32) so that a lane holds 8
     // consecutive features of its row: 16 bytes.
@@ -422,9 +449,32 @@ static void dequant_frag_launch(const int32_t* qw, const void* scales, const voi
 #undef BIE_DQ
 }
 
+// K splits of the 128 x 128-tile grid when it is far from filling the chip: enough workgroups for two per CU, at least eight stages each
+int mpq_dense_splits(int M, int K, int N) {
+    const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
+    if (t256 >= 192) return 1;
+    const long g128 = (long)cdiv(M, 128) * cdiv(N, 128);
+    if (g128 >= 256) return 1;
+    long S = (512 + g128 - 1) / g128;
+    const long max_s = (K >> 5) / 8 > 0 ? (K >> 5) / 8 : 1;
+    if (S > max_s) S = max_s;
+    if (S > 32) S = 32;
+    return S < 1 ? 1 : (int)S;
+}
+size_t mpq_dense_part_bytes(int M, int K, int N) {
+    const int S = mpq_dense_splits(M, K, N);
+    return S > 1 ? (size_t)S * M * N * sizeof(float) : 0;
+}
+
 template <int DT>
-static void dense_gemm_launch(const void* x, const void* img, const void* bias, void* y, int M, int K, int N, int ldy, hipStream_t st) {
+static void dense_gemm_launch(const void* x, const void* img, const void* bias, void* y, int M, int K, int N, int ldy, hipStream_t st, float* part = nullptr) {
     const int NB32 = cdiv(N, 32);
+    if (part != nullptr) {  // K split over gridDim.y (mpq_dense_splits), fp32 partial sums; the caller runs launch_splitk_finalize
+        const int S = mpq_dense_splits(M, K, N), KTs = cdiv(K >> 5, S), tn = cdiv(N, 128);
+        hipLaunchKernelGGL((mpq_dense_gemm_kernel<DT, 2, 2>), dim3((unsigned)(cdiv(M, 128) * tn), (unsigned)cdiv(K >> 5, KTs)), dim3(256), 0, st, (const uint16_t*)x, (const uint8_t*)img,
+                           (const uint16_t*)nullptr, (uint16_t*)y, M, N, K, tn, NB32, 1, ldy, part, KTs);
+        return;
+    }
     const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
     static const int tile_once = env_int_dense("BIE_GEMM_DENSE_TILE", 0), gm_once = env_int_dense("BIE_GEMM_DENSE_GM", 4);
     const bool tuning = getenv("BIE_TUNING") != nullptr;
@@ -434,20 +484,25 @@ static void dense_gemm_launch(const void* x, const void* img, const void* bias, 
     if (tile == 256 || (tile != 128 && t256 >= 192)) {
         const int tn = cdiv(N, 256);
         hipLaunchKernelGGL((mpq_dense_gemm_kernel<DT, 4, 4>), dim3((unsigned)t256), dim3(256), 0, st, (const uint16_t*)x, (const uint8_t*)img, (const uint16_t*)bias,
-                           (uint16_t*)y, M, N, K, tn, NB32, gm, ldy);
+                           (uint16_t*)y, M, N, K, tn, NB32, gm, ldy, (float*)nullptr, 0);
     } else {
         const int tn = cdiv(N, 128);
         hipLaunchKernelGGL((mpq_dense_gemm_kernel<DT, 2, 2>), dim3((unsigned)(cdiv(M, 128) * tn)), dim3(256), 0, st, (const uint16_t*)x, (const uint8_t*)img,
-                           (const uint16_t*)bias, (uint16_t*)y, M, N, K, tn, NB32, gm, ldy);
+                           (const uint16_t*)bias, (uint16_t*)y, M, N, K, tn, NB32, gm, ldy, (float*)nullptr, 0);
     }
 }
 
 // the GEMM alone on an image somebody else wrote (mbwq.hip: the mixed-bit layout's own dequantise pass)
 bool mpq_dense_shape_ok(int K, int N) { return (K & 31) == 0 && (N & 7) == 0; }
-int mpq_dense_gemm_only_launch(const void* x, const void* img, const void* bias, void* y, int M, int K, int N, int dtype, hipStream_t st, int ldy) {
-    if (dtype == BIE_F16) dense_gemm_launch<BIE_F16>(x, img, bias, y, M, K, N, ldy, st);
-    else dense_gemm_launch<BIE_BF16>(x, img, bias, y, M, K, N, ldy, st);
-    return check_launch("mpq_dense_gemm_kernel");
+// part: mpq_dense_part_bytes(M, K, N) bytes of fp32 scratch, or nullptr when that is 0 (or for a pitched y: one split, whatever the grid)
+int mpq_dense_gemm_only_launch(const void* x, const void* img, const void* bias, void* y, int M, int K, int N, int dtype, hipStream_t st, int ldy, float* part) {
+    if (part != nullptr && (ldy != N || mpq_dense_splits(M, K, N) <= 1)) part = nullptr;
+    if (dtype == BIE_F16) dense_gemm_launch<BIE_F16>(x, img, bias, y, M, K, N, ldy, st, part);
+    else dense_gemm_launch<BIE_BF16>(x, img, bias, y, M, K, N, ldy, st, part);
+    int rc = check_launch("mpq_dense_gemm_kernel");
+    if (rc || part == nullptr) return rc;
+    const int S = mpq_dense_splits(M, K, N), KTs = cdiv(K >> 5, S);
+    return launch_splitk_finalize(part, bias, y, cdiv(K >> 5, KTs), M, N, dtype, st);
 }
 
 // explicit, irregular g_idx: per-k groups (mpq_dequant_frag_gidx_kernel), then the same GEMM
@@ -465,7 +520,7 @@ int mpq_dense_gidx_launch(const void* x, const int32_t* qw, const void* scales, 
 #undef BIE_DQG3
     int rc = check_launch("mpq_dequant_frag_gidx_kernel");
     if (rc) return rc;
-    return mpq_dense_gemm_only_launch(x, scratch, bias, y, M, K, N, dtype, st, N);
+    return mpq_dense_gemm_only_launch(x, scratch, bias, y, M, K, N, dtype, st, N, nullptr);
 }
 
 // scratch: mpq_dense_workspace_bytes(K, N) bytes, 16-byte aligned

@@ -1725,8 +1725,9 @@ def test_sort_rows_and_gather_cols_are_exact(w_bit):
         want |= fields[:, i, :].astype(np.uint32) << np.uint32(i * w_bit)
     assert np.array_equal(qs.cpu().numpy().view(np.uint32), want)
     for tdt in (torch.float16, torch.float32):
-        x = torch.randn((5, K), generator=gen).to(tdt)
-        assert torch.equal(q_linear_cuda.gather_cols(x.to(DEV), perm).cpu(), x[:, torch.from_numpy(perm_np)])
+        for rows in (5, 16, 300, 2500):  # >= 16 rows of two-byte elements: the LDS-staged row form (gather_rows_kernel), 2500: rows per workgroup > 1
+            x = torch.randn((rows, K), generator=gen).to(tdt)
+            assert torch.equal(q_linear_cuda.gather_cols(x.to(DEV), perm).cpu(), x[:, torch.from_numpy(perm_np)])
     assert q_linear_cuda.act_order_sorted(qw.to(DEV), g_idx.to(DEV), w_bit, gs) is not None
 
 
