@@ -214,7 +214,12 @@ __global__ __launch_bounds__(256) void mpq_dense_gemm_kernel(const uint16_t* __r
             static_for<imin(m * RPM, NR), imin((m + 1) * RPM, NR)>([&](auto rc) { read_item(rc, ic_t<1>{}, so, QA, QB); });
         });
         wait_frags<0>(QA, QB);  // every LDS read of this stage has returned: its buffer may be refilled behind the barrier
+#if BIE_DENSE_LAB != 5 && BIE_DENSE_LAB != 6
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");  // K tile kt+1 landed (kt+2 still in flight)
+#endif
+#if BIE_DENSE_LAB == 4 || BIE_DENSE_LAB == 6      // timing experiments (wrong results): no barrier in the loop (4), no counted wait (5), neither (6)
+        if (kt & 1)
+#endif
         __builtin_amdgcn_s_barrier();
         static_for<0, NM>([&](auto mc) {
             constexpr int m = decltype(mc)::value, i = m / WN, j = m % WN;

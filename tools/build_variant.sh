@@ -8,7 +8,7 @@ name="$1"; file="$2"; flags="$3"
 base="$(basename "$file" .hip)"
 mkdir -p "$PKG/variants/$name"
 extra=""
-[ "$base" = "mpq_gemm" ] && extra="-fno-slp-vectorize"
+{ [ "$base" = "mpq_gemm" ] || [ "$base" = "mpq_prod" ]; } && extra="-fno-slp-vectorize"
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function $extra $flags -c "$PKG/csrc/$base.hip" -o "$PKG/variants/$name/$base.o"
 objs=$(ls "$PKG"/build/*.o | grep -v "/$base.o")
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$PKG/variants/$name/libbie_hip.so" "$PKG/variants/$name/$base.o" $objs
