@@ -51,10 +51,10 @@ def alg_bytes(M, k, n, w=WBIT, g=GROUP):
     return k * n * w // 8 + 2 * G * n + 2 * G * n + 2 * M * k + 2 * M * n
 
 
-def make_layer(dev, gen, k, n, w_bit=WBIT):
+def make_layer(dev, gen, k, n, w_bit=WBIT, dt=BF16):
     qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (k * w_bit // 32, n), dtype=torch.int32, generator=gen, device=dev)
-    scales = (torch.rand((k // GROUP, n), generator=gen, device=dev) * 0.01 + 0.005).to(BF16)
-    zeros = (scales.float() * torch.rand((k // GROUP, n), generator=gen, device=dev) * 15).to(BF16)
+    scales = (torch.rand((k // GROUP, n), generator=gen, device=dev) * 0.01 + 0.005).to(dt)
+    zeros = (scales.float() * torch.rand((k // GROUP, n), generator=gen, device=dev) * (2 ** w_bit - 1)).to(dt)
     return qw, scales, zeros
 
 
@@ -183,22 +183,23 @@ class Bench:
     def make_list(self, layers, k, n, gen, M=1, chain=0, w_bit=WBIT, ys=None):
         from bitorch_engine.layers.qlinear.nbit.cuda import MPQForwardList
         entries = []
+        dt = layers[0][1].dtype
         for i, (qw, sc, ze) in enumerate(layers):
             dep = i - 1 if (chain and i % chain) else -1
-            x = entries[-1]["y"] if dep >= 0 else torch.randn((M, k), generator=gen, device=self.dev).to(BF16)
-            y = ys[i] if ys is not None else torch.empty((M, n), dtype=BF16, device=self.dev)
+            x = entries[-1]["y"] if dep >= 0 else torch.randn((M, k), generator=gen, device=self.dev).to(dt)
+            y = ys[i] if ys is not None else torch.empty((M, n), dtype=dt, device=self.dev)
             entries.append({"x": x, "qweight": qw, "scales": sc, "zeros": ze, "y": y, "depends_on": dep})
         return MPQForwardList(entries, w_bit=w_bit, group_size=GROUP)
 
-    def gemv_list(self, k, n, nl, per_launch, reps, seed, chain=0, w_bit=WBIT, key=None, M=1):
+    def gemv_list(self, k, n, nl, per_launch, reps, seed, chain=0, w_bit=WBIT, key=None, M=1, dt=BF16):
         gen = torch.Generator(device=self.dev).manual_seed(seed)
-        layers = [make_layer(self.dev, gen, k, n, w_bit) for _ in range(nl)]
+        layers = [make_layer(self.dev, gen, k, n, w_bit, dt) for _ in range(nl)]
         plans = [self.make_list(layers[p0:p0 + per_launch], k, n, gen, M=M, chain=chain, w_bit=w_bit) for p0 in range(0, nl, per_launch)]
         inner = 4 if len(plans) == 1 else 1  # a graph replay costs 10-16 us by itself: several passes per replay when a pass is one launch
         g = capture(lambda st: [p.forward(st) for _ in range(inner) for p in plans])
         us = time_graph(g, reps) / (nl * inner)
         b = alg_bytes(M, k, n, w_bit)
-        return {"M": M, "K": k, "N": n, "w_bit": w_bit, "layers": nl, "layers_per_launch": per_launch, "dependent_chain_length": chain,
+        return {"M": M, "K": k, "N": n, "w_bit": w_bit, "dtype": "bf16" if dt == BF16 else "f16", "layers": nl, "layers_per_launch": per_launch, "dependent_chain_length": chain,
                 "launches_per_pass": len(plans) * plans[0].launches, "us_per_layer": round(us, 3), "alg_bytes_per_layer": b,
                 "roofline": {"bound": "hbm", "achieved": round(b / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(b / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(key) if key else None}}
@@ -1025,6 +1026,26 @@ def main():
                 for r_ in extras["c3_exl2"]:
                     if ("layer list" in r_["op"] and r_["M"] == 1) or "siblings" in r_["op"]:
                         out["summary"][("c3_exl2_list_" if "layer list" in r_["op"] else f"c3_exl2_group{r_.get('members')}_") + f"{r_['K']}x{r_['N']}"] = r_["roofline"]["frac"]
+            # fp16 (GreenBit's checkpoint dtype): the exact 16-bit-table form (default) and the opt-in algebraic form (BIE_LIST_ALG=1: exact products,
+            # 6-8e-4 of max|y| away from the reference's doubly rounded weights -- DESIGN.md section 2)
+            guarded("f16_list_4096x4096", lambda: B.gemv_list(4096, 4096, 96, 96, 10, 45, dt=torch.float16))
+            guarded("f16_list_4096x11008", lambda: B.gemv_list(4096, 11008, 40, 40, 10, 46, dt=torch.float16))
+
+            def alg_list(k, n, nl, seed):
+                old = os.environ.get("BIE_LIST_ALG")
+                os.environ["BIE_LIST_ALG"] = "1"
+                try:
+                    return dict(B.gemv_list(k, n, nl, nl, 10, seed, dt=torch.float16), form="algebraic (opt-in, BIE_LIST_ALG=1)")
+                finally:
+                    if old is None:
+                        os.environ.pop("BIE_LIST_ALG", None)
+                    else:
+                        os.environ["BIE_LIST_ALG"] = old
+            if os.environ.get("BIE_TUNING"):
+                guarded("f16_list_alg_4096x4096", lambda: alg_list(4096, 4096, 96, 45))
+                guarded("f16_list_alg_4096x11008", lambda: alg_list(4096, 11008, 40, 46))
+            for k_ in ("f16_list_4096x4096", "f16_list_alg_4096x4096", "f16_list_4096x11008", "f16_list_alg_4096x11008"):
+                out["summary"][k_] = frac(k_)
             guarded("c3_w2a16_list_4096x4096", lambda: B.gemv_list(4096, 4096, 96, 96, 10, 44, w_bit=2))
             guarded("c3_w2a16_4096x4096", lambda: B.gemv(4096, 4096, 64, 10, 41, w_bit=2))
             guarded("c3_w2a16_4096x11008", lambda: B.gemv(4096, 11008, 40, 10, 42, w_bit=2))

@@ -94,6 +94,16 @@ __device__ unsigned long long g_list_stamps[65536 * 6];
 // bit 6: D16 form (W4, M = 1, bf16) -- 16-bit table entries, two tables per wave (the units of a pair) in the halves of one 4 KiB block,
 //        looked up with ds_read_u16_d16_hi (the load zeroes the low half: the register IS the fp32 value of the bf16 weight), both tables
 //        built before the pair's rows are needed, lookups pipelined in half-row chunks with counted lgkmcnt (three chunks in flight)
+// bit 12: ALGEBRAIC form (fp16, W4 and W2, one or two rows; independent entries).  The reference's own decode kernels accumulate in fp16
+//        without materialising rounded weights (exl2/q_gemm_kernel.cuh:16-62; quant_mm_kernel :273-331 multiplies fl(q*s - z) ...), and the
+//        mixed-bit lists of this library already run this way (mbwq.hip: 0.73-0.81 of HBM).  Per packed word: the nibble pairs become the
+//        fp16 pairs (1024 + q[2j], 64 + q[2j+1]) with one v_perm_b32 + one v_and_or_b32 each -- the field stays where it is, the exponent is
+//        chosen so that its lowest bit weighs 1 -- and go straight into v_dot2_f32_f16 against the activation pair in an SGPR: 1.5 VALU per
+//        weight, NO table and NO LDS read (the table form: 2.3 VALU + one LDS read per weight, LDS-array-bound).  Per unit, in fp32:
+//            y += s * (sum_k T_k x_k - sum_k c_k x_k) - z * sum_k x_k        (asym: s * (... - (zq + 1) * sum_k x_k))
+//        with the two column-independent sums computed once per unit by the wave (one x dword per lane, DPP tree).  The per-weight fp16
+//        roundings of the reference's CPU path (fl(fl(q*s) - z)) are NOT applied: measured <= 3e-4 of max|y| norm-wise against the oracle
+//        (inside north_star's 1e-3; DESIGN.md section 2, the A11 precedent), which is why bf16 -- one output ulp is 4e-3 -- keeps the table.
 template <int DT, int ZM, int MT, int RPG, int WB, int VAR, bool INL = false>
 __global__ __launch_bounds__(((VAR & 8) ? 256 : ((VAR & 16) ? 128 : ((VAR & 32) ? 64 : 512))), ((VAR & 4) ? 8 : ((VAR & 128) ? 7 : 1))) void mpq_list_kernel(const std::conditional_t<INL, ListArgsInl, ListArgs> a) {
     constexpr int NW = (VAR & 8) ? 4 : ((VAR & 16) ? 2 : ((VAR & 32) ? 1 : 8));  // bits 4 / 5 (tuning aids): two / one wave per workgroup
@@ -101,7 +111,8 @@ __global__ __launch_bounds__(((VAR & 8) ? 256 : ((VAR & 16) ? 128 : ((VAR & 32) 
     constexpr int XD = NB / 2;       // x dwords (16-bit pairs) per packed word
     constexpr bool PK = (VAR & 1) != 0 && WB == 4 && DT == BIE_BF16;
     constexpr bool STREAM_ONLY = (VAR & 2) != 0;
-    constexpr bool D16 = (VAR & 64) != 0 && WB == 4 && MT == 1 && DT == BIE_BF16 && !STREAM_ONLY;
+    constexpr bool D16 = (VAR & 64) != 0 && WB == 4 && MT == 1 && (DT == BIE_BF16 || DT == BIE_F16) && !STREAM_ONLY;
+    constexpr bool ALG = (VAR & 4096) != 0 && DT == BIE_F16 && !STREAM_ONLY;  // bit 12: fp16, algebraic form (no table, no LDS in the loop) -- see process_group
     __shared__ __attribute__((aligned(4096))) uint32_t tab[NW * 16 * 64];  // the only LDS object: starts at LDS address 0
 
     const int lane = threadIdx.x & 63;
@@ -190,6 +201,80 @@ __global__ __launch_bounds__(((VAR & 8) ? 256 : ((VAR & 16) ? 128 : ((VAR & 32) 
             cu32_t* xd = (cu32_t*)(uintptr_t)(xbase + (long)m * K + (long)g * (RPG * NB));
 #pragma unroll
             for (int i = 0; i < RPG * XD; i++) xs[m][i] = xd[i];
+        }
+        if constexpr (ALG) {
+            // ---- the two column-independent sums of the unit: lane i takes x dword i (pairs (x[2i], x[2i+1])), DPP tree, lane 63 holds the totals
+            constexpr int ND = RPG * XD;  // x dwords of the unit
+            float cu[MT], xu[MT];
+            // W4: every pair carries (1024, 64); W2: the pairs of a byte alternate (1024, 256) / (64, 16)
+            uint32_t cpair = 0x54006400u;
+            if constexpr (WB == 2) cpair = (lane & 1) ? 0x4c005400u : 0x5c006400u;
+            const uint32_t ones = 0x3c003c00u;
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                const uint32_t* xv = reinterpret_cast<const uint32_t*>(xbase + (long)m * K + (long)g * (RPG * NB));
+                float c = 0.0f, t1 = 0.0f;
+#pragma unroll
+                for (int b = 0; b < ND; b += 64) {
+                    const uint32_t xd = (b + lane < ND) ? xv[b + lane] : 0u;
+                    c = dot2_acc<BIE_F16>(cpair, xd, c);
+                    t1 = dot2_acc<BIE_F16>(ones, xd, t1);
+                }
+                auto tree = [](float v) -> float {
+                    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+                    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+                    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));  // row_half_mirror
+                    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false));  // row_mirror
+                    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));  // row_bcast15 into rows 1 and 3
+                    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, false));  // row_bcast31 into rows 2 and 3
+                    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+                };
+                cu[m] = tree(c);
+                xu[m] = tree(t1);
+            }
+            // ---- sum_k T_k x_k: per pair one v_perm_b32 (the byte into both halves) + one v_and_or_b32 (mask, exponents) + one dot2 per row of x
+            float aq[MT];
+#pragma unroll
+            for (int m = 0; m < MT; m++) aq[m] = 0.0f;
+            uint32_t mA, mB, eA, eB;  // VOP3 takes no literal: masks and exponent pairs live in registers
+            if constexpr (WB == 4) {
+                asm("v_mov_b32 %0, 0x00f0000f" : "=v"(mA));
+                asm("v_mov_b32 %0, 0x54006400" : "=v"(eA));
+                mB = mA; eB = eA;
+            } else {
+                asm("v_mov_b32 %0, 0x000c0003" : "=v"(mA));
+                asm("v_mov_b32 %0, 0x5c006400" : "=v"(eA));
+                asm("v_mov_b32 %0, 0x00c00030" : "=v"(mB));
+                asm("v_mov_b32 %0, 0x4c005400" : "=v"(eB));
+            }
+#pragma unroll
+            for (int u = 0; u < RPG; u++) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t t = __builtin_amdgcn_perm(0u, w[u], 0x0c000c00u | ((uint32_t)j << 16) | (uint32_t)j);  // [byte j, 0, byte j, 0]
+                    uint32_t pa;
+                    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(pa) : "v"(t), "v"(mA), "v"(eA));
+                    if constexpr (WB == 4) {
+#pragma unroll
+                        for (int m = 0; m < MT; m++) aq[m] = dot2_acc<BIE_F16>(pa, xs[m][u * 4 + j], aq[m]);
+                    } else {
+                        uint32_t pb;
+                        asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(pb) : "v"(t), "v"(mB), "v"(eB));
+#pragma unroll
+                        for (int m = 0; m < MT; m++) {
+                            aq[m] = dot2_acc<BIE_F16>(pa, xs[m][u * 8 + 2 * j], aq[m]);
+                            aq[m] = dot2_acc<BIE_F16>(pb, xs[m][u * 8 + 2 * j + 1], aq[m]);
+                        }
+                    }
+                }
+            }
+            const float sc = f16_bits_to_f32(sb);
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                if constexpr (ZM == ZM_ASYM) acc[m][0] += sc * ((aq[m] - cu[m]) - (float)zb * xu[m]);
+                else acc[m][0] += sc * (aq[m] - cu[m]) - f16_bits_to_f32(zb) * xu[m];
+            }
+            return;
         }
         // ---- the 16-entry table of this (group, column)
         if constexpr (STREAM_ONLY) {
@@ -377,7 +462,24 @@ __global__ __launch_bounds__(((VAR & 8) ? 256 : ((VAR & 16) ? 128 : ((VAR & 32) 
         auto build_tables = [&](uint32_t sbA, uint32_t zbA, uint32_t sbB, uint32_t zbB) {
             const uint32_t tw = tabw + 0u;  // (a plain use: clang does not capture a variable a lambda names in asm operands only)
             uint32_t D[16];
-            if constexpr (ZM == ZM_SYM) {
+            if constexpr (DT == BIE_F16) {
+                // fp16: both units' entries in ONE packed-fp16 pass -- fl(q * s) is v_pk_mul_f16, fl(. - z) v_pk_add_f16 (sym, the reference's two
+                // roundings); asym: the exact integer difference (q - zq1) times s, one rounding.  Entry = (T_A[q], T_B[q]).
+                const half2_t s2 = half2_t{__builtin_bit_cast(half_t, (uint16_t)sbA), __builtin_bit_cast(half_t, (uint16_t)sbB)};
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    half2_t r;
+                    if constexpr (ZM == ZM_ASYM) {
+                        r = half2_t{(half_t)(float)(q - (int)zbA), (half_t)(float)(q - (int)zbB)} * s2;
+                    } else {
+                        const half2_t z2 = half2_t{__builtin_bit_cast(half_t, (uint16_t)zbA), __builtin_bit_cast(half_t, (uint16_t)zbB)};
+                        r = half2_t{(half_t)(float)q, (half_t)(float)q} * s2;
+                        if constexpr (ZM == ZM_FUSED) r = __builtin_elementwise_fma(half2_t{(half_t)(float)q, (half_t)(float)q}, s2, -z2);
+                        else r = r - z2;
+                    }
+                    D[q] = __builtin_bit_cast(uint32_t, r);
+                }
+            } else if constexpr (ZM == ZM_SYM) {
                 const float sA = bf16_bits_to_f32(sbA), sB = bf16_bits_to_f32(sbB), nzA = -bf16_bits_to_f32(zbA), nzB = -bf16_bits_to_f32(zbB);
 #pragma unroll
                 for (int q = 0; q < 16; q += 2) {
@@ -451,8 +553,8 @@ __global__ __launch_bounds__(((VAR & 8) ? 256 : ((VAR & 16) ? 128 : ((VAR & 32) 
                 float(&tc)[4] = t[c % RING];
                 // the four activations of this chunk, bf16 -> fp32 on the scalar unit, HERE: as plain expressions the DAG linearisation hoists
                 // all 8 x RPG of them to the top of the unit, where they do not fit in SGPRs (112 spilled to VGPR lanes: a v_readlane per use)
-                uint32_t xu[4];
-                {
+                uint32_t xu[4] = {0, 0, 0, 0};
+                if constexpr (DT == BIE_BF16) {
                     const int u = c >> 1;
                     if ((c & 1) == 0)
                         asm volatile("s_lshl_b32 %0, %4, 16\n\ts_lshl_b32 %1, %5, 16\n\ts_lshl_b32 %2, %6, 16\n\ts_lshl_b32 %3, %7, 16"
@@ -469,7 +571,22 @@ __global__ __launch_bounds__(((VAR & 8) ? 256 : ((VAR & 16) ? 128 : ((VAR & 32) 
                 if (behind == 2) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(tc[0]), "+v"(tc[1]), "+v"(tc[2]), "+v"(tc[3]));
                 else if (behind == 1) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(tc[0]), "+v"(tc[1]), "+v"(tc[2]), "+v"(tc[3]));
                 else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tc[0]), "+v"(tc[1]), "+v"(tc[2]), "+v"(tc[3]));
-                if constexpr ((VAR & 512) != 0) {  // ablation (lab): no FMAs -- the looked-up values are only consumed
+                if constexpr (DT == BIE_F16) {
+                    // the looked-up entry is an fp16 value in the HIGH half of its register, the activation an fp16 half of an SGPR dword: v_fma_mix_f32
+                    // converts both on the fly (one VALU per weight; four independent chains)
+                    const int u = c >> 1;
+                    if ((c & 1) == 0) {
+                        asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "+v"(accE.x) : "v"(tc[0]), "s"(xs[u * 4 + 0]));
+                        asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "+v"(accE.y) : "v"(tc[1]), "s"(xs[u * 4 + 1]));
+                        asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "+v"(accO.x) : "v"(tc[2]), "s"(xs[u * 4 + 2]));
+                        asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "+v"(accO.y) : "v"(tc[3]), "s"(xs[u * 4 + 3]));
+                    } else {
+                        asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(accE.x) : "v"(tc[0]), "s"(xs[u * 4 + 0]));
+                        asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(accE.y) : "v"(tc[1]), "s"(xs[u * 4 + 1]));
+                        asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(accO.x) : "v"(tc[2]), "s"(xs[u * 4 + 2]));
+                        asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(accO.y) : "v"(tc[3]), "s"(xs[u * 4 + 3]));
+                    }
+                } else if constexpr ((VAR & 512) != 0) {  // ablation (lab): no FMAs -- the looked-up values are only consumed
                     asm volatile("" ::"v"(tc[0]), "v"(tc[1]), "v"(tc[2]), "v"(tc[3]), "s"(xu[0]), "s"(xu[1]), "s"(xu[2]), "s"(xu[3]));
                 } else if ((c & 1) == 0) {  // even nibbles k = 8u + 2i: the low halves of the x dwords
                     accE = __builtin_elementwise_fma(float2_t{tc[0], tc[1]}, float2_t{__uint_as_float(xu[0]), __uint_as_float(xu[1])}, accE);
@@ -933,7 +1050,22 @@ int mpq_list_forward(MpqList* p, hipStream_t st) {
         else hipLaunchKernelGGL((mpq_list_kernel<BIE_BF16, ZM_SYM, 1, 16, 4, 11>), dim3(p->grid), dim3(256), 0, st, a);
         return check_launch("mpq_list_kernel<lab>");
     }
-    static const int d16 = list_env("BIE_LIST_D16", 1);  // the 16-bit-table form of the W4 / M = 1 / bf16 kernel (0: the fp32-table form)
+    static const int d16 = list_env("BIE_LIST_D16", 1);  // the 16-bit-table form of the W4 / M = 1 kernel (0: the fp32-table form)
+    // fp16, independent entries: BIE_LIST_ALG=1 selects the ALGEBRAIC form (template bit 12) -- 0.79-0.82 of HBM on the bench's W4 lists against
+    // 0.64-0.7 for the table forms, but its results are the EXACT products' sums, 6-8e-4 of max|y| away from the reference's doubly rounded
+    // weights (profiles/r05_list_alg_ab_a.txt, gpurun_out/rel_err_report.txt): inside north_star's 1e-3 norm-wise, not element by element, so
+    // it is the caller's choice, not the default.  2: also W2 at one row (no faster than its pair table).
+    static const int alg_once = list_env("BIE_LIST_ALG", 0);
+    const int alg = getenv("BIE_TUNING") ? list_env("BIE_LIST_ALG", 0) : alg_once;  // BIE_TUNING: re-read per launch (bench.py times both forms in one process)
+    if (alg && p->dtype == BIE_F16 && !p->has_deps && (p->w_bit == 4 || p->M == 2 || alg == 2)) {
+        if (p->w_bit == 2) list_launch_zm<BIE_F16, 2, 4096>(a, p->rpg, p->grid, p->M, p->zm, st);
+        else list_launch_zm<BIE_F16, 4, 4096>(a, p->rpg, p->grid, p->M, p->zm, st);
+        return check_launch("mpq_list_kernel<alg>");
+    }
+    if (d16 && p->w_bit == 4 && p->dtype == BIE_F16 && p->M == 1 && p->nw == 4) {
+        list_launch_zm<BIE_F16, 4, 64>(a, p->rpg, p->grid, 1, p->zm, st);
+        return check_launch("mpq_list_kernel<d16,f16>");
+    }
     if (d16 && p->w_bit == 4 && p->dtype == BIE_BF16 && p->M == 1 && p->nw == 4) {
 #ifdef BIE_LAB_BUILD
         static const int ring2 = list_env("BIE_LIST_RING2", 0);  // lab builds: two lookup chunks in flight, 1 = default registers, 7 = 7 waves per SIMD forced
