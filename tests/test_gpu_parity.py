@@ -2275,6 +2275,40 @@ def test_the_list_instances_bench_py_times_against_the_oracle(K, N, nl, w_bit, t
             assert_close_elementwise_f16(y_all[i:i + 1], ref, f"f16 list {nl} x {K}x{N} w{w_bit}, layer {i}")
 
 
+@pytest.mark.parametrize("w_bit,asym,M,gs", [(4, 0, 1, 128), (4, 1, 1, 64), (2, 0, 2, 128), (2, 1, 1, 64), (4, 0, 1, 32), (2, 0, 1, 256)])
+def test_list_forward_algebraic_form_fp16_opt_in(w_bit, asym, M, gs, monkeypatch):
+    """The opt-in ALGEBRAIC list form (BIE_LIST_ALG, mpq_list.hip template bit 12; =2 to cover W2 at one row too): fp16, sum_k (c_k + q_k) x_k on
+    v_dot2_f32_f16, the group's scale / zero applied once per unit in fp32 -- no per-weight fp16 rounding.  Against the oracle (the
+    reference's doubly rounded weights) norm-wise, north_star's 1e-3; against the EXACT real-number product it must be tighter than the
+    reference's own arithmetic is (that is the point of the form, and what keeps a wiring mistake from hiding inside the tolerance)."""
+    from bitorch_engine.layers.qlinear.nbit.cuda import MPQForwardList
+    monkeypatch.setenv("BIE_TUNING", "1")
+    monkeypatch.setenv("BIE_LIST_ALG", "2")
+    specs = [(1024, 200, True), (512, 520, False), (2048, 64, True), (768, 136, False), (4096, 1000, False)]
+    if asym:
+        specs = [(K, (N + 15) // 16 * 16, b) for (K, N, b) in specs]
+    entries, host = _list_case(specs, orc.F16, w_bit, gs, asym, M, seed=5000 + w_bit + gs + M)
+    plan = MPQForwardList(entries, w_bit=w_bit, group_size=gs, asym=bool(asym))
+    plan()
+    torch.cuda.synchronize()
+    for i, (e, (x, qw, scales, zeros, bias)) in enumerate(zip(entries, host)):
+        ref = oracle_forward(x, qw, scales, zeros, None, w_bit, gs, asym, orc.F16, bias)
+        assert_close(e["y"], ref, orc.F16, f"algebraic list entry {i} {specs[i]} w{w_bit} g{gs} asym={asym} M={M}")
+        # the exact product in float64: s * (q - zq1) or s * q - z with the fp16 constants taken as real numbers
+        K, N = qw.shape[0] * 32 // w_bit, qw.shape[1]
+        fields = ((qw.numpy().view(np.uint32)[:, None, :] >> (np.arange(32 // w_bit, dtype=np.uint32) * w_bit)[None, :, None]) & np.uint32(2 ** w_bit - 1)).reshape(K, N).astype(np.float64)
+        sc = np.repeat(scales.double().numpy(), gs, axis=0)[:K]
+        if asym:
+            zq = ((zeros.numpy().view(np.uint32)[:, :, None] >> (np.arange(32 // w_bit, dtype=np.uint32) * w_bit)[None, None, :]) & np.uint32(2 ** w_bit - 1)).reshape(zeros.shape[0], -1)[:, :N]
+            W = sc * (fields - (np.repeat(zq.astype(np.float64), gs, axis=0)[:K] + 1.0))
+        else:
+            W = sc * fields - np.repeat(zeros.double().numpy(), gs, axis=0)[:K]
+        exact = x.double().numpy() @ W + (0 if bias is None else bias.double().numpy())
+        got = e["y"].double().cpu().numpy()
+        err = np.abs(got - exact).max() / np.abs(exact).max()
+        assert err <= 2.0 ** -10, f"algebraic form vs the exact product: {err:.3e} of max|y| (one output ulp is 4.9e-4 at most)"
+
+
 @pytest.mark.parametrize("asym", [0, 1])
 def test_lone_decode_launches_of_100_mb_and_more_take_the_inline_list_form(asym):
     """bie_mpq_forward / bie_mpq_forward_grouped at M = 1, W4, bf16 with >= 96 MB of packed weights per launch run the list kernel's D16
