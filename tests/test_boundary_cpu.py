@@ -211,3 +211,30 @@ def test_list_plan_validation_without_a_device():
     assert L.bie_mpq_list_create(ctypes.byref(h), 2, ok, 1, 4, 128, 0, 1, 256, 16) == -3  # device buffer too small
     assert L.bie_mpq_list_forward(None, None) == -1
     assert L.bie_device_status(0) == 0  # no status page without a GPU: reads as clear
+
+
+def test_the_512_register_gemm_kernels_do_not_spill():
+    """The 256 x 256 dense GEMM instances run one wave per SIMD on all 512 registers (256 accumulators): a change that costs them a few
+    more is compiled WITH scratch -- still correct, 5-10 % slower, and silent (round 5 hit it three times while editing the epilogue).
+    hipcc's own resource report (-Rpass-analysis=kernel-resource-usage; cross-compiles without a GPU) must say ScratchSize 0 for every
+    mpq_dense_gemm_kernel instance."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not found")
+    src = os.path.join(ROOT, "bitorch-engine_amd", "csrc", "mpq_dense.hip")
+    p = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Rpass-analysis=kernel-resource-usage",
+                        "--cuda-device-only", "-c", src, "-o", os.devnull], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    name, seen = None, {}
+    for line in p.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m and name and "mpq_dense_gemm_kernel" in name:
+            seen[name] = int(m.group(1))
+    assert len(seen) >= 4, f"resource report not parsed: {list(seen)}"
+    assert all(v == 0 for v in seen.values()), f"a dense GEMM instance spills: {seen}"

@@ -2309,6 +2309,52 @@ def test_list_forward_algebraic_form_fp16_opt_in(w_bit, asym, M, gs, monkeypatch
         assert err <= 2.0 ** -10, f"algebraic form vs the exact product: {err:.3e} of max|y| (one output ulp is 4.9e-4 at most)"
 
 
+def _same_nonfinite_and_close(y, ref, dt, what):
+    """NaN where the oracle has NaN, the same infinity where it has one, assert_close on the rest."""
+    yf, rf = to_f32(y), to_f32(ref)
+    assert np.array_equal(np.isnan(yf), np.isnan(rf)), f"{what}: NaN pattern differs ({int(np.isnan(yf).sum())} vs {int(np.isnan(rf).sum())} NaNs)"
+    inf = np.isinf(rf)
+    assert np.array_equal(np.isinf(yf), inf) and np.array_equal(yf[inf], rf[inf]), f"{what}: infinities differ"
+    fin = np.isfinite(rf)
+    if fin.any():
+        assert_close(torch.from_numpy(np.where(fin, yf, 0.0)), torch.from_numpy(np.where(fin, rf, 0.0)), dt, what)
+
+
+@pytest.mark.parametrize("dt", [orc.BF16, orc.F16])
+@pytest.mark.parametrize("M,path", [(1, "lone"), (1, "list"), (2, "list"), (8, "lone"), (8, "list"), (40, "lone"), (1100, "lone")])
+def test_special_values_propagate_like_the_oracle(dt, M, path):
+    """NaN / Inf activations, a zero scale, an infinite scale, denormal zeros and all-zero weights through the
+    table-lookup decode kernels (lone launch and list form), the lookup / matrix-pipe kernel (M = 8), the fused MFMA GEMM (M = 40)
+    and the dequantise-once dense form (M = 1100).  The tables are built from s and z with the reference's expressions, so an
+    infinite scale gives NaN for q = 0 (0 * inf) and infinities elsewhere -- exactly as orc_mpq_dequant does; a NaN in x poisons its
+    row, an infinity gives inf or (inf - inf) NaN.  Non-finite outputs must MATCH the oracle's class, finite ones its value."""
+    from bitorch_engine.layers.qlinear.nbit.cuda import MPQForwardList
+    K, N, gs = 1024, 256, 128
+    rng = np.random.default_rng(900 + M)
+    qw, scales, zeros, gen = rand_case(rng, K, N, 4, gs, dt, 0)
+    tdt = TDT[dt]
+    scales, zeros = scales.clone(), zeros.clone()
+    scales[1, 5] = 0.0                                   # a zero scale: the column's group contributes -z only
+    scales[2, 9] = float("inf")                          # an infinite scale: NaN (q = 0) / inf weights in that group and column
+    zeros[3, 17] = torch.tensor(2.0 ** -133 if dt == orc.BF16 else 2.0 ** -24).to(tdt)   # denormal in the storage type
+    zeros[0, 33] = 0.0
+    qw[:, 64:96] = 0                                     # all-zero packed weights in 32 columns
+    x = torch.randn((M, K), generator=gen).to(tdt)
+    x[0, 3] = float("nan") if M > 1 else x[0, 3]         # row 0 poisoned (only with more than one row: M = 1 keeps finite outputs to compare)
+    x[M - 1, 700] = float("inf")                         # an infinity in the last row (group 5)
+    ref = oracle_forward(x, qw, scales, zeros, None, 4, gs, 0, dt)
+    if path == "lone":
+        y = hip_forward(x, qw, scales, zeros, None, 4, gs, 0)
+    else:
+        d = lambda t: t.to(DEV)
+        ent = [{"x": d(x), "qweight": d(qw), "scales": d(scales), "zeros": d(zeros), "y": torch.zeros((M, N), dtype=tdt, device=DEV), "depends_on": -1}]
+        MPQForwardList(ent, w_bit=4, group_size=gs, asym=False)()
+        torch.cuda.synchronize()
+        y = ent[0]["y"]
+    _same_nonfinite_and_close(y, ref, dt, f"special values M={M} {path}")
+    assert np.isinf(to_f32(ref)).any() or np.isnan(to_f32(ref)).any()   # the case really exercises non-finite outputs
+
+
 @pytest.mark.parametrize("asym", [0, 1])
 def test_lone_decode_launches_of_100_mb_and_more_take_the_inline_list_form(asym):
     """bie_mpq_forward / bie_mpq_forward_grouped at M = 1, W4, bf16 with >= 96 MB of packed weights per launch run the list kernel's D16
