@@ -129,21 +129,21 @@ def pmc_traffic(shape):
         return None
 
 
-def pmc_gemm():
-    """MFMA-pipe utilisation of the GEMM kernel from this round's counters (tools/gpu_pmc_gemm_r03.sh -> profiles/r03_pmc_gemm.json:
-    SQ_VALU_MFMA_BUSY_CYCLES per SIMD / GRBM_GUI_ACTIVE per XCD, M = 4096, 4096 -> 11008, bf16).  None when absent or collected on
-    another mpq_gemm.hip."""
+def pmc_gemm(shape="M4096_K4096_N4096"):
+    """Counters of the dense GEMM kernel at the TIMED shape (tools/gpu_pmc_gemm_r05.sh -> profiles/r05_pmc_gemm.json: MFMA-pipe utilisation =
+    SQ_VALU_MFMA_BUSY_CYCLES per SIMD / GRBM_GUI_ACTIVE per XCD; FETCH_SIZE / WRITE_SIZE from their own passes).  None when absent or collected
+    on other sources of mpq_dense.hip."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_gemm.json")))
-        dense = "mpq_dense_gemm_kernel" in (d.get("bf16", {}).get("kernel") or "")  # the sources of the kernel the counters belong to
+        d = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_gemm.json")))
         h = hashlib.sha256()
-        for f in (("mpq_dense.hip", "mfma_pipe.cuh", "mpq_frag_dequant.cuh") if dense else ("mpq_gemm.hip", "mpq_frag_dequant.cuh")):
+        for f in ("mpq_dense.hip", "mfma_pipe.cuh", "mpq_frag_dequant.cuh"):
             h.update(open(os.path.join(ROOT, "bitorch-engine_amd", "csrc", f), "rb").read())
         if d.get("gemm_source_sha") != h.hexdigest()[:16]:
             return None
-        b = d["bf16"]
-        return {"shape": d["shape"], "kernel": b.get("kernel"), "mfma_pipe_utilisation": b["mfma_pipe_utilisation"], "valu_per_mfma": b["instructions"]["valu_per_mfma"],
-                "fetch_bytes": b["fetch_bytes_corrected"], "write_bytes": b["write_bytes"], "algorithmic_bytes": b["algorithmic_bytes"]}
+        b = d["shapes"][shape]
+        return {"shape": shape, "kernel": b["kernel"], "mfma_pipe_utilisation": b["mfma_pipe_utilisation"], "effective_clock_ghz": b["effective_clock_ghz"],
+                "fetch_bytes": b["fetch_bytes_corrected"], "write_bytes": b["write_bytes"], "operand_bytes": b["operand_bytes"],
+                "fetch_over_operands": b["fetch_over_operands"], "fetch_over_tiling_floor": b["fetch_over_tiling_floor"]}
     except Exception:
         return None
 
@@ -974,7 +974,7 @@ def main():
                                         us_per_launch=extras["gemm"]["us_per_launch"], M=4096, K=4096, N=4096)
             pg = pmc_gemm()
             if pg:
-                out["roofline_gemm"]["pmc"] = {k: pg[k] for k in ("mfma_pipe_utilisation", "fetch_bytes", "algorithmic_bytes") if k in pg}
+                out["roofline_gemm"]["pmc"] = pg  # the counters of THIS shape (4096^3): fetch = 3.0 x the operands = 1.00 x what 8 private L2s must fetch with 256^2 tiles
         guarded("per_layer_launches_4096x4096", lambda: B.gemv(4096, 4096, 96, 10, 1))
         guarded("chain8_4096x4096_launches", lambda: B.chain_launches(4096, 96, 8, 10, 5))
         guarded("c2_gemv_4096x11008", lambda: B.gemv(4096, 11008, 40, 10, 11))
