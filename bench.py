@@ -104,7 +104,7 @@ def time_graph(g, reps):
     return e0.elapsed_time(e1) * 1e3 / reps
 
 
-PMC_FILE = "r04_pmc_gemv.json"
+PMC_FILE = "r05_pmc_gemv.json"
 
 
 def kernel_source_sha():

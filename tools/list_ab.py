@@ -22,16 +22,18 @@ def list_case(k, n, nl, per_launch, chain=0, reps=20, seed=1):
     """nl distinct layers, `per_launch` entries per list launch (nl % per_launch == 0); chain > 0: entries form dependent chains of
     that length (needs k == n)."""
     gen = torch.Generator(device=dev).manual_seed(seed)
-    layers = [make_layer(dev, gen, k, n) for _ in range(nl)]
+    wb = int(os.environ.get("LIST_AB_WBIT", "4"))                       # PMC passes of other instances: W2, fp16
+    tdt = torch.float16 if os.environ.get("LIST_AB_DT") == "f16" else BF16
+    layers = [make_layer(dev, gen, k, n, wb, tdt) for _ in range(nl)]
     plans = []
     for p0 in range(0, nl, per_launch):
         entries = []
         for i in range(per_launch):
             qw, sc, ze = layers[p0 + i]
             dep = i - 1 if (chain and i % chain) else -1
-            x = entries[-1]["y"] if dep >= 0 else torch.randn((1, k), generator=gen, device=dev).to(BF16)
-            entries.append({"x": x, "qweight": qw, "scales": sc, "zeros": ze, "y": torch.empty((1, n), dtype=BF16, device=dev), "depends_on": dep})
-        plans.append(MPQForwardList(entries, w_bit=4, group_size=GROUP))
+            x = entries[-1]["y"] if dep >= 0 else torch.randn((1, k), generator=gen, device=dev).to(tdt)
+            entries.append({"x": x, "qweight": qw, "scales": sc, "zeros": ze, "y": torch.empty((1, n), dtype=tdt, device=dev), "depends_on": dep})
+        plans.append(MPQForwardList(entries, w_bit=wb, group_size=GROUP))
     if os.environ.get("LIST_AB_NOGRAPH"):  # PMC passes: every launch a dispatch row of its own
         for _ in range(3):
             for p in plans:
