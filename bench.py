@@ -714,7 +714,13 @@ def cpu_baselines(check_layers=(), check_x=(), check_y=(), budget_s=24.0):
         omp = ctypes.CDLL("libgomp.so.1")
     except OSError:
         omp = None
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)  # cores this process may run on
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)  # cores this process may run on ...
+    try:  # ... capped by the container's CPU quota (cgroup v2 cpu.max "<quota> <period>"): the GPU boxes show 256 logical CPUs and grant 16 --
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]  # 256 OpenMP threads on 16 cores' worth of time measured 0.7 GB/s against 12 at 32 threads
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
     res = []
     t_start = time.perf_counter()
 
@@ -1076,6 +1082,7 @@ def main():
             best = dict(max(head, key=lambda b: b["value"]))  # the headline shape at its best thread count ...
             best["threads_used"] = best["cores"]
             best["nproc"] = os.cpu_count()
+            best["cores_granted"] = max(b["cores"] for b in head)  # min(affinity, cgroup CPU quota): "all host cores" as far as this container gets them
             best["by_threads"] = {str(b["cores"]): b["value"] for b in head}  # ... with all cores, 32, 8 and one thread beside it
             out["cpu_baseline"] = best
             out["verified_vs_oracle"] = next((b["verified"] for b in bl if b["workload"] == "oracle_check_of_timed_launch"), None)
