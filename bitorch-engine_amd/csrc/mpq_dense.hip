@@ -337,7 +337,11 @@ __global__ __launch_bounds__(256) void mpq_dense_gemm_kernel(const uint16_t* __r
                     const int m = (tile_m * AF + wy * WM + i) * 32 + r;
                     const int n = (tile_n * BF + wx * WN) * 32 + 8 * rch;
                     asm volatile("" : "+v"(w[t]));
+#if BIE_DENSE_LAB == 7   // lab: streaming (non-temporal) stores -- y drains to HBM while the epilogue issues instead of at the kernel-end write-back
+                    if (m < M && n < N) __builtin_nontemporal_store(w[t], reinterpret_cast<uint4_t*>(y + (long)m * ldy + n));
+#else
                     if (m < M && n < N) *reinterpret_cast<uint4_t*>(y + (long)m * ldy + n) = w[t];
+#endif
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }

@@ -511,7 +511,7 @@ __global__ __launch_bounds__(((VAR & 8) ? 256 : ((VAR & 16) ? 128 : ((VAR & 32) 
             for (int q = 0; q < 16; q += 2)
                 asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(tw), "v"(D[q]), "v"(D[q + 1]), "n"(q), "n"(q + 1));
         };
-        float2_t accE = {0.0f, 0.0f}, accO = {0.0f, 0.0f};
+        float2_t accE = {0.0f, 0.0f}, accO = {0.0f, 0.0f}, accE2 = {0.0f, 0.0f}, accO2 = {0.0f, 0.0f};
         auto process_unit = [&](auto half_c, const uint32_t (&w)[RPG], int g) {
             constexpr int HALF = decltype(half_c)::value;
             const uint32_t mask = m0f + 0u, wpat = wavepat + 0u, la = lane_addr + 0u;  // plain uses (see build_table)
@@ -591,13 +591,14 @@ __global__ __launch_bounds__(((VAR & 8) ? 256 : ((VAR & 16) ? 128 : ((VAR & 32) 
                 } else if constexpr ((VAR & 512) != 0) {  // ablation (lab): no FMAs -- the looked-up values are only consumed
                     asm volatile("" ::"v"(tc[0]), "v"(tc[1]), "v"(tc[2]), "v"(tc[3]), "s"(xu[0]), "s"(xu[1]), "s"(xu[2]), "s"(xu[3]));
                 } else if ((c & 1) == 0) {  // even nibbles k = 8u + 2i: the low halves of the x dwords
+                    // four chains (E, E2, O, O2): two v_pk_fma_f32 on ONE accumulator back to back cost a wait state each (the hazard recogniser's s_nop)
                     accE = __builtin_elementwise_fma(float2_t{tc[0], tc[1]}, float2_t{__uint_as_float(xu[0]), __uint_as_float(xu[1])}, accE);
-                    accE = __builtin_elementwise_fma(float2_t{tc[2], tc[3]}, float2_t{__uint_as_float(xu[2]), __uint_as_float(xu[3])}, accE);
-                    asm volatile("" : "+v"(accE));
+                    accE2 = __builtin_elementwise_fma(float2_t{tc[2], tc[3]}, float2_t{__uint_as_float(xu[2]), __uint_as_float(xu[3])}, accE2);
+                    asm volatile("" : "+v"(accE), "+v"(accE2));
                 } else {
                     accO = __builtin_elementwise_fma(float2_t{tc[0], tc[1]}, float2_t{__uint_as_float(xu[0]), __uint_as_float(xu[1])}, accO);
-                    accO = __builtin_elementwise_fma(float2_t{tc[2], tc[3]}, float2_t{__uint_as_float(xu[2]), __uint_as_float(xu[3])}, accO);
-                    asm volatile("" : "+v"(accO));
+                    accO2 = __builtin_elementwise_fma(float2_t{tc[2], tc[3]}, float2_t{__uint_as_float(xu[2]), __uint_as_float(xu[3])}, accO2);
+                    asm volatile("" : "+v"(accO), "+v"(accO2));
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -618,8 +619,8 @@ __global__ __launch_bounds__(((VAR & 8) ? 256 : ((VAR & 16) ? 128 : ((VAR & 32) 
             if (g + 5 < g1) load_params(g + 5, sD, zD);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every table access of this wave is done before the table block is reused below
-        acc[0][0] = accE.x + accO.x;
-        acc[0][1] = accE.y + accO.y;
+        acc[0][0] = (accE.x + accE2.x) + (accO.x + accO2.x);
+        acc[0][1] = (accE.y + accE2.y) + (accO.y + accO2.y);
     } else {
         for (int g = g0; g < g1; g += 2) {
             process_group(wa, g, sa, za);
