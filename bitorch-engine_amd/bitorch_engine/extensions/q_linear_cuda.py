@@ -245,12 +245,14 @@ def mbwq_exl2_stream_copy(qweight, rows):
     """A COPY of a re-arranged exl2 tensor in the checkpoint's own form (the LSB-first chunk streams the reference stores and, its
     shuffle being a no-op, also saves after prepare_params): bie_mbwq_exl2_unshuffle on a clone.  What MBWQLinearCuda's state_dict
     hook writes, so that a saved checkpoint is the reference's format and `load -> prepare_params` re-arranges exactly once."""
-    t = (qweight.data if hasattr(qweight, "data") else qweight).detach().clone()
+    src = (qweight.data if hasattr(qweight, "data") else qweight).detach()
+    home = src.device
+    t = src.clone() if src.is_cuda else src.to("cuda")  # a prepared layer moved to the CPU for saving: the copy makes the trip (a kernel, as the shuffle was)
     _hip.need_gpu(t)
     keep, rp = _rows_arg(rows)
     rc = _hip.lib().bie_mbwq_exl2_unshuffle(_hip.ptr(t), rp, int(rows[5]), t.shape[1], _hip.stream())
     _hip.check(rc, "bie_mbwq_exl2_unshuffle")
-    return t
+    return t if home == t.device else t.to(home)
 
 
 def mbwq_q42fp_weight(qweight, scales, zeros, group_size, bits, q_perm):

@@ -537,8 +537,10 @@ def test_exl2_state_dict_is_the_reference_format_and_a_reloaded_tensor_is_prepar
         layer(x)
     layer.prepare_params()
     assert torch.equal(layer(x), y0)
-    # (4) device moves carry the prepared state
+    # (4) device moves carry the prepared state; a prepared layer moved to the CPU still saves the checkpoint's format
     layer.cpu()
+    sd_cpu = layer.state_dict()
+    assert sd_cpu["qweight"].device.type == "cpu" and torch.equal(sd_cpu["qweight"], qw)
     layer.to(DEV)
     assert torch.equal(layer(x), y0)
     assert torch.equal(layer.state_dict()["qweight"].cpu(), qw)
