@@ -83,6 +83,23 @@ class MBWQLinearCuda(MPQLinearBase):
                 pass
         return out
 
+    def __getstate__(self):
+        # copy.deepcopy / pickle: the copy's qweight lives at a new address, so the (address, version) mark cannot travel as it is; what travels is
+        # WHETHER the layer was in its prepared state, and __setstate__ re-keys the mark on the copy's own tensor
+        state = self.__dict__.copy()
+        state["_exl2_prepared_at_copy"] = bool(self.use_mbw and self._exl2_mark is not None and self._exl2_current())
+        return state
+
+    def __setstate__(self, state):
+        was = state.pop("_exl2_prepared_at_copy", False)
+        super().__setstate__(state)
+        self._exl2_mark = (self.qweight.data_ptr(), self.qweight._version) if was else None
+        if was:
+            try:
+                self.qweight._bie_exl2_shuffled = self._exl2_mark
+            except AttributeError:
+                pass
+
     @staticmethod
     def _checkpoint_format_hook(module, state_dict, prefix, local_metadata):
         key = prefix + "qweight"
@@ -120,9 +137,10 @@ class MBWQLinearCuda(MPQLinearBase):
     def load_state_dict(self, state_dict, strict=True) -> None:
         """Like the reference (:205-237): exl2 tensors whose shapes differ from the constructor's guess are
         adopted as they come."""
-        own = self.state_dict()
-        if "qweight" in own:
-            own["qweight"] = self.qweight.detach()  # the tensor itself (detach() shares its version counter), not the stream copy the checkpoint hook hands out
+        # the layer's own tensors (detach() shares the version counter), collected WITHOUT state_dict(): its checkpoint hook would hand out (and
+        # compute, on the GPU) a stream copy of a prepared qweight
+        own = {n: p.detach() for n, p in self._parameters.items() if p is not None}
+        own.update({n: b for n, b in self._buffers.items() if b is not None and n not in self._non_persistent_buffers_set})
         for name, value in state_dict.items():
             if name not in own:
                 if strict:
@@ -159,6 +177,8 @@ class MBWQLinearCuda(MPQLinearBase):
             self.qweight.scales, self.qweight.zeros, self.qweight.q_perm = self.scales, self.zeros, self.q_perm
             height, groups = self.q_perm.size(0), self.scales.size(0)
             if self.use_mbw:
+                if self._exl2_mark is not None and self._exl2_current():
+                    raise RuntimeError("this layer's qweight has already been re-arranged (a second pass would scramble it)")
                 self.qweight.data, self.rows = q_linear_cuda.mbwq_trans_qweight(self.qweight, self.q_groups, True,
                                                                                 height, groups, self.w_bit)
                 self._exl2_mark = (self.qweight.data_ptr(), self.qweight._version)

@@ -334,3 +334,30 @@ def test_sibling_group_never_serves_a_recycled_address(monkeypatch):
     assert [m(g3, h) for m in (q, k, v)] == [("q", 4096.0), ("k", 4096.0), ("v", 4096.0)]
     assert mpq_layer.GROUP_STATS["grouped_launches"] == before["grouped_launches"] + 1
     assert recycles or True  # informational: CPython + the CPU allocator recycle on this platform, but the test does not depend on it
+
+
+def test_exl2_layout_mark_survives_deepcopy_and_pickle_but_not_new_contents():
+    """MBWQLinearCuda keeps the fact "qweight is in the kernels' private layout" as (address, version) of the tensor.  The
+    mark must follow the layer through copy.deepcopy / pickle (new address), and must NOT survive new contents (load_state_dict, a new .data).
+    Host logic only: the mark is set by hand here, prepare_params() needs the GPU."""
+    import copy
+    import pickle
+    from bitorch_engine.layers.qlinear.nbit.cuda import MBWQLinearCuda
+    layer = MBWQLinearCuda(in_channels=64, out_channels=32, w_bit=4, dtype=torch.half, group_size=32, dq_group_size=1, use_gba_quant=True, asym=False,
+                           dq_mode=2, use_mbw=True, groups=2, rows_packed=8)
+    layer._exl2_mark = (layer.qweight.data_ptr(), layer.qweight._version)
+    assert layer._exl2_current()
+    twin = copy.deepcopy(layer)
+    assert twin.qweight.data_ptr() != layer.qweight.data_ptr() and twin._exl2_current() and layer._exl2_current()
+    again = pickle.loads(pickle.dumps(layer))
+    assert again._exl2_current()
+    fresh = copy.deepcopy(MBWQLinearCuda(in_channels=64, out_channels=32, w_bit=4, dtype=torch.half, group_size=32, dq_group_size=1, use_gba_quant=True,
+                                         asym=False, dq_mode=2, use_mbw=True, groups=2, rows_packed=8))
+    assert fresh._exl2_mark is None and not fresh._exl2_current()          # an unprepared layer stays unprepared
+    sd = {k: v.clone() for k, v in fresh.state_dict().items() if k == "qweight"}   # (state_dict() of a MARKED layer calls the GPU un-shuffle)
+    twin.load_state_dict(sd, strict=False)
+    assert not twin._exl2_current() and twin.qweight.rows is None          # new contents: the stream again, table detached
+    layer.qweight.data = torch.zeros_like(layer.qweight.data)
+    assert not layer._exl2_current()
+    with pytest.raises(RuntimeError, match="prepare_params"):
+        layer._require_prepared()
