@@ -929,7 +929,7 @@ __global__ __launch_bounds__(NW * 64, (RB == 1 ? 2 : 1)) void mpq_gemv_lutm_kern
 // ONE launch over a LIST of layers, 3 <= M <= 32 (bie_mpq_list_*): block b -> {entry, tile | slice << 20}; the entry's granules and
 // generation words are its own (tile numbers local to the entry).
 template <int DT, int ZM, int RPG, int NW, bool PF, int RB>
-__global__ __launch_bounds__(NW * 64, (RB == 1 ? 2 : 1)) void mpq_lutm_list_kernel(const ListEntry* __restrict__ ent, const uint2_t* __restrict__ blk, const int M,
+__global__ __launch_bounds__(NW * 64, (RB == 1 ? 2 : (NW == 4 && RPG <= 16 ? 3 : 1))) void mpq_lutm_list_kernel(const ListEntry* __restrict__ ent, const uint2_t* __restrict__ blk, const int M,
                                                                   const unsigned epoch, unsigned* status, const unsigned tag_skew, const int spin_limit) {
     typedef const __attribute__((address_space(4))) uint2_t cu2_t;
     typedef const __attribute__((address_space(4))) ListEntry cent_t;
@@ -1180,31 +1180,46 @@ template <int DT>
 static void lutm_launch(const LutArgs& a, int rpg, int grid, int zm, hipStream_t st) { lutm_launch_rb<DT, 1>(a, rpg, grid, zm, st); }
 
 // the list form of the matrix-pipe kernel (mpq_list.hip builds the entries and the block table)
-template <int DT, bool PF, int RB>
+template <int DT, bool PF, int RB, int NW = 8>
 static void lutm_list_launch_dt(const ListEntry* ent, const uint2_t* blk, unsigned grid, int M, int rpg, int zm, unsigned epoch, unsigned* status,
                                 unsigned skew, int spin, hipStream_t st) {
 #define BIE_LUTML(ZMV)                                                                                                                               \
     switch (rpg) {                                                                                                                                   \
-        case 4: hipLaunchKernelGGL((mpq_lutm_list_kernel<DT, ZMV, 4, 8, PF, RB>), dim3(grid), dim3(512), 0, st, ent, blk, M, epoch, status, skew, spin); break;   \
-        case 8: hipLaunchKernelGGL((mpq_lutm_list_kernel<DT, ZMV, 8, 8, PF, RB>), dim3(grid), dim3(512), 0, st, ent, blk, M, epoch, status, skew, spin); break;   \
-        case 16: hipLaunchKernelGGL((mpq_lutm_list_kernel<DT, ZMV, 16, 8, PF, RB>), dim3(grid), dim3(512), 0, st, ent, blk, M, epoch, status, skew, spin); break; \
-        default: hipLaunchKernelGGL((mpq_lutm_list_kernel<DT, ZMV, 32, 8, PF, RB>), dim3(grid), dim3(512), 0, st, ent, blk, M, epoch, status, skew, spin); break; \
+        case 4: hipLaunchKernelGGL((mpq_lutm_list_kernel<DT, ZMV, 4, NW, PF, RB>), dim3(grid), dim3(NW * 64), 0, st, ent, blk, M, epoch, status, skew, spin); break;   \
+        case 8: hipLaunchKernelGGL((mpq_lutm_list_kernel<DT, ZMV, 8, NW, PF, RB>), dim3(grid), dim3(NW * 64), 0, st, ent, blk, M, epoch, status, skew, spin); break;   \
+        case 16: hipLaunchKernelGGL((mpq_lutm_list_kernel<DT, ZMV, 16, NW, PF, RB>), dim3(grid), dim3(NW * 64), 0, st, ent, blk, M, epoch, status, skew, spin); break; \
+        default: hipLaunchKernelGGL((mpq_lutm_list_kernel<DT, ZMV, 32, NW, PF, RB>), dim3(grid), dim3(NW * 64), 0, st, ent, blk, M, epoch, status, skew, spin); break; \
     }
     if (zm == ZM_ASYM) { BIE_LUTML(ZM_ASYM) }
     else { BIE_LUTML(ZM_SYM) }
 #undef BIE_LUTML
 }
-int mpq_lutm_list_launch(const ListEntry* ent, const uint2_t* blk, unsigned grid, int M, int rpg, int zm, int dtype, hipStream_t st) {
+// waves per workgroup of the list form (the plan in mpq_list.hip is made for this number): FOUR.  17 <= M <= 32 (two row blocks, ~132
+// registers): three four-wave workgroups fit a CU (3 waves per SIMD, 96 KiB of tables) where ONE eight-wave workgroup does (2 per SIMD) --
+// 10.3 -> 7.7 us per 4096x11008 layer at 32 rows.  M <= 16: same residency either way, but a wave walks twice the units (prologue, barriers and
+// the workgroup reduction amortised): 6.48 -> 5.96 us at 16 rows (profiles/r05_lutm_list_nw_ab.txt).  BIE_LUTM_NW32 / BIE_LUTM_NW16 = 8: the old plan.
+int mpq_lutm_list_nw(int M) {
+    static const int nw32 = lut_env("BIE_LUTM_NW32", 4);
+    static const int nw16 = lut_env("BIE_LUTM_NW16", 4);
+    return M > 16 ? (nw32 == 8 ? 8 : 4) : (nw16 == 8 ? 8 : 4);
+}
+int mpq_lutm_list_launch(const ListEntry* ent, const uint2_t* blk, unsigned grid, int M, int rpg, int zm, int dtype, int nw, hipStream_t st) {
     unsigned skew;
     int spin;
     test_forge_get(&skew, &spin);
     const unsigned epoch = next_launch_epoch();
     // (the next-unit prefetch variant, PF = true, needs 139 registers: one 8-wave workgroup per CU instead of two -- measured 8.4 against
     //  6.7 us per 4096x11008 layer at M = 8, profiles/r03_z_lutm_list_ab.txt; not instantiated)
-    // 17 <= M <= 32: two 16-row blocks of x per pass over the weights (one 8-wave workgroup per CU: ~135 registers)
-    if (M > 16) {
+    // 17 <= M <= 32: two 16-row blocks of x per pass over the weights
+    if (M > 16 && nw == 4) {
+        if (dtype == BIE_F16) lutm_list_launch_dt<BIE_F16, false, 2, 4>(ent, blk, grid, M, rpg, zm, epoch, device_status_word(), skew, spin, st);
+        else lutm_list_launch_dt<BIE_BF16, false, 2, 4>(ent, blk, grid, M, rpg, zm, epoch, device_status_word(), skew, spin, st);
+    } else if (M > 16) {
         if (dtype == BIE_F16) lutm_list_launch_dt<BIE_F16, false, 2>(ent, blk, grid, M, rpg, zm, epoch, device_status_word(), skew, spin, st);
         else lutm_list_launch_dt<BIE_BF16, false, 2>(ent, blk, grid, M, rpg, zm, epoch, device_status_word(), skew, spin, st);
+    } else if (nw == 4) {
+        if (dtype == BIE_F16) lutm_list_launch_dt<BIE_F16, false, 1, 4>(ent, blk, grid, M, rpg, zm, epoch, device_status_word(), skew, spin, st);
+        else lutm_list_launch_dt<BIE_BF16, false, 1, 4>(ent, blk, grid, M, rpg, zm, epoch, device_status_word(), skew, spin, st);
     } else if (dtype == BIE_F16) lutm_list_launch_dt<BIE_F16, false, 1>(ent, blk, grid, M, rpg, zm, epoch, device_status_word(), skew, spin, st);
     else lutm_list_launch_dt<BIE_BF16, false, 1>(ent, blk, grid, M, rpg, zm, epoch, device_status_word(), skew, spin, st);
     return check_launch("mpq_lutm_list_kernel");

@@ -38,7 +38,8 @@ namespace bie {
 unsigned* device_status_word();  // status.hip: device pointer of the host-mapped status page (NULL before bie_status_init)
 void test_forge_get(unsigned* tag_skew, int* spin_limit);
 int test_forge_dep_get();
-int mpq_lutm_list_launch(const ListEntry* ent, const uint2_t* blk, unsigned grid, int M, int rpg, int zm, int dtype, hipStream_t st);  // mpq_gemv_lut.hip
+int mpq_lutm_list_launch(const ListEntry* ent, const uint2_t* blk, unsigned grid, int M, int rpg, int zm, int dtype, int nw, hipStream_t st);  // mpq_gemv_lut.hip
+int mpq_lutm_list_nw(int M);
 
 struct ListArgs {
     const ListEntry* ent;
@@ -788,10 +789,11 @@ static int list_nw(int M, int w_bit) {
     return (M == 1 && w_bit == 4) ? 4 : 8;
 }
 
-static void list_plan(int n, const bie_mpq_list_entry* ent, int w_bit, int group_size, int* rpg_out, std::vector<ListPlanEntry>& pe, int nw = 8) {
+static void list_plan(int n, const bie_mpq_list_entry* ent, int w_bit, int group_size, int* rpg_out, std::vector<ListPlanEntry>& pe, int nw = 8, int max_gpw_plan = 0) {
     static const int want = list_env("BIE_LIST_WANT_WAVES", 6144);
     static const int force_h = list_env("BIE_LIST_H", 0);
-    static const int max_gpw = list_env("BIE_LIST_MAX_GPW", 16);
+    static const int max_gpw_env = list_env("BIE_LIST_MAX_GPW", 0);
+    const int max_gpw = max_gpw_env > 0 ? max_gpw_env : (max_gpw_plan > 0 ? max_gpw_plan : 16);
     const int NB = 32 / w_bit;
     long units = 0;  // at H = 1
     int min_gs = group_size;
@@ -921,8 +923,10 @@ int mpq_list_create(MpqList** out, int n, const bie_mpq_list_entry* ent, int M, 
         for (int i = 0; i < n; i++)
             if (ent[i].depends_on >= 0 || ent[i].N % 4 || (reinterpret_cast<uintptr_t>(ent[i].x) & 15) || ent[i].K % 8) lutm = false;
     }
-    if (lutm) nw = 8;  // the matrix-pipe kernel: eight waves, each with its own 8 KiB table
-    list_plan(n, ent, w_bit, group_size, &rpg, pe, nw);
+    if (lutm) nw = mpq_lutm_list_nw(M);  // the matrix-pipe kernel: eight waves (four at 17 <= M <= 32), each with its own 8 KiB table
+    // the matrix-pipe form with four-wave workgroups: up to 24 units per wave before K is sliced over workgroups (K = 11008 stays whole:
+    // 8.56 -> 7.60 us per 11008x4096 layer at 32 rows, profiles/r05_lutm_list_nw_ab.txt)
+    list_plan(n, ent, w_bit, group_size, &rpg, pe, nw, (lutm && nw == 4) ? 24 : 0);
     const ListLayout L = list_layout(n, pe, M);
     BIE_REQUIRE(device_bytes >= L.total, BIE_ERR_WORKSPACE, "bie_mpq_list_create: device buffer of %zu bytes required, got %zu", L.total, device_bytes);
     BIE_REQUIRE((reinterpret_cast<uintptr_t>(device_mem) & 255) == 0, BIE_ERR_INVALID_ARG, "bie_mpq_list_create: the device buffer must be 256-byte aligned");
@@ -1031,7 +1035,7 @@ int mpq_list_forward(MpqList* p, hipStream_t st) {
         BIE_REQUIRE(e == hipSuccess, BIE_ERR_HIP, "bie_mpq_list_forward: hipMemsetAsync: %s", hipGetErrorString(e));
     }
     if (p->lutm)  // 2 / 3 <= M <= 32: lookups feeding v_mfma_f32_16x16x32 (mpq_gemv_lut.hip), same entries and block table
-        return mpq_lutm_list_launch(p->d_ent, p->d_blk, p->grid, p->M, p->rpg, p->zm, p->dtype, st);
+        return mpq_lutm_list_launch(p->d_ent, p->d_blk, p->grid, p->M, p->rpg, p->zm, p->dtype, p->nw, st);
     ListArgs a;
     a.ent = p->d_ent;
     a.blk = p->d_blk;
