@@ -10,8 +10,11 @@ binary_conv2d_cutlass = import_extension("binary_conv2d_cutlass")
 
 
 class BinaryConv2dCutlass(BinaryConv2dBase):
-    def __init__(self, *args, **kwargs):
+    def __init__(self, *args, reference_convention=None, **kwargs):
         super().__init__(*args, **kwargs)
+        # the reference kernel's own output convention (viewed layouts, raw popcounts, NHWC result) instead of the A15 convolution: opt-in,
+        # see extensions/binary_conv2d_cutlass.forward_reference_convention
+        self.reference_convention = binary_conv2d_cutlass.reference_convention_default() if reference_convention is None else bool(reference_convention)
         self.bias_a = torch.nn.Parameter(torch.zeros(self.in_channels, dtype=self.dtype))
         self.scale_a = torch.nn.Parameter(torch.tensor(0, dtype=torch.float))
         self.scale_w = torch.nn.Parameter(torch.tensor(1, dtype=torch.float), requires_grad=False)
@@ -42,6 +45,6 @@ class BinaryConv2dCutlass(BinaryConv2dBase):
         self._check_forward(x)
         x = self.set_activation(x)
         scale = self.scale_a.item() * self.scale_w.item()
-        out = binary_conv2d_cutlass.forward(x, self.opt_weight, scale, self.training, self.kernel_size, self.stride,
-                                            self.padding, self.dilation)
+        fwd = binary_conv2d_cutlass.forward_reference_convention if self.reference_convention else binary_conv2d_cutlass.forward
+        out = fwd(x, self.opt_weight, scale, self.training, self.kernel_size, self.stride, self.padding, self.dilation)
         return out.to(x.dtype)

@@ -255,6 +255,46 @@ def binary_conv2d(x, w, stride, pad, dil):
     return y
 
 
+def binary_conv2d_cutlass_reference_convention(x, w, scale, ksz, stride, pad, dil):
+    """What the reference's BinaryConv2dCutlass kernel computes, read off its source (PARITY UNPINNED: the kernel needs CUDA + CUTLASS, the
+    reference's own test only compares packed with unpacked weights after a layer norm, tests/layers/test_binary_conv.py:157-170).
+    layers/qconv/binary/cutlass/binary_conv2d_cutlass_kernel.cu:
+      :438      the NCHW input is VIEWED (not permuted) as [B, H, W, C]; :430 / :474 the weights as [OC, k, k, C]
+      :64-117   bits = (value >= 0), eight consecutive elements of that memory order per byte, LSB first (:325-345: packed shape [.., C/8])
+      :206-228  the PACKED tensors' sizes are handed to CUTLASS as the extents of one-bit tensors: it sees C/8 one-bit channels per pixel with
+                packed NHWC strides, i.e. it walks the FIRST B*H*W*C/8 (OC*k*k*C/8) bits of each buffer
+      :260      Mode::kConvolution: the filter is flipped (tap (r, s) meets input offset (k-1-r, k-1-s) * dilation)
+      :142-147,:271  int32 accumulator of popcount(a XOR w), alpha 1 / beta 0, no K - 2*popc; padded positions read as zero bits
+      :414      out_edge = (W - k + 2*pad) / stride + 1 for BOTH output extents (the dilation is not in it)
+      :419-423,:453  output [B, out_edge, out_edge, OC] (NHWC, not permuted back), int32 * scale -> float32
+    x [B, C, H, W], w [OC, C, k, k] values (numpy); returns float32 [B, out_edge, out_edge, OC]."""
+    x = np.ascontiguousarray(np.asarray(x, dtype=np.float32))
+    w = np.ascontiguousarray(np.asarray(w, dtype=np.float32))
+    B, C, H, W = x.shape
+    OC = w.shape[0]
+    assert C % 8 == 0
+    C8 = C // 8
+    oe = (W - ksz + 2 * pad) // stride + 1
+    abits = (x.reshape(-1) >= 0)[: B * H * W * C8].reshape(B, H, W, C8).astype(np.int64)
+    wbits = (w.reshape(-1) >= 0)[: OC * ksz * ksz * C8].reshape(OC, ksz, ksz, C8).astype(np.int64)
+    out = np.zeros((B, oe, oe, OC), dtype=np.int64)
+    for r in range(ksz):
+        for s_ in range(ksz):
+            f = wbits[:, r, s_, :]                                # [OC, C8]
+            plane = np.zeros((B, oe, oe, C8), dtype=np.int64)      # zero bits where the tap falls outside the image
+            for p in range(oe):
+                h = p * stride - pad + (ksz - 1 - r) * dil
+                if h < 0 or h >= H:
+                    continue
+                for q in range(oe):
+                    ww = q * stride - pad + (ksz - 1 - s_) * dil
+                    if 0 <= ww < W:
+                        plane[:, p, q, :] = abits[:, h, ww, :]
+            # popcount(a ^ f) over the channel bits = sum a + sum f - 2 a.f
+            out += plane.sum(-1, keepdims=True) + f.sum(-1)[None, None, None, :] - 2 * np.einsum("bpqc,oc->bpqo", plane, f)
+    return out.astype(np.float32) * np.float32(scale)
+
+
 def pack_sign_u8(a):
     a = _c(a, np.float32)
     out = np.empty(a.size // 8, dtype=np.uint8)
