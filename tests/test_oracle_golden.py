@@ -247,3 +247,26 @@ def test_btc_bstc_image_oracle_against_a_thread_by_thread_emulation():
                     val = ((val << 1) + int(A[bx * 32 + i][by * 32 + lane] >= 0)) & 0xffffffff
                 bstc[bx * gy * 32 + by * 32 + lane] = val
     assert to_bytes(bstc) == orc.binary_pack_bstc32(w)
+
+
+def test_cutlass_conv_reference_convention_restatement_on_a_case_small_enough_to_read():
+    """oracle.binary_conv2d_cutlass_reference_convention (parity UNPINNED: the reference kernel needs CUDA + CUTLASS): a 1x1 filter makes the
+    convention readable -- output (b, p, q, o) = popcount over the C/8 bits starting at flat bit ((b*H + p)*W + q) * C/8 of the NCHW memory's
+    sign bits XOR the C/8 bits starting at o * C/8 of the weight memory's (binary_conv2d_cutlass_kernel.cu:206-228,271,438,453)."""
+    rng = np.random.default_rng(5)
+    B, C, H, W, OC = 2, 1024, 2, 3, 3
+    x = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    w = rng.standard_normal((OC, C, 1, 1)).astype(np.float32)
+    y = orc.binary_conv2d_cutlass_reference_convention(x, w, 0.5, 1, 1, 0, 1)
+    c8 = C // 8
+    oe = W
+    xb, wb = (x.reshape(-1) >= 0), (w.reshape(-1) >= 0)
+    assert y.shape == (B, oe, oe, OC) and y.dtype == np.float32
+    for b in range(B):
+        for p in range(H):  # rows p >= H of the (W x W) output read zero bits only
+            for q in range(W):
+                a = xb[((b * H + p) * W + q) * c8:][:c8]
+                for o in range(OC):
+                    assert y[b, p, q, o] == 0.5 * np.count_nonzero(a ^ wb[o * c8:(o + 1) * c8])
+    for o in range(OC):  # H = 2 < out_edge = 3: the last output row lies outside the image -> popcount of the filter bits alone
+        assert np.all(y[:, 2, :, o] == 0.5 * np.count_nonzero(wb[o * c8:(o + 1) * c8]))
