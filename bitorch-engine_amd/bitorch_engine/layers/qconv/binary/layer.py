@@ -10,8 +10,14 @@ class BinaryConvParameter(nn.Parameter):
         return super().__new__(cls, data, requires_grad=requires_grad)
 
     @staticmethod
-    def update(qweight, *args, **kwargs):
-        raise NotImplementedError("BinaryConvParameter.update (training) is outside the inference hot path of this build")
+    def update(qweight: torch.nn.Parameter, exp_avg_s: torch.Tensor = None, exp_avg_l: torch.Tensor = None, step: torch.Tensor = None,
+               lr: float = 1e-4, weight_decay: float = 0.0, beta1: float = 0.99, beta2: float = 0.9999, eps: float = 1e-6, dtype=torch.half,
+               correct_bias=None, projector=None, grad: torch.Tensor = None) -> None:
+        """The optimiser-side update of this parameter kind (reference layers/qconv/binary/layer.py): utils/model_helper.qweight_update_fn on `qweight.grad`."""
+        from bitorch_engine.utils.model_helper import qweight_update_fn
+        assert isinstance(qweight, BinaryConvParameter), 'Error: the type of qweight must be BinaryConvParameter. '
+        qweight_update_fn(qweight=qweight, exp_avg_s=exp_avg_s, exp_avg_l=exp_avg_l, step=step, lr=lr, weight_decay=weight_decay, beta1=beta1,
+                          beta2=beta2, correct_bias=correct_bias, eps=eps, dtype=dtype, projector=projector, grad=grad)
 
 
 class BinaryConv2dBase(nn.Module):

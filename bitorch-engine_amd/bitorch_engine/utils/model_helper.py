@@ -143,6 +143,61 @@ def _add_scaled_(t: torch.Tensor, other: torch.Tensor, alpha: float) -> torch.Te
     return t.add_(other, alpha=alpha)
 
 
+def _update_integer_parameter(qweight, exp_avg_s, exp_avg_l, step, lr, weight_decay, beta1, beta2, eps, dtype, correct_bias) -> None:
+    """The branches of the reference's qweight_update_fn for parameters whose gradient is an INTEGER (or boolean) tensor in `qweight.grad`
+    (utils/model_helper.py:403-478).  Plain torch elementwise ops in the reference, and here: the same ops in the same order, so the
+    roundings land where the reference's do (pinned to reference outputs: tests/golden/update_step_integer_params.npz).  Stock torch's
+    autograd cannot PRODUCE such a gradient (the reference runs a patched torch); whoever computes it assigns `.grad` (with
+    `grad_dtype = None` where the data has been re-typed).
+      * binary linear / conv (:436-444): first moment lerp-ed towards the gradient, second towards lr * sign(first); a weight keeps its sign
+        where it equals -sign(second) (zero counts as +1) and flips elsewhere;
+      * W4A4 / W8A8 (:450-478): Adam on the integer values in `dtype`, decoupled weight decay, then nv_tensor_quant -- the data comes back
+        in `dtype` holding integers, as the reference leaves it;
+      * boolean binary embedding table (:412-434): the second moment lerp-ed towards +-lr (gradient bits), its sign bits XOR-ed into the
+        active rows.  The packed uint8 table cannot run in the reference either (:408 builds a shape from a tensor row)."""
+    from bitorch_engine.layers.qembedding.binary.layer import BinaryEmbeddingParameter
+    from bitorch_engine.layers.qlinear.binary.layer import BinaryLinearParameter
+    from bitorch_engine.layers.qconv.binary.layer import BinaryConvParameter
+    from bitorch_engine.layers.qlinear.nbit.layer import nBitLinearParameter
+    from bitorch_engine.layers.qconv.nbit.layer import nBitConvParameter
+    from bitorch_engine.utils.quant_operators import nv_tensor_quant
+    if qweight.grad is None:
+        raise RuntimeError("qweight_update_fn: qweight.grad is not set (integer gradients are assigned by the caller; stock autograd cannot produce them)")
+    if isinstance(qweight, BinaryEmbeddingParameter):
+        if qweight.data.dtype is not torch.bool:
+            raise NotImplementedError("qweight.dtype '{}' has not been supported yet.".format(str(qweight.data.dtype)))
+        towards = qweight.grad.to(dtype)
+        towards = torch.where(towards == 0, torch.tensor(-1, dtype=dtype, device=qweight.device), towards).mul_(lr)
+        exp_avg_s.lerp_(towards, (1 - beta2))
+        bits = exp_avg_s >= 0
+        rows = qweight.active_indices
+        qweight[rows] ^= qweight[rows] ^ bits[rows]
+        return
+    if isinstance(qweight, (BinaryLinearParameter, BinaryConvParameter)):
+        exp_avg_l.lerp_(qweight.grad.to(dtype), (1 - beta1))
+        exp_avg_s.lerp_(exp_avg_l.clone().sign_().mul_(lr), (1 - beta2))
+        keep = exp_avg_s.clone().sign_().mul_(-1)
+        keep[keep == 0] = 1
+        flip = keep != qweight.sign()
+        qweight.data.copy_(torch.where(flip, -qweight.data, qweight.data))
+        return
+    if isinstance(qweight, (nBitLinearParameter, nBitConvParameter)):
+        g = qweight.grad.to(dtype)
+        w = qweight.data.to(dtype)
+        exp_avg_l.mul_(beta1).add_(g, alpha=(1.0 - beta1))
+        exp_avg_s.mul_(beta2).addcmul_(g, g, value=1.0 - beta2)
+        denom = exp_avg_s.sqrt().add_(eps)
+        step_size = lr
+        if correct_bias:
+            step_size = step_size * math.sqrt(1.0 - beta2 ** step.item()) / (1.0 - beta1 ** step.item())
+        w.addcdiv_(exp_avg_l, denom, value=-step_size)
+        if weight_decay > 0.0:
+            w.add_(w, alpha=(-lr * weight_decay))
+        qweight.data = nv_tensor_quant(w)[0]
+        return
+    raise NotImplementedError("qweight.dtype '{}' has not been supported yet.".format(str(qweight.data.dtype)))
+
+
 def qweight_update_fn(qweight: torch.nn.Parameter, exp_avg_s: torch.Tensor = None, exp_avg_l: torch.Tensor = None, step: torch.Tensor = None,
                       lr: float = 1e-4, weight_decay: float = 0.0, beta1: float = 0.99, beta2: float = 0.9999, eps: float = 1e-6,
                       dtype=torch.half, correct_bias=None, projector=None, grad: torch.Tensor = None) -> None:
@@ -164,8 +219,7 @@ def qweight_update_fn(qweight: torch.nn.Parameter, exp_avg_s: torch.Tensor = Non
     from bitorch_engine.layers.qlinear.nbit.layer import MPQWeightParameter
     step.add_(1)  # FIRST, as the reference (utils/model_helper.py:401: the counter moves before the parameter kind is looked at, also when a branch then raises)
     if not isinstance(qweight, MPQWeightParameter):
-        raise NotImplementedError("qweight_update_fn: only MPQWeightParameter is updated by this build (the binary / n-bit integer parameters need "
-                                  "the reference's custom torch with gradients on integer tensors)")
+        return _update_integer_parameter(qweight, exp_avg_s, exp_avg_l, step, lr, weight_decay, beta1, beta2, eps, dtype, correct_bias)
     if not (qweight.layer_type == 1 and qweight.asym and qweight.g_idx is not None):
         raise NotImplementedError("qweight_update_fn: MPQWeightParameter is updated in its GPTQ form (layer_type 1, asym, g_idx), the form the "
                                   "reference's own update executes")

@@ -127,6 +127,56 @@ def update_step_vectors():
     return out
 
 
+def update_step_integer_params_vectors():
+    """The other branches of the reference's qweight_update_fn (utils/model_helper.py:403-478): binary linear / conv parameters (sign flips
+    from two lerp-ed moments), W4A4 / W8A8 integer parameters (Adam on the integer values, re-quantised with nv_tensor_quant) and the
+    boolean binary embedding table (XOR with the moment's sign bits on the active rows).  The integer gradients are ASSIGNED to `.grad`
+    (stock torch cannot produce them; the reference runs a patched torch), three steps each, fp16 and bf16 moments."""
+    from bitorch_engine.layers.qlinear.binary import BinaryLinearParameter
+    from bitorch_engine.layers.qconv.binary import BinaryConvParameter
+    from bitorch_engine.layers.qlinear.nbit import nBitLinearParameter
+    from bitorch_engine.layers.qconv.nbit import nBitConvParameter
+    from bitorch_engine.layers.qembedding.binary import BinaryEmbeddingParameter
+    from bitorch_engine.utils.model_helper import qweight_update_fn
+    out = {}
+    plain = lambda cls, data: torch.Tensor._make_subclass(cls, data, False)  # stock torch: no requires_grad on integer data
+    for tag, dtype in (("f16", torch.float16), ("bf16", torch.bfloat16)):
+        for kind, cls, shape in (("binlin", BinaryLinearParameter, (24, 40)), ("binconv", BinaryConvParameter, (6, 8, 3, 3)),
+                                 ("nbitlin", nBitLinearParameter, (24, 40)), ("nbitconv", nBitConvParameter, (6, 8, 3, 3)),
+                                 ("binemb", BinaryEmbeddingParameter, (16, 32))):
+            g = torch.Generator().manual_seed(77 + len(kind) * 5 + len(tag))
+            key = f"{tag}_{kind}"
+            if kind.startswith("bin") and kind != "binemb":
+                data = torch.where(torch.rand(shape, generator=g) > 0.5, 1, -1).to(torch.int8)
+            elif kind == "binemb":
+                data = torch.rand(shape, generator=g) > 0.5
+            else:
+                data = torch.randint(-7, 8, shape, generator=g).to(torch.int8)
+            p = plain(cls, data.clone())
+            if kind == "binemb":
+                p.active_indices = torch.tensor([1, 3, 4, 9, 15])
+                out[key + "_active"] = tonp(p.active_indices)
+            out[key + "_w0"] = tonp(data)
+            exp_l, exp_s = torch.zeros(shape, dtype=dtype), torch.zeros(shape, dtype=dtype)
+            step = torch.tensor(0.0)
+            for it in range(1, 4):
+                if kind == "binemb":
+                    grad = torch.rand(shape, generator=g) > 0.5
+                else:
+                    grad = torch.randint(-5, 6, shape, generator=g).to(torch.int8)
+                p.grad = None
+                p.grad_dtype = None  # the W4A4 / W8A8 branch re-types the data (nv_tensor_quant returns `dtype`); the gradient stays integer
+                p.grad = grad
+                out[f"{key}_grad{it}"] = tonp(grad)
+                qweight_update_fn(p, exp_avg_s=exp_s, exp_avg_l=exp_l, step=step, lr=3e-2, weight_decay=(0.01 if it == 2 else 0.0), beta1=0.9, beta2=0.99,
+                                  eps=1e-6, dtype=dtype, correct_bias=(it % 2 == 1), projector=None, grad=None)
+                out[f"{key}_w{it}"] = tonp(p.data).copy()  # a snapshot: the binary branches update the data in place
+                out[f"{key}_wdtype{it}"] = np.array([str(p.data.dtype)])
+                out[f"{key}_exp_l{it}"], out[f"{key}_exp_s{it}"] = tonp(exp_l).copy(), tonp(exp_s).copy()
+            out[key + "_step"] = np.array([float(step)])
+    return out
+
+
 def extension_signatures():
     import glob
     import re
@@ -160,6 +210,10 @@ def main():
     sys.path.insert(0, REF)
     import warnings
     warnings.filterwarnings("ignore")
+    if len(sys.argv) > 1 and sys.argv[1] == "update_int":  # this one fixture only (the others stay byte-identical)
+        np.savez_compressed(os.path.join(OUT, "update_step_integer_params.npz"), **update_step_integer_params_vectors())
+        print("written", os.path.join(OUT, "update_step_integer_params.npz"))
+        return
     from bitorch_engine.layers.qlinear.nbit import MPQWeightParameter
     from bitorch_engine.layers.qlinear.nbit.cuda.utils import unpack_qweight, pack_fp_weight, make_group_map
     from bitorch_engine.layers.qlinear.nbit.cuda import MPQLinearCuda, MBWQLinearCuda
@@ -379,6 +433,7 @@ def main():
     # ---- the DiodeMix re-pack step, MPQWeightParameter.update -> qweight_update_fn (utils/model_helper.py:363-532) on a
     # GPTQ-style (asym, g_idx) parameter: five steps each (step 5 also runs update_zeros), trivial and permuted g_idx, fp16 and bf16
     np.savez_compressed(os.path.join(OUT, "update_step.npz"), **update_step_vectors())
+    np.savez_compressed(os.path.join(OUT, "update_step_integer_params.npz"), **update_step_integer_params_vectors())
 
     # ---- the extension modules' boundary: name and positional parameter list of every function the reference binds with pybind11
     # (m.def("name", &fn)), read off the reference's own C++ definitions.  Data only (names), consumed by tests/test_boundary_cpu.py.
