@@ -1421,7 +1421,7 @@ __global__ __launch_bounds__(256) void exl2_group_permute_kernel(const Exl2Group
 // 8 chunks so that the 8 waves of a workgroup get equal shares; at most BIE_WS_COUNTERS column blocks use the slab reduction
 static void exl2_decode_plan(int M, int K, int N, int& cps, int& S, int& nw, bool direct = false) {
     const int C = K / 32, colblocks = cdiv(N, 64);
-    const int CPS_MAX = 768 / M;  // the slab's x (q_perm applied, M rows) / group-map copy in LDS: 64 M + 4 bytes per chunk (<= 52 KiB)
+    const int CPS_MAX = M <= 2 ? 768 / M : 384;  // (callers pass M <= 2) the slab's x (q_perm applied, M rows) / group-map copy in LDS: 64 M + 4 bytes per chunk (<= 52 KiB)
     static const int nw16_min = [] { const char* ev = getenv("BIE_EXL2_NW16_MIN"); return ev ? atoi(ev) : 160; }();
     static const int want_wgs = [] { const char* ev = getenv("BIE_EXL2_PLAN_WGS"); return ev && atoi(ev) > 0 ? atoi(ev) : 512; }();
     static const int min_cpw = [] { const char* ev = getenv("BIE_EXL2_MIN_CPW"); return ev && atoi(ev) > 0 ? atoi(ev) : 4; }();
@@ -1501,9 +1501,12 @@ size_t mbwq_workspace_bytes(int M, int K, int N) {
     const int S = cdiv(K / 32, cps);
     const int mc = M < 8 ? M : 8;
     size_t c = (size_t)S * mc * N * sizeof(float);
-    int cps2, S2, nw2;
-    exl2_decode_plan(M, K, N, cps2, S2, nw2);
-    const size_t d = M <= 2 && S2 > 1 ? (size_t)(S2 - 1) * exl2_decode_mt(M) * cdiv(N, 64) * 64 * 8 : 0;  // decode granules (unused when another kernel takes over)
+    size_t d = 0;  // decode granules (unused when another kernel takes over).  The decode plan is defined for its own row counts only: asked about
+    if (M <= 2) {  // 769 rows and more it divided by zero (768 / M chunks per slab) -- a host SIGFPE for big M on shapes the prefill form cannot take
+        int cps2, S2, nw2;
+        exl2_decode_plan(M, K, N, cps2, S2, nw2);
+        if (S2 > 1) d = (size_t)(S2 - 1) * exl2_decode_mt(M) * cdiv(N, 64) * 64 * 8;
+    }
     if (d > c) c = d;
     const size_t e = exl2_mfma_granule_bytes(M, K, N);  // 3 <= M <= 64: granules of the matrix-pipe kernel's K slabs
     if (e > c) c = e;

@@ -238,3 +238,22 @@ def test_the_512_register_gemm_kernels_do_not_spill():
             seen[name] = int(m.group(1))
     assert len(seen) >= 4, f"resource report not parsed: {list(seen)}"
     assert all(v == 0 for v in seen.values()), f"a dense GEMM instance spills: {seen}"
+
+
+def test_workspace_sizing_is_total_over_row_counts_and_shapes():
+    """The host-only sizing functions answer for EVERY (M, K, N), also where a plan is not defined for M: bie_mbwq_workspace_bytes asked the
+    one/two-row decode plan about M >= 769 on shapes the prefill form cannot take (N % 8 != 0, or the prefill switched off) and divided by
+    zero -- a SIGFPE in the caller's process (found by the knob matrix, tools/gpu_knob_matrix.sh).  Monotone enough to be usable: more rows
+    never need less than one row."""
+    from bitorch_engine import _hip
+    L = _hip.lib()
+    for (K, N) in ((4096, 4096), (4096, 11008), (4096, 100), (1024, 12), (11008, 4100), (32, 8)):
+        one = L.bie_mbwq_workspace_bytes(1, K, N)
+        assert one > 0
+        for M in (2, 3, 16, 17, 48, 49, 64, 65, 768, 769, 1000, 4096, 65536):
+            b = L.bie_mbwq_workspace_bytes(M, K, N)
+            assert b > 0, (M, K, N)
+    for w_bit in (1, 2, 4, 8):
+        for (K, N) in ((4096, 4096), (4096, 100), (11008, 4100)):
+            for M in (1, 2, 16, 17, 32, 33, 1000, 4096, 65536):
+                assert L.bie_mpq_workspace_bytes(M, K, N, w_bit) > 0, (M, K, N, w_bit)

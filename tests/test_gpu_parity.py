@@ -429,6 +429,34 @@ def test_mbwq_exl2_dequant_and_forward(cfg, M, monkeypatch):
         assert torch.equal(y2, y)
 
 
+@pytest.mark.parametrize("N,M,off", [(100, 800, False), (192, 900, True), (100, 70, False)])
+def test_mbwq_exl2_many_rows_where_the_prefill_form_does_not_apply(N, M, off, monkeypatch):
+    """M beyond the matrix-pipe kernel's 64 rows on a layer the fragment-image form cannot take (N % 8 != 0) or with that form switched off
+    (BIE_EXL2_DENSE_MIN_M): the streaming kernel in slabs of eight rows.  The workspace function used to die on the host for M >= 769 here
+    (SIGFPE: the one/two-row plan asked about 769 rows); values against the oracle."""
+    from bitorch_engine.extensions import q_linear_cuda
+    from bitorch_engine.layers.qlinear.nbit.cuda.utils import make_group_map
+    if off:
+        monkeypatch.setenv("BIE_TUNING", "1")
+        monkeypatch.setenv("BIE_EXL2_DENSE_MIN_M", "1000000")
+    g = np.load(os.path.join(GOLDEN, "exl2_group_maps.npz"))
+    cfg = "w3w2"
+    K, groups, rows_packed = [int(v) for v in g[cfg + "_meta"]]
+    q_groups = torch.from_numpy(g[cfg + "_q_groups"])
+    rng = np.random.default_rng(K + M + N)
+    gen = torch.Generator().manual_seed(K + M + N)
+    qw = torch.from_numpy(rng.integers(-2 ** 31, 2 ** 31 - 1, (rows_packed, N), dtype=np.int64).astype(np.int32))
+    scales = (torch.rand((groups, N), generator=gen) * 0.02 + 0.001).half()
+    zeros = (torch.randn((groups, N), generator=gen) * 0.1).half()
+    q_perm = torch.randperm(K, generator=gen).to(torch.short)
+    gmap = make_group_map(q_groups, rows_packed)
+    qs, rows = exl2_load(qw, q_groups, K, groups)
+    Wo = orc.exl2_dequant(qw.numpy(), orc.torch_to_np(scales), orc.torch_to_np(zeros), q_perm.numpy(), q_groups.numpy(), K)
+    x = torch.randn((M, K), generator=gen).half()
+    y = q_linear_cuda.mbwq_exl2_forward(x.to(DEV), qs, scales.to(DEV), zeros.to(DEV), q_perm.to(DEV), gmap.to(DEV), rows, False)
+    assert_close(y, t16(orc.gemm(orc.torch_to_np(x), Wo, orc.F16), orc.F16), orc.F16, f"exl2 {cfg} N={N} M={M} streaming slabs")
+
+
 def exl2_half_pair_words(q, bits):
     """The half-pair layout as DESIGN.md section 3 states it, in numpy: q [32, N] values of one chunk -> [bits, N] words.
     F = 16 // bits whole fields per 16-bit half; pair j = (q[2j], q[2j+1]) for j < bits * F sits at bit (j % F) * bits of the low /
