@@ -981,6 +981,7 @@ def main():
             pg = pmc_gemm()
             if pg:
                 out["roofline_gemm"]["pmc"] = pg  # the counters of THIS shape (4096^3): fetch = 3.0 x the operands = 1.00 x what 8 private L2s must fetch with 256^2 tiles
+                out["roofline_gemm"]["traffic"] = pg["fetch_bytes"] + pg["write_bytes"]  # HBM-side bytes of the GEMM kernel per launch (the dequantise pass adds 8 MB read + 32 MB written)
         guarded("per_layer_launches_4096x4096", lambda: B.gemv(4096, 4096, 96, 10, 1))
         guarded("chain8_4096x4096_launches", lambda: B.chain_launches(4096, 96, 8, 10, 5))
         guarded("c2_gemv_4096x11008", lambda: B.gemv(4096, 11008, 40, 10, 11))

@@ -18,73 +18,79 @@ import test_gpu_parity as T  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 from bitorch_engine.layers.qlinear.nbit.cuda import MPQForwardList  # noqa: E402
 
-cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
-seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-rng = np.random.default_rng(seed)
-refused, ok, bad = {}, 0, []
-for c in range(cases):
-    w_bit = 4 if rng.random() < 0.75 else 2
-    gs = int(rng.choice([32, 64, 128, 128, 256])) if w_bit == 4 else int(rng.choice([64, 128, 256]))
-    dt = orc.F16 if rng.random() < 0.5 else orc.BF16
-    asym = int(rng.random() < 0.35)
-    M = int(rng.choice([1, 1, 1, 2, 2, 3, 4, 5, 8, 13, 16, 17, 24, 31, 32, 33, 40, 64]))
-    if w_bit == 2 and M > 2:
-        M = int(rng.choice([1, 2]))
-    n = int(rng.integers(1, 25))
-    chain = bool(rng.random() < 0.2) and M <= 2
-    specs = []
-    if chain:
-        d = gs * int(rng.integers(1, 9))
-        d = max(d, 64) // 64 * 64
-        d = (d // gs) * gs if (d // gs) * gs else gs
-        specs = [(d, d, bool(rng.random() < 0.5)) for _ in range(n)]
-    else:
-        for _ in range(n):
-            K = gs * int(rng.integers(1, 1024 // gs + 1))
-            mode = rng.random()
-            N = 64 * int(rng.integers(1, 10)) if mode < 0.4 else (8 * int(rng.integers(1, 80)) if mode < 0.8 else 4 * int(rng.integers(1, 150)))
-            if asym:
-                N = max(32 // w_bit, N // (32 // w_bit) * (32 // w_bit))
-            specs.append((K, N, bool(rng.random() < 0.3)))
-    tag = f"w{w_bit} g{gs} asym={asym} {'f16' if dt == orc.F16 else 'bf16'} M={M} n={n} chain={chain} specs={specs[:3]}"
-    try:
-        entries, host = T._list_case(specs, dt, w_bit, gs, asym, M, seed=int(rng.integers(1 << 30)), chain=chain)
-        plan = MPQForwardList(entries, w_bit=w_bit, group_size=gs, asym=bool(asym))
-        plan.forward()
-        torch.cuda.synchronize()
-        first = [e["y"].clone() for e in entries]
-        for e in entries:
-            e["y"].fill_(float("nan"))
-        plan.forward()
-        torch.cuda.synchronize()
-    except RuntimeError as e:
-        key = str(e)[:100]
-        refused[key] = refused.get(key, 0) + 1
-        continue
-    good = True
-    prev = None
-    for i, (e, (x, qw, scales, zeros, bias)) in enumerate(zip(entries, host)):
-        xin = x if x is not None else prev
-        ref = T.oracle_forward(xin, qw, scales, zeros, None, w_bit, gs, asym, dt, bias)
-        prev = e["y"].cpu()  # a chain is judged link by link: the next entry's reference starts from what this launch produced
+
+
+def run(cases=120, seed=1):
+    rng = np.random.default_rng(seed)
+    refused, ok, bad = {}, 0, []
+    for c in range(cases):
+        w_bit = 4 if rng.random() < 0.75 else 2
+        gs = int(rng.choice([32, 64, 128, 128, 256])) if w_bit == 4 else int(rng.choice([64, 128, 256]))
+        dt = orc.F16 if rng.random() < 0.5 else orc.BF16
+        asym = int(rng.random() < 0.35)
+        M = int(rng.choice([1, 1, 1, 2, 2, 3, 4, 5, 8, 13, 16, 17, 24, 31, 32, 33, 40, 64]))
+        if w_bit == 2 and M > 2:
+            M = int(rng.choice([1, 2]))
+        n = int(rng.integers(1, 25))
+        chain = bool(rng.random() < 0.2) and M <= 2
+        specs = []
+        if chain:
+            d = gs * int(rng.integers(1, 9))
+            d = max(d, 64) // 64 * 64
+            d = (d // gs) * gs if (d // gs) * gs else gs
+            specs = [(d, d, bool(rng.random() < 0.5)) for _ in range(n)]
+        else:
+            for _ in range(n):
+                K = gs * int(rng.integers(1, 1024 // gs + 1))
+                mode = rng.random()
+                N = 64 * int(rng.integers(1, 10)) if mode < 0.4 else (8 * int(rng.integers(1, 80)) if mode < 0.8 else 4 * int(rng.integers(1, 150)))
+                if asym:
+                    N = max(32 // w_bit, N // (32 // w_bit) * (32 // w_bit))
+                specs.append((K, N, bool(rng.random() < 0.3)))
+        tag = f"w{w_bit} g{gs} asym={asym} {'f16' if dt == orc.F16 else 'bf16'} M={M} n={n} chain={chain} specs={specs[:3]}"
         try:
-            yf, rf = T.to_f32(e["y"]), T.to_f32(ref)
-            if chain:  # a long random chain overflows fp16 sooner or later: where BOTH sides are non-finite they agree (inf - inf = NaN on both)
-                both = ~np.isfinite(yf) & ~np.isfinite(rf)
-                yf, rf = np.where(both, 0.0, yf), np.where(both, 0.0, rf)
-            ulp = 2.0 ** -7 if dt == orc.BF16 else 2.0 ** -10
-            tol = 1e-3 * np.abs(rf).max() + ulp * np.abs(rf)
-            if bias is not None:  # y = dt(dt(acc) + bias): one ulp of each magnitude involved (tools/fuzz_mpq_forward.py)
-                bf = T.to_f32(bias)[None, :]
-                tol = tol + ulp * (np.abs(bf) + np.abs(rf - bf))
-            nbad = int((~(np.abs(yf - rf) <= tol)).sum())
-            if nbad:
-                raise AssertionError(f"{tag} entry {i}: {nbad} outside tolerance, max err {np.nanmax(np.abs(yf - rf)):.4g} vs max|ref| {np.abs(rf).max():.4g}")
-            if not torch.equal(torch.nan_to_num(first[i]), torch.nan_to_num(e["y"])):
-                raise AssertionError(tag + f" entry {i}: the second launch of the plan differs from the first")
-        except AssertionError as err:
-            bad.append(str(err)[:400])
-            good = False
-            break
-    ok += good
-print(json.dumps({"cases": cases, "seed": seed, "ok": ok, "refused": refused, "bad": bad}, indent=1))
+            entries, host = T._list_case(specs, dt, w_bit, gs, asym, M, seed=int(rng.integers(1 << 30)), chain=chain)
+            plan = MPQForwardList(entries, w_bit=w_bit, group_size=gs, asym=bool(asym))
+            plan.forward()
+            torch.cuda.synchronize()
+            first = [e["y"].clone() for e in entries]
+            for e in entries:
+                e["y"].fill_(float("nan"))
+            plan.forward()
+            torch.cuda.synchronize()
+        except RuntimeError as e:
+            key = str(e)[:100]
+            refused[key] = refused.get(key, 0) + 1
+            continue
+        good = True
+        prev = None
+        for i, (e, (x, qw, scales, zeros, bias)) in enumerate(zip(entries, host)):
+            xin = x if x is not None else prev
+            ref = T.oracle_forward(xin, qw, scales, zeros, None, w_bit, gs, asym, dt, bias)
+            prev = e["y"].cpu()  # a chain is judged link by link: the next entry's reference starts from what this launch produced
+            try:
+                yf, rf = T.to_f32(e["y"]), T.to_f32(ref)
+                if chain:  # a long random chain overflows fp16 sooner or later: where BOTH sides are non-finite they agree (inf - inf = NaN on both)
+                    both = ~np.isfinite(yf) & ~np.isfinite(rf)
+                    yf, rf = np.where(both, 0.0, yf), np.where(both, 0.0, rf)
+                ulp = 2.0 ** -7 if dt == orc.BF16 else 2.0 ** -10
+                tol = 1e-3 * np.abs(rf).max() + ulp * np.abs(rf)
+                if bias is not None:  # y = dt(dt(acc) + bias): one ulp of each magnitude involved (tools/fuzz_mpq_forward.py)
+                    bf = T.to_f32(bias)[None, :]
+                    tol = tol + ulp * (np.abs(bf) + np.abs(rf - bf))
+                nbad = int((~(np.abs(yf - rf) <= tol)).sum())
+                if nbad:
+                    raise AssertionError(f"{tag} entry {i}: {nbad} outside tolerance, max err {np.nanmax(np.abs(yf - rf)):.4g} vs max|ref| {np.abs(rf).max():.4g}")
+                if not torch.equal(torch.nan_to_num(first[i]), torch.nan_to_num(e["y"])):
+                    raise AssertionError(tag + f" entry {i}: the second launch of the plan differs from the first")
+            except AssertionError as err:
+                bad.append(str(err)[:400])
+                good = False
+                break
+        ok += good
+
+    return {"cases": cases, "seed": seed, "ok": ok, "refused": refused, "bad": bad}
+
+
+if __name__ == "__main__":
+    print(json.dumps(run(int(sys.argv[1]) if len(sys.argv) > 1 else 120, int(sys.argv[2]) if len(sys.argv) > 2 else 1), indent=1))
