@@ -14,7 +14,7 @@ int mpq_gemv_launch(const void* x, const int32_t* qw, const void* scales, const 
                     hipStream_t st);
 int mpq_gemv_generic_launch(const void* x, const int32_t* qw, const void* scales, const void* zeros, const int32_t* g_idx,
                             const void* bias, void* y, float* part, int M, int K, int N, int w_bit, int group_size,
-                            int asym, int dtype, hipStream_t st);
+                            int asym, int dtype, hipStream_t st, const uint16_t* perm = nullptr);
 // mpq_gemv_lut.hip
 bool mpq_gemv_lut_ok(int M, int K, int w_bit, int group_size, int dtype, bool has_gidx);
 size_t mpq_gemv_lut_part_floats(int M, int K, int group_size, int tiles_total, int w_bit);

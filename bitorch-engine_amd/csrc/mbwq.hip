@@ -35,6 +35,9 @@ int mpq_gemm_launch(const void* x, const int32_t* qw, const void* scales, const 
                     float* part, int M, int K, int N, int w_bit, int group_size, int zm, int dtype, const uint16_t* perm,
                     hipStream_t st);
 bool mpq_gemm_ok(int M, int K, int N, int w_bit, int group_size, int dtype, bool has_gidx);
+int mpq_gemv_generic_launch(const void* x, const int32_t* qw, const void* scales, const void* zeros, const int32_t* g_idx, const void* bias, void* y, float* part,
+                            int M, int K, int N, int w_bit, int group_size, int asym, int dtype, hipStream_t st, const uint16_t* perm);
+constexpr int MBWQ_GENERIC_M_CHUNK = 32;  // rows per launch of the any-shape kernel (its partial sums: cdiv(K, 512) x rows x N floats)
 size_t mpq_gemm_workspace_bytes(int M, int K, int N);
 
 struct Exl2Rows {
@@ -1512,6 +1515,8 @@ size_t mbwq_workspace_bytes(int M, int K, int N) {
     if (e > c) c = e;
     const size_t g1 = exl2_lone_group_bytes(M, K, N);
     if (g1 > c) c = g1;
+    const size_t gen = (size_t)cdiv(K, 512) * (M < MBWQ_GENERIC_M_CHUNK ? M : MBWQ_GENERIC_M_CHUNK) * N * sizeof(float);  // the any-shape kernel of the uniform q4 / q2 forward
+    if (gen > c) c = gen;
     size_t r = a > b ? a : b;
     return r > c ? r : c;
 }
@@ -1569,7 +1574,19 @@ int mbwq_q4_forward_launch(const void* x, const int32_t* qw, const void* scales,
         return mpq_gemv_launch(x, qw, scales, zeros, nullptr, y, part, M, K, N, bits, group_size, 2, BIE_F16, p, st);
     if (gemm_ok)
         return mpq_gemm_launch(x, qw, scales, zeros, nullptr, y, part + BIE_WS_HEAD_BYTES / sizeof(float), M, K, N, bits, group_size, 2, BIE_F16, p, st);
-    set_error("bie_mbwq_q4_forward: unsupported shape M=%d K=%d N=%d bits=%d group_size=%d (need K %% 64 == 0, N %% 4 == 0)", M,
+    // any other shape the layout itself allows (whole packed words: K a multiple of 32 / bits; whole groups): the one-column-per-lane kernel with the
+    // same per-weight rounding, 32 rows per launch.  The reference takes such shapes too (its kernels bound-check K and N,
+    // mbwq_linear_cuda_kernel.cu:740-830); this used to be a refusal (found by tools/fuzz_other_ops.py).  A correctness path, not a fast one.
+    if (K % (32 / bits) == 0 && (group_size >= K || K % group_size == 0)) {
+        for (int m0 = 0; m0 < M; m0 += MBWQ_GENERIC_M_CHUNK) {
+            const int mc = (M - m0) < MBWQ_GENERIC_M_CHUNK ? (M - m0) : MBWQ_GENERIC_M_CHUNK;
+            const int rc = mpq_gemv_generic_launch((const uint16_t*)x + (size_t)m0 * K, qw, scales, zeros, nullptr, nullptr, (uint16_t*)y + (size_t)m0 * N,
+                                                   part + BIE_WS_HEAD_BYTES / sizeof(float), mc, K, N, bits, group_size, 2, BIE_F16, st, p);
+            if (rc) return rc;
+        }
+        return BIE_OK;
+    }
+    set_error("bie_mbwq_q4_forward: unsupported shape M=%d K=%d N=%d bits=%d group_size=%d (K must hold whole packed words and whole groups)", M,
               K, N, bits, group_size);
     return BIE_ERR_UNSUPPORTED;
 }

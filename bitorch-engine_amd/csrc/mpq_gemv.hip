@@ -497,7 +497,7 @@ template <int DT>
 __global__ __launch_bounds__(256) void mpq_gemv_generic_kernel(
     const void* __restrict__ x, const uint32_t* __restrict__ qw, const void* __restrict__ scales,
     const void* __restrict__ zeros, const int32_t* __restrict__ g_idx, float* __restrict__ part, int M, int K,
-    int N, int w_bit, int group_size, int asym, int k_per_slab) {
+    int N, int w_bit, int group_size, int asym, int k_per_slab, const uint16_t* __restrict__ perm) {  // asym: 0 / 1, or 2 = the uniform MBWQ rounding fl(q * s - z) in one step; perm: x is read at perm[k] (MBWQ act-order)
     const int n = blockIdx.x * 256 + threadIdx.x;
     const int m = blockIdx.z;
     const int k_begin = blockIdx.y * k_per_slab;
@@ -514,14 +514,16 @@ __global__ __launch_bounds__(256) void mpq_gemv_generic_kernel(
         const uint32_t q = (word >> ((k % nb) * w_bit)) & mask;
         const float s = dt_traits<DT>::load(scales, (long)g * N + n);
         float w;
-        if (asym) {
+        if (asym == 1) {
             const uint32_t zw = reinterpret_cast<const uint32_t*>(zeros)[(long)g * zero_width + n / nb];
             const int zq1 = (int)((zw >> ((n % nb) * w_bit)) & mask) + 1;
             w = dequant_scalar_asym<DT>(q, s, zq1);
+        } else if (asym == 2) {
+            w = dt_traits<DT>::round(__builtin_fmaf((float)q, s, -dt_traits<DT>::load(zeros, (long)g * N + n)));
         } else {
             w = dequant_scalar_sym<DT>(q, s, dt_traits<DT>::load(zeros, (long)g * N + n));
         }
-        acc = __builtin_fmaf(w, dt_traits<DT>::load(x, (long)m * K + k), acc);
+        acc = __builtin_fmaf(w, dt_traits<DT>::load(x, (long)m * K + (perm ? (int)perm[k] : k)), acc);
     }
     part[((long)blockIdx.y * M + m) * N + n] = acc;
 }
@@ -672,16 +674,16 @@ int mpq_gemv_launch(const void* x, const int32_t* qw, const void* scales, const 
 
 int mpq_gemv_generic_launch(const void* x, const int32_t* qw, const void* scales, const void* zeros, const int32_t* g_idx,
                             const void* bias, void* y, float* part, int M, int K, int N, int w_bit, int group_size,
-                            int asym, int dtype, hipStream_t st) {
+                            int asym, int dtype, hipStream_t st, const uint16_t* perm) {
     const int k_per_slab = 512;
     const int S = cdiv(K, k_per_slab);
     dim3 grid(cdiv(N, 256), S, M);
     if (dtype == BIE_F16)
-        hipLaunchKernelGGL(mpq_gemv_generic_kernel<BIE_F16>, grid, dim3(256), 0, st, x, (const uint32_t*)qw, scales, zeros, g_idx, part, M, K, N, w_bit, group_size, asym, k_per_slab);
+        hipLaunchKernelGGL(mpq_gemv_generic_kernel<BIE_F16>, grid, dim3(256), 0, st, x, (const uint32_t*)qw, scales, zeros, g_idx, part, M, K, N, w_bit, group_size, asym, k_per_slab, perm);
     else if (dtype == BIE_BF16)
-        hipLaunchKernelGGL(mpq_gemv_generic_kernel<BIE_BF16>, grid, dim3(256), 0, st, x, (const uint32_t*)qw, scales, zeros, g_idx, part, M, K, N, w_bit, group_size, asym, k_per_slab);
+        hipLaunchKernelGGL(mpq_gemv_generic_kernel<BIE_BF16>, grid, dim3(256), 0, st, x, (const uint32_t*)qw, scales, zeros, g_idx, part, M, K, N, w_bit, group_size, asym, k_per_slab, perm);
     else
-        hipLaunchKernelGGL(mpq_gemv_generic_kernel<BIE_F32>, grid, dim3(256), 0, st, x, (const uint32_t*)qw, scales, zeros, g_idx, part, M, K, N, w_bit, group_size, asym, k_per_slab);
+        hipLaunchKernelGGL(mpq_gemv_generic_kernel<BIE_F32>, grid, dim3(256), 0, st, x, (const uint32_t*)qw, scales, zeros, g_idx, part, M, K, N, w_bit, group_size, asym, k_per_slab, perm);
     int rc = check_launch("mpq_gemv_generic_kernel");
     if (rc) return rc;
     return launch_splitk_finalize(part, bias, y, S, M, N, dtype, st);

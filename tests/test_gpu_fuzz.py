@@ -37,3 +37,13 @@ def test_randomised_layer_lists_against_the_oracle(seed):
     r = fuzz_mpq_lists.run(cases=60, seed=seed)
     assert not r["bad"], r["bad"][:3]
     assert r["ok"] >= 50, r
+
+
+@pytest.mark.parametrize("seed", [401])
+def test_randomised_binary_integer_uniform_mbwq_and_grouped_calls_against_the_oracle(seed):
+    import fuzz_other_ops
+    r = fuzz_other_ops.run(cases=40, seed=seed)
+    for op, v in r["ops"].items():
+        assert not v["bad"], (op, v["bad"][:3])
+        assert not v["refused"], (op, v["refused"])  # every configuration this generator draws is one the reference's layers accept
+        assert v["ok"] >= 30, (op, v)

@@ -336,6 +336,25 @@ def test_mbwq_q4_dequant_and_forward(bits, M, perm):
     assert_close(y, ref, orc.F16, f"mbwq q{bits} M={M} perm={perm}")
 
 
+@pytest.mark.parametrize("bits,M,K,N,gs,perm", [(4, 300, 608, 368, 32, True), (2, 16, 256, 200, 64, False), (4, 17, 960, 12, 64, True), (4, 33, 928, 152, 32, False),
+                                                 (2, 1100, 768, 396, 128, True), (4, 5, 96, 7, 32, True), (2, 3, 160, 30, 32, False)])
+def test_mbwq_uniform_forward_takes_every_shape_the_layout_allows(bits, M, K, N, gs, perm):
+    """K that is not a multiple of 64, N that is not a multiple of 8 (4-bit) / 16 (2-bit) / 4: bie_mbwq_q4_forward used to REFUSE these
+    (unsupported shape) although the reference's kernels bound-check K and N and take them (mbwq_linear_cuda_kernel.cu:740-830) -- found by
+    tools/fuzz_other_ops.py.  Now the one-column-per-lane kernel with the same per-weight rounding serves them; values against the oracle."""
+    from bitorch_engine.extensions import q_linear_cuda
+    rng = np.random.default_rng(bits * 1000 + M + K + N)
+    qw, scales, zeros, gen = rand_case(rng, K, N, bits, gs, orc.F16, 0)
+    zeros = torch.randn(zeros.shape, generator=gen).half() * 0.05
+    q_perm = (torch.randperm(K, generator=gen) if perm else torch.zeros(K)).to(torch.short)
+    Wo = orc.mbwq_q4_dequant(qw.numpy(), orc.torch_to_np(scales), orc.torch_to_np(zeros), q_perm.numpy() if perm else None, bits, gs)
+    Wd = q_linear_cuda.mbwq_q42fp_weight(qw.to(DEV), scales.to(DEV), zeros.to(DEV), gs, bits, q_perm.to(DEV))
+    assert np.array_equal(orc.torch_to_np(Wd), Wo)
+    x = torch.randn((M, K), generator=gen).half()
+    y = q_linear_cuda.mbwq_q4_forward(x.to(DEV), qw.to(DEV), scales.to(DEV), zeros.to(DEV), gs, q_perm.to(DEV), bits)
+    assert_close(y, t16(orc.gemm(orc.torch_to_np(x), Wo, orc.F16), orc.F16), orc.F16, f"mbwq q{bits} M={M} K={K} N={N} perm={perm}")
+
+
 @pytest.mark.parametrize("bits", [2, 4])
 def test_mbwq_q4_forward_through_the_dense_form(bits, monkeypatch):
     """The uniform MBWQ layers reach the MFMA GEMM with the one-rounding fma (ZM_FUSED); forced through mpq_dense.hip (no q_perm: the
