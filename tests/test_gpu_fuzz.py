@@ -47,3 +47,14 @@ def test_randomised_binary_integer_uniform_mbwq_and_grouped_calls_against_the_or
         assert not v["bad"], (op, v["bad"][:3])
         assert not v["refused"], (op, v["refused"])  # every configuration this generator draws is one the reference's layers accept
         assert v["ok"] >= 30, (op, v)
+
+
+@pytest.mark.parametrize("seed", [501])
+def test_random_call_programs_never_get_another_tensors_result_from_the_sibling_grouping(seed):
+    """tools/fuzz_sibling_groups.py: parents with 3..6 quantised children, random programs of calls (shared tensor, freed temporaries, clones,
+    slices, in-place updates, a second tensor), several rounds, programs that change between rounds -- every output against the layer's own
+    launch on the same input.  Groups must actually form (the sweep is not vacuous)."""
+    import fuzz_sibling_groups
+    r = fuzz_sibling_groups.run(parents=30, seed=seed)
+    assert not r["bad"], r["bad"][:2]
+    assert r["calls"] > 500 and r["grouped_launches"] > 0 and r["served_from_group"] > 0, r
