@@ -20,7 +20,7 @@ from oracle import oracle as orc  # noqa: E402
 DEV = T.DEV
 
 
-def run(cases=60, seed=1, ops=("binlin", "binconv", "q4", "q8", "mbwq", "grouped")):
+def run(cases=60, seed=1, ops=("binlin", "binconv", "q4", "q8", "mbwq", "grouped", "grad", "pack")):
     from bitorch_engine.extensions import binary_linear_cuda, q_linear_cutlass as qc, q_linear_cuda
     from bitorch_engine.extensions._binary_common import pack_rows, conv2d
     rng = np.random.default_rng(seed)
@@ -97,6 +97,35 @@ def run(cases=60, seed=1, ops=("binlin", "binconv", "q4", "q8", "mbwq", "grouped
                     y = q_linear_cuda.mbwq_q4_forward(x.to(DEV), qw.to(DEV), scales.to(DEV), zeros.to(DEV), gs, q_perm.to(DEV), bits)
                     T.assert_close(y, T.t16(orc.gemm(orc.torch_to_np(x), Wo, orc.F16), orc.F16), orc.F16, tag)
                     good = True
+                elif op in ("grad", "pack"):
+                    w_bit = int(rng.choice([1, 2, 4, 4, 8]))
+                    gs = int(rng.choice([32, 64, 128]))
+                    dt = orc.F16 if rng.random() < 0.5 else orc.BF16
+                    asym = bool(rng.random() < 0.4)
+                    K = gs * int(rng.integers(1, 1024 // gs + 1))
+                    N = 32 * int(rng.integers(1, 20)) if asym else int(rng.integers(1, 500))
+                    qw, scales, zeros, g2 = T.rand_case(rng, K, N, w_bit, gs, dt, asym)
+                    g_idx = torch.arange(K, dtype=torch.int32) // gs
+                    if rng.random() < 0.4:
+                        g_idx = g_idx[torch.randperm(K, generator=g2)]
+                    if op == "grad":
+                        M = int(rng.choice([1, 2, 9, 33, 100, 300]))
+                        tag = f"grad_input w{w_bit} g{gs} asym={asym} K={K} N={N} M={M}"
+                        gy = torch.randn((M, N), generator=g2).to(T.TDT[dt])
+                        gx = q_linear_cuda.mpq_grad_input(qw.to(DEV), scales.to(DEV), zeros.to(DEV), g_idx.to(DEV), gy.to(DEV), 16, w_bit, asym)
+                        ref = orc.mpq_grad_input(orc.torch_to_np(gy), qw.numpy(), orc.torch_to_np(scales), orc.torch_to_np(zeros) if not asym else zeros.numpy(),
+                                                 g_idx.numpy(), w_bit, gs, int(asym), dt)
+                        T.assert_close(gx, T.t16(ref, dt), dt, tag)
+                        good = True
+                    else:
+                        tag = f"dequant/pack w{w_bit} g{gs} asym={asym} K={K} N={N}"
+                        Wd = q_linear_cuda.mpq_dequant(qw.to(DEV), scales.to(DEV), zeros.to(DEV), g_idx.to(DEV), w_bit, asym, gs)
+                        Wo = orc.mpq_dequant(qw.numpy(), orc.torch_to_np(scales), orc.torch_to_np(zeros) if not asym else zeros.numpy(), g_idx.numpy(), w_bit, gs, int(asym), dt)
+                        good = np.array_equal(orc.torch_to_np(Wd), Wo)
+                        if good:  # and back: packing the dequantised weight reproduces the packed words where the reference's own round trip does
+                            back = q_linear_cuda.mpq_pack(Wd, scales.to(DEV), zeros.to(DEV), g_idx.to(DEV), w_bit, asym, gs)
+                            want = orc.mpq_pack(Wo, orc.torch_to_np(scales), orc.torch_to_np(zeros) if not asym else zeros.numpy(), g_idx.numpy(), w_bit, gs, int(asym), dt)
+                            good = np.array_equal(back.cpu().numpy(), want)
                 else:  # grouped decode call: 2..8 weight sets on one x
                     w_bit = 4 if rng.random() < 0.8 else 2
                     gs = int(rng.choice([32, 64, 128])) if w_bit == 4 else int(rng.choice([64, 128]))
