@@ -649,10 +649,11 @@ __global__ __launch_bounds__(256) void mpq_gemv_lutc_kernel(const LutArgs a) {
 // activations enter as the B operand: lane (kb, m) supplies x[m][32*rq + 8*kb .. +8] (one 16-byte buffer load; lanes m >= M
 // read out of bounds = 0), so D accumulates all M rows at the price of one: lane (kb', m) ends with acc[f][r] = column
 // 16*kb' + 4*r + f.  Per word: 2 + 8 + 4 VALU, 8 LDS reads, one MFMA; no FMAs, no scalar unpacking of x.
-// Table layout (per wave 8 KiB): byte ((f >> 1) << 12) | (q << 8) | ((f & 1) << 7) | (rep << 6) | (c << 2) -- the f part is an
-// instruction offset, q is the byte v_perm_b32 drops into the address, and rep = kb & 1 holds a second copy so that the 32
-// lanes the LDS serves per clock (two kb values x 16 c) fall on 32 different banks.  Lane (kb, c) builds the entries
-// q = 4*kb .. 4*kb+3 of its four columns.
+// Table layout (per wave 8 KiB): byte ((f >> 1) << 12) | (q << 8) | (rep << 6) | (c << 2) | ((f & 1) << 1) -- the f part is an
+// instruction offset (the columns of a pair share a dword: even column in the low half; bf16 with two row blocks: (f & 1) << 7, a dword per
+// entry), q is the byte v_perm_b32 drops into the address,
+// and rep = kb & 1 holds a second copy so that the 32 lanes the LDS serves per clock (two kb values x 16 c) fall on 32 different banks.
+// Lane (kb, c) builds the entries q = 4*kb .. 4*kb+3 of its four columns.
 // =====================================================================================================================
 typedef float lutm_acc_t __attribute__((ext_vector_type(4)));
 
@@ -694,6 +695,7 @@ __device__ __forceinline__ void lutm_body(const LutmView& lv, const int tile_loc
                                           unsigned* status, const unsigned tag_skew, const int spin_limit) {
     constexpr int NB = 8;
     constexpr int RQ = RPG / 4;  // row quads (32 k) per unit
+    constexpr bool PAIRCOL = RB == 1 || DT == BIE_F16;  // table layout: see process_unit
     static_assert(NW <= 8 && RPG % 4 == 0, "wave bits of the table address / whole row quads");
     __shared__ __attribute__((aligned(8192))) uint32_t tab[NW * 2048];  // the only LDS object: starts at LDS address 0
 
@@ -760,24 +762,87 @@ __device__ __forceinline__ void lutm_body(const LutmView& lv, const int tile_loc
     asm("v_mov_b32 %0, 0x0f0f0f0f" : "=v"(m0f));
 
     auto process_unit = [&](const uint4_t (&w)[RQ], const uint4_t (&xf)[RB][RQ], const uint32_t (&sb)[4], const uint32_t (&zb)[4]) {
-        // ---- this lane's 16 entries (q = 4*kb .. 4*kb+3 of its four columns), each stored for both bank replicas;
-        // 16-bit value in the low half of a dword
-#pragma unroll
-        for (int f = 0; f < 4; f++) {
-            float s, z = 0.0f;
-            int zq1 = 0;
-            if constexpr (DT == BIE_BF16) s = bf16_bits_to_f32(sb[f]); else s = f16_bits_to_f32(sb[f]);
-            if constexpr (ZM == ZM_ASYM) zq1 = (int)zb[f];
-            else if constexpr (DT == BIE_BF16) z = bf16_bits_to_f32(zb[f]); else z = f16_bits_to_f32(zb[f]);
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const uint32_t q = (uint32_t)(4 * kb + e);
-                const float t = lut_entry<DT, ZM>(q, s, z, zq1);
-                uint32_t bits;
-                if constexpr (DT == BIE_BF16) bits = __float_as_uint(t) >> 16; else bits = f32_to_f16_bits(t);
-                uint32_t* p = mytab + (f >> 1) * 1024 + q * 64 + (f & 1) * 32 + c;
-                p[0] = bits;
-                p[16] = bits;
+        // PAIRCOL (one 16-row block of x, and fp16 at either size): the entries of a column pair share a dword.  bf16 with two row blocks keeps one
+        // dword per entry: the pair form measured 2-5 % slower there (profiles/r05_lutm_colpair_ab.txt)
+        if constexpr (PAIRCOL) {
+            // ---- this lane's 16 entries (q = 4*kb .. 4*kb+3 of its four columns), each stored for both bank replicas.  The entries of a column
+            // PAIR (f, f + 1) share a dword -- low half the even column, high half the odd one -- so the sixteen entries leave as eight stores
+            // and come out of ONE conversion per pair; a lookup of the odd column is the same read two bytes further
+    #pragma unroll
+            for (int fp = 0; fp < 2; fp++) {
+                float s[2], z[2] = {0.0f, 0.0f};
+                int zq1[2] = {0, 0};
+    #pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int f = 2 * fp + h;
+                    if constexpr (DT == BIE_BF16) s[h] = bf16_bits_to_f32(sb[f]); else s[h] = f16_bits_to_f32(sb[f]);
+                    if constexpr (ZM == ZM_ASYM) zq1[h] = (int)zb[f];
+                    else if constexpr (DT == BIE_BF16) z[h] = bf16_bits_to_f32(zb[f]); else z[h] = f16_bits_to_f32(zb[f]);
+                }
+                uint32_t bits[4];
+                if constexpr (DT == BIE_BF16 && ZM == ZM_SYM) {
+                    // fl(q * s) of both columns in one v_cvt_pk_bf16_f32, unpacked by shift / mask, the second rounding's subtraction in fp32, one more
+                    // v_cvt_pk_bf16_f32: 8 operations per pair of entries instead of 11.  (NOT the dot-unit subtraction of the one-row list kernel,
+                    // 1 * lo + 0 * hi - z: the halves here are two different COLUMNS, and 0 * inf = NaN would carry one column's infinite scale into
+                    // its neighbour's entries -- caught by the special-value tests)
+    #pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float qf = (float)(4 * kb + e);
+                        const uint32_t A = pack_bf16x2(qf * s[0], qf * s[1]);
+                        bits[e] = pack_bf16x2(__uint_as_float(A << 16) - z[0], __uint_as_float(A & 0xffff0000u) - z[1]);
+                    }
+                } else if constexpr (DT == BIE_F16) {
+                    // fp16: both columns' entries in ONE packed-fp16 pass (fl(q * s): v_pk_mul_f16, fl(. - z): v_pk_add_f16 -- sym, the reference's two roundings;
+                    // fused: v_pk_fma_f16; asym: the exact integer difference times s, one rounding)
+                    const half2_t s2 = half2_t{__builtin_bit_cast(half_t, (uint16_t)sb[2 * fp]), __builtin_bit_cast(half_t, (uint16_t)sb[2 * fp + 1])};
+    #pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int q = 4 * kb + e;
+                        half2_t r;
+                        if constexpr (ZM == ZM_ASYM) {
+                            r = half2_t{(half_t)(float)(q - zq1[0]), (half_t)(float)(q - zq1[1])} * s2;
+                        } else {
+                            const half2_t z2 = half2_t{__builtin_bit_cast(half_t, (uint16_t)zb[2 * fp]), __builtin_bit_cast(half_t, (uint16_t)zb[2 * fp + 1])};
+                            const half2_t q2 = half2_t{(half_t)(float)q, (half_t)(float)q};
+                            if constexpr (ZM == ZM_FUSED) r = __builtin_elementwise_fma(q2, s2, -z2);
+                            else r = q2 * s2 - z2;
+                        }
+                        bits[e] = __builtin_bit_cast(uint32_t, r);
+                    }
+                } else {
+    #pragma unroll
+                    for (int e = 0; e < 4; e++) {  // both values are representable in the 16-bit type: the conversion is exact
+                        const uint32_t q = (uint32_t)(4 * kb + e);
+                        bits[e] = pack_bf16x2(lut_entry<DT, ZM>(q, s[0], z[0], zq1[0]), lut_entry<DT, ZM>(q, s[1], z[1], zq1[1]));
+                    }
+                }
+    #pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    uint32_t* p = mytab + fp * 1024 + (4 * kb + e) * 64 + c;
+                    p[0] = bits[e];
+                    p[16] = bits[e];
+                }
+            }
+        } else {
+            // ---- this lane's 16 entries (q = 4*kb .. 4*kb+3 of its four columns), each stored for both bank replicas;
+            // 16-bit value in the low half of a dword
+    #pragma unroll
+            for (int f = 0; f < 4; f++) {
+                float s, z = 0.0f;
+                int zq1 = 0;
+                if constexpr (DT == BIE_BF16) s = bf16_bits_to_f32(sb[f]); else s = f16_bits_to_f32(sb[f]);
+                if constexpr (ZM == ZM_ASYM) zq1 = (int)zb[f];
+                else if constexpr (DT == BIE_BF16) z = bf16_bits_to_f32(zb[f]); else z = f16_bits_to_f32(zb[f]);
+    #pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const uint32_t q = (uint32_t)(4 * kb + e);
+                    const float t = lut_entry<DT, ZM>(q, s, z, zq1);
+                    uint32_t bits;
+                    if constexpr (DT == BIE_BF16) bits = __float_as_uint(t) >> 16; else bits = f32_to_f16_bits(t);
+                    uint32_t* p = mytab + (f >> 1) * 1024 + q * 64 + (f & 1) * 32 + c;
+                    p[0] = bits;
+                    p[16] = bits;
+                }
             }
         }
         // ---- fragment steps st = 4*rq + f: the eight 16-bit lookups of step st+1 are in flight while step st feeds the MFMA
@@ -789,10 +854,11 @@ __device__ __forceinline__ void lutm_body(const LutmView& lv, const int tile_loc
             uint32_t we, wo;
             asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(we) : "v"(word), "v"(m0f), "s"(wavepat));
             asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(wo) : "v"(word >> 4), "v"(m0f), "s"(wavepat));
+            constexpr int ODD = PAIRCOL ? 2 : 128;  // the odd column of a pair: the high half of the same dword / a block of its own
             if (f == 0) lutm_issue8<0>(l, lane_addr, we, wo);
-            else if (f == 1) lutm_issue8<128>(l, lane_addr, we, wo);
+            else if (f == 1) lutm_issue8<ODD>(l, lane_addr, we, wo);
             else if (f == 2) lutm_issue8<4096>(l, lane_addr, we, wo);
-            else lutm_issue8<4096 + 128>(l, lane_addr, we, wo);
+            else lutm_issue8<4096 + ODD>(l, lane_addr, we, wo);
         };
         auto wait_pack = [&](uint32_t (&l)[8], bool more, uint32_t (&b)[4]) {
             if (more) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3]), "+v"(l[4]), "+v"(l[5]), "+v"(l[6]), "+v"(l[7])::"memory");
