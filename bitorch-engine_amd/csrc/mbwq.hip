@@ -1576,7 +1576,7 @@ int mbwq_q4_forward_launch(const void* x, const int32_t* qw, const void* scales,
         return mpq_gemm_launch(x, qw, scales, zeros, nullptr, y, part + BIE_WS_HEAD_BYTES / sizeof(float), M, K, N, bits, group_size, 2, BIE_F16, p, st);
     // any other shape the layout itself allows (whole packed words: K a multiple of 32 / bits; whole groups): the one-column-per-lane kernel with the
     // same per-weight rounding, 32 rows per launch.  The reference takes such shapes too (its kernels bound-check K and N,
-    // mbwq_linear_cuda_kernel.cu:740-830); this used to be a refusal (found by tools/fuzz_other_ops.py).  A correctness path, not a fast one.
+    // mbwq_linear_cuda_kernel.cu:740-830); this used to be a refusal (found by tests/sweeps/fuzz_other_ops.py).  A correctness path, not a fast one.
     if (K % (32 / bits) == 0 && (group_size >= K || K % group_size == 0)) {
         for (int m0 = 0; m0 < M; m0 += MBWQ_GENERIC_M_CHUNK) {
             const int mc = (M - m0) < MBWQ_GENERIC_M_CHUNK ? (M - m0) : MBWQ_GENERIC_M_CHUNK;

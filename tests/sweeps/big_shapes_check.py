@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Vocabulary-sized and other very wide / very deep layers through bie_mpq_forward against the CPU restatement (sampled rows of x at large M):
    lm_head shapes (4096 x 32000, 4096 x 128256, 8192 x 128256), a very deep one (28672 x 8192) and a tall-skinny one (65536 x 256).
-   usage: python tools/big_shapes_check.py   (test infrastructure: imports oracle/)"""
+   usage: python tests/sweeps/big_shapes_check.py   (test infrastructure: imports oracle/)"""
 import json
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "bitorch-engine_amd"))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -2,12 +2,12 @@
 """Randomised sweep of the mixed-bit (exl2) layout: random band structures (bits 8/6/5/4/3/2 in descending order, groups of 32/64/128 k, whole
    groups), ragged N, random q_perm, every dispatch boundary of M -- load-time step (shuffle + table), dequantised weight BIT-EXACT and forward
    within the parity gate against the CPU restatement.  A refusal (RuntimeError) is fine; a wrong value, a NaN or a crash is a finding.
-   usage: python tools/fuzz_exl2_forward.py [cases=150] [seed=1]   (test infrastructure: imports oracle/)"""
+   usage: python tests/sweeps/fuzz_exl2_forward.py [cases=150] [seed=1]   (test infrastructure: imports oracle/)"""
 import json
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "bitorch-engine_amd"))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -3,12 +3,12 @@
    w_bit 1/2/4/8, group sizes 32..256, sym / asym, fp16 / bf16, ragged N (not a multiple of 64 / 8 / 4), every dispatch boundary of M
    (1, 2, 3, 8, 9, 16, 17, 32, 33, 64, 65, ... 1024+), bias on / off, act-order g_idx now and then.  A configuration may be REFUSED (a
    RuntimeError with the library's message: loud is fine); a wrong value, a NaN or a crash is a finding.
-   usage: python tools/fuzz_mpq_forward.py [cases=200] [seed=1]   (test infrastructure: imports oracle/)"""
+   usage: python tests/sweeps/fuzz_mpq_forward.py [cases=200] [seed=1]   (test infrastructure: imports oracle/)"""
 import json
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "bitorch-engine_amd"))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -3,12 +3,12 @@
    groups 32..256, sym / asym, fp16 / bf16, 1..64 rows, bias on some entries, dependent chains now and then; every entry against the CPU
    restatement, a second launch of the same plan (generation words / granule tags carry over), lists small (K sliced over workgroups) and
    large (whole K per workgroup).  A refusal (RuntimeError) is fine; a wrong value, a NaN or a crash is a finding.
-   usage: python tools/fuzz_mpq_lists.py [cases=120] [seed=1]   (test infrastructure: imports oracle/)"""
+   usage: python tests/sweeps/fuzz_mpq_lists.py [cases=120] [seed=1]   (test infrastructure: imports oracle/)"""
 import json
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "bitorch-engine_amd"))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -75,7 +75,7 @@ def run(cases=120, seed=1):
                     yf, rf = np.where(both, 0.0, yf), np.where(both, 0.0, rf)
                 ulp = 2.0 ** -7 if dt == orc.BF16 else 2.0 ** -10
                 tol = 1e-3 * np.abs(rf).max() + ulp * np.abs(rf)
-                if bias is not None:  # y = dt(dt(acc) + bias): one ulp of each magnitude involved (tools/fuzz_mpq_forward.py)
+                if bias is not None:  # y = dt(dt(acc) + bias): one ulp of each magnitude involved (tests/sweeps/fuzz_mpq_forward.py)
                     bf = T.to_f32(bias)[None, :]
                     tol = tol + ulp * (np.abs(bf) + np.abs(rf - bf))
                 nbad = int((~(np.abs(yf - rf) <= tol)).sum())

@@ -3,12 +3,12 @@
    (XNOR kernels and the matrix-pipe form on either side of its switch), binary conv (tap form / im2col form / matrix-pipe form by geometry), the
    W4A4 / W8A8 integer GEMMs, uniform MBWQ q4 / q2 (dequantised weight bit-exact, forward within the parity gate), grouped decode calls.
    A refusal (RuntimeError) is fine; a wrong value, a NaN or a crash is a finding.
-   usage: python tools/fuzz_other_ops.py [cases=60 per operator] [seed=1]   (test infrastructure: imports oracle/)"""
+   usage: python tests/sweeps/fuzz_other_ops.py [cases=60 per operator] [seed=1]   (test infrastructure: imports oracle/)"""
 import json
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "bitorch-engine_amd"))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))

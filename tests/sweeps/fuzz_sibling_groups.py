@@ -5,12 +5,12 @@
    slice, the shared tensor after an in-place update, a second tensor -- repeated for several rounds with fresh or refilled inputs, the program
    mutated now and then (a call dropped / two swapped / row count changed).  EVERY output is compared with the same layer's own launch on the
    same input (grouping off): whatever the protocol concludes, it must never hand out another tensor's result.
-   usage: python tools/fuzz_sibling_groups.py [parents=40] [seed=1]   (test infrastructure: imports the tests' helpers)"""
+   usage: python tests/sweeps/fuzz_sibling_groups.py [parents=40] [seed=1]   (test infrastructure: imports the tests' helpers)"""
 import json
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "bitorch-engine_amd"))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))

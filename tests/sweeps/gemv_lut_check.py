@@ -2,7 +2,7 @@
 at the bench shapes (rotating distinct layers, HIP graph), for the LUT kernel and -- BIE_GEMV_LUT=0 in a second process --
 the dot2 kernel."""
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "bitorch-engine_amd")); sys.path.insert(0, ROOT)
 import numpy as np, torch
 from bitorch_engine import _hip

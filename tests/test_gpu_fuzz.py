@@ -1,4 +1,4 @@
-"""Randomised shape sweeps (run with -m gpu on an MI355X): the tools/fuzz_*.py generators at a size that takes seconds -- random bit widths, group
+"""Randomised shape sweeps (run with -m gpu on an MI355X): the tests/sweeps/fuzz_*.py generators at a size that takes seconds -- random bit widths, group
 sizes, ragged N, every dispatch boundary of M, random mixed-bit band structures, random layer lists -- each configuration against the CPU
 restatement.  A configuration the library REFUSES (RuntimeError with its message) is acceptable; a wrong value, a NaN or a crash is not.
 The long runs (2000 / 800 / 600 cases, no finding) are recorded in profiles/r05_fuzz.txt."""
@@ -10,7 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (os.path.join(ROOT, "tools"), os.path.join(ROOT, "tests")):
+for p in (os.path.join(ROOT, "tests", "sweeps"), os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
@@ -51,7 +51,7 @@ def test_randomised_binary_integer_uniform_mbwq_and_grouped_calls_against_the_or
 
 @pytest.mark.parametrize("seed", [501])
 def test_random_call_programs_never_get_another_tensors_result_from_the_sibling_grouping(seed):
-    """tools/fuzz_sibling_groups.py: parents with 3..6 quantised children, random programs of calls (shared tensor, freed temporaries, clones,
+    """tests/sweeps/fuzz_sibling_groups.py: parents with 3..6 quantised children, random programs of calls (shared tensor, freed temporaries, clones,
     slices, in-place updates, a second tensor), several rounds, programs that change between rounds -- every output against the layer's own
     launch on the same input.  Groups must actually form (the sweep is not vacuous)."""
     import fuzz_sibling_groups

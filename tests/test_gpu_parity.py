@@ -341,7 +341,7 @@ def test_mbwq_q4_dequant_and_forward(bits, M, perm):
 def test_mbwq_uniform_forward_takes_every_shape_the_layout_allows(bits, M, K, N, gs, perm):
     """K that is not a multiple of 64, N that is not a multiple of 8 (4-bit) / 16 (2-bit) / 4: bie_mbwq_q4_forward used to REFUSE these
     (unsupported shape) although the reference's kernels bound-check K and N and take them (mbwq_linear_cuda_kernel.cu:740-830) -- found by
-    tools/fuzz_other_ops.py.  Now the one-column-per-lane kernel with the same per-weight rounding serves them; values against the oracle."""
+    tests/sweeps/fuzz_other_ops.py.  Now the one-column-per-lane kernel with the same per-weight rounding serves them; values against the oracle."""
     from bitorch_engine.extensions import q_linear_cuda
     rng = np.random.default_rng(bits * 1000 + M + K + N)
     qw, scales, zeros, gen = rand_case(rng, K, N, bits, gs, orc.F16, 0)
