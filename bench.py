@@ -16,10 +16,13 @@ launches q/k/v and gate/up, configs[2] (exl2 3/2-bit decode), configs[3] (binary
 (8192x28672, M = 4096) -- every object carries its own roofline fraction.  `cpu_baseline`: the oracle's fused dequant+GEMV on
 the host cores (all cores, and one thread) on a bounded sample.
 
-Multi-GPU (--gpus N, one process per GPU, launched by torch.distributed.run): the headline decode pass with the output
-columns of a [4096 -> 4096*N] stack sharded over the ranks (weak scaling, x replicated, ONE bucketed RCCL all-gather per
-step), plus configs[4] itself in `c5`: 8192x28672 W4 g128, M = 4096, N/world column shards, the all-gather timed
-separately and overlapped with the GEMM by M-tiles (bitorch_engine.distributed).
+Multi-GPU (--gpus N, one process per GPU; started by the driver under torch.distributed.run, or by bench.py itself when WORLD_SIZE is
+unset -- bench_sharded.launch_ranks): every rank runs the headline pass over its own 96 layers (independent output-column blocks: weak
+scaling) and ONE bucketed RCCL all-gather per step assembles the step's outputs, on a communication stream under the next pass; the
+`rccl` object carries the world the collective really saw and the exchange timed alone / sequential / overlapped.  configs[4] itself is
+in `c5`: 8192x28672 W4 g128, M = 4096, N/world column shards (strong scaling), the all-gather timed separately and overlapped with the
+GEMM by M-tiles (bitorch_engine.distributed; timed by bench_sharded.bench_column_sharded).  `--dry-run --backend gloo` rehearses the
+launcher, the rendezvous and the timed-region protocol on the CPU (tests/test_bench_launcher_cpu.py); it measures nothing.
 
 Prints ONE JSON line on rank 0.
 """
@@ -831,20 +834,41 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="headline only (used under rocprofv3)")
     ap.add_argument("--only", default="", help="profiling aid: run only this shape's M=1 decode pass, e.g. 4096x11008")
     ap.add_argument("--short", action="store_true", help="first-class rows only (decode step, per-layer launches, GEMM); skips the wide sweep written to gpurun_out/bench_extras.json")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"), help="collective back end of the N > 1 legs (nccl = RCCL; gloo only with --dry-run)")
+    ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the launcher / rendezvous / timed-region protocol under gloo: no kernel runs, value is null")
+    ap.add_argument("--sequential-gather", action="store_true", help="N > 1: all-gather on the compute stream after every pass instead of overlapped under the next pass")
     args = ap.parse_args()
 
+    import bench_sharded as bs
+    # The driver's contract names two ways of starting N ranks: `python -m torch.distributed.run ... bench.py --gpus N` (WORLD_SIZE set: this
+    # process IS a rank) and a bare `python bench.py --gpus N` (WORLD_SIZE unset: start the ranks here).  Round 5 parsed --gpus and never read it.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(bs.launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    if world != args.gpus and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world wins; n_gpus reports {world}", file=sys.stderr, flush=True)
+    if args.dry_run:
+        return bs.dry_run(args, world, rank)
+    if args.backend != "nccl":
+        raise SystemExit("bench.py measures on GPUs over RCCL (--backend nccl); gloo is for --dry-run only")
+    # BIE_BENCH_FORCE_DIST=1: a world of ONE goes through the whole multi-rank code path (RCCL group, overlapped gather, c5 leg) --
+    # the only way to execute that code on a one-GPU box; its numbers are not a scaling result
+    distributed = world > 1 or os.environ.get("BIE_BENCH_FORCE_DIST", "0") == "1"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible -- one process per GPU")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rccl = None
     if distributed:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if "RANK" not in os.environ:  # forced world of one without a launcher
+            os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_PORT=str(bs.free_port()))
+        bs.init_world("nccl", dev)
+        rccl = bs.world_proof(dev, world)
 
     B = Bench(dev)
     K, N, LAYERS = 4096, 4096, 96
@@ -854,42 +878,25 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     layers = [make_layer(dev, gen, K, N) for _ in range(LAYERS)]
     y_all = torch.empty((LAYERS, N), dtype=BF16, device=dev)  # row l = output of layer l
-    gathered = torch.empty((world * LAYERS, N), dtype=BF16, device=dev) if distributed else None  # rank-major
     plan = B.make_list(layers, K, N, gen, ys=[y_all[i:i + 1] for i in range(LAYERS)])  # every layer has its own x; ONE launch per pass
     # Single GPU: the K timed steps (K decode passes = K list launches) are ONE captured graph, replayed once -- a serving loop captures
     # a whole token step, not one launch, and a replay has a fixed cost of its own (10-16 us on this stack, MI355X_MICROARCH.md
     # "graph-replay-floor"; rocprofv3 shows 194 us of kernel inside a 210 us replay when every pass is its own replay).  Multi-GPU: a
-    # pass per replay, each followed by the all-gather of the ranks' outputs.
+    # pass per replay, each followed by ONE all-gather of the rank's 96 output rows, on a communication stream under the next pass.
     passes_per_replay = 1 if distributed else args.steps
     graph = capture(lambda st: [plan.forward(st) for _ in range(passes_per_replay)])
+    gather = bs.OverlappedGather(y_all, world, sequential=args.sequential_gather) if distributed else None
 
     def step():
         graph.replay()
         if distributed:
-            dist.all_gather_into_tensor(gathered, y_all)
+            gather()
 
-    def barrier():
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
+    barrier = bs.make_barrier(distributed, True)
 
     def timed_region():
         """EXACTLY K passes between two barriers: (wall seconds, max over ranks; GPU milliseconds between the events on this rank)."""
-        barrier()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        ev0.record()
-        for _ in range(args.steps if distributed else 1):  # one replay holds the K passes on a single GPU
-            step()
-        ev1.record()
-        barrier()
-        el = time.perf_counter() - t0
-        ms = ev0.elapsed_time(ev1)
-        if distributed:
-            t = torch.tensor([el], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        return el, ms
+        return bs.timed_region(step, args.steps, barrier, distributed, dev, replays=None if distributed else 1)
 
     for _ in range(args.warmup if distributed else max(1, -(-args.warmup // args.steps))):  # at least W warm-up passes
         step()
@@ -937,7 +944,9 @@ def main():
             "config": {"workload": f"BASELINE.json metric config: W4A16 qlinear {K}x{N} g128 bf16, M=1 decode pass over {LAYERS} distinct layers "
                                    f"({LAYERS * K * N // 2 / 1e9:.2f} GB packed), one layer-list launch per pass, K passes in one HIP graph",
                        "layers_per_step": LAYERS, "launches_per_step": 1,
-                       "parallelism": "output-column sharding x%d + 1 all-gather/step" % world if distributed else "single GPU"},
+                       "parallelism": ("%d ranks (one per GPU), each its own %d layers (weak scaling: independent output-column blocks), "
+                                       "1 RCCL all-gather of the step's outputs per step, %s") % (world, LAYERS, "sequential" if args.sequential_gather else "overlapped under the next pass")
+                       if distributed else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": (lambda t: None if t is None else t * LAYERS)(pmc_traffic(f"list{LAYERS}_{K}x{N}")),
                          "kernel": "bie::mpq_list_kernel<bf16,sym,M=1,rpg=16,w4,D16> (16-bit pair tables, ds_read_u16_d16_hi lookups, v_pk_fma_f32)", "avg_launch_us": round(avg_us, 3), "us_per_layer": round(avg_us / LAYERS, 3),
@@ -954,7 +963,7 @@ def main():
             "verified": verified,
         }
 
-    run_extras = rank == 0 and world == 1 and not args.no_extras and not args.only
+    run_extras = rank == 0 and not distributed and not args.no_extras and not args.only
     if run_extras:
         def guarded(key, fn):
             try:
@@ -1067,16 +1076,20 @@ def main():
 
     # ---- configs[4] sharded: 8192 x 28672, M = 4096, N / world column shards + all-gather (separate and overlapped)
     if distributed and not args.only:
-        from bitorch_engine.distributed import bench_column_sharded
-        try:  # reporting only: the headline line must come out whatever this leg does (it has run under gloo on CPU and on no RCCL node yet)
-            c5 = bench_column_sharded(B, world, rank, dev, M=4096, K=8192, N=28672, reps=5)
+        try:  # reporting only: the headline line must come out whatever these legs do (they have run under gloo on CPU and under a world of one)
+            rccl = bs.rccl_report(rccl, graph.replay, y_all, world, dev)
+        except Exception as e:
+            rccl = dict(rccl or {}, error=str(e)[:300])
+        try:
+            c5 = bs.bench_column_sharded(world, rank, dev, M=4096, K=8192, N=28672, reps=5)
         except Exception as e:
             c5 = {"error": str(e)[:300]}
         if rank == 0:
             extras["c5"] = c5
-            out["c5"] = {k: c5[k] for k in list(c5)[:12]} if isinstance(c5, dict) else c5
+            out["rccl"] = rccl
+            out["c5"] = {k: c5[k] for k in list(c5)[:14]} if isinstance(c5, dict) else c5
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.only:
+    if rank == 0 and not distributed and not args.no_cpu_baseline and not args.only:
         try:
             bl = cpu_baselines(layers[:2], plan_x(plan)[:2], y_all[:2])
             head = [b for b in bl if b["workload"] == "w4a16_gemv_M1_4096x4096"]

@@ -237,59 +237,3 @@ def _comm_stream(device):
         s = torch.cuda.Stream(device=device)
         _COMM_STREAMS[key] = s
     return s
-
-
-def bench_column_sharded(B, world: int, rank: int, dev, M: int = 4096, K: int = 8192, N: int = 28672, reps: int = 5, m_tile: int = 1024):
-    """bench.py's configs[4] leg: W4A16 K x N g128 bf16, M rows, the N output columns sharded over `world` ranks (strong scaling).
-    Times, with a barrier + synchronize on both sides and the MAX over ranks: the local GEMM alone, the all-gather alone,
-    GEMM + all-gather back to back, and the M-tiled overlapped schedule.  Aggregate TFLOP/s = 2*M*K*N / time."""
-    import time
-    lo, hi = column_range(N, rank, world)
-    gen = torch.Generator(device=dev).manual_seed(4242 + rank)
-    n_loc = hi - lo
-    qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // 8, n_loc), dtype=torch.int32, generator=gen, device=dev)
-    sc = (torch.rand((K // 128, n_loc), generator=gen, device=dev) * 0.01 + 0.005).to(torch.bfloat16)
-    ze = (sc.float() * torch.rand((K // 128, n_loc), generator=gen, device=dev) * 15).to(torch.bfloat16)
-    layer = ColumnShardedMPQLinear.__new__(ColumnShardedMPQLinear)
-    torch.nn.Module.__init__(layer)
-    layer.N, layer.rank, layer.world, layer.group = N, rank, world, None
-    layer.w_bit, layer.group_size, layer.asym = 4, 128, False
-    layer.ranges = [column_range(N, r, world) for r in range(world)]
-    layer.lo, layer.hi = lo, hi
-    for name, t in (("qweight", qw), ("scales", sc), ("zeros", ze), ("g_idx", None), ("bias", None)):
-        layer.register_buffer(name, t)
-    layer._impl = None
-    x = torch.randn((M, K), generator=torch.Generator(device=dev).manual_seed(7), device=dev).to(torch.bfloat16)
-    y_loc = layer.local_forward(x)
-    gathered = torch.empty((world * M, n_loc), dtype=torch.bfloat16, device=dev)
-
-    def timed(fn):
-        fn()
-        dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        torch.cuda.synchronize()
-        dist.barrier()
-        t = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item()) * 1e6
-
-    us_gemm = timed(lambda: layer.local_forward(x))
-    us_gather = timed(lambda: dist.all_gather_into_tensor(gathered, y_loc))
-    us_seq = timed(lambda: layer.forward(x))
-    us_ovl = timed(lambda: layer.forward_overlapped(x, m_tile))
-    us_ovl_rm = timed(lambda: layer.forward_overlapped(x, m_tile, interleave=False))
-    direct = {}
-    import os
-    if os.environ.get("BIE_BENCH_DIRECT", "0") == "1":  # opt-in: the grouped send/recv exchange has only ever run under gloo (CPU tests)
-        direct = {"us_direct_interleaved": round(timed(lambda: layer.forward_direct(x, m_tile)), 1),
-                  "us_direct_rank_major_zero_copy": round(timed(lambda: layer.forward_direct(x, m_tile, interleave=False)), 1)}
-    flops = 2.0 * M * K * N
-    return {**direct, "workload": f"BASELINE.json configs[4]: W4A16 {K}x{N} g128 bf16, M={M}, {world} column shards of {n_loc}",
-            "scaling": "strong", "us_local_gemm": round(us_gemm, 1), "us_all_gather": round(us_gather, 1),
-            "us_gemm_then_gather": round(us_seq, 1), "us_overlapped_m_tiles": round(us_ovl, 1),
-            "us_overlapped_rank_major_output": round(us_ovl_rm, 1), "m_tile": m_tile,
-            "TFLOP/s_aggregate_overlapped": round(flops / us_ovl / 1e6, 1), "TFLOP/s_aggregate_local_gemm_only": round(flops / us_gemm / 1e6, 1),
-            "gather_bytes_per_rank": M * n_loc * 2 * (world - 1)}

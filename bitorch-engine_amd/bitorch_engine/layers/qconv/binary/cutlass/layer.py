@@ -1,12 +1,36 @@
 """BinaryConv2dCutlass: mirror of reference layers/qconv/binary/cutlass/layer.py (activation scale/bias,
 int8 sign carriers, packed weights); see extensions/binary_conv2d_cutlass.py for the output convention."""
-import torch
+import typing
 
+import torch
+from torch.autograd import Function
+
+from bitorch_engine.utils import ste
 from bitorch_engine.utils.safe_import import import_extension
 from bitorch_engine.utils.model_helper import init_weight
 from ..layer import BinaryConv2dBase, BinaryConvParameter
 
 binary_conv2d_cutlass = import_extension("binary_conv2d_cutlass")
+
+
+class BinaryConv2dForward(Function):
+    """Binary convolution forward (this library's kernel) + straight-through backward (reference layer.py:57-110)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, scale_a, scale_w, is_train, kernel_size, stride, padding, dilation, run):
+        if is_train:
+            ctx.save_for_backward(x, weight, scale_w, scale_a)
+            ctx.geometry = (stride, padding, dilation)
+        out = run(x, weight, scale_a.item() * scale_w.item(), is_train, kernel_size, stride, padding, dilation)
+        return out.to(x.dtype)
+
+    @staticmethod
+    @typing.no_type_check
+    def backward(ctx, output_gradient):
+        x, weight, scale_w, scale_a = ctx.saved_tensors
+        stride, padding, dilation = ctx.geometry
+        grad_x, grad_w, grad_scale_a = ste.binary_conv_backward(output_gradient, x, weight, scale_a, scale_w, stride, padding, dilation)
+        return (grad_x, ste.integer_leaf_grad(weight, grad_w, ctx.needs_input_grad[1]), grad_scale_a) + (None,) * 7
 
 
 class BinaryConv2dCutlass(BinaryConv2dBase):
@@ -43,8 +67,14 @@ class BinaryConv2dCutlass(BinaryConv2dBase):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         self._check_forward(x)
+        ste.refuse_eval_grad(self, x)
         x = self.set_activation(x)
-        scale = self.scale_a.item() * self.scale_w.item()
         fwd = binary_conv2d_cutlass.forward_reference_convention if self.reference_convention else binary_conv2d_cutlass.forward
+        if ste.wants_grad(self):
+            if self.reference_convention:
+                raise RuntimeError("BinaryConv2dCutlass(reference_convention=True) is an inference compatibility mode: its NHWC / raw-popcount output has no "
+                                   "straight-through backward (the reference's own backward, layer.py:80-108, is that of the NCHW convolution)")
+            return BinaryConv2dForward.apply(x, self.opt_weight, self.scale_a, self.scale_w, True, self.kernel_size, self.stride, self.padding, self.dilation, fwd)
+        scale = self.scale_a.item() * self.scale_w.item()
         out = fwd(x, self.opt_weight, scale, self.training, self.kernel_size, self.stride, self.padding, self.dilation)
         return out.to(x.dtype)

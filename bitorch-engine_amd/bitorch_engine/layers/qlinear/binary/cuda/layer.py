@@ -1,13 +1,38 @@
 """BinaryLinearCuda: mirror of reference layers/qlinear/binary/cuda/layer.py.  out = (K - 2*popc) * scale_a *
 scale_w with the lazily initialised activation scale (2*mean|x|) and learnable activation bias."""
-import torch
+import typing
 
+import torch
+from torch.autograd import Function
+
+from bitorch_engine.utils import ste
 from bitorch_engine.utils.safe_import import import_extension
 from bitorch_engine.utils.model_helper import flatten_x, unflatten_x, init_weight
 from ..layer import BinaryLinearBase, BinaryLinearParameter
 from .bmm import BMM
 
 binary_linear_cuda = import_extension("binary_linear_cuda")
+
+
+class BinaryLinearForward(Function):
+    """Training-mode forward + straight-through backward (reference layer.py:67-120): the XNOR-popcount product is this library's
+    kernel, the backward is utils.ste.binary_linear_backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bmm_type, scale_a, scale_w, is_train):
+        x2, lead = flatten_x(x)
+        if is_train:
+            ctx.save_for_backward(x2, weight, scale_w, scale_a)
+        out = binary_linear_cuda.forward(x2, weight, bmm_type, True).to(x.dtype)
+        return unflatten_x(out, lead) * scale_a * scale_w
+
+    @staticmethod
+    @typing.no_type_check
+    def backward(ctx, output_gradient):
+        gy2, lead = flatten_x(output_gradient)
+        x2, weight, scale_w, scale_a = ctx.saved_tensors
+        grad_x, grad_w, grad_scale_a = ste.binary_linear_backward(gy2, x2, weight, scale_a, scale_w)
+        return unflatten_x(grad_x, lead), ste.integer_leaf_grad(weight, grad_w, ctx.needs_input_grad[1]), None, grad_scale_a, None, None
 
 
 class BinaryLinearCuda(BinaryLinearBase):
@@ -50,6 +75,10 @@ class BinaryLinearCuda(BinaryLinearBase):
     def forward(self, x: torch.Tensor, bmm_type: BMM = BMM.ADAPTIVE) -> torch.Tensor:
         self._check_forward(x)
         self.bmm_type = bmm_type
+        ste.refuse_eval_grad(self, x)
+        if ste.wants_grad(self):  # training: Function with the straight-through backward (x, bias_a through x, scale_a, the weight's carriers)
+            x = self.set_activation(x)
+            return BinaryLinearForward.apply(x, self.opt_weight, self.bmm_type.value, self.scale_a, self.scale_w, True)
         if not torch.is_grad_enabled() or not (x.requires_grad or self.bias_a.requires_grad or self.scale_a.requires_grad):
             # no gradient can flow (the fused output is detached from bias_a / scale_a: fine-tuning those under model.eval() must
             # take the differentiable composition below).  M <= 64 (<= 512 when K % 512 == 0): the whole layer (activation bias + sign-pack, XNOR-popcount,

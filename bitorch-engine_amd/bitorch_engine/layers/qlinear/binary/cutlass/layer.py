@@ -1,12 +1,60 @@
 """BinaryLinearCutlass / BinaryMatMul: mirror of reference layers/qlinear/binary/cutlass/layer.py.  The
 scale is folded into the kernel epilogue ((K - 2*popc) * scale_a * scale_w)."""
-import torch
+import typing
 
+import torch
+from torch.autograd import Function
+
+from bitorch_engine.utils import ste
 from bitorch_engine.utils.safe_import import import_extension
 from bitorch_engine.utils.model_helper import flatten_x, unflatten_x, init_weight
 from ..layer import BinaryLinearBase, BinaryLinearParameter
 
 binary_linear_cutlass = import_extension("binary_linear_cutlass")
+
+
+class BinaryLinearForward(Function):
+    """Forward with the scale in the kernel epilogue + straight-through backward (reference layer.py:62-126)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, scale_a, scale_w, gemm_kernel_id, is_train):
+        x2, lead = flatten_x(x)
+        if is_train:
+            ctx.save_for_backward(x2, weight, scale_w, scale_a)
+        scale = scale_a.item() * scale_w.item()  # host read, like the reference (one sync per call)
+        out = binary_linear_cutlass.forward(x2, weight, scale, False, gemm_kernel_id)
+        return unflatten_x(out, lead).to(x.dtype)
+
+    @staticmethod
+    @typing.no_type_check
+    def backward(ctx, output_gradient):
+        gy2, lead = flatten_x(output_gradient)
+        x2, weight, scale_w, scale_a = ctx.saved_tensors
+        grad_x, grad_w, grad_scale_a = ste.binary_linear_backward(gy2, x2, weight, scale_a, scale_w)
+        return unflatten_x(grad_x, lead), ste.integer_leaf_grad(weight, grad_w, ctx.needs_input_grad[1]), grad_scale_a, None, None, None
+
+
+class BinaryMatMulFunction(Function):
+    """sign(x) . sign(y)^T * x_clip * y_clip with the straight-through backward of both operands and both clips (reference layer.py:309-362)."""
+
+    @staticmethod
+    def forward(ctx, x, y, x_clip, y_clip):
+        ctx.save_for_backward(x, y, x_clip, y_clip)
+        k = x.size(-1)
+        pad = (-k) % 8  # pad K with -1 on x and +1 on y: each padded position contributes -1, corrected below
+        if pad:
+            x = torch.nn.functional.pad(x, (0, pad), value=-1.0)
+            y = torch.nn.functional.pad(y, (0, pad), value=1.0)
+        out = binary_linear_cutlass.matmul(x, y, 1.0) + float(pad)
+        return out.to(x.dtype) * x_clip * y_clip
+
+    @staticmethod
+    @typing.no_type_check
+    def backward(ctx, output_gradient):
+        x, y, x_clip, y_clip = ctx.saved_tensors
+        grad_x = output_gradient.matmul(y.sign() * y_clip) * ste.clip_masks(x, x_clip, -1.0, 1.0)[3]
+        grad_y = output_gradient.transpose(-1, -2).matmul(x.sign() * x_clip) * ste.clip_masks(y, y_clip, -1.0, 1.0)[3]
+        return grad_x, grad_y, ste.binary_scale_grad(grad_x, x.sign()), ste.binary_scale_grad(grad_y, y.sign())
 
 
 class BinaryLinearCutlass(BinaryLinearBase):
@@ -41,7 +89,10 @@ class BinaryLinearCutlass(BinaryLinearBase):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         self._check_forward(x)
+        ste.refuse_eval_grad(self, x)
         x = self.set_activation(x)
+        if ste.wants_grad(self):
+            return BinaryLinearForward.apply(x, self.opt_weight, self.scale_a, self.scale_w, self.gemm_kernel_id, True)
         x2, lead = flatten_x(x)
         scale = self.scale_a.item() * self.scale_w.item()  # host read, like the reference (one sync per call)
         out = binary_linear_cutlass.forward(x2, self.opt_weight.data, scale, False, self.gemm_kernel_id)
@@ -66,10 +117,4 @@ class BinaryMatMul(torch.nn.Module):
     def forward(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
         assert x.dim() > 2 and y.dim() > 2, "Expected tensor dim > 2, but got input_dim: '{}', other_dim: {}".format(x.dim(), y.dim())
         self.set_activation_scale(x, y)
-        k = x.size(-1)
-        pad = (-k) % 8  # pad K with -1 on x and +1 on y: each padded position contributes -1, corrected below
-        if pad:
-            x = torch.nn.functional.pad(x, (0, pad), value=-1.0)
-            y = torch.nn.functional.pad(y, (0, pad), value=1.0)
-        out = binary_linear_cutlass.matmul(x, y, 1.0) + float(pad)
-        return out.to(x.dtype) * self.x_clip * self.y_clip
+        return BinaryMatMulFunction.apply(x, y, self.x_clip, self.y_clip)

@@ -107,16 +107,25 @@ class MBWQLinearCuda(MPQLinearBase):
             state_dict[key] = q_linear_cuda.mbwq_exl2_stream_copy(module.qweight, module.rows)
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        before = (self.qweight.data_ptr(), self.qweight._version) if self.use_mbw else None
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
-        if prefix + "qweight" in state_dict:
-            self._forget_layout()
+        # forget only when the base class really wrote the tensor: a rejected load (shape mismatch -> error_msgs) leaves a prepared
+        # layer exactly as usable as it was
+        if self.use_mbw and prefix + "qweight" in state_dict and (self.qweight.data_ptr(), self.qweight._version) != before:
+            self._forget_layout(keep_group_map=prefix + "q_group_map" in state_dict)
 
-    def _forget_layout(self):
+    def _forget_layout(self, keep_group_map: bool = False):
         """qweight holds checkpoint streams again: no table of the private layout may stay attached to it (unpack_qweight and the static
-        *fp_weight helpers read qweight.rows): until prepare_params() runs, every exl2 call on this tensor fails on the table."""
+        *fp_weight helpers read qweight.rows): until prepare_params() runs, every exl2 call on this tensor fails on the table.
+        The group map goes too: it is a function of q_groups, and a second checkpoint with the same tensor shapes but another
+        bit allocation would otherwise get new rows and a new shuffle with the OLD map -- scales and zeros of the wrong groups, silently.
+        It stays only when the checkpoint itself supplied one."""
         self._exl2_mark = None
         self.rows = [0] * 7
         self.qweight.rows = None
+        if not keep_group_map:
+            self.q_group_map = None
+            self.qweight.q_group_map = None
 
     def check_parameters(self) -> None:
         assert self.dtype == torch.half, f"The value of dtype ({self.dtype}) must be torch.half."
@@ -158,7 +167,7 @@ class MBWQLinearCuda(MPQLinearBase):
                 # the module's own tensor untouched; adopt the value on the registered parameter / buffer itself
                 (own[name] if target is None else target).data = value.data
             if name == "qweight":
-                self._forget_layout()  # the checkpoint's streams: prepare_params() has to run (again)
+                self._forget_layout(keep_group_map="q_group_map" in state_dict)  # the checkpoint's streams: prepare_params() has to run (again)
         if not strict:
             missing = set(own.keys()) - set(state_dict.keys())
             if missing:

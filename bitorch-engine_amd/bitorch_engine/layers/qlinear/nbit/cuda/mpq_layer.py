@@ -169,6 +169,17 @@ def find_sibling_groups(model: torch.nn.Module) -> int:
     return n
 
 
+def clear_sibling_groups(model: torch.nn.Module) -> int:
+    """Detach every SiblingGroup below `model` (prepare_bie_layers(model, group_siblings=False)): each layer launches for itself again,
+    exactly the reference's call pattern (mpq_layer.py:206-224).  Returns the number of layers that were in a group."""
+    n = 0
+    for m in model.modules():
+        if getattr(m, "_bie_group", None) is not None:
+            m._bie_group = None
+            n += 1
+    return n
+
+
 class MPQLinearCudaFunction(Function):
     @staticmethod
     def forward(ctx, x, qweight, a_bit, w_bit, scales, zeros, g_idx, asym, is_training, privileged_grad=None):

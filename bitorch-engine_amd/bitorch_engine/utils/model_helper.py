@@ -2,7 +2,7 @@
 pad_embedding_dim (:54-82), pad_last_2_dims_to_multiple_of_128 (:85-117), binary_matmul_forward_post_processing (:120-155),
 prepare_bie_layers (:158-196), pack_bie_layers / save_checkpoint / load_checkpoint (:199-283), init_weight (:286-327)."""
 import math
-from typing import Tuple, Type
+from typing import Optional, Tuple, Type
 
 import torch
 import torch.nn.functional as F
@@ -60,9 +60,16 @@ def _bie_layer_kinds(with_embedding: bool):
     return tuple(kinds)
 
 
-def prepare_bie_layers(model: torch.nn.Module, layers=None) -> None:
+def prepare_bie_layers(model: torch.nn.Module, layers=None, group_siblings: Optional[bool] = None) -> None:
     """Call prepare_params() on every BIE layer below `model` (decode double-quantised statistics, build band tables, ...);
-    `layers` optionally restricts the layer classes -- reference :158-196."""
+    `layers` optionally restricts the layer classes -- reference :158-196.
+
+    group_siblings (this library only; the reference keeps no state between calls, layers/qlinear/nbit/cuda/mpq_layer.py:206-224):
+    True / None-with-BIE_AUTO_GROUP!=0 registers sibling layers that may share an input (q/k/v, gate/up) as candidate groups, so that an
+    unchanged module tree runs ONE grouped decode launch per set; False leaves every layer a launch of its own AND removes groups an
+    earlier call attached.  Grouping relies on one contract the reference does not need -- between the first and the last sibling call of
+    one parent forward, x must not be overwritten through `.data`, a raw pointer or any writer autograd's version counter does not see
+    ("Contract differences") -- pass False where that cannot be promised."""
     kinds = tuple(layers) if layers else _bie_layer_kinds(True)
     for i, module in enumerate(model.modules()):
         if i > 0 and isinstance(module, kinds):
@@ -71,10 +78,15 @@ def prepare_bie_layers(model: torch.nn.Module, layers=None) -> None:
     # their first forward passes confirm which of them really receive the same tensor, and from then on ONE grouped decode launch
     # serves them (layers/qlinear/nbit/cuda/mpq_layer.py::SiblingGroup).  The caller's code does not change.
     try:
-        from bitorch_engine.layers.qlinear.nbit.cuda.mpq_layer import find_sibling_groups
-        find_sibling_groups(model)
+        from bitorch_engine.layers.qlinear.nbit.cuda import mpq_layer
     except ImportError:
-        pass
+        return
+    if group_siblings is None:
+        group_siblings = mpq_layer.AUTO_GROUP
+    if group_siblings:
+        mpq_layer.find_sibling_groups(model)
+    else:
+        mpq_layer.clear_sibling_groups(model)
 
 
 def pack_bie_layers(model: torch.nn.Module, qweight_only: bool = True, layers=None) -> None:

@@ -253,6 +253,8 @@ def test_full_size_decode_gemv(K, N, dt):
         ref = t16(orc.mpq_forward(orc.torch_to_np(x), qw.numpy(), orc.torch_to_np(scales), orc.torch_to_np(zeros), None, 4, 128, 0, dt), dt)
         assert_close(y, ref, dt, f"full-size GEMV K={K} N={N} M={M}")
         rel_err_report(y, ref, f"decode GEMV {K}x{N} M={M} {'bf16' if dt == orc.BF16 else 'f16'}")
+        if dt == orc.F16:  # north_star's 1e-3 element by element on the lone decode launches too
+            assert_close_elementwise_f16(y, ref, f"full-size GEMV K={K} N={N} M={M} (lone launch, fp16)")
 
 
 @pytest.mark.parametrize("dt", [orc.BF16, orc.F16])
@@ -267,6 +269,8 @@ def test_full_size_prefill_gemm_sampled_rows(dt):
     rows = torch.tensor([0, 1, 31, 32, 255, 256, 1000, 2047, 2048, 3333, 4094, 4095])
     ref = t16(orc.mpq_forward(orc.torch_to_np(x[rows]), qw.numpy(), orc.torch_to_np(scales), orc.torch_to_np(zeros), None, 4, 128, 0, dt), dt)
     assert_close(y[rows.to(DEV)], ref, dt, "full-size GEMM sampled rows")
+    if dt == orc.F16:
+        assert_close_elementwise_f16(y[rows.to(DEV)], ref, "full-size GEMM M=4096 sampled rows (dense form, fp16)")
     # the same rows through a separate launch (different M tiling + split-K): same values up to fp32 summation order
     y2 = hip_forward(x[1024:1024 + 256], qw, scales, zeros, None, 4, 128, 0)
     assert_close(y2, y[1024:1024 + 256], dt, "rows must not depend on the M tile they land in")
@@ -591,6 +595,47 @@ def test_exl2_state_dict_is_the_reference_format_and_a_reloaded_tensor_is_prepar
     layer.to(DEV)
     assert torch.equal(layer(x), y0)
     assert torch.equal(layer.state_dict()["qweight"].cpu(), qw)
+
+
+def test_exl2_second_checkpoint_with_another_bit_allocation_gets_its_own_group_map(tmp_path):
+    """a checkpoint with the SAME tensor shapes but different q_groups, loaded into an already prepared layer.  The
+    second prepare_params() must rebuild the group map (it used to keep the first checkpoint's: scales / zeros of the wrong groups, silently);
+    a REJECTED load (wrong shape through the nn.Module machinery) must leave the prepared layer working."""
+    K, N = 512, 192
+    spec_a = [(4, 128), (3, 128), (3, 128), (2, 128)]   # 16 + 12 + 12 + 8 = 48 packed rows, 4 groups
+    spec_b = [(4, 64), (4, 192), (2, 128), (2, 128)]    #  8 + 24 +  8 + 8 = 48 packed rows, 4 groups: same shapes, other groups
+    a, qw_a, qg_a = _exl2_layer(K, N, spec_a, torch.Generator().manual_seed(5))
+    b, qw_b, qg_b = _exl2_layer(K, N, spec_b, torch.Generator().manual_seed(6))
+    assert a.qweight.shape == b.qweight.shape and a.scales.shape == b.scales.shape and qg_a != qg_b
+    sd_b = {k: v.clone() for k, v in b.state_dict().items()}       # b is unprepared: its state_dict IS the checkpoint
+    b.eval().to(DEV)
+    b.prepare_params()
+    x = torch.randn((2, K), generator=torch.Generator().manual_seed(7)).half().to(DEV)
+    want_b = b(x).clone()
+    ref = orc.np_to_torch(orc.gemm(orc.torch_to_np(x.cpu()), orc.exl2_dequant(qw_b.numpy(), orc.torch_to_np(b.scales.cpu()), orc.torch_to_np(b.zeros.cpu()),
+                                                                               b.q_perm.cpu().numpy(), np.array(qg_b, np.int16), K), orc.F16), torch.half)
+    assert_close(want_b.cpu(), ref, orc.F16, "exl2 layer b against the oracle")
+    a.eval().to(DEV)
+    a.prepare_params()
+    map_a = a.q_group_map.clone()
+    y_a = a(x).clone()
+    # a load the base class rejects: the layer keeps working (it used to refuse forward() AND prepare_params())
+    bad = {"0." + k: v for k, v in sd_b.items()}
+    bad["0.qweight"] = torch.zeros((47, N), dtype=torch.int32)
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        torch.nn.Sequential(a).load_state_dict(bad)
+    # (the other keys of `bad` were copied: put a's own back before comparing)
+    a.load_state_dict({k: v for k, v in _exl2_layer(K, N, spec_a, torch.Generator().manual_seed(5))[0].state_dict().items() if k != "qweight"}, strict=False)
+    assert a._exl2_current() and torch.equal(a(x), y_a)
+    # the second checkpoint, through the nn.Module machinery
+    torch.nn.Sequential(a).load_state_dict({"0." + k: v for k, v in sd_b.items()})
+    assert a.q_group_map is None and a.qweight.q_group_map is None
+    with pytest.raises(RuntimeError, match="prepare_params"):
+        a(x)
+    a.prepare_params()
+    assert not torch.equal(a.q_group_map.cpu(), map_a.cpu())
+    assert torch.equal(a.q_group_map.cpu(), b.q_group_map.cpu())
+    assert torch.equal(a(x), want_b)
 
 
 @pytest.mark.parametrize("name", ["g64_g128_ragged", "one_group_per_band", "mixed_sizes", "g16", "g96"])
@@ -1199,6 +1244,27 @@ def test_grouped_forward_matches_separate_calls_and_oracle():
                 assert torch.equal(y, single) or dt == orc.BF16, "fallback path must equal separate calls bit for bit"
 
 
+@pytest.mark.parametrize("K,widths", [(4096, (4096, 4096, 4096)), (4096, (11008, 11008))])
+def test_full_size_grouped_launches_fp16_element_wise(K, widths):
+    """the grouped decode launches at the Llama-7B shapes (q/k/v, gate/up), fp16 (GreenBit's checkpoint dtype), against
+    the oracle norm-wise AND element by element (1e-3 relative + one fp16 ulp on every output with |ref| >= 2^-6 max|ref|)."""
+    from bitorch_engine.extensions import q_linear_cuda
+    dt = orc.F16
+    for M in (1, 4):
+        sets, refs, x = [], [], None
+        for i, N in enumerate(widths):
+            rng = np.random.default_rng(77 * i + N + M)
+            qw, scales, zeros, gen = rand_case(rng, K, N, 4, 128, dt, 0)
+            if x is None:
+                x = torch.randn((M, K), generator=gen).to(TDT[dt])
+            sets.append(tuple(None if t is None else t.to(DEV) for t in (qw, scales, zeros, None)))
+            refs.append(oracle_forward(x, qw, scales, zeros, None, 4, 128, 0, dt))
+        ys = q_linear_cuda.mpq_forward_grouped_impl(x.to(DEV), sets, 4, 0, 128)
+        for i, (y, r) in enumerate(zip(ys, refs)):
+            assert_close(y, r, dt, f"grouped full-size fp16 M={M} member {i}")
+            assert_close_elementwise_f16(y, r, f"grouped full-size fp16 {K}x{widths[i]} M={M} member {i}")
+
+
 def test_layer_level_grouped_forward_equals_the_separate_layers():
     """MPQLinearCuda.forward_grouped: q/k/v-style layers sharing x through one grouped launch against each layer's own forward (same
     table values; the K-split plan of the larger grid may differ, hence the summation-order tolerance), and the fallback for a set
@@ -1634,6 +1700,98 @@ def test_sibling_projections_fed_freed_temporaries_are_never_grouped(kind):
     assert not layers[0]._bie_group.trace and not layers[0]._bie_group.parked
 
 
+def _shared_x_attention(tdt, gen, H=512, gs=128):
+    """q/k/v MPQ layers under one parent that all receive the SAME tensor; k_proj is called after `between(x)` ran on it."""
+    from bitorch_engine.layers.qlinear.nbit.cuda import MPQLinearCuda
+
+    def lin():
+        layer = MPQLinearCuda(H, H, w_bit=4, dtype=tdt, group_size=gs, dq_group_size=32, use_gba_quant=True, asym=False)
+        layer.qweight.data = torch.randint(-2 ** 31, 2 ** 31 - 1, layer.qweight.shape, generator=gen, dtype=torch.int64).to(torch.int32)
+        return layer
+
+    class Attn(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.q_proj, self.k_proj, self.v_proj = lin(), lin(), lin()
+            self.between = None
+
+        def forward(self, x):
+            q = self.q_proj(x)
+            if self.between is not None:
+                self.between(x)
+            return q, self.k_proj(x), self.v_proj(x)
+
+    return Attn()
+
+
+def _prepare_shared_x_attention(model, tdt, gen, **kw):
+    from bitorch_engine.utils.model_helper import prepare_bie_layers
+    prepare_bie_layers(model, **kw)
+    for m in model.children():
+        m.scales = (torch.rand(m.scales.shape, generator=gen) * 0.004 + 0.002).to(tdt)
+        m.zeros = (m.scales.float() * 7.5).to(tdt)
+    model.to(DEV).eval()
+
+
+@pytest.mark.xfail(strict=True, reason="documented contract difference (INTEGRATION.md, 'Sibling grouping holds x by identity'): a write to x through .data "
+                                       "between two sibling calls is invisible to the version counter the group keys on, so the second sibling is served "
+                                       "the output for the OLD contents; switch: prepare_bie_layers(model, group_siblings=False) / BIE_AUTO_GROUP=0")
+def test_sibling_group_cannot_see_a_write_through_dot_data():
+    """pins TODAY's behaviour.  The assertion is what a stateless caller (the reference, mpq_layer.py:206-224)
+    would see -- k_proj(x) computed on the doubled x -- and it fails, strictly, while the grouping keys on identity."""
+    from bitorch_engine.layers.qlinear.nbit.cuda import mpq_layer
+    g = torch.Generator().manual_seed(41)
+    model = _shared_x_attention(torch.bfloat16, g)
+    _prepare_shared_x_attention(model, torch.bfloat16, g)
+    with torch.no_grad():
+        for _ in range(2):  # observe, confirm
+            model(torch.randn((1, 512), generator=g).bfloat16().to(DEV))
+        assert mpq_layer.GROUP_STATS["groups_confirmed"] >= 1
+        x = torch.randn((1, 512), generator=g).bfloat16().to(DEV)
+        model.between = lambda t: t.data.mul_(2)
+        _, k, _ = model(x)                       # x now holds 2 * the values q_proj saw
+        model.between = None
+        for l in model.children():
+            l._bie_group = None
+        want = model.k_proj(x)                   # its own launch on the CURRENT contents
+    assert torch.equal(k, want)
+
+
+def test_group_siblings_false_is_the_reference_call_pattern_and_sees_every_write():
+    """prepare_bie_layers(model, group_siblings=False): no group is attached (and groups of an earlier call are removed); every layer launches
+    for itself, so the `.data` write between sibling calls is seen; the same write through a version-bumping in-place op is seen WITH groups."""
+    from bitorch_engine.layers.qlinear.nbit.cuda import mpq_layer
+    from bitorch_engine.utils.model_helper import prepare_bie_layers
+    g = torch.Generator().manual_seed(42)
+    model = _shared_x_attention(torch.bfloat16, g)
+    _prepare_shared_x_attention(model, torch.bfloat16, g, group_siblings=False)
+    layers = list(model.children())
+    assert all(l._bie_group is None for l in layers)
+    mpq_layer.GROUP_STATS.update({k: 0 for k in mpq_layer.GROUP_STATS})
+    with torch.no_grad():
+        for _ in range(3):
+            model(torch.randn((1, 512), generator=g).bfloat16().to(DEV))
+        assert mpq_layer.GROUP_STATS["groups_confirmed"] == 0 and mpq_layer.GROUP_STATS["grouped_launches"] == 0
+        x = torch.randn((1, 512), generator=g).bfloat16().to(DEV)
+        model.between = lambda t: t.data.mul_(2)
+        _, k, _ = model(x)
+        model.between = None
+        assert torch.equal(k, model.k_proj(x))
+        # with groups: a write autograd sees (x.mul_) changes the key -- k_proj leaves the set and runs on the new contents
+        mpq_layer.find_sibling_groups(model)
+        assert all(l._bie_group is not None for l in layers)
+        for _ in range(2):
+            model(torch.randn((1, 512), generator=g).bfloat16().to(DEV))
+        assert mpq_layer.GROUP_STATS["groups_confirmed"] >= 1
+        x = torch.randn((1, 512), generator=g).bfloat16().to(DEV)
+        model.between = lambda t: t.mul_(2)
+        _, k, v = model(x)
+        model.between = None
+        prepare_bie_layers(model, layers=[torch.nn.Identity], group_siblings=False)   # detaches; prepares nothing (no Identity below)
+        assert all(l._bie_group is None for l in layers)
+        assert torch.equal(k, model.k_proj(x)) and torch.equal(v, model.v_proj(x))
+
+
 @pytest.mark.parametrize("shape", [(1024, 4096, 1024, 4096, 256), (256, 512, 384, 1024, 64), (192, 2048, 3584, 28672, 7168), (40, 512, 256, 768, 512), (4, 512, 256, 768, 0)])
 def test_forward_into_a_column_range_of_a_wider_output(shape):
     """bie_mpq_forward_pitched (a column shard's GEMM epilogue stores straight into out[:, lo:hi]): the pitched result is
@@ -1953,6 +2111,8 @@ def test_full_size_exl2_w3w2_random_perm(K, N):
         y = q_linear_cuda.mbwq_exl2_forward(d(x), qs, d(scales), d(zeros), d(q_perm), d(gmap), rows, False)
         ref = t16(orc.gemm(orc.torch_to_np(x), Wo, orc.F16), orc.F16)
         assert_close(y, ref, orc.F16, f"exl2 w3/w2 {K}x{N} M={M}")
+        rel_err_report(y, ref, f"exl2 w3/w2 {K}x{N} M={M}")
+        assert_close_elementwise_f16(y, ref, f"exl2 w3/w2 {K}x{N} M={M} (fp16, element-wise)")
     # prefill at BASELINE's M = 4096 (fragment image + x[:, q_perm] + dense MFMA GEMM): sampled rows against the oracle's product with the
     # bit-exact weight matrix, every row finite
     x = torch.randn((4096, K), generator=gen).half()
@@ -1961,6 +2121,7 @@ def test_full_size_exl2_w3w2_random_perm(K, N):
     pick = [0, 1, 255, 256, 2047, 3000, 4095]
     ref = t16(orc.gemm(orc.torch_to_np(x[pick]), Wo, orc.F16), orc.F16)
     assert_close(y[pick], ref, orc.F16, f"exl2 w3/w2 {K}x{N} M=4096 (sampled rows)")
+    assert_close_elementwise_f16(y[pick], ref, f"exl2 w3/w2 {K}x{N} M=4096 prefill form (fp16, element-wise)")
 
 
 # ------------------------------------------------------------------------------------------------ section 8f: embedding, BMHA, checkpoints
@@ -2373,8 +2534,8 @@ def test_the_list_instances_bench_py_times_against_the_oracle(K, N, nl, w_bit, t
         qw, sc, ze = (t.cpu() for t in layers[i])
         ref = oracle_forward(xs[i].cpu(), qw, sc, ze, None, w_bit, 128, 0, dt)
         assert_close(y_all[i:i + 1], ref, dt, f"bench list instance {nl} x {K}x{N} w{w_bit} {tdt}, layer {i}")
-        if tdt == "f16":  # the fp16 W4 lists run the ALGEBRAIC form (no per-weight fp16 rounding): held to north_star's 1e-3 element by element
-            rel_err_report(y_all[i:i + 1], ref, f"f16 list {nl} x {K}x{N} w{w_bit} layer {i} (algebraic form where w_bit == 4)")
+        if tdt == "f16":  # the DEFAULT fp16 lists (exact 16-bit-table form; the algebraic form is opt-in and has its own test below): north_star's 1e-3 element by element
+            rel_err_report(y_all[i:i + 1], ref, f"f16 list {nl} x {K}x{N} w{w_bit} layer {i} (default exact-table form)")
             assert_close_elementwise_f16(y_all[i:i + 1], ref, f"f16 list {nl} x {K}x{N} w{w_bit}, layer {i}")
 
 
