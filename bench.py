@@ -183,13 +183,13 @@ class Bench:
                              "frac": round(b / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(f"{k}x{n}") if (M == 1 and w_bit == 4) else None}}
 
     # ---- ONE launch over a list of layers (bie_mpq_list_*): `per_launch` entries per launch, optional dependent chains
-    def make_list(self, layers, k, n, gen, M=1, chain=0, w_bit=WBIT, ys=None):
+    def make_list(self, layers, k, n, gen, M=1, chain=0, w_bit=WBIT, ys=None, xs=None):
         from bitorch_engine.layers.qlinear.nbit.cuda import MPQForwardList
         entries = []
         dt = layers[0][1].dtype
         for i, (qw, sc, ze) in enumerate(layers):
             dep = i - 1 if (chain and i % chain) else -1
-            x = entries[-1]["y"] if dep >= 0 else torch.randn((M, k), generator=gen, device=self.dev).to(dt)
+            x = entries[-1]["y"] if dep >= 0 else (xs[i] if xs is not None else torch.randn((M, k), generator=gen, device=self.dev).to(dt))
             y = ys[i] if ys is not None else torch.empty((M, n), dtype=dt, device=self.dev)
             entries.append({"x": x, "qweight": qw, "scales": sc, "zeros": ze, "y": y, "depends_on": dep})
         return MPQForwardList(entries, w_bit=w_bit, group_size=GROUP)
@@ -877,14 +877,18 @@ def main():
         LAYERS = max(8, min(96, int(800e6 // (K * N // 2))))
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     layers = [make_layer(dev, gen, K, N) for _ in range(LAYERS)]
-    y_all = torch.empty((LAYERS, N), dtype=BF16, device=dev)  # row l = output of layer l
-    plan = B.make_list(layers, K, N, gen, ys=[y_all[i:i + 1] for i in range(LAYERS)])  # every layer has its own x; ONE launch per pass
     # Single GPU: the K timed steps (K decode passes = K list launches) are ONE captured graph, replayed once -- a serving loop captures
     # a whole token step, not one launch, and a replay has a fixed cost of its own (10-16 us on this stack, MI355X_MICROARCH.md
-    # "graph-replay-floor"; rocprofv3 shows 194 us of kernel inside a 210 us replay when every pass is its own replay).  Multi-GPU: a
-    # pass per replay, each followed by ONE all-gather of the rank's 96 output rows, on a communication stream under the next pass.
-    passes_per_replay = 1 if distributed else args.steps
-    graph = capture(lambda st: [plan.forward(st) for _ in range(passes_per_replay)])
+    # "graph-replay-floor"; rocprofv3 shows 194 us of kernel inside a 210 us replay when every pass is its own replay).
+    # Multi-GPU: C passes per replay (C = the largest divisor of K up to 10), pass c writing its own 96 rows of a [C x 96, N] bucket, then
+    # ONE all-gather of the bucket on a communication stream under the next replay: fewer, larger collectives (7.9 MB per rank at C = 10
+    # instead of ten of 786 KB), and RCCL's enqueue cost (tens of microseconds of host time) is paid once per C steps.
+    chunk = max(c for c in range(1, 11) if args.steps % c == 0) if distributed else 1
+    y_all = torch.empty((chunk * LAYERS, N), dtype=BF16, device=dev)  # row c * LAYERS + l = output of layer l in pass c of a replay
+    plan = B.make_list(layers, K, N, gen, ys=[y_all[i:i + 1] for i in range(LAYERS)])  # every layer has its own x; ONE launch per pass
+    plans = [plan] + [B.make_list(layers, K, N, gen, ys=[y_all[c * LAYERS + i:c * LAYERS + i + 1] for i in range(LAYERS)], xs=plan_x(plan)) for c in range(1, chunk)]
+    passes_per_replay = chunk if distributed else args.steps
+    graph = capture(lambda st: [plans[c % chunk].forward(st) for c in range(passes_per_replay)])
     gather = bs.OverlappedGather(y_all, world, sequential=args.sequential_gather) if distributed else None
 
     def step():
@@ -896,9 +900,9 @@ def main():
 
     def timed_region():
         """EXACTLY K passes between two barriers: (wall seconds, max over ranks; GPU milliseconds between the events on this rank)."""
-        return bs.timed_region(step, args.steps, barrier, distributed, dev, replays=None if distributed else 1)
+        return bs.timed_region(step, args.steps, barrier, distributed, dev, replays=args.steps // chunk if distributed else 1)
 
-    for _ in range(args.warmup if distributed else max(1, -(-args.warmup // args.steps))):  # at least W warm-up passes
+    for _ in range(-(-args.warmup // chunk) if distributed else max(1, -(-args.warmup // args.steps))):  # at least W warm-up passes
         step()
     # The W warm-up passes last about a millisecond and the K timed ones a few: timed right here the region runs at the clock of a
     # chip that was idle through the host-side set-up.  That cold figure is reported (`cold_start`), then the same passes are replayed
@@ -914,7 +918,7 @@ def main():
             torch.cuda.synchronize()
     if distributed:  # every rank the same number of collectives
         pre_n = max(1, int(pre_s / max(cold_elapsed, 1e-4)))
-        for _ in range(pre_n * args.steps):
+        for _ in range(pre_n * (args.steps // chunk)):
             step()
     # not one lucky region -- BIE_BENCH_REGIONS (5) timed regions of exactly K passes each, back to back; `value` is the
     # MEDIAN region (wall, max over ranks), the fastest and slowest ones and the cold one are reported beside it
@@ -929,7 +933,7 @@ def main():
     # ---- self-check of the TIMED launch: every row of y_all against the per-layer entry point on the same layer and x
     verified = None
     if rank == 0:
-        verified = verify_list_outputs(B, plan, layers, y_all, K, N)
+        verified = all(verify_list_outputs(B, plans[c], layers, y_all[c * LAYERS:(c + 1) * LAYERS], K, N) for c in sorted({0, chunk - 1}))
 
     out, extras = None, {}
     if rank == 0:
@@ -945,7 +949,7 @@ def main():
                                    f"({LAYERS * K * N // 2 / 1e9:.2f} GB packed), one layer-list launch per pass, K passes in one HIP graph",
                        "layers_per_step": LAYERS, "launches_per_step": 1,
                        "parallelism": ("%d ranks (one per GPU), each its own %d layers (weak scaling: independent output-column blocks), "
-                                       "1 RCCL all-gather of the step's outputs per step, %s") % (world, LAYERS, "sequential" if args.sequential_gather else "overlapped under the next pass")
+                                       "1 bucketed RCCL all-gather of the outputs of %d steps, %s") % (world, LAYERS, chunk, "sequential" if args.sequential_gather else "overlapped under the next replay")
                        if distributed else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": (lambda t: None if t is None else t * LAYERS)(pmc_traffic(f"list{LAYERS}_{K}x{N}")),
@@ -1077,7 +1081,7 @@ def main():
     # ---- configs[4] sharded: 8192 x 28672, M = 4096, N / world column shards + all-gather (separate and overlapped)
     if distributed and not args.only:
         try:  # reporting only: the headline line must come out whatever these legs do (they have run under gloo on CPU and under a world of one)
-            rccl = bs.rccl_report(rccl, graph.replay, y_all, world, dev)
+            rccl = bs.rccl_report(rccl, graph.replay, y_all, world, dev, passes_per_step=chunk)
         except Exception as e:
             rccl = dict(rccl or {}, error=str(e)[:300])
         try:
@@ -1091,7 +1095,7 @@ def main():
 
     if rank == 0 and not distributed and not args.no_cpu_baseline and not args.only:
         try:
-            bl = cpu_baselines(layers[:2], plan_x(plan)[:2], y_all[:2])
+            bl = cpu_baselines(layers[:2], plan_x(plan)[:2], y_all[:2])  # rows of pass 0
             head = [b for b in bl if b["workload"] == "w4a16_gemv_M1_4096x4096"]
             best = dict(max(head, key=lambda b: b["value"]))  # the headline shape at its best thread count ...
             best["threads_used"] = best["cores"]

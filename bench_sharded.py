@@ -131,9 +131,10 @@ class OverlappedGather:
         return self.y_all.numel() * self.y_all.element_size() * (w - 1)
 
 
-def rccl_report(proof, replay_one_pass, y_all, world: int, dev, reps: int = 20):
-    """The `rccl` object of the JSON line: the all-gather alone, one pass alone, pass + gather back to back on one stream, and the
-    overlapped schedule the timed region uses -- each `reps` times between barriers, MAX over ranks, microseconds per step."""
+def rccl_report(proof, replay_one_pass, y_all, world: int, dev, reps: int = 20, passes_per_step: int = 1):
+    """The `rccl` object of the JSON line: the all-gather alone, one replay (`passes_per_step` passes) alone, replay + gather back to back on
+    one stream, and the overlapped schedule the timed region uses -- each `reps` times between barriers, MAX over ranks, microseconds per
+    REPLAY (divide by passes_per_replay for a step)."""
     barrier = make_barrier(True, dev.type == "cuda")
 
     def us(step):
@@ -142,12 +143,13 @@ def rccl_report(proof, replay_one_pass, y_all, world: int, dev, reps: int = 20):
         return round(el / reps * 1e6, 2)
     seq, ovl = OverlappedGather(y_all, world, sequential=True), OverlappedGather(y_all, world)
     out = dict(proof)
+    out["passes_per_replay"] = passes_per_step
     out["all_gather_bytes_per_rank"] = ovl.bytes_per_rank
     out["us_all_gather_alone"] = us(seq)
-    out["us_pass_alone"] = us(replay_one_pass)
-    out["us_step_sequential"] = us(lambda: (replay_one_pass(), seq()))
-    out["us_step_overlapped"] = us(lambda: (replay_one_pass(), ovl()))
-    out["schedule_timed"] = "overlapped (snapshot + all-gather on a communication stream under the next pass)"
+    out["us_replay_alone"] = us(replay_one_pass)
+    out["us_replay_then_gather"] = us(lambda: (replay_one_pass(), seq()))
+    out["us_replay_gather_overlapped"] = us(lambda: (replay_one_pass(), ovl()))
+    out["schedule_timed"] = "overlapped (bucket snapshot + ONE all-gather per replay on a communication stream, under the next replay)"
     return out
 
 
