@@ -663,9 +663,11 @@ def bench_binary(dev, L):
         try:
             us = time_graph(capture(fn), 20) / 16
             tops = 2.0 * B * 49 * 512 * 4608 / us / 1e6
-            fp4 = B * 49 >= 1024  # the dispatch of extensions/_binary_common.py::conv2d: large batches run as an FP4 GEMM on the matrix pipe
+            from bitorch_engine.extensions import _binary_common as bc
+            fused = B * 49 <= bc.conv_fused_max_rows()  # the dispatch of extensions/_binary_common.py::conv2d: ONE launch (sign-pack into LDS + XNOR-popcount) up to that many pixels
+            fp4 = not fused and B * 49 >= 1024          # beyond: the FP4 GEMM on the matrix pipe (three launches)
             peak = FP4_MFMA_PEAK_TOPS if fp4 else XOR_POPC_PEAK_TOPS
-            out.append({"op": "binary conv 512->512 3x3 on 7x7", "B": B, "us_per_call": round(us, 2), "TOP/s": round(tops, 2),
+            out.append({"op": "binary conv 512->512 3x3 on 7x7", "B": B, "us_per_call": round(us, 2), "TOP/s": round(tops, 2), "launches": 1 if fused else (3 if fp4 else 2),
                         "roofline": {"bound": "mfma fp4 (bits + image passes included in the time)" if fp4 else "valu xor+bcnt", "achieved": round(tops, 2),
                                      "peak": peak, "unit": "TOP/s", "frac": round(tops / peak, 5), "traffic": None}})
         except Exception as e:  # reporting only

@@ -79,6 +79,12 @@ SIGNATURES = {
     "bie_binary_conv2d_taps_ok": (_i, [_i] * 3),
     "bie_binary_conv_weight_taps": (_i, [_vp, _vp] + [_i] * 3 + [_vp]),
     "bie_binary_conv2d_forward_taps": (_i, [_vp] * 4 + [_sz] + [_i] * 9 + [_f, _i, _vp]),
+    "bie_binary_conv2d_mfma_ok": (_i, [_i] * 9),
+    "bie_binary_conv2d_forward_mfma": (_i, [_vp] * 3 + [_i] * 9 + [_f, _i, _vp]),
+    "bie_binary_conv2d_fused_ok": (_i, [_i] * 9),
+    "bie_binary_conv_weight_lanes_bytes": (_sz, [_i] * 3),
+    "bie_binary_conv_weight_lanes": (_i, [_vp, _vp] + [_i] * 3 + [_vp]),
+    "bie_binary_conv2d_forward_fused": (_i, [_vp] * 3 + [_i] * 9 + [_f, _i, _vp]),
     "bie_pack_sign_u8": (_i, [_vp, _vp, _l, _i, _vp]),
     "bie_unpack_u8_scaled": (_i, [_vp, _vp, _vp, _l, _l, _vp]),
     "bie_q4_pack": (_i, [_vp, _vp, _l, _vp]),

@@ -174,6 +174,33 @@ def conv_weight_taps(wpacked, OC, C, ksize):
     return _cached(wpacked, ("taps", OC, C, ksize), convert)
 
 
+def conv_weight_lanes(wpacked, OC, C, ksize):
+    """Lane-major image of the tap words for the one-launch conv (bie_binary_conv_weight_lanes), remembered on the packed tensor."""
+    from .q_linear_cuda import _cached
+
+    def convert():
+        L = _hip.lib()
+        out = torch.empty((L.bie_binary_conv_weight_lanes_bytes(OC, C, ksize) // 4,), dtype=torch.int32, device=wpacked.device)
+        rc = L.bie_binary_conv_weight_lanes(_hip.ptr(conv_weight_taps(wpacked, OC, C, ksize)), _hip.ptr(out), OC, C, ksize, _hip.stream())
+        _hip.check(rc, "bie_binary_conv_weight_lanes")
+        return out
+    return _cached(wpacked, ("lanes", OC, C, ksize), convert)
+
+
+def conv_fused_max_rows() -> int:
+    """Largest number of output pixels (B * OH * OW) the one-launch VALU form serves before the one-launch matrix-pipe form takes over
+    (BIE_CONV_FUSED_MAX_ROWS; 0 = that form off)."""
+    v = os.environ.get("BIE_CONV_FUSED_MAX_ROWS")
+    return int(v) if v else 392
+
+
+def conv_mfma_max_rows() -> int:
+    """Largest number of output pixels the one-launch matrix-pipe form serves (BIE_CONV_MFMA_MAX_ROWS; 0 = off: the three-launch FP4 GEMM
+    / the tap kernels of round 5)."""
+    v = os.environ.get("BIE_CONV_MFMA_MAX_ROWS")
+    return int(v) if v else 1 << 30
+
+
 def conv_fp4_min_rows() -> int:
     """Smallest number of output pixels (B * OH * OW) the matrix-pipe form of the conv serves (BIE_FP4_CONV_MIN_ROWS; 0 = off).
     Measured on the ResNet-18 stage shapes (profiles/r03_fp4_g_conv_ab.txt, r03_fp4_h_tile64.txt): with the 128 x 64 GEMM tile for small
@@ -197,6 +224,22 @@ def conv2d(x, wpacked, OC, ksize, stride, pad, dil, scale):
     OW = (W + 2 * pad - dil * (ksize - 1) - 1) // stride + 1
     y = torch.empty((B, OC, OH, OW), dtype=torch.float32, device=x.device)
     L = _hip.lib()
+    if (B * OH * OW <= conv_fused_max_rows() and x.dtype in _hip._DT and (C * ksize * ksize) % 8 == 0
+            and L.bie_binary_conv2d_fused_ok(B, C, H, W, OC, ksize, stride, pad, dil)):
+        # ONE launch, no workspace: sign-pack into LDS + register-resident weights + XNOR-popcount (binary_conv_fused.hip)
+        wl = conv_weight_lanes(wpacked, OC, C, ksize)
+        rc = L.bie_binary_conv2d_forward_fused(_hip.ptr(x), _hip.ptr(wl), _hip.ptr(y), B, C, H, W, OC, ksize, stride, pad, dil, float(scale), _hip.dt(x),
+                                               _hip.stream())
+        _hip.check(rc, "bie_binary_conv2d_forward_fused")
+        return y
+    if (B * OH * OW <= conv_mfma_max_rows() and x.dtype in _hip._DT and (C * ksize * ksize) % 8 == 0
+            and L.bie_binary_conv2d_mfma_ok(B, C, H, W, OC, ksize, stride, pad, dil)):
+        # ONE launch on the matrix pipe: FP4 image of the input rows in LDS, pixel fragments gathered tap by tap (binary_conv_fused.hip)
+        wimg = conv_weight_fp4_image(wpacked, OC, C, ksize)
+        rc = L.bie_binary_conv2d_forward_mfma(_hip.ptr(x), _hip.ptr(wimg), _hip.ptr(y), B, C, H, W, OC, ksize, stride, pad, dil, float(scale), _hip.dt(x),
+                                              _hip.stream())
+        _hip.check(rc, "bie_binary_conv2d_forward_mfma")
+        return y
     rows_min = conv_fp4_min_rows()
     if rows_min and C % 32 == 0 and B * OH * OW >= rows_min and OC >= 64 and x.dtype in _hip._DT:
         # large batch: the conv as a GEMM on the matrix pipe (+-1 as FP4 MFMA operands), bit-identical

@@ -94,6 +94,15 @@ int binary_conv_taps_launch(const void* x, const uint32_t* wtaps, float* y, void
                             int stride, int pad, int dil, float scale, int dtype, hipStream_t st);
 int binary_linear_launch(const uint8_t* xp, const uint8_t* wp, float* y, long M, long N, long K, int w_layout, float scale,
                          hipStream_t st);
+// binary_conv_fused.hip
+bool binary_conv_fused_ok(int B, int C, int H, int W, int OC, int ks, int stride, int pad, int dil);
+size_t binary_conv_weight_lanes_words(int OC, int C, int ks);
+int binary_conv_weight_lanes_launch(const uint32_t* wtaps, uint32_t* wl, int OC, int C, int ks, hipStream_t st);
+int binary_conv_fused_launch(const void* x, const uint32_t* wl, float* y, int B, int C, int H, int W, int OC, int ks, int stride, int pad, int dil,
+                             float scale, int dtype, hipStream_t st);
+bool binary_conv_mfma_ok(int B, int C, int H, int W, int OC, int ks, int stride, int pad, int dil);
+int binary_conv_mfma_launch(const void* x, const uint8_t* wimg, float* y, int B, int C, int H, int W, int OC, int ks, int stride, int pad, int dil,
+                            float scale, int dtype, hipStream_t st);
 size_t binary_fp4_image_bytes(long rows, long K);
 int binary_fp4_image_launch(const uint8_t* rowpacked, uint8_t* image, long rows, long K, hipStream_t st);
 int binary_fp4_image_values_launch(const void* v, const void* bias, uint8_t* image, long rows, long K, int dtype, hipStream_t st);
@@ -679,6 +688,44 @@ int bie_binary_conv2d_forward_taps(const void* x, const uint32_t* wtaps, float* 
     const size_t need = WS_HEAD + binary_conv_taps_workspace_bytes(B, C, H, W);
     BIE_REQUIRE(workspace_bytes >= need, BIE_ERR_WORKSPACE, "bie_binary_conv2d_forward_taps: workspace of %zu bytes required, got %zu", need, workspace_bytes);
     return binary_conv_taps_launch(x, wtaps, y, static_cast<char*>(workspace) + WS_HEAD, B, C, H, W, OC, ksize, stride, pad, dilation, scale, dtype, as_stream(stream));
+}
+
+int bie_binary_conv2d_fused_ok(int B, int C, int H, int W, int OC, int ksize, int stride, int pad, int dilation) {
+    return binary_conv_fused_ok(B, C, H, W, OC, ksize, stride, pad, dilation) ? 1 : 0;
+}
+
+size_t bie_binary_conv_weight_lanes_bytes(int OC, int C, int ksize) {
+    return (OC > 0 && C > 0 && C % 128 == 0 && ksize > 0) ? binary_conv_weight_lanes_words(OC, C, ksize) * 4 : 0;
+}
+
+int bie_binary_conv_weight_lanes(const uint32_t* wtaps, uint32_t* wlanes, int OC, int C, int ksize, void* stream) {
+    BIE_REQUIRE(wtaps && wlanes && OC > 0 && C > 0 && ksize > 0, BIE_ERR_INVALID_ARG, "bie_binary_conv_weight_lanes: bad argument");
+    BIE_REQUIRE(C % 128 == 0, BIE_ERR_UNSUPPORTED, "bie_binary_conv_weight_lanes: C=%d must be a multiple of 128 (four K quarters of whole channel words)", C);
+    return binary_conv_weight_lanes_launch(wtaps, wlanes, OC, C, ksize, as_stream(stream));
+}
+
+int bie_binary_conv2d_forward_fused(const void* x, const uint32_t* wlanes, float* y, int B, int C, int H, int W, int OC, int ksize, int stride, int pad,
+                                    int dilation, float scale, int dtype, void* stream) {
+    BIE_REQUIRE(x && wlanes && y, BIE_ERR_INVALID_ARG, "bie_binary_conv2d_forward_fused: NULL tensor pointer");
+    BIE_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && OC > 0 && ksize > 0 && stride > 0 && dilation > 0 && pad >= 0, BIE_ERR_INVALID_ARG, "bie_binary_conv2d_forward_fused: bad geometry");
+    BIE_REQUIRE(dtype >= 0 && dtype <= 2, BIE_ERR_UNSUPPORTED, "bie_binary_conv2d_forward_fused: dtype %d", dtype);
+    BIE_REQUIRE((long)B * C * H * W < (1L << 31) && (long)B * OC * H * W < (1L << 31), BIE_ERR_UNSUPPORTED, "bie_binary_conv2d_forward_fused: tensor beyond 2^31 elements");
+    return binary_conv_fused_launch(x, wlanes, y, B, C, H, W, OC, ksize, stride, pad, dilation, scale, dtype, as_stream(stream));
+}
+
+int bie_binary_conv2d_mfma_ok(int B, int C, int H, int W, int OC, int ksize, int stride, int pad, int dilation) {
+    return binary_conv_mfma_ok(B, C, H, W, OC, ksize, stride, pad, dilation) ? 1 : 0;
+}
+
+int bie_binary_conv2d_forward_mfma(const void* x, const uint8_t* wimage, float* y, int B, int C, int H, int W, int OC, int ksize, int stride, int pad,
+                                   int dilation, float scale, int dtype, void* stream) {
+    BIE_REQUIRE(x && wimage && y, BIE_ERR_INVALID_ARG, "bie_binary_conv2d_forward_mfma: NULL tensor pointer");
+    BIE_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && OC > 0 && ksize > 0 && stride > 0 && dilation > 0 && pad >= 0, BIE_ERR_INVALID_ARG, "bie_binary_conv2d_forward_mfma: bad geometry");
+    BIE_REQUIRE(dtype >= 0 && dtype <= 2, BIE_ERR_UNSUPPORTED, "bie_binary_conv2d_forward_mfma: dtype %d", dtype);
+    BIE_REQUIRE((reinterpret_cast<uintptr_t>(wimage) & 15) == 0, BIE_ERR_INVALID_ARG, "bie_binary_conv2d_forward_mfma: the weight image must be 16-byte aligned");
+    BIE_REQUIRE((long)B * C * H * W < (1L << 31) && (long)B * OC * H * W < (1L << 31), BIE_ERR_UNSUPPORTED, "bie_binary_conv2d_forward_mfma: tensor beyond 2^31 elements");
+    BIE_REQUIRE((long)ksize * ksize * C < (1L << 24), BIE_ERR_UNSUPPORTED, "bie_binary_conv2d_forward_mfma: C*k*k beyond the exact range of the fp32 accumulator");
+    return binary_conv_mfma_launch(x, wimage, y, B, C, H, W, OC, ksize, stride, pad, dilation, scale, dtype, as_stream(stream));
 }
 
 int bie_binary_conv2d_forward(const void* x, const uint8_t* wpacked, float* y, void* workspace, size_t workspace_bytes, int B,

@@ -355,6 +355,30 @@ int bie_binary_conv2d_forward_fp4(const void* x, const uint8_t* wimage, float* y
                                   int H, int W, int OC, int ksize, int stride, int pad, int dilation, float scale, int dtype,
                                   void* stream);
 
+/* The same convolution as ONE launch and without a workspace (round 6; C in {128, 256, 512}, k in {1, 3}, dilation 1, output rows of at
+ * most 64 pixels -- bie_binary_conv2d_fused_ok says whether a geometry is in range): a workgroup = (image, 64 or 128 output channels, a
+ * range of whole output rows) sign-packs the input rows it needs straight from x into a zero-bordered LDS bit image, keeps its K quarter of
+ * the weights in registers (lane = output channel) and runs XNOR-popcount against uniform-address LDS reads; the quarters meet in LDS and y
+ * leaves pixel-contiguous.  wlanes = bie_binary_conv_weight_lanes of the tap-major words of bie_binary_conv_weight_taps
+ * ([ceil(OC/64)][4 quarters][k*k*C/128][64 lanes] uint32, bie_binary_conv_weight_lanes_bytes, once per weight tensor).  Bit-identical to
+ * bie_binary_conv2d_forward.  Replaces binary_conv_cpp.forward (binary_conv.cpp:319-365 im2binary_col + :464-530) and the implicit-GEMM
+ * convolution of binary_conv2d_cutlass_kernel.cu:122-183. */
+int bie_binary_conv2d_fused_ok(int B, int C, int H, int W, int OC, int ksize, int stride, int pad, int dilation);
+size_t bie_binary_conv_weight_lanes_bytes(int OC, int C, int ksize);
+int bie_binary_conv_weight_lanes(const uint32_t* wtaps, uint32_t* wlanes, int OC, int C, int ksize, void* stream);
+int bie_binary_conv2d_forward_fused(const void* x, const uint32_t* wlanes, float* y, int B, int C, int H, int W, int OC, int ksize, int stride,
+                                    int pad, int dilation, float scale, int dtype, void* stream);
+
+/* The matrix-pipe convolution as ONE launch (round 6; C % 64 == 0, k in {1, 3}, dilation 1, output rows of at most 128 pixels --
+ * bie_binary_conv2d_mfma_ok): a workgroup sign-packs its input rows from x into a -1.0-bordered FP4 NHWC image in LDS and gathers the
+ * pixel operand fragments of v_mfma_scale_f32_32x32x64_f8f6f4 from it, tap by tap -- the FP4 im2col matrix of
+ * bie_binary_conv2d_forward_fp4 (and its two extra launches) never exists.  wimage as for bie_binary_conv2d_forward_fp4 (bie_binary_fp4_image
+ * of the tap-major weight words, rows = OC, K = ksize*ksize*C).  Bit-identical to bie_binary_conv2d_forward.
+ * Replaces binary_conv_cpp.forward (binary_conv.cpp:319-365, :464-530) / binary_conv2d_cutlass_kernel.cu:122-183. */
+int bie_binary_conv2d_mfma_ok(int B, int C, int H, int W, int OC, int ksize, int stride, int pad, int dilation);
+int bie_binary_conv2d_forward_mfma(const void* x, const uint8_t* wimage, float* y, int B, int C, int H, int W, int OC, int ksize, int stride,
+                                   int pad, int dilation, float scale, int dtype, void* stream);
+
 /* `batch` independent XNOR GEMMs in ONE launch: y[b][M, N] = (K - 2*popc(x[b] ^ w[b])) * scale, both operands row-packed
  * uint8 [rows, K/8]; strides in BYTES (packed operands) / ELEMENTS (y) between consecutive matrices.
  * Replaces binary_linear_cutlass.matmul -> binary_batched_forward_cutlass

@@ -870,6 +870,79 @@ def test_binary_conv_tap_form_equals_the_im2col_form_and_the_oracle(B, C, H, W, 
         assert torch.equal(conv2d(x.to(tdt).to(DEV), wp, OC, ks, st, pad, dil, 0.5), y * 0.5)
 
 
+@pytest.mark.parametrize("B,C,H,W,OC,ks,st,pad", [(1, 512, 7, 7, 512, 3, 1, 1), (32, 512, 7, 7, 512, 3, 1, 1), (128, 512, 7, 7, 512, 3, 1, 1), (5, 512, 7, 7, 200, 3, 1, 1),
+                                                 (2, 256, 14, 14, 256, 3, 1, 1), (3, 256, 14, 14, 512, 3, 2, 1), (1, 128, 28, 28, 128, 3, 1, 1), (9, 128, 28, 28, 256, 3, 2, 1),
+                                                 (2, 256, 14, 14, 512, 1, 2, 0), (3, 128, 9, 11, 64, 3, 2, 1), (2, 512, 5, 60, 72, 3, 1, 1), (1, 128, 13, 64, 130, 1, 1, 0),
+                                                 (2, 256, 6, 6, 96, 3, 1, 0), (70, 128, 4, 4, 64, 3, 1, 2)])
+def test_binary_conv_one_launch_form_against_the_oracle_and_the_other_forms(B, C, H, W, OC, ks, st, pad, monkeypatch):
+    """bie_binary_conv2d_forward_fused (configs[3] as ONE launch, no workspace): sign-pack into an LDS bit image, register-resident
+    weight quarters, XNOR-popcount against uniform LDS reads.  Bit-exact against the oracle's integers (pinned by the compiled binary_conv.cpp,
+    tests/test_oracle_golden.py) and against the forms it replaces on these shapes (tap kernels / FP4 matrix-pipe GEMM, forced through
+    BIE_CONV_FUSED_MAX_ROWS=0); ResNet stage shapes, stride 2, 1x1, pad 0 and 2, output channel counts that are not multiples of 64 / 128,
+    one / several row chunks per image, both channel-group widths, fp32 / fp16 / bf16 inputs with zeros, negative zeros and NaNs."""
+    from bitorch_engine import _hip
+    from bitorch_engine.extensions import _binary_common as bc
+    gen = torch.Generator().manual_seed(B * 7 + C + H + W + OC + ks)
+    x = torch.randn((B, C, H, W), generator=gen)
+    x.view(-1)[::97] = 0.0
+    x.view(-1)[5::131] = -0.0
+    x.view(-1)[11::257] = float("nan")
+    w = torch.randn((OC, C, ks, ks), generator=gen)
+    wp = bc.pack_rows(w.reshape(OC, -1).to(DEV)).contiguous()
+    L = _hip.lib()
+    assert L.bie_binary_conv2d_fused_ok(B, C, H, W, OC, ks, st, pad, 1) == 1
+    OH, OW = (H + 2 * pad - ks) // st + 1, (W + 2 * pad - ks) // st + 1
+    wl = bc.conv_weight_lanes(wp, OC, C, ks)
+    assert wl.numel() * 4 == L.bie_binary_conv_weight_lanes_bytes(OC, C, ks)
+    xd = x.to(DEV)
+    y = torch.full((B, OC, OH, OW), float("nan"), dtype=torch.float32, device=DEV)
+    rc = L.bie_binary_conv2d_forward_fused(xd.data_ptr(), wl.data_ptr(), y.data_ptr(), B, C, H, W, OC, ks, st, pad, 1, 0.25, _hip.F32, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, L.bie_last_error().decode()
+    xo = torch.where(torch.isnan(x), torch.tensor(-1.0), x)  # the sign rule (value >= 0) makes a NaN a -1; the oracle takes the value it stands for
+    want = orc.binary_conv2d(xo.numpy(), w.numpy(), st, pad, 1).astype(np.float32) * np.float32(0.25)
+    assert np.array_equal(y.cpu().numpy(), want), "one-launch conv differs from the oracle"
+    # the one-launch MATRIX-PIPE form (FP4 image of the input rows in LDS, fragments gathered tap by tap) through the C ABI
+    mfma = L.bie_binary_conv2d_mfma_ok(B, C, H, W, OC, ks, st, pad, 1) == 1
+    assert mfma or (H, W) == (5, 60)   # (three input rows of 62 pixels x 512 channels as FP4 do not fit its 64 KiB LDS image)
+    wimg = bc.conv_weight_fp4_image(wp, OC, C, ks)
+    y2 = torch.full_like(y, float("nan"))
+    rc = L.bie_binary_conv2d_forward_mfma(xd.data_ptr(), wimg.data_ptr(), y2.data_ptr(), B, C, H, W, OC, ks, st, pad, 1, 0.25, _hip.F32, torch.cuda.current_stream().cuda_stream)
+    if mfma:
+        assert rc == 0, L.bie_last_error().decode()
+        assert torch.equal(y2, y), "one-launch matrix-pipe conv differs from the one-launch VALU conv"
+    else:
+        assert rc == -2
+    # the dispatch (whichever one-launch form it picks for this size) and the forms of round 5 (both one-launch forms switched off)
+    assert torch.equal(bc.conv2d(xd, wp, OC, ks, st, pad, 1, 0.25), y)
+    monkeypatch.setenv("BIE_CONV_FUSED_MAX_ROWS", "0")
+    assert torch.equal(bc.conv2d(xd, wp, OC, ks, st, pad, 1, 0.25), y)          # forced onto the matrix-pipe one-launch form
+    monkeypatch.setenv("BIE_CONV_MFMA_MAX_ROWS", "0")
+    assert torch.equal(bc.conv2d(xd, wp, OC, ks, st, pad, 1, 0.25), y)          # tap kernels / three-launch FP4 GEMM agree bit for bit
+    monkeypatch.delenv("BIE_CONV_FUSED_MAX_ROWS")
+    monkeypatch.delenv("BIE_CONV_MFMA_MAX_ROWS")
+    for tdt in (torch.float16, torch.bfloat16):
+        xt = x.to(tdt).to(DEV)
+        assert torch.equal(bc.conv2d(xt, wp, OC, ks, st, pad, 1, 0.25), y)
+        if mfma:
+            rc = L.bie_binary_conv2d_forward_mfma(xt.data_ptr(), wimg.data_ptr(), y2.data_ptr(), B, C, H, W, OC, ks, st, pad, 1, 0.25, _hip._DT[tdt], torch.cuda.current_stream().cuda_stream)
+            assert rc == 0 and torch.equal(y2, y)
+
+
+def test_binary_conv_one_launch_form_refuses_what_it_cannot_run():
+    from bitorch_engine import _hip
+    L = _hip.lib()
+    ok = lambda *a: L.bie_binary_conv2d_fused_ok(*a)  # noqa: E731  (B, C, H, W, OC, k, stride, pad, dil)
+    assert ok(1, 512, 7, 7, 512, 3, 1, 1, 1) == 1
+    assert ok(1, 64, 56, 56, 64, 3, 1, 1, 1) == 0      # C = 64: no four K quarters of whole words
+    assert ok(1, 512, 7, 7, 512, 5, 1, 2, 1) == 0      # k = 5
+    assert ok(1, 512, 7, 7, 512, 3, 1, 2, 2) == 0      # dilation
+    assert ok(1, 128, 8, 300, 8, 3, 1, 1, 1) == 0      # an output row longer than a wave
+    x = torch.zeros((1, 64, 8, 8), device=DEV)
+    y = torch.zeros((1, 8, 8, 8), device=DEV)
+    rc = L.bie_binary_conv2d_forward_fused(x.data_ptr(), x.data_ptr(), y.data_ptr(), 1, 64, 8, 8, 8, 3, 1, 1, 1, 1.0, _hip.F32, None)
+    assert rc == -2 and "one-launch form" in L.bie_last_error().decode()
+
+
 @pytest.mark.parametrize("B,C,H,OC,ks,st,pad,dil", [(2, 64, 14, 64, 3, 1, 1, 1), (1, 512, 7, 512, 3, 1, 1, 1), (3, 32, 9, 48, 3, 2, 1, 1), (2, 128, 8, 64, 1, 1, 0, 1)])
 def test_binary_conv2d_cutlass_layer_packed_equals_unpacked_and_the_a15_oracle(B, C, H, OC, ks, st, pad, dil):
     """SURVEY A16 / VERDICT r3: BinaryConv2dCutlass and binary_conv2d_cutlass.forward / w_pack.  What the reference's own test pins
