@@ -550,15 +550,15 @@ bool conv_mfma_plan(int B, int C, int H, int W, int OC, int ks, int stride, int 
     p.ocbs = cdiv(OC, 128);
     p.WP = (OW - 1) * stride + ks;
     p.npb = 4;
-    if (P <= 128) {  // whole images: as many as fill 128 pixel rows and fit 64 KiB of LDS
+    if (P <= 128) {
+        // ONE whole image per workgroup (two pixel blocks up to 64 pixels, four up to 128).  Two images per workgroup halve the weight traffic but
+        // measured slower at every batch size (B = 128: 19.2 against 16.1 us, B = 512: 67.6 against 52.4): the two-block instance needs 228
+        // registers (two workgroups per CU: one packs while the other multiplies), the four-block one 308 (one workgroup per CU)
         p.chunks = 1;
         p.rpw = OH;
         p.IR = (OH - 1) * stride + ks;
-        p.ni = 128 / P;
-        while (p.ni > 1 && (size_t)p.ni * p.IR * p.WP * pitch > 64 * 1024) p.ni--;
-        if (p.ni == 1 && P <= 64) p.npb = 2;
-        // few images: one per workgroup keeps more CUs busy (B = 8: 8 x ocbs workgroups instead of 4 x ocbs)
-        if ((long)cdiv(B, p.ni) * p.ocbs < 128 && p.ni > 1 && P <= 64) { p.ni = 1; p.npb = 2; }
+        p.ni = 1;
+        p.npb = P <= 64 ? 2 : 4;
     } else {
         p.ni = 1;
         p.rpw = 128 / OW;
