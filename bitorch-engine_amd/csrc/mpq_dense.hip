@@ -23,7 +23,10 @@
 
 #ifndef BIE_DENSE_LAB
 #define BIE_DENSE_LAB 0  // compile-time ablation switch of tools/dense_lab.py (0 = product code): 1 no epilogue stores, 2 no main loop,
-#endif                   // 3 the round-4 epilogue (64 rows x 16 bytes per store instruction)
+#endif                   // 3 the round-4 epilogue (64 rows x 16 bytes per store instruction); 8 the MFMA-pipe probe (round 6): the loop's own
+                         // instruction stream -- fragment reads, barriers, MFMAs -- on operands that STAY in LDS after the prologue (no LDS-DMA,
+                         // no vmcnt wait in the loop, no stores): what this tiling can reach on this chip with zero memory traffic; 9: 8 without the
+                         // fragment reads (MFMAs and barriers only)
 
 namespace bie {
 
@@ -165,6 +168,9 @@ __global__ __launch_bounds__(256) void mpq_dense_gemm_kernel(const uint16_t* __r
     [[maybe_unused]] const int kt_last = KT - 1;
     auto issue_piece = [&](int kt, int j) {
 #if defined(__HIP_DEVICE_COMPILE__)
+#if BIE_DENSE_LAB == 8 || BIE_DENSE_LAB == 9
+        if (kt >= 3) return;  // probe: only the prologue's three stages are ever fetched
+#endif
         const int ks = kt < kt_last ? kt : kt_last;  // a look-ahead past the end re-fetches the last tile into a buffer nobody reads again
         auto* dst = (__attribute__((address_space(3))) unsigned char*)lds + (kt % 3) * STAGE + wave * (PW * 1024);
         __builtin_amdgcn_global_load_lds(src[j] + ks * step, dst + j * 1024, 16, 0, 0);
@@ -192,6 +198,9 @@ __global__ __launch_bounds__(256) void mpq_dense_gemm_kernel(const uint16_t* __r
     // fragment read R (0 .. NR-1) of k16 step H of the stage at byte offset so: the first WM are x row blocks (2 KiB apart)
     auto read_item = [&](auto ic, auto hc, uint32_t so, v4i_t (&TA)[WM], v4i_t (&TB)[WN]) {
         constexpr int R = decltype(ic)::value, H = decltype(hc)::value;
+#if BIE_DENSE_LAB == 9
+        if (so == 0xffffffffu)  // never: the fragment registers keep the prologue's values
+#endif
         if constexpr (R < WM) TA[R] = lds_read16<R * 2048>(a_addr[H] + so);
         else TB[R - WM] = lds_read16<(R - WM) * 2048 + H * 1024>(b_addr + so);
     };
@@ -214,7 +223,7 @@ __global__ __launch_bounds__(256) void mpq_dense_gemm_kernel(const uint16_t* __r
             static_for<imin(m * RPM, NR), imin((m + 1) * RPM, NR)>([&](auto rc) { read_item(rc, ic_t<1>{}, so, QA, QB); });
         });
         wait_frags<0>(QA, QB);  // every LDS read of this stage has returned: its buffer may be refilled behind the barrier
-#if BIE_DENSE_LAB != 5 && BIE_DENSE_LAB != 6
+#if BIE_DENSE_LAB != 5 && BIE_DENSE_LAB != 6 && BIE_DENSE_LAB != 8 && BIE_DENSE_LAB != 9
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");  // K tile kt+1 landed (kt+2 still in flight)
 #endif
 #if BIE_DENSE_LAB == 4 || BIE_DENSE_LAB == 6      // timing experiments (wrong results): no barrier in the loop (4), no counted wait (5), neither (6)
@@ -278,7 +287,7 @@ __global__ __launch_bounds__(256) void mpq_dense_gemm_kernel(const uint16_t* __r
         const auto s1 = __builtin_amdgcn_permlane32_swap(p1, p3, false, false);
         return uint4_t{s0[0], s1[0], s0[1], s1[1]};
     };
-#if BIE_DENSE_LAB == 1
+#if BIE_DENSE_LAB == 1 || BIE_DENSE_LAB == 8 || BIE_DENSE_LAB == 9
     if (M == -12345)  // never: the accumulators stay live, nothing is stored
 #endif
 #if BIE_DENSE_LAB != 3
@@ -368,7 +377,7 @@ __global__ __launch_bounds__(256) void mpq_dense_gemm_kernel(const uint16_t* __r
             }
         }
     };
-#if BIE_DENSE_LAB == 1
+#if BIE_DENSE_LAB == 1 || BIE_DENSE_LAB == 8 || BIE_DENSE_LAB == 9
     if (M == -12345)
 #endif
     if (bias == nullptr) {
