@@ -1141,7 +1141,7 @@ static InlinePlan inline_plan(int K, int group_size, int tiles_total) {
 // SIMD hide that chain better; the list form's leaner stream only pays from ~96 MB of packed weights per launch.
 bool mpq_list_inline_ok(int M, int K, long n_total, int w_bit, int group_size, int zm, int dtype) {
     static const int enabled = list_env("BIE_DECODE_INLINE", 1);  // 0: never; 2: always (tuning)
-    static const long min_mb = list_env("BIE_DECODE_INLINE_MIN_MB", 96);
+    static const long min_mb = list_env("BIE_DECODE_INLINE_MIN_MB", 40);  // round 6: 96 -> 40 (gate/up of a 7B layer, 45 MB: 16.1 -> 15.5 us; profiles/r06_lone_plan_sweeps.txt)
     if (!enabled || M != 1 || w_bit != 4 || dtype != BIE_BF16 || (zm != ZM_SYM && zm != ZM_ASYM)) return false;
     const int gs = group_size > K ? K : group_size;
     if (!((gs == 32 || gs == 64 || gs == 128 || gs == 256) && K % gs == 0)) return false;

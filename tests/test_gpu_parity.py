@@ -1318,12 +1318,13 @@ def test_grouped_forward_matches_separate_calls_and_oracle():
                 assert torch.equal(y, single) or dt == orc.BF16, "fallback path must equal separate calls bit for bit"
 
 
+@pytest.mark.parametrize("dt", [orc.F16, orc.BF16])
 @pytest.mark.parametrize("K,widths", [(4096, (4096, 4096, 4096)), (4096, (11008, 11008))])
-def test_full_size_grouped_launches_fp16_element_wise(K, widths):
+def test_full_size_grouped_launches_fp16_element_wise(K, widths, dt):
     """the grouped decode launches at the Llama-7B shapes (q/k/v, gate/up), fp16 (GreenBit's checkpoint dtype), against
-    the oracle norm-wise AND element by element (1e-3 relative + one fp16 ulp on every output with |ref| >= 2^-6 max|ref|)."""
+    the oracle norm-wise AND element by element (1e-3 relative + one fp16 ulp on every output with |ref| >= 2^-6 max|ref|); bf16: norm-wise +
+    one output ulp (gate/up at M = 1 is 45 MB: the inline list form since round 6's 40 MB threshold)."""
     from bitorch_engine.extensions import q_linear_cuda
-    dt = orc.F16
     for M in (1, 4):
         sets, refs, x = [], [], None
         for i, N in enumerate(widths):
@@ -1335,8 +1336,9 @@ def test_full_size_grouped_launches_fp16_element_wise(K, widths):
             refs.append(oracle_forward(x, qw, scales, zeros, None, 4, 128, 0, dt))
         ys = q_linear_cuda.mpq_forward_grouped_impl(x.to(DEV), sets, 4, 0, 128)
         for i, (y, r) in enumerate(zip(ys, refs)):
-            assert_close(y, r, dt, f"grouped full-size fp16 M={M} member {i}")
-            assert_close_elementwise_f16(y, r, f"grouped full-size fp16 {K}x{widths[i]} M={M} member {i}")
+            assert_close(y, r, dt, f"grouped full-size M={M} member {i}")
+            if dt == orc.F16:
+                assert_close_elementwise_f16(y, r, f"grouped full-size fp16 {K}x{widths[i]} M={M} member {i}")
 
 
 def test_layer_level_grouped_forward_equals_the_separate_layers():
