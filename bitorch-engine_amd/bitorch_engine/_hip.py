@@ -55,6 +55,7 @@ SIGNATURES = {
     "bie_mbwq_q4_dequant": (_i, [_vp] * 5 + [_i] * 4 + [_vp]),
     "bie_mbwq_exl2_dequant": (_i, [_vp] * 7 + [_i] * 3 + [_vp]),
     "bie_mbwq_workspace_bytes": (_sz, [_i, _i, _i]),
+    "bie_mbwq_q4_workspace_bytes": (_sz, [_i, _i, _i]),
     "bie_mbwq_q4_forward": (_i, [_vp] * 7 + [_sz] + [_i] * 5 + [_vp]),
     "bie_mbwq_exl2_forward": (_i, [_vp] * 9 + [_sz] + [_i] * 4 + [_vp]),
     "bie_binary_pack_rows_u8": (_i, [_vp, _vp, _l, _l, _i, _vp]),

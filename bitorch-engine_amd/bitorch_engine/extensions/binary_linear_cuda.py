@@ -60,7 +60,7 @@ def forward(input: torch.Tensor, weights: torch.Tensor, bmm_type: int, transpose
     if weights.dtype == torch.uint8:
         n = weights.numel() * 8 // k
         wp = image_to_rows(weights, n, k, bmm_type)
-    elif weights.requires_grad:  # a weight under training: optimisers and clamps may write through `.data` (no version bump): pack every call
+    elif weights.requires_grad and torch.is_grad_enabled():  # a weight under training: optimisers and clamps may write through `.data` (no version bump): pack every call
         wp = pack_rows(weights).contiguous()
     else:  # frozen unpacked sign carriers: packed once per tensor version, remembered on the weight tensor.  Writes through `.data` / raw
         # pointers do not advance the version counter: after one, rebind the tensor (or set requires_grad) to have it packed again

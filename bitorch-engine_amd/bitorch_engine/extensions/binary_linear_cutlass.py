@@ -16,7 +16,7 @@ def forward(input: torch.Tensor, weight: torch.Tensor, scale: float, transpose: 
     m, k = input.shape
     if weight.dtype == torch.uint8:
         wp = weight.contiguous()
-    elif weight.requires_grad:  # under training: `.data` writes (optimiser, clamp) do not advance the version counter -- pack every call
+    elif weight.requires_grad and torch.is_grad_enabled():  # under training: `.data` writes (optimiser, clamp) do not advance the version counter -- pack every call
         wp = w_pack(weight, transpose).contiguous()
     else:  # frozen unpacked weight: packed once per tensor version (and with it the FP4 image memoised on the packed tensor)
         from .q_linear_cuda import _cached

@@ -304,7 +304,7 @@ def mbwq_q4_forward(x, qweight, scales, zeros, group_size, q_perm, bits):
     if M == 0:
         return y
     L = _hip.lib()
-    ws = _hip.workspace(L.bie_mbwq_workspace_bytes(M, K, N), x.device)
+    ws = _hip.workspace(L.bie_mbwq_q4_workspace_bytes(M, K, N), x.device)  # (not the mixed-bit sizing: that one holds a dense weight image from M = 49)
     perm = perm_or_none(q_perm)
     rc = L.bie_mbwq_q4_forward(_hip.ptr(x), _hip.ptr(qweight), _hip.ptr(scales.contiguous()), _hip.ptr(zeros.contiguous()),
                                _hip.ptr(perm), _hip.ptr(y), _hip.ptr(ws), 0 if ws is None else ws.numel(), M, K, N, bits,

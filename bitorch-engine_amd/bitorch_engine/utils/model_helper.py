@@ -127,6 +127,15 @@ def init_weight(weight: torch.Tensor, cls: Type[torch.nn.Parameter] = torch.nn.P
     return cls(carriers.to(torch.int8), requires_grad=False), scale_w
 
 
+def _forget_conversions(t: torch.Tensor) -> None:
+    """Drop what the extension shims memoised ON the tensor (packed rows, FP4 / tap / lane images: extensions.q_linear_cuda._cached keys on
+    (version, address), and an optimiser-side write through `.data` moves neither).  Called after every update of an integer parameter."""
+    try:
+        t.__dict__.pop("_bie_memo", None)
+    except AttributeError:
+        pass
+
+
 def _unpack_gptq_zeros(qzeros: torch.Tensor, w_bit: int, n_cols: int) -> torch.Tensor:
     """int32 [G, N*w/32] packed along N -> integer zeros + 1, [G, N] (the zeros half of gptq_style_unpacking,
     reference utils/quant_operators.py:326-331)."""
@@ -184,6 +193,7 @@ def _update_integer_parameter(qweight, exp_avg_s, exp_avg_l, step, lr, weight_de
         bits = exp_avg_s >= 0
         rows = qweight.active_indices
         qweight[rows] ^= qweight[rows] ^ bits[rows]
+        _forget_conversions(qweight)
         return
     if isinstance(qweight, (BinaryLinearParameter, BinaryConvParameter)):
         exp_avg_l.lerp_(qweight.grad.to(dtype), (1 - beta1))
@@ -192,6 +202,7 @@ def _update_integer_parameter(qweight, exp_avg_s, exp_avg_l, step, lr, weight_de
         keep[keep == 0] = 1
         flip = keep != qweight.sign()
         qweight.data.copy_(torch.where(flip, -qweight.data, qweight.data))
+        _forget_conversions(qweight)  # written through .data: neither the version counter nor the address moved
         return
     if isinstance(qweight, (nBitLinearParameter, nBitConvParameter)):
         g = qweight.grad.to(dtype)
@@ -206,6 +217,7 @@ def _update_integer_parameter(qweight, exp_avg_s, exp_avg_l, step, lr, weight_de
         if weight_decay > 0.0:
             w.add_(w, alpha=(-lr * weight_decay))
         qweight.data = nv_tensor_quant(w)[0]
+        _forget_conversions(qweight)
         return
     raise NotImplementedError("qweight.dtype '{}' has not been supported yet.".format(str(qweight.data.dtype)))
 

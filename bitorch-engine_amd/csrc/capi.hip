@@ -60,7 +60,7 @@ size_t mpq_dense_workspace_bytes(int K, int N);
 int mpq_dense_gidx_launch(const void* x, const int32_t* qw, const void* scales, const void* zeros, const int32_t* g_idx, const void* bias, void* y, void* scratch,
                           int M, int K, int N, int w_bit, int asym, int dtype, hipStream_t st);
 // mbwq.hip
-size_t mbwq_workspace_bytes(int M, int K, int N);
+size_t mbwq_workspace_bytes(int M, int K, int N, bool exl2);
 int mbwq_q4_dequant_launch(const int32_t* qw, const void* scales, const void* zeros, const int16_t* perm, void* out, int K,
                            int N, int bits, int group_size, hipStream_t st);
 int mbwq_exl2_shuffle_launch(int32_t* qw, const int* rows6, int K, int N, hipStream_t st, bool inverse);
@@ -395,7 +395,12 @@ int bie_mbwq_rows(const int16_t* q_groups_host, int groups, int K, int* rows7_ho
 
 size_t bie_mbwq_workspace_bytes(int M, int K, int N) {
     if (M <= 0 || K <= 0 || N <= 0) return 0;
-    return WS_HEAD + mbwq_workspace_bytes(M, K, N);
+    return WS_HEAD + mbwq_workspace_bytes(M, K, N, true);
+}
+
+size_t bie_mbwq_q4_workspace_bytes(int M, int K, int N) {
+    if (M <= 0 || K <= 0 || N <= 0) return 0;
+    return WS_HEAD + mbwq_workspace_bytes(M, K, N, false);
 }
 
 int bie_mbwq_q4_dequant(const int32_t* qweight, const void* scales, const void* zeros, const int16_t* q_perm, void* out, int K,
@@ -491,7 +496,7 @@ int bie_mbwq_q4_forward(const void* x, const int32_t* qweight, const void* scale
                         void* stream) {
     BIE_REQUIRE(x && qweight && scales && zeros && y && M > 0 && K > 0 && N > 0 && group_size > 0, BIE_ERR_INVALID_ARG, "bie_mbwq_q4_forward: bad argument");
     BIE_REQUIRE(bits == 2 || bits == 4, BIE_ERR_UNSUPPORTED, "bie_mbwq_q4_forward: weight bit width %d has not been supported yet", bits);
-    const size_t need = WS_HEAD + mbwq_workspace_bytes(M, K, N);
+    const size_t need = WS_HEAD + mbwq_workspace_bytes(M, K, N, false);
     BIE_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), BIE_ERR_WORKSPACE, "bie_mbwq_q4_forward: workspace of %zu bytes required, got %zu", need, workspace_bytes);
     return mbwq_q4_forward_launch(x, qweight, scales, zeros, q_perm, y, (float*)workspace, M, K, N, bits, group_size, as_stream(stream));
 }
@@ -502,7 +507,7 @@ int bie_mbwq_exl2_forward(const void* x, const int32_t* qweight, const void* sca
     BIE_REQUIRE(x && qweight && scales && zeros && q_group_map && y && M > 0 && K > 0 && N > 0, BIE_ERR_INVALID_ARG, "bie_mbwq_exl2_forward: bad argument");
     int rc = check_rows("bie_mbwq_exl2_forward", rows7_host, K);
     if (rc) return rc;
-    const size_t need = WS_HEAD + mbwq_workspace_bytes(M, K, N);
+    const size_t need = WS_HEAD + mbwq_workspace_bytes(M, K, N, true);
     BIE_REQUIRE(workspace && workspace_bytes >= need, BIE_ERR_WORKSPACE, "bie_mbwq_exl2_forward: workspace of %zu bytes required, got %zu", need, workspace_bytes);
     rc = status_report("bie_mbwq_exl2_forward");
     if (rc) return rc;

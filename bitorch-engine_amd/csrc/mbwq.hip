@@ -1489,8 +1489,11 @@ static size_t exl2_dense_bytes(int M, int K, int N) {  // [image][x[:, q_perm]][
     return exl2_dense_ok(M, K, N) ? mpq_dense_workspace_bytes(K, N) + exl2_dense_xp_bytes(M, K) + mpq_dense_part_bytes(M, K, N) : 0;
 }
 
-size_t mbwq_workspace_bytes(int M, int K, int N) {
-    if (exl2_dense_ok(M, K, N)) {  // the uniform q4 / q2 kernels of the same workspace function keep their own needs below
+// exl2 = true: the mixed-bit forward (its prefill form keeps a dense fp16 image of the weights: 2*K*N bytes and more); false: the uniform q4 / q2
+// forward, which never touches that image -- sized together (round 5) a q4 prefill on an 8192 x 28672 layer pinned 470 MB of per-stream workspace
+// for the rest of the process
+size_t mbwq_workspace_bytes(int M, int K, int N, bool exl2) {
+    if (exl2 && exl2_dense_ok(M, K, N)) {
         const size_t f = exl2_dense_bytes(M, K, N), b0 = mpq_gemm_workspace_bytes(M, K, N);
         return f > b0 ? f : b0;
     }

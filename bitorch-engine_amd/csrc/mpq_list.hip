@@ -880,8 +880,12 @@ size_t mpq_list_device_bytes(int n, const bie_mpq_list_entry* ent, int M, int w_
     std::vector<ListPlanEntry> pe;
     int rpg;
     size_t need = 0;
-    for (int nw : {8, 4, 2, 1}) {  // the dtype / zero mode decide the plan (tuning overrides apply to one configuration only): size for the largest
-        list_plan(n, ent, w_bit, group_size, &rpg, pe, nw);
+    // the dtype / zero mode decide the plan (tuning overrides apply to one configuration only): size for the largest of EVERY (waves, units per
+    // wave) pair mpq_list_create can choose -- including the matrix-pipe form's (4, 24), which used to be planned there only (the two
+    // must never be able to disagree)
+    const int plans[][2] = {{8, 0}, {4, 0}, {2, 0}, {1, 0}, {4, 24}, {8, 24}};
+    for (const auto& pl : plans) {
+        list_plan(n, ent, w_bit, group_size, &rpg, pe, pl[0], pl[1]);
         const size_t b = list_layout(n, pe, M).total;
         if (b > need) need = b;
     }

@@ -236,7 +236,8 @@ int bie_mbwq_exl2_dequant(const int32_t* qweight, const void* scales, const void
                           const int16_t* q_perm, const int16_t* q_group_map, const int* rows7_host,
                           void* out, int K, int N, int groups, void* stream);
 
-size_t bie_mbwq_workspace_bytes(int M, int K, int N);
+size_t bie_mbwq_workspace_bytes(int M, int K, int N);     /* bie_mbwq_exl2_forward (covers bie_mbwq_q4_forward too) */
+size_t bie_mbwq_q4_workspace_bytes(int M, int K, int N);  /* bie_mbwq_q4_forward alone: without the mixed-bit prefill form's dense weight image */
 
 /* y[M, N] fp16 = x[:, q_perm] . dequant.  Replace q_linear_cuda.mbwq_q4_forward
  * (mbwq_linear_cuda_kernel.cu:742-825) and q_linear_cuda.mbwq_exl2_forward (:926-1007).

@@ -285,3 +285,35 @@ def test_eval_mode_gradient_request_fails_loudly_and_plain_inference_still_works
         y0 = layer(xr)
     y1 = layer(xr.detach())
     assert torch.equal(y0, y1)
+
+
+@pytest.mark.parametrize("kind", ["cuda", "cutlass"])
+def test_a_training_step_end_to_end_changes_what_the_next_forward_multiplies_by(kind):
+    """loss.backward() puts the max-scaled int8 gradient on weight.grad, BinaryLinearParameter.update() flips sign carriers THROUGH `.data` (neither the
+    version counter nor the address of the weight moves), and the next forward -- under torch.no_grad(), where the packed rows are memoised on the weight
+    tensor -- must multiply by the NEW signs (the memoised pack of an un-prepared layer; the update now drops the tensor's conversions)."""
+    if kind == "cuda":
+        from bitorch_engine.layers.qlinear.binary.cuda import BinaryLinearCuda as Layer
+    else:
+        from bitorch_engine.layers.qlinear.binary.cutlass import BinaryLinearCutlass as Layer
+    from bitorch_engine.layers.qlinear.binary import BinaryLinearParameter
+    g = torch.Generator().manual_seed(21)
+    K, N = 256, 64
+    layer = Layer(K, N, dtype=torch.float)
+    layer.set_weight_data(torch.randn((N, K), generator=g))
+    layer.to(DEV).train()
+    x = torch.randn((8, K), generator=g).to(DEV)
+    with torch.no_grad():
+        y_before = layer(x).clone()       # memoises the packed rows of the carriers on layer.weight
+    layer(x.clone().requires_grad_(True)).sum().backward()
+    assert layer.weight.grad is not None
+    w_before = layer.weight.data.clone()
+    exp_s, exp_l = torch.zeros((N, K), device=DEV, dtype=torch.half), torch.zeros((N, K), device=DEV, dtype=torch.half)
+    BinaryLinearParameter.update(layer.weight, exp_avg_s=exp_s, exp_avg_l=exp_l, step=torch.tensor(1), lr=1e-2, beta1=0.0, beta2=0.0)
+    flipped = int((layer.weight.data != w_before).sum())
+    assert flipped > 0, "the update flipped nothing: the test would not see a stale pack"
+    with torch.no_grad():
+        y_after = layer(x)
+        want = (torch.where(x + layer.bias_a >= 0, 1.0, -1.0) @ torch.where(layer.weight.data >= 0, 1.0, -1.0).t().float()) * layer.scale_a * layer.scale_w
+    assert not torch.equal(y_after, y_before)
+    assert torch.allclose(y_after, want.to(y_after.dtype), rtol=1e-5, atol=1e-5)
