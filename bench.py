@@ -652,7 +652,7 @@ def bench_binary(dev, L):
                                   "frac": round(byts / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None} if M < 16 else
                                  {"bound": "valu xor+bcnt", "achieved": round(2.0 * M * K * N / us / 1e6, 1), "peak": XOR_POPC_PEAK_TOPS,
                                   "unit": "TOP/s", "frac": round(2.0 * M * K * N / us / 1e6 / XOR_POPC_PEAK_TOPS, 4), "traffic": None})})
-    for B in (1, 32, 128):  # B = 128 (6272 output pixels) takes the matrix-pipe form (FP4 GEMM over (pixel) x (tap, channel))
+    for B in (1, 32, 128):  # BASELINE configs[3]
         x = torch.randn((B, 512, 7, 7), device=dev)
         w = torch.randn((512, 512, 3, 3), device=dev)
         from bitorch_engine.extensions._binary_common import pack_rows
@@ -664,11 +664,13 @@ def bench_binary(dev, L):
             us = time_graph(capture(fn), 20) / 16
             tops = 2.0 * B * 49 * 512 * 4608 / us / 1e6
             from bitorch_engine.extensions import _binary_common as bc
-            fused = B * 49 <= bc.conv_fused_max_rows()  # the dispatch of extensions/_binary_common.py::conv2d: ONE launch (sign-pack into LDS + XNOR-popcount) up to that many pixels
-            fp4 = not fused and B * 49 >= 1024          # beyond: the FP4 GEMM on the matrix pipe (three launches)
-            peak = FP4_MFMA_PEAK_TOPS if fp4 else XOR_POPC_PEAK_TOPS
-            out.append({"op": "binary conv 512->512 3x3 on 7x7", "B": B, "us_per_call": round(us, 2), "TOP/s": round(tops, 2), "launches": 1 if fused else (3 if fp4 else 2),
-                        "roofline": {"bound": "mfma fp4 (bits + image passes included in the time)" if fp4 else "valu xor+bcnt", "achieved": round(tops, 2),
+            # the dispatch of extensions/_binary_common.py::conv2d: ONE launch either way (round 6) -- the VALU form (sign-pack into LDS + XNOR-popcount)
+            # up to conv_fused_max_rows() output pixels, the matrix-pipe form (FP4 image of the input rows in LDS, fragments gathered tap by tap) beyond
+            valu = B * 49 <= bc.conv_fused_max_rows()
+            peak = XOR_POPC_PEAK_TOPS if valu else FP4_MFMA_PEAK_TOPS
+            out.append({"op": "binary conv 512->512 3x3 on 7x7", "B": B, "us_per_call": round(us, 2), "TOP/s": round(tops, 2), "launches": 1,
+                        "kernel": "bie::xnor_conv_fused_kernel (v_xor + v_bcnt)" if valu else "bie::xnor_conv_mfma_kernel (v_mfma_scale_f32_32x32x64_f8f6f4)",
+                        "roofline": {"bound": "valu xor+bcnt" if valu else "mfma fp4 (sign-pack and write-out inside the same launch)", "achieved": round(tops, 2),
                                      "peak": peak, "unit": "TOP/s", "frac": round(tops / peak, 5), "traffic": None}})
         except Exception as e:  # reporting only
             out.append({"op": "binary conv 512->512 3x3 on 7x7", "B": B, "error": str(e)[:200]})
