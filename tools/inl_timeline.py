@@ -38,9 +38,12 @@ nw = 65536
 buf = (ctypes.c_ulonglong * (nw * 6))()
 assert raw.bie_debug_list_stamps(buf, nw) == 0
 a = np.frombuffer(buf, dtype=np.uint64).reshape(nw, 6).astype(np.int64)
-a = a[a[:, 0] > 0]
+wid_all = np.arange(nw)
+keep0 = a[:, 0] > 0
+wid_all, a = wid_all[keep0], a[keep0]
 # keep the waves of the LAST launch: stamps within 100 us of the newest start
-a = a[a[:, 0] > a[:, 0].max() - 10000]
+keep1 = a[:, 0] > a[:, 0].max() - 10000
+wid_all, a = wid_all[keep1], a[keep1]
 t0 = a[:, 0].min()
 tick = 1e-2
 start, landed, done = (a[:, 0] - t0) * tick, (a[:, 1] - t0) * tick, (a[:, 2] - t0) * tick
@@ -54,3 +57,24 @@ print("rows landed     ", pct(landed))
 print("lookups done    ", pct(done))
 print("compute duration", pct(done - landed))
 print("workgroup end   ", pct(wg_end))
+
+# phases: ramp = launch start -> the first rows have landed; stream = first -> last rows landed; tail = last rows landed -> last lookups done;
+# reduce = last lookups done -> last workgroup end.  Reducers are the workgroups of the LAST K slice (block id / tiles): their wave 0 ends the tile.
+NWv = int(os.environ.get("BIE_INL_NW", "4"))
+tiles = sum((N + 63) // 64 for N in Ns)
+blk = wid_all // NWv
+S = int(blk.max()) // tiles + 1
+sl = blk // tiles
+print(f"plan: {tiles} column tiles x {S} K slices = {tiles * S} workgroups of {NWv} waves; bytes {sum(K * N // 2 for N in Ns) / 1e6:.1f} MB")
+print(f"phases (us): ramp {landed.min():.2f} | stream {landed.max() - landed.min():.2f} (last rows landed at {landed.max():.2f}) | tail {done.max() - landed.max():.2f} "
+      f"(last lookups done at {done.max():.2f}) | reduce + store {wg_end.max() - done.max():.2f} (last workgroup end {wg_end.max():.2f})")
+w0 = (wid_all % NWv) == 0
+red = w0 & (sl == S - 1) & (a[:, 3] > 0)
+pub = w0 & (sl < S - 1) & (a[:, 3] > 0)
+if red.any():
+    print("reducers   : own lookups done -> tile written", pct(((a[red, 3] - a[red, 2]) * tick)))
+if pub.any():
+    print("publishers : own lookups done -> granules out ", pct(((a[pub, 3] - a[pub, 2]) * tick)))
+for lo in range(0, int(np.ceil(done.max())) + 1, 2):
+    m = lambda v: int(((v >= lo) & (v < lo + 2)).sum())
+    print(f"  t in [{lo:2d},{lo + 2:2d}) us: waves started {m(start):5d}  rows landed {m(landed):5d}  lookups done {m(done):5d}")
