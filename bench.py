@@ -107,7 +107,7 @@ def time_graph(g, reps):
     return e0.elapsed_time(e1) * 1e3 / reps
 
 
-PMC_FILE = "r05_pmc_gemv.json"
+PMC_FILE = "r06_pmc_gemv.json"
 
 
 def kernel_source_sha():
@@ -133,11 +133,11 @@ def pmc_traffic(shape):
 
 
 def pmc_gemm(shape="M4096_K4096_N4096"):
-    """Counters of the dense GEMM kernel at the TIMED shape (tools/gpu_pmc_gemm_r05.sh -> profiles/r05_pmc_gemm.json: MFMA-pipe utilisation =
+    """Counters of the dense GEMM kernel at the TIMED shape (tools/gpu_pmc_gemm_r06.sh -> profiles/r06_pmc_gemm.json: MFMA-pipe utilisation =
     SQ_VALU_MFMA_BUSY_CYCLES per SIMD / GRBM_GUI_ACTIVE per XCD; FETCH_SIZE / WRITE_SIZE from their own passes).  None when absent or collected
     on other sources of mpq_dense.hip."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_gemm.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r06_pmc_gemm.json")))
         h = hashlib.sha256()
         for f in ("mpq_dense.hip", "mfma_pipe.cuh", "mpq_frag_dequant.cuh"):
             h.update(open(os.path.join(ROOT, "bitorch-engine_amd", "csrc", f), "rb").read())
