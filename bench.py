@@ -1115,6 +1115,14 @@ def main():
         out["cpu_baseline"] = None
 
     if distributed:
+        # RCCL prints a version banner through C stdio, which is flushed when a process exits -- i.e. AFTER rank 0's JSON line (seen on the
+        # world-of-one run: the line was not the last one on stdout).  Every rank flushes its C buffers, then the ranks meet, then rank 0 prints.
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
@@ -1132,7 +1140,7 @@ def main():
                 if len(line) > 6000 and k in out:
                     out[k] = "see extras_file"
                     line = json.dumps(out)
-        print(line)
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
