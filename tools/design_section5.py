@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Print the rows of DESIGN.md section 5 from profiles/r05_bench.json + r05_bench_extras.json + the rocprofv3 kernel stats of the same box, so that the
+"""Print the rows of DESIGN.md section 5 from profiles/r06_bench.json + r06_bench_extras.json + the rocprofv3 kernel stats of the same box, so that the
    table is the evidence set and nothing else.  usage: python tools/design_section5.py"""
 import csv
 import json
@@ -7,8 +7,8 @@ import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
-d = json.load(open(os.path.join(P, "r05_bench.json")))
-ex = json.load(open(os.path.join(P, "r05_bench_extras.json")))["extras"]
+d = json.load(open(os.path.join(P, "r06_bench.json")))
+ex = json.load(open(os.path.join(P, "r06_bench_extras.json")))["extras"]
 S = d["summary"]
 
 
@@ -21,7 +21,7 @@ def us(k, key="us_per_layer"):
 
 
 prof = {}
-for f, tag in (("r05_kernel_stats_headline.csv", "headline"), ("r05_kernel_stats_short_bench.csv", "short")):
+for f, tag in (("r06_kernel_stats_headline.csv", "headline"), ("r06_kernel_stats_short_bench.csv", "short")):
     for r in csv.DictReader(open(os.path.join(P, f))):
         n = r["Name"]
         if "mpq_list_kernel<1, 0, 1, 16, 4, 73, false>" in n and tag == "headline":
@@ -61,10 +61,10 @@ rows = [
     ("**decode step, Llama-7B linears, true y → x dependencies** (C ABI / unchanged module tree / one launch per layer)",
      f"{d['decode_step_llama7b']['us_per_layer']:.1f} / {S['decode_step_modules_auto_grouped']['us']:.1f} / {S['decode_step_modules_one_launch_per_layer']['us']:.1f} µs per layer",
      f"{d['decode_step_llama7b']['roofline_frac']:.2f} / {S['decode_step_modules_auto_grouped']['frac']:.2f} / {S['decode_step_modules_one_launch_per_layer']['frac']:.2f}",
-     "4 launches per layer; round 5 refuted weight prefetching as a lever (`DEAD_ENDS.md`)"),
+     "4 launches per layer; per-wave timelines with ramp / stream / tail / reduce phases: `profiles/r06_inl_timeline.txt`"),
     ("**GEMM M = 4096, 4096² (both launches timed)**", f"{g['us_per_launch']:.1f} µs (under the profiler: dequant {prof['dequant_min_us']:.1f} + GEMM {prof['gemm_min_us']:.1f})",
-     f"**{g['frac']:.3f} of 2.5 PF** (0.453–0.474 by box)",
-     f"the GEMM kernel alone ≈ 0.50–0.53; hipBLASLt dense bf16 on this shape: 111 µs; counters: MFMA pipe {g['pmc']['mfma_pipe_utilisation']:.3f} busy at {g['pmc']['effective_clock_ghz']:.2f} GHz, fetch = {g['pmc']['fetch_over_tiling_floor']:.3f} × the tiling floor"),
+     f"**{g['frac']:.3f} of 2.5 PF**",
+     f"MFMA-pipe probe (`profiles/r06_dense_mfma_probe.txt`): MFMAs + barriers only 0.76, + fragment reads 0.60, the loop 0.52, + stores 0.50, + dequantise launch 0.47; counters: MFMA pipe {g['pmc']['mfma_pipe_utilisation']:.3f} busy at {g['pmc']['effective_clock_ghz']:.2f} GHz, fetch = {g['pmc']['fetch_over_tiling_floor']:.3f} × the tiling floor"),
     ("GEMM M = 4096, 4096→11008 / 11008→4096 / 8192→28672", f"{S['c2_gemm_4096x11008']['us']:.1f} / {S['c2_gemm_11008x4096']['us']:.1f} / {us('c5_single_gpu_8192x28672', 'us_per_launch'):.0f} µs",
      f"{S['c2_gemm_4096x11008']['frac']:.2f} / {S['c2_gemm_11008x4096']['frac']:.2f} / {fr('c5_single_gpu_8192x28672'):.2f}",
      f"688 tiles = 2.69 rounds of 256 CUs; long launches clock lower (1.53 GHz under the profiler); act-order (`g_idx` permutation) at M = 4096: {ex['c2_act_order_4096x11008']['M4096_ratio']:.2f} × the plain time (was 1.13 ×)"),
@@ -73,6 +73,17 @@ rows = [
      " / ".join(f"{e2[(4096, k, n)]['roofline']['frac']:.2f}" for k, n in ((4096, 4096), (4096, 11008), (11008, 4096))),
      "= 0.98–1.11 × the MPQ W4 dense form of the same shape and box (`profiles/r05_exl2_prefill_ab.txt`); M = 64: "
      + "–".join(f"{v:.0f}" for v in sorted(e2[(64, k, n)]['us_per_launch'] for k, n in ((4096, 4096), (4096, 11008), (11008, 4096)))[::2]) + " µs (was 39–59 with the vendor GEMM)"),
+    ("**binary conv2d 512→512 3×3 on 7×7 (configs[3]), ONE launch** B = 1 / 32 / 128",
+     " / ".join(f"{e['us_per_call']:.1f}" for e in ex["c4_binary"] if "conv" in e["op"]) + " µs (round 5: 8.9 / 20.7 / 29.8 in two / two / three launches)",
+     " / ".join(f"{e['roofline']['frac']:.3f}" for e in ex["c4_binary"] if "conv" in e["op"]) + " (VALU xor+bcnt peak at B = 1, FP4 MFMA peak beyond)",
+     "B ≤ 8: `xnor_conv_fused_kernel`; beyond: `xnor_conv_mfma_kernel` (FP4 image of the input rows in LDS, no im2col image); history `profiles/r06_conv_timelines.txt`, counters `r06_pmc_conv.txt`"),
+    ("binary linear 4096² M = 1 / 64 / 512 / 4096 (XNOR kernels) · matrix pipe M = 512 / 4096",
+     " / ".join(f"{e['us_per_launch']:.1f}" for e in ex["c4_binary"] if e["op"] == "binary linear 4096x4096") + " · " + " / ".join(f"{e['us_per_call']:.1f}" for e in ex["c4_binary"] if "matrix pipe" in e["op"] and e["M"] in (512, 4096)) + " µs",
+     " / ".join(f"{e['roofline']['frac']:.2f}" for e in ex["c4_binary"] if e["op"] == "binary linear 4096x4096") + " · " + " / ".join(f"{e['roofline']['frac']:.2f}" for e in ex["c4_binary"] if "matrix pipe" in e["op"] and e["M"] in (512, 4096)), "unchanged this round"),
+    ("W8A8 / W4A4 GEMM 4096³ · 4096→11008 at M = 4096",
+     " · ".join(" / ".join(f"{e['us_per_launch']:.1f}" for e in ex["f1_int_gemm"] if (e["M"], e["N"]) == mn) for mn in ((4096, 4096), (4096, 11008))) + " µs",
+     " · ".join(" / ".join(f"{e['roofline']['frac']:.2f}" for e in ex["f1_int_gemm"] if (e["M"], e["N"]) == mn) for mn in ((4096, 4096), (4096, 11008))) + " of 5 POP/s",
+     "counters `profiles/r06_pmc_int_gemm.txt`: the i8 pipe 0.43 busy at 32 cycles per instruction; the loop runs at the bf16 kernel's stage time, the fp32 output of W8A8 (67 MB) is what separates it"),
     (f"CPU baseline (oracle port; the box grants {d['cpu_baseline']['cores_granted']} of its {d['cpu_baseline']['nproc']} logical CPUs)",
      " / ".join(f"{cb[k]:.1f}" for k in sorted(cb, key=int, reverse=True)) + " GB/s at " + " / ".join(sorted(cb, key=int, reverse=True)) + " threads", "—",
      "list of 16 layer GEMVs, statically partitioned"),
