@@ -348,11 +348,14 @@ __global__ __launch_bounds__(256) void xnor_conv_mfma_kernel(const ConvMfmaArgs 
                 const int qc = live ? q : run - 1;  // lanes past the run re-read its last pixel (valid memory) and store nothing
                 const int r = qc / a.W, c = qc - r * a.W;
                 const int pix = (ia - ih_lo + r) * a.WP + c + a.pad;
+                // with a stride the last picture columns may lie beyond the last tap (WP < W + 2 * pad): not part of the image -- stored, they
+                // would land on the next row's left border (found by tests/sweeps/fuzz_other_ops.py at stride 3)
+                const bool keep = live && c + a.pad < a.WP;
                 unsigned char* dst = img + (size_t)(sl * slot_pix + pix) * PITCH;
                 for (int cw0 = wave * NW; cw0 < CW; cw0 += 4 * NW) {
                     uint32_t v[NW];
                     conv_pixel_words<DT, NW>(rs, (unsigned)(ia * a.W + qc) * EB, (unsigned)(cw0 * 32) * plane_bytes, plane_bytes, v);
-                    if (live) {
+                    if (keep) {
 #pragma unroll
                         for (int i = 0; i < NW; i++)
                             *reinterpret_cast<uint4_t*>(dst + (cw0 + i) * 16) = uint4_t{conv_fp4_from_bits8(v[i]), conv_fp4_from_bits8(v[i] >> 8),

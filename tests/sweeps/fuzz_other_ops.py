@@ -20,7 +20,7 @@ from oracle import oracle as orc  # noqa: E402
 DEV = T.DEV
 
 
-def run(cases=60, seed=1, ops=("binlin", "binconv", "q4", "q8", "mbwq", "grouped", "grad", "pack")):
+def run(cases=60, seed=1, ops=("binlin", "binconv", "binconv1", "q4", "q8", "mbwq", "grouped", "grad", "pack")):
     from bitorch_engine.extensions import binary_linear_cuda, q_linear_cutlass as qc, q_linear_cuda
     from bitorch_engine.extensions._binary_common import pack_rows, conv2d
     rng = np.random.default_rng(seed)
@@ -53,6 +53,41 @@ def run(cases=60, seed=1, ops=("binlin", "binconv", "q4", "q8", "mbwq", "grouped
                     wp = pack_rows(w.reshape(OC, -1).to(DEV)).contiguous()
                     y = conv2d(x.to(DEV), wp, OC, ks, st, pad, dil, 1.0).cpu().numpy()
                     good = np.array_equal(y, orc.binary_conv2d(x.numpy(), w.numpy(), st, pad, dil))
+                elif op == "binconv1":
+                    # the ONE-launch forms of round 6 (binary_conv_fused.hip) through the C ABI, both of them where the geometry allows, on geometries drawn
+                    # inside their range: every channel count / kernel size they take, strides, paddings, ragged channel blocks, all three input dtypes
+                    from bitorch_engine import _hip
+                    from bitorch_engine.extensions import _binary_common as bc
+                    L = _hip.lib()
+                    B, C = int(rng.integers(1, 12)), int(rng.choice([64, 128, 256, 512]))
+                    H, W = int(rng.integers(2, 30)), int(rng.integers(2, 34))
+                    OC = int(rng.choice([1, 31, 32, 33, 64, 65, 100, 128, 129, 200, 256, 300]))
+                    ks, st, pad = int(rng.choice([1, 3, 3])), int(rng.choice([1, 1, 2, 3])), int(rng.integers(0, 3))
+                    if H + 2 * pad < ks or W + 2 * pad < ks:
+                        continue
+                    dts = str(rng.choice(["f32", "f16", "bf16"]))
+                    tag = f"binconv1 {dts} B={B} C={C} H={H} W={W} OC={OC} k={ks} s={st} p={pad}"
+                    x, w = torch.randn((B, C, H, W), generator=gen), torch.randn((OC, C, ks, ks), generator=gen)
+                    x.view(-1)[::53] = 0.0
+                    x.view(-1)[7::97] = -0.0
+                    xd = x.to(T._TDT[dts]).to(DEV)
+                    wp = pack_rows(w.reshape(OC, -1).to(DEV)).contiguous()
+                    want = orc.binary_conv2d(xd.float().cpu().numpy(), w.numpy(), st, pad, 1)
+                    OH, OW = want.shape[2], want.shape[3]
+                    good, ran = True, 0
+                    stream = torch.cuda.current_stream().cuda_stream
+                    if L.bie_binary_conv2d_fused_ok(B, C, H, W, OC, ks, st, pad, 1):
+                        y = torch.full((B, OC, OH, OW), float("nan"), device=DEV)
+                        rc = L.bie_binary_conv2d_forward_fused(xd.data_ptr(), bc.conv_weight_lanes(wp, OC, C, ks).data_ptr(), y.data_ptr(), B, C, H, W, OC, ks, st, pad, 1, 1.0,
+                                                               _hip.dt(xd), stream)
+                        good, ran = good and rc == 0 and np.array_equal(y.cpu().numpy(), want), ran + 1
+                    if L.bie_binary_conv2d_mfma_ok(B, C, H, W, OC, ks, st, pad, 1):
+                        y = torch.full((B, OC, OH, OW), float("nan"), device=DEV)
+                        rc = L.bie_binary_conv2d_forward_mfma(xd.data_ptr(), bc.conv_weight_fp4_image(wp, OC, C, ks).data_ptr(), y.data_ptr(), B, C, H, W, OC, ks, st, pad, 1, 1.0,
+                                                              _hip.dt(xd), stream)
+                        good, ran = good and rc == 0 and np.array_equal(y.cpu().numpy(), want), ran + 1
+                    if ran == 0:
+                        continue
                 elif op == "q4":
                     M = int(rng.choice([1, 5, 64, 127, 128, 129, 130, 257, 300, 512]))
                     N = int(rng.choice([4, 36, 124, 128, 132, 260, 520, 1024]))

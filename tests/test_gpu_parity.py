@@ -873,7 +873,9 @@ def test_binary_conv_tap_form_equals_the_im2col_form_and_the_oracle(B, C, H, W, 
 @pytest.mark.parametrize("B,C,H,W,OC,ks,st,pad", [(1, 512, 7, 7, 512, 3, 1, 1), (32, 512, 7, 7, 512, 3, 1, 1), (128, 512, 7, 7, 512, 3, 1, 1), (5, 512, 7, 7, 200, 3, 1, 1),
                                                  (2, 256, 14, 14, 256, 3, 1, 1), (3, 256, 14, 14, 512, 3, 2, 1), (1, 128, 28, 28, 128, 3, 1, 1), (9, 128, 28, 28, 256, 3, 2, 1),
                                                  (2, 256, 14, 14, 512, 1, 2, 0), (3, 128, 9, 11, 64, 3, 2, 1), (2, 512, 5, 60, 72, 3, 1, 1), (1, 128, 13, 64, 130, 1, 1, 0),
-                                                 (2, 256, 6, 6, 96, 3, 1, 0), (70, 128, 4, 4, 64, 3, 1, 2)])
+                                                 (2, 256, 6, 6, 96, 3, 1, 0), (70, 128, 4, 4, 64, 3, 1, 2),
+                                                 # stride 3: picture columns beyond the last tap (the fuzz sweep's finding: they were stored onto the next row's border)
+                                                 (1, 128, 19, 12, 32, 3, 3, 1), (8, 512, 29, 6, 200, 3, 3, 1), (10, 256, 9, 7, 129, 1, 3, 1)])
 def test_binary_conv_one_launch_form_against_the_oracle_and_the_other_forms(B, C, H, W, OC, ks, st, pad, monkeypatch):
     """bie_binary_conv2d_forward_fused (configs[3] as ONE launch, no workspace): sign-pack into an LDS bit image, register-resident
     weight quarters, XNOR-popcount against uniform LDS reads.  Bit-exact against the oracle's integers (pinned by the compiled binary_conv.cpp,
