@@ -59,7 +59,10 @@ def integer_leaf_grad(weight: torch.Tensor, grad_weight: torch.Tensor, needs_gra
         return grad_weight
     if isinstance(weight, torch.nn.Parameter) and not weight.is_floating_point():
         g = grad_weight.to(weight.dtype)
-        weight.grad = g if weight.grad is None else weight.grad + g
+        if weight.grad is not None:  # a second backward before the update: accumulate like autograd would, saturating instead of wrapping
+            info = torch.iinfo(weight.dtype)
+            g = (weight.grad.to(torch.int32) + g.to(torch.int32)).clamp_(info.min, info.max).to(weight.dtype)
+        weight.grad = g
     return None
 
 
