@@ -99,6 +99,13 @@ __global__ __launch_bounds__(256) void xnor_conv_fused_kernel(const ConvFusedArg
     const int nblk = (a.OC + 63) >> 6;
 
     BIE_CONV_STAMP(0);
+    // what the write-out needs of the kernel arguments is fetched HERE (opaque copies): read where it is used, the scalar loads of the argument
+    // segment missed their cache after the last barrier (write-out of 7 pixels x 64 channels at B = 1: 2.0 -> 1.76 us)
+    float* ybase = a.y + ((b * a.OC) * (long)a.OH + oh0) * a.OW;
+    float yscale = a.scale;
+    int yoc = a.OC, ypitch = a.PP;
+    long yplane = (long)a.OH * a.OW;
+    asm volatile("" : "+s"(ybase), "+s"(yscale), "+s"(yoc), "+s"(ypitch), "+s"(yplane));
     // ---- 1. this wave's K quarter of the weights (requested first: in flight under the pack phase)
     uint32_t wreg[G][NWW];
 #pragma unroll
@@ -193,16 +200,16 @@ __global__ __launch_bounds__(256) void xnor_conv_fused_kernel(const ConvFusedArg
 
     // ---- 4b. write-out, pixel-contiguous: row (group, channel) of `red` = P consecutive floats of y
     const int Kc = a.C * T;
-    const long plane = (long)a.OH * a.OW;
+    const __attribute__((address_space(3))) int* red3 = (const __attribute__((address_space(3))) int*)red;
     for (int row0 = wq * 4; row0 < G * 64; row0 += 16) {  // four rows per pass: their LDS reads and stores overlap
         for (int p = lane; p < P; p += 64) {
             int pc[4];
 #pragma unroll
-            for (int r = 0; r < 4; r++) pc[r] = red[(row0 + r) * a.PP + p];
+            for (int r = 0; r < 4; r++) pc[r] = red3[(row0 + r) * ypitch + p];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int row = row0 + r, oc = (ocb * G + (row >> 6)) * 64 + (row & 63);
-                if (oc < a.OC) a.y[(b * a.OC + oc) * plane + (long)oh0 * a.OW + p] = (float)(Kc - 2 * pc[r]) * a.scale;
+                if (oc < yoc) ybase[oc * yplane + p] = (float)(Kc - 2 * pc[r]) * yscale;
             }
         }
     }

@@ -14,7 +14,7 @@ for B in [int(v) for v in (sys.argv[1:] or ["1", "32", "128"])]:
     x = torch.randn((B, 512, 7, 7), device=dev)
     w = torch.randn((512, 512, 3, 3), device=dev)
     wp = bc.pack_rows(w.reshape(512, -1)).contiguous()
-    for _ in range(5):
+    for _ in range(int(os.environ.get('CONV_TL_CALLS', '5'))):
         y = bc.conv2d(x, wp, 512, 3, 1, 1, 1, 1.0)
     torch.cuda.synchronize()
     n = 8192
