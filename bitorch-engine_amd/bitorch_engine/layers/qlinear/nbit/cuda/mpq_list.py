@@ -72,6 +72,7 @@ class MPQForwardList:
         self._L = L
         self.device = dev
         self.launches = L.bie_mpq_list_launches(handle)
+        self.form = L.bie_mpq_list_form(handle)  # 0 lookup + FMA, 1 matrix pipe (K split inside a workgroup), 2 matrix pipe (x shared by a workgroup)
 
     def forward(self, stream=None):
         """Enqueue the launch on `stream` (a raw hipStream_t / None = the current stream of the plan's device)."""

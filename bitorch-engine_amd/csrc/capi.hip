@@ -28,6 +28,7 @@ int mpq_list_create(MpqList** out, int n, const bie_mpq_list_entry* ent, int M, 
                     void* device_mem, size_t device_bytes);
 int mpq_list_forward(MpqList* p, hipStream_t st);
 int mpq_list_launches(const MpqList* p);
+int mpq_list_form(const MpqList* p);
 void mpq_list_destroy(MpqList* p);
 // splitk.hip
 int status_init();
@@ -166,6 +167,7 @@ int bie_mpq_list_create(bie_mpq_list_t** plan, int n_entries, const bie_mpq_list
 }
 int bie_mpq_list_forward(bie_mpq_list_t* plan, void* stream) { return mpq_list_forward(reinterpret_cast<MpqList*>(plan), as_stream(stream)); }
 int bie_mpq_list_launches(const bie_mpq_list_t* plan) { return mpq_list_launches(reinterpret_cast<const MpqList*>(plan)); }
+int bie_mpq_list_form(const bie_mpq_list_t* plan) { return mpq_list_form(reinterpret_cast<const MpqList*>(plan)); }
 void bie_mpq_list_destroy(bie_mpq_list_t* plan) { mpq_list_destroy(reinterpret_cast<MpqList*>(plan)); }
 
 // explicit g_idx that is not a permutation of k // group_size, prefill: per-k dequantise into the fragment image + the dense GEMM (mpq_dense.hip)

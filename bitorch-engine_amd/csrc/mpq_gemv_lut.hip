@@ -678,6 +678,217 @@ __device__ __forceinline__ void lutm_issue8(uint32_t (&l)[8], uint32_t ca, uint3
     asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(l[7]) : "v"(lut_addr<3>(ca, wo)), "n"(OFF) : "memory");
 }
 
+// One unit (RPG packed rows of this wave's 64 columns) against RB 16-row blocks of x: the weights' reference values into the A operand of
+// v_mfma_f32_16x16x32, by table (bf16) or by packed-fp16 arithmetic (fp16).  XPERM: the fp16 form still has to put the activations' eight k
+// of a fragment into the pair order (the x-sharing form does it once per workgroup while staging)
+// eight consecutive k (16 bytes of x) in the order the fp16 arithmetic form leaves a word's fields in: (k0, k4), (k1, k5), (k2, k6), (k3, k7)
+__device__ __forceinline__ uint4_t lutm_pair_order(const uint4_t v) {
+    return uint4_t{__builtin_amdgcn_perm(v.z, v.x, 0x05040100u), __builtin_amdgcn_perm(v.z, v.x, 0x07060302u),
+                   __builtin_amdgcn_perm(v.w, v.y, 0x05040100u), __builtin_amdgcn_perm(v.w, v.y, 0x07060302u)};
+}
+
+struct LutmCtx { int kb, c; uint32_t* mytab; uint32_t lane_addr, wavepat, m0f; };
+
+// xfrag(rq, dst): the RB fragments of row quad rq (registers already loaded, or an LDS read issued here -- the table form calls it where the
+// read is older than the lookups its next counted wait leaves in flight); after_rq(rq): every word of w[rq] has been consumed (the x-sharing
+// form loads the next unit's row quad into the same registers there)
+template <int DT, int ZM, int RPG, int RB, bool DIRECT, bool XPERM, class XF, class AR>
+__device__ __forceinline__ void lutm_process_unit(const LutmCtx& cx, uint4_t (&w)[RPG / 4], XF&& xfrag, const uint32_t (&sb)[4],
+                                                  const uint32_t (&zb)[4], lutm_acc_t (&acc)[RB][4], AR&& after_rq) {
+    constexpr int RQ = RPG / 4;
+    constexpr bool PAIRCOL = RB == 1 || DT == BIE_F16;  // table layout: below
+    const int kb = cx.kb, c = cx.c;
+    uint32_t* const mytab = cx.mytab;
+    const uint32_t lane_addr = cx.lane_addr, wavepat = cx.wavepat, m0f = cx.m0f;
+    if constexpr (DIRECT) {
+        // fp16: no table.  The reference's value of a weight IS packed-fp16 arithmetic on the exact integer -- (1024 + q) by one v_and_or_b32
+        // per PAIR of fields, v_pk_add_f16 (exact), v_pk_mul_f16 = fl(q * s), v_pk_add_f16 = fl(. - z) (fused: one v_pk_fma_f16; asym: the
+        // exact difference, one v_pk_mul_f16) -- 2 vector instructions per weight against 2.75 + the table build, and no LDS.  A pair is
+        // (k_i, k_{i+4}) of the word, so the activations' eight k are put in the same order by four v_perm_b32 per fragment.
+        // fields 0 / 2 of a byte pair sit in the mantissa of 1024 (0x6400 | q), fields 1 / 3 four bits higher in the mantissa of 64
+        // (0x5400 | q << 4 = 64 + q): one shift per word instead of three
+        half2_t s2[4], zlo[4], zhi[4];  // sym / fused: zlo = z; asym: the exact offsets 1024 + (zq + 1) and 64 + (zq + 1)
+#pragma unroll
+        for (int f = 0; f < 4; f++) {
+            const half_t sh = __builtin_bit_cast(half_t, (uint16_t)sb[f]);
+            s2[f] = half2_t{sh, sh};
+            if constexpr (ZM == ZM_ASYM) {
+                const half_t o1 = (half_t)(1024.0f + (float)zb[f]), o2 = (half_t)(64.0f + (float)zb[f]);
+                zlo[f] = half2_t{o1, o1};
+                zhi[f] = half2_t{o2, o2};
+            } else {
+                const half_t zh = __builtin_bit_cast(half_t, (uint16_t)zb[f]);
+                zlo[f] = half2_t{zh, zh};
+            }
+        }
+        uint32_t mlo, mhi;
+        asm("v_mov_b32 %0, 0x000f000f" : "=v"(mlo));
+        asm("v_mov_b32 %0, 0x00f000f0" : "=v"(mhi));
+        const uint32_t k1024u = 0x64006400u, k64u = 0x54005400u;
+        const half2_t k1024 = __builtin_bit_cast(half2_t, k1024u), k64 = __builtin_bit_cast(half2_t, k64u);
+        uint4_t xq[2][RB];  // the fragments of the current and the next row quad (an LDS read of the x-sharing form gets a row quad of cover)
+        xfrag(0, xq[0]);
+#pragma unroll
+        for (int rq = 0; rq < RQ; rq++) {
+            if (rq + 1 < RQ) xfrag(rq + 1, xq[(rq + 1) & 1]);
+            uint4_t xp[RB];
+#pragma unroll
+            for (int b = 0; b < RB; b++) xp[b] = XPERM ? lutm_pair_order(xq[rq & 1][b]) : xq[rq & 1][b];
+#pragma unroll
+            for (int f = 0; f < 4; f++) {
+                const uint32_t word = f == 0 ? w[rq].x : (f == 1 ? w[rq].y : (f == 2 ? w[rq].z : w[rq].w));
+                const uint32_t word8 = word >> 8;
+                uint32_t b4[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {  // b4[i] = the reference's values of fields (i, i + 4)
+                    uint32_t P;
+                    if (i & 1) asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(P) : "v"(i < 2 ? word : word8), "v"(mhi), "s"(k64u));
+                    else asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(P) : "v"(i < 2 ? word : word8), "v"(mlo), "s"(k1024u));
+                    const half2_t a = __builtin_bit_cast(half2_t, P);
+                    half2_t r;
+                    if constexpr (ZM == ZM_ASYM) {
+                        r = (a - ((i & 1) ? zhi[f] : zlo[f])) * s2[f];  // exact integer difference, one rounding
+                    } else {
+                        const half2_t q = a - ((i & 1) ? k64 : k1024);  // exact
+                        if constexpr (ZM == ZM_FUSED) r = __builtin_elementwise_fma(q, s2[f], -zlo[f]);
+                        else r = q * s2[f] - zlo[f];  // fl(q * s), then fl(. - z)
+                    }
+                    b4[i] = __builtin_bit_cast(uint32_t, r);
+                }
+#pragma unroll
+                for (int rb = 0; rb < RB; rb++) acc[rb][f] = lutm_mfma<DT>(b4, xp[rb], acc[rb][f]);
+            }
+            after_rq(rq);
+        }
+        return;
+    }
+    // PAIRCOL (one 16-row block of x, and fp16 at either size): the entries of a column pair share a dword.  bf16 with two row blocks keeps one
+    // dword per entry: the pair form measured 2-5 % slower there (profiles/r05_lutm_colpair_ab.txt)
+    if constexpr (PAIRCOL) {
+        // ---- this lane's 16 entries (q = 4*kb .. 4*kb+3 of its four columns), each stored for both bank replicas.  The entries of a column
+        // PAIR (f, f + 1) share a dword -- low half the even column, high half the odd one -- so the sixteen entries leave as eight stores
+        // and come out of ONE conversion per pair; a lookup of the odd column is the same read two bytes further
+#pragma unroll
+        for (int fp = 0; fp < 2; fp++) {
+            float s[2], z[2] = {0.0f, 0.0f};
+            int zq1[2] = {0, 0};
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int f = 2 * fp + h;
+                if constexpr (DT == BIE_BF16) s[h] = bf16_bits_to_f32(sb[f]); else s[h] = f16_bits_to_f32(sb[f]);
+                if constexpr (ZM == ZM_ASYM) zq1[h] = (int)zb[f];
+                else if constexpr (DT == BIE_BF16) z[h] = bf16_bits_to_f32(zb[f]); else z[h] = f16_bits_to_f32(zb[f]);
+            }
+            uint32_t bits[4];
+            if constexpr (DT == BIE_BF16 && ZM == ZM_SYM) {
+                // fl(q * s) of both columns in one v_cvt_pk_bf16_f32, unpacked by shift / mask, the second rounding's subtraction in fp32, one more
+                // v_cvt_pk_bf16_f32: 8 operations per pair of entries instead of 11.  (NOT the dot-unit subtraction of the one-row list kernel,
+                // 1 * lo + 0 * hi - z: the halves here are two different COLUMNS, and 0 * inf = NaN would carry one column's infinite scale into
+                // its neighbour's entries -- caught by the special-value tests)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float qf = (float)(4 * kb + e);
+                    const uint32_t A = pack_bf16x2(qf * s[0], qf * s[1]);
+                    bits[e] = pack_bf16x2(__uint_as_float(A << 16) - z[0], __uint_as_float(A & 0xffff0000u) - z[1]);
+                }
+            } else if constexpr (DT == BIE_F16) {
+                // fp16: both columns' entries in ONE packed-fp16 pass (fl(q * s): v_pk_mul_f16, fl(. - z): v_pk_add_f16 -- sym, the reference's two roundings;
+                // fused: v_pk_fma_f16; asym: the exact integer difference times s, one rounding)
+                const half2_t s2 = half2_t{__builtin_bit_cast(half_t, (uint16_t)sb[2 * fp]), __builtin_bit_cast(half_t, (uint16_t)sb[2 * fp + 1])};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int q = 4 * kb + e;
+                    half2_t r;
+                    if constexpr (ZM == ZM_ASYM) {
+                        r = half2_t{(half_t)(float)(q - zq1[0]), (half_t)(float)(q - zq1[1])} * s2;
+                    } else {
+                        const half2_t z2 = half2_t{__builtin_bit_cast(half_t, (uint16_t)zb[2 * fp]), __builtin_bit_cast(half_t, (uint16_t)zb[2 * fp + 1])};
+                        const half2_t q2 = half2_t{(half_t)(float)q, (half_t)(float)q};
+                        if constexpr (ZM == ZM_FUSED) r = __builtin_elementwise_fma(q2, s2, -z2);
+                        else r = q2 * s2 - z2;
+                    }
+                    bits[e] = __builtin_bit_cast(uint32_t, r);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {  // both values are representable in the 16-bit type: the conversion is exact
+                    const uint32_t q = (uint32_t)(4 * kb + e);
+                    bits[e] = pack_bf16x2(lut_entry<DT, ZM>(q, s[0], z[0], zq1[0]), lut_entry<DT, ZM>(q, s[1], z[1], zq1[1]));
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                uint32_t* p = mytab + fp * 1024 + (4 * kb + e) * 64 + c;
+                p[0] = bits[e];
+                p[16] = bits[e];
+            }
+        }
+    } else {
+        // ---- this lane's 16 entries (q = 4*kb .. 4*kb+3 of its four columns), each stored for both bank replicas;
+        // 16-bit value in the low half of a dword
+#pragma unroll
+        for (int f = 0; f < 4; f++) {
+            float s, z = 0.0f;
+            int zq1 = 0;
+            if constexpr (DT == BIE_BF16) s = bf16_bits_to_f32(sb[f]); else s = f16_bits_to_f32(sb[f]);
+            if constexpr (ZM == ZM_ASYM) zq1 = (int)zb[f];
+            else if constexpr (DT == BIE_BF16) z = bf16_bits_to_f32(zb[f]); else z = f16_bits_to_f32(zb[f]);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const uint32_t q = (uint32_t)(4 * kb + e);
+                const float t = lut_entry<DT, ZM>(q, s, z, zq1);
+                uint32_t bits;
+                if constexpr (DT == BIE_BF16) bits = __float_as_uint(t) >> 16; else bits = f32_to_f16_bits(t);
+                uint32_t* p = mytab + (f >> 1) * 1024 + q * 64 + (f & 1) * 32 + c;
+                p[0] = bits;
+                p[16] = bits;
+            }
+        }
+    }
+    // ---- fragment steps st = 4*rq + f: the eight 16-bit lookups of step st+1 are in flight while step st feeds the MFMA
+    // (plain ds_read_u16 + one v_lshl_or_b32 per pair: with SRAM-ECC register files a d16 load does not preserve the other
+    // half of its destination, so a d16 / d16_hi pair cannot share a register)
+    uint32_t la[8], lb[8];
+    auto issue = [&](uint32_t (&l)[8], int rq, int f) {
+        const uint32_t word = f == 0 ? w[rq].x : (f == 1 ? w[rq].y : (f == 2 ? w[rq].z : w[rq].w));
+        uint32_t we, wo;
+        asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(we) : "v"(word), "v"(m0f), "s"(wavepat));
+        asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(wo) : "v"(word >> 4), "v"(m0f), "s"(wavepat));
+        constexpr int ODD = PAIRCOL ? 2 : 128;  // the odd column of a pair: the high half of the same dword / a block of its own
+        if (f == 0) lutm_issue8<0>(l, lane_addr, we, wo);
+        else if (f == 1) lutm_issue8<ODD>(l, lane_addr, we, wo);
+        else if (f == 2) lutm_issue8<4096>(l, lane_addr, we, wo);
+        else lutm_issue8<4096 + ODD>(l, lane_addr, we, wo);
+    };
+    auto wait_pack = [&](uint32_t (&l)[8], bool more, uint32_t (&b)[4]) {
+        if (more) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3]), "+v"(l[4]), "+v"(l[5]), "+v"(l[6]), "+v"(l[7])::"memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3]), "+v"(l[4]), "+v"(l[5]), "+v"(l[6]), "+v"(l[7])::"memory");
+#pragma unroll
+        for (int i = 0; i < 4; i++) b[i] = (l[2 * i + 1] << 16) | l[2 * i];
+    };
+    uint4_t xq[2][RB];  // the fragments of the current and the next row quad
+    xfrag(0, xq[0]);
+    issue(la, 0, 0);
+#pragma unroll
+    for (int st = 0; st < 4 * RQ; st++) {
+        const int rq = st >> 2, f = st & 3;
+        const bool more = st + 1 < 4 * RQ;
+        uint32_t b[4];
+        if (more && f == 3) xfrag(rq + 1, xq[(rq + 1) & 1]);  // ahead of the next issue: complete at this step's counted wait
+        if (st & 1) {
+            if (more) issue(la, (st + 1) >> 2, (st + 1) & 3);
+            if (f == 2) after_rq(rq);  // word 3 of this row quad has just gone out
+            wait_pack(lb, more, b);
+        } else {
+            if (more) issue(lb, (st + 1) >> 2, (st + 1) & 3);
+            if (f == 2) after_rq(rq);
+            wait_pack(la, more, b);
+        }
+#pragma unroll
+        for (int rb = 0; rb < RB; rb++) acc[rb][f] = lutm_mfma<DT>(b, xq[rq & 1][rb], acc[rb][f]);
+    }
+}
+
 // what one workgroup of the matrix-pipe form needs about its layer: filled from the kernel arguments (one launch per layer / set of
 // layers sharing x) or from a device-resident ListEntry (bie_mpq_list_*, 3 <= M <= 32: many layers in one launch)
 struct LutmView {
@@ -686,6 +897,7 @@ struct LutmView {
     unsigned* gen;             // generation words, indexed by the tile number the granule columns are counted in
     int N, M, K, G, S, gpw, hshift;
     long ncat;                 // granule columns: tiles * 64
+    unsigned qw_bytes = 0;     // bytes of qw (the x-sharing form reads the rows through a buffer descriptor)
 };
 
 // RB: 16-row blocks of x served by one pass over the weights (RB = 2: 17 <= M <= 32 -- the lookups and the pairing are shared, a word
@@ -695,7 +907,11 @@ __device__ __forceinline__ void lutm_body(const LutmView& lv, const int tile_loc
                                           unsigned* status, const unsigned tag_skew, const int spin_limit) {
     constexpr int NB = 8;
     constexpr int RQ = RPG / 4;  // row quads (32 k) per unit
-    constexpr bool PAIRCOL = RB == 1 || DT == BIE_F16;  // table layout: see process_unit
+#ifdef BIE_LUTM_F16_TABLE
+    constexpr bool DIRECT = false;
+#else
+    constexpr bool DIRECT = DT == BIE_F16;  // fp16: packed-fp16 arithmetic instead of the table (process_unit)
+#endif
     static_assert(NW <= 8 && RPG % 4 == 0, "wave bits of the table address / whole row quads");
     __shared__ __attribute__((aligned(8192))) uint32_t tab[NW * 2048];  // the only LDS object: starts at LDS address 0
 
@@ -761,127 +977,15 @@ __device__ __forceinline__ void lutm_body(const LutmView& lv, const int tile_loc
     uint32_t m0f;
     asm("v_mov_b32 %0, 0x0f0f0f0f" : "=v"(m0f));
 
-    auto process_unit = [&](const uint4_t (&w)[RQ], const uint4_t (&xf)[RB][RQ], const uint32_t (&sb)[4], const uint32_t (&zb)[4]) {
-        // PAIRCOL (one 16-row block of x, and fp16 at either size): the entries of a column pair share a dword.  bf16 with two row blocks keeps one
-        // dword per entry: the pair form measured 2-5 % slower there (profiles/r05_lutm_colpair_ab.txt)
-        if constexpr (PAIRCOL) {
-            // ---- this lane's 16 entries (q = 4*kb .. 4*kb+3 of its four columns), each stored for both bank replicas.  The entries of a column
-            // PAIR (f, f + 1) share a dword -- low half the even column, high half the odd one -- so the sixteen entries leave as eight stores
-            // and come out of ONE conversion per pair; a lookup of the odd column is the same read two bytes further
-    #pragma unroll
-            for (int fp = 0; fp < 2; fp++) {
-                float s[2], z[2] = {0.0f, 0.0f};
-                int zq1[2] = {0, 0};
-    #pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const int f = 2 * fp + h;
-                    if constexpr (DT == BIE_BF16) s[h] = bf16_bits_to_f32(sb[f]); else s[h] = f16_bits_to_f32(sb[f]);
-                    if constexpr (ZM == ZM_ASYM) zq1[h] = (int)zb[f];
-                    else if constexpr (DT == BIE_BF16) z[h] = bf16_bits_to_f32(zb[f]); else z[h] = f16_bits_to_f32(zb[f]);
-                }
-                uint32_t bits[4];
-                if constexpr (DT == BIE_BF16 && ZM == ZM_SYM) {
-                    // fl(q * s) of both columns in one v_cvt_pk_bf16_f32, unpacked by shift / mask, the second rounding's subtraction in fp32, one more
-                    // v_cvt_pk_bf16_f32: 8 operations per pair of entries instead of 11.  (NOT the dot-unit subtraction of the one-row list kernel,
-                    // 1 * lo + 0 * hi - z: the halves here are two different COLUMNS, and 0 * inf = NaN would carry one column's infinite scale into
-                    // its neighbour's entries -- caught by the special-value tests)
-    #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const float qf = (float)(4 * kb + e);
-                        const uint32_t A = pack_bf16x2(qf * s[0], qf * s[1]);
-                        bits[e] = pack_bf16x2(__uint_as_float(A << 16) - z[0], __uint_as_float(A & 0xffff0000u) - z[1]);
-                    }
-                } else if constexpr (DT == BIE_F16) {
-                    // fp16: both columns' entries in ONE packed-fp16 pass (fl(q * s): v_pk_mul_f16, fl(. - z): v_pk_add_f16 -- sym, the reference's two roundings;
-                    // fused: v_pk_fma_f16; asym: the exact integer difference times s, one rounding)
-                    const half2_t s2 = half2_t{__builtin_bit_cast(half_t, (uint16_t)sb[2 * fp]), __builtin_bit_cast(half_t, (uint16_t)sb[2 * fp + 1])};
-    #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const int q = 4 * kb + e;
-                        half2_t r;
-                        if constexpr (ZM == ZM_ASYM) {
-                            r = half2_t{(half_t)(float)(q - zq1[0]), (half_t)(float)(q - zq1[1])} * s2;
-                        } else {
-                            const half2_t z2 = half2_t{__builtin_bit_cast(half_t, (uint16_t)zb[2 * fp]), __builtin_bit_cast(half_t, (uint16_t)zb[2 * fp + 1])};
-                            const half2_t q2 = half2_t{(half_t)(float)q, (half_t)(float)q};
-                            if constexpr (ZM == ZM_FUSED) r = __builtin_elementwise_fma(q2, s2, -z2);
-                            else r = q2 * s2 - z2;
-                        }
-                        bits[e] = __builtin_bit_cast(uint32_t, r);
-                    }
-                } else {
-    #pragma unroll
-                    for (int e = 0; e < 4; e++) {  // both values are representable in the 16-bit type: the conversion is exact
-                        const uint32_t q = (uint32_t)(4 * kb + e);
-                        bits[e] = pack_bf16x2(lut_entry<DT, ZM>(q, s[0], z[0], zq1[0]), lut_entry<DT, ZM>(q, s[1], z[1], zq1[1]));
-                    }
-                }
-    #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    uint32_t* p = mytab + fp * 1024 + (4 * kb + e) * 64 + c;
-                    p[0] = bits[e];
-                    p[16] = bits[e];
-                }
-            }
-        } else {
-            // ---- this lane's 16 entries (q = 4*kb .. 4*kb+3 of its four columns), each stored for both bank replicas;
-            // 16-bit value in the low half of a dword
-    #pragma unroll
-            for (int f = 0; f < 4; f++) {
-                float s, z = 0.0f;
-                int zq1 = 0;
-                if constexpr (DT == BIE_BF16) s = bf16_bits_to_f32(sb[f]); else s = f16_bits_to_f32(sb[f]);
-                if constexpr (ZM == ZM_ASYM) zq1 = (int)zb[f];
-                else if constexpr (DT == BIE_BF16) z = bf16_bits_to_f32(zb[f]); else z = f16_bits_to_f32(zb[f]);
-    #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const uint32_t q = (uint32_t)(4 * kb + e);
-                    const float t = lut_entry<DT, ZM>(q, s, z, zq1);
-                    uint32_t bits;
-                    if constexpr (DT == BIE_BF16) bits = __float_as_uint(t) >> 16; else bits = f32_to_f16_bits(t);
-                    uint32_t* p = mytab + (f >> 1) * 1024 + q * 64 + (f & 1) * 32 + c;
-                    p[0] = bits;
-                    p[16] = bits;
-                }
-            }
-        }
-        // ---- fragment steps st = 4*rq + f: the eight 16-bit lookups of step st+1 are in flight while step st feeds the MFMA
-        // (plain ds_read_u16 + one v_lshl_or_b32 per pair: with SRAM-ECC register files a d16 load does not preserve the other
-        // half of its destination, so a d16 / d16_hi pair cannot share a register)
-        uint32_t la[8], lb[8];
-        auto issue = [&](uint32_t (&l)[8], int rq, int f) {
-            const uint32_t word = f == 0 ? w[rq].x : (f == 1 ? w[rq].y : (f == 2 ? w[rq].z : w[rq].w));
-            uint32_t we, wo;
-            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(we) : "v"(word), "v"(m0f), "s"(wavepat));
-            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(wo) : "v"(word >> 4), "v"(m0f), "s"(wavepat));
-            constexpr int ODD = PAIRCOL ? 2 : 128;  // the odd column of a pair: the high half of the same dword / a block of its own
-            if (f == 0) lutm_issue8<0>(l, lane_addr, we, wo);
-            else if (f == 1) lutm_issue8<ODD>(l, lane_addr, we, wo);
-            else if (f == 2) lutm_issue8<4096>(l, lane_addr, we, wo);
-            else lutm_issue8<4096 + ODD>(l, lane_addr, we, wo);
-        };
-        auto wait_pack = [&](uint32_t (&l)[8], bool more, uint32_t (&b)[4]) {
-            if (more) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3]), "+v"(l[4]), "+v"(l[5]), "+v"(l[6]), "+v"(l[7])::"memory");
-            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3]), "+v"(l[4]), "+v"(l[5]), "+v"(l[6]), "+v"(l[7])::"memory");
+    const LutmCtx cx{kb, c, mytab, lane_addr, wavepat, m0f};
+    auto process_unit = [&](uint4_t (&w)[RQ], const uint4_t (&xf)[RB][RQ], const uint32_t (&sb)[4], const uint32_t (&zb)[4]) {
+        lutm_process_unit<DT, ZM, RPG, RB, DIRECT, true>(
+            cx, w,
+            [&](int rq, uint4_t (&dst)[RB]) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) b[i] = (l[2 * i + 1] << 16) | l[2 * i];
-        };
-        issue(la, 0, 0);
-#pragma unroll
-        for (int st = 0; st < 4 * RQ; st++) {
-            const int rq = st >> 2, f = st & 3;
-            const bool more = st + 1 < 4 * RQ;
-            uint32_t b[4];
-            if (st & 1) {
-                if (more) issue(la, (st + 1) >> 2, (st + 1) & 3);
-                wait_pack(lb, more, b);
-            } else {
-                if (more) issue(lb, (st + 1) >> 2, (st + 1) & 3);
-                wait_pack(la, more, b);
-            }
-#pragma unroll
-            for (int rb = 0; rb < RB; rb++) acc[rb][f] = lutm_mfma<DT>(b, xf[rb][rq], acc[rb][f]);
-        }
+                for (int b = 0; b < RB; b++) dst[b] = xf[b][rq];
+            },
+            sb, zb, acc, [](int) {});
     };
 
     // one unit per wave is the normal plan (its rows, activations and constants are requested up front, constants first so that
@@ -1004,6 +1108,243 @@ __global__ __launch_bounds__(NW * 64, (RB == 1 ? 2 : (NW == 4 && RPG <= 16 ? 3 :
     const int tile = (int)(rec.y & 0xfffffu), slice = (int)(rec.y >> 20);
     const LutmView v{e->qw, e->scales, e->zeros, e->bias, e->y, e->x, e->gran, e->gen, e->N, M, e->K, e->G, e->S, e->gpw, e->hshift, (long)e->tiles * 64};
     lutm_body<DT, ZM, RPG, NW, PF, RB>(v, tile, tile, slice, epoch, status, tag_skew, spin_limit);
+}
+
+// =====================================================================================================================
+// x-sharing list form (3 <= M <= 32 over a list with enough layers to fill the chip without slicing K finely): the four waves of a
+// workgroup take four ADJACENT column tiles over the SAME k units, and the unit's M x (RPG * 8) block of x enters the workgroup ONCE --
+// whole 128-byte lines (eight rows x 128 bytes per wave instruction), written to LDS in fragment order (a wave's B operand of row quad rq,
+// row block b is the 1 KiB at ((rq * RB + b) * 64 + lane) * 16: lane-linear ds_read_b128) -- instead of once per wave in fragment-shaped
+// 64-byte row pieces from L2.  In the k-split form above every wave pulls its own M x 256 bytes per unit: at 32 rows that is twice the weight
+// bytes through the texture path, and the launch ran at 9 TB/s of L2 -> CU traffic whatever the decode cost (the fp16 arithmetic form took a
+// third of the instructions out of the 16-row launch and all of its LDS work, and moved the time by 8 %; at 32 rows by nothing).
+// A wave owns its 64 columns over the workgroup's whole k range: no cross-wave sum; K slices (S > 1) meet through the tagged granules as above.
+// One barrier per unit: stage (u + 1) is loaded under the work on u and written to the other buffer before the barrier.
+// =====================================================================================================================
+template <int DT, int ZM, int RPG, int RB>
+__device__ __forceinline__ void lutm_xs_body(const LutmView& lv, const int tile0, const int slice, const unsigned epoch, unsigned* status,
+                                             const unsigned tag_skew, const int spin_limit) {
+    constexpr int NB = 8, NW = 4;
+    constexpr int RQ = RPG / 4;
+#ifdef BIE_LUTM_F16_TABLE
+    constexpr bool DIRECT = false;
+#else
+    constexpr bool DIRECT = DT == BIE_F16;
+#endif
+    constexpr int REDW = DIRECT ? RB * 1024 : 2048;  // a wave's words of the first region: its table (8 KiB) / its [M][64] transpose
+    constexpr int TABW = NW * REDW;
+    constexpr int XW = RB * RQ * 256;                // words of one stage buffer: RB * RQ fragments of 1 KiB
+    constexpr int XOFF = DIRECT ? 0 : TABW;          // fp16 has no tables: the stage buffers share the words of the closing transpose
+    constexpr int LDSW = DIRECT ? (TABW > 2 * XW ? TABW : 2 * XW) : TABW + 2 * XW;
+    __shared__ __attribute__((aligned(8192))) uint32_t tab[LDSW];  // the only LDS object: starts at LDS address 0
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 15, kb = lane >> 4;
+    const int N = lv.N, M = lv.M;
+    const int tiles = (int)(lv.ncat >> 6);
+    const bool active = tile0 + wave < tiles;  // a wave past the last tile of a ragged quad works on the last tile and stores nothing
+    const int tile = active ? tile0 + wave : tiles - 1;
+    const int nt0 = tile * 64;
+    const int n4 = nt0 + 4 * c < N ? nt0 + 4 * c : N - 4;
+    const int g0 = slice * lv.gpw;
+    int g1 = g0 + lv.gpw;
+    if (g1 > lv.G) g1 = lv.G;
+    unsigned tag = 0, gen_next = 0;
+    if (lv.S > 1) {
+        gen_next = lv.gen[tile] + 1u;
+        tag = epoch | (gen_next & 0xffu);
+    }
+
+    const uint64_t xb = (uint64_t)(uintptr_t)lv.x;
+    const uint32_t xlo = __builtin_amdgcn_readfirstlane((uint32_t)xb), xhi = __builtin_amdgcn_readfirstlane((uint32_t)(xb >> 32));
+    const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((uint64_t)xhi << 32) | xlo), 0,
+                                                         __builtin_amdgcn_readfirstlane((uint32_t)((long)M * lv.K * 2)), 0x00020000);
+    // staging: lane (j8, c3) = (lane >> 3, lane & 7) moves the 16 bytes of row 8 * o + c3, k chunk 8 * h + j8 of the unit; (o, h) from
+    // the wave and the pass.  Eight contiguous lanes = eight rows of one chunk = 128 contiguous bytes of a fragment: conflict-free ds_write_b128
+    constexpr int HALVES = RPG >= 8 ? RPG / 8 : 1;
+    constexpr int COMBOS = RB * 2 * HALVES;
+    constexpr int SLD = (COMBOS + NW - 1) / NW;
+    const int c3 = lane & 7, j8 = lane >> 3;
+    uint32_t svoff[SLD], sdst[SLD];
+    bool svalid[SLD];
+#pragma unroll
+    for (int i = 0; i < SLD; i++) {
+        const int combo = i * NW + wave;
+        const int o = combo % (RB * 2), h = combo / (RB * 2);
+        const int r = o * 8 + c3, j = h * 8 + j8;
+        svalid[i] = combo < COMBOS && j < RPG;
+        svoff[i] = (svalid[i] && r < M) ? (uint32_t)(r * lv.K * 2 + j * 16) : 0x80000000u;  // rows >= M: zeros
+        sdst[i] = (uint32_t)(((((j >> 2) * RB + (r >> 4)) * 64 + (j & 3) * 16 + (r & 15)) * 4));
+    }
+    uint32_t* const xst = tab + XOFF;
+    auto stage_load = [&](uint4_t (&xs)[SLD], int unit) {
+#pragma unroll
+        for (int i = 0; i < SLD; i++) xs[i] = __builtin_bit_cast(uint4_t, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, svoff[i], (uint32_t)(unit * RPG * 16), 0));
+    };
+    auto stage_store = [&](const uint4_t (&xs)[SLD], int buf) {
+#pragma unroll
+        for (int i = 0; i < SLD; i++)
+            if (svalid[i]) {
+                uint4_t v = xs[i];
+                if constexpr (DIRECT) v = lutm_pair_order(v);  // once per workgroup, not once per wave and fragment
+                *reinterpret_cast<uint4_t*>(xst + buf * XW + sdst[i]) = v;
+            }
+    };
+    // a wave's B operand of (row quad rq, row block b): the 1 KiB at ((rq * RB + b) * 64 + lane) * 16 of the stage buffer
+    const uint32_t xfrag_addr = (uint32_t)(XOFF * 4 + lane * 16);
+    auto read_frags = [&](int rq, uint4_t (&dst)[RB], int buf) {
+        if constexpr (DIRECT) {
+#pragma unroll
+            for (int b = 0; b < RB; b++) dst[b] = *reinterpret_cast<const uint4_t*>(xst + buf * XW + ((rq * RB + b) * 64 + lane) * 4);
+        } else {
+            // the table form counts its own lgkmcnt: the fragment reads go out as asm too, where lutm_process_unit asks for them (in-order
+            // LDS returns: the next counted wait of the lookups covers them)
+            const uint32_t a = xfrag_addr + (uint32_t)(buf * XW * 4);
+#pragma unroll
+            for (int b = 0; b < RB; b++) asm volatile("ds_read_b128 %0, %1" : "=v"(dst[b]) : "v"(a + (uint32_t)((rq * RB + b) * 1024)) : "memory");
+        }
+    };
+
+    auto load_params = [&](int unit, uint32_t (&sb)[4], uint32_t (&zb)[4]) {
+        const int g = unit >> lv.hshift;
+        const uint2_t s2 = *reinterpret_cast<const uint2_t*>(lv.scales + (long)g * N + n4);
+        sb[0] = s2.x & 0xffffu; sb[1] = s2.x >> 16; sb[2] = s2.y & 0xffffu; sb[3] = s2.y >> 16;
+        if constexpr (ZM == ZM_ASYM) {
+            const uint32_t zw = reinterpret_cast<const uint32_t*>(lv.zeros)[(long)g * (N / NB) + n4 / NB];
+#pragma unroll
+            for (int f = 0; f < 4; f++) zb[f] = ((zw >> (((n4 % NB) + f) * 4)) & 15u) + 1u;
+        } else {
+            const uint2_t z2 = *reinterpret_cast<const uint2_t*>(reinterpret_cast<const uint16_t*>(lv.zeros) + (long)g * N + n4);
+            zb[0] = z2.x & 0xffffu; zb[1] = z2.x >> 16; zb[2] = z2.y & 0xffffu; zb[3] = z2.y >> 16;
+        }
+    };
+    // the rows through a buffer descriptor: lane (kb, c) reads 16 bytes of row 4 * rq + kb at a scalar offset per (unit, row quad).  The
+    // request for the unit after the workgroup's last goes out all the same -- against a descriptor of no records, which fetches nothing --
+    // so that every wait of the loop is counted exactly (a branch around a load makes the compiler drain the queue at the join)
+    const uint64_t qb = (uint64_t)(uintptr_t)lv.qw;
+    const uint32_t qlo = __builtin_amdgcn_readfirstlane((uint32_t)qb), qhi = __builtin_amdgcn_readfirstlane((uint32_t)(qb >> 32));
+    const auto qrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((uint64_t)qhi << 32) | qlo), 0, __builtin_amdgcn_readfirstlane((int)lv.qw_bytes), 0x00020000);
+    const auto qnone = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((uint64_t)qhi << 32) | qlo), 0, 0, 0x00020000);
+    const uint32_t wvoff = (uint32_t)((kb * N + n4) * 4);
+    auto load_row_quad = [&](int unit, int rq, bool real) {
+        const uint32_t soff = (uint32_t)(((long)unit * RPG + 4 * rq) * N * 4);
+        return __builtin_bit_cast(uint4_t, __builtin_amdgcn_raw_buffer_load_b128(real ? qrsrc : qnone, wvoff, soff, 2));  // aux 2 = nt
+    };
+
+    lutm_acc_t acc[RB][4];
+#pragma unroll
+    for (int b = 0; b < RB; b++)
+#pragma unroll
+        for (int f = 0; f < 4; f++) acc[b][f] = lutm_acc_t{0.0f, 0.0f, 0.0f, 0.0f};
+
+    uint32_t m0f;
+    asm("v_mov_b32 %0, 0x0f0f0f0f" : "=v"(m0f));
+    const LutmCtx cx{kb, c, tab + wave * 2048, (uint32_t)((kb & 1) * 64 + c * 4), (uint32_t)wave * 0x20202020u, m0f};
+
+    // One register set for the rows: row quad rq of unit g + 1 is requested into w[rq] as soon as unit g has consumed it (a full unit ahead of
+    // its use), the next unit's constants and its stage of x at the top of the step.  The trip count is the workgroup's: every wave meets every barrier
+    uint4_t w[RQ], xs[SLD];
+    uint32_t sa[4] = {0, 0, 0, 0}, za[4] = {0, 0, 0, 0}, sn[4] = {0, 0, 0, 0}, zn[4] = {0, 0, 0, 0};
+    load_params(g0, sn, zn);
+#pragma unroll
+    for (int rq = 0; rq < RQ; rq++) w[rq] = load_row_quad(g0, rq, true);
+    stage_load(xs, g0);
+    stage_store(xs, 0);
+    __syncthreads();
+    for (int g = g0; g < g1; g++) {
+        const int p = (g - g0) & 1;
+        const bool more = g + 1 < g1;           // workgroup-uniform
+        const int gn = more ? g + 1 : g;        // the last step asks for its own constants and stage again (cache hits; stored to the idle buffer)
+#pragma unroll
+        for (int f = 0; f < 4; f++) { sa[f] = sn[f]; za[f] = zn[f]; }
+        load_params(gn, sn, zn);
+        stage_load(xs, gn);
+        asm volatile("" ::: "memory");  // the requests stay where they are written: hipcc otherwise sinks them to their first use (lower register
+                                        // pressure), and the loop runs without a unit of rows in flight
+        lutm_process_unit<DT, ZM, RPG, RB, DIRECT, false>(
+            cx, w, [&](int rq, uint4_t (&dst)[RB]) { read_frags(rq, dst, p); }, sa, za, acc,
+            [&](int rq) {
+                asm volatile("" ::: "memory");
+                w[rq] = load_row_quad(gn, rq, more);
+                asm volatile("" ::: "memory");
+            });
+        stage_store(xs, p ^ 1);
+        __syncthreads();
+    }
+
+    // ---- a wave's own [M][64] through LDS (D layout of the 16x16 MFMA: lane (kb', m) holds in acc[f][r] column 16 * kb' + 4 * r + f of row m)
+    float* red = reinterpret_cast<float*>(tab + wave * REDW);
+#pragma unroll
+    for (int b = 0; b < RB; b++)
+        if (16 * b + c < M) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float4_t v = {acc[b][0][r], acc[b][1][r], acc[b][2][r], acc[b][3][r]};
+                *reinterpret_cast<float4_t*>(red + ((16 * b + c) * 64 + 16 * kb + 4 * r)) = v;
+            }
+        }
+    __syncthreads();
+    if (!active) return;
+    const int n = nt0 + lane;
+    const bool owner = n < N;
+    const long ncat = lv.ncat;
+    const long col = (long)tile * 64 + lane;
+    for (int m = 0; m < M; m++) {
+        float tot = red[m * 64 + lane];
+        if (lv.S > 1) {
+            if (slice != lv.S - 1) {
+                const unsigned long long gval = ((unsigned long long)tag << 32) | __float_as_uint(tot);
+                __hip_atomic_store(lv.gran + ((long)slice * M + m) * ncat + col, gval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                continue;
+            }
+            float v = 0.0f;
+            for (int s0 = 0; s0 < lv.S - 1; s0 += 8) {
+                unsigned long long gv[8];
+                bool ready;
+                int spins = 0;
+                do {
+#pragma unroll
+                    for (int jj = 0; jj < 8; jj++) {
+                        const int sidx = (s0 + jj < lv.S - 1) ? s0 + jj : lv.S - 2;
+                        gv[jj] = __hip_atomic_load(lv.gran + ((long)sidx * M + m) * ncat + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    ready = true;
+#pragma unroll
+                    for (int jj = 0; jj < 8; jj++) ready = ready && ((unsigned)(gv[jj] >> 32) == (tag ^ tag_skew));
+                    ready = __builtin_amdgcn_ballot_w64(!ready) == 0;
+                    if (!ready) __builtin_amdgcn_s_sleep(2);
+                } while (!ready && ++spins < spin_limit);
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++)
+                    if (s0 + jj < lv.S - 1) v += __uint_as_float((unsigned)gv[jj]);
+                if (!ready) {  // wave-uniform: never a silent number
+                    v = __uint_as_float(0x7fc00000u);
+                    if (lane == 0 && status) __hip_atomic_fetch_or(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+            tot = v + tot;
+        }
+        if (owner) {
+            float o = dt_traits<DT>::round(tot);
+            if (lv.bias) o = o + dt_traits<DT>::load(lv.bias, n);
+            dt_traits<DT>::store(lv.y, (long)m * N + n, o);
+        }
+    }
+    if (lv.S > 1 && slice == lv.S - 1 && lane == 0) lv.gen[tile] = gen_next;  // read only by the next launch
+}
+
+// block b -> {entry, first tile of the quad | slice << 20}
+template <int DT, int ZM, int RPG, int RB>
+__global__ __launch_bounds__(256) void mpq_lutm_xs_list_kernel(const ListEntry* __restrict__ ent, const uint2_t* __restrict__ blk, const int M, const unsigned epoch,
+                                                               unsigned* status, const unsigned tag_skew, const int spin_limit) {
+    typedef const __attribute__((address_space(4))) uint2_t cu2_t;
+    typedef const __attribute__((address_space(4))) ListEntry cent_t;
+    const uint2_t rec = *((cu2_t*)(uintptr_t)(blk + blockIdx.x));
+    cent_t* e = (cent_t*)(uintptr_t)(ent + rec.x);
+    const int tile0 = (int)(rec.y & 0xfffffu), slice = (int)(rec.y >> 20);
+    const LutmView v{e->qw, e->scales, e->zeros, e->bias, e->y, e->x, e->gran, e->gen, e->N, M, e->K, e->G, e->S, e->gpw, e->hshift, (long)e->tiles * 64, e->qw_bytes};
+    lutm_xs_body<DT, ZM, RPG, RB>(v, tile0, slice, epoch, status, tag_skew, spin_limit);
 }
 
 #ifdef BIE_LAB_BUILD
@@ -1289,6 +1630,36 @@ int mpq_lutm_list_launch(const ListEntry* ent, const uint2_t* blk, unsigned grid
     } else if (dtype == BIE_F16) lutm_list_launch_dt<BIE_F16, false, 1>(ent, blk, grid, M, rpg, zm, epoch, device_status_word(), skew, spin, st);
     else lutm_list_launch_dt<BIE_BF16, false, 1>(ent, blk, grid, M, rpg, zm, epoch, device_status_word(), skew, spin, st);
     return check_launch("mpq_lutm_list_kernel");
+}
+
+// the x-sharing form (lutm_xs_body): four-wave workgroups over tile quads; the block table holds the first tile of each quad
+template <int DT, int RB>
+static void lutm_xs_list_launch_dt(const ListEntry* ent, const uint2_t* blk, unsigned grid, int M, int rpg, int zm, unsigned epoch, unsigned* status,
+                                   unsigned skew, int spin, hipStream_t st) {
+#define BIE_LUTMX(ZMV)                                                                                                                        \
+    switch (rpg) {                                                                                                                            \
+        case 4: hipLaunchKernelGGL((mpq_lutm_xs_list_kernel<DT, ZMV, 4, RB>), dim3(grid), dim3(256), 0, st, ent, blk, M, epoch, status, skew, spin); break;   \
+        case 8: hipLaunchKernelGGL((mpq_lutm_xs_list_kernel<DT, ZMV, 8, RB>), dim3(grid), dim3(256), 0, st, ent, blk, M, epoch, status, skew, spin); break;   \
+        case 16: hipLaunchKernelGGL((mpq_lutm_xs_list_kernel<DT, ZMV, 16, RB>), dim3(grid), dim3(256), 0, st, ent, blk, M, epoch, status, skew, spin); break; \
+        default: hipLaunchKernelGGL((mpq_lutm_xs_list_kernel<DT, ZMV, 32, RB>), dim3(grid), dim3(256), 0, st, ent, blk, M, epoch, status, skew, spin); break; \
+    }
+    if (zm == ZM_ASYM) { BIE_LUTMX(ZM_ASYM) }
+    else { BIE_LUTMX(ZM_SYM) }
+#undef BIE_LUTMX
+}
+int mpq_lutm_xs_list_launch(const ListEntry* ent, const uint2_t* blk, unsigned grid, int M, int rpg, int zm, int dtype, hipStream_t st) {
+    unsigned skew;
+    int spin;
+    test_forge_get(&skew, &spin);
+    const unsigned epoch = next_launch_epoch();
+    if (M > 16) {
+        if (dtype == BIE_F16) lutm_xs_list_launch_dt<BIE_F16, 2>(ent, blk, grid, M, rpg, zm, epoch, device_status_word(), skew, spin, st);
+        else lutm_xs_list_launch_dt<BIE_BF16, 2>(ent, blk, grid, M, rpg, zm, epoch, device_status_word(), skew, spin, st);
+    } else {
+        if (dtype == BIE_F16) lutm_xs_list_launch_dt<BIE_F16, 1>(ent, blk, grid, M, rpg, zm, epoch, device_status_word(), skew, spin, st);
+        else lutm_xs_list_launch_dt<BIE_BF16, 1>(ent, blk, grid, M, rpg, zm, epoch, device_status_word(), skew, spin, st);
+    }
+    return check_launch("mpq_lutm_xs_list_kernel");
 }
 
 // sets: n weight sets sharing x (one for a plain forward).  `gen` = the workspace's head, `gran` = granule area.

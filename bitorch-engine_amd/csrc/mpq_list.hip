@@ -40,6 +40,7 @@ void test_forge_get(unsigned* tag_skew, int* spin_limit);
 int test_forge_dep_get();
 int mpq_lutm_list_launch(const ListEntry* ent, const uint2_t* blk, unsigned grid, int M, int rpg, int zm, int dtype, int nw, hipStream_t st);  // mpq_gemv_lut.hip
 int mpq_lutm_list_nw(int M);
+int mpq_lutm_xs_list_launch(const ListEntry* ent, const uint2_t* blk, unsigned grid, int M, int rpg, int zm, int dtype, hipStream_t st);  // x-sharing form
 
 struct ListArgs {
     const ListEntry* ent;
@@ -760,7 +761,7 @@ static int list_env(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
-struct ListPlanEntry { int rpg, G, gpw, S, H, tiles; };
+struct ListPlanEntry { int rpg, G, gpw, S, H, tiles, tpb; };  // tpb: column tiles per workgroup (4: the x-sharing matrix-pipe form)
 
 struct MpqList {
     int n = 0, M = 1, w_bit = 4, group_size = 128, zm = 0, dtype = BIE_BF16;
@@ -769,6 +770,7 @@ struct MpqList {
     unsigned grid = 0;
     bool has_deps = false;
     bool lutm = false;         // the lookup / matrix-pipe kernel (mpq_gemv_lut.hip) instead of the lookup / FMA kernel below
+    bool xs = false;           // ... in its x-sharing form (four column tiles per workgroup, x staged once per workgroup)
     ListEntry* d_ent = nullptr;
     uint2_t* d_blk = nullptr;
     unsigned* d_done = nullptr;
@@ -789,8 +791,10 @@ static int list_nw(int M, int w_bit) {
     return (M == 1 && w_bit == 4) ? 4 : 8;
 }
 
-static void list_plan(int n, const bie_mpq_list_entry* ent, int w_bit, int group_size, int* rpg_out, std::vector<ListPlanEntry>& pe, int nw = 8, int max_gpw_plan = 0) {
-    static const int want = list_env("BIE_LIST_WANT_WAVES", 6144);
+static void list_plan(int n, const bie_mpq_list_entry* ent, int w_bit, int group_size, int* rpg_out, std::vector<ListPlanEntry>& pe, int nw = 8, int max_gpw_plan = 0,
+                      int want_plan = 0) {
+    static const int want_env = list_env("BIE_LIST_WANT_WAVES", 6144);
+    const int want = want_plan > 0 ? want_plan : want_env;
     static const int force_h = list_env("BIE_LIST_H", 0);
     static const int max_gpw_env = list_env("BIE_LIST_MAX_GPW", 0);
     const int max_gpw = max_gpw_env > 0 ? max_gpw_env : (max_gpw_plan > 0 ? max_gpw_plan : 16);
@@ -827,8 +831,47 @@ static void list_plan(int n, const bie_mpq_list_entry* ent, int w_bit, int group
         p.S = cdiv(p.G, gpw * nw);
         p.gpw = cdiv(p.G, p.S * nw);     // even out
         p.S = cdiv(p.G, p.gpw * nw);
+        p.tpb = 1;
     }
     *rpg_out = rpg;
+}
+
+// The x-sharing matrix-pipe form (lutm_xs_body, mpq_gemv_lut.hip): a workgroup = four adjacent column tiles over the same `gpw` units, so K is
+// sliced over workgroups only (nw = 1 in the arithmetic above).  Taken when the list fills the chip that way with at most XS_MAX_S slices per
+// tile (each slice is a granule round of the reducer); smaller lists keep the k-split form, whose workgroup sums its four waves in LDS.
+static bool list_xs_plan(int n, const bie_mpq_list_entry* ent, int M, int w_bit, int group_size, int dtype, int* rpg_out, std::vector<ListPlanEntry>& pe) {
+    // plan knobs: read once per process -- per call under BIE_TUNING (tests force the form onto small lists, sweep tools change them between plans)
+    struct Knobs { int min_m_f16, min_m_bf16, max_s, max_gpw, want, bf16_whole_pct; };
+    auto read_knobs = [] {
+        return Knobs{list_env("BIE_LUTM_XS_MIN_M", 3), list_env("BIE_LUTM_XS_MIN_M_BF16", 12), list_env("BIE_LUTM_XS_MAX_S", 4),
+                     list_env("BIE_LUTM_XS_MAX_GPW", 48), list_env("BIE_LUTM_XS_WANT_WAVES", 5120), list_env("BIE_LUTM_XS_BF16_WHOLE_PCT", 50)};
+    };
+    static const Knobs once = read_knobs();
+    const Knobs kn = getenv("BIE_TUNING") ? read_knobs() : once;
+    const int min_m_f16 = kn.min_m_f16, min_m_bf16 = kn.min_m_bf16, max_s = kn.max_s, max_gpw = kn.max_gpw, want = kn.want;
+    const int min_m = dtype == BIE_F16 ? min_m_f16 : (min_m_f16 <= 0 ? 0 : min_m_bf16);
+    // waves wanted: 5120 makes two slices of a K = 11008 layer (43 units each) where the k-split plans' 6144 makes three; measured over 40 layers
+    // of 11008x4096 at 16 / 32 rows, fp16: 4.93 / 6.23 us per layer with two slices, 5.08 / 6.54 with three, 5.02 / 6.07 with one
+    // (profiles/r06_lutm_xs.txt)
+    if (w_bit != 4 || M < min_m || min_m <= 0) return false;
+    std::vector<ListPlanEntry> px;
+    int rpg;
+    list_plan(n, ent, w_bit, group_size, &rpg, px, 1, max_gpw, want);
+    double whole = 0.0, all = 0.0;
+    for (int i = 0; i < n; i++) {
+        if (px[i].S > max_s) return false;
+        px[i].tpb = 4;
+        const double b = (double)ent[i].K * ent[i].N;
+        all += b;
+        if (px[i].S == 1) whole += b;
+    }
+    // bf16 (table form: instruction-bound, the shared x is worth 4-9 %): only from 12 rows, and only when the layers whose K one workgroup
+    // walks whole hold at least half of the weights -- a sliced K = 11008 layer is 3-4 % SLOWER than in the k-split form, whose workgroup
+    // of 4 x 24 units takes it whole (profiles/r06_lutm_xs.txt).  fp16 (arithmetic form): 9-27 % faster at every row count and shape measured
+    if (dtype != BIE_F16 && whole * 100.0 < all * kn.bf16_whole_pct) return false;
+    pe = px;
+    *rpg_out = rpg;
+    return true;
 }
 
 static bool list_shape_ok(int n, const bie_mpq_list_entry* ent, int M, int w_bit, int group_size) {
@@ -861,7 +904,7 @@ static ListLayout list_layout(int n, const std::vector<ListPlanEntry>& pe, int M
     size_t gran = 0;
     for (int i = 0; i < n; i++) {
         tiles += pe[i].tiles;
-        blocks += (long)pe[i].tiles * pe[i].S;
+        blocks += (long)cdiv(pe[i].tiles, pe[i].tpb) * pe[i].S;
         if (pe[i].S > 1) gran += (size_t)(pe[i].S - 1) * M * pe[i].tiles * 64 * 8;
     }
     L.tiles = tiles;
@@ -886,6 +929,10 @@ size_t mpq_list_device_bytes(int n, const bie_mpq_list_entry* ent, int M, int w_
     const int plans[][2] = {{8, 0}, {4, 0}, {2, 0}, {1, 0}, {4, 24}, {8, 24}};
     for (const auto& pl : plans) {
         list_plan(n, ent, w_bit, group_size, &rpg, pe, pl[0], pl[1]);
+        const size_t b = list_layout(n, pe, M).total;
+        if (b > need) need = b;
+    }
+    if (list_xs_plan(n, ent, M, w_bit, group_size, BIE_F16, &rpg, pe)) {  // the x-sharing matrix-pipe form: the plan create takes for fp16 (bf16: the same or none)
         const size_t b = list_layout(n, pe, M).total;
         if (b > need) need = b;
     }
@@ -931,6 +978,7 @@ int mpq_list_create(MpqList** out, int n, const bie_mpq_list_entry* ent, int M, 
     // the matrix-pipe form with four-wave workgroups: up to 24 units per wave before K is sliced over workgroups (K = 11008 stays whole:
     // 8.56 -> 7.60 us per 11008x4096 layer at 32 rows, profiles/r05_lutm_list_nw_ab.txt)
     list_plan(n, ent, w_bit, group_size, &rpg, pe, nw, (lutm && nw == 4) ? 24 : 0);
+    const bool xs = lutm && list_xs_plan(n, ent, M, w_bit, group_size, dtype, &rpg, pe);  // replaces the plan when the list is big enough (below)
     const ListLayout L = list_layout(n, pe, M);
     BIE_REQUIRE(device_bytes >= L.total, BIE_ERR_WORKSPACE, "bie_mpq_list_create: device buffer of %zu bytes required, got %zu", L.total, device_bytes);
     BIE_REQUIRE((reinterpret_cast<uintptr_t>(device_mem) & 255) == 0, BIE_ERR_INVALID_ARG, "bie_mpq_list_create: the device buffer must be 256-byte aligned");
@@ -978,7 +1026,7 @@ int mpq_list_create(MpqList** out, int n, const bie_mpq_list_entry* ent, int M, 
             e.dep_tiles = d.tiles;
         }
         for (int sl = 0; sl < p.S; sl++)      // slice-major inside an entry: a tile's reducer (last slice) comes after its publishers
-            for (int t = 0; t < p.tiles; t++) hb[b++] = uint2_t{(uint32_t)i, (uint32_t)t | ((uint32_t)sl << 20)};
+            for (int t = 0; t < p.tiles; t += p.tpb) hb[b++] = uint2_t{(uint32_t)i, (uint32_t)t | ((uint32_t)sl << 20)};
         BIE_REQUIRE(p.S < 4096, BIE_ERR_UNSUPPORTED, "bie_mpq_list_create: entry %d needs %d K slices (< 4096)", i, p.S);
         tile0 += p.tiles;
     }
@@ -994,6 +1042,7 @@ int mpq_list_create(MpqList** out, int n, const bie_mpq_list_entry* ent, int M, 
     pl->grid = L.grid;
     pl->has_deps = has_deps;
     pl->lutm = lutm;
+    pl->xs = xs;
     pl->d_ent = reinterpret_cast<ListEntry*>(base + L.ent);
     pl->d_blk = reinterpret_cast<uint2_t*>(base + L.blk);
     pl->d_done = reinterpret_cast<unsigned*>(base + L.done);
@@ -1004,6 +1053,7 @@ int mpq_list_create(MpqList** out, int n, const bie_mpq_list_entry* ent, int M, 
 
 void mpq_list_destroy(MpqList* p) { delete p; }
 int mpq_list_launches(const MpqList* p) { return p ? (p->has_deps ? 2 : 1) : 0; }
+int mpq_list_form(const MpqList* p) { return p ? (p->xs ? 2 : (p->lutm ? 1 : 0)) : -1; }
 
 template <int DT, int ZM, int MT, int WB, int VAR0>
 static void list_launch_rpg(const ListArgs& a, int rpg, unsigned grid, hipStream_t st) {
@@ -1038,6 +1088,7 @@ int mpq_list_forward(MpqList* p, hipStream_t st) {
         const hipError_t e = hipMemsetAsync(p->d_done, 0, p->done_bytes, st);
         BIE_REQUIRE(e == hipSuccess, BIE_ERR_HIP, "bie_mpq_list_forward: hipMemsetAsync: %s", hipGetErrorString(e));
     }
+    if (p->xs) return mpq_lutm_xs_list_launch(p->d_ent, p->d_blk, p->grid, p->M, p->rpg, p->zm, p->dtype, st);
     if (p->lutm)  // 2 / 3 <= M <= 32: lookups feeding v_mfma_f32_16x16x32 (mpq_gemv_lut.hip), same entries and block table
         return mpq_lutm_list_launch(p->d_ent, p->d_blk, p->grid, p->M, p->rpg, p->zm, p->dtype, p->nw, st);
     ListArgs a;

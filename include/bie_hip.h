@@ -151,6 +151,8 @@ int bie_mpq_list_create(bie_mpq_list_t** plan, int n_entries, const bie_mpq_list
                         int group_size, int asym, int dtype, void* device_mem, size_t device_bytes);
 int bie_mpq_list_forward(bie_mpq_list_t* plan, void* stream);
 int bie_mpq_list_launches(const bie_mpq_list_t* plan); /* kernel launches one forward issues (1, or 1 + a memset node) */
+int bie_mpq_list_form(const bie_mpq_list_t* plan);     /* which kernel the plan chose: 0 lookup + FMA (M <= 2), 1 matrix pipe with K split over
+                                                         * the waves of a workgroup, 2 matrix pipe with x shared by the four column tiles of a workgroup */
 void bie_mpq_list_destroy(bie_mpq_list_t* plan);
 
 /* out[K, N] (dtype) = dequantised weight.  Bit-exact twin of unpack_qweight layer_type 1

@@ -2524,6 +2524,99 @@ def test_list_forward_big_list_whole_k_per_workgroup_and_graph_replay(M):
             assert_close(entries[i]["y"], oracle_forward(newx[i], qw, scales, zeros, None, 4, 128, 0, orc.BF16, bias), orc.BF16, f"replay {rep} entry {i}")
 
 
+_XS_PLANS = {  # knobs of list_xs_plan (mpq_list.hip), re-read per plan under BIE_TUNING (tests/conftest.py sets it)
+    "whole_k": {"BIE_LUTM_XS_WANT_WAVES": "1", "BIE_LUTM_XS_MAX_GPW": "48"},                        # every workgroup walks its tiles' whole K
+    "sliced": {"BIE_LUTM_XS_WANT_WAVES": "1", "BIE_LUTM_XS_MAX_GPW": "3", "BIE_LUTM_XS_MAX_S": "64"},  # K in slices of <= 3 units: tagged granules
+    "split_groups": {"BIE_LUTM_XS_MAX_S": "64"},                                                    # small list: groups split into 2 / 4 units, one unit per workgroup
+}
+
+
+@pytest.mark.parametrize("plan_kind", ["whole_k", "sliced", "split_groups"])
+@pytest.mark.parametrize("dt,gs,asym,M", [(orc.F16, 128, 0, 3), (orc.BF16, 128, 0, 16), (orc.F16, 64, 1, 8), (orc.BF16, 32, 0, 12), (orc.F16, 256, 0, 16),
+                                           (orc.BF16, 256, 1, 5), (orc.F16, 128, 0, 17), (orc.BF16, 128, 0, 32), (orc.F16, 32, 1, 25), (orc.BF16, 64, 1, 24),
+                                           (orc.F16, 256, 1, 32), (orc.BF16, 256, 0, 19)])
+def test_list_forward_x_sharing_form_vs_oracle(plan_kind, dt, gs, asym, M, monkeypatch):
+    """The x-sharing matrix-pipe list form (lutm_xs_body: four column tiles per workgroup, x staged once per workgroup through LDS; fp16
+    dequantises by packed-fp16 arithmetic, bf16 by table) forced onto a small mixed list -- ragged quads (1, 3, 4, 9, 16 tiles), N % 64 = 8 /
+    40, bias on some -- in three plans: whole K per workgroup, K sliced over workgroups (granule reduction), groups split into units.  Every
+    entry against the oracle, a second launch bit-identical; bie_mpq_list_form says which kernel ran."""
+    from bitorch_engine.layers.qlinear.nbit.cuda import MPQForwardList
+    for k, v in _XS_PLANS[plan_kind].items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("BIE_LUTM_XS_MIN_M_BF16", "3")
+    monkeypatch.setenv("BIE_LUTM_XS_BF16_WHOLE_PCT", "0")  # bf16 by default takes the form only when most weights sit in unsliced layers
+    specs = [(1024, 200, True), (512, 520, False), (2048, 64, True), (768, 136, False), (1024, 1000, False)]
+    if gs == 256:
+        specs = [(K if K % 256 == 0 else 1024, N, b) for (K, N, b) in specs]
+    if asym:
+        specs = [(K, (N + 15) // 16 * 16, b) for (K, N, b) in specs]
+    entries, host = _list_case(specs, dt, 4, gs, asym, M, seed=8800 + gs + M)
+    plan = MPQForwardList(entries, w_bit=4, group_size=gs, asym=bool(asym))
+    assert plan.form == 2, f"the x-sharing form was not chosen ({plan_kind}: form {plan.form})"
+    assert plan.launches == 1
+    plan()
+    torch.cuda.synchronize()
+    first = [e["y"].clone() for e in entries]
+    for i, (e, (x, qw, scales, zeros, bias)) in enumerate(zip(entries, host)):
+        ref = oracle_forward(x, qw, scales, zeros, None, 4, gs, asym, dt, bias)
+        assert_close(e["y"], ref, dt, f"x-sharing list ({plan_kind}) entry {i} {specs[i]} g{gs} asym={asym} M={M}")
+    plan()
+    torch.cuda.synchronize()
+    for i, e in enumerate(entries):
+        assert torch.equal(e["y"], first[i]), f"entry {i}: a second launch of the plan differs"
+    # the same list in the k-split form (the default for a list this small): same numbers up to the fp32 summation order
+    monkeypatch.setenv("BIE_LUTM_XS_MIN_M", "0")
+    entries2, _ = _list_case(specs, dt, 4, gs, asym, M, seed=8800 + gs + M)
+    plan2 = MPQForwardList(entries2, w_bit=4, group_size=gs, asym=bool(asym))
+    assert plan2.form == 1
+    plan2()
+    torch.cuda.synchronize()
+    for i, (e, e2) in enumerate(zip(entries, entries2)):
+        assert_close(e["y"], e2["y"], dt, f"x-sharing against k-split, entry {i}")
+
+
+def test_list_forward_x_sharing_form_is_the_default_for_big_lists_and_fails_loudly(monkeypatch):
+    """Defaults: 80 layers of 4096 -> 4096 (a workgroup walks the whole K) take the x-sharing form in fp16 from 3 rows and in bf16 from 12 rows
+    (below: the k-split form);
+    a small list never does.  With K sliced, a reducer that never sees its partial sums (forged tag) returns NaN and raises the status bit."""
+    from bitorch_engine import _hip
+    from bitorch_engine.layers.qlinear.nbit.cuda import MPQForwardList
+    specs = [(4096, 4096, i % 5 == 0) for i in range(80)]
+    for dt, M, want in ((orc.F16, 3, 2), (orc.BF16, 8, 1), (orc.BF16, 12, 2), (orc.F16, 2, 1)):
+        entries, host = _list_case(specs, dt, 4, 128, 0, M, seed=9100 + M)
+        plan = MPQForwardList(entries, w_bit=4, group_size=128)
+        assert plan.form == want, f"dtype {dt} M {M}: form {plan.form}, expected {want}"
+        plan()
+        torch.cuda.synchronize()
+        for i in (0, 13, 79):
+            x, qw, scales, zeros, bias = host[i]
+            assert_close(entries[i]["y"], oracle_forward(x, qw, scales, zeros, None, 4, 128, 0, dt, bias), dt, f"default plan, entry {i}, M={M}")
+    small, _ = _list_case(specs[:2], orc.F16, 4, 128, 0, 8, seed=9200)
+    assert MPQForwardList(small, w_bit=4, group_size=128).form == 1
+    for k, v in _XS_PLANS["sliced"].items():
+        monkeypatch.setenv(k, v)
+    L = _hip.lib()
+    entries, host = _list_case([(2048, 256, False)], orc.F16, 4, 128, 0, 8, seed=9300)
+    plan = MPQForwardList(entries, w_bit=4, group_size=128)
+    assert plan.form == 2
+    assert L.bie_device_status(1) == 0
+    L.bie_test_forge_reducer(0x5a, 2000)
+    try:
+        plan()
+        torch.cuda.synchronize()
+    finally:
+        L.bie_test_forge_reducer(0, 0)
+    assert torch.isnan(entries[0]["y"].float()).all(), "a timed-out reducer returned numbers"
+    assert L.bie_device_status(0) & 1
+    with pytest.raises(RuntimeError, match="device status"):
+        plan()
+    assert L.bie_device_status(0) == 0
+    plan()
+    torch.cuda.synchronize()
+    x, qw, scales, zeros, bias = host[0]
+    assert_close(entries[0]["y"], oracle_forward(x, qw, scales, zeros, None, 4, 128, 0, orc.F16, bias), orc.F16, "after the forged timeout")
+
+
 @pytest.mark.parametrize("dt,gs,asym,M", [(orc.BF16, 128, 0, 33), (orc.F16, 64, 1, 40), (orc.BF16, 128, 0, 48), (orc.BF16, 32, 0, 64)])
 def test_list_forward_row_blocks_for_33_to_64_rows(dt, gs, asym, M):
     """32 < M <= 64: MPQForwardList cuts the rows into two balanced blocks of <= 32, one single-launch plan per block over the row slices of

@@ -15,8 +15,12 @@ from bench import Bench, BF16  # noqa: E402
 B = Bench(torch.device("cuda", 0))
 dt = torch.float16 if (len(sys.argv) > 1 and sys.argv[1] == "f16") else BF16
 out = {"env": {k: v for k, v in os.environ.items() if k.startswith("BIE_LUTM")}, "dtype": str(dt)}
-for (k, n, nl) in ((4096, 11008, 40), (4096, 4096, 96), (11008, 4096, 40)):
-    for M in (2, 8, 16, 17, 24, 32):
+shapes = ((4096, 11008, 40), (4096, 4096, 96), (11008, 4096, 40))
+if os.environ.get("LUTM_AB_SHAPES"):  # e.g. "2" or "0,2": indices into the list above
+    shapes = tuple(shapes[int(i)] for i in os.environ["LUTM_AB_SHAPES"].split(","))
+rows = tuple(int(m) for m in os.environ.get("LUTM_AB_ROWS", "2,8,16,17,24,32").split(","))
+for (k, n, nl) in shapes:
+    for M in rows:
         r = B.gemv_list(k, n, nl, nl, 10, 100 + M, M=M, dt=dt)
         out[f"{k}x{n}_M{M}"] = {"us": r["us_per_layer"], "frac": r["roofline"]["frac"]}
 print(json.dumps(out))
