@@ -1121,10 +1121,10 @@ __global__ __launch_bounds__(NW * 64, (RB == 1 ? 2 : (NW == 4 && RPG <= 16 ? 3 :
 // A wave owns its 64 columns over the workgroup's whole k range: no cross-wave sum; K slices (S > 1) meet through the tagged granules as above.
 // One barrier per unit: stage (u + 1) is loaded under the work on u and written to the other buffer before the barrier.
 // =====================================================================================================================
-template <int DT, int ZM, int RPG, int RB>
+template <int DT, int ZM, int RPG, int RB, int NW>
 __device__ __forceinline__ void lutm_xs_body(const LutmView& lv, const int tile0, const int slice, const unsigned epoch, unsigned* status,
                                              const unsigned tag_skew, const int spin_limit) {
-    constexpr int NB = 8, NW = 4;
+    constexpr int NB = 8;
     constexpr int RQ = RPG / 4;
 #ifdef BIE_LUTM_F16_TABLE
     constexpr bool DIRECT = false;
@@ -1242,20 +1242,30 @@ __device__ __forceinline__ void lutm_xs_body(const LutmView& lv, const int tile0
     asm("v_mov_b32 %0, 0x0f0f0f0f" : "=v"(m0f));
     const LutmCtx cx{kb, c, tab + wave * 2048, (uint32_t)((kb & 1) * 64 + c * 4), (uint32_t)wave * 0x20202020u, m0f};
 
-    // One register set for the rows: row quad rq of unit g + 1 is requested into w[rq] as soon as unit g has consumed it (a full unit ahead of
-    // its use), the next unit's constants and its stage of x at the top of the step.  The trip count is the workgroup's: every wave meets every barrier
-    uint4_t w[RQ], xs[SLD];
+    // The rows in a ring of DEPTH register sets: row quad rq of unit g + DEPTH is requested into the set of unit g as soon as unit g has consumed
+    // it (DEPTH units ahead of its use); the next unit's constants and its stage of x at the top of the step.  The trip count is the
+    // workgroup's: every wave meets every barrier
+#ifdef BIE_LUTM_XS_DEPTH
+    constexpr int DEPTH = BIE_LUTM_XS_DEPTH;
+#else
+    constexpr int DEPTH = 1;
+#endif
+    uint4_t w[DEPTH][RQ], xs[SLD];
     uint32_t sa[4] = {0, 0, 0, 0}, za[4] = {0, 0, 0, 0}, sn[4] = {0, 0, 0, 0}, zn[4] = {0, 0, 0, 0};
     load_params(g0, sn, zn);
 #pragma unroll
-    for (int rq = 0; rq < RQ; rq++) w[rq] = load_row_quad(g0, rq, true);
+    for (int d = 0; d < DEPTH; d++)
+#pragma unroll
+        for (int rq = 0; rq < RQ; rq++) w[d][rq] = load_row_quad(g0 + d < g1 ? g0 + d : g0, rq, g0 + d < g1);
     stage_load(xs, g0);
     stage_store(xs, 0);
     __syncthreads();
-    for (int g = g0; g < g1; g++) {
+    auto step = [&](uint4_t (&wc)[RQ], int g) {
         const int p = (g - g0) & 1;
         const bool more = g + 1 < g1;           // workgroup-uniform
         const int gn = more ? g + 1 : g;        // the last step asks for its own constants and stage again (cache hits; stored to the idle buffer)
+        const bool ring = g + DEPTH < g1;
+        const int gr = ring ? g + DEPTH : g;
 #pragma unroll
         for (int f = 0; f < 4; f++) { sa[f] = sn[f]; za[f] = zn[f]; }
         load_params(gn, sn, zn);
@@ -1263,14 +1273,19 @@ __device__ __forceinline__ void lutm_xs_body(const LutmView& lv, const int tile0
         asm volatile("" ::: "memory");  // the requests stay where they are written: hipcc otherwise sinks them to their first use (lower register
                                         // pressure), and the loop runs without a unit of rows in flight
         lutm_process_unit<DT, ZM, RPG, RB, DIRECT, false>(
-            cx, w, [&](int rq, uint4_t (&dst)[RB]) { read_frags(rq, dst, p); }, sa, za, acc,
+            cx, wc, [&](int rq, uint4_t (&dst)[RB]) { read_frags(rq, dst, p); }, sa, za, acc,
             [&](int rq) {
                 asm volatile("" ::: "memory");
-                w[rq] = load_row_quad(gn, rq, more);
+                wc[rq] = load_row_quad(gr, rq, ring);
                 asm volatile("" ::: "memory");
             });
         stage_store(xs, p ^ 1);
         __syncthreads();
+    };
+    for (int g = g0; g < g1; g += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++)
+            if (g + d < g1) step(w[d], g + d);
     }
 
     // ---- a wave's own [M][64] through LDS (D layout of the 16x16 MFMA: lane (kb', m) holds in acc[f][r] column 16 * kb' + 4 * r + f of row m)
@@ -1335,8 +1350,8 @@ __device__ __forceinline__ void lutm_xs_body(const LutmView& lv, const int tile0
 }
 
 // block b -> {entry, first tile of the quad | slice << 20}
-template <int DT, int ZM, int RPG, int RB>
-__global__ __launch_bounds__(256) void mpq_lutm_xs_list_kernel(const ListEntry* __restrict__ ent, const uint2_t* __restrict__ blk, const int M, const unsigned epoch,
+template <int DT, int ZM, int RPG, int RB, int NW>
+__global__ __launch_bounds__(NW * 64) void mpq_lutm_xs_list_kernel(const ListEntry* __restrict__ ent, const uint2_t* __restrict__ blk, const int M, const unsigned epoch,
                                                                unsigned* status, const unsigned tag_skew, const int spin_limit) {
     typedef const __attribute__((address_space(4))) uint2_t cu2_t;
     typedef const __attribute__((address_space(4))) ListEntry cent_t;
@@ -1344,7 +1359,7 @@ __global__ __launch_bounds__(256) void mpq_lutm_xs_list_kernel(const ListEntry* 
     cent_t* e = (cent_t*)(uintptr_t)(ent + rec.x);
     const int tile0 = (int)(rec.y & 0xfffffu), slice = (int)(rec.y >> 20);
     const LutmView v{e->qw, e->scales, e->zeros, e->bias, e->y, e->x, e->gran, e->gen, e->N, M, e->K, e->G, e->S, e->gpw, e->hshift, (long)e->tiles * 64, e->qw_bytes};
-    lutm_xs_body<DT, ZM, RPG, RB>(v, tile0, slice, epoch, status, tag_skew, spin_limit);
+    lutm_xs_body<DT, ZM, RPG, RB, NW>(v, tile0, slice, epoch, status, tag_skew, spin_limit);
 }
 
 #ifdef BIE_LAB_BUILD
@@ -1632,33 +1647,37 @@ int mpq_lutm_list_launch(const ListEntry* ent, const uint2_t* blk, unsigned grid
     return check_launch("mpq_lutm_list_kernel");
 }
 
-// the x-sharing form (lutm_xs_body): four-wave workgroups over tile quads; the block table holds the first tile of each quad
-template <int DT, int RB>
+// the x-sharing form (lutm_xs_body): workgroups of NW waves over NW adjacent tiles; the block table holds the first tile of each
+template <int DT, int RB, int NW>
 static void lutm_xs_list_launch_dt(const ListEntry* ent, const uint2_t* blk, unsigned grid, int M, int rpg, int zm, unsigned epoch, unsigned* status,
                                    unsigned skew, int spin, hipStream_t st) {
-#define BIE_LUTMX(ZMV)                                                                                                                        \
-    switch (rpg) {                                                                                                                            \
-        case 4: hipLaunchKernelGGL((mpq_lutm_xs_list_kernel<DT, ZMV, 4, RB>), dim3(grid), dim3(256), 0, st, ent, blk, M, epoch, status, skew, spin); break;   \
-        case 8: hipLaunchKernelGGL((mpq_lutm_xs_list_kernel<DT, ZMV, 8, RB>), dim3(grid), dim3(256), 0, st, ent, blk, M, epoch, status, skew, spin); break;   \
-        case 16: hipLaunchKernelGGL((mpq_lutm_xs_list_kernel<DT, ZMV, 16, RB>), dim3(grid), dim3(256), 0, st, ent, blk, M, epoch, status, skew, spin); break; \
-        default: hipLaunchKernelGGL((mpq_lutm_xs_list_kernel<DT, ZMV, 32, RB>), dim3(grid), dim3(256), 0, st, ent, blk, M, epoch, status, skew, spin); break; \
+#define BIE_LUTMX(ZMV)                                                                                                                                \
+    switch (rpg) {                                                                                                                                    \
+        case 4: hipLaunchKernelGGL((mpq_lutm_xs_list_kernel<DT, ZMV, 4, RB, NW>), dim3(grid), dim3(NW * 64), 0, st, ent, blk, M, epoch, status, skew, spin); break;   \
+        case 8: hipLaunchKernelGGL((mpq_lutm_xs_list_kernel<DT, ZMV, 8, RB, NW>), dim3(grid), dim3(NW * 64), 0, st, ent, blk, M, epoch, status, skew, spin); break;   \
+        case 16: hipLaunchKernelGGL((mpq_lutm_xs_list_kernel<DT, ZMV, 16, RB, NW>), dim3(grid), dim3(NW * 64), 0, st, ent, blk, M, epoch, status, skew, spin); break; \
+        default: hipLaunchKernelGGL((mpq_lutm_xs_list_kernel<DT, ZMV, 32, RB, NW>), dim3(grid), dim3(NW * 64), 0, st, ent, blk, M, epoch, status, skew, spin); break; \
     }
     if (zm == ZM_ASYM) { BIE_LUTMX(ZM_ASYM) }
     else { BIE_LUTMX(ZM_SYM) }
 #undef BIE_LUTMX
 }
-int mpq_lutm_xs_list_launch(const ListEntry* ent, const uint2_t* blk, unsigned grid, int M, int rpg, int zm, int dtype, hipStream_t st) {
+int mpq_lutm_xs_list_launch(const ListEntry* ent, const uint2_t* blk, unsigned grid, int M, int rpg, int zm, int dtype, int nw, hipStream_t st) {
     unsigned skew;
     int spin;
     test_forge_get(&skew, &spin);
     const unsigned epoch = next_launch_epoch();
-    if (M > 16) {
-        if (dtype == BIE_F16) lutm_xs_list_launch_dt<BIE_F16, 2>(ent, blk, grid, M, rpg, zm, epoch, device_status_word(), skew, spin, st);
-        else lutm_xs_list_launch_dt<BIE_BF16, 2>(ent, blk, grid, M, rpg, zm, epoch, device_status_word(), skew, spin, st);
-    } else {
-        if (dtype == BIE_F16) lutm_xs_list_launch_dt<BIE_F16, 1>(ent, blk, grid, M, rpg, zm, epoch, device_status_word(), skew, spin, st);
-        else lutm_xs_list_launch_dt<BIE_BF16, 1>(ent, blk, grid, M, rpg, zm, epoch, device_status_word(), skew, spin, st);
+#define BIE_LUTMX_NW(NWV)                                                                                                                             \
+    if (M > 16) {                                                                                                                                     \
+        if (dtype == BIE_F16) lutm_xs_list_launch_dt<BIE_F16, 2, NWV>(ent, blk, grid, M, rpg, zm, epoch, device_status_word(), skew, spin, st);         \
+        else lutm_xs_list_launch_dt<BIE_BF16, 2, NWV>(ent, blk, grid, M, rpg, zm, epoch, device_status_word(), skew, spin, st);                        \
+    } else {                                                                                                                                          \
+        if (dtype == BIE_F16) lutm_xs_list_launch_dt<BIE_F16, 1, NWV>(ent, blk, grid, M, rpg, zm, epoch, device_status_word(), skew, spin, st);         \
+        else lutm_xs_list_launch_dt<BIE_BF16, 1, NWV>(ent, blk, grid, M, rpg, zm, epoch, device_status_word(), skew, spin, st);                        \
     }
+    if (nw == 8) { BIE_LUTMX_NW(8) }
+    else { BIE_LUTMX_NW(4) }
+#undef BIE_LUTMX_NW
     return check_launch("mpq_lutm_xs_list_kernel");
 }
 

@@ -40,7 +40,7 @@ void test_forge_get(unsigned* tag_skew, int* spin_limit);
 int test_forge_dep_get();
 int mpq_lutm_list_launch(const ListEntry* ent, const uint2_t* blk, unsigned grid, int M, int rpg, int zm, int dtype, int nw, hipStream_t st);  // mpq_gemv_lut.hip
 int mpq_lutm_list_nw(int M);
-int mpq_lutm_xs_list_launch(const ListEntry* ent, const uint2_t* blk, unsigned grid, int M, int rpg, int zm, int dtype, hipStream_t st);  // x-sharing form
+int mpq_lutm_xs_list_launch(const ListEntry* ent, const uint2_t* blk, unsigned grid, int M, int rpg, int zm, int dtype, int nw, hipStream_t st);  // x-sharing form
 
 struct ListArgs {
     const ListEntry* ent;
@@ -836,15 +836,21 @@ static void list_plan(int n, const bie_mpq_list_entry* ent, int w_bit, int group
     *rpg_out = rpg;
 }
 
+// BIE_LIST_ALG (the opt-in algebraic fp16 form, mpq_list_forward): read once per process; under BIE_TUNING per call (bench.py times both forms in one process)
+static int list_alg_choice() {
+    static const int alg_once = list_env("BIE_LIST_ALG", 0);
+    return getenv("BIE_TUNING") ? list_env("BIE_LIST_ALG", 0) : alg_once;
+}
+
 // The x-sharing matrix-pipe form (lutm_xs_body, mpq_gemv_lut.hip): a workgroup = four adjacent column tiles over the same `gpw` units, so K is
 // sliced over workgroups only (nw = 1 in the arithmetic above).  Taken when the list fills the chip that way with at most XS_MAX_S slices per
 // tile (each slice is a granule round of the reducer); smaller lists keep the k-split form, whose workgroup sums its four waves in LDS.
 static bool list_xs_plan(int n, const bie_mpq_list_entry* ent, int M, int w_bit, int group_size, int dtype, int* rpg_out, std::vector<ListPlanEntry>& pe) {
     // plan knobs: read once per process -- per call under BIE_TUNING (tests force the form onto small lists, sweep tools change them between plans)
-    struct Knobs { int min_m_f16, min_m_bf16, max_s, max_gpw, want, bf16_whole_pct; };
+    struct Knobs { int min_m_f16, min_m_bf16, max_s, max_gpw, want, bf16_whole_pct, nw; };
     auto read_knobs = [] {
-        return Knobs{list_env("BIE_LUTM_XS_MIN_M", 3), list_env("BIE_LUTM_XS_MIN_M_BF16", 12), list_env("BIE_LUTM_XS_MAX_S", 4),
-                     list_env("BIE_LUTM_XS_MAX_GPW", 48), list_env("BIE_LUTM_XS_WANT_WAVES", 5120), list_env("BIE_LUTM_XS_BF16_WHOLE_PCT", 50)};
+        return Knobs{list_env("BIE_LUTM_XS_MIN_M", 1), list_env("BIE_LUTM_XS_MIN_M_BF16", 12), list_env("BIE_LUTM_XS_MAX_S", 4),
+                     list_env("BIE_LUTM_XS_MAX_GPW", 48), list_env("BIE_LUTM_XS_WANT_WAVES", 5120), list_env("BIE_LUTM_XS_BF16_WHOLE_PCT", 50), list_env("BIE_LUTM_XS_NW", 4)};
     };
     static const Knobs once = read_knobs();
     const Knobs kn = getenv("BIE_TUNING") ? read_knobs() : once;
@@ -854,20 +860,21 @@ static bool list_xs_plan(int n, const bie_mpq_list_entry* ent, int M, int w_bit,
     // of 11008x4096 at 16 / 32 rows, fp16: 4.93 / 6.23 us per layer with two slices, 5.08 / 6.54 with three, 5.02 / 6.07 with one
     // (profiles/r06_lutm_xs.txt)
     if (w_bit != 4 || M < min_m || min_m <= 0) return false;
+    if (M <= 2 && dtype == BIE_F16 && list_alg_choice()) return false;  // the caller asked for the algebraic form of the one / two-row kernel
     std::vector<ListPlanEntry> px;
     int rpg;
     list_plan(n, ent, w_bit, group_size, &rpg, px, 1, max_gpw, want);
     double whole = 0.0, all = 0.0;
     for (int i = 0; i < n; i++) {
         if (px[i].S > max_s) return false;
-        px[i].tpb = 4;
+        px[i].tpb = kn.nw == 8 ? 8 : 4;
         const double b = (double)ent[i].K * ent[i].N;
         all += b;
         if (px[i].S == 1) whole += b;
     }
     // bf16 (table form: instruction-bound, the shared x is worth 4-9 %): only from 12 rows, and only when the layers whose K one workgroup
     // walks whole hold at least half of the weights -- a sliced K = 11008 layer is 3-4 % SLOWER than in the k-split form, whose workgroup
-    // of 4 x 24 units takes it whole (profiles/r06_lutm_xs.txt).  fp16 (arithmetic form): 9-27 % faster at every row count and shape measured
+    // of 4 x 24 units takes it whole (profiles/r06_lutm_xs.txt).  fp16 (arithmetic form): 6-27 % faster at every row count (from ONE row: 4.12 against the lookup + FMA kernel's 4.41 us per 4096x11008 layer) and shape measured
     if (dtype != BIE_F16 && whole * 100.0 < all * kn.bf16_whole_pct) return false;
     pe = px;
     *rpg_out = rpg;
@@ -969,16 +976,21 @@ int mpq_list_create(MpqList** out, int n, const bie_mpq_list_entry* ent, int M, 
     // 6.6 against 7.5 us per 4096x11008 layer for the two-row FMA form (profiles/r03_z_lutm_list_ab.txt).  BIE_LIST_M2_MFMA=0: FMA form.
     static const int m2_mfma = list_env("BIE_LIST_M2_MFMA", 1);
     bool lutm = M > 2;
-    if (M == 2 && w_bit == 4 && m2_mfma) {
-        lutm = true;
-        for (int i = 0; i < n; i++)
-            if (ent[i].depends_on >= 0 || ent[i].N % 4 || (reinterpret_cast<uintptr_t>(ent[i].x) & 15) || ent[i].K % 8) lutm = false;
-    }
+    bool mfma_ok = w_bit == 4;  // what the matrix-pipe kernels ask of the entries (validated above for M > 2)
+    for (int i = 0; i < n; i++)
+        if (ent[i].depends_on >= 0 || ent[i].N % 4 || (reinterpret_cast<uintptr_t>(ent[i].x) & 15) || ent[i].K % 8) mfma_ok = false;
+    if (M == 2 && mfma_ok && m2_mfma) lutm = true;
     if (lutm) nw = mpq_lutm_list_nw(M);  // the matrix-pipe kernel: eight waves (four at 17 <= M <= 32), each with its own 8 KiB table
     // the matrix-pipe form with four-wave workgroups: up to 24 units per wave before K is sliced over workgroups (K = 11008 stays whole:
     // 8.56 -> 7.60 us per 11008x4096 layer at 32 rows, profiles/r05_lutm_list_nw_ab.txt)
     list_plan(n, ent, w_bit, group_size, &rpg, pe, nw, (lutm && nw == 4) ? 24 : 0);
-    const bool xs = lutm && list_xs_plan(n, ent, M, w_bit, group_size, dtype, &rpg, pe);  // replaces the plan when the list is big enough (below)
+    // the x-sharing matrix-pipe form replaces the plan when the list is big enough (list_xs_plan) -- fp16 from ONE row: its arithmetic
+    // dequantisation feeding the matrix pipe is faster than the lookup + FMA kernel even with fifteen of sixteen rows empty
+    const bool xs = mfma_ok && list_xs_plan(n, ent, M, w_bit, group_size, dtype, &rpg, pe);
+    if (xs) {
+        lutm = true;
+        nw = pe[0].tpb;
+    }
     const ListLayout L = list_layout(n, pe, M);
     BIE_REQUIRE(device_bytes >= L.total, BIE_ERR_WORKSPACE, "bie_mpq_list_create: device buffer of %zu bytes required, got %zu", L.total, device_bytes);
     BIE_REQUIRE((reinterpret_cast<uintptr_t>(device_mem) & 255) == 0, BIE_ERR_INVALID_ARG, "bie_mpq_list_create: the device buffer must be 256-byte aligned");
@@ -1088,7 +1100,7 @@ int mpq_list_forward(MpqList* p, hipStream_t st) {
         const hipError_t e = hipMemsetAsync(p->d_done, 0, p->done_bytes, st);
         BIE_REQUIRE(e == hipSuccess, BIE_ERR_HIP, "bie_mpq_list_forward: hipMemsetAsync: %s", hipGetErrorString(e));
     }
-    if (p->xs) return mpq_lutm_xs_list_launch(p->d_ent, p->d_blk, p->grid, p->M, p->rpg, p->zm, p->dtype, st);
+    if (p->xs) return mpq_lutm_xs_list_launch(p->d_ent, p->d_blk, p->grid, p->M, p->rpg, p->zm, p->dtype, p->nw, st);
     if (p->lutm)  // 2 / 3 <= M <= 32: lookups feeding v_mfma_f32_16x16x32 (mpq_gemv_lut.hip), same entries and block table
         return mpq_lutm_list_launch(p->d_ent, p->d_blk, p->grid, p->M, p->rpg, p->zm, p->dtype, p->nw, st);
     ListArgs a;
@@ -1117,8 +1129,7 @@ int mpq_list_forward(MpqList* p, hipStream_t st) {
     // 0.64-0.7 for the table forms, but its results are the EXACT products' sums, 6-8e-4 of max|y| away from the reference's doubly rounded
     // weights (profiles/r05_list_alg_ab_a.txt, gpurun_out/rel_err_report.txt): inside north_star's 1e-3 norm-wise, not element by element, so
     // it is the caller's choice, not the default.  2: also W2 at one row (no faster than its pair table).
-    static const int alg_once = list_env("BIE_LIST_ALG", 0);
-    const int alg = getenv("BIE_TUNING") ? list_env("BIE_LIST_ALG", 0) : alg_once;  // BIE_TUNING: re-read per launch (bench.py times both forms in one process)
+    const int alg = list_alg_choice();
     if (alg && p->dtype == BIE_F16 && !p->has_deps && (p->w_bit == 4 || p->M == 2 || alg == 2)) {
         if (p->w_bit == 2) list_launch_zm<BIE_F16, 2, 4096>(a, p->rpg, p->grid, p->M, p->zm, st);
         else list_launch_zm<BIE_F16, 4, 4096>(a, p->rpg, p->grid, p->M, p->zm, st);

@@ -2534,7 +2534,7 @@ _XS_PLANS = {  # knobs of list_xs_plan (mpq_list.hip), re-read per plan under BI
 @pytest.mark.parametrize("plan_kind", ["whole_k", "sliced", "split_groups"])
 @pytest.mark.parametrize("dt,gs,asym,M", [(orc.F16, 128, 0, 3), (orc.BF16, 128, 0, 16), (orc.F16, 64, 1, 8), (orc.BF16, 32, 0, 12), (orc.F16, 256, 0, 16),
                                            (orc.BF16, 256, 1, 5), (orc.F16, 128, 0, 17), (orc.BF16, 128, 0, 32), (orc.F16, 32, 1, 25), (orc.BF16, 64, 1, 24),
-                                           (orc.F16, 256, 1, 32), (orc.BF16, 256, 0, 19)])
+                                           (orc.F16, 256, 1, 32), (orc.BF16, 256, 0, 19), (orc.F16, 128, 0, 1), (orc.F16, 64, 1, 2), (orc.BF16, 128, 1, 1)])
 def test_list_forward_x_sharing_form_vs_oracle(plan_kind, dt, gs, asym, M, monkeypatch):
     """The x-sharing matrix-pipe list form (lutm_xs_body: four column tiles per workgroup, x staged once per workgroup through LDS; fp16
     dequantises by packed-fp16 arithmetic, bf16 by table) forced onto a small mixed list -- ragged quads (1, 3, 4, 9, 16 tiles), N % 64 = 8 /
@@ -2543,7 +2543,7 @@ def test_list_forward_x_sharing_form_vs_oracle(plan_kind, dt, gs, asym, M, monke
     from bitorch_engine.layers.qlinear.nbit.cuda import MPQForwardList
     for k, v in _XS_PLANS[plan_kind].items():
         monkeypatch.setenv(k, v)
-    monkeypatch.setenv("BIE_LUTM_XS_MIN_M_BF16", "3")
+    monkeypatch.setenv("BIE_LUTM_XS_MIN_M_BF16", "1")
     monkeypatch.setenv("BIE_LUTM_XS_BF16_WHOLE_PCT", "0")  # bf16 by default takes the form only when most weights sit in unsliced layers
     specs = [(1024, 200, True), (512, 520, False), (2048, 64, True), (768, 136, False), (1024, 1000, False)]
     if gs == 256:
@@ -2564,11 +2564,11 @@ def test_list_forward_x_sharing_form_vs_oracle(plan_kind, dt, gs, asym, M, monke
     torch.cuda.synchronize()
     for i, e in enumerate(entries):
         assert torch.equal(e["y"], first[i]), f"entry {i}: a second launch of the plan differs"
-    # the same list in the k-split form (the default for a list this small): same numbers up to the fp32 summation order
+    # the same list in the k-split form (one row: the lookup + FMA kernel), the default for a list this small: same numbers up to the fp32 summation order
     monkeypatch.setenv("BIE_LUTM_XS_MIN_M", "0")
     entries2, _ = _list_case(specs, dt, 4, gs, asym, M, seed=8800 + gs + M)
     plan2 = MPQForwardList(entries2, w_bit=4, group_size=gs, asym=bool(asym))
-    assert plan2.form == 1
+    assert plan2.form == (0 if M == 1 else 1)
     plan2()
     torch.cuda.synchronize()
     for i, (e, e2) in enumerate(zip(entries, entries2)):
@@ -2576,13 +2576,13 @@ def test_list_forward_x_sharing_form_vs_oracle(plan_kind, dt, gs, asym, M, monke
 
 
 def test_list_forward_x_sharing_form_is_the_default_for_big_lists_and_fails_loudly(monkeypatch):
-    """Defaults: 80 layers of 4096 -> 4096 (a workgroup walks the whole K) take the x-sharing form in fp16 from 3 rows and in bf16 from 12 rows
-    (below: the k-split form);
+    """Defaults: 80 layers of 4096 -> 4096 (a workgroup walks the whole K) take the x-sharing form in fp16 from ONE row and in bf16 from 12 rows
+    (below: the k-split form, at one row the lookup + FMA kernel);
     a small list never does.  With K sliced, a reducer that never sees its partial sums (forged tag) returns NaN and raises the status bit."""
     from bitorch_engine import _hip
     from bitorch_engine.layers.qlinear.nbit.cuda import MPQForwardList
     specs = [(4096, 4096, i % 5 == 0) for i in range(80)]
-    for dt, M, want in ((orc.F16, 3, 2), (orc.BF16, 8, 1), (orc.BF16, 12, 2), (orc.F16, 2, 1)):
+    for dt, M, want in ((orc.F16, 3, 2), (orc.BF16, 8, 1), (orc.BF16, 12, 2), (orc.F16, 1, 2), (orc.BF16, 1, 0)):
         entries, host = _list_case(specs, dt, 4, 128, 0, M, seed=9100 + M)
         plan = MPQForwardList(entries, w_bit=4, group_size=128)
         assert plan.form == want, f"dtype {dt} M {M}: form {plan.form}, expected {want}"
