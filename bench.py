@@ -161,7 +161,7 @@ class Bench:
     def forward(self, x, layer, y, ws, M, k, n, st, w_bit=WBIT):
         qw, sc, ze = layer
         rc = self.L.bie_mpq_forward(x.data_ptr(), qw.data_ptr(), sc.data_ptr(), ze.data_ptr(), None, None, y.data_ptr(), ws.data_ptr(),
-                                    ws.numel(), M, k, n, w_bit, GROUP, 0, self._hip.BF16, st)
+                                    ws.numel(), M, k, n, w_bit, GROUP, 0, self._hip.BF16 if x.dtype == BF16 else self._hip.F16, st)
         if rc:
             raise RuntimeError(self.L.bie_last_error().decode())
 
@@ -169,11 +169,11 @@ class Bench:
         return torch.zeros(max(self.L.bie_mpq_workspace_bytes(M, k, n, w_bit), 16), dtype=torch.uint8, device=self.dev)
 
     # ---- M = 1 decode over `nl` distinct layers -> per-launch microseconds
-    def gemv(self, k, n, nl, reps, seed, M=1, w_bit=WBIT):
+    def gemv(self, k, n, nl, reps, seed, M=1, w_bit=WBIT, dt=BF16):
         gen = torch.Generator(device=self.dev).manual_seed(seed)
-        layers = [make_layer(self.dev, gen, k, n, w_bit) for _ in range(nl)]
-        x = torch.randn((M, k), generator=gen, device=self.dev).to(BF16)
-        y = torch.empty((M, n), dtype=BF16, device=self.dev)
+        layers = [make_layer(self.dev, gen, k, n, w_bit, dt) for _ in range(nl)]
+        x = torch.randn((M, k), generator=gen, device=self.dev).to(dt)
+        y = torch.empty((M, n), dtype=dt, device=self.dev)
         ws = self.workspace(M, k, n, w_bit)
         g = capture(lambda st: [self.forward(x, l, y, ws, M, k, n, st, w_bit) for l in layers])
         us = time_graph(g, reps) / nl
@@ -1041,6 +1041,9 @@ def main():
             guarded("c2_list_M16_4096x11008", lambda: B.gemv_list(4096, 11008, 40, 40, 10, 20, M=16))
             guarded("c2_list_M32_4096x11008", lambda: B.gemv_list(4096, 11008, 40, 40, 10, 21, M=32))
             guarded("c2_gemv_M32_4096x11008", lambda: B.gemv(4096, 11008, 40, 10, 22, M=32))
+            # the same batched lists in fp16 (the reference kernels' own dtype): arithmetic dequantisation, x shared by the workgroup's four column tiles
+            for m_ in (2, 8, 16, 32):
+                guarded(f"f16_list_M{m_}_4096x11008", lambda m_=m_: B.gemv_list(4096, 11008, 40, 40, 10, 30 + m_, M=m_, dt=torch.float16))
             guarded("c2_act_order_4096x11008", lambda: bench_act_order(dev))
             guarded("c3_exl2", lambda: bench_exl2(dev))
             guarded("c3_exl2_decode_step_llama7b", lambda: bench_exl2_decode_step(dev))

@@ -759,6 +759,9 @@ __device__ __forceinline__ void lutm_process_unit(const LutmCtx& cx, uint4_t (&w
                 for (int rb = 0; rb < RB; rb++) acc[rb][f] = lutm_mfma<DT>(b4, xp[rb], acc[rb][f]);
             }
             after_rq(rq);
+            // one row quad at a time: left to itself hipcc interleaves all four (every v_and_or_b32 first), 130 registers in the lone-launch
+            // kernel -- one 8-wave workgroup per CU instead of two, 13.1 against the table form's 11.1 us per 4096x11008 launch
+            __builtin_amdgcn_sched_barrier(0);
         }
         return;
     }
@@ -1351,7 +1354,7 @@ __device__ __forceinline__ void lutm_xs_body(const LutmView& lv, const int tile0
 
 // block b -> {entry, first tile of the quad | slice << 20}
 template <int DT, int ZM, int RPG, int RB, int NW>
-__global__ __launch_bounds__(NW * 64) void mpq_lutm_xs_list_kernel(const ListEntry* __restrict__ ent, const uint2_t* __restrict__ blk, const int M, const unsigned epoch,
+__global__ __launch_bounds__(NW * 64, (DT == BIE_F16 && NW == 4 && RPG <= 16 ? 4 : 1)) void mpq_lutm_xs_list_kernel(const ListEntry* __restrict__ ent, const uint2_t* __restrict__ blk, const int M, const unsigned epoch,
                                                                unsigned* status, const unsigned tag_skew, const int spin_limit) {
     typedef const __attribute__((address_space(4))) uint2_t cu2_t;
     typedef const __attribute__((address_space(4))) ListEntry cent_t;

@@ -39,7 +39,7 @@ rows = [
     ("**headline: 96 × 4096² W4 g128 bf16, M = 1, ONE list launch**", f"{r['avg_launch_us']:.1f} µs per launch ({r['us_per_layer']:.2f} µs per layer); {prof['headline_us']:.1f} µs under the profiler",
      f"**{r['frac']:.3f} of 8 TB/s** ({r['achieved']:,.0f} GB/s); cold {d['cold_start']['roofline_frac']:.3f}; five regions {reg[0]:.3f} / {reg[1]:.3f} / {reg[2]:.3f}",
      f"traffic {r['traffic'] / 1e6:.1f} MB = {r['traffic'] / r['alg_bytes_per_launch']:.3f} × algorithmic; stream-only floor of the same launch 0.80"),
-    ("fp16 lists (exact D16 form, round 5) 96 × 4096² / 40 × 4096→11008", f"{S['f16_list_4096x4096']['us']:.2f} / {S['f16_list_4096x11008']['us']:.2f} µs per layer",
+    ("fp16 lists, one row (exact; round 6: arithmetic dequantisation on the matrix pipe) 96 × 4096² / 40 × 4096→11008", f"{S['f16_list_4096x4096']['us']:.2f} / {S['f16_list_4096x11008']['us']:.2f} µs per layer",
      f"{S['f16_list_4096x4096']['frac']:.3f} / {S['f16_list_4096x11008']['frac']:.3f}", "GreenBit checkpoints are fp16"),
     ("fp16 lists, algebraic form (opt-in)", f"{S['f16_list_alg_4096x4096']['us']:.2f} / {S['f16_list_alg_4096x11008']['us']:.2f} µs per layer",
      f"**{S['f16_list_alg_4096x4096']['frac']:.3f} / {S['f16_list_alg_4096x11008']['frac']:.3f}**", "§2 for what it costs in agreement with the oracle"),
@@ -48,7 +48,11 @@ rows = [
     ("**batched decode lists, 40 × 4096→11008 at 2 / 8 / 16 / 32 rows** (matrix-pipe lookup form)",
      " / ".join(f"{us(f'c2_list_M{m}_4096x11008'):.2f}" for m in (2, 8, 16, 32)) + " µs per layer",
      " / ".join(f"{fr(f'c2_list_M{m}_4096x11008'):.3f}" for m in (2, 8, 16, 32)) + " (round 4: 0.51 / 0.50 / 0.46 / 0.30)",
-     "round 5: four-wave workgroups, up to 24 units per wave, column-pair table entries (`r05_lutm_list_nw_ab.txt`, `r05_lutm_colpair_ab.txt`)"),
+     "bf16; round 6: x-sharing workgroups from 12 rows (`r06_lutm_xs.txt`); round 5: four-wave workgroups, column-pair table entries"),
+    ("**the same lists in fp16** (round 6: packed-fp16 arithmetic instead of the table; the four column tiles of a workgroup share one LDS stage of x)",
+     " / ".join(f"{us(f'f16_list_M{m}_4096x11008'):.2f}" for m in (2, 8, 16, 32)) + " µs per layer",
+     "**" + " / ".join(f"{fr(f'f16_list_M{m}_4096x11008'):.3f}" for m in (2, 8, 16, 32)) + "**",
+     "`profiles/r06_lutm_xs.txt`; bf16 takes the x-sharing form from 12 rows (table form, instruction-bound: 4–9 %)"),
     ("W2A16 list 96 × 4096²", f"{us('c3_w2a16_list_4096x4096'):.2f} µs per layer", f"{fr('c3_w2a16_list_4096x4096'):.3f}",
      "VALU-bound (1.61 VALU per weight, 0.73 busy); two restructurings rejected this round"),
     ("exl2 3/2-bit lists 4096² / 4096→11008 / 11008→4096", "—", f"{S['c3_exl2_list_4096x4096']:.3f} / {S['c3_exl2_list_4096x11008']:.3f} / {S['c3_exl2_list_11008x4096']:.3f}", ""),
