@@ -20,9 +20,13 @@ from bitorch_engine.layers.qlinear.nbit.cuda import MPQForwardList  # noqa: E402
 
 
 
+XS_KNOBS = ("BIE_LUTM_XS_WANT_WAVES", "BIE_LUTM_XS_MAX_GPW", "BIE_LUTM_XS_MAX_S", "BIE_LUTM_XS_MIN_M_BF16", "BIE_LUTM_XS_BF16_WHOLE_PCT")
+
+
 def run(cases=120, seed=1):
+    os.environ.setdefault("BIE_TUNING", "1")
     rng = np.random.default_rng(seed)
-    refused, ok, bad = {}, 0, []
+    refused, ok, bad, forms = {}, 0, [], {}
     for c in range(cases):
         w_bit = 4 if rng.random() < 0.75 else 2
         gs = int(rng.choice([32, 64, 128, 128, 256])) if w_bit == 4 else int(rng.choice([64, 128, 256]))
@@ -47,10 +51,20 @@ def run(cases=120, seed=1):
                 if asym:
                     N = max(32 // w_bit, N // (32 // w_bit) * (32 // w_bit))
                 specs.append((K, N, bool(rng.random() < 0.3)))
-        tag = f"w{w_bit} g{gs} asym={asym} {'f16' if dt == orc.F16 else 'bf16'} M={M} n={n} chain={chain} specs={specs[:3]}"
+        # the x-sharing matrix-pipe form (list_xs_plan) is the default for BIG lists only: force it onto half of the W4 cases in one of its three plans
+        # (the knobs are re-read per plan under BIE_TUNING)
+        xs_plan = str(rng.choice(["", "", "", "whole_k", "sliced", "split_groups"])) if w_bit == 4 else ""
+        for k_ in XS_KNOBS:
+            os.environ.pop(k_, None)
+        if xs_plan:
+            os.environ.update(T._XS_PLANS[xs_plan])
+            os.environ.update({"BIE_LUTM_XS_MIN_M_BF16": "1", "BIE_LUTM_XS_BF16_WHOLE_PCT": "0"})
+        tag = f"w{w_bit} g{gs} asym={asym} {'f16' if dt == orc.F16 else 'bf16'} M={M} n={n} chain={chain} xs={xs_plan or '-'} specs={specs[:3]}"
         try:
             entries, host = T._list_case(specs, dt, w_bit, gs, asym, M, seed=int(rng.integers(1 << 30)), chain=chain)
             plan = MPQForwardList(entries, w_bit=w_bit, group_size=gs, asym=bool(asym))
+            fk = f"form{getattr(plan, 'form', 'blocks')}"
+            forms[fk] = forms.get(fk, 0) + 1
             plan.forward()
             torch.cuda.synchronize()
             first = [e["y"].clone() for e in entries]
@@ -89,7 +103,9 @@ def run(cases=120, seed=1):
                 break
         ok += good
 
-    return {"cases": cases, "seed": seed, "ok": ok, "refused": refused, "bad": bad}
+    for k_ in XS_KNOBS:
+        os.environ.pop(k_, None)
+    return {"cases": cases, "seed": seed, "ok": ok, "forms": forms, "refused": refused, "bad": bad}
 
 
 if __name__ == "__main__":
