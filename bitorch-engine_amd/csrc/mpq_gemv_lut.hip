@@ -903,12 +903,76 @@ struct LutmView {
     unsigned qw_bytes = 0;     // bytes of qw (the x-sharing form reads the rows through a buffer descriptor)
 };
 
+// the scale / zero patterns of a lane's four adjacent columns n4 .. n4 + 3 for `unit` (asym: zq + 1 of the packed zero fields)
+template <int ZM>
+__device__ __forceinline__ void lutm_load_params(const LutmView& lv, const int n4, const int unit, uint32_t (&sb)[4], uint32_t (&zb)[4]) {
+    constexpr int NB = 8;
+    const int N = lv.N;
+    const int g = unit >> lv.hshift;
+    const uint2_t s2 = *reinterpret_cast<const uint2_t*>(lv.scales + (long)g * N + n4);
+    sb[0] = s2.x & 0xffffu; sb[1] = s2.x >> 16; sb[2] = s2.y & 0xffffu; sb[3] = s2.y >> 16;
+    if constexpr (ZM == ZM_ASYM) {
+        const uint32_t zw = reinterpret_cast<const uint32_t*>(lv.zeros)[(long)g * (N / NB) + n4 / NB];
+#pragma unroll
+        for (int f = 0; f < 4; f++) zb[f] = ((zw >> (((n4 % NB) + f) * 4)) & 15u) + 1u;
+    } else {
+        const uint2_t z2 = *reinterpret_cast<const uint2_t*>(reinterpret_cast<const uint16_t*>(lv.zeros) + (long)g * N + n4);
+        zb[0] = z2.x & 0xffffu; zb[1] = z2.x >> 16; zb[2] = z2.y & 0xffffu; zb[3] = z2.y >> 16;
+    }
+}
+
+// One row of a column tile, lane = column: a publisher slice writes its partial sum as a tagged granule; the tile's last slice collects the
+// others' (spinning on the tags, bounded: a reducer that never sees them returns NaN and raises the status bit), rounds, adds the bias, stores
+template <int DT>
+__device__ __forceinline__ void lutm_finish_row(const LutmView& lv, float tot, const int m, const int slice, const unsigned tag, const unsigned tag_skew,
+                                                const int spin_limit, unsigned* status, const long col, const long ncat, const bool owner, const int n,
+                                                const int lane) {
+    const int M = lv.M, N = lv.N;
+    if (lv.S > 1) {
+        if (slice != lv.S - 1) {
+            const unsigned long long gval = ((unsigned long long)tag << 32) | __float_as_uint(tot);
+            __hip_atomic_store(lv.gran + ((long)slice * M + m) * ncat + col, gval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        float v = 0.0f;
+        for (int s0 = 0; s0 < lv.S - 1; s0 += 8) {
+            unsigned long long gv[8];
+            bool ready;
+            int spins = 0;
+            do {
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++) {
+                    const int sidx = (s0 + jj < lv.S - 1) ? s0 + jj : lv.S - 2;
+                    gv[jj] = __hip_atomic_load(lv.gran + ((long)sidx * M + m) * ncat + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                ready = true;
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++) ready = ready && ((unsigned)(gv[jj] >> 32) == (tag ^ tag_skew));
+                ready = __builtin_amdgcn_ballot_w64(!ready) == 0;
+                if (!ready) __builtin_amdgcn_s_sleep(2);
+            } while (!ready && ++spins < spin_limit);
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++)
+                if (s0 + jj < lv.S - 1) v += __uint_as_float((unsigned)gv[jj]);
+            if (!ready) {  // wave-uniform: never a silent number
+                v = __uint_as_float(0x7fc00000u);
+                if (lane == 0 && status) __hip_atomic_fetch_or(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        tot = v + tot;
+    }
+    if (owner) {
+        float o = dt_traits<DT>::round(tot);
+        if (lv.bias) o = o + dt_traits<DT>::load(lv.bias, n);
+        dt_traits<DT>::store(lv.y, (long)m * N + n, o);
+    }
+}
+
 // RB: 16-row blocks of x served by one pass over the weights (RB = 2: 17 <= M <= 32 -- the lookups and the pairing are shared, a word
 // costs one more MFMA, the activations one more 16-byte load per row quad; list launches only)
 template <int DT, int ZM, int RPG, int NW, bool PF, int RB = 1>  // PF: the next unit's loads in flight under the current one (costs ~40 registers)
 __device__ __forceinline__ void lutm_body(const LutmView& lv, const int tile_local, const int gtile, const int slice, const unsigned epoch,
                                           unsigned* status, const unsigned tag_skew, const int spin_limit) {
-    constexpr int NB = 8;
     constexpr int RQ = RPG / 4;  // row quads (32 k) per unit
 #ifdef BIE_LUTM_F16_TABLE
     constexpr bool DIRECT = false;
@@ -944,19 +1008,7 @@ __device__ __forceinline__ void lutm_body(const LutmView& lv, const int tile_loc
     for (int b = 0; b < RB; b++) xvoff[b] = 16 * b + c < M ? (uint32_t)((16 * b + c) * lv.K * 2 + kb * 16) : 0x80000000u;
 
     const uint32_t* wcol = lv.qw + n4;
-    auto load_params = [&](int unit, uint32_t (&sb)[4], uint32_t (&zb)[4]) {
-        const int g = unit >> lv.hshift;
-        const uint2_t s2 = *reinterpret_cast<const uint2_t*>(lv.scales + (long)g * N + n4);
-        sb[0] = s2.x & 0xffffu; sb[1] = s2.x >> 16; sb[2] = s2.y & 0xffffu; sb[3] = s2.y >> 16;
-        if constexpr (ZM == ZM_ASYM) {
-            const uint32_t zw = reinterpret_cast<const uint32_t*>(lv.zeros)[(long)g * (N / NB) + n4 / NB];
-#pragma unroll
-            for (int f = 0; f < 4; f++) zb[f] = ((zw >> (((n4 % NB) + f) * 4)) & 15u) + 1u;
-        } else {
-            const uint2_t z2 = *reinterpret_cast<const uint2_t*>(reinterpret_cast<const uint16_t*>(lv.zeros) + (long)g * N + n4);
-            zb[0] = z2.x & 0xffffu; zb[1] = z2.x >> 16; zb[2] = z2.y & 0xffffu; zb[3] = z2.y >> 16;
-        }
-    };
+    auto load_params = [&](int unit, uint32_t (&sb)[4], uint32_t (&zb)[4]) { lutm_load_params<ZM>(lv, n4, unit, sb, zb); };
     auto load_unit = [&](uint4_t (&w)[RQ], uint4_t (&xf)[RB][RQ], int unit) {
 #pragma unroll
         for (int rq = 0; rq < RQ; rq++) {
@@ -1042,44 +1094,7 @@ __device__ __forceinline__ void lutm_body(const LutmView& lv, const int tile_loc
         float tot = 0.0f;
 #pragma unroll
         for (int ww = 0; ww < NW; ww++) tot += red[(ww * M + m) * 64 + lane];
-        if (lv.S > 1) {
-            if (slice != lv.S - 1) {
-                const unsigned long long gval = ((unsigned long long)tag << 32) | __float_as_uint(tot);
-                __hip_atomic_store(lv.gran + ((long)slice * M + m) * ncat + col, gval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                continue;
-            }
-            float v = 0.0f;
-            for (int s0 = 0; s0 < lv.S - 1; s0 += 8) {
-                unsigned long long gv[8];
-                bool ready;
-                int spins = 0;
-                do {
-#pragma unroll
-                    for (int jj = 0; jj < 8; jj++) {
-                        const int sidx = (s0 + jj < lv.S - 1) ? s0 + jj : lv.S - 2;
-                        gv[jj] = __hip_atomic_load(lv.gran + ((long)sidx * M + m) * ncat + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    ready = true;
-#pragma unroll
-                    for (int jj = 0; jj < 8; jj++) ready = ready && ((unsigned)(gv[jj] >> 32) == (tag ^ tag_skew));
-                    ready = __builtin_amdgcn_ballot_w64(!ready) == 0;
-                    if (!ready) __builtin_amdgcn_s_sleep(2);
-                } while (!ready && ++spins < spin_limit);
-#pragma unroll
-                for (int jj = 0; jj < 8; jj++)
-                    if (s0 + jj < lv.S - 1) v += __uint_as_float((unsigned)gv[jj]);
-                if (!ready) {  // wave-uniform: never a silent number
-                    v = __uint_as_float(0x7fc00000u);
-                    if (lane == 0 && status) __hip_atomic_fetch_or(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                }
-            }
-            tot = v + tot;
-        }
-        if (owner) {
-            float o = dt_traits<DT>::round(tot);
-            if (lv.bias) o = o + dt_traits<DT>::load(lv.bias, n);
-            dt_traits<DT>::store(lv.y, (long)m * N + n, o);
-        }
+        lutm_finish_row<DT>(lv, tot, m, slice, tag, tag_skew, spin_limit, status, col, ncat, owner, n, lane);
     }
     if (lv.S > 1 && slice == lv.S - 1 && threadIdx.x == 0) lv.gen[gtile] = gen_next;  // read only by the next launch
 }
@@ -1127,7 +1142,6 @@ __global__ __launch_bounds__(NW * 64, (RB == 1 ? 2 : (NW == 4 && RPG <= 16 ? 3 :
 template <int DT, int ZM, int RPG, int RB, int NW>
 __device__ __forceinline__ void lutm_xs_body(const LutmView& lv, const int tile0, const int slice, const unsigned epoch, unsigned* status,
                                              const unsigned tag_skew, const int spin_limit) {
-    constexpr int NB = 8;
     constexpr int RQ = RPG / 4;
 #ifdef BIE_LUTM_F16_TABLE
     constexpr bool DIRECT = false;
@@ -1209,19 +1223,7 @@ __device__ __forceinline__ void lutm_xs_body(const LutmView& lv, const int tile0
         }
     };
 
-    auto load_params = [&](int unit, uint32_t (&sb)[4], uint32_t (&zb)[4]) {
-        const int g = unit >> lv.hshift;
-        const uint2_t s2 = *reinterpret_cast<const uint2_t*>(lv.scales + (long)g * N + n4);
-        sb[0] = s2.x & 0xffffu; sb[1] = s2.x >> 16; sb[2] = s2.y & 0xffffu; sb[3] = s2.y >> 16;
-        if constexpr (ZM == ZM_ASYM) {
-            const uint32_t zw = reinterpret_cast<const uint32_t*>(lv.zeros)[(long)g * (N / NB) + n4 / NB];
-#pragma unroll
-            for (int f = 0; f < 4; f++) zb[f] = ((zw >> (((n4 % NB) + f) * 4)) & 15u) + 1u;
-        } else {
-            const uint2_t z2 = *reinterpret_cast<const uint2_t*>(reinterpret_cast<const uint16_t*>(lv.zeros) + (long)g * N + n4);
-            zb[0] = z2.x & 0xffffu; zb[1] = z2.x >> 16; zb[2] = z2.y & 0xffffu; zb[3] = z2.y >> 16;
-        }
-    };
+    auto load_params = [&](int unit, uint32_t (&sb)[4], uint32_t (&zb)[4]) { lutm_load_params<ZM>(lv, n4, unit, sb, zb); };
     // the rows through a buffer descriptor: lane (kb, c) reads 16 bytes of row 4 * rq + kb at a scalar offset per (unit, row quad).  The
     // request for the unit after the workgroup's last goes out all the same -- against a descriptor of no records, which fetches nothing --
     // so that every wait of the loop is counted exactly (a branch around a load makes the compiler drain the queue at the join)
@@ -1310,44 +1312,7 @@ __device__ __forceinline__ void lutm_xs_body(const LutmView& lv, const int tile0
     const long col = (long)tile * 64 + lane;
     for (int m = 0; m < M; m++) {
         float tot = red[m * 64 + lane];
-        if (lv.S > 1) {
-            if (slice != lv.S - 1) {
-                const unsigned long long gval = ((unsigned long long)tag << 32) | __float_as_uint(tot);
-                __hip_atomic_store(lv.gran + ((long)slice * M + m) * ncat + col, gval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                continue;
-            }
-            float v = 0.0f;
-            for (int s0 = 0; s0 < lv.S - 1; s0 += 8) {
-                unsigned long long gv[8];
-                bool ready;
-                int spins = 0;
-                do {
-#pragma unroll
-                    for (int jj = 0; jj < 8; jj++) {
-                        const int sidx = (s0 + jj < lv.S - 1) ? s0 + jj : lv.S - 2;
-                        gv[jj] = __hip_atomic_load(lv.gran + ((long)sidx * M + m) * ncat + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    ready = true;
-#pragma unroll
-                    for (int jj = 0; jj < 8; jj++) ready = ready && ((unsigned)(gv[jj] >> 32) == (tag ^ tag_skew));
-                    ready = __builtin_amdgcn_ballot_w64(!ready) == 0;
-                    if (!ready) __builtin_amdgcn_s_sleep(2);
-                } while (!ready && ++spins < spin_limit);
-#pragma unroll
-                for (int jj = 0; jj < 8; jj++)
-                    if (s0 + jj < lv.S - 1) v += __uint_as_float((unsigned)gv[jj]);
-                if (!ready) {  // wave-uniform: never a silent number
-                    v = __uint_as_float(0x7fc00000u);
-                    if (lane == 0 && status) __hip_atomic_fetch_or(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                }
-            }
-            tot = v + tot;
-        }
-        if (owner) {
-            float o = dt_traits<DT>::round(tot);
-            if (lv.bias) o = o + dt_traits<DT>::load(lv.bias, n);
-            dt_traits<DT>::store(lv.y, (long)m * N + n, o);
-        }
+        lutm_finish_row<DT>(lv, tot, m, slice, tag, tag_skew, spin_limit, status, col, ncat, owner, n, lane);
     }
     if (lv.S > 1 && slice == lv.S - 1 && lane == 0) lv.gen[tile] = gen_next;  // read only by the next launch
 }
