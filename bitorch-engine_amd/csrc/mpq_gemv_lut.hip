@@ -692,11 +692,11 @@ struct LutmCtx { int kb, c; uint32_t* mytab; uint32_t lane_addr, wavepat, m0f; }
 // xfrag(rq, dst): the RB fragments of row quad rq (registers already loaded, or an LDS read issued here -- the table form calls it where the
 // read is older than the lookups its next counted wait leaves in flight); after_rq(rq): every word of w[rq] has been consumed (the x-sharing
 // form loads the next unit's row quad into the same registers there)
-template <int DT, int ZM, int RPG, int RB, bool DIRECT, bool XPERM, class XF, class AR>
+template <int DT, int ZM, int RPG, int RB, bool DIRECT, bool XPERM, bool PAIR2 = false, class XF, class AR>
 __device__ __forceinline__ void lutm_process_unit(const LutmCtx& cx, uint4_t (&w)[RPG / 4], XF&& xfrag, const uint32_t (&sb)[4],
                                                   const uint32_t (&zb)[4], lutm_acc_t (&acc)[RB][4], AR&& after_rq) {
     constexpr int RQ = RPG / 4;
-    constexpr bool PAIRCOL = RB == 1 || DT == BIE_F16;  // table layout: below
+    constexpr bool PAIRCOL = RB == 1 || DT == BIE_F16 || PAIR2;  // table layout: below (PAIR2: the pair form for bf16 with two row blocks too)
     const int kb = cx.kb, c = cx.c;
     uint32_t* const mytab = cx.mytab;
     const uint32_t lane_addr = cx.lane_addr, wavepat = cx.wavepat, m0f = cx.m0f;
@@ -1277,7 +1277,9 @@ __device__ __forceinline__ void lutm_xs_body(const LutmView& lv, const int tile0
         stage_load(xs, gn);
         asm volatile("" ::: "memory");  // the requests stay where they are written: hipcc otherwise sinks them to their first use (lower register
                                         // pressure), and the loop runs without a unit of rows in flight
-        lutm_process_unit<DT, ZM, RPG, RB, DIRECT, false>(
+        // bf16 with two row blocks: column-pair table entries here (6.9 against 7.3 us per 4096x11008 layer at 32 rows, profiles/r06_lutm_xs.txt;
+        // in the k-split form, at 157 registers, the pair form was the slower one)
+        lutm_process_unit<DT, ZM, RPG, RB, DIRECT, false, true>(
             cx, wc, [&](int rq, uint4_t (&dst)[RB]) { read_frags(rq, dst, p); }, sa, za, acc,
             [&](int rq) {
                 asm volatile("" ::: "memory");
