@@ -1148,11 +1148,15 @@ __device__ __forceinline__ void lutm_xs_body(const LutmView& lv, const int tile0
 #else
     constexpr bool DIRECT = DT == BIE_F16;
 #endif
-    constexpr int REDW = DIRECT ? RB * 1024 : 2048;  // a wave's words of the first region: its table (8 KiB) / its [M][64] transpose
-    constexpr int TABW = NW * REDW;
+    // LDS: [tables][two stage buffers]; the closing [M][64] transposes of the waves (RB * 1024 words each) reuse everything from word 0.
+    // bf16 tables: the pair form (always, here) fills only 128 of the 256 bytes of a table row (q), so the tables of a PAIR of waves interleave
+    // in one 8 KiB block -- wave w: block w >> 1, byte offset (w & 1) * 128 -- and four waves take 16 KiB instead of 32
+    constexpr int REDW = RB * 1024;
+    constexpr int TABW = DIRECT ? 0 : (NW / 2) * 2048;
     constexpr int XW = RB * RQ * 256;                // words of one stage buffer: RB * RQ fragments of 1 KiB
-    constexpr int XOFF = DIRECT ? 0 : TABW;          // fp16 has no tables: the stage buffers share the words of the closing transpose
-    constexpr int LDSW = DIRECT ? (TABW > 2 * XW ? TABW : 2 * XW) : TABW + 2 * XW;
+    constexpr int XOFF = TABW;
+    constexpr int LDSW = TABW + 2 * XW > NW * REDW ? TABW + 2 * XW : NW * REDW;
+    static_assert(NW % 2 == 0, "the bf16 tables interleave by wave pairs");
     __shared__ __attribute__((aligned(8192))) uint32_t tab[LDSW];  // the only LDS object: starts at LDS address 0
 
     const int lane = threadIdx.x & 63;
@@ -1245,7 +1249,7 @@ __device__ __forceinline__ void lutm_xs_body(const LutmView& lv, const int tile0
 
     uint32_t m0f;
     asm("v_mov_b32 %0, 0x0f0f0f0f" : "=v"(m0f));
-    const LutmCtx cx{kb, c, tab + wave * 2048, (uint32_t)((kb & 1) * 64 + c * 4), (uint32_t)wave * 0x20202020u, m0f};
+    const LutmCtx cx{kb, c, tab + (wave >> 1) * 2048 + (wave & 1) * 32, (uint32_t)((kb & 1) * 64 + c * 4 + (wave & 1) * 128), (uint32_t)(wave >> 1) * 0x20202020u, m0f};
 
     // The rows in a ring of DEPTH register sets: row quad rq of unit g + DEPTH is requested into the set of unit g as soon as unit g has consumed
     // it (DEPTH units ahead of its use); the next unit's constants and its stage of x at the top of the step.  The trip count is the
@@ -1320,8 +1324,10 @@ __device__ __forceinline__ void lutm_xs_body(const LutmView& lv, const int tile0
 }
 
 // block b -> {entry, first tile of the quad | slice << 20}
+// four four-wave workgroups per CU (<= 128 registers; LDS 16 .. 32 KiB each): bf16 at 32 rows 6.8 -> 6.6 us per 4096x11008 layer against the 136-140
+// registers hipcc takes when left alone (profiles/r06_lutm_xs.txt)
 template <int DT, int ZM, int RPG, int RB, int NW>
-__global__ __launch_bounds__(NW * 64, (DT == BIE_F16 && NW == 4 && RPG <= 16 ? 4 : 1)) void mpq_lutm_xs_list_kernel(const ListEntry* __restrict__ ent, const uint2_t* __restrict__ blk, const int M, const unsigned epoch,
+__global__ __launch_bounds__(NW * 64, (NW == 4 && RPG <= 16 ? 4 : 1)) void mpq_lutm_xs_list_kernel(const ListEntry* __restrict__ ent, const uint2_t* __restrict__ blk, const int M, const unsigned epoch,
                                                                unsigned* status, const unsigned tag_skew, const int spin_limit) {
     typedef const __attribute__((address_space(4))) uint2_t cu2_t;
     typedef const __attribute__((address_space(4))) ListEntry cent_t;
