@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libbie_oracle.so")
+_LIB_PATH = os.environ.get("BIE_ORACLE_LIB", os.path.join(_HERE, "libbie_oracle.so"))  # BIE_ORACLE_LIB: e.g. the sanitizer build (make -C oracle asan)
 F16, BF16, F32 = 0, 1, 2
 _lib = None
 
