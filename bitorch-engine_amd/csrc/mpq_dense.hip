@@ -453,10 +453,14 @@ template <int DT, int ZM>
 static void dequant_frag_launch(const int32_t* qw, const void* scales, const void* zeros, void* img, int K, int N, int w_bit, int gshift, hipStream_t st) {
     const int KS = K / 16;
     const long nfrag = (long)cdiv(N, 32) * KS;
-    const int fpw = (KS & 7) == 0 ? 8 : 1;
+    // fragments per wave: W4 takes 2 (four times the waves of the 8-fragment form -- two residency rounds, the store stream of the first under the
+    // loads of the second: 0.5-0.8 % of the whole M = 4096 call on every shape, profiles/r06_dq_fpw_ab.txt); BIE_DQ_FPW = 8 | 4 | 1 for the A/B
+    static const int fpw_knob = env_int_dense("BIE_DQ_FPW", 2);
+    int fpw = (KS & 7) == 0 ? 8 : 1;
+    if (fpw == 8 && w_bit == 4 && (fpw_knob == 1 || fpw_knob == 2 || fpw_knob == 4)) fpw = fpw_knob;
     const dim3 grid((unsigned)cdivl(nfrag / fpw, 4));
 #define BIE_DQ2(WB, F) hipLaunchKernelGGL((mpq_dequant_frag_kernel<DT, WB, ZM, F>), grid, dim3(256), 0, st, (const uint32_t*)qw, (const uint16_t*)scales, zeros, (uint4_t*)img, N, gshift, nfrag, KS)
-#define BIE_DQ(WB) do { if (fpw == 8) BIE_DQ2(WB, 8); else BIE_DQ2(WB, 1); } while (0)
+#define BIE_DQ(WB) do { if (fpw == 8) BIE_DQ2(WB, 8); else if (WB == 4 && fpw == 4) BIE_DQ2(4, 4); else if (WB == 4 && fpw == 2) BIE_DQ2(4, 2); else BIE_DQ2(WB, 1); } while (0)
     switch (w_bit) {
         case 1: BIE_DQ(1); break;
         case 2: BIE_DQ(2); break;
