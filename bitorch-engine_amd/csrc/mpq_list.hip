@@ -971,6 +971,9 @@ int mpq_list_create(MpqList** out, int n, const bie_mpq_list_entry* ent, int M, 
     int rpg;
     list_plan(n, ent, w_bit, group_size, &rpg, pe);
     int nw = (M == 1 && w_bit == 4) ? 4 : 8;
+    // W2 at one row: four waves as well (+1-2 % on three shapes in both dtypes, profiles/r06_w2_nw_ab.txt); BIE_LIST_W2_NW=8: the eight-wave arm
+    static const int w2_nw = list_env("BIE_LIST_W2_NW", 4);
+    if (M == 1 && w_bit == 2 && w2_nw == 4) nw = 4;
     if (dtype == BIE_BF16 && !asym && M == 1 && rpg == 16 && w_bit == 4) nw = list_nw(M, w_bit);  // the lab configuration takes the override
     // Two rows of W4 also go to the matrix-pipe kernel when the entries allow it (independent, N % 4 == 0, 16-byte aligned x): measured
     // 6.6 against 7.5 us per 4096x11008 layer for the two-row FMA form (profiles/r03_z_lutm_list_ab.txt).  BIE_LIST_M2_MFMA=0: FMA form.
@@ -1158,7 +1161,10 @@ int mpq_list_forward(MpqList* p, hipStream_t st) {
         list_launch_zm<BIE_BF16, 4, 1 | 64>(a, p->rpg, p->grid, 1, p->zm, st);
         return check_launch("mpq_list_kernel<d16>");
     }
-    if (p->w_bit == 2) {
+    if (p->w_bit == 2 && p->nw == 4 && p->M == 1) {
+        if (p->dtype == BIE_F16) list_launch_zm<BIE_F16, 2, 8>(a, p->rpg, p->grid, 1, p->zm, st);
+        else list_launch_zm<BIE_BF16, 2, 8>(a, p->rpg, p->grid, 1, p->zm, st);
+    } else if (p->w_bit == 2) {
         if (p->dtype == BIE_F16) list_launch_zm<BIE_F16, 2, 0>(a, p->rpg, p->grid, p->M, p->zm, st);
         else list_launch_zm<BIE_BF16, 2, 0>(a, p->rpg, p->grid, p->M, p->zm, st);
     } else {
