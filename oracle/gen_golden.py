@@ -177,6 +177,89 @@ def update_step_integer_params_vectors():
     return out
 
 
+def optim_diodemix_vectors():
+    """SURVEY 8f-2, the caller of the update step: the reference's DiodeMix optimiser (optim/diode_beta.py:37-196) and GaLoreProjector
+    (optim/galore_projector.py:17-124) run on CPU tensors.  Float parameters (the AdamW branch, two groups), GaLore groups of every projection
+    type, a binary linear and a W4A4-style integer parameter through the optimiser (the sign carriers' first moments are drawn with
+    torch.rand_like under torch.manual_seed: a mirror must consume the generator identically), and an MPQ parameter fed by privileged_grad."""
+    from bitorch_engine.optim import DiodeMix
+    from bitorch_engine.layers.qlinear.binary import BinaryLinearParameter
+    from bitorch_engine.layers.qlinear.nbit import nBitLinearParameter, MPQWeightParameter
+    out = {}
+    plain = lambda cls, data: torch.Tensor._make_subclass(cls, data, False)
+    # ---- float parameters: two groups with different options, four steps
+    g = torch.Generator().manual_seed(501)
+    p1 = torch.nn.Parameter(torch.randn((24, 40), generator=g))
+    p2 = torch.nn.Parameter(torch.randn((40,), generator=g))
+    p3 = torch.nn.Parameter(torch.randn((8, 8), generator=g))
+    out["float_p1_0"], out["float_p2_0"], out["float_p3_0"] = tonp(p1).copy(), tonp(p2).copy(), tonp(p3).copy()  # snapshots: step() updates in place
+    opt = DiodeMix([{"params": [p1, p2], "weight_decay": 0.01}, {"params": [p3], "lr": 5e-4, "correct_bias": False}], lr=1e-3, betas=(0.9, 0.99), eps=1e-6)
+    torch.manual_seed(9001)
+    for it in range(1, 5):
+        for name, p in (("p1", p1), ("p2", p2), ("p3", p3)):
+            p.grad = torch.randn(p.shape, generator=g) * 0.1
+            out[f"float_{name}_grad{it}"] = tonp(p.grad)
+        opt.step()
+        for name, p in (("p1", p1), ("p2", p2), ("p3", p3)):
+            out[f"float_{name}_{it}"] = tonp(p).copy()
+    out["float_p1_m"], out["float_p1_v"] = tonp(opt.state[p1]["exp_avg_l"]), tonp(opt.state[p1]["exp_avg_s"])
+    # ---- GaLore groups: every projection type, tall and wide gradients, the projector refreshed every second step
+    for tag, pt, shape in (("std_tall", "std", (48, 20)), ("std_wide", "std", (20, 48)), ("rstd_tall", "reverse_std", (48, 20)), ("rstd_wide", "reverse_std", (20, 48)),
+                           ("left", "left", (20, 48)), ("right", "right", (20, 48)), ("full", "full", (20, 48))):
+        g = torch.Generator().manual_seed(600 + len(tag))
+        p = torch.nn.Parameter(torch.randn(shape, generator=g))
+        out[f"galore_{tag}_0"] = tonp(p).copy()
+        opt = DiodeMix([{"params": [p], "rank": 4, "update_proj_gap": 2, "scale": 0.25, "proj_type": pt}], lr=2e-3, betas=(0.9, 0.99), weight_decay=0.0)
+        for it in range(1, 5):
+            p.grad = torch.randn(shape, generator=g) * 0.1
+            out[f"galore_{tag}_grad{it}"] = tonp(p.grad)
+            opt.step()
+            out[f"galore_{tag}_{it}"] = tonp(p).copy()
+    # ---- quantised parameters through the optimiser: binary linear (sign flips) and W4A4-style integer values, moments in fp32 and bf16
+    for tag, dtype in (("f32", torch.float), ("bf16", torch.bfloat16)):
+        for kind, cls in (("binlin", BinaryLinearParameter), ("nbitlin", nBitLinearParameter)):
+            g = torch.Generator().manual_seed(700 + len(kind) + len(tag))
+            shape = (24, 40)
+            data = torch.where(torch.rand(shape, generator=g) > 0.5, 1, -1).to(torch.int8) if kind == "binlin" else torch.randint(-7, 8, shape, generator=g).to(torch.int8)
+            p = plain(cls, data.clone())
+            key = f"q_{tag}_{kind}"
+            out[key + "_w0"] = tonp(data)
+            opt = DiodeMix([p], lr=3e-2, betas=(0.9, 0.99), eps=1e-6, weight_decay=0.0, dtype=dtype)
+            torch.manual_seed(4242)  # the first step draws the sign carriers' starting moments
+            for it in range(1, 4):
+                grad = torch.randint(-5, 6, shape, generator=g).to(torch.int8)
+                p.grad = None
+                p.grad_dtype = None
+                p.grad = grad
+                out[f"{key}_grad{it}"] = tonp(grad)
+                opt.step()
+                out[f"{key}_w{it}"] = tonp(p.data).copy()
+                out[f"{key}_wdtype{it}"] = np.array([str(p.data.dtype)])
+                out[f"{key}_exp_s{it}"] = tonp(opt.state[p]["exp_avg_s"]).copy()
+                out[f"{key}_exp_l{it}"] = tonp(opt.state[p]["exp_avg_l"]).copy()
+    # ---- an MPQ parameter (GPTQ form) fed through privileged_grad, five steps (the fifth also moves the zero points)
+    K, N, w_bit, gs = 128, 64, 4, 32
+    g = torch.Generator().manual_seed(811)
+    qweight = torch.randint(-2 ** 31, 2 ** 31 - 1, (K * w_bit // 32, N), generator=g, dtype=torch.int64).to(torch.int32)
+    scales = (torch.rand((K // gs, N), generator=g) * 0.01 + 0.005).to(torch.float16)
+    qzeros = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // gs, N * w_bit // 32), generator=g, dtype=torch.int64).to(torch.int32)
+    g_idx = torch.arange(K, dtype=torch.int32) // gs
+    p = MPQWeightParameter(qweight.clone(), requires_grad=False, scales=scales.clone(), zeros=qzeros.clone(), g_idx=g_idx.clone(), w_bit=w_bit, asym=True,
+                           group_size=gs, layer_type=1)
+    out["mpq_qweight0"], out["mpq_scales"], out["mpq_qzeros0"], out["mpq_g_idx"] = tonp(qweight), tonp(scales), tonp(qzeros), tonp(g_idx)
+    out["mpq_meta"] = np.array([K, N, w_bit, gs])
+    opt = DiodeMix([p], lr=2e-3, betas=(0.9, 0.99), eps=1e-6, dtype=torch.float16)
+    for it in range(1, 6):
+        p.privileged_grad = (torch.randn((K, N), generator=g) * 0.02).to(torch.float16)
+        p.grad = torch.zeros_like(p.data)  # step() skips parameters without .grad; the MPQ branch reads privileged_grad
+        out[f"mpq_grad{it}"] = tonp(p.privileged_grad)
+        opt.step()
+        out[f"mpq_qweight{it}"] = tonp(p.data).copy()
+    out["mpq_qzeros5"] = tonp(p.zeros)
+    return out
+
+
+
 def extension_signatures():
     import glob
     import re
@@ -210,6 +293,10 @@ def main():
     sys.path.insert(0, REF)
     import warnings
     warnings.filterwarnings("ignore")
+    if len(sys.argv) > 1 and sys.argv[1] == "optim":  # this one fixture only
+        np.savez_compressed(os.path.join(OUT, "optim_diodemix.npz"), **optim_diodemix_vectors())
+        print("written", os.path.join(OUT, "optim_diodemix.npz"))
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "update_int":  # this one fixture only (the others stay byte-identical)
         np.savez_compressed(os.path.join(OUT, "update_step_integer_params.npz"), **update_step_integer_params_vectors())
         print("written", os.path.join(OUT, "update_step_integer_params.npz"))
@@ -434,6 +521,7 @@ def main():
     # GPTQ-style (asym, g_idx) parameter: five steps each (step 5 also runs update_zeros), trivial and permuted g_idx, fp16 and bf16
     np.savez_compressed(os.path.join(OUT, "update_step.npz"), **update_step_vectors())
     np.savez_compressed(os.path.join(OUT, "update_step_integer_params.npz"), **update_step_integer_params_vectors())
+    np.savez_compressed(os.path.join(OUT, "optim_diodemix.npz"), **optim_diodemix_vectors())
 
     # ---- the extension modules' boundary: name and positional parameter list of every function the reference binds with pybind11
     # (m.def("name", &fn)), read off the reference's own C++ definitions.  Data only (names), consumed by tests/test_boundary_cpu.py.

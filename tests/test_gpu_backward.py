@@ -317,3 +317,45 @@ def test_a_training_step_end_to_end_changes_what_the_next_forward_multiplies_by(
         want = (torch.where(x + layer.bias_a >= 0, 1.0, -1.0) @ torch.where(layer.weight.data >= 0, 1.0, -1.0).t().float()) * layer.scale_a * layer.scale_w
     assert not torch.equal(y_after, y_before)
     assert torch.allclose(y_after, want.to(y_after.dtype), rtol=1e-5, atol=1e-5)
+
+
+def test_diodemix_trains_a_small_quantised_model_end_to_end():
+    """The whole fine-tune loop through the reference's API names and nothing else: a binary linear layer (int8 sign carriers), a W4A4 layer (float weight behind its quantiser)
+    and a float head, `loss.backward()` through this library's Functions, `bitorch_engine.optim.DiodeMix.step()` through the parameter classes'
+    update().  Ten steps on a fixed batch: every kind of parameter moves (carriers flip, integer values change, float weights change), the
+    optimiser state carries the reference's keys per kind, and the loss at the end is below the loss at the start."""
+    from bitorch_engine.layers.qlinear.binary.cutlass import BinaryLinearCutlass
+    from bitorch_engine.layers.qlinear.nbit.cutlass import Q4LinearCutlass
+    from bitorch_engine.layers.qlinear.binary import BinaryLinearParameter
+    from bitorch_engine.optim import DiodeMix
+    g = torch.Generator().manual_seed(77)
+    K, H, N = 256, 128, 16
+    b1 = BinaryLinearCutlass(K, H, dtype=torch.float)
+    b1.set_weight_data(torch.randn((H, K), generator=g))
+    q4 = Q4LinearCutlass(in_channels=H, out_channels=H, dtype=torch.float)
+    q4.weight.data = torch.randn((H, H), generator=g) * 0.05
+    q4.prepare_params()
+    head = torch.nn.Linear(H, N)
+    model = torch.nn.Sequential(b1, q4, head).to(DEV).train()
+    assert isinstance(b1.weight, BinaryLinearParameter) and q4.weight.requires_grad  # the W4A4 layer trains a float weight behind its quantiser (reference nbit/layer.py:206)
+    x = torch.randn((32, K), generator=g).to(DEV)
+    target = torch.randn((32, N), generator=g).to(DEV)
+    opt = DiodeMix(model.parameters(), lr=2e-2, betas=(0.9, 0.99), dtype=torch.float)
+    w_b0, w_q0, w_h0 = b1.weight.data.clone(), q4.weight.data.clone(), head.weight.data.clone()
+    losses = []
+    torch.manual_seed(5)
+    for _ in range(10):
+        opt.zero_grad(set_to_none=True)
+        y = model(x)
+        loss = torch.nn.functional.mse_loss(y.float(), target)
+        loss.backward()
+        assert b1.weight.grad is not None and q4.weight.grad is not None and head.weight.grad is not None
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(math.isfinite(v) for v in losses)
+    assert int((b1.weight.data != w_b0).sum()) > 0, "no sign carrier flipped in ten steps"
+    assert not torch.equal(q4.weight.data.float(), w_q0.float()), "the W4A4 weight never moved"
+    assert not torch.equal(head.weight.data, w_h0)
+    assert set(opt.state[b1.weight]) == {"step", "exp_avg_l", "exp_avg_s"} and float(opt.state[b1.weight]["step"]) == 10.0
+    assert set(opt.state[head.weight]) == {"step", "exp_avg_l", "exp_avg_s"}
+    assert losses[-1] < losses[0], f"the loss did not go down: {losses[0]:.4f} -> {losses[-1]:.4f}"

@@ -2996,6 +2996,41 @@ def test_exl2_list_forward_equals_the_per_layer_calls(M):
         assert torch.equal(e["y"], first[i]), f"exl2 list entry {i}: second launch differs"
 
 
+def test_diodemix_steps_an_mpq_parameter_like_the_reference():
+    """The optimiser side of SURVEY 8f-2: bitorch_engine.optim.DiodeMix on the device.  An MPQWeightParameter in its GPTQ form, fed through
+    `privileged_grad` for five steps (the fifth also moves the zero points), against the REFERENCE's DiodeMix.step on CPU tensors
+    (tests/golden/optim_diodemix.npz, oracle/gen_golden.py optim_diodemix_vectors): the re-packed weights after every step and the re-packed
+    zero points at the end, bit for bit; the optimiser's state carries the reference's keys.  A float parameter in the same optimiser takes the
+    AdamW branch on the device (1e-5 against the CPU vectors: the GPU kernels contract multiply-adds the CPU ones do not)."""
+    from bitorch_engine.layers.qlinear.nbit.layer import MPQWeightParameter
+    from bitorch_engine.optim import DiodeMix
+    g = np.load(os.path.join(GOLDEN, "optim_diodemix.npz"))
+    K, N, w_bit, gs = [int(v) for v in g["mpq_meta"]]
+    as_f16 = lambda a: torch.from_numpy(a.view(np.int16).copy()).view(torch.float16)
+    p = MPQWeightParameter(torch.from_numpy(g["mpq_qweight0"]).to(DEV), scales=as_f16(g["mpq_scales"]).to(DEV), zeros=torch.from_numpy(g["mpq_qzeros0"]).to(DEV),
+                           g_idx=torch.from_numpy(g["mpq_g_idx"]).to(DEV), w_bit=w_bit, asym=True, group_size=gs, layer_type=1)
+    opt = DiodeMix([p], lr=2e-3, betas=(0.9, 0.99), eps=1e-6, dtype=torch.float16)
+    for it in range(1, 6):
+        p.privileged_grad = as_f16(g[f"mpq_grad{it}"]).to(DEV)
+        p.grad = torch.zeros_like(p.data)
+        opt.step()
+        got, want = p.data.cpu().numpy(), g[f"mpq_qweight{it}"]
+        assert np.array_equal(got, want), f"packed weights differ after step {it} ({(got != want).sum()} of {want.size} words)"
+    assert np.array_equal(p.zeros.cpu().numpy(), g["mpq_qzeros5"]), "re-packed qzeros differ after the fifth step"
+    st = opt.state[p]
+    assert set(st) == {"step", "exp_avg_l", "exp_avg_s"} and float(st["step"]) == 5.0 and st["exp_avg_l"].dtype == torch.float16 and st["exp_avg_l"].is_cuda
+    assert not np.array_equal(p.data.cpu().numpy(), g["mpq_qweight0"])
+    # the AdamW branch on the device
+    ps = {n: torch.nn.Parameter(torch.from_numpy(g[f"float_{n}_0"]).to(DEV)) for n in ("p1", "p2", "p3")}
+    opt = DiodeMix([{"params": [ps["p1"], ps["p2"]], "weight_decay": 0.01}, {"params": [ps["p3"]], "lr": 5e-4, "correct_bias": False}], lr=1e-3, betas=(0.9, 0.99), eps=1e-6)
+    for it in range(1, 5):
+        for n, q in ps.items():
+            q.grad = torch.from_numpy(g[f"float_{n}_grad{it}"]).to(DEV)
+        opt.step()
+        for n, q in ps.items():
+            torch.testing.assert_close(q.detach().cpu(), torch.from_numpy(g[f"float_{n}_{it}"]), rtol=1e-5, atol=1e-6, msg=lambda m: f"{n} after step {it}: {m}")
+
+
 @pytest.mark.parametrize("key", ["f16_trivial", "f16_actorder", "bf16_trivial", "bf16_actorder"])
 def test_qweight_update_step_bit_exact_vs_reference(key):
     """MPQWeightParameter.update -> qweight_update_fn on the device (HIP unpack + Adam moments + HIP re-pack) against
