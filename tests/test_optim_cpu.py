@@ -125,3 +125,37 @@ def test_constructor_checks_and_skipped_parameters():
     w.grad = torch.ones(3).to_sparse()
     with pytest.raises(RuntimeError, match="sparse"):
         opt.step()
+
+
+def test_state_dict_round_trip_continues_the_same_trajectory(vec):
+    """Optimiser checkpoints: state_dict() after two steps, loaded into a fresh optimiser over copies of the parameters, then two more steps ==
+    four uninterrupted steps -- float group and GaLore group (the projector object travels inside the state, as in the reference)."""
+    def make():
+        a = torch.nn.Parameter(torch.from_numpy(vec["float_p1_0"]).clone())
+        b = torch.nn.Parameter(torch.from_numpy(vec["galore_std_wide_0"]).clone())
+        opt = DiodeMix([{"params": [a], "weight_decay": 0.01}, {"params": [b], "rank": 4, "update_proj_gap": 2, "scale": 0.25, "proj_type": "std"}], lr=1e-3, betas=(0.9, 0.99))
+        return a, b, opt
+
+    def feed(a, b, it):
+        a.grad = torch.from_numpy(vec[f"float_p1_grad{it}"]).clone()
+        b.grad = torch.from_numpy(vec[f"galore_std_wide_grad{it}"]).clone()
+
+    a, b, opt = make()
+    for it in (1, 2, 3, 4):
+        feed(a, b, it)
+        opt.step()
+    a2, b2, opt2 = make()
+    for it in (1, 2):
+        feed(a2, b2, it)
+        opt2.step()
+    sd = opt2.state_dict()
+    a3, b3, opt3 = make()
+    with torch.no_grad():
+        a3.copy_(a2)
+        b3.copy_(b2)
+    opt3.load_state_dict(sd)
+    assert isinstance(opt3.state[b3]["projector"], GaLoreProjector) and float(opt3.state[a3]["step"]) == 2.0
+    for it in (3, 4):
+        feed(a3, b3, it)
+        opt3.step()
+    assert torch.equal(a3.detach(), a.detach()) and torch.equal(b3.detach(), b.detach())
