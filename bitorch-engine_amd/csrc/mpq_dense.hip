@@ -428,18 +428,36 @@ static int env_int_dense(const char* name, int dflt) {
 // (4096x4096: 57 vs 61 us at M = 1024, 96 vs 102 at 2048, 124 vs 137 at 4096, 279 vs 301 at 8192) and loses otherwise (4096x11008
 // M = 1024: 150 vs 120; K = 8192 .. 16384: equal or slower) -- the rule below.  BIE_GEMM_DENSE=0 switches it off, =2 forces it (tests).
 // Depends on (M, K, N) and the process environment only: bie_mpq_workspace_bytes has to reproduce the choice.
+#include "mpq_dense_table.inc"
+
+// nearest grid point in log space (the geometric mean of two neighbours is the boundary); -1 when x is more than 20 % outside the grid
+static int dense_grid_index(const int* g, int n, long x) {
+    if ((double)x * 1.2 < (double)g[0] || (double)x > (double)g[n - 1] * 1.2) return -1;
+    int i = 0;
+    while (i + 1 < n && (double)x * (double)x > (double)g[i] * (double)g[i + 1]) i++;
+    return i;
+}
+
 bool mpq_dense_ok(int M, int K, int N) {
     static const bool tuning = getenv("BIE_TUNING") != nullptr;
-    static const int on_once = env_int_dense("BIE_GEMM_DENSE", 1), min_once = env_int_dense("BIE_GEMM_DENSE_MIN_M", 1024);
-    const int on = tuning ? env_int_dense("BIE_GEMM_DENSE", 1) : on_once, min_m = tuning ? env_int_dense("BIE_GEMM_DENSE_MIN_M", 1024) : min_once;
+    static const int on_once = env_int_dense("BIE_GEMM_DENSE", 1), min_once = env_int_dense("BIE_GEMM_DENSE_MIN_M", 897);
+    const int on = tuning ? env_int_dense("BIE_GEMM_DENSE", 1) : on_once, min_m = tuning ? env_int_dense("BIE_GEMM_DENSE_MIN_M", 897) : min_once;
     if (!on || (K & 31) || (N & 7)) return false;
     if (on == 2) return true;  // forced (tests: every shape the kernels can take)
     // profiles/r03_dense_ab4_gm4.txt (dense / fused time, 7 layer shapes x M = 512 .. 8192, tiles walked gm = 4 rows deep per XCD run): with
     // 256 x 256 tiles (>= 192 of them) the dense form is 0.89-0.98 of the fused time up to K = 5120 at every M >= 1024, and beyond that K from
     // M = 4096 on (0.89-1.0; at M = 2048 1.04-1.08: the dequantise pass is K*N work that only M amortises); with 128 x 128 tiles it wins
     // only on whole rounds of short-K square layers (0.82-0.93) and loses 1.05-1.6x elsewhere.
+    // Round 6: inside the measured grid (70 layer shapes x 6 row counts, fused against dense on one box: profiles/r06_dense_rule_sweep.txt) the answer is the
+    // measurement at the nearest grid point -- the analytic rule below left 1.9 % on the table on average (77 of 420 cells more than 4 % off, up to 28 %: it
+    // knew Llama-7B's shapes only); BIE_GEMM_DENSE_TABLE=0 switches the table off.  Outside the grid (M > 4915, K or N beyond 20 % of it) the rule answers.
+    static const int table_once = env_int_dense("BIE_GEMM_DENSE_TABLE", 1);
+    if ((tuning ? env_int_dense("BIE_GEMM_DENSE_TABLE", 1) : table_once) && M >= min_m) {
+        const int ki = dense_grid_index(kDenseK, 8, K), ni = dense_grid_index(kDenseN, 9, N), mi = dense_grid_index(kDenseM, 6, M);
+        if (ki >= 0 && ni >= 0 && mi >= 0) return (kDenseTable[ki][ni] >> mi) & 1;
+    }
     const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
-    if (M < min_m) return false;
+    if (M < min_m) return false;  // 897 = the first row count with the tile grid of 1024 rows (eight 128-row / four 256-row tiles): 4096x4096 at 1023 rows 49.0 against 58.2 us fused (profiles/r06_dense_mid_m.txt); below, the fused kernel wins every cell
     // beyond K = 5120 from M = 4096 while the image (K*N*2 bytes) stays inside the 256 MiB MALL, from M = 8192 when it does not (8192 -> 28672, 470 MB:
     // 1.007 at M = 4096 in the A/B, 1.02 in the bench's two-layer rotation, 0.954 at M = 8192)
     if (t256 >= 192) return K <= 5120 || M >= ((long)K * N * 2 > (192l << 20) ? 8192 : 4096);
