@@ -58,6 +58,7 @@ int mpq_grad_input_launch(const void* gy, const int32_t* qw, const void* scales,
 // mpq_dense.hip
 bool mpq_dense_shape_ok(int K, int N);
 size_t mpq_dense_workspace_bytes(int K, int N);
+bool mpq_dense_ok(int M, int K, int N);
 int mpq_dense_gidx_launch(const void* x, const int32_t* qw, const void* scales, const void* zeros, const int32_t* g_idx, const void* bias, void* y, void* scratch,
                           int M, int K, int N, int w_bit, int asym, int dtype, hipStream_t st);
 // mbwq.hip
@@ -173,6 +174,7 @@ void bie_mpq_list_destroy(bie_mpq_list_t* plan) { mpq_list_destroy(reinterpret_c
 // explicit g_idx that is not a permutation of k // group_size, prefill: per-k dequantise into the fragment image + the dense GEMM (mpq_dense.hip)
 static bool gidx_dense_ok(int M, int K, int N, int dtype) { return M > 32 && (dtype == BIE_F16 || dtype == BIE_BF16) && mpq_dense_shape_ok(K, N); }
 
+int bie_mpq_prefill_form(int M, int K, int N) { return (M > 32 && mpq_dense_ok(M, K, N)) ? 1 : 0; }
 size_t bie_mpq_workspace_bytes_gidx(int M, int K, int N, int w_bit) {
     const size_t base = bie_mpq_workspace_bytes(M, K, N, w_bit);
     if (base == 0 || !gidx_dense_ok(M, K, N, BIE_F16)) return base;

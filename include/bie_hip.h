@@ -74,6 +74,10 @@ unsigned bie_device_status(int clear);
  * zero-filled, or to recover a workspace after a launch that did not complete (device reset, aborted graph). */
 int bie_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
 size_t bie_mpq_workspace_bytes(int M, int K, int N, int w_bit);
+/* Which prefill form a call of these rows takes (host-only, depends on (M, K, N) and the process environment like the sizing function above): 1 = the
+ * dense two-launch form (dequantise once into the fragment image + dense MFMA GEMM: the reference's own split, mpq_layer.py:59-63), 0 = the fused
+ * kernels.  Round 6: inside the measured grid the answer is the measurement (csrc/mpq_dense_table.inc). */
+int bie_mpq_prefill_form(int M, int K, int N);
 /* The same for a call that passes an EXPLICIT g_idx which is not a permutation of k // group_size (unequal groups) with M > 32: room for
  * the dequantised MFMA fragment image, so that bie_mpq_forward runs "per-k dequantise + dense MFMA GEMM" instead of the row-chunked generic
  * kernel.  The reference's branch for those calls is unpack_qweight(g_idx) + torch.matmul (layers/qlinear/nbit/cuda/mpq_layer.py:59-63,

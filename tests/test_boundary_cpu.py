@@ -257,3 +257,25 @@ def test_workspace_sizing_is_total_over_row_counts_and_shapes():
         for (K, N) in ((4096, 4096), (4096, 100), (11008, 4100)):
             for M in (1, 2, 16, 17, 32, 33, 1000, 4096, 65536):
                 assert L.bie_mpq_workspace_bytes(M, K, N, w_bit) > 0, (M, K, N, w_bit)
+
+
+def test_prefill_dispatch_follows_the_measured_table_inside_its_grid(monkeypatch):
+    """mpq_dense_ok (csrc/mpq_dense.hip): inside the measured grid the dense two-launch form is chosen where the sweep found it faster
+    (profiles/r06_dense_rule_sweep.txt -> csrc/mpq_dense_table.inc), by the nearest grid point in log space; outside the grid and with
+    BIE_GEMM_DENSE_TABLE=0 the round-3 analytic rule answers.  Seen through bie_mpq_prefill_form (host-only); the sizing function must agree: a plan that takes the dense form holds the
+    K x N x 2-byte fragment image.  (BIE_TUNING, set by tests/conftest.py, makes the library re-read its knobs per call.)"""
+    from bitorch_engine import _hip
+    L = _hip.lib()
+    dense = lambda M, K, N: L.bie_mpq_prefill_form(M, K, N) == 1
+    for (M, K, N, want) in ((1024, 4096, 4096, True), (1024, 4096, 11008, False), (4096, 4096, 11008, True), (1024, 14336, 4096, False), (3072, 8192, 8192, True),
+                            (1000, 4000, 4104, True),      # off the grid: the nearest point is (1024, 4096, 4096)
+                            (896, 4096, 4096, False),      # below the row floor
+                            (512, 4096, 4096, False)):
+        assert dense(M, K, N) == want, (M, K, N)
+    for (M, K, N) in ((1024, 4096, 4096), (4096, 4096, 11008), (3072, 8192, 8192)):
+        assert L.bie_mpq_workspace_bytes(M, K, N, 4) >= K * N * 2
+    assert dense(8192, 4096, 4096)             # beyond the row grid: the analytic rule (whole rounds of 256 x 256 tiles, short K)
+    assert not dense(2048, 1024, 1024)         # below the K / N grid: the analytic rule (too few tiles)
+    monkeypatch.setenv("BIE_GEMM_DENSE_TABLE", "0")  # BIE_TUNING (tests/conftest.py): knobs are re-read per call
+    assert not dense(3072, 8192, 8192), "without the table the round-3 rule keeps K = 8192 fused below 4096 rows"
+    assert dense(1024, 4096, 4096)
