@@ -8,7 +8,9 @@ res = {n: [] for n in names}
 for rnd in range(3):
     for n in names:
         env = dict(os.environ)
-        if n != "product":
+        if n.startswith("env:"):  # "env:K=V,K=V": the product library under these environment variables
+            env.update(dict(kv.split("=", 1) for kv in n[4:].split(",")))
+        elif n != "product":
             env["BIE_HIP_LIB"] = os.path.join(ROOT, "bitorch-engine_amd", "variants", n, "libbie_hip.so")
         p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True)
         try:
