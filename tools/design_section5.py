@@ -54,7 +54,7 @@ rows = [
      "**" + " / ".join(f"{fr(f'f16_list_M{m}_4096x11008'):.3f}" for m in (2, 8, 16, 32)) + "**",
      "`profiles/r06_lutm_xs.txt`; bf16 takes the x-sharing form from 12 rows (table form, instruction-bound: 4–9 %)"),
     ("W2A16 list 96 × 4096²", f"{us('c3_w2a16_list_4096x4096'):.2f} µs per layer", f"{fr('c3_w2a16_list_4096x4096'):.3f}",
-     "VALU-bound (1.61 VALU per weight, 0.73 busy); two restructurings rejected this round"),
+     "VALU-bound (1.61 VALU per weight, 0.73 busy); round 6: four-wave workgroups (+1–2 %, `r06_w2_nw_ab.txt`)"),
     ("exl2 3/2-bit lists 4096² / 4096→11008 / 11008→4096", "—", f"{S['c3_exl2_list_4096x4096']:.3f} / {S['c3_exl2_list_4096x11008']:.3f} / {S['c3_exl2_list_11008x4096']:.3f}", ""),
     ("lone launch 4096² / 4096→11008 / 11008→4096 / 8192→28672",
      f"{S['per_layer_launches_4096x4096']['us']:.2f} / {S['c2_gemv_4096x11008']['us']:.2f} / {S['c2_gemv_11008x4096']['us']:.2f} / {S['c5_gemv_8192x28672']['us']:.1f} µs",
