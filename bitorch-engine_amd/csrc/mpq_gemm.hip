@@ -521,6 +521,16 @@ static int env_int(const char* name, int dflt) {
 // takes ~1.7x one block).  A launch is a sequence of rounds of `cap` blocks; split-K adds S fp32 partial slabs written and
 // re-read plus the finalize launch.  The plan depends on (M, K, N) only: bie_mpq_workspace_bytes has to reproduce it
 // without knowing dtype or bit width.
+#include "mpq_gemm_plan_table.inc"
+
+// nearest grid point in log space; -1 when x is more than 20 % outside the grid
+static int plan_grid_index(const int* g, int n, long x) {
+    if ((double)x * 1.2 < (double)g[0] || (double)x > (double)g[n - 1] * 1.2) return -1;
+    int i = 0;
+    while (i + 1 < n && (double)x * (double)x > (double)g[i] * (double)g[i + 1]) i++;
+    return i;
+}
+
 static GemmPlan plan_gemm(int M, int K, int N) {
     // tuning knobs: read ONCE per process -- unless BIE_TUNING is set (tests / sweep tools change them between calls), in which
     // case they are re-read on every launch.  No getenv on the product's launch path.
@@ -528,6 +538,25 @@ static GemmPlan plan_gemm(int M, int K, int N) {
     static const int bm_once = env_int("BIE_GEMM_BM", 0), s_once = env_int("BIE_GEMM_S", 0);
     const int force_bm = tuning ? env_int("BIE_GEMM_BM", 0) : bm_once, force_s = tuning ? env_int("BIE_GEMM_S", 0) : s_once;
     const int T = K / GEMM_BK;
+    // Round 6: where a sweep of EVERY (BM, S) over 40 layer shapes x 11 row counts found a plan more than 2 % ahead of this model's choice
+    // (114 of 440 cells, up to 24 %: profiles/r06_gemm_plan_table_sweep.txt -> mpq_gemm_plan_table.inc), the grid point's plan is taken for the grid's own (K, N) and the
+    // row counts around its M that make the same number of row tiles.  BIE_GEMM_PLAN_TABLE=0: the model alone.
+    static const int table_once = env_int("BIE_GEMM_PLAN_TABLE", 1);
+    if (!force_bm && !force_s && (tuning ? env_int("BIE_GEMM_PLAN_TABLE", 1) : table_once)) {
+        const int ki = plan_grid_index(kPlanK, (int)(sizeof(kPlanK) / sizeof(int)), K), ni = plan_grid_index(kPlanN, (int)(sizeof(kPlanN) / sizeof(int)), N),
+                  mi = plan_grid_index(kPlanM, (int)(sizeof(kPlanM) / sizeof(int)), M);
+        if (ki >= 0 && ni >= 0 && mi >= 0) {
+            const unsigned e = kPlanTable[ki][ni][mi];
+            const int BM = 32 << (e >> 5), S = (int)(e & 31u);
+            // a plan is a statement about tile COUNTS: it is taken for the grid's own K and N only, and for row counts that make as many row tiles as the
+            // grid point's (nearest-point lookup across shapes measured WORSE than the model off the grid: 1.015 against 1.005 over 132 held-out cells,
+            // up to +28 % -- profiles/r06_gemm_plan_table_holdout_nearest.txt)
+            if (e != 0 && K == kPlanK[ki] && N == kPlanN[ni] && cdiv(M, BM) == cdiv(kPlanM[mi], BM) && !(BM > 32 && BM >= 2 * M) && S >= 1 && (S == 1 || T / S >= 2)) {
+                const int tps = cdiv(T, S);
+                return GemmPlan{BM, cdiv(T, tps), tps};
+            }
+        }
+    }
     const int bms[4] = {32, 64, 128, 256};
     const double c0[4] = {0.93, 1.00, 1.19, 1.53};
     double best = 1e30;

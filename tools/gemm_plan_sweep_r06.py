@@ -13,7 +13,7 @@ import torch  # noqa: E402
 from bench import Bench  # noqa: E402
 
 B = Bench(torch.device("cuda", 0))
-shapes = ((4096, 11008), (4096, 4096), (11008, 4096))
+shapes = tuple(tuple(int(v) for v in x.split("x")) for x in os.environ.get("SWEEP_SHAPES", "4096x11008,4096x4096,11008x4096").split(","))
 Ms = tuple(int(m) for m in os.environ.get("SWEEP_MS", "17,32,48,64,96,128,192,256,384,512,768,1023").split(","))
 
 
@@ -42,4 +42,4 @@ for (k, n) in shapes:
         os.environ.pop("BIE_GEMM_S", None)
         best = min(res, key=res.get)
         top = sorted(res.items(), key=lambda kv: kv[1])[:4]
-        print(json.dumps({"K": k, "N": n, "M": M, "model_us": base, "best": best, "best_us": res[best], "gain": round(base / res[best], 3), "top4": top}), flush=True)
+        print(json.dumps({"K": k, "N": n, "M": M, "model_us": base, "best": best, "best_us": res[best], "gain": round(base / res[best], 3), "top4": top, "all": res}), flush=True)
