@@ -16,7 +16,7 @@ int mpq_gemv_generic_launch(const void* x, const int32_t* qw, const void* scales
                             const void* bias, void* y, float* part, int M, int K, int N, int w_bit, int group_size,
                             int asym, int dtype, hipStream_t st, const uint16_t* perm = nullptr);
 // mpq_gemv_lut.hip
-bool mpq_gemv_lut_ok(int M, int K, int w_bit, int group_size, int dtype, bool has_gidx);
+bool mpq_gemv_lut_ok(int M, int K, int w_bit, int group_size, int dtype, bool has_gidx, int N = 0);  // N > 0: a lone call (17 .. 32 rows on measured shapes)
 size_t mpq_gemv_lut_part_floats(int M, int K, int group_size, int tiles_total, int w_bit);
 int mpq_gemv_lut_launch(int nsets, const int32_t* const* qw, const void* const* scales, const void* const* zeros,
                         const void* const* bias, void* const* y, const int* N, const void* x, unsigned* counters, float* part,
@@ -175,6 +175,12 @@ void bie_mpq_list_destroy(bie_mpq_list_t* plan) { mpq_list_destroy(reinterpret_c
 static bool gidx_dense_ok(int M, int K, int N, int dtype) { return M > 32 && (dtype == BIE_F16 || dtype == BIE_BF16) && mpq_dense_shape_ok(K, N); }
 
 int bie_mpq_prefill_form(int M, int K, int N) { return (M > 32 && mpq_dense_ok(M, K, N)) ? 1 : 0; }
+int bie_mpq_rows_form(int M, int K, int N, int w_bit, int group_size, int dtype) {
+    static const int lut_max_m = []() { const char* e = getenv("BIE_LUT_MAX_M"); return e ? atoi(e) : 16; }();
+    if (M <= 0 || K <= 0 || N <= 0) return 0;
+    if (M <= (lut_max_m >= 16 ? 32 : lut_max_m) && cdiv(N, 64) <= BIE_WS_COUNTERS && (N & 3) == 0 && mpq_gemv_lut_ok(M, K, w_bit, group_size, dtype, false, N)) return 2;
+    return bie_mpq_prefill_form(M, K, N);
+}
 size_t bie_mpq_workspace_bytes_gidx(int M, int K, int N, int w_bit) {
     const size_t base = bie_mpq_workspace_bytes(M, K, N, w_bit);
     if (base == 0 || !gidx_dense_ok(M, K, N, BIE_F16)) return base;
@@ -184,7 +190,7 @@ size_t bie_mpq_workspace_bytes_gidx(int M, int K, int N, int w_bit) {
 
 size_t bie_mpq_workspace_bytes(int M, int K, int N, int w_bit) {
     if (M <= 0 || K <= 0 || N <= 0 || !(w_bit == 1 || w_bit == 2 || w_bit == 4 || w_bit == 8)) return 0;
-    size_t a = M <= 16 ? mpq_gemv_workspace_bytes(M, K, N, w_bit) : 0;
+    size_t a = M <= 32 ? mpq_gemv_workspace_bytes(M, K, N, w_bit) : 0;
     size_t b = mpq_gemm_workspace_bytes(M, K, N);
     const int mc = M < GENERIC_M_CHUNK ? M : GENERIC_M_CHUNK;
     size_t c = (size_t)cdiv(K, 512) * mc * N * sizeof(float);
@@ -216,7 +222,7 @@ int bie_mpq_forward(const void* x, const int32_t* qweight, const void* scales, c
     static const int gemv_max_m = []() { const char* e = getenv("BIE_GEMV_MAX_M"); return e ? atoi(e) : 2; }();  // tuning knob
     // W4 decode and small batches: the table-lookup kernels (mpq_gemv_lut_ok says which M each form takes)
     static const int lut_max_m = []() { const char* e = getenv("BIE_LUT_MAX_M"); return e ? atoi(e) : 16; }();
-    if (M <= lut_max_m && cdiv(N, 64) <= BIE_WS_COUNTERS && (N & 3) == 0 && mpq_gemv_lut_ok(M, K, w_bit, group_size, dtype, has_gidx))
+    if (M <= (lut_max_m >= 16 ? 32 : lut_max_m) && cdiv(N, 64) <= BIE_WS_COUNTERS && (N & 3) == 0 && mpq_gemv_lut_ok(M, K, w_bit, group_size, dtype, has_gidx, N))
         return mpq_gemv_launch(x, qweight, scales, zeros, bias, y, head, M, K, N, w_bit, group_size, asym ? 1 : 0, dtype, nullptr, st);
     if (M <= 8 && (M <= gemv_max_m || !gemm_ok) && mpq_gemv_fast_ok(M, K, N, w_bit, group_size, dtype, has_gidx))
         return mpq_gemv_launch(x, qweight, scales, zeros, bias, y, head, M, K, N, w_bit, group_size, asym ? 1 : 0, dtype, nullptr, st);

@@ -22,7 +22,7 @@
 namespace bie {
 
 // mpq_gemv_lut.hip
-bool mpq_gemv_lut_ok(int M, int K, int w_bit, int group_size, int dtype, bool has_gidx);
+bool mpq_gemv_lut_ok(int M, int K, int w_bit, int group_size, int dtype, bool has_gidx, int N = 0);  // N > 0: a lone call (17 .. 32 rows on measured shapes)
 size_t mpq_gemv_lut_part_floats(int M, int K, int group_size, int tiles_total, int w_bit);
 int mpq_gemv_lut_launch(int nsets, const int32_t* const* qw, const void* const* scales, const void* const* zeros,
                         const void* const* bias, void* const* y, const int* N, const void* x, unsigned* counters, float* part,
@@ -625,7 +625,7 @@ bool mpq_gemv_fast_ok(int M, int K, int N, int w_bit, int group_size, int dtype,
 
 size_t mpq_gemv_workspace_bytes(int M, int K, int N, int w_bit) {
     size_t lut = 0;  // the group size is not known here: take the largest slab count any supported group size gives
-    if ((w_bit == 4 && M <= 16) || (w_bit == 2 && M <= 2))
+    if ((w_bit == 4 && M <= 32) || (w_bit == 2 && M <= 2))  // W4: 17 .. 32 rows may take the matrix-pipe decode kernel with two row blocks (mpq_lut_rb2_ok)
         for (int gs = 32; gs <= 256; gs *= 2)
             if (K % gs == 0) {
                 const size_t f = mpq_gemv_lut_part_floats(M, K, gs, cdiv(N, 64), w_bit);
@@ -646,7 +646,7 @@ size_t mpq_gemv_workspace_bytes(int M, int K, int N, int w_bit) {
 int mpq_gemv_launch(const void* x, const int32_t* qw, const void* scales, const void* zeros, const void* bias, void* y,
                     float* part, int M, int K, int N, int w_bit, int group_size, int zm, int dtype, const uint16_t* perm,
                     hipStream_t st) {
-    if (perm == nullptr && cdiv(N, 64) <= BIE_WS_COUNTERS && mpq_gemv_lut_ok(M, K, w_bit, group_size, dtype, false)) {  // bf16 W4: table-lookup kernel
+    if (perm == nullptr && cdiv(N, 64) <= BIE_WS_COUNTERS && mpq_gemv_lut_ok(M, K, w_bit, group_size, dtype, false, N)) {  // W4: table-lookup / matrix-pipe decode kernels
         const void* sc1[1] = {scales};
         const void* ze1[1] = {zeros};
         const void* bi1[1] = {bias};

@@ -1361,9 +1361,23 @@ static bool lut_use_mfma(int M, int dtype) {
     static const int lo = lut_env("BIE_LUT_MFMA_MIN_M", 2);
     static const int hi = lut_env("BIE_LUT_MFMA_MAX_M", 16);
     static const int lo16 = lut_env("BIE_LUT_MFMA_MIN_M_F16", 2);
-    return v != 0 && M >= (dtype == BIE_F16 ? lo16 : lo) && M <= hi && M <= 16;
+    return v != 0 && M >= (dtype == BIE_F16 ? lo16 : lo) && M <= hi && M <= 32;  // hi defaults to 16; 17 .. 32 (two row blocks) is an A/B arm: BIE_LUT_MFMA_MAX_M=32 with BIE_LUT_MAX_M=32
 }
-bool mpq_gemv_lut_ok(int M, int K, int w_bit, int group_size, int dtype, bool has_gidx) {
+#include "mpq_lut_rb2_table.inc"
+
+// 17 .. 32 rows of a LONE W4 call on the matrix-pipe decode kernel with two row blocks (RB = 2) instead of the fused MFMA GEMM + its finalize launch: round 6's
+// fp16 arithmetic form made it the faster one on most 4096- and 8192-wide layers (4096x4096 fp16: 10.2 / 11.6 / 14.2 against 12.3 / 13.5 / 15.0 us at 17 / 24 / 32 rows;
+// 4096x8192: 0.75-0.82 of the GEMM's time) and it is 1.2-1.7 x slower on narrow or very wide ones -- so the answer is the measurement, per dtype and exact shape
+// (profiles/r06_lone_rb2_sweep.txt -> mpq_lut_rb2_table.inc); shapes outside the table keep the GEMM.  BIE_LUT_RB2=0: never.
+bool mpq_lut_rb2_ok(int M, int K, int N, int dtype) {
+    static const int on = lut_env("BIE_LUT_RB2", 1);
+    if (!on || M <= 16 || M > 32 || (dtype != BIE_F16 && dtype != BIE_BF16)) return false;
+    for (const auto& e : kLutRb2)
+        if (e[0] == K && e[1] == N) return M <= e[dtype == BIE_F16 ? 2 : 3];
+    return false;
+}
+
+bool mpq_gemv_lut_ok(int M, int K, int w_bit, int group_size, int dtype, bool has_gidx, int N) {
     static const int enabled = lut_env("BIE_GEMV_LUT", 1);
     static const int w2 = lut_env("BIE_GEMV_LUT_W2", 1);
     if (!enabled || has_gidx || M < 1) return false;
@@ -1375,7 +1389,8 @@ bool mpq_gemv_lut_ok(int M, int K, int w_bit, int group_size, int dtype, bool ha
         return K % gs == 0;
     }
     if (w_bit != 4) return false;
-    if (!lut_use_mfma(M, dtype) && M > 2) return false;  // the FMA form: M <= 2, bf16 and fp16 (v_fma_mix_f32)
+    if (M > 16 && !(N > 0 && mpq_lut_rb2_ok(M, K, N, dtype)) && !lut_use_mfma(M, dtype)) return false;  // 17 .. 32 rows: measured shapes only (or the A/B arm BIE_LUT_MFMA_MAX_M=32)
+    if (M <= 16 && !lut_use_mfma(M, dtype) && M > 2) return false;  // the FMA form: M <= 2, bf16 and fp16 (v_fma_mix_f32)
     if (gs != 32 && gs != 64 && gs != 128 && gs != 256) return false;
     return K % gs == 0;
 }
@@ -1399,7 +1414,7 @@ static LutPlan lut_plan(int M, int dtype, int K, int group_size, int tiles_total
     const int gs = group_size > K ? K : group_size;
     p.rpg = gs / (32 / w_bit);
     p.G = K / gs;
-    const bool mfma = w_bit == 4 && lut_use_mfma(M, dtype);
+    const bool mfma = w_bit == 4 && (M > 16 || lut_use_mfma(M, dtype));
     p.coop = coop && !mfma && w_bit == 4 && dtype == BIE_BF16;
     p.H = 1;
     if (p.coop) {  // four waves per group, 128 / rpg groups per workgroup (mpq_gemv_lutc_kernel)
@@ -1575,7 +1590,10 @@ static void lutm_launch_rb(const LutArgs& a, int rpg, int grid, int zm, hipStrea
 // Per-layer launches stay at M <= 16: with two row blocks (RB = 2, one workgroup per CU) a lone layer measured 22.7-28.9 us at
 // 4096x11008 for M = 17 .. 32 against 20.2-21.3 us for the MFMA GEMM -- the form pays only in list launches (9.4-10.5 us per layer).
 template <int DT>
-static void lutm_launch(const LutArgs& a, int rpg, int grid, int zm, hipStream_t st) { lutm_launch_rb<DT, 1>(a, rpg, grid, zm, st); }
+static void lutm_launch(const LutArgs& a, int rpg, int grid, int zm, hipStream_t st) {
+    if (a.M > 16) lutm_launch_rb<DT, 2>(a, rpg, grid, zm, st);
+    else lutm_launch_rb<DT, 1>(a, rpg, grid, zm, st);
+}
 
 // the list form of the matrix-pipe kernel (mpq_list.hip builds the entries and the block table)
 template <int DT, bool PF, int RB, int NW = 8>
@@ -1699,7 +1717,7 @@ int mpq_gemv_lut_launch(int nsets, const int32_t* const* qw, const void* const* 
         else lut2_launch<BIE_BF16>(a, p.rpg, grid, M, zm, st);
         return check_launch("mpq_gemv_lut_kernel<W2>");
     }
-    if (lut_use_mfma(M, dtype) && !p.coop) {
+    if ((M > 16 || lut_use_mfma(M, dtype)) && !p.coop) {
         if (dtype == BIE_F16) lutm_launch<BIE_F16>(a, p.rpg, grid, zm, st);
         else lutm_launch<BIE_BF16>(a, p.rpg, grid, zm, st);
         return check_launch("mpq_gemv_lutm_kernel");

@@ -78,6 +78,10 @@ size_t bie_mpq_workspace_bytes(int M, int K, int N, int w_bit);
  * dense two-launch form (dequantise once into the fragment image + dense MFMA GEMM: the reference's own split, mpq_layer.py:59-63), 0 = the fused
  * kernels.  Round 6: inside the measured grid the answer is the measurement (csrc/mpq_dense_table.inc). */
 int bie_mpq_prefill_form(int M, int K, int N);
+/* Which kernel family bie_mpq_forward takes for these rows (host-only; implicit groups, no g_idx): 2 = the decode kernels (lookup / matrix pipe: M <= 16, and
+ * 17 .. 32 rows on the layer shapes where round 6 measured them ahead of the GEMM, csrc/mpq_lut_rb2_table.inc), 1 = the dense prefill form, 0 = the fused MFMA GEMM
+ * (or the generic kernels for shapes it cannot take). */
+int bie_mpq_rows_form(int M, int K, int N, int w_bit, int group_size, int dtype);
 /* The same for a call that passes an EXPLICIT g_idx which is not a permutation of k // group_size (unequal groups) with M > 32: room for
  * the dequantised MFMA fragment image, so that bie_mpq_forward runs "per-k dequantise + dense MFMA GEMM" instead of the row-chunked generic
  * kernel.  The reference's branch for those calls is unpack_qweight(g_idx) + torch.matmul (layers/qlinear/nbit/cuda/mpq_layer.py:59-63,

@@ -279,3 +279,17 @@ def test_prefill_dispatch_follows_the_measured_table_inside_its_grid(monkeypatch
     monkeypatch.setenv("BIE_GEMM_DENSE_TABLE", "0")  # BIE_TUNING (tests/conftest.py): knobs are re-read per call
     assert not dense(3072, 8192, 8192), "without the table the round-3 rule keeps K = 8192 fused below 4096 rows"
     assert dense(1024, 4096, 4096)
+
+
+def test_rows_form_follows_the_measured_decode_table():
+    """bie_mpq_rows_form (host-only): the decode kernels take every W4 call up to 16 rows, 17 .. 32 rows only on the measured shapes and up to the measured row count per
+    dtype (csrc/mpq_lut_rb2_table.inc), never W2 beyond two rows; prefill rows report the dense / fused choice of bie_mpq_prefill_form."""
+    from bitorch_engine import _hip
+    L = _hip.lib()
+    F16, BF16 = _hip.F16, _hip.BF16
+    for (M, K, N, w, dt, want) in ((1, 4096, 4096, 4, BF16, 2), (16, 4096, 2048, 4, F16, 2), (17, 4096, 4096, 4, F16, 2), (32, 4096, 4096, 4, BF16, 2), (33, 4096, 4096, 4, F16, 0),
+                                   (24, 4096, 11008, 4, F16, 2), (24, 4096, 11008, 4, BF16, 0), (32, 4096, 2048, 4, F16, 0), (20, 11008, 4096, 4, F16, 2), (24, 11008, 4096, 4, F16, 0),
+                                   (17, 4096, 4160, 4, F16, 0), (17, 4096, 4096, 2, F16, 0), (2, 4096, 4096, 2, F16, 2), (1024, 4096, 4096, 4, BF16, 1), (512, 4096, 4096, 4, BF16, 0)):
+        assert L.bie_mpq_rows_form(M, K, N, w, 128, dt) == want, (M, K, N, w, dt)
+    # the workspace the library asks for covers the decode kernel's partial sums at 17 .. 32 rows (it used to stop at 16: a fault on the first sweep of this form)
+    assert L.bie_mpq_workspace_bytes(28, 4096, 6144, 4) >= L.bie_mpq_workspace_bytes(16, 4096, 6144, 4)

@@ -140,6 +140,28 @@ def test_mpq_forward_vs_oracle(dt, w_bit, asym, M):
     assert_close(y, ref, dt, f"dt={dt} w{w_bit} asym={asym} M={M}")
 
 
+@pytest.mark.parametrize("dt,K,N,M,asym", [(orc.F16, 4096, 4096, 17, 0), (orc.F16, 4096, 4096, 32, 1), (orc.BF16, 4096, 4096, 29, 0), (orc.F16, 8192, 4096, 24, 0),
+                                            (orc.BF16, 2048, 8192, 20, 1), (orc.F16, 4096, 11008, 31, 0), (orc.BF16, 4096, 6144, 28, 0), (orc.F16, 11008, 4096, 20, 0)])
+def test_lone_calls_of_17_to_32_rows_on_the_measured_shapes_take_the_decode_kernel(dt, K, N, M, asym):
+    """Round 6: on the layer shapes where the matrix-pipe decode kernel with two row blocks measured ahead of the fused MFMA GEMM (csrc/mpq_lut_rb2_table.inc
+    from profiles/r06_lone_rb2_sweep.txt) a lone call of 17 .. 32 rows is routed to it -- bie_mpq_rows_form says so -- and gives the oracle's numbers; one row more,
+    another dtype's limit or a shape outside the table keeps the GEMM."""
+    from bitorch_engine import _hip
+    L = _hip.lib()
+    code = _hip.F16 if dt == orc.F16 else _hip.BF16
+    assert L.bie_mpq_rows_form(M, K, N, 4, 128, code) == 2
+    assert L.bie_mpq_rows_form(33, K, N, 4, 128, code) != 2 and L.bie_mpq_rows_form(M, K, N + 64, 4, 128, code) != 2
+    rng = np.random.default_rng(31 * M + K + N + asym)
+    qw, scales, zeros, gen = rand_case(rng, K, N, 4, 128, dt, asym)
+    bias = (torch.randn((N,), generator=gen) * 0.1).to(TDT[dt])
+    x = torch.randn((M, K), generator=gen).to(TDT[dt])
+    y = hip_forward(x, qw, scales, zeros, None, 4, 128, asym, bias)
+    ref = oracle_forward(x, qw, scales, zeros, None, 4, 128, asym, dt, bias)
+    assert_close(y, ref, dt, f"rows form 2: dt={dt} {K}x{N} M={M} asym={asym}")
+    y2 = hip_forward(x, qw, scales, zeros, None, 4, 128, asym, bias)
+    assert torch.equal(y, y2), "a second call differs"
+
+
 @pytest.mark.parametrize("bm", [32, 64, 128, 256])
 @pytest.mark.parametrize("S", [1, 2, 3, 5])
 def test_mfma_gemm_every_tile_height_and_split(bm, S, monkeypatch):

@@ -14,6 +14,7 @@ run "BIE_FP4_MIN_M=0 BIE_FP4_CONV_MIN_ROWS=0" "binary"
 # round 6 knobs
 run "BIE_GEMM_DENSE_TABLE=0" "gemm or prefill or forward_sizes or special"
 run "BIE_GEMM_PLAN_TABLE=0" "gemm or prefill or forward_sizes or special"
+run "BIE_LUT_RB2=0" "mpq_forward_vs_oracle or forward_sizes or special or gemm"   # (test_lone_calls_of_17_to_32_rows asserts the DEFAULT routing)
 run "BIE_DQ_FPW=8" "gemm or prefill or forward_sizes or special"
 run "BIE_LIST_W2_NW=8" "list_forward or w2 or W2"
 run "BIE_LUTM_XS_MIN_M=0" "(list_forward or list_instances) and not x_sharing"
