@@ -308,7 +308,7 @@ class Bench:
                              "frac": round(b / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None}}
 
     # ---- the same decode step through the UNCHANGED module API (MPQLinearCuda modules, prepare_bie_layers): what a caller of the reference gets
-    def decode_step_modules(self, n_layers, reps, seed, auto_group=True, hidden=4096, inter=11008):
+    def decode_step_modules(self, n_layers, reps, seed, auto_group=True, hidden=4096, inter=11008, rows=1, dt=BF16):
         """q_proj(h), k_proj(h), v_proj(h), o_proj(q), gate_proj(o), up_proj(o), down_proj(g) per block, written against the reference's module
         API (layers/qlinear/nbit/cuda/mpq_layer.py:206-224); prepare_bie_layers() is the only model-level call.  With auto_group the sibling
         launches are grouped by the library after one observed forward; without, every layer is its own launch (the reference's call pattern)."""
@@ -318,7 +318,7 @@ class Bench:
         gen = torch.Generator(device=self.dev).manual_seed(seed)
 
         def lin(k, n):
-            l = MPQLinearCuda(k, n, w_bit=WBIT, dtype=BF16, group_size=GROUP, dq_group_size=32, use_gba_quant=True, asym=False)
+            l = MPQLinearCuda(k, n, w_bit=WBIT, dtype=dt, group_size=GROUP, dq_group_size=32, use_gba_quant=True, asym=False)
             l.qweight.data = torch.empty(l.qweight.shape, dtype=torch.int32)
             return l
 
@@ -341,12 +341,12 @@ class Bench:
                 k = m.in_channels
                 m.qweight.data = torch.randint(-2 ** 31, 2 ** 31 - 1, m.qweight.shape, dtype=torch.int32, generator=gen, device=self.dev)
                 s0 = 1.0 / (21.25 * k) ** 0.5
-                m.scales = (s0 * (0.8 + 0.4 * torch.rand(m.scales.shape, generator=gen, device=self.dev))).to(BF16)
-                m.zeros = (m.scales.float() * 7.5).to(BF16)
+                m.scales = (s0 * (0.8 + 0.4 * torch.rand(m.scales.shape, generator=gen, device=self.dev))).to(dt)
+                m.zeros = (m.scales.float() * 7.5).to(dt)
         old = mpq_layer.AUTO_GROUP
         mpq_layer.AUTO_GROUP = bool(auto_group)
         try:
-            h0 = torch.randn((1, hidden), generator=gen, device=self.dev).to(BF16)
+            h0 = torch.randn((rows, hidden), generator=gen, device=self.dev).to(dt)
             with torch.no_grad():
                 model(h0)  # the observation round (sibling groups are confirmed by what they receive)
                 model(h0)

@@ -39,6 +39,7 @@ SIGNATURES = {
     "bie_mpq_list_form": (_i, [_vp]),
     "bie_mpq_prefill_form": (_i, [_i, _i, _i]),
     "bie_mpq_rows_form": (_i, [_i, _i, _i, _i, _i, _i]),
+    "bie_mpq_grouped_max_rows": (_i, [_i, _l, _i, _i]),
     "bie_mpq_list_destroy": (None, [_vp]),
     "bie_mbwq_exl2_list_device_bytes": (_sz, [_i, _vp, _i]),
     "bie_mbwq_exl2_list_create": (_i, [_vp, _i, _vp, _i, _vp, _sz]),
@@ -110,7 +111,7 @@ TEST_HOOKS = {
 }
 
 _HOST_ONLY = ("bie_version", "bie_last_error", "bie_mbwq_rows", "bie_mbwq_exl2_table", "bie_status_init", "bie_device_status", "bie_test_forge_reducer",
-              "bie_test_forge_dependency", "bie_mpq_list_launches", "bie_mpq_list_form", "bie_mpq_prefill_form", "bie_mpq_rows_form", "bie_mpq_list_destroy", "bie_mbwq_exl2_list_destroy")
+              "bie_test_forge_dependency", "bie_mpq_list_launches", "bie_mpq_list_form", "bie_mpq_prefill_form", "bie_mpq_rows_form", "bie_mpq_grouped_max_rows", "bie_mpq_list_destroy", "bie_mbwq_exl2_list_destroy")
 
 
 class ListEntry(ctypes.Structure):

@@ -19,7 +19,18 @@ q_linear_cuda = import_extension("q_linear_cuda")
 GROUP_STATS = {"grouped_launches": 0, "served_from_group": 0, "single_launches": 0, "groups_confirmed": 0, "groups_dissolved": 0,
                "not_groupable": 0}
 AUTO_GROUP = os.environ.get("BIE_AUTO_GROUP", "1") != "0"
-GROUP_MAX_M = 16  # rows the grouped decode launch takes (bie_mpq_forward_grouped)
+GROUP_MAX_M = 16  # rows every grouped decode launch takes (bie_mpq_forward_grouped)
+GROUP_MAX_M_WIDE = 32  # ... and the rows it takes for the sets bie_mpq_grouped_max_rows names (round 6: two row blocks per pass where that measured ahead)
+
+
+def _set_rows_limit(members) -> int:
+    """Rows of x up to which this confirmed set runs as one grouped launch: the library's answer for (K, total output columns, bit width, dtype)."""
+    from bitorch_engine import _hip
+    first = members[0]
+    if first.scales.dtype not in (torch.float16, torch.bfloat16):
+        return GROUP_MAX_M
+    n_total = sum(int(m.out_channels) for m in members)
+    return int(_hip.lib().bie_mpq_grouped_max_rows(int(first.in_channels), n_total, int(first.w_bit), _hip.F16 if first.scales.dtype == torch.float16 else _hip.BF16))
 
 
 def _x_key(x):
@@ -64,6 +75,26 @@ class SiblingGroup:
         self.ungroupable = 0       # consecutive leader calls the grouped launch refused
         self.unclaimed = 0
         self.dead = False
+        self._limits = {}          # id(leader) -> rows limit of its set
+
+    def rows_limit(self, module) -> int:
+        """How many rows of x a call of `module` may have and still go through the group: while observing, GROUP_MAX_M_WIDE (nothing is launched, and a caller that
+        only ever decodes 17 .. 32 sequences must be observable too); confirmed: what the library takes for the module's set (cached per leader)."""
+        if self.dead:
+            return 0
+        if self.sets is None:
+            return GROUP_MAX_M_WIDE
+        leader = self.leader_of.get(id(module))
+        if leader is None:
+            return GROUP_MAX_M  # in no set: the group still sees its calls (it may be the member that delimits the rounds)
+        lim = self._limits.get(id(leader))
+        if lim is None:
+            try:
+                lim = _set_rows_limit(self.sets[id(leader)]) if hasattr(leader, "w_bit") and hasattr(leader, "scales") and not getattr(leader, "use_mbw", False) else GROUP_MAX_M
+            except Exception:
+                lim = GROUP_MAX_M
+            self._limits[id(leader)] = lim
+        return lim
 
     def _dissolve(self):
         self.sets, self.leader_of, self.dead = None, {}, True
@@ -137,6 +168,7 @@ class SiblingGroup:
         if leader is not None:  # launched with its leader's x but asked for another tensor (or called before its leader): not a sibling after all
             members = self.sets[id(leader)]
             members.remove(module)
+            self._limits.pop(id(leader), None)
             del self.leader_of[id(module)]
             if len(members) < 2:
                 del self.sets[id(leader)]
@@ -262,7 +294,7 @@ class MPQLinearCuda(MPQLinearBase):
         # inference fast path: bias fused into the kernel epilogue; whether g_idx is the trivial k // group_size is
         # remembered on the g_idx tensor itself (keyed by its version), so load_state_dict / in-place edits invalidate it
         x2, lead = flatten_x(x)
-        if AUTO_GROUP and self._bie_group is not None and 0 < x2.shape[0] <= GROUP_MAX_M:
+        if AUTO_GROUP and self._bie_group is not None and 0 < x2.shape[0] <= GROUP_MAX_M_WIDE and x2.shape[0] <= self._bie_group.rows_limit(self):
             out = self._bie_group.forward(self, x)  # decode: siblings that share x run as ONE grouped launch (see SiblingGroup)
             if out is not None:
                 return out
@@ -288,7 +320,7 @@ class MPQLinearCuda(MPQLinearBase):
         x2, lead = flatten_x(x)
         same = all(l.w_bit == first.w_bit and l.group_size == first.group_size and l.asym == first.asym and l.in_channels == first.in_channels
                    and l.scales.dtype == first.scales.dtype and not l.training for l in layers)
-        max_rows = 16 if first.w_bit == 4 else 2  # the grouped decode launch: W4 up to 16 rows (lookup / matrix-pipe kernel), W2 up to 2 (pair lookup)
+        max_rows = (_set_rows_limit(layers) if same and first.w_bit == 4 else 16) if first.w_bit == 4 else 2  # W4: 16 rows, 32 for the sets the library names (two row blocks); W2: 2 (pair lookup)
         ok = (same and first.w_bit in (4, 2) and 1 <= x2.shape[0] <= max_rows and 2 <= len(layers) <= 8 and x2.dtype == first.scales.dtype
               and not (torch.is_grad_enabled() and x.requires_grad)
               and all(q_linear_cuda.gidx_is_trivial(l.g_idx, l.group_size) for l in layers))

@@ -17,6 +17,7 @@ int mpq_gemv_generic_launch(const void* x, const int32_t* qw, const void* scales
                             int asym, int dtype, hipStream_t st, const uint16_t* perm = nullptr);
 // mpq_gemv_lut.hip
 bool mpq_gemv_lut_ok(int M, int K, int w_bit, int group_size, int dtype, bool has_gidx, int N = 0);  // N > 0: a lone call (17 .. 32 rows on measured shapes)
+bool mpq_lut_rb2_grouped_ok(int M, int K, long n_total, int dtype);
 size_t mpq_gemv_lut_part_floats(int M, int K, int group_size, int tiles_total, int w_bit);
 int mpq_gemv_lut_launch(int nsets, const int32_t* const* qw, const void* const* scales, const void* const* zeros,
                         const void* const* bias, void* const* y, const int* N, const void* x, unsigned* counters, float* part,
@@ -175,6 +176,11 @@ void bie_mpq_list_destroy(bie_mpq_list_t* plan) { mpq_list_destroy(reinterpret_c
 static bool gidx_dense_ok(int M, int K, int N, int dtype) { return M > 32 && (dtype == BIE_F16 || dtype == BIE_BF16) && mpq_dense_shape_ok(K, N); }
 
 int bie_mpq_prefill_form(int M, int K, int N) { return (M > 32 && mpq_dense_ok(M, K, N)) ? 1 : 0; }
+int bie_mpq_grouped_max_rows(int K, long n_total, int w_bit, int dtype) {
+    if (w_bit == 2) return 2;
+    if (w_bit != 4) return 0;
+    return mpq_lut_rb2_grouped_ok(32, K, n_total, dtype) ? 32 : 16;
+}
 int bie_mpq_rows_form(int M, int K, int N, int w_bit, int group_size, int dtype) {
     static const int lut_max_m = []() { const char* e = getenv("BIE_LUT_MAX_M"); return e ? atoi(e) : 16; }();
     if (M <= 0 || K <= 0 || N <= 0) return 0;
@@ -288,7 +294,7 @@ size_t bie_mpq_grouped_workspace_bytes(int n_sets, const int* N, int M, int K, i
         const size_t b = bie_mpq_workspace_bytes(M, K, N[i], w_bit);
         if (b > need) need = b;
     }
-    if ((w_bit == 4 && M <= 16) || (w_bit == 2 && M <= 2)) {
+    if ((w_bit == 4 && M <= 32) || (w_bit == 2 && M <= 2)) {  // 17 .. 32 rows: the two-row-block instance (taken on measured sets only, sized always)
         const int tiles = grouped_tiles(n_sets, N);
         for (int gs = 32; gs <= 256; gs *= 2)
             if (K % gs == 0) {
@@ -320,7 +326,11 @@ int bie_mpq_forward_grouped(const void* x, int n_sets, const int32_t* const* qwe
     const int tiles = grouped_tiles(n_sets, N);
     bool n4 = true;  // the matrix-pipe form loads four adjacent columns with one 16-byte load
     for (int i = 0; i < n_sets; i++) n4 = n4 && (N[i] & 3) == 0;
-    if (n4 && tiles <= BIE_WS_COUNTERS && mpq_gemv_lut_ok(M, K, w_bit, group_size, dtype, false)) {
+    long n_total = 0;
+    for (int i = 0; i < n_sets; i++) n_total += N[i];
+    // 17 .. 32 rows: the two-row-block instance where it measured ahead of the members' own calls (mpq_lut_rb2_grouped_ok); the shape checks are those of a 16-row call
+    const bool rb2 = w_bit == 4 && M > 16 && M <= 32 && n_sets > 1 && mpq_lut_rb2_grouped_ok(M, K, n_total, dtype) && mpq_gemv_lut_ok(16, K, w_bit, group_size, dtype, false);
+    if (n4 && tiles <= BIE_WS_COUNTERS && (rb2 || mpq_gemv_lut_ok(M, K, w_bit, group_size, dtype, false))) {
         float* head = reinterpret_cast<float*>(workspace);
         return mpq_gemv_lut_launch(n_sets, qweight, scales, zeros, bias, y, N, x, reinterpret_cast<unsigned*>(head) + BIE_WS_GEN_OFFSET,
                                    head + WS_HEAD / sizeof(float), M, K, group_size, asym ? 1 : 0, dtype, as_stream(stream), w_bit);

@@ -1377,6 +1377,16 @@ bool mpq_lut_rb2_ok(int M, int K, int N, int dtype) {
     return false;
 }
 
+// ... and SIBLING SETS of 17 .. 32 rows in one grouped launch of the same instance: q/k/v (3 x 4096x4096) 16.1 / 17.9 / 20.8 us against 31.3 / 35.7 / 42.8 for the members'
+// lone calls in fp16 (bf16: 21.5 / 24.0 / 27.3 against 34.6 / 38.7 / 45.3), an 8192 -> 8192 + 1024 + 1024 set 0.55-0.73 of the lone calls' time; gate/up (2 x 4096x11008): fp16
+// 0.79-0.80, bf16 1.01-1.15 -- so fp16 always, bf16 (table form) up to 16384 output columns in the set (profiles/r06_grouped_rb2_probe.txt).
+bool mpq_lut_rb2_grouped_ok(int M, int K, long n_total, int dtype) {
+    static const int on = lut_env("BIE_LUT_RB2", 1);
+    (void)K;
+    if (!on || M <= 16 || M > 32) return false;
+    return dtype == BIE_F16 || (dtype == BIE_BF16 && n_total <= 16384);
+}
+
 bool mpq_gemv_lut_ok(int M, int K, int w_bit, int group_size, int dtype, bool has_gidx, int N) {
     static const int enabled = lut_env("BIE_GEMV_LUT", 1);
     static const int w2 = lut_env("BIE_GEMV_LUT_W2", 1);

@@ -82,6 +82,9 @@ int bie_mpq_prefill_form(int M, int K, int N);
  * 17 .. 32 rows on the layer shapes where round 6 measured them ahead of the GEMM, csrc/mpq_lut_rb2_table.inc), 1 = the dense prefill form, 0 = the fused MFMA GEMM
  * (or the generic kernels for shapes it cannot take). */
 int bie_mpq_rows_form(int M, int K, int N, int w_bit, int group_size, int dtype);
+/* Rows of x up to which bie_mpq_forward_grouped runs a sibling set of n_total output columns as ONE decode launch (host-only): W4 16, or 32 where round 6 measured the
+ * two-row-block instance ahead of the members' own calls (fp16; bf16 up to 16384 columns); W2 2.  More rows are served member by member. */
+int bie_mpq_grouped_max_rows(int K, long n_total, int w_bit, int dtype);
 /* The same for a call that passes an EXPLICIT g_idx which is not a permutation of k // group_size (unequal groups) with M > 32: room for
  * the dequantised MFMA fragment image, so that bie_mpq_forward runs "per-k dequantise + dense MFMA GEMM" instead of the row-chunked generic
  * kernel.  The reference's branch for those calls is unpack_qweight(g_idx) + torch.matmul (layers/qlinear/nbit/cuda/mpq_layer.py:59-63,

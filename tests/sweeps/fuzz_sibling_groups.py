@@ -51,7 +51,7 @@ def run(parents=40, seed=1):
             l.zeros = (l.scales.float() * torch.rand(l.scales.shape, generator=g) * 15).to(tdt)
         model = model.to(DEV).eval()
         layers = [getattr(model, f"l{i}") for i in range(n)]
-        M = int(rng.choice([1, 1, 1, 2, 4, 16, 20]))
+        M = int(rng.choice([1, 1, 1, 2, 4, 16, 20, 24, 32]))
         kinds = ["shared", "shared", "shared", "temp", "temp", "clone", "slice", "bumped", "other"]
         program = [(int(rng.integers(0, n)), str(rng.choice(kinds))) for _ in range(int(rng.integers(2, 2 * n + 2)))]
         h = torch.randn((M, K), generator=g).to(tdt).to(DEV)
@@ -69,7 +69,7 @@ def run(parents=40, seed=1):
                     i, j = rng.integers(0, len(program), 2)
                     program[i], program[j] = program[j], program[i]
                 else:
-                    M = int(rng.choice([1, 2, 4, 16, 20]))
+                    M = int(rng.choice([1, 2, 4, 16, 20, 24, 32]))
                     h = torch.randn((M, K), generator=g).to(tdt).to(DEV)
                     other = torch.randn((M, K), generator=g).to(tdt).to(DEV)
             before = dict(mpq_layer.GROUP_STATS)

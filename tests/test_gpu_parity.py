@@ -1473,6 +1473,82 @@ def test_unmodified_module_tree_gets_grouped_launches_after_prepare_bie_layers(w
         assert torch.equal(yp, model(xp))
 
 
+@pytest.mark.parametrize("tdt,odt", [(torch.float16, orc.F16), (torch.bfloat16, orc.BF16)])
+def test_module_tree_groups_siblings_at_17_to_32_rows_where_the_library_takes_them(tdt, odt):
+    """Round 6: a decode batch of 17 .. 32 sequences through the unchanged module tree.  bie_mpq_grouped_max_rows says which sets the grouped launch takes at that many
+    rows (two row blocks per pass: fp16 always, bf16 up to 16384 output columns: profiles/r06_grouped_rb2_probe.txt); the first forward is observed even though it never had
+    16 rows or fewer, the following ones run q/k/v (and gate/up where taken) as ONE launch each -- with the numbers of the members' own calls, and straight against the oracle
+    for a q/k/v set at 24 and 32 rows through the C entry point."""
+    from bitorch_engine import _hip
+    from bitorch_engine.layers.qlinear.nbit.cuda import MPQLinearCuda
+    from bitorch_engine.layers.qlinear.nbit.cuda import mpq_layer
+    from bitorch_engine.utils.model_helper import prepare_bie_layers
+    from bitorch_engine.extensions import q_linear_cuda
+    L = _hip.lib()
+    code = _hip.F16 if tdt == torch.float16 else _hip.BF16
+    assert L.bie_mpq_grouped_max_rows(4096, 12288, 4, code) == 32 and L.bie_mpq_grouped_max_rows(4096, 12288, 2, code) == 2
+    assert L.bie_mpq_grouped_max_rows(4096, 22016, 4, code) == (32 if tdt == torch.float16 else 16)
+    H, I, gs = 512, 9216, 128  # gate + up = 18432 columns: beyond the bf16 limit
+    g = torch.Generator().manual_seed(29)
+
+    def lin(K, N):
+        layer = MPQLinearCuda(K, N, w_bit=4, dtype=tdt, group_size=gs, dq_group_size=32, use_gba_quant=True, asym=False)
+        layer.qweight.data = torch.randint(-2 ** 31, 2 ** 31 - 1, layer.qweight.shape, generator=g, dtype=torch.int64).to(torch.int32)
+        return layer
+
+    class Block(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.q_proj, self.k_proj, self.v_proj, self.o_proj = lin(H, H), lin(H, H), lin(H, H), lin(H, H)
+            self.gate_proj, self.up_proj, self.down_proj = lin(H, I), lin(H, I), lin(I, H)
+
+        def forward(self, h):
+            q, k, v = self.q_proj(h), self.k_proj(h), self.v_proj(h)
+            h = h + self.o_proj(torch.tanh(q + k) * v)
+            return h + self.down_proj(torch.sigmoid(self.gate_proj(h)) * self.up_proj(h))
+
+    model = torch.nn.Sequential(Block())
+    prepare_bie_layers(model)
+    for m in model.modules():
+        if isinstance(m, MPQLinearCuda):
+            m.scales = (torch.rand(m.scales.shape, generator=g) * 0.004 + 0.002).to(tdt)
+            m.zeros = (m.scales.float() * 7.5).to(tdt)
+    model.to(DEV).eval()
+    layers = [m for m in model.modules() if isinstance(m, MPQLinearCuda)]
+    xs = [torch.randn((M, H), generator=g).to(tdt).to(DEV) for M in (24, 24, 32, 17)]
+    with torch.no_grad():
+        saved = [l._bie_group for l in layers]
+        for l in layers:
+            l._bie_group = None
+        refs = [model(x) for x in xs]
+        for l, grp in zip(layers, saved):
+            l._bie_group = grp
+        mpq_layer.GROUP_STATS.update({k: 0 for k in mpq_layer.GROUP_STATS})
+        y0 = model(xs[0])  # observed, although it has 24 rows
+        assert mpq_layer.GROUP_STATS["grouped_launches"] == 0 and mpq_layer.GROUP_STATS["single_launches"] == 7
+        assert_close(y0, refs[0], odt, "observation round")
+        want_grouped = 2 if tdt == torch.float16 else 1  # bf16: gate/up (18432 columns) stays member by member at these row counts
+        for x, r in zip(xs[1:], refs[1:]):
+            before = dict(mpq_layer.GROUP_STATS)
+            y = model(x)
+            d = {k: mpq_layer.GROUP_STATS[k] - before[k] for k in before}
+            assert d["grouped_launches"] == want_grouped and d["served_from_group"] == (3 if want_grouped == 2 else 2) and d["not_groupable"] == 0, (tuple(x.shape), d)
+            assert_close(y, r, odt, f"grouped rounds at {x.shape[0]} rows")
+        assert mpq_layer.GROUP_STATS["groups_dissolved"] == 0 and mpq_layer.GROUP_STATS["groups_confirmed"] == 2
+        y1 = model(torch.randn((1, H), generator=g).to(tdt).to(DEV))  # and one row still groups both sets
+        assert torch.isfinite(y1.float()).all()
+    # the C entry point against the oracle: a q/k/v set of real width at 24 and 32 rows
+    rng = np.random.default_rng(77)
+    K, N = 4096, 4096
+    members = [rand_case(rng, K, N, 4, 128, odt, 0) for _ in range(3)]
+    for M in (24, 32):
+        x = torch.randn((M, K), generator=members[0][3]).to(tdt)
+        sets = [(qw.to(DEV), sc.to(DEV), ze.to(DEV), None) for (qw, sc, ze, _) in members]
+        outs = q_linear_cuda.mpq_forward_grouped_impl(x.to(DEV), sets, 4, False, 128)
+        for i, (qw, sc, ze, _) in enumerate(members):
+            assert_close(outs[i], oracle_forward(x, qw, sc, ze, None, 4, 128, 0, odt), odt, f"grouped q/k/v member {i} at {M} rows")
+
+
 def _exl2_layer(K, N, spec, gen, bias=False):
     """An MBWQLinearCuda (exl2) layer with random packed weights; returns (layer, raw qweight, q_groups list)."""
     from bitorch_engine.layers.qlinear.nbit.cuda import MBWQLinearCuda
