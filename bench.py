@@ -990,6 +990,9 @@ def main():
         guarded("decode_step_llama7b", lambda: B.decode_step(32, 5, 77))
         guarded("decode_step_modules_auto_grouped", lambda: B.decode_step_modules(16, 5, 78, auto_group=True))
         guarded("decode_step_modules_one_launch_per_layer", lambda: B.decode_step_modules(16, 5, 78, auto_group=False))
+        # a decode batch of 24 sequences through the same unchanged module tree (round 6: sibling sets and lone calls of 17 .. 32 rows keep the decode kernels where they measured ahead)
+        guarded("decode_step_modules_24rows_f16", lambda: B.decode_step_modules(8, 5, 79, auto_group=True, rows=24, dt=torch.float16))
+        guarded("decode_step_modules_24rows_bf16", lambda: B.decode_step_modules(8, 5, 79, auto_group=True, rows=24, dt=BF16))
         guarded("gemm", lambda: B.gemm(4096, 4096, 4096, 24, 3, 7))
         if "roofline" in extras.get("gemm", {}):
             out["roofline_gemm"] = dict(extras["gemm"]["roofline"], kernel=("bie::mpq_dequant_frag_kernel + bie::mpq_dense_gemm_kernel<bf16,256x256> (both launches timed)"
@@ -1012,7 +1015,7 @@ def main():
                                       if isinstance(v, dict) and "roofline" in v else v)(extras.get("decode_step_llama7b"))
         out["summary"] = {k: frac(k) for k in ("per_layer_launches_4096x4096", "chain8_4096x4096_launches", "c2_gemv_4096x11008", "c2_gemv_11008x4096", "c5_gemv_8192x28672",
                                                "grouped_qkv_3x4096x4096", "grouped_gate_up_2x4096x11008", "c2_gemm_4096x11008", "c2_gemm_11008x4096", "decode_step_modules_auto_grouped",
-                                               "decode_step_modules_one_launch_per_layer")}
+                                               "decode_step_modules_one_launch_per_layer", "decode_step_modules_24rows_f16", "decode_step_modules_24rows_bf16")}
         if not args.short:
             # the fused form (dequantisation beside the MFMAs) on the same layers, same box: the A/B behind the dense form's dispatch rule
             def fused_gemm():
