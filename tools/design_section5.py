@@ -66,6 +66,9 @@ rows = [
      f"{d['decode_step_llama7b']['us_per_layer']:.1f} / {S['decode_step_modules_auto_grouped']['us']:.1f} / {S['decode_step_modules_one_launch_per_layer']['us']:.1f} µs per layer",
      f"{d['decode_step_llama7b']['roofline_frac']:.2f} / {S['decode_step_modules_auto_grouped']['frac']:.2f} / {S['decode_step_modules_one_launch_per_layer']['frac']:.2f}",
      "4 launches per layer; per-wave timelines with ramp / stream / tail / reduce phases: `profiles/r06_inl_timeline.txt`"),
+    ("**the same step for a batch of 24 sequences, unchanged module tree** (round 6: sibling sets and lone calls of 17 … 32 rows keep the decode kernels where they measured ahead) fp16 / bf16",
+     f"{S['decode_step_modules_24rows_f16']['us']:.1f} / {S['decode_step_modules_24rows_bf16']['us']:.1f} µs per layer (round-5 routing, `BIE_LUT_RB2=0`: 115.6 / 123.3)",
+     f"{S['decode_step_modules_24rows_f16']['frac']:.2f} / {S['decode_step_modules_24rows_bf16']['frac']:.2f}", "4 / 5 launches per layer instead of 7; `profiles/r06_module_step_rows.txt`, `r06_grouped_rb2_probe.txt`, `r06_lone_rb2_check.txt`"),
     ("**GEMM M = 4096, 4096² (both launches timed)**", f"{g['us_per_launch']:.1f} µs (under the profiler: dequant {prof['dequant_min_us']:.1f} + GEMM {prof['gemm_min_us']:.1f})",
      f"**{g['frac']:.3f} of 2.5 PF**",
      f"MFMA-pipe probe (`profiles/r06_dense_mfma_probe.txt`): MFMAs + barriers only 0.76, + fragment reads 0.60, the loop 0.52, + stores 0.50, + dequantise launch 0.47; counters: MFMA pipe {g['pmc']['mfma_pipe_utilisation']:.3f} busy at {g['pmc']['effective_clock_ghz']:.2f} GHz, fetch = {g['pmc']['fetch_over_tiling_floor']:.3f} × the tiling floor"),
